@@ -1,0 +1,175 @@
+/*
+ * kaiju_gpu.h — C-ABI of the MI355X-native Kaiju classification path.
+ *
+ * This is the drop-in boundary for the body of the reference's
+ * ConsumerThread::doWork() between queue->pop() and the output line
+ * (/root/reference/src/ConsumerThread.cpp:632-743): six-frame translation,
+ * SEG, MEM / Greedy backward search on the protein FM-index, locate and
+ * taxon-id collection run in HIP kernels on gfx950; the caller keeps ingest,
+ * the work queue, LCA and output formatting (helpers for the latter two are
+ * exported here too so that a host needs nothing else).
+ *
+ * Plain C: opaque handles, plain pointers and sizes, no C++/torch types, no
+ * exit() inside the library.  Every function returns 0 on success or a
+ * negative kaiju_gpu_status; kaiju_gpu_strerror() maps it to text.
+ *
+ * Reference interfaces replaced / mirrored (file:line in /root/reference/src):
+ *   kaiju_gpu_index_load        readFMI util.cpp:265-276 -> readIndexes bwt/bwt.c:78-88
+ *   kaiju_gpu_index_from_host   the in-memory BWT/FMI/suffixArray structs, bwt/bwt.h:10-22,
+ *                               bwt/fmi.h:9-18, bwt/suffixArray.h:10-33
+ *   kaiju_gpu_params            Config fields, Config.hpp:33-48 (+ kaiju.cpp:77-80 for -a mem)
+ *   kaiju_gpu_create/destroy    ConsumerThread::ConsumerThread ConsumerThread.cpp:6-187
+ *   kaiju_gpu_classify_batch    ConsumerThread::doWork ConsumerThread.cpp:630-749, i.e.
+ *                               getAllFragmentsBits :190-270, getNextFragment :272-342,
+ *                               classify_length :543-628, classify_greedyblosum :424-541,
+ *                               ids_from_SI :799-845 (everything up to, not including, lca_from_ids)
+ *   kaiju_taxonomy_load         parseNodesDmp util.cpp:79-99
+ *   kaiju_taxonomy_lca          lca_from_ids util.cpp:194-263
+ *   kaiju_finalize_hits         E-value gate ConsumerThread.cpp:500-513, LCA call :538,:625 and the
+ *                               C/U decision :724-739
+ */
+#ifndef KAIJU_GPU_H
+#define KAIJU_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAIJU_GPU_ABI_VERSION 1
+#define KAIJU_GPU_MAX_IDS 21   /* ids_from_SI stops once the set holds > max_match_ids (20) ids */
+
+typedef enum {
+  KAIJU_GPU_OK = 0,
+  KAIJU_GPU_ERR_ARG = -1,        /* bad argument                                  */
+  KAIJU_GPU_ERR_IO = -2,         /* file could not be opened / short read          */
+  KAIJU_GPU_ERR_FORMAT = -3,     /* .fmi / nodes.dmp content not understood        */
+  KAIJU_GPU_ERR_NO_DEVICE = -4,  /* no usable HIP device (the path has NO CPU fallback) */
+  KAIJU_GPU_ERR_HIP = -5,        /* a HIP runtime call failed (see strerror)       */
+  KAIJU_GPU_ERR_NOMEM = -6,
+  KAIJU_GPU_ERR_UNSUPPORTED = -7,/* parameter outside what the kernels implement   */
+  KAIJU_GPU_ERR_INDEX_BUG = -8   /* index hits one of the reference's latent bugs  */
+} kaiju_gpu_status;
+
+typedef struct kaiju_gpu_index kaiju_gpu_index;   /* FM-index resident in HBM (shareable by contexts) */
+typedef struct kaiju_gpu_ctx kaiju_gpu_ctx;       /* one classification stream on one GPU             */
+typedef struct kaiju_taxonomy kaiju_taxonomy;     /* host-side nodes.dmp tree                          */
+
+/* mirrors Config (Config.hpp:33-48) */
+typedef struct {
+  int32_t mode;                 /* 0 = MEM, 1 = GREEDY                               */
+  uint32_t min_fragment_length; /* -m, default 11                                    */
+  uint32_t mismatches;          /* -e, default 3 (Greedy)                            */
+  uint32_t min_score;           /* -s, default 65 (Greedy)                           */
+  uint32_t seed_length;         /* -l, default 7 (Greedy)                            */
+  int32_t seg;                  /* -x / -X, default on                               */
+  int32_t use_evalue;           /* Greedy default on; "-a mem" turns it off          */
+  double min_evalue;            /* -E, default 0.01                                  */
+  uint32_t max_matches_SI;      /* 20                                                */
+  uint32_t max_match_ids;       /* 20                                                */
+} kaiju_gpu_params;
+
+/* what the device produces per read (everything before lca_from_ids) */
+typedef struct {
+  uint32_t best;                /* MEM: longest match length; GREEDY: best score; 0 = no match */
+  uint32_t n_ids;               /* distinct taxon ids collected, <= KAIJU_GPU_MAX_IDS          */
+  uint32_t flags;               /* KAIJU_HIT_* bits                                            */
+  uint32_t reserved;
+  uint64_t taxid[KAIJU_GPU_MAX_IDS]; /* in the reference's traversal (first seen) order       */
+} kaiju_gpu_hit;
+
+#define KAIJU_HIT_ID_CAP 1u     /* the 21-id cap ended the traversal (order sensitive case)   */
+#define KAIJU_HIT_SI_CAP 2u     /* Greedy: > max_matches_SI equal-score matches existed       */
+
+/* what the host seam turns a hit into: one output line "C/U \t name \t taxon" */
+typedef struct {
+  uint64_t taxon;               /* LCA, 0 when unclassified            */
+  uint32_t best;                /* column 4 of the -v output           */
+  uint8_t classified;           /* 1 = 'C', 0 = 'U'                    */
+  uint8_t pad[3];
+} kaiju_result;
+
+/* In-memory view of an index as the reference's loader holds it.  All pointers are
+   borrowed for the duration of the call only. */
+typedef struct {
+  int64_t bwtlen;               /* FMI::bwtlen                                              */
+  int32_t nseq;                 /* BWT::nseq                                                */
+  int32_t alen;                 /* BWT::alen (21 for Kaiju's protein indexes)               */
+  const char *alphabet;         /* BWT::alphabet, alen chars, [0] = terminator              */
+  const uint8_t *bwt;           /* FMI::bwt, byte-coded (letter, in-block count)            */
+  const int32_t *startLcode;    /* FMI::startLcode[alen+1]                                  */
+  const uint8_t *sa;            /* suffixArray::sa, ncheck * nbytes big-endian entries      */
+  int64_t ncheck;               /* suffixArray::ncheck                                      */
+  int32_t chpt_exp, nbytes, pbits; /* suffixArray::chpt_exp / nbytes / pbits                */
+  const char *const *ids;       /* suffixArray::ids[nseq], "accession_taxid"                */
+} kaiju_gpu_host_index;
+
+typedef struct {
+  int64_t bwtlen;
+  int32_t nseq, alen, chpt_exp;
+  double db_length;             /* Config::db_length = len - nseq (Config.cpp:20)           */
+  uint64_t device_bytes;        /* HBM held by the packed index                             */
+  uint32_t warnings;            /* KAIJU_IDX_WARN_* bits                                    */
+  char alphabet[64];
+} kaiju_gpu_index_info;
+
+#define KAIJU_IDX_WARN_SA_SHORT 1u   /* header ncheck one short (suffixArray.c:160 vs bwt.c:115) */
+#define KAIJU_IDX_WARN_RANK_BUG 2u   /* bwtlen hits the fmi_chpt_value_with_dir corner case      */
+
+/* work / timing of the last batch of a context */
+typedef struct {
+  uint64_t n_reads, n_fragments, n_overflow_retries;
+  double ms_translate, ms_seg, ms_search, ms_total;   /* HIP-event times on the ctx stream */
+} kaiju_gpu_stats;
+
+int kaiju_gpu_abi_version(void);
+const char *kaiju_gpu_strerror(int status);
+/* last detailed message of the calling thread (HIP error strings etc.) */
+const char *kaiju_gpu_last_error(void);
+int kaiju_gpu_device_count(void);
+
+/* ---- index ---------------------------------------------------------- */
+int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_gpu_index **out);
+int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *view, int device_id, kaiju_gpu_index **out);
+int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info);
+void kaiju_gpu_index_free(kaiju_gpu_index *ix);
+
+/* ---- classification -------------------------------------------------- */
+void kaiju_gpu_default_params(kaiju_gpu_params *p, int mode);
+int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, const kaiju_gpu_params *p);
+void kaiju_gpu_destroy(kaiju_gpu_ctx *ctx);
+
+/* Host buffers.  seqs: concatenated, already strip()'d ASCII nucleotides;
+   off[2*n+1]: read r is seqs[off[2r], off[2r+1]) and its mate seqs[off[2r+1], off[2r+2])
+   (empty when unpaired).  paired selects the length gate of ConsumerThread.cpp:647-654.
+   Blocks until out[0..n) is filled. */
+int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off,
+                             uint32_t n_reads, int paired, kaiju_gpu_hit *out);
+
+/* Device-resident variant: all pointers are HIP device pointers on the context's
+   GPU, work is enqueued on `stream` (a hipStream_t; NULL = the context's own
+   stream) and the call returns without synchronising. */
+int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d_seqs, uint64_t seq_bytes,
+                                    const uint64_t *d_off, uint32_t n_reads, int paired,
+                                    kaiju_gpu_hit *d_out, void *stream);
+int kaiju_gpu_synchronize(kaiju_gpu_ctx *ctx);
+int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats);
+
+/* ---- host side of the seam ------------------------------------------- */
+int kaiju_taxonomy_load(const char *nodes_dmp_path, kaiju_taxonomy **out);
+void kaiju_taxonomy_free(kaiju_taxonomy *t);
+/* ids need not be sorted; returns 0 if none of them is in the tree */
+uint64_t kaiju_taxonomy_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n);
+/* E-value gate + LCA + C/U decision for a batch.  len1/len2 are the nucleotide
+   lengths (query_len = len1/3.0 [+ len2/3.0], ConsumerThread.cpp:698,704); pass
+   off as given to classify_batch.  db_length from kaiju_gpu_index_get_info. */
+int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p, double db_length,
+                        const kaiju_gpu_hit *hits, const uint64_t *off, uint32_t n_reads,
+                        int paired, kaiju_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAIJU_GPU_H */

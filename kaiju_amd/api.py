@@ -1,0 +1,206 @@
+"""Python mirror of the host side of the seam, over the C-ABI (include/kaiju_gpu.h).
+
+The names follow the reference: ``Config``-like parameters (Config.hpp:33-48), an index
+loaded from a ``.fmi`` file (readFMI, util.cpp:265-276), a classifier that turns batches of
+reads into per-read hit records (ConsumerThread::doWork, ConsumerThread.cpp:630-749) and the
+taxonomy / LCA helpers (util.cpp:79-99, 194-263).  Everything numerical happens in
+``libkaiju_gpu.so``; if that library or a HIP device is missing the calls raise — there is
+no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MAX_IDS = 21
+MEM, GREEDY = 0, 1
+
+
+class Params(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("min_fragment_length", C.c_uint32),
+                ("mismatches", C.c_uint32), ("min_score", C.c_uint32),
+                ("seed_length", C.c_uint32), ("seg", C.c_int32),
+                ("use_evalue", C.c_int32), ("min_evalue", C.c_double),
+                ("max_matches_SI", C.c_uint32), ("max_match_ids", C.c_uint32)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("bwtlen", C.c_int64), ("nseq", C.c_int32), ("alen", C.c_int32),
+                ("chpt_exp", C.c_int32), ("db_length", C.c_double),
+                ("device_bytes", C.c_uint64), ("warnings", C.c_uint32),
+                ("alphabet", C.c_char * 64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_fragments", C.c_uint64), ("n_overflow_retries", C.c_uint64),
+                ("ms_translate", C.c_double), ("ms_seg", C.c_double), ("ms_search", C.c_double),
+                ("ms_total", C.c_double)]
+
+
+HIT_DTYPE = np.dtype([("best", "<u4"), ("n_ids", "<u4"), ("flags", "<u4"), ("reserved", "<u4"),
+                      ("taxid", "<u8", (MAX_IDS,))])
+RESULT_DTYPE = np.dtype([("taxon", "<u8"), ("best", "<u4"), ("classified", "u1"), ("pad", "u1", (3,))])
+assert HIT_DTYPE.itemsize == 184 and RESULT_DTYPE.itemsize == 16
+
+
+class KaijuGpuError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (building if necessary) libkaiju_gpu.so.  Raises if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        _build.build()
+    L = C.CDLL(path)
+    L.kaiju_gpu_strerror.restype = C.c_char_p
+    L.kaiju_gpu_last_error.restype = C.c_char_p
+    L.kaiju_gpu_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.kaiju_gpu_index_get_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
+    L.kaiju_gpu_index_free.argtypes = [C.c_void_p]
+    L.kaiju_gpu_default_params.argtypes = [C.POINTER(Params), C.c_int]
+    L.kaiju_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Params)]
+    L.kaiju_gpu_destroy.argtypes = [C.c_void_p]
+    L.kaiju_gpu_classify_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    L.kaiju_gpu_classify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                                  C.c_int, C.c_void_p, C.c_void_p]
+    L.kaiju_gpu_synchronize.argtypes = [C.c_void_p]
+    L.kaiju_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.kaiju_taxonomy_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.kaiju_taxonomy_free.argtypes = [C.c_void_p]
+    L.kaiju_taxonomy_lca.restype = C.c_uint64
+    L.kaiju_taxonomy_lca.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.kaiju_finalize_hits.argtypes = [C.c_void_p, C.POINTER(Params), C.c_double, C.c_void_p, C.c_void_p,
+                                      C.c_uint32, C.c_int, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        L = lib()
+        raise KaijuGpuError(f"{L.kaiju_gpu_strerror(rc).decode()} ({rc}): {L.kaiju_gpu_last_error().decode()}")
+
+
+def default_params(mode="greedy", **kw) -> Params:
+    p = Params()
+    lib().kaiju_gpu_default_params(C.byref(p), GREEDY if mode in ("greedy", GREEDY) else MEM)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def device_count() -> int:
+    return lib().kaiju_gpu_device_count()
+
+
+class Index:
+    """FM-index resident in HBM (readFMI + Config::init of the reference)."""
+
+    def __init__(self, fmi_path: str, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().kaiju_gpu_index_load(fmi_path.encode(), device, C.byref(self._h)))
+        self.info = IndexInfo()
+        _check(lib().kaiju_gpu_index_get_info(self._h, C.byref(self.info)))
+        self.device = device
+
+    @property
+    def db_length(self):
+        return self.info.db_length
+
+    def close(self):
+        if self._h:
+            lib().kaiju_gpu_index_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Taxonomy:
+    def __init__(self, nodes_dmp: str):
+        self._h = C.c_void_p()
+        _check(lib().kaiju_taxonomy_load(nodes_dmp.encode(), C.byref(self._h)))
+
+    def lca(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.uint64)
+        return int(lib().kaiju_taxonomy_lca(self._h, a.ctypes.data, len(a)))
+
+    def close(self):
+        if self._h:
+            lib().kaiju_taxonomy_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Classifier:
+    """One classification stream on one GPU (the ConsumerThread of the reference)."""
+
+    def __init__(self, index: Index, params: Params):
+        self.index = index
+        self.params = params
+        self._h = C.c_void_p()
+        _check(lib().kaiju_gpu_create(C.byref(self._h), index._h, C.byref(params)))
+
+    def classify(self, seqs: np.ndarray, off: np.ndarray, paired=False) -> np.ndarray:
+        """Host buffers in, hit records out (blocking)."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = (len(off) - 1) // 2
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        _check(lib().kaiju_gpu_classify_batch(self._h, seqs.ctypes.data, off.ctypes.data, n,
+                                              1 if paired else 0, hits.ctypes.data))
+        return hits
+
+    def classify_device(self, d_seqs_ptr: int, seq_bytes: int, d_off_ptr: int, n: int, d_out_ptr: int,
+                        paired=False, stream: int = 0):
+        """Device-resident buffers (raw pointers, e.g. torch ``data_ptr()``); asynchronous on ``stream``."""
+        _check(lib().kaiju_gpu_classify_batch_device(self._h, d_seqs_ptr, seq_bytes, d_off_ptr, n,
+                                                     1 if paired else 0, d_out_ptr, stream))
+
+    def synchronize(self):
+        _check(lib().kaiju_gpu_synchronize(self._h))
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _check(lib().kaiju_gpu_get_stats(self._h, C.byref(s)))
+        return s
+
+    def finalize(self, tax: Taxonomy, hits: np.ndarray, off: np.ndarray, paired=False) -> np.ndarray:
+        """E-value gate + LCA + C/U decision on the host (ConsumerThread.cpp:500-513,538,625,724-739)."""
+        hits = np.ascontiguousarray(hits)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(hits)
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        _check(lib().kaiju_finalize_hits(tax._h, C.byref(self.params), self.index.db_length, hits.ctypes.data,
+                                         off.ctypes.data, n, 1 if paired else 0, res.ctypes.data))
+        return res
+
+    def close(self):
+        if self._h:
+            lib().kaiju_gpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

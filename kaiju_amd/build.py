@@ -1,0 +1,46 @@
+"""Build the HIP library in-tree: kaiju_amd/libkaiju_gpu.so (gfx950).
+
+hipcc cross-compiles without a GPU, so this runs in the build container as well as on the
+GPU box.  The library is the product: kernels + C-ABI (include/kaiju_gpu.h)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libkaiju_gpu.so")
+SOURCES = ["capi.hip", "host_index.cpp", "host_tables.cpp", "taxonomy.cpp"]
+HEADERS = ["kj_core.h", "host_index.h", "host_tables.h", os.path.join("..", "..", "include", "kaiju_gpu.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-gpu-rdc", "-Wno-unused-result"]
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the Kaiju GPU library cannot be built")
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)

@@ -1,0 +1,479 @@
+// capi.hip — HIP kernels (gfx950) and the C-ABI of include/kaiju_gpu.h.
+//
+// Kernels:
+//   k_fragments  one lane per read: six-frame translation, fragment list in queue order,
+//                eager SEG split for MEM (stage 1, kj_core.h:build_fragments)
+//   k_mem        persistent lanes, one read at a time per lane: MEM search + locate
+//   k_greedy     persistent lanes: Greedy search (priority queue, substitutions) + locate
+// Both search kernels are launched twice per batch: the main pass with small per-lane scratch
+// and a retry pass (device-side work list, no host round trip) with worst-case scratch for the
+// few reads whose match buffer / queue overflowed.
+//
+// There is no CPU fallback: without a HIP device every entry point that needs one fails with
+// KAIJU_GPU_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kaiju_gpu.h"
+#include "host_index.h"
+#include "host_tables.h"
+#include "kj_core.h"
+
+using namespace kj;
+
+// ----------------------------------------------------------------------------------------
+// kernels
+// ----------------------------------------------------------------------------------------
+constexpr int kBlock = 256;
+
+__global__ void __launch_bounds__(kBlock)
+k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, uint32_t *err) {
+  __shared__ ConstTables s_ct;
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
+    for (uint32_t i = threadIdx.x; i < sizeof(ConstTables) / 4; i += kBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= b.n_reads) return;
+  uint32_t e = 0;
+  build_fragments(s_ct, p, st, b, r, &e);
+  if (e) atomicOr(err, e);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  mem_lane(ix, p, b, wl, ls);
+}
+
+struct GreedyArrays {
+  GItem *pool; uint16_t *ord; GMatch *matches; uint32_t *prefix; GBest *best;
+  uint32_t pool_cap, match_cap, prefix_cap;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, WorkList wl,
+         GreedyArrays ga) {
+  __shared__ uint8_t s_win[kBlock * kWinStride];
+  __shared__ ConstTables s_ct;
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
+    for (uint32_t i = threadIdx.x; i < sizeof(ConstTables) / 4; i += kBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  GreedyScratch gs;
+  gs.pool = ga.pool + lane * ga.pool_cap; gs.pool_cap = ga.pool_cap;
+  gs.ord = ga.ord + lane * ga.pool_cap;
+  gs.matches = ga.matches + lane * ga.match_cap; gs.match_cap = ga.match_cap;
+  gs.prefix = ga.prefix + lane * ga.prefix_cap; gs.prefix_cap = ga.prefix_cap;
+  gs.best = ga.best + lane * 64;
+  gs.win = s_win + threadIdx.x * kWinStride;
+  greedy_lane(ix, s_ct, p, st, b, wl, gs);
+}
+
+static_assert(sizeof(ConstTables) % 4 == 0, "ConstTables is copied as dwords");
+static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");
+
+// ----------------------------------------------------------------------------------------
+// error handling
+// ----------------------------------------------------------------------------------------
+static thread_local std::string tl_error;
+static int fail(int code, const std::string &msg) { tl_error = msg; return code; }
+#define KJ_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(KAIJU_GPU_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+extern "C" int kaiju_gpu_abi_version(void) { return KAIJU_GPU_ABI_VERSION; }
+extern "C" const char *kaiju_gpu_last_error(void) { return tl_error.c_str(); }
+extern "C" const char *kaiju_gpu_strerror(int status) {
+  switch (status) {
+    case KAIJU_GPU_OK: return "ok";
+    case KAIJU_GPU_ERR_ARG: return "bad argument";
+    case KAIJU_GPU_ERR_IO: return "I/O error";
+    case KAIJU_GPU_ERR_FORMAT: return "unrecognised file content";
+    case KAIJU_GPU_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case KAIJU_GPU_ERR_HIP: return "HIP runtime error";
+    case KAIJU_GPU_ERR_NOMEM: return "out of memory";
+    case KAIJU_GPU_ERR_UNSUPPORTED: return "parameter not supported by the kernels";
+    case KAIJU_GPU_ERR_INDEX_BUG: return "index triggers a latent bug of the reference";
+    default: return "unknown status";
+  }
+}
+extern "C" int kaiju_gpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ----------------------------------------------------------------------------------------
+// index
+// ----------------------------------------------------------------------------------------
+struct kaiju_gpu_index {
+  int device = 0;
+  DevIndex dev{};                 // device pointers
+  ConstTables ct_host{};
+  ConstTables *d_ct = nullptr;
+  SegTables st{};                 // lnfact points to device memory
+  double *d_lnfact = nullptr;
+  std::vector<void *> allocs;
+  kaiju_gpu_index_info info{};
+  std::vector<std::string> names;
+  ~kaiju_gpu_index() {
+    (void)hipSetDevice(device);
+    for (void *p : allocs) (void)hipFree(p);
+  }
+};
+
+template <class T>
+static int upload(kaiju_gpu_index *ix, const std::vector<T> &v, const T **dst) {
+  void *p = nullptr;
+  const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  KJ_HIP(hipMalloc(&p, bytes));
+  ix->allocs.push_back(p);
+  if (!v.empty()) KJ_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = static_cast<const T *>(p);
+  return 0;
+}
+
+static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_index **out) {
+  if (!out) return fail(KAIJU_GPU_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(KAIJU_GPU_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+  if (device_id < 0 || device_id >= ndev) return fail(KAIJU_GPU_ERR_ARG, "device_id out of range");
+  std::string msg;
+  PackedIndex pk;
+  int rc = pk.build(v, msg);
+  if (rc) return fail(rc, msg);
+  std::unique_ptr<kaiju_gpu_index> ix(new kaiju_gpu_index());
+  ix->device = device_id;
+  rc = build_const_tables(pk.trans, ix->ct_host, msg);
+  if (rc) return fail(rc, msg);
+  std::vector<double> lnfact;
+  rc = build_seg_tables(lnfact, ix->st, msg);
+  if (rc) return fail(rc, msg);
+  KJ_HIP(hipSetDevice(device_id));
+  DevIndex &d = ix->dev;
+  if ((rc = upload(ix.get(), pk.blocks, &d.blocks))) return rc;
+  if ((rc = upload(ix.get(), pk.sb, &d.sb))) return rc;
+  if ((rc = upload(ix.get(), pk.sa_iseq, &d.sa_iseq))) return rc;
+  if ((rc = upload(ix.get(), pk.seq_taxid, &d.seq_taxid))) return rc;
+  if ((rc = upload(ix.get(), pk.seq_valid, &d.seq_valid))) return rc;
+  if ((rc = upload(ix.get(), pk.term_pos, &d.term_pos))) return rc;
+  const double *dl = nullptr;
+  if ((rc = upload(ix.get(), lnfact, &dl))) return rc;
+  ix->st.lnfact = dl;
+  std::vector<ConstTables> ctv(1, ix->ct_host);
+  const ConstTables *dct = nullptr;
+  if ((rc = upload(ix.get(), ctv, &dct))) return rc;
+  ix->d_ct = const_cast<ConstTables *>(dct);
+  for (int a = 0; a < 22; a++) d.C[a] = pk.C[a];
+  d.bwtlen = pk.bwtlen; d.n_sa = pk.n_sa; d.sa_skip = pk.sa_skip; d.nseq = pk.nseq; d.chpt_exp = pk.chpt_exp;
+  kaiju_gpu_index_info &inf = ix->info;
+  memset(&inf, 0, sizeof inf);
+  inf.bwtlen = (int64_t)pk.bwtlen; inf.nseq = (int32_t)pk.nseq; inf.alen = (int32_t)pk.alen;
+  inf.chpt_exp = (int32_t)pk.chpt_exp;
+  inf.db_length = (double)((int64_t)pk.bwtlen - (int64_t)pk.nseq);   // Config.cpp:20
+  inf.device_bytes = pk.bytes();
+  inf.warnings = pk.warnings;
+  snprintf(inf.alphabet, sizeof inf.alphabet, "%s", pk.alphabet.c_str());
+  ix->names.swap(pk.names);
+  KJ_HIP(hipDeviceSynchronize());
+  *out = ix.release();
+  return KAIJU_GPU_OK;
+}
+
+extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_gpu_index **out) {
+  if (!fmi_path || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(KAIJU_GPU_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+  FmiFile f;
+  std::string msg;
+  int rc = f.load(fmi_path, msg);
+  if (rc) return fail(rc, msg);
+  return index_from_view(f.view(), device_id, out);
+}
+
+extern "C" int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *hv, int device_id, kaiju_gpu_index **out) {
+  if (!hv || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  HostIndexView v;
+  v.bwtlen = hv->bwtlen; v.nseq = hv->nseq; v.alen = hv->alen; v.alphabet = hv->alphabet; v.bwt = hv->bwt;
+  v.startLcode = hv->startLcode; v.sa = hv->sa; v.ncheck = hv->ncheck; v.chpt_exp = hv->chpt_exp;
+  v.nbytes = hv->nbytes; v.pbits = hv->pbits; v.ids = hv->ids;
+  return index_from_view(v, device_id, out);
+}
+
+extern "C" int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info) {
+  if (!ix || !info) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  *info = ix->info;
+  return KAIJU_GPU_OK;
+}
+extern "C" void kaiju_gpu_index_free(kaiju_gpu_index *ix) { delete ix; }
+
+// ----------------------------------------------------------------------------------------
+// context
+// ----------------------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct kaiju_gpu_ctx {
+  const kaiju_gpu_index *ix = nullptr;
+  kaiju_gpu_params params{};
+  Params kp{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool ev_valid = false;
+  int n_cu = 0, blocks_main = 0, blocks_retry = 0;
+  DevBuf pep, frags, nfrag, counters, retry_list;
+  DevBuf scratch_main[5], scratch_retry[5];
+  DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
+  kaiju_gpu_stats stats{};
+  uint32_t last_n = 0;
+  ~kaiju_gpu_ctx() {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    DevBuf *all[] = {&pep, &frags, &nfrag, &counters, &retry_list, &h_seqs, &h_off, &h_hits};
+    for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 5; i++) { if (scratch_main[i].p) (void)hipFree(scratch_main[i].p); if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p); }
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+static int ensure(DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return 0;
+  if (b.p) { KJ_HIP(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  const size_t want = bytes + bytes / 8 + 256;
+  KJ_HIP(hipMalloc(&b.p, want));
+  b.cap = want;
+  return 0;
+}
+
+extern "C" void kaiju_gpu_default_params(kaiju_gpu_params *p, int mode) {
+  if (!p) return;
+  p->mode = mode ? 1 : 0;                 // Config.hpp:33-48
+  p->min_fragment_length = 11;
+  p->mismatches = 3;
+  p->min_score = 65;
+  p->seed_length = 7;
+  p->seg = 1;
+  p->use_evalue = mode ? 1 : 0;           // "-a mem" clears use_Evalue, kaiju.cpp:77-80
+  p->min_evalue = 0.01;
+  p->max_matches_SI = 20;
+  p->max_match_ids = 20;
+}
+
+extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, const kaiju_gpu_params *p) {
+  if (!out || !ix || !p) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  if (p->mode != 0 && p->mode != 1) return fail(KAIJU_GPU_ERR_ARG, "mode must be 0 (MEM) or 1 (GREEDY)");
+  if (p->min_fragment_length < 1 || p->min_fragment_length > 10000)
+    return fail(KAIJU_GPU_ERR_UNSUPPORTED, "min_fragment_length out of range");
+  if (p->mode == 1 && p->mismatches > (uint32_t)kMaxMismatch)
+    return fail(KAIJU_GPU_ERR_UNSUPPORTED, "more than 8 mismatches are not supported");
+  if (p->mode == 1 && p->seed_length < 1) return fail(KAIJU_GPU_ERR_ARG, "seed_length must be >= 1");
+  if (p->max_match_ids > 20 || p->max_matches_SI > 64 || p->max_matches_SI < 1)
+    return fail(KAIJU_GPU_ERR_UNSUPPORTED, "max_match_ids <= 20 and 1 <= max_matches_SI <= 64 required");
+  std::unique_ptr<kaiju_gpu_ctx> c(new kaiju_gpu_ctx());
+  c->ix = ix;
+  c->params = *p;
+  c->kp.mode = p->mode; c->kp.m = p->min_fragment_length; c->kp.mismatches = p->mismatches;
+  c->kp.min_score = p->min_score; c->kp.seed_length = p->seed_length; c->kp.seg = p->seg ? 1 : 0;
+  c->kp.max_matches_SI = p->max_matches_SI; c->kp.max_match_ids = p->max_match_ids;
+  KJ_HIP(hipSetDevice(ix->device));
+  hipDeviceProp_t prop;
+  KJ_HIP(hipGetDeviceProperties(&prop, ix->device));
+  c->n_cu = prop.multiProcessorCount;
+  int occ = 0;
+  if (p->mode == 0) KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mem, kBlock, 0));
+  else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy, kBlock, 0));
+  if (occ < 1) occ = 1;
+  if (occ > 8) occ = 8;
+  if (const char *e = getenv("KAIJU_GPU_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }
+  c->blocks_main = c->n_cu * occ;
+  c->blocks_retry = p->mode == 0 ? 16 : 4;
+  KJ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto &e : c->ev) KJ_HIP(hipEventCreate(&e));
+  *out = c.release();
+  return KAIJU_GPU_OK;
+}
+
+extern "C" void kaiju_gpu_destroy(kaiju_gpu_ctx *ctx) { delete ctx; }
+
+// counters buffer layout (uint32): [0] main work counter, [1] retry work counter,
+// [2] retry list length, [3] stage-1 error flags
+static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes, const uint64_t *d_off,
+                        uint32_t n, int paired, uint32_t max_read_len, kaiju_gpu_hit *d_out, hipStream_t s) {
+  const kaiju_gpu_index *ix = c->ix;
+  const Params &p = c->kp;
+  if (max_read_len == 0) max_read_len = 1024;
+  const uint64_t max_pair = (uint64_t)max_read_len * (paired ? 2 : 1);
+  // stage buffers
+  const uint64_t pep_bytes = 2 * seq_bytes + 24ull * n + 8 + 64;
+  const uint64_t n_frag_slots = 2 * ((2 * seq_bytes) / (p.m + 1) + 7ull * n) + 8;
+  int rc;
+  if ((rc = ensure(c->pep, pep_bytes))) return rc;
+  if ((rc = ensure(c->frags, n_frag_slots * sizeof(Frag)))) return rc;
+  if ((rc = ensure(c->nfrag, (size_t)n * 4 + 16))) return rc;
+  if ((rc = ensure(c->counters, 64))) return rc;
+  if ((rc = ensure(c->retry_list, (size_t)n * 4 + 16))) return rc;
+  Batch b;
+  b.seqs = static_cast<const uint8_t *>(d_seqs); b.off = d_off; b.n_reads = n; b.paired = paired ? 1 : 0;
+  b.pep = static_cast<uint8_t *>(c->pep.p); b.frags = static_cast<Frag *>(c->frags.p);
+  b.nfrag = static_cast<uint32_t *>(c->nfrag.p); b.hits = reinterpret_cast<Hit *>(d_out);
+  uint32_t *cnt = static_cast<uint32_t *>(c->counters.p);
+  KJ_HIP(hipMemsetAsync(cnt, 0, 64, s));
+  KJ_HIP(hipEventRecord(c->ev[0], s));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_fragments, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ix->d_ct, p, ix->st, b, cnt + 3);
+    KJ_HIP(hipGetLastError());
+  }
+  KJ_HIP(hipEventRecord(c->ev[1], s));
+  WorkList wl_main;
+  wl_main.counter = cnt + 0; wl_main.reads = nullptr; wl_main.n_items_ptr = nullptr; wl_main.n_items = n;
+  wl_main.retry_list = static_cast<uint32_t *>(c->retry_list.p); wl_main.retry_count = cnt + 2;
+  WorkList wl_retry;
+  wl_retry.counter = cnt + 1; wl_retry.reads = static_cast<const uint32_t *>(c->retry_list.p);
+  wl_retry.n_items_ptr = cnt + 2; wl_retry.n_items = 0; wl_retry.retry_list = nullptr; wl_retry.retry_count = nullptr;
+  const uint64_t lanes_main = (uint64_t)c->blocks_main * kBlock;
+  if (p.mode == 0) {
+    const uint32_t si_cap = 16;
+    if ((rc = ensure(c->scratch_main[0], lanes_main * si_cap * sizeof(SIEntry)))) return rc;
+    // every (fragment, end position) can yield at most one match
+    const uint32_t si_cap_retry = (uint32_t)std::min<uint64_t>(2 * max_pair + 64, 1u << 24);
+    int blocks_retry = c->blocks_retry;
+    while (blocks_retry > 1 && (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry) > (1ull << 30)) blocks_retry /= 2;
+    if ((rc = ensure(c->scratch_retry[0], (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry)))) return rc;
+    if (n > 0) {
+      hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), dim3(kBlock), 0, s, ix->dev, p, b, wl_main,
+                         static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+      KJ_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_mem, dim3(blocks_retry), dim3(kBlock), 0, s, ix->dev, p, b, wl_retry,
+                         static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry);
+      KJ_HIP(hipGetLastError());
+    }
+  } else {
+    const uint32_t frag_max = max_read_len / 3 + 4;
+    GreedyArrays ga;
+    ga.pool_cap = 192; ga.match_cap = 64; ga.prefix_cap = frag_max + 1;
+    if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
+    if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(c->scratch_main[2], lanes_main * ga.match_cap * sizeof(GMatch)))) return rc;
+    if ((rc = ensure(c->scratch_main[3], lanes_main * ga.prefix_cap * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c->scratch_main[4], lanes_main * 64 * sizeof(GBest)))) return rc;
+    ga.pool = static_cast<GItem *>(c->scratch_main[0].p); ga.ord = static_cast<uint16_t *>(c->scratch_main[1].p);
+    ga.matches = static_cast<GMatch *>(c->scratch_main[2].p); ga.prefix = static_cast<uint32_t *>(c->scratch_main[3].p);
+    ga.best = static_cast<GBest *>(c->scratch_main[4].p);
+    GreedyArrays gr;
+    gr.pool_cap = 65535; gr.match_cap = frag_max + 8; gr.prefix_cap = frag_max + 1;
+    const uint64_t lanes_retry = (uint64_t)c->blocks_retry * kBlock;
+    if ((rc = ensure(c->scratch_retry[0], lanes_retry * gr.pool_cap * sizeof(GItem)))) return rc;
+    if ((rc = ensure(c->scratch_retry[1], lanes_retry * gr.pool_cap * sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(c->scratch_retry[2], lanes_retry * gr.match_cap * sizeof(GMatch)))) return rc;
+    if ((rc = ensure(c->scratch_retry[3], lanes_retry * gr.prefix_cap * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c->scratch_retry[4], lanes_retry * 64 * sizeof(GBest)))) return rc;
+    gr.pool = static_cast<GItem *>(c->scratch_retry[0].p); gr.ord = static_cast<uint16_t *>(c->scratch_retry[1].p);
+    gr.matches = static_cast<GMatch *>(c->scratch_retry[2].p); gr.prefix = static_cast<uint32_t *>(c->scratch_retry[3].p);
+    gr.best = static_cast<GBest *>(c->scratch_retry[4].p);
+    if (n > 0) {
+      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), dim3(kBlock), 0, s, ix->dev, ix->d_ct, p, ix->st, b, wl_main, ga);
+      KJ_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_retry), dim3(kBlock), 0, s, ix->dev, ix->d_ct, p, ix->st, b, wl_retry, gr);
+      KJ_HIP(hipGetLastError());
+    }
+  }
+  KJ_HIP(hipEventRecord(c->ev[2], s));
+  c->ev_valid = true;
+  c->last_n = n;
+  return KAIJU_GPU_OK;
+}
+
+extern "C" int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d_seqs, uint64_t seq_bytes,
+                                               const uint64_t *d_off, uint32_t n_reads, int paired,
+                                               kaiju_gpu_hit *d_out, void *stream) {
+  if (!ctx || (!d_seqs && seq_bytes) || !d_off || (!d_out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  uint32_t max_len = 0;
+  if (const char *e = getenv("KAIJU_GPU_MAX_READ_LEN")) max_len = (uint32_t)atoi(e);
+  return launch_batch(ctx, d_seqs, seq_bytes, d_off, n_reads, paired, max_len, d_out, s);
+}
+
+extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off,
+                                        uint32_t n_reads, int paired, kaiju_gpu_hit *out) {
+  if (!ctx || !off || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (n_reads == 0) return KAIJU_GPU_OK;
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  if (off[0] != 0) return fail(KAIJU_GPU_ERR_ARG, "off[0] must be 0");
+  const uint64_t seq_bytes = off[2 * (uint64_t)n_reads];
+  uint32_t max_len = 0;
+  for (uint64_t i = 0; i < 2 * (uint64_t)n_reads; i++) {
+    if (off[i + 1] < off[i]) return fail(KAIJU_GPU_ERR_ARG, "offsets must be non-decreasing");
+    const uint64_t l = off[i + 1] - off[i];
+    if (l > 0x3fffffffull) return fail(KAIJU_GPU_ERR_UNSUPPORTED, "read longer than 2^30");
+    if (l > max_len) max_len = (uint32_t)l;
+  }
+  if (seq_bytes && !seqs) return fail(KAIJU_GPU_ERR_ARG, "seqs is NULL");
+  int rc;
+  if ((rc = ensure(ctx->h_seqs, seq_bytes + 64))) return rc;
+  if ((rc = ensure(ctx->h_off, (2 * (size_t)n_reads + 1) * 8))) return rc;
+  if ((rc = ensure(ctx->h_hits, (size_t)n_reads * sizeof(kaiju_gpu_hit)))) return rc;
+  hipStream_t s = ctx->stream;
+  if (seq_bytes) KJ_HIP(hipMemcpyAsync(ctx->h_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, s));
+  KJ_HIP(hipMemcpyAsync(ctx->h_off.p, off, (2 * (size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+  rc = launch_batch(ctx, ctx->h_seqs.p, seq_bytes, static_cast<const uint64_t *>(ctx->h_off.p), n_reads, paired,
+                    max_len ? max_len : 1, static_cast<kaiju_gpu_hit *>(ctx->h_hits.p), s);
+  if (rc) return rc;
+  KJ_HIP(hipMemcpyAsync(out, ctx->h_hits.p, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipStreamSynchronize(s));
+  return KAIJU_GPU_OK;
+}
+
+extern "C" int kaiju_gpu_synchronize(kaiju_gpu_ctx *ctx) {
+  if (!ctx) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  KJ_HIP(hipDeviceSynchronize());
+  return KAIJU_GPU_OK;
+}
+
+extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
+  if (!ctx || !stats) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  memset(stats, 0, sizeof *stats);
+  if (!ctx->ev_valid) return KAIJU_GPU_OK;
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  KJ_HIP(hipEventSynchronize(ctx->ev[2]));
+  float t01 = 0, t12 = 0;
+  KJ_HIP(hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
+  KJ_HIP(hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
+  uint32_t cnt[4] = {0, 0, 0, 0};
+  KJ_HIP(hipMemcpy(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
+  stats->n_reads = ctx->last_n;
+  stats->n_overflow_retries = cnt[2];
+  stats->ms_translate = t01;
+  stats->ms_search = t12;
+  stats->ms_total = t01 + t12;
+  return KAIJU_GPU_OK;
+}

@@ -1,0 +1,237 @@
+// host_index.cpp — see host_index.h
+#include "host_index.h"
+
+#include <algorithm>
+#include <cctype>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "../../include/kaiju_gpu.h"
+
+namespace kj {
+
+namespace {
+struct Reader {
+  FILE *fp;
+  bool ok = true;
+  template <class T> void get(T &v) { if (ok && fread(&v, sizeof(T), 1, fp) != 1) ok = false; }
+  void bytes(void *dst, size_t n) { if (ok && n && fread(dst, 1, n, fp) != n) ok = false; }
+  void skip(int64_t n) { if (ok && fseeko(fp, (off_t)n, SEEK_CUR) != 0) ok = false; }
+};
+unsigned hw_threads() {
+  unsigned n = std::thread::hardware_concurrency();
+  return n ? std::min(n, 64u) : 4u;
+}
+template <class F> void parallel_for(uint64_t n, F &&fn) {
+  const unsigned nt = (unsigned)std::min<uint64_t>(hw_threads(), n ? n : 1);
+  if (nt <= 1) { for (uint64_t i = 0; i < n; i++) fn(i); return; }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++)
+    th.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) fn(i); });
+  for (auto &x : th) x.join();
+}
+}  // namespace
+
+bool parse_taxid(const char *name, uint64_t &id) {
+  // "AX1235.1_4567", "WP_12345.1_987" or "987": digits after the last '_' (or the whole name)
+  const char *pch = strrchr(name, '_');
+  const unsigned long v = strtoul(pch ? pch + 1 : name, nullptr, 10);
+  id = (uint64_t)v;
+  return v != ULONG_MAX;
+}
+
+int FmiFile::load(const char *path, std::string &msg) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
+  Reader rd{fp};
+  // BWT header, bwt/bwt.c:51-61
+  rd.get(len); rd.get(nseq); rd.get(alen);
+  if (!rd.ok || alen <= 1 || alen > 60 || nseq <= 0 || len <= 0) {
+    fclose(fp); msg = "not a Kaiju .fmi file (bad BWT header)"; return KAIJU_GPU_ERR_FORMAT;
+  }
+  alphabet.resize((size_t)alen);
+  rd.bytes(&alphabet[0], (size_t)alen);
+  // suffix array header, bwt/suffixArray.c:282-312
+  rd.get(salen); rd.get(ncheck); rd.get(chpt_exp); rd.get(nbytes); rd.get(sbits); rd.get(pbits);
+  rd.get(mask); rd.get(check); rd.get(sa_nseq);
+  if (!rd.ok || sa_nseq != nseq || nbytes <= 0 || nbytes > 8 || chpt_exp < 0 || chpt_exp > 30 || ncheck < 0) {
+    fclose(fp); msg = "not a Kaiju .fmi file (bad suffix array header)"; return KAIJU_GPU_ERR_FORMAT;
+  }
+  ids.resize((size_t)nseq);
+  for (int32_t i = 0; i < nseq && rd.ok; i++) {
+    uint8_t l = 0;
+    rd.get(l);
+    ids[(size_t)i].resize(l);
+    rd.bytes(l ? &ids[(size_t)i][0] : nullptr, l);
+  }
+  rd.skip((int64_t)nseq * 4);   // seqTermOrder: not used by the search
+  rd.skip((int64_t)nseq * 8);   // seqlengths: not used by the search
+  sa.resize((size_t)ncheck * (size_t)nbytes);
+  rd.bytes(sa.data(), sa.size());
+  // FMI, bwt/fmicommon.h:190-217 + compactfmi.c:165-171
+  rd.get(f_alen); rd.get(bwtlen); rd.get(N1); rd.get(N2);
+  if (!rd.ok || f_alen != alen || bwtlen != len || N1 <= 0 || N2 <= 0) {
+    fclose(fp); msg = "not a Kaiju .fmi file (bad FMI header)"; return KAIJU_GPU_ERR_FORMAT;
+  }
+  bwt.resize((size_t)bwtlen);
+  rd.bytes(bwt.data(), bwt.size());
+  rd.skip((int64_t)(N1 - 1) * alen * 8);
+  index1_last.resize((size_t)alen);
+  rd.bytes(index1_last.data(), (size_t)alen * 8);
+  rd.skip((int64_t)N2 * alen * 2);   // index2: rebuilt in the packed layout
+  startLcode.resize((size_t)alen + 1);
+  rd.bytes(startLcode.data(), ((size_t)alen + 1) * 4);
+  const bool ok = rd.ok;
+  fclose(fp);
+  if (!ok) { msg = "truncated .fmi file"; return KAIJU_GPU_ERR_IO; }
+  id_ptrs.resize(ids.size());
+  for (size_t i = 0; i < ids.size(); i++) id_ptrs[i] = ids[i].c_str();
+  return 0;
+}
+
+HostIndexView FmiFile::view() const {
+  HostIndexView v;
+  v.bwtlen = bwtlen; v.nseq = nseq; v.alen = alen; v.alphabet = alphabet.data();
+  v.bwt = bwt.data(); v.startLcode = startLcode.data();
+  v.sa = sa.data(); v.ncheck = ncheck; v.chpt_exp = chpt_exp; v.nbytes = nbytes; v.pbits = pbits;
+  v.ids = id_ptrs.data();
+  return v;
+}
+
+int PackedIndex::build(const HostIndexView &v, std::string &msg) {
+  if (!v.bwt || !v.startLcode || !v.alphabet || !v.ids || v.bwtlen <= 0 || v.nseq <= 0) {
+    msg = "incomplete index view"; return KAIJU_GPU_ERR_ARG;
+  }
+  if (v.alen < 2 || v.alen > 21) {
+    msg = "alphabets with more than 20 letters + terminator are not supported"; return KAIJU_GPU_ERR_UNSUPPORTED;
+  }
+  alen = (uint32_t)v.alen; bwtlen = (uint64_t)v.bwtlen; nseq = (uint32_t)v.nseq; chpt_exp = (uint32_t)v.chpt_exp;
+  alphabet.assign(v.alphabet, (size_t)v.alen);
+  warnings = 0;
+  // translation_table(alphabet, NULL, dummy = len-1, case-insensitive), sequence.c:68-97,132-141
+  trans[0] = 0;
+  for (int i = 1; i < 128; i++) trans[i] = isalpha(i) ? (uint8_t)(alen - 1) : (uint8_t)255;
+  for (uint32_t i = 0; i < alen; i++) {
+    trans[toupper((unsigned char)alphabet[i]) & 127] = (uint8_t)i;
+    trans[tolower((unsigned char)alphabet[i]) & 127] = (uint8_t)i;
+  }
+  // byte code -> letter (fmi_fill_codes, compactfmi.c:75-89)
+  uint8_t lcode[256];
+  memset(lcode, 31, sizeof lcode);
+  for (uint32_t a = 0; a < alen; a++) {
+    const int s = v.startLcode[a], e = v.startLcode[a + 1];
+    if (s < 0 || e > 256 || s > e) { msg = "bad startLcode table"; return KAIJU_GPU_ERR_FORMAT; }
+    for (int k = s; k < e; k++) lcode[k] = (uint8_t)a;
+  }
+  const uint64_t nblk = (bwtlen >> kBlkShift) + 1;
+  const uint64_t nsb = (bwtlen >> kSbShift) + 1;
+  const uint64_t blk_per_sb = 1ull << (kSbShift - kBlkShift);
+  blocks.assign((size_t)nblk, RankBlock{});
+  sb.assign((size_t)nsb * 20, 0);
+  // pass 1: letter histogram of every superblock
+  std::vector<uint64_t> hist((size_t)nsb * 21, 0);
+  const uint8_t *bwt = v.bwt;
+  parallel_for(nsb, [&](uint64_t s) {
+    const uint64_t b = s << kSbShift, e = std::min<uint64_t>(bwtlen, b + (1ull << kSbShift));
+    uint64_t h[32] = {0};
+    for (uint64_t k = b; k < e; k++) h[lcode[bwt[k]]]++;
+    for (int a = 0; a < 21; a++) hist[(size_t)s * 21 + a] = h[a];
+  });
+  uint64_t total[21] = {0};
+  for (uint64_t s = 0; s < nsb; s++) for (int a = 0; a < 21; a++) total[a] += hist[(size_t)s * 21 + a];
+  {
+    uint64_t sum = 0;
+    for (int a = 0; a < 21; a++) sum += total[a];
+    if (sum != bwtlen) { msg = "BWT contains byte codes outside the code table"; return KAIJU_GPU_ERR_FORMAT; }
+    if (total[0] != nseq) { msg = "number of terminators in the BWT differs from nseq"; return KAIJU_GPU_ERR_FORMAT; }
+  }
+  // C[] (index1[N1-1], fmicommon.h:160-165; InitialSI bwt.c:146-152 uses bwtlen after the last letter)
+  C[0] = 0;
+  for (uint32_t a = 1; a < alen; a++) C[a] = C[a - 1] + total[a - 1];
+  for (uint32_t a = alen; a < 22; a++) C[a] = bwtlen;
+  {
+    uint64_t run[21] = {0};
+    for (uint64_t s = 0; s < nsb; s++) {
+      for (int a = 1; a < 21; a++) {
+        sb[(size_t)s * 20 + (a - 1)] = C[a] + run[a];
+        run[a] += hist[(size_t)s * 21 + a];
+      }
+    }
+  }
+  // pass 2: rank blocks
+  parallel_for(nsb, [&](uint64_t s) {
+    uint32_t cnt[32] = {0};
+    const uint64_t b0 = s * blk_per_sb, b1 = std::min<uint64_t>(nblk, b0 + blk_per_sb);
+    for (uint64_t bi = b0; bi < b1; bi++) {
+      RankBlock &rb = blocks[(size_t)bi];
+      for (int a = 1; a < 21; a++) rb.cnt[a - 1] = (uint16_t)cnt[a];
+      const uint64_t k0 = bi << kBlkShift;
+      for (uint32_t t = 0; t < 128; t++) {
+        const uint64_t k = k0 + t;
+        const uint32_t c = k < bwtlen ? lcode[bwt[k]] : 31u;   // padding never matches a letter
+        if (k < bwtlen) cnt[c]++;
+        for (int p = 0; p < 5; p++)
+          if ((c >> p) & 1u) rb.plane[p][t >> 6] |= 1ull << (t & 63);
+      }
+    }
+  });
+  // terminator positions (rows whose BWT letter is 0): rank_term
+  term_pos.clear();
+  term_pos.reserve(nseq);
+  for (uint64_t k = 0; k < bwtlen; k++) if (lcode[bwt[k]] == 0) term_pos.push_back(k);
+  // sampled suffix array: only the sequence number is needed (suffixArray.h:37-51)
+  sa_skip = (((uint64_t)nseq - 1) >> chpt_exp) + 1;
+  n_sa = (uint64_t)v.ncheck;
+  sa_iseq.assign((size_t)n_sa, 0);
+  if (v.nbytes < 1 || v.nbytes > 8 || v.pbits < 0 || v.pbits > 62) { msg = "bad suffix array coding"; return KAIJU_GPU_ERR_FORMAT; }
+  {
+    const uint8_t *sa = v.sa;
+    const int nb = v.nbytes, pb = v.pbits;
+    uint32_t *dst = sa_iseq.data();
+    parallel_for((n_sa + 65535) / 65536, [&](uint64_t chunk) {
+      const uint64_t b = chunk * 65536, e = std::min<uint64_t>(n_sa, b + 65536);
+      for (uint64_t i = b; i < e; i++) {
+        const uint8_t *c = sa + i * (uint64_t)nb;
+        uint64_t val = 0;
+        for (int q = 0; q < nb; q++) val = (val << 8) + c[q];
+        dst[i] = (uint32_t)(val >> pb);
+      }
+    });
+  }
+  {
+    const uint64_t need = bwtlen > 0 ? (((bwtlen - 1) >> chpt_exp) - sa_skip + 1) : 0;
+    if (((bwtlen - 1) >> chpt_exp) >= sa_skip && need > n_sa) warnings |= KAIJU_IDX_WARN_SA_SHORT;
+  }
+  if (bwtlen > 65536 && (bwtlen % 65536 >= 65408 || bwtlen % 65536 == 0)) warnings |= KAIJU_IDX_WARN_RANK_BUG;
+  // taxon ids
+  seq_taxid.assign(nseq, 0);
+  seq_valid.assign(nseq, 0);
+  names.resize(nseq);
+  for (uint32_t i = 0; i < nseq; i++) {
+    const char *nm = v.ids[i] ? v.ids[i] : "";
+    names[i] = nm;
+    uint64_t id = 0;
+    seq_valid[i] = parse_taxid(nm, id) ? 1 : 0;
+    seq_taxid[i] = id;
+  }
+  return 0;
+}
+
+uint64_t PackedIndex::bytes() const {
+  return blocks.size() * sizeof(RankBlock) + sb.size() * 8 + sa_iseq.size() * 4 + seq_taxid.size() * 8 +
+         seq_valid.size() + term_pos.size() * 8;
+}
+
+DevIndex PackedIndex::host_view() const {
+  DevIndex d;
+  d.blocks = blocks.data(); d.sb = sb.data(); d.sa_iseq = sa_iseq.data();
+  d.seq_taxid = seq_taxid.data(); d.seq_valid = seq_valid.data(); d.term_pos = term_pos.data();
+  for (int a = 0; a < 22; a++) d.C[a] = C[a];
+  d.bwtlen = bwtlen; d.n_sa = n_sa; d.sa_skip = sa_skip; d.nseq = nseq; d.chpt_exp = chpt_exp;
+  return d;
+}
+
+}  // namespace kj

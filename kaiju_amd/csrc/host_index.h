@@ -1,0 +1,77 @@
+// host_index.h — .fmi parsing and re-packing of the FM-index into the HBM layout.
+//
+// Reads the reference's on-disk index format byte for byte (bwt/bwt.c:51-88,
+// bwt/suffixArray.c:282-321, bwt/fmicommon.h:190-217, bwt/compactfmi.c:165-171) or takes
+// the same arrays from memory (kaiju_gpu_host_index), decodes the byte-coded BWT to plain
+// letters and builds the rank blocks / superblocks / SA sample / taxon tables the kernels
+// use (kj_core.h).  Pure host code; the arrays are uploaded by capi.hip.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "kj_core.h"
+
+namespace kj {
+
+struct HostIndexView {        // borrowed pointers (== kaiju_gpu_host_index)
+  int64_t bwtlen = 0;
+  int32_t nseq = 0, alen = 0;
+  const char *alphabet = nullptr;
+  const uint8_t *bwt = nullptr;
+  const int32_t *startLcode = nullptr;
+  const uint8_t *sa = nullptr;
+  int64_t ncheck = 0;
+  int32_t chpt_exp = 0, nbytes = 0, pbits = 0;
+  const char *const *ids = nullptr;
+};
+
+// owns everything read from a .fmi file
+struct FmiFile {
+  int64_t len = 0;
+  int32_t nseq = 0, alen = 0;
+  std::string alphabet;
+  int64_t salen = 0, ncheck = 0;
+  int32_t chpt_exp = 0, nbytes = 0, sbits = 0, pbits = 0;
+  int64_t mask = 0, check = 0;
+  int32_t sa_nseq = 0;
+  std::vector<std::string> ids;
+  std::vector<const char *> id_ptrs;
+  std::vector<uint8_t> sa;
+  int32_t f_alen = 0;
+  int64_t bwtlen = 0;
+  int32_t N1 = 0, N2 = 0;
+  std::vector<uint8_t> bwt;
+  std::vector<int64_t> index1_last;   // index1[N1-1][*] = C[] as stored by the reference
+  std::vector<int32_t> startLcode;
+  // returns 0 or a negative kaiju_gpu_status; msg receives details
+  int load(const char *path, std::string &msg);
+  HostIndexView view() const;
+};
+
+// the packed index in host memory, ready for upload
+struct PackedIndex {
+  std::vector<RankBlock> blocks;
+  std::vector<uint64_t> sb;
+  std::vector<uint32_t> sa_iseq;
+  std::vector<uint64_t> seq_taxid;
+  std::vector<uint8_t> seq_valid;
+  std::vector<uint64_t> term_pos;
+  std::vector<std::string> names;   // sequence names (for the verbose columns)
+  uint64_t C[22] = {0};
+  uint64_t bwtlen = 0, n_sa = 0, sa_skip = 0;
+  uint32_t nseq = 0, chpt_exp = 0, alen = 0;
+  uint32_t warnings = 0;
+  std::string alphabet;
+  uint8_t trans[128];               // translate2numbers table (sequence.c:68-97)
+  // fills everything from a view; returns 0 or negative status
+  int build(const HostIndexView &v, std::string &msg);
+  uint64_t bytes() const;
+  // DevIndex whose pointers refer to THIS object's host vectors (used by the test emulation)
+  DevIndex host_view() const;
+};
+
+// name -> taxon id with the rule of ids_from_SI (ConsumerThread.cpp:809-833)
+bool parse_taxid(const char *name, uint64_t &id);
+
+}  // namespace kj

@@ -1,0 +1,131 @@
+// host_tables.cpp — see host_tables.h
+#include "host_tables.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/kaiju_gpu.h"
+
+namespace kj {
+
+namespace {
+// the reference's aa2int order (ConsumerThread.cpp:40-60)
+const char kAaOrder[21] = "ARNDCQEGHILKMFPSTWYV";
+// BLOSUM62, rows/columns in kAaOrder (diagonal: ConsumerThread.cpp:61-80, rest :83-102)
+const int8_t kB62[20][20] = {
+  { 4,-1,-2,-2, 0,-1,-1, 0,-2,-1,-1,-1,-1,-2,-1, 1, 0,-3,-2, 0},
+  {-1, 5, 0,-2,-3, 1, 0,-2, 0,-3,-2, 2,-1,-3,-2,-1,-1,-3,-2,-3},
+  {-2, 0, 6, 1,-3, 0, 0, 0, 1,-3,-3, 0,-2,-3,-2, 1, 0,-4,-2,-3},
+  {-2,-2, 1, 6,-3, 0, 2,-1,-1,-3,-4,-1,-3,-3,-1, 0,-1,-4,-3,-3},
+  { 0,-3,-3,-3, 9,-3,-4,-3,-3,-1,-1,-3,-1,-2,-3,-1,-1,-2,-2,-1},
+  {-1, 1, 0, 0,-3, 5, 2,-2, 0,-3,-2, 1, 0,-3,-1, 0,-1,-2,-1,-2},
+  {-1, 0, 0, 2,-4, 2, 5,-2, 0,-3,-3, 1,-2,-3,-1, 0,-1,-3,-2,-2},
+  { 0,-2, 0,-1,-3,-2,-2, 6,-2,-4,-4,-2,-3,-3,-2, 0,-2,-2,-3,-3},
+  {-2, 0, 1,-1,-3, 0, 0,-2, 8,-3,-3,-1,-2,-1,-2,-1,-2,-2, 2,-3},
+  {-1,-3,-3,-3,-1,-3,-3,-4,-3, 4, 2,-3, 1, 0,-3,-2,-1,-3,-1, 3},
+  {-1,-2,-3,-4,-1,-2,-3,-4,-3, 2, 4,-2, 2, 0,-3,-2,-1,-2,-1, 1},
+  {-1, 2, 0,-1,-3, 1, 1,-2,-1,-3,-2, 5,-1,-3,-1, 0,-1,-3,-2,-2},
+  {-1,-1,-2,-3,-1, 0,-2,-3,-2, 1, 2,-1, 5, 0,-2,-1,-1,-1,-1, 1},
+  {-2,-3,-3,-3,-2,-3,-3,-3,-1, 0, 0,-3, 0, 6,-4,-2,-2, 1, 3,-1},
+  {-1,-2,-2,-1,-3,-1,-1,-2,-2,-3,-3,-1,-2,-4, 7,-1,-1,-4,-3,-2},
+  { 1,-1, 1, 0,-1, 0, 0, 0,-1,-2,-2, 0,-1,-2,-1, 4, 1,-3,-2,-2},
+  { 0,-1, 0,-1,-1,-1,-1,-2,-2,-1,-1,-1,-1,-2,-1, 1, 5,-2,-2, 0},
+  {-3,-3,-4,-4,-2,-2,-3,-2,-2,-3,-2,-3,-1, 1,-4,-3,-2,11, 2,-3},
+  {-2,-2,-2,-3,-2,-1,-2,-3, 2,-1,-1,-2,-1, 3,-3,-2,-2, 2, 7,-1},
+  { 0,-3,-3,-3,-1,-2,-2,-3,-3, 3, 1,-2, 1,-1,-2,-2, 0,-3,-1, 4}};
+// standard genetic code, index = n0*16 + n1*4 + n2 with A,C,G,T = 0..3 (codon2aa, :111-177)
+const char kCodonAa[65] = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVV*Y*YSSSS*CWCLFLF";
+}  // namespace
+
+int build_const_tables(const uint8_t trans[128], ConstTables &t, std::string &msg) {
+  memset(&t, 0, sizeof t);
+  memcpy(t.b62, kB62, sizeof kB62);
+  // blosum_subst (:10-30): the other 19 residues by descending score; equal scores in
+  // descending aa2int order
+  for (int a = 0; a < 20; a++) {
+    int n = 0;
+    for (int s = 11; s >= -4; s--)
+      for (int b = 19; b >= 0; b--)
+        if (b != a && kB62[a][b] == s) t.subst[a][n++] = (uint8_t)b;
+    if (n != 19) { msg = "internal: substitution table"; return KAIJU_GPU_ERR_ARG; }
+  }
+  uint8_t aa2int[128];
+  memset(aa2int, 255, sizeof aa2int);
+  for (int a = 0; a < 20; a++) aa2int[(int)kAaOrder[a]] = (uint8_t)a;
+  for (int i = 0; i < 64; i++) t.codon_aa[i] = kCodonAa[i] == '*' ? 255 : aa2int[(int)kCodonAa[i]];
+  memset(t.nuc, 255, sizeof t.nuc);
+  t.nuc['A'] = t.nuc['a'] = 0; t.nuc['C'] = t.nuc['c'] = 1; t.nuc['G'] = t.nuc['g'] = 2;
+  t.nuc['T'] = t.nuc['t'] = 3; t.nuc['U'] = t.nuc['u'] = 3;
+  memset(t.idx_to_aa, 0, sizeof t.idx_to_aa);
+  bool seen[32] = {false};
+  for (int a = 0; a < 20; a++) {
+    const uint8_t c = trans[(int)kAaOrder[a]];
+    if (c < 1 || c > 20 || seen[c]) {
+      msg = std::string("index alphabet does not hold the 20 amino acids as distinct letters (") + kAaOrder[a] + ")";
+      return KAIJU_GPU_ERR_UNSUPPORTED;
+    }
+    seen[c] = true;
+    t.aa_to_idx[a] = c;
+    t.idx_to_aa[c] = (uint8_t)a;
+  }
+  return 0;
+}
+
+namespace {
+// the reference's s_Entropy (blast_seg.c:1596-1626) on a descending state vector
+double ref_entropy(const int *sv, int n) {
+  const double ln2 = 0.693147180559945309417232121458176568;   // NCBIMATH_LN2
+  int total = 0;
+  for (int i = 0; i < n; i++) total += sv[i];
+  if (total == 0) return 0.;
+  double ent = 0.0;
+  for (int i = 0; i < n; i++) ent += ((double)sv[i]) * log(((double)sv[i]) / (double)total) / ln2;
+  return fabs(ent / (double)total);
+}
+bool check_partitions(int remaining, int maxpart, int *sv, int n, const SegTables &st, std::string &msg) {
+  if (remaining == 0) {
+    if (n > 20) return true;                      // more than 20 distinct letters cannot occur
+    const double H = ref_entropy(sv, n);
+    int64_t score = 0;
+    for (int i = 0; i < n; i++) score += st.ent_g[sv[i]];
+    const bool lo_ref = H <= 2.2, hi_ref = H > 2.5;   // kSegLocut / kSegHicut, blast_seg.c:48-50
+    const bool lo_int = score <= st.ent_locut, hi_int = score > st.ent_hicut;
+    if (lo_ref != lo_int || hi_ref != hi_int) { msg = "integer SEG entropy classification disagrees with libm"; return false; }
+    return true;
+  }
+  for (int p = remaining < maxpart ? remaining : maxpart; p >= 1; p--) {
+    sv[n] = p;
+    if (!check_partitions(remaining - p, p, sv, n + 1, st, msg)) return false;
+  }
+  return true;
+}
+}  // namespace
+
+int build_seg_tables(std::vector<double> &lnfact_host, SegTables &st, std::string &msg) {
+  // blast_seg.c:52-1308 tabulates ln(n!) for n = 0..10000 printed with six decimals
+  const int N = 10001;
+  lnfact_host.resize(N);
+  char buf[64];
+  for (int n = 0; n < N; n++) {
+    snprintf(buf, sizeof buf, "%.6f", lgamma((double)n + 1.0));
+    lnfact_host[n] = strtod(buf, nullptr);
+  }
+  if (lnfact_host[2] != 0.693147 || lnfact_host[20] != 42.335616 || lnfact_host[50] != 148.477767) {
+    msg = "ln(n!) table self-check failed"; return KAIJU_GPU_ERR_ARG;
+  }
+  st.lnfact = lnfact_host.data();
+  st.lnfact_n = (uint32_t)N;
+  // fixed-point entropy: H = sum_letters (c/12) log2(12/c); scale 2^40
+  const double scale = 1099511627776.0;
+  st.ent_g[0] = 0;
+  for (int c = 1; c <= 12; c++) st.ent_g[c] = (int64_t)llround(scale * ((double)c / 12.0) * log2(12.0 / (double)c));
+  st.ent_locut = (int64_t)floor(scale * 2.2);
+  st.ent_hicut = (int64_t)floor(scale * 2.5);
+  int sv[16];
+  if (!check_partitions(12, 12, sv, 0, st, msg)) return KAIJU_GPU_ERR_ARG;
+  return 0;
+}
+
+}  // namespace kj

@@ -1,0 +1,1139 @@
+// kj_core.h — per-lane logic of the Kaiju classification kernels for gfx950.
+//
+// Everything here is written as plain inline functions over raw pointers so that
+//   (a) hipcc compiles it into the __global__ kernels of kj_kernels.hip, and
+//   (b) tests/emu/ compiles the very same source with g++ to check the kernel
+//       logic against the oracle on machines without a GPU (test infrastructure
+//       only — the product library has no CPU path).
+//
+// Design: the FM-index is re-packed into 128-byte rank blocks
+// (one L2 line = one rank query); every lane runs a small state machine that
+// advances ONE dependent memory step (a backward-extension step = two rank
+// queries, or one LF step of the locate walk) per loop iteration and pulls the
+// next read from a global work counter when it is done, so all 64 lanes of a
+// wavefront always have a memory request in flight regardless of how long their
+// individual read takes.
+//
+// Reference behaviour reproduced (file:line in /root/reference/src) is cited at
+// each function.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KJ_HD __host__ __device__ __forceinline__
+#define KJ_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define KJ_HD inline
+#define KJ_HD_NOINLINE inline
+#endif
+
+namespace kj {
+
+// ----------------------------------------------------------------------------
+// constants shared with the host
+// ----------------------------------------------------------------------------
+constexpr int kMaxIds = 21;
+constexpr int kSbShift = 16;          // superblock = 65536 symbols
+constexpr int kBlkShift = 7;          // rank block = 128 symbols = 128 bytes
+constexpr uint32_t kHitIdCap = 1u, kHitSiCap = 2u;
+constexpr uint32_t kHitInternalOverflow = 0x80000000u;   // scratch too small even in the retry pass
+constexpr uint32_t kHitRetry = 0x40000000u;              // internal: queued for the retry pass
+constexpr int kWin = 64, kWinStride = 68;                // per-lane peptide window (bytes / LDS stride)
+
+// One rank block: 128 BWT symbols as five bit-planes (2 x 64 bit each) plus the
+// number of occurrences of letters 1..20 between the superblock start and the
+// block start (16 bit is enough: < 65536).  128 bytes, 128-byte aligned.
+struct alignas(128) RankBlock {
+  uint64_t plane[5][2];
+  uint16_t cnt[20];
+  uint16_t pad[4];
+};
+static_assert(sizeof(RankBlock) == 128, "RankBlock must be one 128-byte line");
+
+struct DevIndex {
+  const RankBlock *blocks;   // [(bwtlen >> 7) + 1]
+  const uint64_t *sb;        // [nsb][20]: C[c] + occurrences of c before the superblock
+  const uint32_t *sa_iseq;   // sequence number of every sampled SA row (rows >= nseq)
+  const uint64_t *seq_taxid; // taxon id per sequence (rule of ConsumerThread.cpp:809-833)
+  const uint8_t *seq_valid;  // 0 where strtoul gave ULONG_MAX
+  const uint64_t *term_pos;  // sorted BWT positions holding the terminator (letter 0)
+  uint64_t C[22];            // C[c] = first SA row of suffixes starting with letter c; C[21] = bwtlen
+  uint64_t bwtlen;
+  uint64_t n_sa;             // number of entries in sa_iseq
+  uint64_t sa_skip;          // ((nseq-1) >> e) + 1, see get_suffix bwt.c:115-116
+  uint32_t nseq;
+  uint32_t chpt_exp;
+};
+
+struct Params {
+  int32_t mode;              // 0 MEM, 1 GREEDY
+  uint32_t m;                // min_fragment_length
+  uint32_t mismatches, min_score, seed_length;
+  int32_t seg;
+  uint32_t max_matches_SI, max_match_ids;
+};
+
+// fragment descriptor (16 bytes)
+struct Frag {
+  uint32_t start;            // offset of the first residue relative to the read's peptide base
+  uint32_t len;
+  uint32_t key;              // MEM: length, GREEDY: BLOSUM62 diagonal score
+  uint32_t flags;            // bit0: SEG-checked, bit1: removed (transient)
+};
+
+struct SIEntry {             // one maximal match (16 bytes)
+  uint64_t lo;
+  uint32_t len;              // interval length (int truncation as alloc_SI, bwt.c:180)
+  uint32_t frag;
+};
+
+struct Hit {                 // == kaiju_gpu_hit
+  uint32_t best, n_ids, flags, reserved;
+  uint64_t taxid[kMaxIds];
+};
+
+// SEG tables built on the host (host_tables.cpp)
+struct SegTables {
+  const double *lnfact;      // ln(n!) rounded to 6 decimals, blast_seg.c:52-1308
+  uint32_t lnfact_n;
+  int64_t ent_g[13];         // fixed-point entropy contribution of a letter seen c times in a 12-window
+  int64_t ent_locut, ent_hicut;   // thresholds in the same fixed-point scale
+};
+
+// Constant tables (ConsumerThread.cpp:6-187); the kernels keep a copy in LDS.
+struct ConstTables {
+  int8_t b62[20][20];        // BLOSUM62 in aa2int order ARNDCQEGHILKMFPSTWYV
+  uint8_t subst[20][19];     // blosum_subst as aa2int codes, ConsumerThread.cpp:10-30
+  uint8_t codon_aa[64];      // codon (A,C,G,T=0..3; n0*16+n1*4+n2) -> aa2int code, 255 = stop
+  uint8_t nuc[256];          // nuc2int (255 = not ACGTU)
+  uint8_t aa_to_idx[20];     // aa2int code -> index-alphabet code (astruct->trans)
+  uint8_t idx_to_aa[32];     // index-alphabet code -> aa2int code
+};
+
+struct Batch {
+  const uint8_t *seqs;       // ASCII nucleotides
+  const uint64_t *off;       // [2n+1]
+  uint32_t n_reads;
+  int32_t paired;
+  uint8_t *pep;              // six-frame translations, index-alphabet codes, 0 = stop
+  Frag *frags;               // canonical fragment lists
+  uint32_t *nfrag;           // [n]
+  Hit *hits;                 // [n]
+};
+
+// layout helpers (closed form, no prefix sums needed) -------------------------
+// peptide area of read r: <= 2*(len1+len2) + 12 bytes of strings after 8 bytes of front padding
+KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return 2 * off[2 * (uint64_t)r] + 24ull * r + 8; }
+// fragment slots of read r: a read has at most (2*(len1+len2)+12)/(m+1) disjoint fragments;
+// twice that is reserved so that SEG pieces can sit next to their parents
+KJ_HD uint64_t frag_base(const uint64_t *off, uint32_t r, uint32_t m) {
+  return 2 * ((2 * off[2 * (uint64_t)r]) / (m + 1) + 7ull * r);
+}
+KJ_HD uint32_t frag_cap(const uint64_t *off, uint32_t r, uint32_t m) {
+  return (uint32_t)(frag_base(off, r + 1, m) - frag_base(off, r, m));
+}
+
+KJ_HD uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+
+// ----------------------------------------------------------------------------
+// rank / LF on the packed index
+// ----------------------------------------------------------------------------
+// C[c] + #{ i < k : bwt[i] == c }  for c in 1..20  (== FMindex, compactfmi.c:267-307)
+KJ_HD uint64_t rank_c(const DevIndex &ix, uint32_t c, uint64_t k) {
+  const RankBlock *b = ix.blocks + (k >> kBlkShift);
+  const uint32_t r = (uint32_t)k & 127u;
+  uint64_t m0 = ~0ull, m1 = ~0ull;
+#pragma unroll
+  for (int p = 0; p < 5; p++) {
+    const uint64_t inv = ((c >> p) & 1u) ? 0ull : ~0ull;
+    m0 &= b->plane[p][0] ^ inv;
+    m1 &= b->plane[p][1] ^ inv;
+  }
+  const uint64_t lm0 = r >= 64 ? ~0ull : ((1ull << r) - 1);
+  const uint64_t lm1 = r > 64 ? ((1ull << (r - 64)) - 1) : 0ull;
+  return ix.sb[(k >> kSbShift) * 20 + (c - 1)] + b->cnt[c - 1] + popc64(m0 & lm0) + popc64(m1 & lm1);
+}
+
+KJ_HD uint32_t symbol_at(const DevIndex &ix, uint64_t k) {
+  const RankBlock *b = ix.blocks + (k >> kBlkShift);
+  const uint32_t w = ((uint32_t)k >> 6) & 1u, s = (uint32_t)k & 63u;
+  uint32_t c = 0;
+#pragma unroll
+  for (int p = 0; p < 5; p++) c |= (uint32_t)((b->plane[p][w] >> s) & 1ull) << p;
+  return c;
+}
+
+// number of terminators in bwt[0, k)  (FMindexCurrent for letter 0; C[0] == 0)
+KJ_HD uint64_t rank_term(const DevIndex &ix, uint64_t k) {
+  uint64_t lo = 0, hi = ix.nseq;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (ix.term_pos[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// nucleotide triplet -> aa2int code (255 = stop).  Any non-ACGTU base gives a stop
+// (codon_to_int + codon2aa default, ConsumerThread.cpp:111,869-875).
+KJ_HD uint32_t codon_fwd(const ConstTables &t, const uint8_t *s) {
+  const uint32_t a = t.nuc[s[0]], b = t.nuc[s[1]], c = t.nuc[s[2]];
+  if ((a | b | c) > 3u) return 255u;
+  return t.codon_aa[a * 16 + b * 4 + c];
+}
+KJ_HD uint32_t codon_rev(const ConstTables &t, const uint8_t *s) {
+  const uint32_t a = t.nuc[s[2]], b = t.nuc[s[1]], c = t.nuc[s[0]];
+  if ((a | b | c) > 3u) return 255u;
+  return t.codon_aa[(3 - a) * 16 + (3 - b) * 4 + (3 - c)];
+}
+
+// ----------------------------------------------------------------------------
+// SEG — bit-exact device version of SeqBufferSeg with Kaiju's parameters
+// (blast_seg.c:1596-2332: window 12, locut 2.2, hicut 2.5, maxtrim 50, overlaps)
+// ----------------------------------------------------------------------------
+// The entropy of a 12-window only enters through the comparisons H <= locut and
+// H > hicut.  H is a function of the partition of 12 formed by the letter counts
+// (77 cases); the host evaluates the reference's floating-point expression for
+// every partition and verifies that the integer score  sum_letters ent_g[count]
+// classifies all of them identically (host_tables.cpp), so the device only adds
+// integers.  The trim step (s_Trim/s_GetProb) is done in double precision in
+// exactly the reference's operation order (adds/subtracts of table entries, no
+// contraction).  Letters: the peptide buffer holds index codes 1..20; SEG only
+// looks at letter identity, so code-1 (0..19) is used directly.
+constexpr int kSegWindow = 12, kSegDown = 5, kSegUp = 7, kSegMaxTrim = 50;
+constexpr int kSegMaxRegions = 32;
+constexpr int kSegHist = 255;          // histogram fast path for windows up to this length
+
+#define KJ_SL(s, i) ((uint32_t)(s)[(i)] - 1u)
+
+struct SegWin {              // 12-window: nibble-packed counts of the 20 letters + entropy score
+  uint64_t c0, c1;
+  int64_t score;
+};
+KJ_HD void segwin_add(SegWin &w, const SegTables &st, uint32_t a, int d) {
+  const uint32_t old = a < 16 ? (uint32_t)(w.c0 >> (4 * a)) & 15u : (uint32_t)(w.c1 >> (4 * (a - 16))) & 15u;
+  w.score += st.ent_g[(int)old + d] - st.ent_g[old];
+  if (a < 16) w.c0 += (uint64_t)(int64_t)d << (4 * a);
+  else w.c1 += (uint64_t)(int64_t)d << (4 * (a - 16));
+}
+KJ_HD void segwin_open(SegWin &w, const SegTables &st, const uint8_t *s, int start) {
+  w.c0 = w.c1 = 0; w.score = 0;
+  for (int i = 0; i < kSegWindow; i++) segwin_add(w, st, KJ_SL(s, start + i), +1);
+}
+KJ_HD void segwin_shift(SegWin &w, const SegTables &st, const uint8_t *s, int start) {   // start -> start+1
+  segwin_add(w, st, KJ_SL(s, start), -1);
+  segwin_add(w, st, KJ_SL(s, start + kSegWindow), +1);
+}
+
+KJ_HD double kj_lnfact(const SegTables &st, int n) { return st.lnfact[(uint32_t)n < st.lnfact_n ? n : st.lnfact_n - 1]; }
+
+KJ_HD double seg_finish_prob(double ans1, double ans2, int total) {
+  const double totseq = ((double)total) * 2.9957322735539909;   // kLn20, blast_seg.c:2193
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __dsub_rn(__dadd_rn(ans1, ans2), totseq);
+#else
+  volatile double t = ans1 + ans2;
+  return t - totseq;
+#endif
+}
+
+// ln P0 from the histogram of counts (s_GetProb blast_seg.c:1944-1967, s_LnAss :1890-1933,
+// s_LnPerm :1864-1879).  hist[v] = number of letters occurring v times in the window.
+KJ_HD double seg_getprob_hist(const SegTables &st, const uint8_t *hist, int vmax, int total) {
+  double ans1 = st.lnfact[20];
+  int nz = 0;
+  for (int v = vmax; v >= 1; v--) {
+    const int n = hist[v];
+    if (n) { ans1 -= st.lnfact[n]; nz += n; }
+  }
+  if (nz > 0 && nz < 20) ans1 -= st.lnfact[20 - nz];
+  double ans2 = kj_lnfact(st, total);
+  for (int v = vmax; v >= 1; v--)
+    for (int n = hist[v]; n > 0; n--) ans2 -= kj_lnfact(st, v);
+  return seg_finish_prob(ans1, ans2, total);
+}
+// same from the composition itself (any window length): visits counts in descending order
+KJ_HD double seg_getprob_comp(const SegTables &st, const uint32_t *comp, int total) {
+  double ans1 = st.lnfact[20];
+  double ans2 = kj_lnfact(st, total);
+  int nz = 0;
+  uint32_t bound = 0xFFFFFFFFu;           // next distinct value strictly below bound
+  for (;;) {
+    uint32_t v = 0; int n = 0;
+    for (int a = 0; a < 20; a++) if (comp[a] < bound && comp[a] > v) v = comp[a];
+    if (v == 0) break;
+    for (int a = 0; a < 20; a++) if (comp[a] == v) n++;
+    ans1 -= st.lnfact[n]; nz += n;
+    for (int q = 0; q < n; q++) ans2 -= kj_lnfact(st, (int)v);
+    bound = v;
+  }
+  if (nz > 0 && nz < 20) ans1 -= st.lnfact[20 - nz];
+  return seg_finish_prob(ans1, ans2, total);
+}
+
+// s_Trim (blast_seg.c:1971-2015) on s[0..len): trimmed [lend, rend] relative to s
+KJ_HD void seg_trim(const SegTables &st, const uint8_t *s, int len, int &lend_out, int &rend_out) {
+  int lend = 0, rend = len - 1, minlen = 1;
+  if (len - kSegMaxTrim > minlen) minlen = len - kSegMaxTrim;
+  double minprob = 1.;
+  if (len <= kSegHist) {
+    uint8_t comp[20];
+    uint8_t hist[kSegHist + 1];
+    for (int l = len; l > minlen; l--) {
+      for (int a = 0; a < 20; a++) comp[a] = 0;
+      for (int v = 0; v <= l; v++) hist[v] = 0;
+      int vmax = 0;
+      for (int i = 0; i < l; i++) comp[KJ_SL(s, i)]++;
+      for (int a = 0; a < 20; a++) { hist[comp[a]]++; if (comp[a] > vmax) vmax = comp[a]; }
+      for (int i = 0;; i++) {
+        const double prob = seg_getprob_hist(st, hist, vmax, l);
+        if (prob < minprob) { minprob = prob; lend = i; rend = l + i - 1; }
+        if (i + 1 + l > len) break;
+        const uint32_t o = KJ_SL(s, i), n = KJ_SL(s, i + l);
+        hist[comp[o]]--; comp[o]--; hist[comp[o]]++;
+        hist[comp[n]]--; comp[n]++; hist[comp[n]]++;
+        if (comp[n] > vmax) vmax = comp[n];
+        while (vmax > 0 && hist[vmax] == 0) vmax--;
+      }
+    }
+  } else {
+    uint32_t comp[20];
+    for (int l = len; l > minlen; l--) {
+      for (int a = 0; a < 20; a++) comp[a] = 0;
+      for (int i = 0; i < l; i++) comp[KJ_SL(s, i)]++;
+      for (int i = 0;; i++) {
+        const double prob = seg_getprob_comp(st, comp, l);
+        if (prob < minprob) { minprob = prob; lend = i; rend = l + i - 1; }
+        if (i + 1 + l > len) break;
+        comp[KJ_SL(s, i)]--; comp[KJ_SL(s, i + l)]++;
+      }
+    }
+  }
+  lend_out = lend; rend_out = rend;
+}
+
+// One level of s_SegSeq (blast_seg.c:2027-2113) on s[0..len).  At the top level
+// (`top` set) a trigger window lying left of its trimmed segment starts a second scan of
+// the left remainder, of which only the LAST segment survives (:2093-2097: the head of
+// the nested list is linked in, its tail is dropped); the nested scan therefore never
+// needs to recurse itself.  Segments are appended in creation order.
+KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset, bool top,
+                   int32_t *beg, int32_t *end, int n, int cap, bool &overflow) {
+  if (len < kSegWindow) return n;
+  const int first = kSegDown, last = len - kSegUp;
+  int lowlim = first;
+  SegWin w{0, 0, 0};
+  int wi = -1000;                        // position the window w is centred at
+  for (int i = first; i <= last; i++) {
+    if (wi + 1 == i) segwin_shift(w, st, s, wi - first);
+    else if (wi != i) segwin_open(w, st, s, i - first);
+    wi = i;
+    if (w.score > st.ent_locut) continue;                 // H > locut: no trigger
+    // s_FindLow (:1810-1822): down from i to lowlim while H <= hicut
+    int loi = i;
+    {
+      SegWin b;
+      while (loi - 1 >= lowlim) {
+        segwin_open(b, st, s, loi - 1 - first);
+        if (b.score > st.ent_hicut) break;
+        loi--;
+      }
+    }
+    // s_FindHigh (:1833-1845): up from i to last while H <= hicut
+    int hii = i;
+    {
+      SegWin f = w;
+      while (hii + 1 <= last) {
+        segwin_shift(f, st, s, hii - first);
+        if (f.score > st.ent_hicut) break;
+        hii++;
+      }
+    }
+    const int rawleft = loi - kSegDown, rawright = hii + kSegUp - 1;
+    int tl, tr;
+    seg_trim(st, s + rawleft, rawright - rawleft + 1, tl, tr);
+    const int leftend = rawleft + tl, rightend = rawleft + tr;
+    if (top && i + kSegUp - 1 < leftend) {
+      int32_t tb[kSegMaxRegions], te[kSegMaxRegions];
+      bool ov = false;
+      const int k = seg_scan(st, s + rawleft, leftend - rawleft, offset + rawleft, false, tb, te, 0,
+                             kSegMaxRegions, ov);
+      if (ov) overflow = true;
+      if (k > 0) {
+        if (n < cap) { beg[n] = tb[k - 1]; end[n] = te[k - 1]; n++; } else overflow = true;
+      }
+    }
+    if (n < cap) { beg[n] = leftend + offset; end[n] = rightend + offset; n++; } else overflow = true;
+    i = hii < rightend + kSegDown ? hii : rightend + kSegDown;   // loop adds 1
+    lowlim = i + 1;
+  }
+  return n;
+}
+
+// SeqBufferSeg (blast_seg.c:2278-2332).  Writes the merged regions in ascending order.
+static KJ_HD_NOINLINE int seg_regions(const SegTables &st, const uint8_t *s, int len, int32_t *left,
+                                      int32_t *right, bool &overflow) {
+  int32_t b[kSegMaxRegions], e[kSegMaxRegions];
+  const int n = seg_scan(st, s, len, 0, true, b, e, 0, kSegMaxRegions, overflow);
+  if (n == 0) return 0;
+  // the reference's list is in reverse creation order; s_MergeSegs (:2122-2152, hilenmin 0)
+  // walks it from the head and merges a node with its successor while they overlap
+  int m = 0;
+  int32_t cb = b[n - 1], ce = e[n - 1];
+  for (int k = n - 2; k >= 0; k--) {
+    if (cb - e[k] - 1 < 0) {
+      if (ce < e[k]) ce = e[k];
+      if (cb > b[k]) cb = b[k];
+    } else {
+      left[m] = cb; right[m] = ce; m++;
+      cb = b[k]; ce = e[k];
+    }
+  }
+  left[m] = cb; right[m] = ce; m++;
+  // s_SegsToBlastSeqLoc (:2162-2171) reverses the list once more
+  for (int a = 0, z = m - 1; a < z; a++, z--) {
+    int32_t t = left[a]; left[a] = left[z]; left[z] = t;
+    t = right[a]; right[a] = right[z]; right[z] = t;
+  }
+  return m;
+}
+
+// ----------------------------------------------------------------------------
+// stage 1: six-frame translation + canonical fragment list of one read
+// (getAllFragmentsBits ConsumerThread.cpp:190-270; for MEM also the SEG split of
+//  getNextFragment :272-342 applied eagerly, which SURVEY.md §8a shows equivalent)
+// ----------------------------------------------------------------------------
+KJ_HD uint32_t diag_score(const ConstTables &t, const uint8_t *pep, uint32_t start, uint32_t len) {
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < len; i++) { const uint32_t a = t.idx_to_aa[pep[start + i]]; s += (uint32_t)t.b62[a][a]; }
+  return s;
+}
+
+// std::multimap<unsigned, Fragment*, std::greater>::emplace: behind every key >= f.key
+KJ_HD void frag_insert(Frag *list, uint32_t &n, uint32_t cap, const Frag &f) {
+  if (n >= cap) return;               // cannot happen: cap is a proven bound
+  uint32_t pos = n;
+  while (pos > 0 && list[pos - 1].key < f.key) { list[pos] = list[pos - 1]; pos--; }
+  list[pos] = f;
+  n++;
+}
+
+KJ_HD void emit_run(const ConstTables &t, const Params &p, const uint8_t *pep, Frag *list, uint32_t &n,
+                    uint32_t cap, uint32_t start, uint32_t len) {
+  if (len < p.m) return;
+  Frag f; f.start = start; f.len = len; f.flags = 0;
+  if (p.mode == 1) {
+    f.key = diag_score(t, pep, start, len);
+    if (f.key < p.min_score) return;
+  } else f.key = len;
+  frag_insert(list, n, cap, f);
+}
+
+// translate one mate into six frame strings at pep[base..] and emit its fragments
+KJ_HD void translate_mate(const ConstTables &t, const Params &p, const uint8_t *s, uint32_t len,
+                          uint8_t *pep, uint32_t base, Frag *list, uint32_t &n, uint32_t cap) {
+  const uint32_t fcap = len / 3 + 1;         // room of one frame string incl. closing stop
+  uint32_t run_start[3], run_len[3];
+  // forward strand, ConsumerThread.cpp:196-233
+  for (uint32_t f = 0; f < 3; f++) { run_start[f] = base + f * fcap; run_len[f] = 0; }
+  for (uint32_t count = 0; count + 2 < len; count++) {
+    const uint32_t f = count % 3, pos = base + f * fcap + count / 3;
+    const uint32_t aa = codon_fwd(t, s + count);
+    if (aa == 255u) {
+      pep[pos] = 0;
+      emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
+      run_start[f] = pos + 1; run_len[f] = 0;
+    } else { pep[pos] = t.aa_to_idx[aa]; run_len[f]++; }
+  }
+  for (uint32_t f = 0; f < 3; f++) {
+    emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
+    pep[run_start[f] + run_len[f]] = 0;
+  }
+  // reverse strand, :235-268: count runs len-3 .. 0, frame = count % 3, residues are appended
+  // in visiting order (the count = len-2 iteration of the reference only sees the string
+  // terminator on an empty frame and is a no-op)
+  const uint32_t rbase = base + 3 * fcap, top = len - 3;
+  uint32_t cmax[3];
+  for (uint32_t f = 0; f < 3; f++) {
+    run_start[f] = rbase + f * fcap; run_len[f] = 0;
+    cmax[f] = top - ((top + 3 - f) % 3);      // largest count <= top with count % 3 == f
+  }
+  for (int64_t cnt = (int64_t)top; cnt >= 0; cnt--) {
+    const uint32_t count = (uint32_t)cnt, f = count % 3;
+    const uint32_t pos = rbase + f * fcap + (cmax[f] - count) / 3;
+    const uint32_t aa = codon_rev(t, s + count);
+    if (aa == 255u) {
+      pep[pos] = 0;
+      emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
+      run_start[f] = pos + 1; run_len[f] = 0;
+    } else { pep[pos] = t.aa_to_idx[aa]; run_len[f]++; }
+  }
+  for (uint32_t f = 0; f < 3; f++) {
+    emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
+    pep[run_start[f] + run_len[f]] = 0;
+  }
+}
+
+// getNextFragment's SEG split (ConsumerThread.cpp:285-339) of ONE fragment: appends the
+// unmasked pieces (length > m strictly, :298,312; Greedy: score >= min_score) to out[].
+// Returns true if SEG found regions (the parent is then dropped by the caller).
+template <class Sink>
+KJ_HD bool seg_split(const ConstTables &t, const Params &p, const SegTables &st, const uint8_t *pep,
+                     const Frag &f, Sink &&sink, bool &overflow) {
+  if (f.len < (uint32_t)kSegWindow) return false;
+  int32_t left[kSegMaxRegions], right[kSegMaxRegions];
+  const int nreg = seg_regions(st, pep + f.start, (int)f.len, left, right, overflow);
+  if (nreg == 0) return false;
+  uint64_t start = 0;
+  for (int r = 0; r <= nreg; r++) {
+    // size_t arithmetic as in the reference (a region starting left of `start` wraps)
+    const uint64_t length = (r < nreg ? (uint64_t)(int64_t)left[r] : (uint64_t)f.len) - start;
+    if (length > p.m) {
+      const uint64_t avail = start <= f.len ? f.len - start : 0;
+      const uint32_t take = (uint32_t)(length < avail ? length : avail);   // std::string::substr clamps
+      Frag q; q.start = f.start + (uint32_t)start; q.len = take; q.flags = 1;
+      if (p.mode == 1) {
+        q.key = diag_score(t, pep, q.start, take);
+        if (q.key >= p.min_score) sink(q);
+      } else { q.key = (uint32_t)length; sink(q); }
+    }
+    if (r < nreg) start = (uint64_t)(int64_t)right[r] + 1;
+  }
+  return true;
+}
+
+struct FragAppend {
+  Frag *dst; uint32_t *n; uint32_t cap;
+  KJ_HD void operator()(const Frag &q) const { if (*n < cap) dst[(*n)++] = q; }
+};
+
+// the whole of stage 1 for read r
+KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegTables &st, const Batch &b,
+                           uint32_t r, uint32_t *err_flags) {
+  const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
+  const uint32_t len1 = (uint32_t)(o1 - o0), len2 = (uint32_t)(o2 - o1);
+  const uint32_t m3 = p.m * 3;
+  Frag *list = b.frags + frag_base(b.off, r, p.m);
+  const uint32_t cap = frag_cap(b.off, r, p.m);
+  uint8_t *pep = b.pep + pep_base(b.off, r);
+  uint32_t n = 0;
+  // length gate, ConsumerThread.cpp:647-654
+  const bool skip = b.paired ? (len1 < m3 && len2 < m3) : (len1 < m3);
+  if (!skip) {
+    if (len1 >= m3) translate_mate(t, p, b.seqs + o0, len1, pep, 0, list, n, cap);
+    if (b.paired && len2 >= m3) translate_mate(t, p, b.seqs + o1, len2, pep, 6 * (len1 / 3 + 1), list, n, cap);
+    if (p.seg && p.mode == 0 && n > 0) {
+      // eager SEG for MEM: pieces go behind the originals, parents are dropped, then the
+      // pieces are re-inserted behind all equal keys in parent order, left to right
+      const uint32_t n_orig = n;
+      uint32_t np = 0;
+      bool overflow = false;
+      for (uint32_t k = 0; k < n_orig; k++) {
+        const Frag f = list[k];
+        uint32_t cnt = n_orig + np;
+        if (seg_split(t, p, st, pep, f, FragAppend{list, &cnt, cap}, overflow)) list[k].flags |= 2u;
+        np = cnt - n_orig;
+      }
+      if (np > 0 || overflow) {
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < n_orig; k++) if (!(list[k].flags & 2u)) list[w++] = list[k];
+        // at least one parent was dropped whenever np > 0, so w <= n_orig - 1 and the
+        // insertion below never overwrites a piece that has not been read yet
+        for (uint32_t q = 0; q < np; q++) { const Frag pc = list[n_orig + q]; frag_insert(list, w, cap, pc); }
+        n = w;
+      }
+      if (overflow && err_flags) *err_flags |= 1u;
+    }
+  }
+  b.nfrag[r] = n;
+}
+
+// ----------------------------------------------------------------------------
+// per-lane peptide window (LDS on the device): 64 residues of the current fragment
+// ----------------------------------------------------------------------------
+struct LaneWin {
+  uint8_t *w;                // kWin bytes
+  int32_t q;                 // fragment position of w[0]
+};
+KJ_HD void win_fill(LaneWin &lw, const uint8_t *fs, int flen, int top) {
+  int q = top - (kWin - 1);
+  if (q < 0) q = 0;
+  lw.q = q;
+  int n = flen - q;
+  if (n > kWin) n = kWin;
+  for (int t = 0; t < n; t++) lw.w[t] = fs[q + t];
+}
+KJ_HD uint32_t win_get(LaneWin &lw, const uint8_t *fs, int flen, int pos) {
+  if (pos < lw.q || pos >= lw.q + kWin) win_fill(lw, fs, flen, pos);
+  return lw.w[pos - lw.q];
+}
+
+// ----------------------------------------------------------------------------
+// work distribution
+// ----------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+KJ_HD uint32_t fetch_work(uint32_t *counter) { return atomicAdd(counter, 1u); }
+KJ_HD uint32_t append_slot(uint32_t *counter) { return atomicAdd(counter, 1u); }
+#else
+KJ_HD uint32_t fetch_work(uint32_t *counter) { return (*counter)++; }
+KJ_HD uint32_t append_slot(uint32_t *counter) { return (*counter)++; }
+#endif
+
+struct LaneScratch {
+  SIEntry *si;               // this lane's match buffer
+  uint32_t si_cap;
+  uint8_t *win;              // this lane's peptide window (kWin bytes)
+};
+
+struct WorkList {
+  uint32_t *counter;         // next work item
+  const uint32_t *reads;     // nullptr: item i is read i; else read ids (retry pass)
+  const uint32_t *n_items_ptr; // number of items lives in device memory for the retry pass
+  uint32_t n_items;          // used when n_items_ptr == nullptr
+  uint32_t *retry_list;      // reads whose match buffer overflowed are appended here (or nullptr)
+  uint32_t *retry_count;
+};
+
+// ----------------------------------------------------------------------------
+// the locate half shared by MEM and Greedy (ids_from_SI ConsumerThread.cpp:799-845,
+// get_suffix bwt.c:105-121): one LF step per memory step
+// ----------------------------------------------------------------------------
+KJ_HD bool sa_lookup(const DevIndex &ix, uint64_t k, uint32_t &iseq) {
+  const uint64_t idx = (k >> ix.chpt_exp) - ix.sa_skip;
+  if (idx >= ix.n_sa) return false;      // the reference reads out of bounds here
+  iseq = ix.sa_iseq[idx];
+  return true;
+}
+KJ_HD void add_id(const DevIndex &ix, Hit *hit, uint32_t &nids, uint32_t iseq) {
+  if (iseq >= ix.nseq || !ix.seq_valid[iseq]) return;
+  const uint64_t id = ix.seq_taxid[iseq];
+  for (uint32_t q = 0; q < nids; q++) if (hit->taxid[q] == id) return;
+  if (nids < (uint32_t)kMaxIds) hit->taxid[nids++] = id;
+}
+
+// ----------------------------------------------------------------------------
+// MEM lane: classify_length (ConsumerThread.cpp:543-628) + greedyExact (bwt.c:347-380)
+// ----------------------------------------------------------------------------
+enum MemState : int {
+  MS_FETCH, MS_NEXT_FRAG, MS_START_J, MS_END_MATCH, MS_LOC_INIT, MS_LOC_NEXT_GROUP,
+  MS_LOC_NEXT_SI, MS_LOC_ROW, MS_LF_CHECK, MS_ADD_ID, MS_LOC_DONE,
+  MS_STEP, MS_LF, MS_EXIT
+};
+
+KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
+                    const LaneScratch &ls) {
+  int st = MS_FETCH;
+  uint32_t r = 0, nf = 0, f = 0, fcur = 0;
+  const Frag *F = nullptr;
+  const uint8_t *pep = nullptr, *fs = nullptr;
+  int flen = 0, j = 0, i = 0;
+  uint64_t lo = 0, hi = 0;
+  uint32_t L = p.m, nsi = 0;
+  bool found = false, ovf = false;
+  // locate state
+  uint32_t gs = 0, ge = 0, cur = 0, nids = 0, flags = 0, iseq = 0;
+  uint64_t row = 0, rowend = 0, k = 0;
+  Hit *hit = nullptr;
+  LaneWin lw{ls.win, 0};
+  const uint64_t check = (1ull << ix.chpt_exp) - 1;
+  const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
+
+  for (;;) {
+    // ---- transitions that need no index access ----
+    while (st < MS_STEP) {
+      switch (st) {
+        case MS_FETCH: {
+          const uint32_t item = fetch_work(wl.counter);
+          if (item >= n_items) { st = MS_EXIT; break; }
+          r = wl.reads ? wl.reads[item] : item;
+          nf = b.nfrag[r];
+          F = b.frags + frag_base(b.off, r, p.m);
+          pep = b.pep + pep_base(b.off, r);
+          f = 0; L = p.m; nsi = 0; found = false; ovf = false;
+          st = MS_NEXT_FRAG;
+          break;
+        }
+        case MS_NEXT_FRAG: {
+          // getNextFragment(longest): stop when the best remaining key < longest (:550, :279)
+          if (f >= nf) { st = MS_LOC_INIT; break; }
+          const Frag d = F[f];
+          if (found && d.key < L) { st = MS_LOC_INIT; break; }
+          fcur = f; f++;
+          fs = pep + d.start; flen = (int)d.len;
+          j = flen - 1;
+          win_fill(lw, fs, flen, j);
+          st = MS_START_J;
+          break;
+        }
+        case MS_START_J: {
+          // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356)
+          if (j < (int)L - 1) { st = MS_NEXT_FRAG; break; }
+          const uint32_t c = win_get(lw, fs, flen, j);
+          lo = ix.C[c]; hi = ix.C[c + 1];          // InitialSI, bwt.c:146-152
+          i = j;
+          st = i > 0 ? MS_STEP : MS_END_MATCH;
+          break;
+        }
+        case MS_END_MATCH: {
+          const uint32_t l = (uint32_t)(j - i + 1);
+          if (l >= L) {
+            if (l > L) { nsi = 0; ovf = false; L = l; }    // shorter matches are dropped (bwt.c:366-370, :577-582)
+            if (nsi < ls.si_cap) {
+              SIEntry e; e.lo = lo; e.len = (uint32_t)(int32_t)(hi - lo); e.frag = fcur;
+              ls.si[nsi] = e;
+            } else ovf = true;
+            nsi++;
+            found = true;
+          }
+          if (i <= 1) st = MS_NEXT_FRAG;                   // bwt.c:376
+          else { j--; st = MS_START_J; }
+          break;
+        }
+        case MS_LOC_INIT: {
+          hit = b.hits + r;
+          nids = 0; flags = 0;
+          hit->best = found ? L : 0u;
+          hit->reserved = 0;
+          if (!found) { st = MS_LOC_DONE; break; }
+          if (ovf) {
+            if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+            else flags = kHitInternalOverflow;
+            st = MS_LOC_DONE; break;
+          }
+          ge = 0;
+          st = MS_LOC_NEXT_GROUP;
+          break;
+        }
+        case MS_LOC_NEXT_GROUP: {
+          // matches of one fragment were found for descending j but are visited for ascending j
+          // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845)
+          gs = ge;
+          if (gs >= nsi) { st = MS_LOC_DONE; break; }
+          const uint32_t fr = ls.si[gs].frag;
+          ge = gs + 1;
+          while (ge < nsi && ls.si[ge].frag == fr) ge++;
+          cur = ge;
+          st = MS_LOC_NEXT_SI;
+          break;
+        }
+        case MS_LOC_NEXT_SI: {
+          if (cur == gs) { st = MS_LOC_NEXT_GROUP; break; }
+          cur--;
+          row = ls.si[cur].lo; rowend = row + (uint64_t)(int64_t)(int32_t)ls.si[cur].len;
+          st = MS_LOC_ROW;
+          break;
+        }
+        case MS_LOC_ROW: {
+          if ((int64_t)row >= (int64_t)rowend) { st = MS_LOC_NEXT_SI; break; }
+          if (nids > p.max_match_ids) { flags |= kHitIdCap; st = MS_LOC_DONE; break; }   // :805-807
+          k = row;
+          st = MS_LF_CHECK;
+          break;
+        }
+        case MS_LF_CHECK: {
+          if ((k & check) == 0) {
+            if (sa_lookup(ix, k, iseq)) st = MS_ADD_ID; else { row++; st = MS_LOC_ROW; }
+          } else st = MS_LF;
+          break;
+        }
+        case MS_ADD_ID: {
+          add_id(ix, hit, nids, iseq);
+          row++;
+          st = MS_LOC_ROW;
+          break;
+        }
+        case MS_LOC_DONE: {
+          hit->n_ids = nids; hit->flags = flags;
+          st = MS_FETCH;
+          break;
+        }
+      }
+    }
+    if (st == MS_EXIT) break;
+    // ---- one dependent index access ----
+    if (st == MS_STEP) {
+      // UpdateSI(str[i-1]) (bwt.c:160-173)
+      const uint32_t c = win_get(lw, fs, flen, i - 1);
+      const uint64_t nlo = rank_c(ix, c, lo), nhi = rank_c(ix, c, hi);
+      if (nlo >= nhi) st = MS_END_MATCH;
+      else { lo = nlo; hi = nhi; i--; if (i == 0) st = MS_END_MATCH; }
+    } else {
+      // one LF step of get_suffix (bwt.c:109-112): FMindexCurrent
+      const uint32_t c = symbol_at(ix, k);
+      if (c == 0) { iseq = (uint32_t)rank_term(ix, k); st = MS_ADD_ID; }
+      else { k = rank_c(ix, c, k); st = MS_LF_CHECK; }
+    }
+  }
+}
+
+
+// ----------------------------------------------------------------------------
+// Greedy lane: classify_greedyblosum (ConsumerThread.cpp:424-541), maxMatches /
+// maxMatches_withStart (bwt.c:261-336), addAllMismatchVariantsAtPosSI (:346-395),
+// eval_match_scores (:751-797)
+// ----------------------------------------------------------------------------
+constexpr int kMaxMismatch = 8;
+
+struct GItem {               // one queue entry: a fragment or a substitution variant (64 bytes)
+  uint64_t si0, si1;         // resume interval (variants)
+  uint32_t key, start, len;  // start: peptide offset of the underlying fragment
+  int32_t diff;
+  uint32_t matchlen;
+  uint8_t num_mm, segchecked;
+  uint16_t pad;
+  uint16_t sub_pos[kMaxMismatch];
+  uint8_t sub_aa[kMaxMismatch];   // index-alphabet codes
+};
+static_assert(sizeof(GItem) == 64, "GItem is 64 bytes");
+
+struct GMatch {              // one SI of the current fragment (bwt.h:25-34)
+  uint64_t lo;
+  uint32_t len;
+  int32_t qi, ql;
+  uint32_t ord;              // quirk-walk order (index of the t-th visited match)
+};
+
+struct GBest { uint64_t lo; uint32_t len; uint32_t pad; };
+
+struct GreedyScratch {
+  GItem *pool;  uint32_t pool_cap;       // append-only item pool of the current read
+  uint16_t *ord;                         // queue order: indices into pool, [pool_cap]
+  GMatch *matches; uint32_t match_cap;
+  uint32_t *prefix; uint32_t prefix_cap; // prefix sums of the BLOSUM62 diagonal over the fragment
+  GBest *best;                           // [64]
+  uint8_t *win;
+};
+
+struct GQueue { uint32_t head, tail, npool; bool overflow; };
+
+// multimap emplace: behind every entry whose key is >= key
+KJ_HD void gq_push(const GreedyScratch &gs, GQueue &q, const GItem &it) {
+  if (q.npool >= gs.pool_cap || q.tail >= gs.pool_cap) { q.overflow = true; return; }
+  const uint32_t id = q.npool++;
+  gs.pool[id] = it;
+  uint32_t pos = q.tail;
+  while (pos > q.head && gs.pool[gs.ord[pos - 1]].key < it.key) { gs.ord[pos] = gs.ord[pos - 1]; pos--; }
+  gs.ord[pos] = (uint16_t)id;
+  q.tail++;
+}
+
+KJ_HD GItem gitem_from_frag(const Frag &f, uint8_t segchecked) {
+  GItem it; it.si0 = it.si1 = 0; it.key = f.key; it.start = f.start; it.len = f.len; it.diff = 0;
+  it.matchlen = 0; it.num_mm = 0; it.segchecked = segchecked; it.pad = 0;
+  for (int x = 0; x < kMaxMismatch; x++) { it.sub_pos[x] = 0; it.sub_aa[x] = 0; }
+  return it;
+}
+struct GSink {               // SEG pieces enter the queue as checked fragments (:302,316)
+  const GreedyScratch *gs; GQueue *q;
+  KJ_HD void operator()(const Frag &f) const { gq_push(*gs, *q, gitem_from_frag(f, 1)); }
+};
+
+// residue `pos` of the (possibly substituted) fragment of item t
+KJ_HD void gwin_fill(LaneWin &lw, const uint8_t *pep, const GItem &t, int top) {
+  win_fill(lw, pep + t.start, (int)t.len, top);
+  for (uint32_t x = 0; x < t.num_mm; x++) {
+    const int pz = (int)t.sub_pos[x];
+    if (pz >= lw.q && pz < lw.q + kWin && pz < (int)t.len) lw.w[pz - lw.q] = t.sub_aa[x];
+  }
+}
+KJ_HD uint32_t gwin_get(LaneWin &lw, const uint8_t *pep, const GItem &t, int pos) {
+  if (pos < lw.q || pos >= lw.q + kWin) gwin_fill(lw, pep, t, pos);
+  return lw.w[pos - lw.q];
+}
+
+enum GState : int {
+  GS_FETCH, GS_POP, GS_START_J, GS_END_MATCH, GS_AFTER_SEARCH, GS_VAR_NEXT_MATCH, GS_VAR_NEXT_SUB,
+  GS_EVAL, GS_FINISH, GS_LOC_NEXT_SI, GS_LOC_ROW, GS_LF_CHECK, GS_ADD_ID, GS_LOC_DONE,
+  GS_STEP, GS_VSTEP, GS_LF, GS_EXIT
+};
+
+KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegTables &st,
+                       const Batch &b, const WorkList &wl, const GreedyScratch &gs) {
+  int state = GS_FETCH;
+  uint32_t r = 0;
+  const uint8_t *pep = nullptr;
+  GQueue q{0, 0, 0, false};
+  GItem t;                                   // the fragment being searched
+  for (int x = 0; x < kMaxMismatch; x++) { t.sub_pos[x] = 0; t.sub_aa[x] = 0; }
+  t.si0 = t.si1 = 0; t.key = t.start = t.len = 0; t.diff = 0; t.matchlen = 0; t.num_mm = 0; t.segchecked = 0; t.pad = 0;
+  int flen = 0, j = 0, i = 0;
+  uint64_t lo = 0, hi = 0;
+  uint32_t nm = 0;                           // matches of the current fragment
+  int last_qi = 0;
+  bool m_ovf = false, seg_ovf = false;
+  uint32_t best = 0, nbest = 0, flags = 0;
+  // variant generation
+  uint32_t vw = 0, vmatch = 0, vsub = 0, vorig = 0, vscore = 0, vlen = 0, norder = 0;
+  // locate
+  uint32_t cur = 0, nids = 0, iseq = 0;
+  uint64_t row = 0, rowend = 0, k = 0;
+  Hit *hit = nullptr;
+  LaneWin lw{gs.win, 0};
+  const uint64_t check = (1ull << ix.chpt_exp) - 1;
+  const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
+
+  for (;;) {
+    while (state < GS_STEP) {
+      switch (state) {
+        case GS_FETCH: {
+          const uint32_t item = fetch_work(wl.counter);
+          if (item >= n_items) { state = GS_EXIT; break; }
+          r = wl.reads ? wl.reads[item] : item;
+          pep = b.pep + pep_base(b.off, r);
+          const Frag *F = b.frags + frag_base(b.off, r, p.m);
+          const uint32_t nf = b.nfrag[r];
+          q.head = q.tail = q.npool = 0; q.overflow = false;
+          for (uint32_t f = 0; f < nf; f++)            // already in queue order
+            gq_push(gs, q, gitem_from_frag(F[f], (uint8_t)(F[f].flags & 1u)));
+          best = 0; nbest = 0; flags = 0; m_ovf = false; seg_ovf = false;
+          state = GS_POP;
+          break;
+        }
+        case GS_POP: {
+          // getNextFragment(best_match_score), ConsumerThread.cpp:272-342
+          if (q.head == q.tail || gs.pool[gs.ord[q.head]].key < best) { state = GS_FINISH; break; }
+          t = gs.pool[gs.ord[q.head]];
+          q.head++;
+          if (p.seg && !t.segchecked) {
+            Frag f; f.start = t.start; f.len = t.len; f.key = t.key; f.flags = 0;
+            if (seg_split(ct, p, st, pep, f, GSink{&gs, &q}, seg_ovf)) break;   // parent dropped, pop again
+          }
+          flen = (int)t.len;
+          nm = 0;
+          if (t.num_mm == 0) {
+            // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
+            j = flen - 1;
+            gwin_fill(lw, pep, t, j);
+            state = GS_START_J;
+          } else {
+            // maxMatches_withStart, bwt.c:298-336
+            j = flen - 1;
+            i = j - (int)t.matchlen + 1;
+            lo = t.si0; hi = t.si1;
+            gwin_fill(lw, pep, t, i > 0 ? i - 1 : 0);
+            state = i > 0 ? GS_STEP : GS_END_MATCH;
+          }
+          break;
+        }
+        case GS_START_J: {
+          if (j < (int)p.seed_length - 1) { state = GS_AFTER_SEARCH; break; }
+          const uint32_t c = gwin_get(lw, pep, t, j);
+          lo = ix.C[c]; hi = ix.C[c + 1];
+          i = j;
+          state = i > 0 ? GS_STEP : GS_END_MATCH;
+          break;
+        }
+        case GS_END_MATCH: {
+          const int l = j - i + 1;
+          if (t.num_mm == 0) {
+            if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {      // bwt.c:276-278
+              if (nm < gs.match_cap) {
+                GMatch mm; mm.lo = lo; mm.len = (uint32_t)(int32_t)(hi - lo); mm.qi = i; mm.ql = l; mm.ord = 0;
+                gs.matches[nm] = mm;
+              } else m_ovf = true;
+              nm++;
+              last_qi = i;
+            }
+            if (i <= 1) state = GS_AFTER_SEARCH;                            // bwt.c:292
+            else { j--; state = GS_START_J; }
+          } else {
+            // :443-449: after the last allowed mismatch the match must reach min_fragment_length
+            const int Lreq = (t.num_mm == p.mismatches) ? (int)p.m : (int)t.matchlen;
+            if (l >= Lreq) {
+              GMatch mm; mm.lo = lo; mm.len = (uint32_t)(int32_t)(hi - lo); mm.qi = i; mm.ql = l; mm.ord = 0;
+              if (gs.match_cap > 0) gs.matches[0] = mm; else m_ovf = true;
+              nm = 1;
+            }
+            state = GS_AFTER_SEARCH;
+          }
+          break;
+        }
+        case GS_AFTER_SEARCH: {
+          if (nm == 0 || m_ovf) { state = GS_POP; break; }   // (overflow: the read is redone in the retry pass)
+          // prefix sums of the diagonal scores of t.seq (for calcScore, :397-421)
+          if ((uint32_t)flen + 1 > gs.prefix_cap) { m_ovf = true; state = GS_POP; break; }
+          {
+            uint32_t acc = 0;
+            gs.prefix[0] = 0;
+            for (int x = 0; x < flen; x++) {
+              const uint32_t a = ct.idx_to_aa[gwin_get(lw, pep, t, x)];
+              acc += (uint32_t)ct.b62[a][a];
+              gs.prefix[x + 1] = acc;
+            }
+          }
+          // order in which `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the
+          // sorted list built by insert_SI_sorted (bwt.c:225-252): heads of the length classes in
+          // descending length until a class with a samelen chain is met; that chain (latest
+          // insertion first) is walked and ends the traversal
+          norder = 0;
+          if (p.mismatches > 0 && t.num_mm < p.mismatches) {
+            int v = -1;
+            for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql > v) v = gs.matches[x].ql;
+            for (;;) {
+              uint32_t head = nm, cnt = 0;
+              for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql == v) { if (head == nm) head = x; cnt++; }
+              gs.matches[norder++].ord = head;
+              if (cnt >= 2) {
+                for (uint32_t x = nm; x-- > head + 1;) if (gs.matches[x].ql == v) gs.matches[norder++].ord = x;
+                break;
+              }
+              int nv = -1;
+              for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql < v && gs.matches[x].ql > nv) nv = gs.matches[x].ql;
+              if (nv < 0) break;
+              v = nv;
+            }
+          }
+          vw = 0;
+          state = GS_VAR_NEXT_MATCH;
+          break;
+        }
+        case GS_VAR_NEXT_MATCH: {
+          if (vw >= norder) { state = GS_EVAL; break; }
+          vmatch = gs.matches[vw++].ord;
+          const GMatch it = gs.matches[vmatch];
+          const uint32_t mre = (uint32_t)(it.qi + it.ql - 1);
+          if (!(it.qi > 0 && mre + 1 >= p.m)) break;                       // :469
+          // addAllMismatchVariantsAtPosSI(t, qi-1, erase_pos, it), :346-395
+          vlen = (mre < (uint32_t)flen - 1) ? mre + 1 : (uint32_t)flen;     // fragment.erase(erase_pos)
+          vorig = ct.idx_to_aa[gwin_get(lw, pep, t, it.qi - 1)];
+          {
+            int sc = (int)gs.prefix[vlen] + t.diff;                         // calcScore(fragment, f->diff)
+            const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
+            vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];          // unsigned wrap as in :363
+          }
+          vsub = 0;
+          state = GS_VAR_NEXT_SUB;
+          break;
+        }
+        case GS_VAR_NEXT_SUB: {
+          if (vsub >= 19) { state = GS_VAR_NEXT_MATCH; break; }
+          const uint32_t s = ct.subst[vorig][vsub];
+          const int32_t after = (int32_t)(vscore + (uint32_t)(int32_t)ct.b62[vorig][s]);
+          if (after >= (int32_t)best && after >= (int32_t)p.min_score) state = GS_VSTEP;
+          else state = GS_VAR_NEXT_MATCH;                                   // break at the first too-low score
+          break;
+        }
+        case GS_EVAL: {
+          // eval_match_scores(si, t), :751-797.  Head of the list = longest match.
+          int v1 = -1;
+          for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql > v1) v1 = gs.matches[x].ql;
+          if (v1 < (int)p.m) { state = GS_POP; break; }                     // :482
+          // recursion order: the samelen chains of the classes (descending length, while >= m) in
+          // insertion order, then the class heads in ascending length
+          int v = v1, vlast = v1;
+          for (int pass = 0; pass < 2; pass++) {
+            v = pass == 0 ? v1 : vlast;
+            for (;;) {
+              uint32_t head = nm;
+              for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql == v) { head = x; break; }
+              for (uint32_t x = (pass == 0 ? head + 1 : head); x < (pass == 0 ? nm : head + 1); x++) {
+                if (gs.matches[x].ql != v) continue;
+                const GMatch mm = gs.matches[x];
+                int sc = (int)(gs.prefix[mm.qi + mm.ql] - gs.prefix[mm.qi]) + t.diff;
+                const uint32_t score = sc > 0 ? (uint32_t)sc : 0u;
+                if (score < p.min_score) continue;
+                if (score > best) { best = score; nbest = 0; }
+                if (score == best) {
+                  if (nbest < p.max_matches_SI && nbest < 64) { GBest gb; gb.lo = mm.lo; gb.len = mm.len; gb.pad = 0; gs.best[nbest++] = gb; }
+                  else flags |= kHitSiCap;
+                }
+              }
+              if (pass == 0) {
+                int nv = -1;
+                for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql < v && gs.matches[x].ql > nv) nv = gs.matches[x].ql;
+                if (nv < 0 || nv < (int)p.m) { vlast = v; break; }
+                v = nv;
+              } else {
+                if (v == v1) break;
+                int nv = 0x7fffffff;
+                for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql > v && gs.matches[x].ql < nv) nv = gs.matches[x].ql;
+                v = nv;
+              }
+            }
+          }
+          state = GS_POP;
+          break;
+        }
+        case GS_FINISH: {
+          hit = b.hits + r;
+          nids = 0;
+          hit->reserved = 0;
+          if (q.overflow || m_ovf) {
+            hit->best = 0;
+            if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+            else flags = kHitInternalOverflow;
+            state = GS_LOC_DONE; break;
+          }
+          hit->best = nbest ? best : 0u;
+          cur = 0;
+          state = GS_LOC_NEXT_SI;
+          break;
+        }
+        case GS_LOC_NEXT_SI: {
+          if (cur >= nbest) { state = GS_LOC_DONE; break; }
+          row = gs.best[cur].lo; rowend = row + (uint64_t)(int64_t)(int32_t)gs.best[cur].len;
+          cur++;
+          state = GS_LOC_ROW;
+          break;
+        }
+        case GS_LOC_ROW: {
+          if ((int64_t)row >= (int64_t)rowend) { state = GS_LOC_NEXT_SI; break; }
+          if (nids > p.max_match_ids) { flags |= kHitIdCap; state = GS_LOC_DONE; break; }
+          k = row;
+          state = GS_LF_CHECK;
+          break;
+        }
+        case GS_LF_CHECK: {
+          if ((k & check) == 0) {
+            if (sa_lookup(ix, k, iseq)) state = GS_ADD_ID; else { row++; state = GS_LOC_ROW; }
+          } else state = GS_LF;
+          break;
+        }
+        case GS_ADD_ID: {
+          add_id(ix, hit, nids, iseq);
+          row++;
+          state = GS_LOC_ROW;
+          break;
+        }
+        case GS_LOC_DONE: {
+          hit->n_ids = nids; hit->flags = flags;
+          state = GS_FETCH;
+          break;
+        }
+      }
+    }
+    if (state == GS_EXIT) break;
+    if (state == GS_STEP) {
+      const uint32_t c = gwin_get(lw, pep, t, i - 1);
+      const uint64_t nlo = rank_c(ix, c, lo), nhi = rank_c(ix, c, hi);
+      if (nlo >= nhi) state = GS_END_MATCH;
+      else { lo = nlo; hi = nhi; i--; if (i == 0) state = GS_END_MATCH; }
+    } else if (state == GS_VSTEP) {
+      // UpdateSI(trans[substitute]) on the match's interval (:372)
+      const GMatch it = gs.matches[vmatch];
+      const uint32_t s = ct.subst[vorig][vsub];
+      const uint32_t c = ct.aa_to_idx[s];
+      const uint64_t nlo = rank_c(ix, c, it.lo), nhi = rank_c(ix, c, it.lo + (uint64_t)(int64_t)(int32_t)it.len);
+      if (nlo < nhi) {
+        GItem nf = t;
+        nf.len = vlen;
+        nf.key = (uint32_t)(int32_t)(vscore + (uint32_t)(int32_t)ct.b62[vorig][s]);
+        nf.diff = t.diff + (int)ct.b62[vorig][s] - (int)ct.b62[s][s];
+        nf.si0 = nlo; nf.si1 = nhi;
+        nf.matchlen = (uint32_t)it.ql + 1;
+        nf.segchecked = 1;
+        if (t.num_mm < kMaxMismatch) { nf.sub_pos[t.num_mm] = (uint16_t)(it.qi - 1); nf.sub_aa[t.num_mm] = (uint8_t)c; }
+        nf.num_mm = (uint8_t)(t.num_mm + 1);
+        gq_push(gs, q, nf);
+      }
+      vsub++;
+      state = GS_VAR_NEXT_SUB;
+    } else {
+      const uint32_t c = symbol_at(ix, k);
+      if (c == 0) { iseq = (uint32_t)rank_term(ix, k); state = GS_ADD_ID; }
+      else { k = rank_c(ix, c, k); state = GS_LF_CHECK; }
+    }
+  }
+}
+
+}  // namespace kj

@@ -1,0 +1,150 @@
+// kernel_emu.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the per-lane kernel logic of kaiju_amd/csrc/kj_core.h with g++ and runs it as a
+// single sequential "lane", so that `pytest -m "not gpu"` can check the kernel logic (packed
+// index, fragment construction, SEG, MEM and Greedy state machines) against the oracle on a
+// machine without a GPU.  This library is built and loaded by tests only; the product
+// library (libkaiju_gpu.so) contains no CPU path and fails loudly without a HIP device.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kaiju_gpu.h"
+#include "../../kaiju_amd/csrc/host_index.h"
+#include "../../kaiju_amd/csrc/host_tables.h"
+#include "../../kaiju_amd/csrc/kj_core.h"
+
+using namespace kj;
+
+struct EmuIndex {
+  FmiFile file;
+  PackedIndex packed;
+  ConstTables ct;
+  SegTables st;
+  std::vector<double> lnfact;
+};
+
+extern "C" {
+
+void *emu_index_load(const char *path, char *err, int errlen) {
+  EmuIndex *ix = new EmuIndex();
+  std::string msg;
+  int rc = ix->file.load(path, msg);
+  if (rc == 0) rc = ix->packed.build(ix->file.view(), msg);
+  if (rc == 0) rc = build_const_tables(ix->packed.trans, ix->ct, msg);
+  if (rc == 0) rc = build_seg_tables(ix->lnfact, ix->st, msg);
+  if (rc != 0) { snprintf(err, (size_t)errlen, "%s", msg.c_str()); delete ix; return nullptr; }
+  return ix;
+}
+void emu_index_free(void *h) { delete (EmuIndex *)h; }
+uint32_t emu_index_warnings(void *h) { return ((EmuIndex *)h)->packed.warnings; }
+
+// rank primitives on the packed layout
+uint64_t emu_rank(void *h, uint32_t c, uint64_t k) {
+  EmuIndex *ix = (EmuIndex *)h;
+  DevIndex d = ix->packed.host_view();
+  if (c == 0) return rank_term(d, k);
+  return rank_c(d, c, k);
+}
+uint32_t emu_symbol(void *h, uint64_t k) { DevIndex d = ((EmuIndex *)h)->packed.host_view(); return symbol_at(d, k); }
+
+// SEG on an ASCII peptide (letters of the 20 amino acids)
+int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
+  EmuIndex *ix = (EmuIndex *)h;
+  std::vector<uint8_t> codes((size_t)len + 1);
+  for (int i = 0; i < len; i++) codes[(size_t)i] = ix->packed.trans[(unsigned char)aa[i] & 127];
+  bool ov = false;
+  int n = seg_regions(ix->st, codes.data(), len, left, right, ov);
+  return ov ? -1 : n;
+}
+
+// fragments of one batch (stage 1): returns per-read lists as ASCII for comparison
+// out_text receives "key:PEPTIDE\n" lines per read, reads separated by "\n"
+int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const uint64_t *off, uint32_t n,
+                 int paired, kaiju_gpu_hit *out, uint32_t si_cap, uint32_t pool_cap, uint32_t match_cap,
+                 uint32_t *n_retry_out, char *frag_dump, uint64_t frag_dump_cap) {
+  EmuIndex *ix = (EmuIndex *)h;
+  DevIndex d = ix->packed.host_view();
+  Params p;
+  p.mode = gp->mode; p.m = gp->min_fragment_length; p.mismatches = gp->mismatches; p.min_score = gp->min_score;
+  p.seed_length = gp->seed_length; p.seg = gp->seg; p.max_matches_SI = gp->max_matches_SI; p.max_match_ids = gp->max_match_ids;
+  if (p.mismatches > (uint32_t)kMaxMismatch) return KAIJU_GPU_ERR_UNSUPPORTED;
+  Batch b;
+  b.seqs = (const uint8_t *)seqs; b.off = off; b.n_reads = n; b.paired = paired;
+  std::vector<uint8_t> pep((size_t)pep_base(off, n) + 64, 0);
+  std::vector<Frag> frags((size_t)frag_base(off, n, p.m) + 8);
+  std::vector<uint32_t> nfrag(n);
+  std::vector<Hit> hits(n);
+  b.pep = pep.data(); b.frags = frags.data(); b.nfrag = nfrag.data(); b.hits = hits.data();
+  uint32_t err = 0;
+  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, ix->st, b, r, &err);
+  if (frag_dump) {
+    const char *alpha = ix->packed.alphabet.c_str();
+    uint64_t w = 0;
+    for (uint32_t r = 0; r < n; r++) {
+      const Frag *F = frags.data() + frag_base(off, r, p.m);
+      const uint8_t *pp = pep.data() + pep_base(off, r);
+      for (uint32_t f = 0; f < nfrag[r]; f++) {
+        char tmp[32];
+        int l = snprintf(tmp, sizeof tmp, "%u:", F[f].key);
+        if (w + (uint64_t)l + F[f].len + 2 >= frag_dump_cap) return KAIJU_GPU_ERR_NOMEM;
+        memcpy(frag_dump + w, tmp, (size_t)l); w += (uint64_t)l;
+        for (uint32_t x = 0; x < F[f].len; x++) frag_dump[w++] = alpha[pp[F[f].start + x]];
+        frag_dump[w++] = '\n';
+      }
+      if (w + 2 >= frag_dump_cap) return KAIJU_GPU_ERR_NOMEM;
+      frag_dump[w++] = '\n';
+    }
+    frag_dump[w] = 0;
+  }
+  // first pass with the given scratch sizes, overflowing reads go to the retry list
+  std::vector<uint32_t> retry(n);
+  uint32_t counter = 0, retry_count = 0;
+  uint8_t win[kWin];
+  std::vector<SIEntry> si(si_cap);
+  std::vector<GItem> pool(pool_cap);
+  std::vector<uint16_t> ord(pool_cap);
+  std::vector<GMatch> matches(match_cap);
+  uint32_t maxlen = 0;
+  for (uint32_t r = 0; r < n; r++) {
+    uint32_t l1 = (uint32_t)(off[2 * r + 1] - off[2 * r]), l2 = (uint32_t)(off[2 * r + 2] - off[2 * r + 1]);
+    if (l1 > maxlen) maxlen = l1;
+    if (l2 > maxlen) maxlen = l2;
+  }
+  std::vector<uint32_t> prefix(maxlen / 3 + 4);
+  std::vector<GBest> bestv(64);
+  for (int pass = 0; pass < 2; pass++) {
+    WorkList wl;
+    wl.counter = &counter;
+    uint32_t nitems = pass == 0 ? n : retry_count;
+    wl.n_items = nitems; wl.n_items_ptr = nullptr;
+    wl.reads = pass == 0 ? nullptr : retry.data();
+    wl.retry_list = pass == 0 ? retry.data() : nullptr;
+    wl.retry_count = &retry_count;
+    counter = 0;
+    if (pass == 1) {
+      if (n_retry_out) *n_retry_out = retry_count;
+      if (retry_count == 0) break;
+      // retry with scratch sized for the worst case
+      si.assign(2 * (size_t)maxlen + 64, SIEntry{});
+      pool.assign(65535, GItem{}); ord.assign(65535, 0);
+      matches.assign((size_t)maxlen + 8, GMatch{});
+    }
+    if (p.mode == 0) {
+      LaneScratch ls{si.data(), (uint32_t)si.size(), win};
+      mem_lane(d, p, b, wl, ls);
+    } else {
+      GreedyScratch gs;
+      gs.pool = pool.data(); gs.pool_cap = (uint32_t)pool.size(); gs.ord = ord.data();
+      gs.matches = matches.data(); gs.match_cap = (uint32_t)matches.size();
+      gs.prefix = prefix.data(); gs.prefix_cap = (uint32_t)prefix.size(); gs.best = bestv.data(); gs.win = win;
+      greedy_lane(d, ix->ct, p, ix->st, b, wl, gs);
+    }
+  }
+  static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");
+  memcpy(out, hits.data(), sizeof(Hit) * n);
+  return err ? -100 : 0;
+}
+
+}  // extern "C"
