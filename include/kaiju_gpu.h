@@ -120,8 +120,12 @@ typedef struct {
 
 /* work / timing of the last batch of a context */
 typedef struct {
-  uint64_t n_reads, n_fragments, n_overflow_retries;
-  double ms_translate, ms_seg, ms_search, ms_total;   /* HIP-event times on the ctx stream */
+  uint64_t n_reads;
+  uint64_t n_seg_fragments;      /* fragments that went through the SEG pass              */
+  uint64_t n_overflow_retries;   /* reads redone in the retry pass (scratch overflow)     */
+  uint64_t error_flags;          /* 0 unless a device-side capacity bound was violated    */
+  /* HIP-event times on the stream of the last batch */
+  double ms_translate, ms_seg, ms_search, ms_retry, ms_total;
 } kaiju_gpu_stats;
 
 int kaiju_gpu_abi_version(void);

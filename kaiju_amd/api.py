@@ -36,9 +36,10 @@ class IndexInfo(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("n_reads", C.c_uint64), ("n_fragments", C.c_uint64), ("n_overflow_retries", C.c_uint64),
+    _fields_ = [("n_reads", C.c_uint64), ("n_seg_fragments", C.c_uint64), ("n_overflow_retries", C.c_uint64),
+                ("error_flags", C.c_uint64),
                 ("ms_translate", C.c_double), ("ms_seg", C.c_double), ("ms_search", C.c_double),
-                ("ms_total", C.c_double)]
+                ("ms_retry", C.c_double), ("ms_total", C.c_double)]
 
 
 HIT_DTYPE = np.dtype([("best", "<u4"), ("n_ids", "<u4"), ("flags", "<u4"), ("reserved", "<u4"),

@@ -33,19 +33,40 @@ using namespace kj;
 // ----------------------------------------------------------------------------------------
 constexpr int kBlock = 256;
 
-__global__ void __launch_bounds__(kBlock)
-k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, uint32_t *err) {
-  __shared__ ConstTables s_ct;
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
-    for (uint32_t i = threadIdx.x; i < sizeof(ConstTables) / 4; i += kBlock) dst[i] = src[i];
-  }
+__device__ __forceinline__ void load_tables(ConstTables &s_ct, const ConstTables *g_ct) {
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
+  for (uint32_t i = threadIdx.x; i < sizeof(ConstTables) / 4; i += kBlock) dst[i] = src[i];
   __syncthreads();
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err) {
+  __shared__ ConstTables s_ct;
+  load_tables(s_ct, g_ct);
   const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
   if (r >= b.n_reads) return;
   uint32_t e = 0;
-  build_fragments(s_ct, p, st, b, r, &e);
+  build_fragments(s_ct, p, st, b, sq, r, &e);
+  if (e) atomicOr(err, e);
+}
+
+// SEG pass: one lane per fragment that stage 1 flagged (count lives in device memory)
+__global__ void __launch_bounds__(kBlock)
+k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
+  const uint32_t n = min(*sq.count, sq.cap);
+  for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) seg_compute(st, b, p, sq, s);
+}
+
+// MEM: apply the SEG records to the fragment lists
+__global__ void __launch_bounds__(kBlock)
+k_seg_apply(const ConstTables *__restrict__ g_ct, Params p, Batch b, SegQueue sq, uint32_t *err) {
+  __shared__ ConstTables s_ct;
+  load_tables(s_ct, g_ct);
+  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= b.n_reads) return;
+  uint32_t e = 0;
+  seg_apply_mem(s_ct, p, b, sq, r, &e);
   if (e) atomicOr(err, e);
 }
 
@@ -61,30 +82,24 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
 }
 
 struct GreedyArrays {
-  GItem *pool; uint16_t *ord; GMatch *matches; uint32_t *prefix; GBest *best;
-  uint32_t pool_cap, match_cap, prefix_cap;
+  GItem *pool; uint16_t *ord; GMatch *matches; GBest *best;
+  uint32_t pool_cap, match_cap;
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, WorkList wl,
+k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl,
          GreedyArrays ga) {
   __shared__ uint8_t s_win[kBlock * kWinStride];
   __shared__ ConstTables s_ct;
-  {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
-    for (uint32_t i = threadIdx.x; i < sizeof(ConstTables) / 4; i += kBlock) dst[i] = src[i];
-  }
-  __syncthreads();
+  load_tables(s_ct, g_ct);
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   GreedyScratch gs;
   gs.pool = ga.pool + lane * ga.pool_cap; gs.pool_cap = ga.pool_cap;
   gs.ord = ga.ord + lane * ga.pool_cap;
   gs.matches = ga.matches + lane * ga.match_cap; gs.match_cap = ga.match_cap;
-  gs.prefix = ga.prefix + lane * ga.prefix_cap; gs.prefix_cap = ga.prefix_cap;
   gs.best = ga.best + lane * 64;
   gs.win = s_win + threadIdx.x * kWinStride;
-  greedy_lane(ix, s_ct, p, st, b, wl, gs);
+  greedy_lane(ix, s_ct, p, sq, b, wl, gs);
 }
 
 static_assert(sizeof(ConstTables) % 4 == 0, "ConstTables is copied as dwords");
@@ -244,10 +259,10 @@ struct kaiju_gpu_ctx {
   kaiju_gpu_params params{};
   Params kp{};
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
   int n_cu = 0, blocks_main = 0, blocks_retry = 0;
-  DevBuf pep, frags, nfrag, counters, retry_list;
+  DevBuf pep, frags, nfrag, counters, retry_list, seg_items, seg_recs;
   DevBuf scratch_main[5], scratch_retry[5];
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
   kaiju_gpu_stats stats{};
@@ -255,7 +270,7 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &nfrag, &counters, &retry_list, &h_seqs, &h_off, &h_hits};
+    DevBuf *all[] = {&pep, &frags, &nfrag, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 5; i++) { if (scratch_main[i].p) (void)hipFree(scratch_main[i].p); if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p); }
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -345,13 +360,30 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   b.pep = static_cast<uint8_t *>(c->pep.p); b.frags = static_cast<Frag *>(c->frags.p);
   b.nfrag = static_cast<uint32_t *>(c->nfrag.p); b.hits = reinterpret_cast<Hit *>(d_out);
   uint32_t *cnt = static_cast<uint32_t *>(c->counters.p);
+  // SEG work list: at most one entry per original fragment
+  const uint64_t seg_cap = p.seg ? std::min<uint64_t>(n_frag_slots / 2 + 8, 0x00ffffffull) : 1;
+  if ((rc = ensure(c->seg_items, seg_cap * sizeof(SegWork)))) return rc;
+  if ((rc = ensure(c->seg_recs, seg_cap * sizeof(SegRec)))) return rc;
+  SegQueue sq;
+  sq.items = static_cast<SegWork *>(c->seg_items.p); sq.recs = static_cast<SegRec *>(c->seg_recs.p);
+  sq.count = cnt + 4; sq.cap = (uint32_t)seg_cap;
   KJ_HIP(hipMemsetAsync(cnt, 0, 64, s));
   KJ_HIP(hipEventRecord(c->ev[0], s));
+  const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
   if (n > 0) {
-    hipLaunchKernelGGL(k_fragments, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ix->d_ct, p, ix->st, b, cnt + 3);
+    hipLaunchKernelGGL(k_fragments, grid_reads, blk, 0, s, ix->d_ct, p, ix->st, b, sq, cnt + 3);
     KJ_HIP(hipGetLastError());
   }
   KJ_HIP(hipEventRecord(c->ev[1], s));
+  if (n > 0 && p.seg) {
+    hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 4), blk, 0, s, p, ix->st, b, sq);
+    KJ_HIP(hipGetLastError());
+    if (p.mode == 0) {
+      hipLaunchKernelGGL(k_seg_apply, grid_reads, blk, 0, s, ix->d_ct, p, b, sq, cnt + 3);
+      KJ_HIP(hipGetLastError());
+    }
+  }
+  KJ_HIP(hipEventRecord(c->ev[2], s));
   WorkList wl_main;
   wl_main.counter = cnt + 0; wl_main.reads = nullptr; wl_main.n_items_ptr = nullptr; wl_main.n_items = n;
   wl_main.retry_list = static_cast<uint32_t *>(c->retry_list.p); wl_main.retry_count = cnt + 2;
@@ -368,44 +400,44 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     while (blocks_retry > 1 && (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry) > (1ull << 30)) blocks_retry /= 2;
     if ((rc = ensure(c->scratch_retry[0], (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry)))) return rc;
     if (n > 0) {
-      hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), dim3(kBlock), 0, s, ix->dev, p, b, wl_main,
+      hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                          static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       KJ_HIP(hipGetLastError());
-      hipLaunchKernelGGL(k_mem, dim3(blocks_retry), dim3(kBlock), 0, s, ix->dev, p, b, wl_retry,
+      KJ_HIP(hipEventRecord(c->ev[3], s));
+      hipLaunchKernelGGL(k_mem, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry);
       KJ_HIP(hipGetLastError());
-    }
+    } else KJ_HIP(hipEventRecord(c->ev[3], s));
   } else {
     const uint32_t frag_max = max_read_len / 3 + 4;
     GreedyArrays ga;
-    ga.pool_cap = 192; ga.match_cap = 64; ga.prefix_cap = frag_max + 1;
+    ga.pool_cap = 192; ga.match_cap = 64;
     if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
     if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
     if ((rc = ensure(c->scratch_main[2], lanes_main * ga.match_cap * sizeof(GMatch)))) return rc;
-    if ((rc = ensure(c->scratch_main[3], lanes_main * ga.prefix_cap * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c->scratch_main[4], lanes_main * 64 * sizeof(GBest)))) return rc;
     ga.pool = static_cast<GItem *>(c->scratch_main[0].p); ga.ord = static_cast<uint16_t *>(c->scratch_main[1].p);
-    ga.matches = static_cast<GMatch *>(c->scratch_main[2].p); ga.prefix = static_cast<uint32_t *>(c->scratch_main[3].p);
+    ga.matches = static_cast<GMatch *>(c->scratch_main[2].p);
     ga.best = static_cast<GBest *>(c->scratch_main[4].p);
     GreedyArrays gr;
-    gr.pool_cap = 65535; gr.match_cap = frag_max + 8; gr.prefix_cap = frag_max + 1;
+    gr.pool_cap = 65535; gr.match_cap = frag_max + 8;
     const uint64_t lanes_retry = (uint64_t)c->blocks_retry * kBlock;
     if ((rc = ensure(c->scratch_retry[0], lanes_retry * gr.pool_cap * sizeof(GItem)))) return rc;
     if ((rc = ensure(c->scratch_retry[1], lanes_retry * gr.pool_cap * sizeof(uint16_t)))) return rc;
     if ((rc = ensure(c->scratch_retry[2], lanes_retry * gr.match_cap * sizeof(GMatch)))) return rc;
-    if ((rc = ensure(c->scratch_retry[3], lanes_retry * gr.prefix_cap * sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c->scratch_retry[4], lanes_retry * 64 * sizeof(GBest)))) return rc;
     gr.pool = static_cast<GItem *>(c->scratch_retry[0].p); gr.ord = static_cast<uint16_t *>(c->scratch_retry[1].p);
-    gr.matches = static_cast<GMatch *>(c->scratch_retry[2].p); gr.prefix = static_cast<uint32_t *>(c->scratch_retry[3].p);
+    gr.matches = static_cast<GMatch *>(c->scratch_retry[2].p);
     gr.best = static_cast<GBest *>(c->scratch_retry[4].p);
     if (n > 0) {
-      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), dim3(kBlock), 0, s, ix->dev, ix->d_ct, p, ix->st, b, wl_main, ga);
+      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga);
       KJ_HIP(hipGetLastError());
-      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_retry), dim3(kBlock), 0, s, ix->dev, ix->d_ct, p, ix->st, b, wl_retry, gr);
+      KJ_HIP(hipEventRecord(c->ev[3], s));
+      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr);
       KJ_HIP(hipGetLastError());
-    }
+    } else KJ_HIP(hipEventRecord(c->ev[3], s));
   }
-  KJ_HIP(hipEventRecord(c->ev[2], s));
+  KJ_HIP(hipEventRecord(c->ev[4], s));
   c->ev_valid = true;
   c->last_n = n;
   return KAIJU_GPU_OK;
@@ -464,16 +496,22 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
   memset(stats, 0, sizeof *stats);
   if (!ctx->ev_valid) return KAIJU_GPU_OK;
   KJ_HIP(hipSetDevice(ctx->ix->device));
-  KJ_HIP(hipEventSynchronize(ctx->ev[2]));
-  float t01 = 0, t12 = 0;
+  KJ_HIP(hipEventSynchronize(ctx->ev[4]));
+  float t01 = 0, t12 = 0, t23 = 0, t34 = 0;
   KJ_HIP(hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
   KJ_HIP(hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
-  uint32_t cnt[4] = {0, 0, 0, 0};
+  KJ_HIP(hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
+  KJ_HIP(hipEventElapsedTime(&t34, ctx->ev[3], ctx->ev[4]));
+  uint32_t cnt[8] = {0};
   KJ_HIP(hipMemcpy(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
   stats->n_reads = ctx->last_n;
   stats->n_overflow_retries = cnt[2];
+  stats->n_seg_fragments = cnt[4];
+  stats->error_flags = cnt[3];
   stats->ms_translate = t01;
-  stats->ms_search = t12;
-  stats->ms_total = t01 + t12;
+  stats->ms_seg = t12;
+  stats->ms_search = t23;
+  stats->ms_retry = t34;
+  stats->ms_total = t01 + t12 + t23 + t34;
   return KAIJU_GPU_OK;
 }

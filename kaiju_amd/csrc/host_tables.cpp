@@ -69,6 +69,7 @@ int build_const_tables(const uint8_t trans[128], ConstTables &t, std::string &ms
     seen[c] = true;
     t.aa_to_idx[a] = c;
     t.idx_to_aa[c] = (uint8_t)a;
+    t.diag_idx[c] = kB62[a][a];
   }
   return 0;
 }

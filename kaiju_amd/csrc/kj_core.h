@@ -82,6 +82,25 @@ struct Frag {
   uint32_t flags;            // bit0: SEG-checked, bit1: removed (transient)
 };
 
+// SEG runs as its own pass over the fragments whose 12-windows reach the trigger entropy
+// (stage 1 only detects them); one record per such fragment:
+struct SegWork { uint32_t read, frag; };
+constexpr int kSegRecRegions = 15;
+struct SegRec {              // 64 bytes
+  uint16_t n;                // number of low-complexity regions (ascending, merged)
+  uint16_t overflow;
+  uint16_t lr[kSegRecRegions][2];
+};
+static_assert(sizeof(SegRec) == 64, "SegRec is 64 bytes");
+struct SegQueue {
+  SegWork *items;
+  SegRec *recs;
+  uint32_t *count;
+  uint32_t cap;
+};
+constexpr uint32_t kFragChecked = 1u, kFragRemoved = 2u, kFragSlotShift = 8;
+constexpr uint32_t kNfragSegPending = 0x80000000u;   // nfrag[r] bit: read has fragments awaiting SEG
+
 struct SIEntry {             // one maximal match (16 bytes)
   uint64_t lo;
   uint32_t len;              // interval length (int truncation as alloc_SI, bwt.c:180)
@@ -109,6 +128,7 @@ struct ConstTables {
   uint8_t nuc[256];          // nuc2int (255 = not ACGTU)
   uint8_t aa_to_idx[20];     // aa2int code -> index-alphabet code (astruct->trans)
   uint8_t idx_to_aa[32];     // index-alphabet code -> aa2int code
+  int8_t diag_idx[32];       // BLOSUM62 diagonal by index-alphabet code (blosum62diag, :61-80)
 };
 
 struct Batch {
@@ -317,7 +337,8 @@ KJ_HD void seg_trim(const SegTables &st, const uint8_t *s, int len, int &lend_ou
 // the left remainder, of which only the LAST segment survives (:2093-2097: the head of
 // the nested list is linked in, its tail is dropped); the nested scan therefore never
 // needs to recurse itself.  Segments are appended in creation order.
-KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset, bool top,
+template <bool TOP>
+KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset,
                    int32_t *beg, int32_t *end, int n, int cap, bool &overflow) {
   if (len < kSegWindow) return n;
   const int first = kSegDown, last = len - kSegUp;
@@ -353,17 +374,23 @@ KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset, b
     int tl, tr;
     seg_trim(st, s + rawleft, rawright - rawleft + 1, tl, tr);
     const int leftend = rawleft + tl, rightend = rawleft + tr;
-    if (top && i + kSegUp - 1 < leftend) {
-      int32_t tb[kSegMaxRegions], te[kSegMaxRegions];
-      bool ov = false;
-      const int k = seg_scan(st, s + rawleft, leftend - rawleft, offset + rawleft, false, tb, te, 0,
-                             kSegMaxRegions, ov);
-      if (ov) overflow = true;
-      if (k > 0) {
-        if (n < cap) { beg[n] = tb[k - 1]; end[n] = te[k - 1]; n++; } else overflow = true;
+    if constexpr (TOP) {
+      if (i + kSegUp - 1 < leftend) {
+        // nested scan (a different instantiation: no recursion on the device); it keeps only
+        // its most recent segment, which is all that survives in the reference
+        int32_t tb[1], te[1];
+        bool ov = false;
+        const int k = seg_scan<false>(st, s + rawleft, leftend - rawleft, offset + rawleft, tb, te, 0, 1, ov);
+        if (k > 0) {
+          if (n < cap) { beg[n] = tb[0]; end[n] = te[0]; n++; } else overflow = true;
+        }
       }
     }
-    if (n < cap) { beg[n] = leftend + offset; end[n] = rightend + offset; n++; } else overflow = true;
+    if constexpr (TOP) {
+      if (n < cap) { beg[n] = leftend + offset; end[n] = rightend + offset; n++; } else overflow = true;
+    } else {
+      beg[0] = leftend + offset; end[0] = rightend + offset; n = 1;   // only the last one is kept
+    }
     i = hii < rightend + kSegDown ? hii : rightend + kSegDown;   // loop adds 1
     lowlim = i + 1;
   }
@@ -374,7 +401,7 @@ KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset, b
 static KJ_HD_NOINLINE int seg_regions(const SegTables &st, const uint8_t *s, int len, int32_t *left,
                                       int32_t *right, bool &overflow) {
   int32_t b[kSegMaxRegions], e[kSegMaxRegions];
-  const int n = seg_scan(st, s, len, 0, true, b, e, 0, kSegMaxRegions, overflow);
+  const int n = seg_scan<true>(st, s, len, 0, b, e, 0, kSegMaxRegions, overflow);
   if (n == 0) return 0;
   // the reference's list is in reverse creation order; s_MergeSegs (:2122-2152, hilenmin 0)
   // walks it from the head and merges a node with its successor while they overlap
@@ -397,6 +424,17 @@ static KJ_HD_NOINLINE int seg_regions(const SegTables &st, const uint8_t *s, int
   }
   return m;
 }
+
+// ----------------------------------------------------------------------------
+// work distribution
+// ----------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+KJ_HD uint32_t fetch_work(uint32_t *counter) { return atomicAdd(counter, 1u); }
+KJ_HD uint32_t append_slot(uint32_t *counter) { return atomicAdd(counter, 1u); }
+#else
+KJ_HD uint32_t fetch_work(uint32_t *counter) { return (*counter)++; }
+KJ_HD uint32_t append_slot(uint32_t *counter) { return (*counter)++; }
+#endif
 
 // ----------------------------------------------------------------------------
 // stage 1: six-frame translation + canonical fragment list of one read
@@ -474,32 +512,59 @@ KJ_HD void translate_mate(const ConstTables &t, const Params &p, const uint8_t *
   }
 }
 
-// getNextFragment's SEG split (ConsumerThread.cpp:285-339) of ONE fragment: appends the
-// unmasked pieces (length > m strictly, :298,312; Greedy: score >= min_score) to out[].
-// Returns true if SEG found regions (the parent is then dropped by the caller).
-template <class Sink>
-KJ_HD bool seg_split(const ConstTables &t, const Params &p, const SegTables &st, const uint8_t *pep,
-                     const Frag &f, Sink &&sink, bool &overflow) {
-  if (f.len < (uint32_t)kSegWindow) return false;
+// does any 12-window of the fragment reach the trigger entropy (H <= locut)?  Exactly then
+// SeqBufferSeg reports at least one region (s_SegSeq, blast_seg.c:2061).
+KJ_HD bool seg_triggers(const SegTables &st, const uint8_t *s, int len) {
+  if (len < kSegWindow) return false;
+  SegWin w{0, 0, 0};
+  segwin_open(w, st, s, 0);
+  if (w.score <= st.ent_locut) return true;
+  for (int start = 0; start + kSegWindow < len; start++) {
+    segwin_shift(w, st, s, start);
+    if (w.score <= st.ent_locut) return true;
+  }
+  return false;
+}
+
+// the SEG pass proper: regions of one flagged fragment -> record
+KJ_HD void seg_compute(const SegTables &st, const Batch &b, const Params &p, const SegQueue &sq, uint32_t slot) {
+  const SegWork wk = sq.items[slot];
+  const Frag f = b.frags[frag_base(b.off, wk.read, p.m) + wk.frag];
+  const uint8_t *pep = b.pep + pep_base(b.off, wk.read);
   int32_t left[kSegMaxRegions], right[kSegMaxRegions];
-  const int nreg = seg_regions(st, pep + f.start, (int)f.len, left, right, overflow);
-  if (nreg == 0) return false;
+  bool ov = false;
+  const int n = seg_regions(st, pep + f.start, (int)f.len, left, right, ov);
+  SegRec rec;
+  rec.overflow = (ov || n > kSegRecRegions || f.len > 65535u) ? 1 : 0;
+  rec.n = (uint16_t)(n > kSegRecRegions ? kSegRecRegions : n);
+  for (int k = 0; k < kSegRecRegions; k++) {
+    rec.lr[k][0] = k < n ? (uint16_t)left[k] : 0;
+    rec.lr[k][1] = k < n ? (uint16_t)right[k] : 0;
+  }
+  sq.recs[slot] = rec;
+}
+
+// getNextFragment's SEG split (ConsumerThread.cpp:285-339) of ONE fragment given its regions:
+// hands the unmasked pieces (length > m strictly, :298,312; Greedy: score >= min_score) to sink.
+template <class Sink>
+KJ_HD void seg_split(const ConstTables &t, const Params &p, const SegRec &rec, const uint8_t *pep,
+                     const Frag &f, Sink &&sink) {
+  const int nreg = rec.n;
   uint64_t start = 0;
   for (int r = 0; r <= nreg; r++) {
     // size_t arithmetic as in the reference (a region starting left of `start` wraps)
-    const uint64_t length = (r < nreg ? (uint64_t)(int64_t)left[r] : (uint64_t)f.len) - start;
+    const uint64_t length = (r < nreg ? (uint64_t)rec.lr[r][0] : (uint64_t)f.len) - start;
     if (length > p.m) {
       const uint64_t avail = start <= f.len ? f.len - start : 0;
       const uint32_t take = (uint32_t)(length < avail ? length : avail);   // std::string::substr clamps
-      Frag q; q.start = f.start + (uint32_t)start; q.len = take; q.flags = 1;
+      Frag q; q.start = f.start + (uint32_t)start; q.len = take; q.flags = kFragChecked;
       if (p.mode == 1) {
         q.key = diag_score(t, pep, q.start, take);
         if (q.key >= p.min_score) sink(q);
       } else { q.key = (uint32_t)length; sink(q); }
     }
-    if (r < nreg) start = (uint64_t)(int64_t)right[r] + 1;
+    if (r < nreg) start = (uint64_t)rec.lr[r][1] + 1;
   }
-  return true;
 }
 
 struct FragAppend {
@@ -507,45 +572,67 @@ struct FragAppend {
   KJ_HD void operator()(const Frag &q) const { if (*n < cap) dst[(*n)++] = q; }
 };
 
-// the whole of stage 1 for read r
+// stage 1 for read r: translation, fragment list in queue order, SEG trigger detection
 KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegTables &st, const Batch &b,
-                           uint32_t r, uint32_t *err_flags) {
+                           const SegQueue &sq, uint32_t r, uint32_t *err_flags) {
   const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
   const uint32_t len1 = (uint32_t)(o1 - o0), len2 = (uint32_t)(o2 - o1);
   const uint32_t m3 = p.m * 3;
   Frag *list = b.frags + frag_base(b.off, r, p.m);
   const uint32_t cap = frag_cap(b.off, r, p.m);
   uint8_t *pep = b.pep + pep_base(b.off, r);
-  uint32_t n = 0;
+  uint32_t n = 0, pending = 0;
   // length gate, ConsumerThread.cpp:647-654
   const bool skip = b.paired ? (len1 < m3 && len2 < m3) : (len1 < m3);
   if (!skip) {
     if (len1 >= m3) translate_mate(t, p, b.seqs + o0, len1, pep, 0, list, n, cap);
     if (b.paired && len2 >= m3) translate_mate(t, p, b.seqs + o1, len2, pep, 6 * (len1 / 3 + 1), list, n, cap);
-    if (p.seg && p.mode == 0 && n > 0) {
-      // eager SEG for MEM: pieces go behind the originals, parents are dropped, then the
-      // pieces are re-inserted behind all equal keys in parent order, left to right
-      const uint32_t n_orig = n;
-      uint32_t np = 0;
-      bool overflow = false;
-      for (uint32_t k = 0; k < n_orig; k++) {
-        const Frag f = list[k];
-        uint32_t cnt = n_orig + np;
-        if (seg_split(t, p, st, pep, f, FragAppend{list, &cnt, cap}, overflow)) list[k].flags |= 2u;
-        np = cnt - n_orig;
+    if (p.seg) {
+      for (uint32_t k = 0; k < n; k++) {
+        if (seg_triggers(st, pep + list[k].start, (int)list[k].len)) {
+          const uint32_t slot = append_slot(sq.count);
+          if (slot < sq.cap) {
+            SegWork wk; wk.read = r; wk.frag = k;
+            sq.items[slot] = wk;
+            list[k].flags |= (slot + 1) << kFragSlotShift;
+            pending = kNfragSegPending;
+          } else { list[k].flags |= kFragChecked; if (err_flags) *err_flags |= 2u; }
+        } else list[k].flags |= kFragChecked;      // SEG would report nothing for this fragment
       }
-      if (np > 0 || overflow) {
-        uint32_t w = 0;
-        for (uint32_t k = 0; k < n_orig; k++) if (!(list[k].flags & 2u)) list[w++] = list[k];
-        // at least one parent was dropped whenever np > 0, so w <= n_orig - 1 and the
-        // insertion below never overwrites a piece that has not been read yet
-        for (uint32_t q = 0; q < np; q++) { const Frag pc = list[n_orig + q]; frag_insert(list, w, cap, pc); }
-        n = w;
-      }
-      if (overflow && err_flags) *err_flags |= 1u;
     }
   }
-  b.nfrag[r] = n;
+  b.nfrag[r] = n | pending;
+}
+
+// MEM only: apply the SEG results eagerly (equivalent to the lazy split): split
+// parents are dropped and their pieces re-inserted behind all equal keys, in parent order,
+// left to right
+KJ_HD void seg_apply_mem(const ConstTables &t, const Params &p, const Batch &b, const SegQueue &sq, uint32_t r,
+                         uint32_t *err_flags) {
+  const uint32_t raw = b.nfrag[r];
+  if (!(raw & kNfragSegPending)) return;
+  const uint32_t n_orig = raw & ~kNfragSegPending;
+  Frag *list = b.frags + frag_base(b.off, r, p.m);
+  const uint32_t cap = frag_cap(b.off, r, p.m);
+  const uint8_t *pep = b.pep + pep_base(b.off, r);
+  uint32_t np = 0;
+  for (uint32_t k = 0; k < n_orig; k++) {
+    const Frag f = list[k];
+    const uint32_t slot1 = f.flags >> kFragSlotShift;
+    if (!slot1) continue;
+    const SegRec rec = sq.recs[slot1 - 1];
+    if (rec.overflow && err_flags) *err_flags |= 1u;
+    uint32_t cnt = n_orig + np;
+    seg_split(t, p, rec, pep, f, FragAppend{list, &cnt, cap});
+    np = cnt - n_orig;
+    list[k].flags |= kFragRemoved;
+  }
+  uint32_t w = 0;
+  for (uint32_t k = 0; k < n_orig; k++) if (!(list[k].flags & kFragRemoved)) list[w++] = list[k];
+  // at least one parent was dropped, so w <= n_orig - 1 and the insertion below never
+  // overwrites a piece that has not been read yet
+  for (uint32_t q = 0; q < np; q++) { const Frag pc = list[n_orig + q]; frag_insert(list, w, cap, pc); }
+  b.nfrag[r] = w;
 }
 
 // ----------------------------------------------------------------------------
@@ -567,17 +654,6 @@ KJ_HD uint32_t win_get(LaneWin &lw, const uint8_t *fs, int flen, int pos) {
   if (pos < lw.q || pos >= lw.q + kWin) win_fill(lw, fs, flen, pos);
   return lw.w[pos - lw.q];
 }
-
-// ----------------------------------------------------------------------------
-// work distribution
-// ----------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-KJ_HD uint32_t fetch_work(uint32_t *counter) { return atomicAdd(counter, 1u); }
-KJ_HD uint32_t append_slot(uint32_t *counter) { return atomicAdd(counter, 1u); }
-#else
-KJ_HD uint32_t fetch_work(uint32_t *counter) { return (*counter)++; }
-KJ_HD uint32_t append_slot(uint32_t *counter) { return (*counter)++; }
-#endif
 
 struct LaneScratch {
   SIEntry *si;               // this lane's match buffer
@@ -646,7 +722,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
           const uint32_t item = fetch_work(wl.counter);
           if (item >= n_items) { st = MS_EXIT; break; }
           r = wl.reads ? wl.reads[item] : item;
-          nf = b.nfrag[r];
+          nf = b.nfrag[r] & ~kNfragSegPending;
           F = b.frags + frag_base(b.off, r, p.m);
           pep = b.pep + pep_base(b.off, r);
           f = 0; L = p.m; nsi = 0; found = false; ovf = false;
@@ -774,23 +850,28 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // ----------------------------------------------------------------------------
 constexpr int kMaxMismatch = 8;
 
-struct GItem {               // one queue entry: a fragment or a substitution variant (64 bytes)
+struct GItem {               // one queue entry: a fragment or a substitution variant (80 bytes)
   uint64_t si0, si1;         // resume interval (variants)
   uint32_t key, start, len;  // start: peptide offset of the underlying fragment
   int32_t diff;
-  uint32_t matchlen;
+  uint32_t matchlen;         // variants: residues already matched; unchecked originals: SEG slot + 1
+  uint32_t tot;              // sum of the BLOSUM62 diagonal over the whole sequence
+  uint32_t msum;             // ... over the already matched suffix (variants)
   uint8_t num_mm, segchecked;
   uint16_t pad;
   uint16_t sub_pos[kMaxMismatch];
   uint8_t sub_aa[kMaxMismatch];   // index-alphabet codes
+  uint32_t pad2[2];
 };
-static_assert(sizeof(GItem) == 64, "GItem is 64 bytes");
+static_assert(sizeof(GItem) == 80, "GItem is 80 bytes");
 
-struct GMatch {              // one SI of the current fragment (bwt.h:25-34)
+struct GMatch {              // one SI of the current fragment (bwt.h:25-34), 32 bytes
   uint64_t lo;
   uint32_t len;
   int32_t qi, ql;
   uint32_t ord;              // quirk-walk order (index of the t-th visited match)
+  uint32_t dsum;             // sum of the diagonal scores over the match
+  uint32_t psum;             // ... over the sequence from its start to the end of the match
 };
 
 struct GBest { uint64_t lo; uint32_t len; uint32_t pad; };
@@ -799,7 +880,6 @@ struct GreedyScratch {
   GItem *pool;  uint32_t pool_cap;       // append-only item pool of the current read
   uint16_t *ord;                         // queue order: indices into pool, [pool_cap]
   GMatch *matches; uint32_t match_cap;
-  uint32_t *prefix; uint32_t prefix_cap; // prefix sums of the BLOSUM62 diagonal over the fragment
   GBest *best;                           // [64]
   uint8_t *win;
 };
@@ -817,15 +897,16 @@ KJ_HD void gq_push(const GreedyScratch &gs, GQueue &q, const GItem &it) {
   q.tail++;
 }
 
-KJ_HD GItem gitem_from_frag(const Frag &f, uint8_t segchecked) {
+KJ_HD GItem gitem_from_frag(const Frag &f) {
   GItem it; it.si0 = it.si1 = 0; it.key = f.key; it.start = f.start; it.len = f.len; it.diff = 0;
-  it.matchlen = 0; it.num_mm = 0; it.segchecked = segchecked; it.pad = 0;
+  it.matchlen = f.flags >> kFragSlotShift; it.tot = f.key; it.msum = 0;
+  it.num_mm = 0; it.segchecked = (uint8_t)(f.flags & kFragChecked); it.pad = 0; it.pad2[0] = it.pad2[1] = 0;
   for (int x = 0; x < kMaxMismatch; x++) { it.sub_pos[x] = 0; it.sub_aa[x] = 0; }
   return it;
 }
 struct GSink {               // SEG pieces enter the queue as checked fragments (:302,316)
   const GreedyScratch *gs; GQueue *q;
-  KJ_HD void operator()(const Frag &f) const { gq_push(*gs, *q, gitem_from_frag(f, 1)); }
+  KJ_HD void operator()(const Frag &f) const { gq_push(*gs, *q, gitem_from_frag(f)); }
 };
 
 // residue `pos` of the (possibly substituted) fragment of item t
@@ -847,7 +928,7 @@ enum GState : int {
   GS_STEP, GS_VSTEP, GS_LF, GS_EXIT
 };
 
-KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegTables &st,
+KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                        const Batch &b, const WorkList &wl, const GreedyScratch &gs) {
   int state = GS_FETCH;
   uint32_t r = 0;
@@ -855,12 +936,14 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
   GQueue q{0, 0, 0, false};
   GItem t;                                   // the fragment being searched
   for (int x = 0; x < kMaxMismatch; x++) { t.sub_pos[x] = 0; t.sub_aa[x] = 0; }
-  t.si0 = t.si1 = 0; t.key = t.start = t.len = 0; t.diff = 0; t.matchlen = 0; t.num_mm = 0; t.segchecked = 0; t.pad = 0;
+  t.si0 = t.si1 = 0; t.key = t.start = t.len = 0; t.diff = 0; t.matchlen = 0; t.tot = t.msum = 0;
+  t.num_mm = 0; t.segchecked = 0; t.pad = 0; t.pad2[0] = t.pad2[1] = 0;
   int flen = 0, j = 0, i = 0;
   uint64_t lo = 0, hi = 0;
   uint32_t nm = 0;                           // matches of the current fragment
+  uint32_t acc = 0, tail = 0;                // running diagonal sums: over the match / right of j
   int last_qi = 0;
-  bool m_ovf = false, seg_ovf = false;
+  bool m_ovf = false;
   uint32_t best = 0, nbest = 0, flags = 0;
   // variant generation
   uint32_t vw = 0, vmatch = 0, vsub = 0, vorig = 0, vscore = 0, vlen = 0, norder = 0;
@@ -881,11 +964,10 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           r = wl.reads ? wl.reads[item] : item;
           pep = b.pep + pep_base(b.off, r);
           const Frag *F = b.frags + frag_base(b.off, r, p.m);
-          const uint32_t nf = b.nfrag[r];
+          const uint32_t nf = b.nfrag[r] & ~kNfragSegPending;
           q.head = q.tail = q.npool = 0; q.overflow = false;
-          for (uint32_t f = 0; f < nf; f++)            // already in queue order
-            gq_push(gs, q, gitem_from_frag(F[f], (uint8_t)(F[f].flags & 1u)));
-          best = 0; nbest = 0; flags = 0; m_ovf = false; seg_ovf = false;
+          for (uint32_t f = 0; f < nf; f++) gq_push(gs, q, gitem_from_frag(F[f]));   // already in queue order
+          best = 0; nbest = 0; flags = 0; m_ovf = false;
           state = GS_POP;
           break;
         }
@@ -895,14 +977,22 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           t = gs.pool[gs.ord[q.head]];
           q.head++;
           if (p.seg && !t.segchecked) {
+            // SEG found regions in this fragment (computed by the SEG pass): the parent is dropped,
+            // its unmasked pieces are queued, and the next fragment is popped (:291-334)
             Frag f; f.start = t.start; f.len = t.len; f.key = t.key; f.flags = 0;
-            if (seg_split(ct, p, st, pep, f, GSink{&gs, &q}, seg_ovf)) break;   // parent dropped, pop again
+            if (t.matchlen) {
+              const SegRec rec = sq.recs[t.matchlen - 1];
+              if (rec.overflow) flags |= kHitInternalOverflow;
+              seg_split(ct, p, rec, pep, f, GSink{&gs, &q});
+            }
+            break;
           }
           flen = (int)t.len;
           nm = 0;
           if (t.num_mm == 0) {
             // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
             j = flen - 1;
+            tail = 0;
             gwin_fill(lw, pep, t, j);
             state = GS_START_J;
           } else {
@@ -910,6 +1000,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
             j = flen - 1;
             i = j - (int)t.matchlen + 1;
             lo = t.si0; hi = t.si1;
+            acc = t.msum;
             gwin_fill(lw, pep, t, i > 0 ? i - 1 : 0);
             state = i > 0 ? GS_STEP : GS_END_MATCH;
           }
@@ -919,6 +1010,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           if (j < (int)p.seed_length - 1) { state = GS_AFTER_SEARCH; break; }
           const uint32_t c = gwin_get(lw, pep, t, j);
           lo = ix.C[c]; hi = ix.C[c + 1];
+          acc = (uint32_t)ct.diag_idx[c];
           i = j;
           state = i > 0 ? GS_STEP : GS_END_MATCH;
           break;
@@ -929,18 +1021,24 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
             if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {      // bwt.c:276-278
               if (nm < gs.match_cap) {
                 GMatch mm; mm.lo = lo; mm.len = (uint32_t)(int32_t)(hi - lo); mm.qi = i; mm.ql = l; mm.ord = 0;
+                mm.dsum = acc; mm.psum = t.tot - tail;
                 gs.matches[nm] = mm;
               } else m_ovf = true;
               nm++;
               last_qi = i;
             }
             if (i <= 1) state = GS_AFTER_SEARCH;                            // bwt.c:292
-            else { j--; state = GS_START_J; }
+            else {
+              tail += (uint32_t)ct.diag_idx[gwin_get(lw, pep, t, j)];
+              j--;
+              state = GS_START_J;
+            }
           } else {
             // :443-449: after the last allowed mismatch the match must reach min_fragment_length
             const int Lreq = (t.num_mm == p.mismatches) ? (int)p.m : (int)t.matchlen;
             if (l >= Lreq) {
               GMatch mm; mm.lo = lo; mm.len = (uint32_t)(int32_t)(hi - lo); mm.qi = i; mm.ql = l; mm.ord = 0;
+              mm.dsum = acc; mm.psum = t.tot;
               if (gs.match_cap > 0) gs.matches[0] = mm; else m_ovf = true;
               nm = 1;
             }
@@ -950,37 +1048,29 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
         }
         case GS_AFTER_SEARCH: {
           if (nm == 0 || m_ovf) { state = GS_POP; break; }   // (overflow: the read is redone in the retry pass)
-          // prefix sums of the diagonal scores of t.seq (for calcScore, :397-421)
-          if ((uint32_t)flen + 1 > gs.prefix_cap) { m_ovf = true; state = GS_POP; break; }
-          {
-            uint32_t acc = 0;
-            gs.prefix[0] = 0;
-            for (int x = 0; x < flen; x++) {
-              const uint32_t a = ct.idx_to_aa[gwin_get(lw, pep, t, x)];
-              acc += (uint32_t)ct.b62[a][a];
-              gs.prefix[x + 1] = acc;
-            }
-          }
           // order in which `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the
           // sorted list built by insert_SI_sorted (bwt.c:225-252): heads of the length classes in
           // descending length until a class with a samelen chain is met; that chain (latest
           // insertion first) is walked and ends the traversal
           norder = 0;
           if (p.mismatches > 0 && t.num_mm < p.mismatches) {
-            int v = -1;
-            for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql > v) v = gs.matches[x].ql;
-            for (;;) {
-              uint32_t head = nm, cnt = 0;
-              for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql == v) { if (head == nm) head = x; cnt++; }
-              gs.matches[norder++].ord = head;
-              if (cnt >= 2) {
-                for (uint32_t x = nm; x-- > head + 1;) if (gs.matches[x].ql == v) gs.matches[norder++].ord = x;
-                break;
+            if (nm == 1) { gs.matches[0].ord = 0; norder = 1; }
+            else {
+              int v = -1;
+              for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql > v) v = gs.matches[x].ql;
+              for (;;) {
+                uint32_t head = nm, cnt = 0;
+                for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql == v) { if (head == nm) head = x; cnt++; }
+                gs.matches[norder++].ord = head;
+                if (cnt >= 2) {
+                  for (uint32_t x = nm; x-- > head + 1;) if (gs.matches[x].ql == v) gs.matches[norder++].ord = x;
+                  break;
+                }
+                int nv = -1;
+                for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql < v && gs.matches[x].ql > nv) nv = gs.matches[x].ql;
+                if (nv < 0) break;
+                v = nv;
               }
-              int nv = -1;
-              for (uint32_t x = 0; x < nm; x++) if (gs.matches[x].ql < v && gs.matches[x].ql > nv) nv = gs.matches[x].ql;
-              if (nv < 0) break;
-              v = nv;
             }
           }
           vw = 0;
@@ -997,7 +1087,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           vlen = (mre < (uint32_t)flen - 1) ? mre + 1 : (uint32_t)flen;     // fragment.erase(erase_pos)
           vorig = ct.idx_to_aa[gwin_get(lw, pep, t, it.qi - 1)];
           {
-            int sc = (int)gs.prefix[vlen] + t.diff;                         // calcScore(fragment, f->diff)
+            const int sc = (int)it.psum + t.diff;                           // calcScore(fragment, f->diff)
             const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
             vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];          // unsigned wrap as in :363
           }
@@ -1029,7 +1119,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
               for (uint32_t x = (pass == 0 ? head + 1 : head); x < (pass == 0 ? nm : head + 1); x++) {
                 if (gs.matches[x].ql != v) continue;
                 const GMatch mm = gs.matches[x];
-                int sc = (int)(gs.prefix[mm.qi + mm.ql] - gs.prefix[mm.qi]) + t.diff;
+                const int sc = (int)mm.dsum + t.diff;                       // calcScore(seq, qi, ql, diff)
                 const uint32_t score = sc > 0 ? (uint32_t)sc : 0u;
                 if (score < p.min_score) continue;
                 if (score > best) { best = score; nbest = 0; }
@@ -1107,7 +1197,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
       const uint32_t c = gwin_get(lw, pep, t, i - 1);
       const uint64_t nlo = rank_c(ix, c, lo), nhi = rank_c(ix, c, hi);
       if (nlo >= nhi) state = GS_END_MATCH;
-      else { lo = nlo; hi = nhi; i--; if (i == 0) state = GS_END_MATCH; }
+      else { lo = nlo; hi = nhi; i--; acc += (uint32_t)ct.diag_idx[c]; if (i == 0) state = GS_END_MATCH; }
     } else if (state == GS_VSTEP) {
       // UpdateSI(trans[substitute]) on the match's interval (:372)
       const GMatch it = gs.matches[vmatch];
@@ -1121,6 +1211,8 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
         nf.diff = t.diff + (int)ct.b62[vorig][s] - (int)ct.b62[s][s];
         nf.si0 = nlo; nf.si1 = nhi;
         nf.matchlen = (uint32_t)it.ql + 1;
+        nf.tot = it.psum - (uint32_t)ct.b62[vorig][vorig] + (uint32_t)ct.b62[s][s];
+        nf.msum = it.dsum + (uint32_t)ct.b62[s][s];
         nf.segchecked = 1;
         if (t.num_mm < kMaxMismatch) { nf.sub_pos[t.num_mm] = (uint16_t)(it.qi - 1); nf.sub_aa[t.num_mm] = (uint8_t)c; }
         nf.num_mm = (uint8_t)(t.num_mm + 1);

@@ -1,0 +1,43 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import pyoracle as po
+    po.build_oracle()
+    return po.Oracle()
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """the kernel logic of kaiju_amd/csrc/kj_core.h compiled for the host (test infrastructure)"""
+    import util
+    return util.Emu()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import util
+    return util.Golden()
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    from kaiju_amd import api
+    api.lib()
+    if api.device_count() < 1:
+        pytest.fail("GPU test selected but libkaiju_gpu.so sees no HIP device (no CPU fallback exists)")
+    return api

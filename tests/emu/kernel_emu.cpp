@@ -60,7 +60,7 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
 }
 
 // fragments of one batch (stage 1): returns per-read lists as ASCII for comparison
-// out_text receives "key:PEPTIDE\n" lines per read, reads separated by "\n"
+// frag_dump receives, per read, a "#" line followed by one "key:PEPTIDE" line per fragment
 int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const uint64_t *off, uint32_t n,
                  int paired, kaiju_gpu_hit *out, uint32_t si_cap, uint32_t pool_cap, uint32_t match_cap,
                  uint32_t *n_retry_out, char *frag_dump, uint64_t frag_dump_cap) {
@@ -78,14 +78,26 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   std::vector<Hit> hits(n);
   b.pep = pep.data(); b.frags = frags.data(); b.nfrag = nfrag.data(); b.hits = hits.data();
   uint32_t err = 0;
-  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, ix->st, b, r, &err);
+  // stage 1 -> SEG pass -> (MEM) apply, exactly the kernel sequence of capi.hip
+  uint32_t seg_count = 0;
+  const uint32_t seg_cap = (uint32_t)(frags.size() / 2 + 8);
+  std::vector<SegWork> seg_items(seg_cap);
+  std::vector<SegRec> seg_recs(seg_cap);
+  SegQueue sq{seg_items.data(), seg_recs.data(), &seg_count, seg_cap};
+  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, ix->st, b, sq, r, &err);
+  if (p.seg) {
+    for (uint32_t s = 0; s < seg_count && s < seg_cap; s++) seg_compute(ix->st, b, p, sq, s);
+    if (p.mode == 0) for (uint32_t r = 0; r < n; r++) seg_apply_mem(ix->ct, p, b, sq, r, &err);
+  }
   if (frag_dump) {
     const char *alpha = ix->packed.alphabet.c_str();
     uint64_t w = 0;
     for (uint32_t r = 0; r < n; r++) {
       const Frag *F = frags.data() + frag_base(off, r, p.m);
       const uint8_t *pp = pep.data() + pep_base(off, r);
-      for (uint32_t f = 0; f < nfrag[r]; f++) {
+      if (w + 4 >= frag_dump_cap) return KAIJU_GPU_ERR_NOMEM;
+      frag_dump[w++] = '#'; frag_dump[w++] = '\n';
+      for (uint32_t f = 0; f < (nfrag[r] & ~kNfragSegPending); f++) {
         char tmp[32];
         int l = snprintf(tmp, sizeof tmp, "%u:", F[f].key);
         if (w + (uint64_t)l + F[f].len + 2 >= frag_dump_cap) return KAIJU_GPU_ERR_NOMEM;
@@ -93,8 +105,6 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         for (uint32_t x = 0; x < F[f].len; x++) frag_dump[w++] = alpha[pp[F[f].start + x]];
         frag_dump[w++] = '\n';
       }
-      if (w + 2 >= frag_dump_cap) return KAIJU_GPU_ERR_NOMEM;
-      frag_dump[w++] = '\n';
     }
     frag_dump[w] = 0;
   }
@@ -112,7 +122,6 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     if (l1 > maxlen) maxlen = l1;
     if (l2 > maxlen) maxlen = l2;
   }
-  std::vector<uint32_t> prefix(maxlen / 3 + 4);
   std::vector<GBest> bestv(64);
   for (int pass = 0; pass < 2; pass++) {
     WorkList wl;
@@ -138,8 +147,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       GreedyScratch gs;
       gs.pool = pool.data(); gs.pool_cap = (uint32_t)pool.size(); gs.ord = ord.data();
       gs.matches = matches.data(); gs.match_cap = (uint32_t)matches.size();
-      gs.prefix = prefix.data(); gs.prefix_cap = (uint32_t)prefix.size(); gs.best = bestv.data(); gs.win = win;
-      greedy_lane(d, ix->ct, p, ix->st, b, wl, gs);
+      gs.best = bestv.data(); gs.win = win;
+      greedy_lane(d, ix->ct, p, sq, b, wl, gs);
     }
   }
   static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");

@@ -1,0 +1,89 @@
+"""The C-ABI library: it builds, loads, exports every symbol declared in include/kaiju_gpu.h,
+its host-side helpers work without a GPU, and the compute entry points fail loudly (never fall
+back to the CPU) when no HIP device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from kaiju_amd import api, build
+
+HEADER = os.path.join(util.ROOT, "include", "kaiju_gpu.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kaiju_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = api.lib()
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/kaiju_gpu.h but not exported"
+    assert lib.kaiju_gpu_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(api.Params) == 48
+    assert api.HIT_DTYPE.itemsize == 184
+    assert api.RESULT_DTYPE.itemsize == 16
+
+
+def test_product_library_does_not_link_the_oracle():
+    out = os.popen(f"ldd {build.LIB}").read() + os.popen(f"nm -D {build.LIB}").read()
+    assert "kaiju_oracle" not in out and "ko_classify" not in out and "libkaijuref" not in out
+
+
+def test_default_params_mirror_config():
+    p = api.default_params("greedy")
+    assert (p.mode, p.min_fragment_length, p.mismatches, p.min_score, p.seed_length, p.seg, p.use_evalue) == \
+        (1, 11, 3, 65, 7, 1, 1)
+    assert abs(p.min_evalue - 0.01) < 1e-15 and p.max_matches_SI == 20 and p.max_match_ids == 20
+    p = api.default_params("mem")
+    assert p.mode == 0 and p.use_evalue == 0        # "-a mem" clears use_Evalue, kaiju.cpp:77-80
+
+
+@pytest.mark.skipif(api.device_count() > 0, reason="checks the no-device behaviour")
+def test_no_device_fails_loudly(golden):
+    with pytest.raises(api.KaijuGpuError) as e:
+        api.Index(golden.fmi)
+    assert "no usable HIP device" in str(e.value)
+
+
+def test_bad_arguments():
+    L = api.lib()
+    assert L.kaiju_gpu_index_load(None, 0, None) < 0
+    h = C.c_void_p()
+    assert L.kaiju_taxonomy_load(b"/nonexistent/nodes.dmp", C.byref(h)) == -2
+    assert b"I/O" in L.kaiju_gpu_strerror(-2)
+
+
+def test_taxonomy_lca_matches_oracle(oracle, golden):
+    tax = api.Taxonomy(golden.nodes)
+    otax = oracle.load_nodes(golden.nodes)
+    ids = [int(l.split("\t")[0]) for l in open(golden.nodes)]
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        k = int(rng.integers(1, 8))
+        pick = [int(x) for x in rng.choice(ids + [999999999], size=k, replace=False)]
+        arr = (C.c_uint64 * k)(*pick)
+        assert tax.lca(pick) == oracle.lib.ko_lca(otax, arr, k), pick
+
+
+def test_taxonomy_depth_rules(tmp_path):
+    """lca_from_ids measures depth up to a self-parent root or an unknown parent (util.cpp:218-224)"""
+    p = tmp_path / "nodes.dmp"
+    p.write_text("1\t|\t1\t|\n2\t|\t1\t|\n3\t|\t2\t|\n4\t|\t2\t|\n5\t|\t4\t|\n10\t|\t77\t|\n11\t|\t10\t|\nbad line\n\n12\t|\t10\t|\n")
+    tax = api.Taxonomy(str(p))
+    assert tax.lca([3, 5]) == 2
+    assert tax.lca([3, 4, 5]) == 2
+    assert tax.lca([5]) == 5
+    assert tax.lca([11, 12]) == 10
+    assert tax.lca([3, 424242]) == 3          # ids missing from the tree are dropped
+    assert tax.lca([424242, 434343]) == 0

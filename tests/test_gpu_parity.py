@@ -1,0 +1,196 @@
+"""Parity of the HIP path (through the C-ABI) with the oracle and the reference's golden output.
+
+Small and medium cases are compared record by record with the oracle; the BASELINE-sized case
+(millions of reads on a viruses-scale index) is checked through size-independent properties
+(batch-split invariance, permutation invariance, strand symmetry of the MEM length, planted
+reads must hit their source) plus a record-by-record comparison of a random sample."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("mem", 1), ("mem", 0), ("greedy", 1), ("greedy", 0)]
+
+
+@pytest.fixture(scope="module")
+def gidx(gpu_lib, golden):
+    return gpu_lib.Index(golden.fmi)
+
+
+@pytest.fixture(scope="module")
+def ohandles(oracle, golden):
+    return oracle.load_fmi(golden.fmi), oracle.load_nodes(golden.nodes)
+
+
+def finalize_records(api, clf, tax, hits, off, paired=False):
+    res = clf.finalize(tax, hits, off, paired)
+    out = []
+    for h, r in zip(hits, res):
+        if r["classified"]:
+            out.append(("C", int(r["taxon"]), int(r["best"]), tuple(sorted(int(x) for x in h["taxid"][:h["n_ids"]]))))
+        else:
+            out.append(("U", 0, None, ()))
+    return out
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_golden_single(gpu_lib, golden, gidx, oracle, ohandles, mode, seg):
+    api = gpu_lib
+    clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
+    hits = clf.classify(golden.seqs, golden.off)
+    st = clf.stats()
+    assert st.error_flags == 0
+    assert not (hits["flags"] & 0xC0000000).any()
+    # against the oracle, record by record (ids in traversal order)
+    ix, tax = ohandles
+    oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), golden.seqs, golden.off)
+    bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+    assert not bad, (bad[:5], oh[bad[0]], hits[bad[0]])
+    # against the reference binary's output lines
+    got = finalize_records(api, clf, api.Taxonomy(golden.nodes), hits, golden.off)
+    ref = golden.tsv(f"ref_{mode}_{seg}.tsv")
+    bad = [(n, g, ref[n]) for n, g in zip(golden.names, got) if g != ref[n]]
+    assert not bad, bad[:3]
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_golden_paired(gpu_lib, golden, gidx, mode, seg):
+    api = gpu_lib
+    clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
+    hits = clf.classify(golden.pseqs, golden.poff, paired=True)
+    got = finalize_records(api, clf, api.Taxonomy(golden.nodes), hits, golden.poff, paired=True)
+    ref = golden.tsv(f"ref_{mode}_{seg}_pe.tsv")
+    bad = [(n, g, ref[n]) for n, g in zip(golden.pnames, got) if g != ref[n]]
+    assert not bad, bad[:3]
+
+
+def test_parameter_variants(gpu_lib, golden, gidx):
+    api = gpu_lib
+    tax = api.Taxonomy(golden.nodes)
+    for name, p in (("ref_greedy_e5_s50.tsv", api.default_params("greedy", mismatches=5, min_score=50, min_evalue=10.0)),
+                    ("ref_greedy_e0.tsv", api.default_params("greedy", mismatches=0)),
+                    ("ref_mem_m15.tsv", api.default_params("mem", min_fragment_length=15))):
+        clf = api.Classifier(gidx, p)
+        hits = clf.classify(golden.seqs, golden.off)
+        got = finalize_records(api, clf, tax, hits, golden.off)
+        ref = golden.tsv(name)
+        bad = [(n, g, ref[n]) for n, g in zip(golden.names, got) if g != ref[n]]
+        assert not bad, (name, bad[:3])
+
+
+def test_empty_and_tiny_batches(gpu_lib, golden, gidx):
+    api = gpu_lib
+    clf = api.Classifier(gidx, api.default_params("mem"))
+    h = clf.classify(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    assert len(h) == 0
+    s, o = util.pack([b"", b"ACGT", golden.reads[0]])
+    h = clf.classify(s, o)
+    assert h["best"][0] == 0 and h["best"][1] == 0 and h["n_ids"][0] == 0
+    full = clf.classify(golden.seqs, golden.off)
+    assert util.same_hit(full[0], h[2])
+
+
+def test_unsupported_parameters(gpu_lib, gidx):
+    api = gpu_lib
+    with pytest.raises(api.KaijuGpuError):
+        api.Classifier(gidx, api.default_params("greedy", mismatches=9))
+    with pytest.raises(api.KaijuGpuError):
+        api.Classifier(gidx, api.default_params("mem", max_match_ids=40))
+
+
+# ----------------------------------------------------------------------------------------
+# viruses-scale workload (BASELINE.json configs 1-3)
+# ----------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big(tmp_path_factory, gpu_lib):
+    """viruses-like index + reads; size via KAIJU_TEST_NSEQ / KAIJU_TEST_READS"""
+    from kaiju_amd import synth, mkfmi
+    W = str(tmp_path_factory.mktemp("big"))
+    nseq = int(os.environ.get("KAIJU_TEST_NSEQ", "680001"))
+    nreads = int(os.environ.get("KAIJU_TEST_READS", "2000000"))
+    lines, leaves = synth.make_taxonomy()
+    synth.write_nodes_dmp(f"{W}/nodes.dmp", lines)
+    db = synth.make_db(nseq=nseq, seed=12345, leaves=leaves)
+    synth.write_fasta(db, f"{W}/db.faa")
+    mkfmi.build_fmi(f"{W}/db.faa", f"{W}/db.fmi", threads=os.cpu_count() or 8, exponent=3)
+    reads = synth.make_reads(db, nreads, seed=777)
+    seqs, off = synth.pack_reads(reads)
+    return dict(W=W, db=db, reads=reads, seqs=seqs, off=off, index=gpu_lib.Index(f"{W}/db.fmi"))
+
+
+@pytest.mark.parametrize("mode,seg", [("mem", 1), ("greedy", 1)])
+def test_fullsize_sample_vs_oracle(gpu_lib, oracle, big, mode, seg):
+    api = gpu_lib
+    clf = api.Classifier(big["index"], api.default_params(mode, seg=seg))
+    hits = clf.classify(big["seqs"], big["off"])
+    assert clf.stats().error_flags == 0
+    assert not (hits["flags"] & 0xC0000000).any()
+    rng = np.random.default_rng(11)
+    sample = np.sort(rng.choice(len(hits), size=min(20000, len(hits)), replace=False))
+    from kaiju_amd import synth
+    s2, o2 = synth.pack_reads(big["reads"][sample])
+    ix = oracle.load_fmi(f"{big['W']}/db.fmi")
+    oh = oracle.classify(ix, None, oracle.params(mode, seg=seg, use_evalue=0), s2, o2)
+    bad = [int(sample[i]) for i in range(len(sample)) if not util.same_hit(oh[i], hits[sample[i]])]
+    assert not bad, bad[:5]
+    frac = float((hits["n_ids"] > 0).mean())
+    assert 0.55 < frac < 0.80          # 70 % of the reads come from the database
+
+
+def test_fullsize_invariants(gpu_lib, big):
+    api = gpu_lib
+    clf = api.Classifier(big["index"], api.default_params("mem", seg=1))
+    reads = big["reads"]
+    from kaiju_amd import synth
+    hits = clf.classify(big["seqs"], big["off"])
+    n = len(reads)
+    # (1) batch-split invariance: two halves give the same records as the whole
+    h1 = clf.classify(*synth.pack_reads(reads[: n // 2]))
+    h2 = clf.classify(*synth.pack_reads(reads[n // 2:]))
+    assert (np.concatenate([h1, h2]) == hits).all()
+    # (2) permutation invariance
+    perm = np.random.default_rng(5).permutation(n)
+    hp = clf.classify(*synth.pack_reads(reads[perm]))
+    assert (hp == hits[perm]).all()
+    # (3) strand symmetry: the reverse complement has the same set of peptides, hence the same
+    #     longest match (ids may differ only in the rare 21-id cap case)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    m = min(n, 500000)
+    rc = comp[reads[:m, ::-1]]
+    hr = clf.classify(*synth.pack_reads(rc))
+    assert (hr["best"] == hits["best"][:m]).all()
+    nocap = ((hr["flags"] | hits["flags"][:m]) & 1) == 0
+    a = np.sort(hr["taxid"][nocap], axis=1)
+    b = np.sort(hits["taxid"][:m][nocap], axis=1)
+    assert (a == b).all()
+    # (4) idempotence: same input, same output
+    assert (clf.classify(big["seqs"], big["off"]) == hits).all()
+
+
+def test_planted_reads_hit_their_source(gpu_lib, big):
+    """exact back-translations of database windows must give a 50-aa match containing the source taxon"""
+    api = gpu_lib
+    from kaiju_amd import synth
+    db = big["db"]
+    rng = np.random.default_rng(3)
+    lens = np.diff(db.offsets)
+    elig = np.nonzero(lens >= 60)[0]
+    seq = elig[rng.integers(0, len(elig), size=20000)]
+    start = db.offsets[seq] + (rng.random(len(seq)) * (lens[seq] - 50)).astype(np.int64)
+    win = db.codes[start[:, None] + np.arange(50)[None, :]]
+    cod = synth._CODTAB[win, 0]
+    nts = np.stack([(cod >> 4) & 3, (cod >> 2) & 3, cod & 3], axis=2).reshape(len(seq), 150)
+    reads = np.frombuffer(b"ACGT", dtype=np.uint8)[nts]
+    clf = api.Classifier(big["index"], api.default_params("mem", seg=0))
+    hits = clf.classify(*synth.pack_reads(reads))
+    assert (hits["best"] == 50).all()
+    src = db.taxids[seq].astype(np.uint64)
+    found = (hits["taxid"] == src[:, None]).any(axis=1) | ((hits["flags"] & 1) == 1)
+    assert found.all()

@@ -1,0 +1,129 @@
+"""Kernel logic (kaiju_amd/csrc/kj_core.h compiled for the host, tests/emu) against the oracle
+and the golden vectors: packed rank blocks, SEG, fragment lists, MEM and Greedy lanes incl. the
+scratch-overflow retry pass.  These run without a GPU; the same comparisons run against the real
+kernels in test_gpu_parity.py."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+
+@pytest.fixture(scope="module")
+def handles(oracle, emu, golden):
+    return emu.load(golden.fmi), oracle.load_fmi(golden.fmi), oracle.load_nodes(golden.nodes)
+
+
+def test_packed_rank_matches_fmindex(oracle, emu, golden, handles):
+    h, ix, _ = handles
+    with np.load(os.path.join(golden.dir, "kat_fm.npz")) as z:
+        ks, fm, kk, cur = z["ks"], z["fm"], z["kk"], z["cur"]
+    for a, k in enumerate(ks):
+        for c in range(1, 21):
+            assert emu.lib.emu_rank(h, c, int(k)) == fm[a, c]
+    for a, k in enumerate(kk):
+        v, c = cur[a]
+        assert emu.lib.emu_symbol(h, int(k)) == c
+        assert emu.lib.emu_rank(h, int(c), int(k)) == v      # LF step incl. the terminator (c == 0)
+    assert emu.lib.emu_index_warnings(h) == 0
+
+
+def test_seg_known_answers(emu, golden, handles):
+    h = handles[0]
+    with open(os.path.join(golden.dir, "kat_seg.json")) as f:
+        kat = json.load(f)
+    for aa, regs in kat:
+        assert emu.seg(h, aa.encode()) == [tuple(r) for r in regs], aa
+
+
+def test_fragment_lists(oracle, emu, golden, handles):
+    """stage 1 without SEG == getAllFragmentsBits queue order of the oracle"""
+    h = handles[0]
+    for mode in ("mem", "greedy"):
+        _, _, dump = emu.classify(h, util.gp(mode, seg=0), golden.seqs, golden.off, want_frags=True)
+        per_read = dump.split("#\n")[1:]
+        p = oracle.params(mode, seg=0)
+        for i, r in enumerate(golden.reads):
+            exp = oracle.fragments(p, r) if len(r) >= 33 else []
+            got = [(int(x.split(":")[0]), x.split(":")[1].encode()) for x in per_read[i].split("\n") if x]
+            assert got == exp, (mode, i)
+
+
+CASES = [("mem", 1), ("mem", 0), ("greedy", 1), ("greedy", 0)]
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_lanes_vs_oracle_single(oracle, emu, golden, handles, mode, seg):
+    h, ix, tax = handles
+    oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), golden.seqs, golden.off)
+    gh, nretry = emu.classify(h, util.gp(mode, seg=seg), golden.seqs, golden.off)
+    bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+    assert not bad, (bad[:5], oh[bad[0]], gh[bad[0]])
+    assert not (gh["flags"] & 0xC0000000).any()
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_lanes_vs_oracle_paired(oracle, emu, golden, handles, mode, seg):
+    h, ix, tax = handles
+    oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), golden.pseqs, golden.poff, paired=True)
+    gh, _ = emu.classify(h, util.gp(mode, seg=seg), golden.pseqs, golden.poff, paired=True)
+    bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+    assert not bad, (bad[:5], oh[bad[0]], gh[bad[0]])
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_retry_pass(oracle, emu, golden, handles, mode, seg):
+    """scratch far too small in the main pass: every overflowing read must come out right
+    from the retry pass"""
+    h, ix, tax = handles
+    oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), golden.seqs, golden.off)
+    gh, nretry = emu.classify(h, util.gp(mode, seg=seg), golden.seqs, golden.off, caps=(1, 12, 2))
+    assert nretry > 0
+    bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+    assert not bad, bad[:5]
+
+
+def test_parameter_variants(oracle, emu, golden, handles):
+    h, ix, tax = handles
+    for op, g in ((oracle.params("greedy", mismatches=5, min_score=50, use_evalue=0), util.gp("greedy", mismatches=5, min_score=50)),
+                  (oracle.params("greedy", mismatches=0, use_evalue=0), util.gp("greedy", mismatches=0)),
+                  (oracle.params("greedy", mismatches=1, seed_length=9, use_evalue=0), util.gp("greedy", mismatches=1, seed_length=9)),
+                  (oracle.params("mem", min_fragment_length=15), util.gp("mem", m=15)),
+                  (oracle.params("mem", min_fragment_length=8), util.gp("mem", m=8))):
+        oh = oracle.classify(ix, tax, op, golden.seqs, golden.off)
+        gh, _ = emu.classify(h, g, golden.seqs, golden.off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (g.mode, g.mismatches, bad[:5])
+
+
+def test_golden_tsv_through_host_seam(emu, golden, handles):
+    """device hits -> kaiju_finalize_hits (E-value gate, LCA, C/U) == reference output lines"""
+    from kaiju_amd import api
+    tax = api.Taxonomy(golden.nodes)
+    h = handles[0]
+    L = api.lib()
+    for mode in ("mem", "greedy"):
+        for seg in (1, 0):
+            for pe in (False, True):
+                seqs, off, names = (golden.pseqs, golden.poff, golden.pnames) if pe else (golden.seqs, golden.off, golden.names)
+                gh, _ = emu.classify(h, util.gp(mode, seg=seg), seqs, off, paired=pe)
+                p = api.default_params(mode, seg=seg)
+                res = np.zeros(len(gh), dtype=api.RESULT_DTYPE)
+                # db_length = bwtlen - nseq (Config.cpp:20)
+                with open(golden.fmi, "rb") as f:
+                    hdr = np.frombuffer(f.read(12), dtype=np.uint8)
+                bwtlen = int(hdr[:8].view("<i8")[0]); nseq = int(hdr[8:12].view("<i4")[0])
+                rc = L.kaiju_finalize_hits(tax._h, C.byref(p), float(bwtlen - nseq), gh.ctypes.data,
+                                           np.ascontiguousarray(off).ctypes.data, len(gh), 1 if pe else 0, res.ctypes.data)
+                assert rc == 0
+                ref = golden.tsv(f"ref_{mode}_{seg}{'_pe' if pe else ''}.tsv")
+                for i, n in enumerate(names):
+                    r = ref[n]
+                    if r[0] == "C":
+                        assert res[i]["classified"] == 1 and int(res[i]["taxon"]) == r[1] and int(res[i]["best"]) == r[2], (mode, seg, pe, n)
+                        assert tuple(sorted(int(x) for x in gh[i]["taxid"][:gh[i]["n_ids"]])) == r[3]
+                    else:
+                        assert res[i]["classified"] == 0, (mode, seg, pe, n)

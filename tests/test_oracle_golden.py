@@ -1,0 +1,94 @@
+"""The oracle against the committed golden vectors produced by the unmodified reference
+(tests/golden/make_golden.py): end-to-end TSVs of `kaiju -v -z 1` for every mode, plus
+function-level known answers of FMindex / FMindexCurrent / get_suffix / SeqBufferSeg."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+
+@pytest.fixture(scope="module")
+def ox(oracle, golden):
+    return oracle.load_fmi(golden.fmi), oracle.load_nodes(golden.nodes)
+
+
+CASES = [("mem", 1, {}), ("mem", 0, {}), ("greedy", 1, {}), ("greedy", 0, {})]
+
+
+@pytest.mark.parametrize("mode,seg,kw", CASES)
+def test_end_to_end_single(oracle, golden, ox, mode, seg, kw):
+    ix, tax = ox
+    ref = golden.tsv(f"ref_{mode}_{seg}.tsv")
+    hits = oracle.classify(ix, tax, oracle.params(mode, seg=seg), golden.seqs, golden.off)
+    got = util.oracle_records(hits)
+    assert len(ref) == len(golden.names)
+    bad = [(n, g, ref[n]) for n, g in zip(golden.names, got) if g != ref[n]]
+    assert not bad, bad[:3]
+    assert sum(1 for g in got if g[0] == "C") > 300
+
+
+@pytest.mark.parametrize("mode,seg,kw", CASES)
+def test_end_to_end_paired(oracle, golden, ox, mode, seg, kw):
+    ix, tax = ox
+    ref = golden.tsv(f"ref_{mode}_{seg}_pe.tsv")
+    hits = oracle.classify(ix, tax, oracle.params(mode, seg=seg), golden.pseqs, golden.poff, paired=True)
+    got = util.oracle_records(hits)
+    bad = [(n, g, ref[n]) for n, g in zip(golden.pnames, got) if g != ref[n]]
+    assert not bad, bad[:3]
+
+
+def test_parameter_variants(oracle, golden, ox):
+    ix, tax = ox
+    for name, p in (("ref_greedy_e5_s50.tsv", oracle.params("greedy", mismatches=5, min_score=50, min_evalue=10.0)),
+                    ("ref_greedy_e0.tsv", oracle.params("greedy", mismatches=0)),
+                    ("ref_mem_m15.tsv", oracle.params("mem", min_fragment_length=15))):
+        ref = golden.tsv(name)
+        got = util.oracle_records(oracle.classify(ix, tax, p, golden.seqs, golden.off))
+        bad = [(n, g, ref[n]) for n, g in zip(golden.names, got) if g != ref[n]]
+        assert not bad, (name, bad[:3])
+
+
+def test_fm_known_answers(oracle, golden, ox):
+    ix, _ = ox
+    with np.load(os.path.join(golden.dir, "kat_fm.npz")) as z:
+        ks, fm, kk, cur, suf = z["ks"], z["fm"], z["kk"], z["cur"], z["suf"]
+    L = oracle.lib
+    for a, k in enumerate(ks):
+        for c in range(21):
+            assert L.ko_fmindex(ix, c, int(k)) == fm[a, c]
+    for a, k in enumerate(kk):
+        cc = C.c_int()
+        v = L.ko_fmindex_current(ix, int(k), C.byref(cc))
+        assert (v, cc.value) == tuple(cur[a])
+        iseq, pos = C.c_int32(), C.c_int64()
+        L.ko_get_suffix(ix, int(k), C.byref(iseq), C.byref(pos))
+        assert (iseq.value, pos.value) == tuple(suf[a])
+
+
+def test_seg_known_answers(oracle, golden):
+    with open(os.path.join(golden.dir, "kat_seg.json")) as f:
+        kat = json.load(f)
+    nreg = 0
+    for aa, regs in kat:
+        got = oracle.seg(aa.encode())
+        assert got == [tuple(r) for r in regs], aa
+        nreg += len(regs)
+    assert nreg > 500
+
+
+def test_fragment_order(oracle):
+    """six-frame translation: emission order and key-descending stable queue (ConsumerThread.cpp:190-270)"""
+    p = oracle.params("mem", seg=0)
+    read = b"ATGGCTGCTAAAGGTTCTGCTCCTGAAGAACTGTTCAAAGGTACCGCTTAAATGCGTCGTAAACTGGCTGCTCTGGAAGAACGTGGTTCTCCGGCTTGA"
+    fr = oracle.fragments(p, read)
+    keys = [k for k, _ in fr]
+    assert keys == sorted(keys, reverse=True)
+    assert all(len(s) == k and k >= 11 for k, s in fr)
+    assert any(s.startswith(b"MAAKGSAPEELFKGTA") for _, s in fr)
+    # a base that is not ACGTU terminates the frame like a stop codon
+    fr2 = oracle.fragments(p, read.replace(b"GGT", b"GNT", 1))
+    assert not any(s.startswith(b"MAAKGSAPEELFKGTA") for _, s in fr2)

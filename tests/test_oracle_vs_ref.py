@@ -1,0 +1,76 @@
+"""Live check of the oracle against the unmodified reference compiled into oracle/_ref
+(libkaijuref.so for function-level answers, the kaiju binary end to end) on freshly generated
+random data.  Skipped where oracle/_ref has not been built."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from kaiju_amd import synth
+
+pytestmark = pytest.mark.skipif(not po.have_ref(), reason="oracle/_ref not built (make -C oracle ref)")
+
+
+@pytest.fixture(scope="module")
+def data(tmp_path_factory):
+    W = str(tmp_path_factory.mktemp("refcmp"))
+    lines, leaves = synth.make_taxonomy(6, 4, 5)
+    synth.write_nodes_dmp(f"{W}/nodes.dmp", lines)
+    db = synth.make_db(nseq=3001, seed=31, leaves=leaves)
+    synth.write_fasta(db, f"{W}/db.faa")
+    po.ref_build_index(f"{W}/db.faa", f"{W}/db", threads=4)
+    reads = synth.make_reads(db, 6000, seed=32)
+    synth.write_fastq(reads, f"{W}/reads.fq")
+    return W, db, reads
+
+
+def test_functions(oracle, data):
+    W, db, reads = data
+    R = po.RefLib()
+    bw = R.read_indexes(f"{W}/db.fmi")
+    ix = oracle.load_fmi(f"{W}/db.fmi")
+    bl = bw.len
+    rng = np.random.default_rng(0)
+    ks = np.unique(np.concatenate([rng.integers(0, bl + 1, 3000), np.arange(0, 260), np.arange(bl - 260, bl + 1)]))
+    for k in ks:
+        for c in range(21):
+            assert oracle.lib.ko_fmindex(ix, c, int(k)) == R.fmindex(bw, c, int(k))
+    for k in ks[(ks < bl) & (ks >= bw.nseq)]:
+        cc = C.c_int()
+        v = oracle.lib.ko_fmindex_current(ix, int(k), C.byref(cc))
+        assert (v, cc.value) == R.fmindex_current(bw, int(k))
+        i1, p1 = C.c_int32(), C.c_int64()
+        oracle.lib.ko_get_suffix(ix, int(k), C.byref(i1), C.byref(p1))
+        assert (i1.value, p1.value) == R.get_suffix(bw, int(k))
+
+
+def test_seg(oracle):
+    R = po.RefLib()
+    rng = np.random.default_rng(5)
+    AA = synth.AA
+    for it in range(3000):
+        L = int(rng.integers(5, 140))
+        s = rng.choice(20, L)
+        if it % 3:
+            a = int(rng.integers(0, L)); b = int(rng.integers(a, L))
+            s[a:b] = rng.choice(rng.choice(20, int(rng.integers(1, 4))), b - a)
+        aa = bytes(ord(AA[i]) for i in s)
+        assert oracle.seg(aa) == R.seg(aa), aa
+
+
+@pytest.mark.parametrize("mode,seg", [("mem", True), ("mem", False), ("greedy", True), ("greedy", False)])
+def test_end_to_end(oracle, data, mode, seg):
+    W, db, reads = data
+    out = f"{W}/ref_{mode}_{int(seg)}.tsv"
+    po.ref_kaiju(f"{W}/nodes.dmp", f"{W}/db.fmi", f"{W}/reads.fq", out, mode=mode, seg=seg)
+    ref = po.parse_kaiju_tsv(out)
+    ix = oracle.load_fmi(f"{W}/db.fmi")
+    tax = oracle.load_nodes(f"{W}/nodes.dmp")
+    seqs, off = synth.pack_reads(reads)
+    hits = oracle.classify(ix, tax, oracle.params(mode, seg=int(seg)), seqs, off)
+    for i, h in enumerate(hits):
+        mine = ("C", int(h["lca"]), int(h["best"]), tuple(sorted(int(x) for x in h["taxid"][:h["n_ids"]]))) \
+            if h["classified"] else ("U", 0, None, ())
+        assert mine == ref[f"r{i}"], i

@@ -87,7 +87,8 @@ def main():
             ok = ok and bad == 0
             nC = int(res["classified"].sum())
             print(f"{mode} seg={seg}: gpu {best_ms:.2f} ms/batch ({len(reads)/best_ms*1e3:,.0f} reads/s; "
-                  f"translate {st.ms_translate:.2f} search {st.ms_search:.2f}) retries={st.n_overflow_retries} "
+                  f"translate {st.ms_translate:.2f} seg {st.ms_seg:.2f} [{st.n_seg_fragments} frags] "
+                  f"search {st.ms_search:.2f} retry {st.ms_retry:.2f}) retries={st.n_overflow_retries} err={st.error_flags} "
                   f"classified={nC}  oracle {nchk/dt:,.0f} reads/s ({cnt['update_si']/nchk:.0f} UpdateSI/read, "
                   f"{cnt['fmindex_current']/nchk:.1f} LF/read)  mismatches={bad}/{nchk}", flush=True)
             clf.close()

@@ -1,0 +1,173 @@
+"""Shared helpers of the test-suite (test infrastructure)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_SO = os.path.join(EMU_DIR, "libkaiju_kernel_emu.so")
+CSRC = os.path.join(ROOT, "kaiju_amd", "csrc")
+
+GPU_HIT = np.dtype([("best", "<u4"), ("n_ids", "<u4"), ("flags", "<u4"), ("reserved", "<u4"),
+                    ("taxid", "<u8", (21,))])
+
+
+class GP(C.Structure):      # kaiju_gpu_params
+    _fields_ = [("mode", C.c_int32), ("min_fragment_length", C.c_uint32), ("mismatches", C.c_uint32),
+                ("min_score", C.c_uint32), ("seed_length", C.c_uint32), ("seg", C.c_int32),
+                ("use_evalue", C.c_int32), ("min_evalue", C.c_double), ("max_matches_SI", C.c_uint32),
+                ("max_match_ids", C.c_uint32)]
+
+
+def gp(mode, m=11, mismatches=3, min_score=65, seed_length=7, seg=1, use_evalue=None, min_evalue=0.01):
+    md = 0 if mode in ("mem", 0) else 1
+    if use_evalue is None:
+        use_evalue = md
+    return GP(md, m, mismatches, min_score, seed_length, seg, use_evalue, min_evalue, 20, 20)
+
+
+def build_emu():
+    srcs = [os.path.join(EMU_DIR, "kernel_emu.cpp")] + [os.path.join(CSRC, f) for f in
+                                                        ("host_index.cpp", "host_tables.cpp", "taxonomy.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kj_core.h", "host_index.h", "host_tables.h")]
+    if os.path.exists(EMU_SO) and all(os.path.getmtime(d) <= os.path.getmtime(EMU_SO) for d in deps):
+        return
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-pthread",
+                    "-o", EMU_SO] + srcs, check=True)
+
+
+class Emu:
+    def __init__(self):
+        build_emu()
+        E = self.lib = C.CDLL(EMU_SO)
+        E.emu_index_load.restype = C.c_void_p
+        E.emu_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        E.emu_index_free.argtypes = [C.c_void_p]
+        E.emu_index_warnings.restype = C.c_uint32
+        E.emu_index_warnings.argtypes = [C.c_void_p]
+        E.emu_rank.restype = C.c_uint64
+        E.emu_rank.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        E.emu_symbol.restype = C.c_uint32
+        E.emu_symbol.argtypes = [C.c_void_p, C.c_uint64]
+        E.emu_seg.restype = C.c_int
+        E.emu_seg.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        E.emu_classify.restype = C.c_int
+        E.emu_classify.argtypes = [C.c_void_p, C.POINTER(GP), C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                   C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                   C.c_char_p, C.c_uint64]
+
+    def load(self, fmi):
+        err = C.create_string_buffer(512)
+        h = self.lib.emu_index_load(fmi.encode(), err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return h
+
+    def seg(self, h, aa: bytes):
+        l = (C.c_int32 * 64)()
+        r = (C.c_int32 * 64)()
+        n = self.lib.emu_seg(h, aa, len(aa), l, r)
+        assert n >= 0
+        return [(l[i], r[i]) for i in range(n)]
+
+    def classify(self, h, params, seqs, off, paired=False, caps=(16, 192, 64), want_frags=False):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = (len(off) - 1) // 2
+        out = np.zeros(n, dtype=GPU_HIT)
+        nretry = C.c_uint32(0)
+        dump = C.create_string_buffer(max(1 << 20, 8 * len(seqs) + 64 * n)) if want_frags else None
+        rc = self.lib.emu_classify(h, C.byref(params), seqs.ctypes.data, off.ctypes.data, n, 1 if paired else 0,
+                                   out.ctypes.data, caps[0], caps[1], caps[2], C.byref(nretry), dump,
+                                   len(dump) if dump else 0)
+        assert rc == 0, rc
+        if want_frags:
+            return out, nretry.value, dump.value.decode()
+        return out, nretry.value
+
+
+def read_fastq(path):
+    names, seqs = [], []
+    with open(path, "rb") as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            s = f.readline().rstrip(b"\n")
+            f.readline()
+            f.readline()
+            names.append(h[1:].strip().decode())
+            seqs.append(s)
+    return names, seqs
+
+
+def pack(seqs1, seqs2=None):
+    """list(s) of bytes -> (uint8 array, off[2n+1]) in the batch layout of include/kaiju_gpu.h"""
+    n = len(seqs1)
+    parts = []
+    off = np.zeros(2 * n + 1, dtype=np.uint64)
+    pos = 0
+    for i in range(n):
+        a = seqs1[i]
+        b = seqs2[i] if seqs2 is not None else b""
+        parts.append(a)
+        parts.append(b)
+        off[2 * i] = pos
+        pos += len(a)
+        off[2 * i + 1] = pos
+        pos += len(b)
+    off[2 * n] = pos
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8).copy() if pos else np.zeros(0, dtype=np.uint8)
+    return buf, off
+
+
+def parse_tsv(path):
+    """reference `kaiju -v` output -> dict name -> (C/U, taxon, best, sorted ids)"""
+    res = {}
+    with open(path) as f:
+        for line in f:
+            p = line.rstrip("\n").split("\t")
+            if p[0] == "C":
+                ids = tuple(int(x) for x in p[4].split(",") if x)
+                res[p[1]] = ("C", int(p[2]), int(p[3]), ids)
+            else:
+                res[p[1]] = ("U", 0, None, ())
+    return res
+
+
+class Golden:
+    def __init__(self):
+        self.dir = GOLD
+        self.fmi = os.path.join(GOLD, "db.fmi")
+        self.nodes = os.path.join(GOLD, "nodes.dmp")
+        self.names, self.reads = read_fastq(os.path.join(GOLD, "reads.fq"))
+        self.pnames, self.p1 = read_fastq(os.path.join(GOLD, "pairs_1.fq"))
+        _, self.p2 = read_fastq(os.path.join(GOLD, "pairs_2.fq"))
+        self.seqs, self.off = pack(self.reads)
+        self.pseqs, self.poff = pack(self.p1, self.p2)
+
+    def tsv(self, name):
+        return parse_tsv(os.path.join(GOLD, name))
+
+
+def oracle_records(hits):
+    """oracle hits -> list of (C/U, taxon, best, sorted ids) like parse_tsv values"""
+    out = []
+    for h in hits:
+        if h["classified"]:
+            out.append(("C", int(h["lca"]), int(h["best"]), tuple(sorted(int(x) for x in h["taxid"][:h["n_ids"]]))))
+        else:
+            out.append(("U", 0, None, ()))
+    return out
+
+
+def same_hit(o, g, mask=3):
+    """oracle hit vs device hit: best, ids in traversal order, public flag bits"""
+    return (int(o["best"]) == int(g["best"]) and int(o["n_ids"]) == int(g["n_ids"]) and
+            list(o["taxid"][:o["n_ids"]]) == list(g["taxid"][:g["n_ids"]]) and
+            (int(o["flags"]) & mask) == (int(g["flags"]) & mask))
