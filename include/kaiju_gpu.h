@@ -173,6 +173,14 @@ int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p, double db_
                         const kaiju_gpu_hit *hits, const uint64_t *off, uint32_t n_reads,
                         int paired, kaiju_result *out);
 
+/* ---- index construction (off-line) ------------------------------------ */
+/* Protein FASTA -> .fmi, format-compatible with the reference's kaiju-mkbwt (-a
+   ACDEFGHIKLMNPQRSTVWY -e chpt_exp, util/kaiju-makedb:373) followed by kaiju-mkfmi
+   (bwt/mkbwt.c:922-1099, bwt/mkfmi.c:21-97); the reference binary reads the result.
+   threads <= 0: all hardware threads.  Host only. */
+int kaiju_build_fmi(const char *faa_path, const char *out_fmi_path, int threads, int chpt_exp);
+const char *kaiju_build_fmi_error(void);
+
 #ifdef __cplusplus
 }
 #endif

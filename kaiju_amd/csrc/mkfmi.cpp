@@ -1,0 +1,347 @@
+// mkfmi.cpp — index builder: protein FASTA -> Kaiju .fmi (format-compatible with the
+// reference's kaiju-mkbwt + kaiju-mkfmi, so that the reference binary and this library read the
+// very same file).
+//
+// The reference builds the index off-line with a bucketed multikey quicksort
+// (bwt/mkbwt.c:922-1099), then byte-codes the BWT and samples the rank checkpoints
+// (bwt/mkfmi.c, bwt/compactfmi.c:446-457, bwt/fmicommon.h:95-171).  This is an independent
+// implementation of the same definition:
+//   * text = the sequences in file order, letter codes 1..20 ("*ACDEFGHIKLMNPQRSTVWY"), every
+//     sequence followed by a terminator that sorts below all letters; terminators of
+//     different sequences compare by file order (mkbwt.c:readOrder/encodeOrder, revsort off);
+//   * BWT rows 0..nseq-1 are the terminator suffixes in file order (write_term, mkbwt.c:862-876),
+//     then all letter suffixes in lexicographic order; the BWT letter in front of a sequence
+//     start is the terminator;
+//   * SA samples every 2^e rows (k >= nseq) hold (rank of the sequence among all sequences in
+//     sorted order, offset), big-endian in nbytes (suffixArray.c:45-53,195-226);
+//   * sequence names/lengths are stored in sorted-sequence order (SortSeqs, mkbwt.c:700-733);
+//   * FMI: index1 every 2^16, index2 every 2^8, BWT bytes re-coded as (letter, in-block count)
+//     with the code table of find_startLcode (compactfmi.c:108-150).
+// Suffixes are sorted bucket-wise (first two letters) with std::sort on a word-at-a-time
+// comparator, buckets in parallel.
+#include <algorithm>
+#include <atomic>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kaiju_gpu.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Seq { std::string id; uint64_t start; uint64_t len; };
+
+int bits_needed(long k) { int i = 0; while (k >> i) ++i; return i; }   // suffixArray.c:57
+
+template <class F> void parallel_chunks(unsigned nt, uint64_t n, F &&fn) {
+  if (nt <= 1 || n < 2) { fn(0, n, 0u); return; }
+  std::vector<std::thread> th;
+  const uint64_t step = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; t++) {
+    const uint64_t b = std::min<uint64_t>(n, t * step), e = std::min<uint64_t>(n, b + step);
+    if (b >= e) break;
+    th.emplace_back([=, &fn]() { fn(b, e, t); });
+  }
+  for (auto &x : th) x.join();
+}
+
+// FASTA reader with the reference's conventions (readFasta.c:35-170): id = header up to the first
+// blank; a record starts at '>' in column 0 (but not directly after a header line); letters are
+// translated case-insensitively, alphabetic characters outside the alphabet become the last
+// letter, everything else is skipped.
+bool read_fasta(const char *path, const signed char *trans, std::vector<Seq> &seqs, std::vector<uint8_t> &T) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) { g_err = std::string("cannot open ") + path; return false; }
+  std::vector<char> buf(1 << 22);
+  setvbuf(fp, nullptr, _IOFBF, 1 << 22);
+  int c;
+  do c = getc_unlocked(fp); while (c != '>' && c != EOF);
+  while (c != EOF) {
+    // header line
+    std::string line;
+    while ((c = getc_unlocked(fp)) != EOF && c != '\n') if (line.size() < 10000) line.push_back((char)c);
+    if (c == EOF) { g_err = "EOF while reading an ID line"; fclose(fp); return false; }
+    size_t e = 0;
+    while (e < line.size() && line[e] != ' ' && line[e] != '\t') e++;
+    Seq s; s.id = line.substr(0, e); s.start = T.size(); s.len = 0;
+    int lastc = 0;
+    while ((c = getc_unlocked(fp)) != EOF) {
+      if (c == '>' && lastc == '\n') break;
+      if (c >= 0 && c < 128 && trans[c] >= 0) { T.push_back((uint8_t)trans[c]); s.len++; }
+      lastc = c;
+    }
+    T.push_back(0);                      // terminator
+    seqs.push_back(std::move(s));
+  }
+  fclose(fp);
+  if (seqs.empty()) { g_err = "no sequences read"; return false; }
+  return true;
+}
+
+// suffix comparison from `depth` on: letters until a difference; two terminators at the same
+// offset belong to different sequences and compare by file order == by position
+struct SufLess {
+  const uint8_t *T;
+  int depth;
+  bool operator()(uint32_t a, uint32_t b) const { return less(a, b); }
+  bool operator()(uint64_t a, uint64_t b) const { return less(a, b); }
+  template <class I> bool less(I a, I b) const {
+    const uint8_t *pa = T + a + depth, *pb = T + b + depth;
+    for (;;) {
+      uint64_t wa, wb;
+      memcpy(&wa, pa, 8); memcpy(&wb, pb, 8);
+      const uint64_t x = wa ^ wb;
+      const uint64_t zero = (wa - 0x0101010101010101ull) & ~wa & 0x8080808080808080ull;   // lowest set bit is exact
+      if (x | zero) {
+        const int dx = x ? __builtin_ctzll(x) >> 3 : 8;        // first differing byte
+        const int dz = zero ? __builtin_ctzll(zero) >> 3 : 8;  // first terminator of a
+        if (dz < dx) return a < b;          // both reach their terminator together: file order
+        return pa[dx] < pb[dx];             // plain difference (a terminator is the smallest symbol)
+      }
+      pa += 8; pb += 8;
+    }
+  }
+};
+
+template <class I>
+int build(const char *faa, const char *out, int threads, int chpt_exp) {
+  // alphabet of kaiju-makedb:373 with the terminator in front (mkbwt.c:read_alphabet)
+  const char alphabet[] = "*ACDEFGHIKLMNPQRSTVWY";
+  const int alen = 21;
+  signed char trans[128];
+  trans[0] = 0;
+  for (int i = 1; i < 128; i++) trans[i] = isalpha(i) ? (signed char)(alen - 1) : (signed char)-1;
+  for (int i = 0; i < alen; i++) { trans[toupper(alphabet[i])] = (signed char)i; trans[tolower(alphabet[i])] = (signed char)i; }
+  // the reference's table maps the terminator character itself ('*') to code 0, i.e. a '*' inside
+  // the FASTA would plant a terminator in the middle of a sequence; it is skipped here
+  trans[(int)'*'] = -1;
+  std::vector<Seq> seqs;
+  std::vector<uint8_t> T;
+  if (!read_fasta(faa, trans, seqs, T)) return KAIJU_GPU_ERR_IO;
+  const uint64_t nseq = seqs.size();
+  const uint64_t tlen = T.size();                 // == bwtlen
+  T.resize(tlen + 16, 0);                         // padding for the word-wise comparator
+  if (sizeof(I) == 4 && tlen >= 0xfffffff0ull) { g_err = "internal: index type too small"; return KAIJU_GPU_ERR_ARG; }
+  const unsigned nt = (unsigned)std::max(1, threads);
+
+  // ---- bucket the letter suffixes by their first two symbols --------------------------------
+  const int NB = 21 * 21;
+  std::vector<uint64_t> bstart(NB + 1, 0);
+  {
+    std::vector<std::vector<uint64_t>> cnt(nt, std::vector<uint64_t>(NB, 0));
+    parallel_chunks(nt, tlen, [&](uint64_t b, uint64_t e, unsigned t) {
+      auto &c = cnt[t];
+      for (uint64_t p = b; p < e; p++) if (T[p]) c[T[p] * 21 + T[p + 1]]++;
+    });
+    for (int k = 0; k < NB; k++) { uint64_t s = 0; for (unsigned t = 0; t < nt; t++) s += cnt[t][k]; bstart[k + 1] = bstart[k] + s; }
+  }
+  const uint64_t nsuf = bstart[NB];
+  if (nsuf + nseq != tlen) { g_err = "internal: suffix count"; return KAIJU_GPU_ERR_ARG; }
+  std::vector<I> SA(nsuf);
+  {
+    // positions enter their bucket in increasing order (needed for the terminator tie rule)
+    std::vector<uint64_t> fill(bstart.begin(), bstart.end() - 1);
+    for (uint64_t p = 0; p < tlen; p++) if (T[p]) SA[fill[T[p] * 21 + T[p + 1]]++] = (I)p;
+  }
+  {
+    std::vector<int> order;
+    for (int k = 0; k < NB; k++) if (bstart[k + 1] - bstart[k] > 1 && (k % 21) != 0) order.push_back(k);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return bstart[a + 1] - bstart[a] > bstart[b + 1] - bstart[b]; });
+    std::atomic<size_t> next(0);
+    auto worker = [&]() {
+      for (;;) {
+        const size_t q = next.fetch_add(1);
+        if (q >= order.size()) break;
+        const int k = order[q];
+        std::sort(SA.begin() + bstart[k], SA.begin() + bstart[k + 1], SufLess{T.data(), 2});
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(worker);
+    worker();
+    for (auto &x : th) x.join();
+  }
+
+  // ---- sequence ranks (order of the whole-sequence suffixes), names in sorted order ---------
+  std::vector<uint8_t> is_start(tlen + 1, 0);
+  for (auto &s : seqs) is_start[s.start] = 1;
+  std::vector<uint64_t> starts(nseq);
+  for (uint64_t i = 0; i < nseq; i++) starts[i] = seqs[i].start;
+  auto seq_index = [&](uint64_t p) { return (uint64_t)(std::upper_bound(starts.begin(), starts.end(), p) - starts.begin() - 1); };
+  std::vector<uint32_t> rank_of(nseq, 0), read_of_rank(nseq, 0);
+  {
+    uint32_t r = 0;
+    for (uint64_t i = 0; i < nseq; i++) if (seqs[i].len == 0) { rank_of[i] = r; read_of_rank[r] = (uint32_t)i; r++; }   // empty sequences sort first
+    for (uint64_t k = 0; k < nsuf; k++) {
+      const uint64_t p = SA[k];
+      if (is_start[p]) { const uint64_t i = seq_index(p); rank_of[i] = r; read_of_rank[r] = (uint32_t)i; r++; }
+    }
+    if (r != nseq) { g_err = "internal: sequence ranks"; return KAIJU_GPU_ERR_ARG; }
+  }
+
+  // ---- BWT -----------------------------------------------------------------------------------
+  std::vector<uint8_t> bwt(tlen);
+  for (uint64_t i = 0; i < nseq; i++) bwt[i] = seqs[i].len ? T[seqs[i].start + seqs[i].len - 1] : 0;
+  parallel_chunks(nt, nsuf, [&](uint64_t b, uint64_t e, unsigned) {
+    for (uint64_t k = b; k < e; k++) { const uint64_t p = SA[k]; bwt[nseq + k] = is_start[p] ? 0 : T[p - 1]; }
+  });
+
+  // ---- suffix array samples (init_suffixArray suffixArray.c:140-180) -------------------------
+  long maxlen = 0;
+  for (auto &s : seqs) if ((long)s.len > maxlen) maxlen = (long)s.len;
+  const int sbits = bits_needed((long)nseq), pbits = bits_needed(maxlen);
+  const int nbytes = (7 + sbits + pbits) / 8;
+  const int64_t ncheck = (int64_t)(tlen >> chpt_exp) - (int64_t)(nseq >> chpt_exp);   // the header value
+  const int64_t mask = (1 << pbits) - 1, check = (1 << chpt_exp) - 1;
+  std::vector<uint8_t> sa((size_t)std::max<int64_t>(ncheck, 0) * nbytes, 0);
+  {
+    const uint64_t step = 1ull << chpt_exp;
+    const uint64_t first = ((nseq + step - 1) >> chpt_exp) << chpt_exp;   // first sampled row >= nseq
+    const uint64_t nsamp = first < tlen ? ((tlen - 1 - first) >> chpt_exp) + 1 : 0;
+    parallel_chunks(nt, nsamp, [&](uint64_t b, uint64_t e, unsigned) {
+      for (uint64_t q = b; q < e; q++) {
+        if ((int64_t)q >= ncheck) break;            // mkfmi only carries ncheck entries over
+        const uint64_t k = first + (q << chpt_exp);
+        const uint64_t p = SA[k - nseq];
+        const uint64_t i = seq_index(p);
+        long val = (long)rank_of[i];
+        val = (val << pbits) + (long)(p - seqs[i].start);
+        uint8_t *c = sa.data() + q * nbytes;
+        for (int n = nbytes; n-- > 0;) { c[n] = (uint8_t)val; val >>= 8; }
+      }
+    });
+  }
+
+  // ---- FMI (fmicommon.h:77-171, compactfmi.c:108-150,399-457) ---------------------------------
+  const int64_t bwtlen = (int64_t)tlen;
+  int N1 = (int)(((bwtlen - 1) >> 16) + 2);
+  if (((int64_t)N1 << 16) == bwtlen) N1 -= 1;
+  int N2 = (int)(((bwtlen - 1) >> 8) + 2);
+  if (((int64_t)N1 << 8) == bwtlen) N2 -= 1;
+  std::vector<int64_t> index1((size_t)N1 * alen, 0);
+  std::vector<uint16_t> index2((size_t)N2 * alen, 0);
+  int64_t total[32] = {0};
+  {
+    int64_t R1 = 0;
+    for (int64_t ii = 0; ii < bwtlen; ++ii) {
+      if (!(ii & 65535)) { R1 = ii >> 16; for (int a = 0; a < alen; a++) index1[(size_t)R1 * alen + a] = total[a]; }
+      if (ii > 0 && !(ii & 255)) {
+        const int64_t R2 = ii >> 8;
+        for (int a = 0; a < alen; a++) index2[(size_t)R2 * alen + a] = (uint16_t)(total[a] - index1[(size_t)R1 * alen + a]);
+      }
+      total[bwt[ii]] += 1;
+    }
+    const int64_t R2 = N2 - 1;
+    for (int a = 0; a < alen; a++) index2[(size_t)R2 * alen + a] = (uint16_t)(total[a] - index1[(size_t)R1 * alen + a]);
+    int64_t *last = &index1[(size_t)(N1 - 1) * alen];
+    last[0] = 0;
+    for (int a = 1; a < alen; a++) last[a] = last[a - 1] + total[a - 1];
+    for (int64_t r = 0; r < N1 - 1; ++r) for (int a = 1; a < alen; a++) index1[(size_t)r * alen + a] += last[a];
+  }
+  // find_startLcode, compactfmi.c:108-150
+  int startLcode[32] = {0};
+  {
+    int maxN[32] = {0};
+    int64_t tot = 0;
+    for (int a = 0; a < alen; a++) tot += total[a];
+    int sum = 0, mx = 0;
+    for (int a = 0; a < alen; a++) {
+      maxN[a] = (int)(256 * ((double)total[a] / tot));
+      if (maxN[a] < 2) maxN[a] = 2;
+      if (maxN[a] > maxN[mx]) mx = a;
+      sum += maxN[a];
+    }
+    if (sum < 256) maxN[mx] += 256 - sum;
+    while (sum > 256) {
+      int mn = 0;
+      for (int a = 1; a < alen; a++) {
+        if (maxN[mn] <= 2) mn = a;
+        if (maxN[a] > 2 && maxN[a] < maxN[mn]) mn = a;
+      }
+      maxN[mn] -= 1;
+      sum -= 1;
+    }
+    startLcode[0] = 0;
+    for (int a = 0; a < alen; a++) startLcode[a + 1] = startLcode[a] + maxN[a];
+    startLcode[alen] = 256;
+  }
+  // FMIrecode, compactfmi.c:399-440: first half of a 256-block stores the number of equal letters
+  // before the position, second half the number after it, saturating at the letter's top code
+  {
+    auto encode = [&](uint8_t c, int n) {
+      const int mx = startLcode[c + 1] - startLcode[c] - 1;
+      if (n > mx) n = mx;
+      return (uint8_t)(startLcode[c] + n);
+    };
+    const uint64_t nblk = ((uint64_t)bwtlen + 255) >> 8;
+    parallel_chunks(nt, nblk, [&](uint64_t b, uint64_t e, unsigned) {
+      int current[32], delta[256];
+      for (uint64_t blk = b; blk < e; blk++) {
+        uint8_t *s = bwt.data() + (blk << 8);
+        const int n = (int)std::min<uint64_t>(256, (uint64_t)bwtlen - (blk << 8));
+        for (int a = 0; a < alen; a++) current[a] = 0;
+        for (int i = 0; i < n; i++) { delta[i] = current[s[i]]; current[s[i]] += 1; }
+        int j = 0;
+        for (; j < 128 && j < n; ++j) s[j] = encode(s[j], delta[j]);
+        for (; j < n; ++j) s[j] = encode(s[j], (current[s[j]] - delta[j]) - 1);
+      }
+    });
+  }
+
+  // ---- write the file (bwt.c:38-44, suffixArray.c:255-275, fmicommon.h:176-186, compactfmi.c:175-178)
+  FILE *fp = fopen(out, "wb");
+  if (!fp) { g_err = std::string("cannot write ") + out; return KAIJU_GPU_ERR_IO; }
+  setvbuf(fp, nullptr, _IOFBF, 1 << 22);
+  auto W = [&](const void *p, size_t n) { return n == 0 || fwrite(p, 1, n, fp) == n; };
+  bool ok = true;
+  const int32_t nseq32 = (int32_t)nseq, alen32 = alen;
+  ok &= W(&bwtlen, 8); ok &= W(&nseq32, 4); ok &= W(&alen32, 4); ok &= W(alphabet, alen);
+  ok &= W(&bwtlen, 8); ok &= W(&ncheck, 8);
+  const int32_t e32 = chpt_exp, nb32 = nbytes, sb32 = sbits, pb32 = pbits;
+  ok &= W(&e32, 4); ok &= W(&nb32, 4); ok &= W(&sb32, 4); ok &= W(&pb32, 4);
+  ok &= W(&mask, 8); ok &= W(&check, 8); ok &= W(&nseq32, 4);
+  for (uint64_t r = 0; r < nseq; r++) {
+    const std::string &id = seqs[read_of_rank[r]].id;
+    const uint8_t l = (uint8_t)std::min<size_t>(255, id.size());
+    ok &= W(&l, 1); ok &= W(id.data(), l);
+  }
+  {
+    std::vector<int32_t> sto(nseq);
+    std::vector<int64_t> sl(nseq);
+    for (uint64_t r = 0; r < nseq; r++) { sto[r] = (int32_t)read_of_rank[r]; sl[r] = (int64_t)seqs[read_of_rank[r]].len; }
+    ok &= W(sto.data(), nseq * 4); ok &= W(sl.data(), nseq * 8);
+  }
+  ok &= W(sa.data(), sa.size());
+  const int32_t n1 = N1, n2 = N2;
+  ok &= W(&alen32, 4); ok &= W(&bwtlen, 8); ok &= W(&n1, 4); ok &= W(&n2, 4);
+  ok &= W(bwt.data(), (size_t)bwtlen);
+  ok &= W(index1.data(), index1.size() * 8);
+  ok &= W(index2.data(), index2.size() * 2);
+  ok &= W(startLcode, (size_t)(alen + 1) * 4);
+  ok &= fclose(fp) == 0;
+  if (!ok) { g_err = "write error"; return KAIJU_GPU_ERR_IO; }
+  return KAIJU_GPU_OK;
+}
+
+}  // namespace
+
+extern "C" int kaiju_build_fmi(const char *faa_path, const char *out_fmi_path, int threads, int chpt_exp) {
+  if (!faa_path || !out_fmi_path || chpt_exp < 0 || chpt_exp > 20) return KAIJU_GPU_ERR_ARG;
+  if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  // 32-bit suffix positions suffice below 4 G symbols; the 64-bit instantiation covers the rest
+  FILE *fp = fopen(faa_path, "rb");
+  if (!fp) { g_err = std::string("cannot open ") + faa_path; return KAIJU_GPU_ERR_IO; }
+  fseeko(fp, 0, SEEK_END);
+  const off_t sz = ftello(fp);
+  fclose(fp);
+  if ((uint64_t)sz < 0xf0000000ull) return build<uint32_t>(faa_path, out_fmi_path, threads, chpt_exp);
+  return build<uint64_t>(faa_path, out_fmi_path, threads, chpt_exp);
+}
+
+extern "C" const char *kaiju_build_fmi_error(void) { return g_err.c_str(); }

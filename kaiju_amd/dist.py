@@ -1,0 +1,98 @@
+"""Multi-GPU layer: reads shard embarrassingly across the GPUs of one node (one process per GPU),
+the index is replicated, and the per-read hit records are collected on rank 0 with ONE gather per
+chunk (RCCL over xGMI when the backend is "nccl").  There is no other exchange on the path
+(SURVEY.md §8e): no reduce, no all-to-all.
+
+Everything here works on CPU tensors with the ``gloo`` backend too, which is how the N>1 logic
+is tested without GPUs (tests/test_distributed.py).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+HIT_BYTES = 184
+
+
+def env_world():
+    """(rank, local_rank, world_size) as set by torch.distributed.run; (0, 0, 1) standalone"""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str):
+    import torch.distributed as dist
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(n_items: int, rank: int, world: int):
+    """contiguous input-order block of a strong-scaling job (block b -> rank b)"""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class HitGatherer:
+    """Collects fixed-size hit records of equally sized chunks on rank 0.
+
+    ``gather(chunk)`` issues one asynchronous ``dist.gather`` (ncclGather-equivalent) and returns
+    immediately so that the next chunk's kernels overlap with the transfer; ``wait()`` drains.
+    On rank 0 ``results`` holds, per call, a list of ``world`` tensors (rank order)."""
+
+    def __init__(self, world: int, rank: int, keep_results: bool = True):
+        self.world, self.rank = world, rank
+        self.pending = []
+        self.results = []
+        self.keep = keep_results
+        self.bytes_gathered = 0
+
+    def gather(self, chunk):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            if self.keep:
+                self.results.append([chunk])
+            return
+        bufs = [torch.empty_like(chunk) for _ in range(self.world)] if self.rank == 0 else None
+        work = dist.gather(chunk, gather_list=bufs, dst=0, async_op=True)
+        self.pending.append((work, bufs, chunk))
+        self.bytes_gathered += chunk.numel() * chunk.element_size() * (self.world - 1)
+        if len(self.pending) > 4:
+            self._retire(self.pending.pop(0))
+
+    def _retire(self, item):
+        work, bufs, _ = item
+        work.wait()
+        if self.rank == 0 and self.keep:
+            self.results.append(bufs)
+
+    def wait(self):
+        while self.pending:
+            self._retire(self.pending.pop(0))
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def hits_from_bytes(buf: np.ndarray):
+    from .api import HIT_DTYPE
+    return np.frombuffer(buf.tobytes(), dtype=HIT_DTYPE)

@@ -1,0 +1,18 @@
+"""Index construction: protein FASTA -> Kaiju ``.fmi`` (the off-line step of kaiju-makedb,
+util/kaiju-makedb:373-375: ``kaiju-mkbwt -a ACDEFGHIKLMNPQRSTVWY -e 3`` + ``kaiju-mkfmi``).
+The file is format-compatible with the reference, which can read it unchanged."""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import api
+
+
+def build_fmi(faa_path: str, out_fmi_path: str, threads: int = 0, exponent: int = 3) -> str:
+    L = api.lib()
+    L.kaiju_build_fmi.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    L.kaiju_build_fmi_error.restype = C.c_char_p
+    rc = L.kaiju_build_fmi(faa_path.encode(), out_fmi_path.encode(), threads, exponent)
+    if rc != 0:
+        raise api.KaijuGpuError(f"kaiju_build_fmi failed ({rc}): {L.kaiju_build_fmi_error().decode()}")
+    return out_fmi_path
