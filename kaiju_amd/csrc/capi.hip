@@ -43,19 +43,43 @@ __device__ __forceinline__ void load_tables(ConstTables &s_ct, const ConstTables
 __global__ void __launch_bounds__(kBlock)
 k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err) {
   __shared__ ConstTables s_ct;
+  __shared__ int64_t s_entg[13];
+  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
   load_tables(s_ct, g_ct);
   const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
   if (r >= b.n_reads) return;
   uint32_t e = 0;
-  build_fragments(s_ct, p, st, b, sq, r, &e);
+  build_fragments(s_ct, p, seg_ctx(st, s_entg, nullptr), b, sq, r, &e);
   if (e) atomicOr(err, e);
 }
 
-// SEG pass: one lane per fragment that stage 1 flagged (count lives in device memory)
+// one wavefront per fragment: lanes share the sub-windows of s_Trim
+struct CoopWave {
+  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+  __device__ __forceinline__ int width() const { return 64; }
+  __device__ __forceinline__ void reduce_min(double &prob, int &t) const {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double op = __shfl_xor(prob, o, 64);
+      const int ot = __shfl_xor(t, o, 64);
+      if (op < prob || (op == prob && ot < t)) { prob = op; t = ot; }
+    }
+  }
+};
+
+// SEG pass: one wavefront per fragment that stage 1 flagged (count lives in device memory)
 __global__ void __launch_bounds__(kBlock)
 k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
+  __shared__ int64_t s_entg[13];
+  __shared__ double s_lnf[kSegLnf];
+  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
+  if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
+  __syncthreads();
+  const SegCtx cx = seg_ctx(st, s_entg, s_lnf);
+  const CoopWave coop;
   const uint32_t n = min(*sq.count, sq.cap);
-  for (uint32_t s = blockIdx.x * kBlock + threadIdx.x; s < n; s += gridDim.x * kBlock) seg_compute(st, b, p, sq, s);
+  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+  for (uint32_t s = wave; s < n; s += nwaves) seg_compute(cx, coop, b, p, sq, s);
 }
 
 // MEM: apply the SEG records to the fragment lists
@@ -368,6 +392,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   sq.items = static_cast<SegWork *>(c->seg_items.p); sq.recs = static_cast<SegRec *>(c->seg_recs.p);
   sq.count = cnt + 4; sq.cap = (uint32_t)seg_cap;
   KJ_HIP(hipMemsetAsync(cnt, 0, 64, s));
+  if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
   if (n > 0) {

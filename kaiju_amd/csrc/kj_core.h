@@ -220,32 +220,64 @@ KJ_HD uint32_t codon_rev(const ConstTables &t, const uint8_t *s) {
 // exactly the reference's operation order (adds/subtracts of table entries, no
 // contraction).  Letters: the peptide buffer holds index codes 1..20; SEG only
 // looks at letter identity, so code-1 (0..19) is used directly.
+//
+// Work decomposition on the device: a fragment is handled by one wavefront.  The scan
+// for trigger windows is cheap and runs redundantly in all lanes (uniform control
+// flow); the expensive part, s_Trim's search over every sub-window of a raw segment,
+// is spread over the lanes (one sub-window per lane and round, letter counts packed
+// into two 64-bit registers) and finished with a wave-wide lexicographic
+// (probability, visiting order) minimum — which is what the reference's sequential
+// "strictly smaller wins" loop computes.
 constexpr int kSegWindow = 12, kSegDown = 5, kSegUp = 7, kSegMaxTrim = 50;
 constexpr int kSegMaxRegions = 32;
-constexpr int kSegHist = 255;          // histogram fast path for windows up to this length
+constexpr int kSegPacked = 63;         // windows up to this length use the packed-count path
+constexpr int kSegLnf = 64;            // ln(n!) entries mirrored in LDS
 
 #define KJ_SL(s, i) ((uint32_t)(s)[(i)] - 1u)
+
+struct SegCtx {                        // tables as the SEG code sees them (LDS copies on the device)
+  const int64_t *ent_g;                // [13]
+  int64_t ent_locut, ent_hicut;
+  const double *lnf;                   // [kSegLnf] head of the ln(n!) table
+  const double *lnfact;                // whole table (global memory)
+  uint32_t lnfact_n;
+};
+KJ_HD SegCtx seg_ctx(const SegTables &st, const int64_t *ent_g, const double *lnf) {
+  SegCtx c; c.ent_g = ent_g; c.ent_locut = st.ent_locut; c.ent_hicut = st.ent_hicut;
+  c.lnf = lnf; c.lnfact = st.lnfact; c.lnfact_n = st.lnfact_n;
+  return c;
+}
+
+// how the sub-windows of s_Trim are spread: one lane (host emulation) or a wavefront
+struct CoopSerial {
+  KJ_HD int lane() const { return 0; }
+  KJ_HD int width() const { return 1; }
+  KJ_HD void reduce_min(double &, int &) const {}
+};
 
 struct SegWin {              // 12-window: nibble-packed counts of the 20 letters + entropy score
   uint64_t c0, c1;
   int64_t score;
 };
-KJ_HD void segwin_add(SegWin &w, const SegTables &st, uint32_t a, int d) {
+KJ_HD void segwin_add(SegWin &w, const SegCtx &cx, uint32_t a, int d) {
   const uint32_t old = a < 16 ? (uint32_t)(w.c0 >> (4 * a)) & 15u : (uint32_t)(w.c1 >> (4 * (a - 16))) & 15u;
-  w.score += st.ent_g[(int)old + d] - st.ent_g[old];
+  w.score += cx.ent_g[(int)old + d] - cx.ent_g[old];
   if (a < 16) w.c0 += (uint64_t)(int64_t)d << (4 * a);
   else w.c1 += (uint64_t)(int64_t)d << (4 * (a - 16));
 }
-KJ_HD void segwin_open(SegWin &w, const SegTables &st, const uint8_t *s, int start) {
+KJ_HD void segwin_open(SegWin &w, const SegCtx &cx, const uint8_t *s, int start) {
   w.c0 = w.c1 = 0; w.score = 0;
-  for (int i = 0; i < kSegWindow; i++) segwin_add(w, st, KJ_SL(s, start + i), +1);
+  for (int i = 0; i < kSegWindow; i++) segwin_add(w, cx, KJ_SL(s, start + i), +1);
 }
-KJ_HD void segwin_shift(SegWin &w, const SegTables &st, const uint8_t *s, int start) {   // start -> start+1
-  segwin_add(w, st, KJ_SL(s, start), -1);
-  segwin_add(w, st, KJ_SL(s, start + kSegWindow), +1);
+KJ_HD void segwin_shift(SegWin &w, const SegCtx &cx, const uint8_t *s, int start) {   // start -> start+1
+  segwin_add(w, cx, KJ_SL(s, start), -1);
+  segwin_add(w, cx, KJ_SL(s, start + kSegWindow), +1);
 }
 
-KJ_HD double kj_lnfact(const SegTables &st, int n) { return st.lnfact[(uint32_t)n < st.lnfact_n ? n : st.lnfact_n - 1]; }
+KJ_HD double kj_lnfact(const SegCtx &cx, int n) {
+  if (n < kSegLnf) return cx.lnf[n];
+  return cx.lnfact[(uint32_t)n < cx.lnfact_n ? n : cx.lnfact_n - 1];
+}
 
 KJ_HD double seg_finish_prob(double ans1, double ans2, int total) {
   const double totseq = ((double)total) * 2.9957322735539909;   // kLn20, blast_seg.c:2193
@@ -257,88 +289,100 @@ KJ_HD double seg_finish_prob(double ans1, double ans2, int total) {
 #endif
 }
 
-// ln P0 from the histogram of counts (s_GetProb blast_seg.c:1944-1967, s_LnAss :1890-1933,
-// s_LnPerm :1864-1879).  hist[v] = number of letters occurring v times in the window.
-KJ_HD double seg_getprob_hist(const SegTables &st, const uint8_t *hist, int vmax, int total) {
-  double ans1 = st.lnfact[20];
-  int nz = 0;
-  for (int v = vmax; v >= 1; v--) {
-    const int n = hist[v];
-    if (n) { ans1 -= st.lnfact[n]; nz += n; }
-  }
-  if (nz > 0 && nz < 20) ans1 -= st.lnfact[20 - nz];
-  double ans2 = kj_lnfact(st, total);
-  for (int v = vmax; v >= 1; v--)
-    for (int n = hist[v]; n > 0; n--) ans2 -= kj_lnfact(st, v);
-  return seg_finish_prob(ans1, ans2, total);
+// number of 6-bit fields of x (10 fields) that are zero
+KJ_HD int zero_fields6(uint64_t x) {
+  const uint64_t LOW5 = 0x7DF7DF7DF7DF7DFull;     // low five bits of each field (bits 0..59)
+  const uint64_t HI = 0x820820820820820ull;       // top bit of each field
+  const uint64_t nzmask = (((x & LOW5) + LOW5) | x) & HI;
+  return 10 - (int)popc64(nzmask);
 }
-// same from the composition itself (any window length): visits counts in descending order
-KJ_HD double seg_getprob_comp(const SegTables &st, const uint32_t *comp, int total) {
-  double ans1 = st.lnfact[20];
-  double ans2 = kj_lnfact(st, total);
+
+// ln P0 of the sub-window s[i .. i+l) (s_GetProb blast_seg.c:1944-1967 with s_LnAss :1890-1933 and
+// s_LnPerm :1864-1879 on the descending state vector), l <= kSegPacked
+KJ_HD double seg_window_prob_packed(const SegCtx &cx, const uint8_t *s, int l, int i) {
+  uint64_t c0 = 0, c1 = 0;             // 6-bit counts, letters 0..9 and 10..19
+  for (int k = 0; k < l; k++) {
+    const uint32_t a = KJ_SL(s, i + k);
+    if (a < 10) c0 += 1ull << (6 * a); else c1 += 1ull << (6 * (a - 10));
+  }
+  const uint64_t REP = 0x041041041041041ull;      // 1 in every field
+  double ans1 = cx.lnf[20];
+  double ans2 = kj_lnfact(cx, l);
+  int nz = 0, rem = l;
+  for (int v = l; v >= 1 && rem > 0; v--) {       // descending count value
+    const uint64_t V = REP * (uint64_t)v;
+    const int n = zero_fields6(c0 ^ V) + zero_fields6(c1 ^ V);   // letters occurring exactly v times
+    if (n) {
+      ans1 -= cx.lnf[n];
+      nz += n;
+      rem -= n * v;
+      const double lv = cx.lnf[v];
+      for (int q = 0; q < n; q++) ans2 -= lv;
+    }
+  }
+  if (nz > 0 && nz < 20) ans1 -= cx.lnf[20 - nz];
+  return seg_finish_prob(ans1, ans2, l);
+}
+// the same for windows of any length
+KJ_HD double seg_window_prob_generic(const SegCtx &cx, const uint8_t *s, int l, int i) {
+  uint32_t comp[20];
+  for (int a = 0; a < 20; a++) comp[a] = 0;
+  for (int k = 0; k < l; k++) comp[KJ_SL(s, i + k)]++;
+  double ans1 = cx.lnf[20];
+  double ans2 = kj_lnfact(cx, l);
   int nz = 0;
-  uint32_t bound = 0xFFFFFFFFu;           // next distinct value strictly below bound
+  uint32_t bound = 0xFFFFFFFFu;                   // next distinct value strictly below bound
   for (;;) {
     uint32_t v = 0; int n = 0;
     for (int a = 0; a < 20; a++) if (comp[a] < bound && comp[a] > v) v = comp[a];
     if (v == 0) break;
     for (int a = 0; a < 20; a++) if (comp[a] == v) n++;
-    ans1 -= st.lnfact[n]; nz += n;
-    for (int q = 0; q < n; q++) ans2 -= kj_lnfact(st, (int)v);
+    ans1 -= cx.lnf[n]; nz += n;
+    const double lv = kj_lnfact(cx, (int)v);
+    for (int q = 0; q < n; q++) ans2 -= lv;
     bound = v;
   }
-  if (nz > 0 && nz < 20) ans1 -= st.lnfact[20 - nz];
-  return seg_finish_prob(ans1, ans2, total);
+  if (nz > 0 && nz < 20) ans1 -= cx.lnf[20 - nz];
+  return seg_finish_prob(ans1, ans2, l);
 }
 
-// s_Trim (blast_seg.c:1971-2015) on s[0..len): trimmed [lend, rend] relative to s
-KJ_HD void seg_trim(const SegTables &st, const uint8_t *s, int len, int &lend_out, int &rend_out) {
-  int lend = 0, rend = len - 1, minlen = 1;
+// s_Trim (blast_seg.c:1971-2015) on s[0..len): trimmed [lend, rend] relative to s.  The reference
+// visits window lengths len, len-1, ..., minlen+1 and for each all start positions left to right,
+// keeping a window only if its probability is strictly smaller than the best so far; with the
+// visiting order t = d(d+1)/2 + i (d = len - l) that is the lexicographic minimum of (prob, t).
+template <class Coop>
+KJ_HD void seg_trim(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len, int &lend_out, int &rend_out) {
+  int minlen = 1;
   if (len - kSegMaxTrim > minlen) minlen = len - kSegMaxTrim;
-  double minprob = 1.;
-  if (len <= kSegHist) {
-    uint8_t comp[20];
-    uint8_t hist[kSegHist + 1];
-    for (int l = len; l > minlen; l--) {
-      for (int a = 0; a < 20; a++) comp[a] = 0;
-      for (int v = 0; v <= l; v++) hist[v] = 0;
-      int vmax = 0;
-      for (int i = 0; i < l; i++) comp[KJ_SL(s, i)]++;
-      for (int a = 0; a < 20; a++) { hist[comp[a]]++; if (comp[a] > vmax) vmax = comp[a]; }
-      for (int i = 0;; i++) {
-        const double prob = seg_getprob_hist(st, hist, vmax, l);
-        if (prob < minprob) { minprob = prob; lend = i; rend = l + i - 1; }
-        if (i + 1 + l > len) break;
-        const uint32_t o = KJ_SL(s, i), n = KJ_SL(s, i + l);
-        hist[comp[o]]--; comp[o]--; hist[comp[o]]++;
-        hist[comp[n]]--; comp[n]++; hist[comp[n]]++;
-        if (comp[n] > vmax) vmax = comp[n];
-        while (vmax > 0 && hist[vmax] == 0) vmax--;
-      }
-    }
-  } else {
-    uint32_t comp[20];
-    for (int l = len; l > minlen; l--) {
-      for (int a = 0; a < 20; a++) comp[a] = 0;
-      for (int i = 0; i < l; i++) comp[KJ_SL(s, i)]++;
-      for (int i = 0;; i++) {
-        const double prob = seg_getprob_comp(st, comp, l);
-        if (prob < minprob) { minprob = prob; lend = i; rend = l + i - 1; }
-        if (i + 1 + l > len) break;
-        comp[KJ_SL(s, i)]--; comp[KJ_SL(s, i + l)]++;
-      }
-    }
+  const int D = len - minlen;                     // number of window lengths
+  const int W = D * (D + 1) / 2;                  // number of windows
+  double best = 1.;
+  int best_t = 0x7fffffff;
+  int d = 0, base = 0;                            // base = d(d+1)/2 <= t
+  for (int t = coop.lane(); t < W; t += coop.width()) {
+    while (base + d + 1 <= t) { base += d + 1; d++; }
+    const int i = t - base, l = len - d;
+    const double prob = l <= kSegPacked ? seg_window_prob_packed(cx, s, l, i) : seg_window_prob_generic(cx, s, l, i);
+    if (prob < best) { best = prob; best_t = t; }
+  }
+  coop.reduce_min(best, best_t);
+  int lend = 0, rend = len - 1;
+  if (best_t != 0x7fffffff) {
+    int dd = 0, bb = 0;
+    while (bb + dd + 1 <= best_t) { bb += dd + 1; dd++; }
+    lend = best_t - bb;
+    rend = (len - dd) + lend - 1;
   }
   lend_out = lend; rend_out = rend;
 }
 
 // One level of s_SegSeq (blast_seg.c:2027-2113) on s[0..len).  At the top level
-// (`top` set) a trigger window lying left of its trimmed segment starts a second scan of
+// (`TOP`) a trigger window lying left of its trimmed segment starts a second scan of
 // the left remainder, of which only the LAST segment survives (:2093-2097: the head of
 // the nested list is linked in, its tail is dropped); the nested scan therefore never
 // needs to recurse itself.  Segments are appended in creation order.
-template <bool TOP>
-KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset,
+template <bool TOP, class Coop>
+KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len, int offset,
                    int32_t *beg, int32_t *end, int n, int cap, bool &overflow) {
   if (len < kSegWindow) return n;
   const int first = kSegDown, last = len - kSegUp;
@@ -346,17 +390,17 @@ KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset,
   SegWin w{0, 0, 0};
   int wi = -1000;                        // position the window w is centred at
   for (int i = first; i <= last; i++) {
-    if (wi + 1 == i) segwin_shift(w, st, s, wi - first);
-    else if (wi != i) segwin_open(w, st, s, i - first);
+    if (wi + 1 == i) segwin_shift(w, cx, s, wi - first);
+    else if (wi != i) segwin_open(w, cx, s, i - first);
     wi = i;
-    if (w.score > st.ent_locut) continue;                 // H > locut: no trigger
+    if (w.score > cx.ent_locut) continue;                 // H > locut: no trigger
     // s_FindLow (:1810-1822): down from i to lowlim while H <= hicut
     int loi = i;
     {
       SegWin b;
       while (loi - 1 >= lowlim) {
-        segwin_open(b, st, s, loi - 1 - first);
-        if (b.score > st.ent_hicut) break;
+        segwin_open(b, cx, s, loi - 1 - first);
+        if (b.score > cx.ent_hicut) break;
         loi--;
       }
     }
@@ -365,14 +409,14 @@ KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset,
     {
       SegWin f = w;
       while (hii + 1 <= last) {
-        segwin_shift(f, st, s, hii - first);
-        if (f.score > st.ent_hicut) break;
+        segwin_shift(f, cx, s, hii - first);
+        if (f.score > cx.ent_hicut) break;
         hii++;
       }
     }
     const int rawleft = loi - kSegDown, rawright = hii + kSegUp - 1;
     int tl, tr;
-    seg_trim(st, s + rawleft, rawright - rawleft + 1, tl, tr);
+    seg_trim(cx, coop, s + rawleft, rawright - rawleft + 1, tl, tr);
     const int leftend = rawleft + tl, rightend = rawleft + tr;
     if constexpr (TOP) {
       if (i + kSegUp - 1 < leftend) {
@@ -380,7 +424,7 @@ KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset,
         // its most recent segment, which is all that survives in the reference
         int32_t tb[1], te[1];
         bool ov = false;
-        const int k = seg_scan<false>(st, s + rawleft, leftend - rawleft, offset + rawleft, tb, te, 0, 1, ov);
+        const int k = seg_scan<false>(cx, coop, s + rawleft, leftend - rawleft, offset + rawleft, tb, te, 0, 1, ov);
         if (k > 0) {
           if (n < cap) { beg[n] = tb[0]; end[n] = te[0]; n++; } else overflow = true;
         }
@@ -398,10 +442,11 @@ KJ_HD int seg_scan(const SegTables &st, const uint8_t *s, int len, int offset,
 }
 
 // SeqBufferSeg (blast_seg.c:2278-2332).  Writes the merged regions in ascending order.
-static KJ_HD_NOINLINE int seg_regions(const SegTables &st, const uint8_t *s, int len, int32_t *left,
-                                      int32_t *right, bool &overflow) {
+template <class Coop>
+KJ_HD int seg_regions(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len,
+                      int32_t *left, int32_t *right, bool &overflow) {
   int32_t b[kSegMaxRegions], e[kSegMaxRegions];
-  const int n = seg_scan<true>(st, s, len, 0, b, e, 0, kSegMaxRegions, overflow);
+  const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, kSegMaxRegions, overflow);
   if (n == 0) return 0;
   // the reference's list is in reverse creation order; s_MergeSegs (:2122-2152, hilenmin 0)
   // walks it from the head and merges a node with its successor while they overlap
@@ -514,26 +559,29 @@ KJ_HD void translate_mate(const ConstTables &t, const Params &p, const uint8_t *
 
 // does any 12-window of the fragment reach the trigger entropy (H <= locut)?  Exactly then
 // SeqBufferSeg reports at least one region (s_SegSeq, blast_seg.c:2061).
-KJ_HD bool seg_triggers(const SegTables &st, const uint8_t *s, int len) {
+KJ_HD bool seg_triggers(const SegCtx &cx, const uint8_t *s, int len) {
   if (len < kSegWindow) return false;
   SegWin w{0, 0, 0};
-  segwin_open(w, st, s, 0);
-  if (w.score <= st.ent_locut) return true;
+  segwin_open(w, cx, s, 0);
+  if (w.score <= cx.ent_locut) return true;
   for (int start = 0; start + kSegWindow < len; start++) {
-    segwin_shift(w, st, s, start);
-    if (w.score <= st.ent_locut) return true;
+    segwin_shift(w, cx, s, start);
+    if (w.score <= cx.ent_locut) return true;
   }
   return false;
 }
 
-// the SEG pass proper: regions of one flagged fragment -> record
-KJ_HD void seg_compute(const SegTables &st, const Batch &b, const Params &p, const SegQueue &sq, uint32_t slot) {
+// the SEG pass proper: regions of one flagged fragment -> record (written by lane 0 of the team)
+template <class Coop>
+KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const Params &p, const SegQueue &sq,
+                       uint32_t slot) {
   const SegWork wk = sq.items[slot];
   const Frag f = b.frags[frag_base(b.off, wk.read, p.m) + wk.frag];
   const uint8_t *pep = b.pep + pep_base(b.off, wk.read);
   int32_t left[kSegMaxRegions], right[kSegMaxRegions];
   bool ov = false;
-  const int n = seg_regions(st, pep + f.start, (int)f.len, left, right, ov);
+  const int n = seg_regions(cx, coop, pep + f.start, (int)f.len, left, right, ov);
+  if (coop.lane() != 0) return;
   SegRec rec;
   rec.overflow = (ov || n > kSegRecRegions || f.len > 65535u) ? 1 : 0;
   rec.n = (uint16_t)(n > kSegRecRegions ? kSegRecRegions : n);
@@ -573,7 +621,7 @@ struct FragAppend {
 };
 
 // stage 1 for read r: translation, fragment list in queue order, SEG trigger detection
-KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegTables &st, const Batch &b,
+KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &cx, const Batch &b,
                            const SegQueue &sq, uint32_t r, uint32_t *err_flags) {
   const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
   const uint32_t len1 = (uint32_t)(o1 - o0), len2 = (uint32_t)(o2 - o1);
@@ -589,7 +637,7 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegTable
     if (b.paired && len2 >= m3) translate_mate(t, p, b.seqs + o1, len2, pep, 6 * (len1 / 3 + 1), list, n, cap);
     if (p.seg) {
       for (uint32_t k = 0; k < n; k++) {
-        if (seg_triggers(st, pep + list[k].start, (int)list[k].len)) {
+        if (seg_triggers(cx, pep + list[k].start, (int)list[k].len)) {
           const uint32_t slot = append_slot(sq.count);
           if (slot < sq.cap) {
             SegWork wk; wk.read = r; wk.frag = k;

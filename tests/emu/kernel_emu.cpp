@@ -55,7 +55,8 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   std::vector<uint8_t> codes((size_t)len + 1);
   for (int i = 0; i < len; i++) codes[(size_t)i] = ix->packed.trans[(unsigned char)aa[i] & 127];
   bool ov = false;
-  int n = seg_regions(ix->st, codes.data(), len, left, right, ov);
+  const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact);
+  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov);
   return ov ? -1 : n;
 }
 
@@ -76,6 +77,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   std::vector<Frag> frags((size_t)frag_base(off, n, p.m) + 8);
   std::vector<uint32_t> nfrag(n);
   std::vector<Hit> hits(n);
+  memset(hits.data(), 0, sizeof(Hit) * n);
   b.pep = pep.data(); b.frags = frags.data(); b.nfrag = nfrag.data(); b.hits = hits.data();
   uint32_t err = 0;
   // stage 1 -> SEG pass -> (MEM) apply, exactly the kernel sequence of capi.hip
@@ -84,9 +86,10 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   std::vector<SegWork> seg_items(seg_cap);
   std::vector<SegRec> seg_recs(seg_cap);
   SegQueue sq{seg_items.data(), seg_recs.data(), &seg_count, seg_cap};
-  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, ix->st, b, sq, r, &err);
+  const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact);
+  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, cx, b, sq, r, &err);
   if (p.seg) {
-    for (uint32_t s = 0; s < seg_count && s < seg_cap; s++) seg_compute(ix->st, b, p, sq, s);
+    for (uint32_t s = 0; s < seg_count && s < seg_cap; s++) seg_compute(cx, CoopSerial{}, b, p, sq, s);
     if (p.mode == 0) for (uint32_t r = 0; r < n; r++) seg_apply_mem(ix->ct, p, b, sq, r, &err);
   }
   if (frag_dump) {

@@ -1,0 +1,25 @@
+"""Classify a prepared workload a few times (run this one under rocprofv3).
+usage: prof_run.py <dir> <mode> <seg> <reps> [chunk]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from kaiju_amd import api, synth  # noqa: E402
+
+W, mode, seg, reps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+reads = np.load(f"{W}/reads.npy")
+if len(sys.argv) > 5:
+    reads = reads[: int(sys.argv[5])]
+seqs, off = synth.pack_reads(reads)
+index = api.Index(f"{W}/db.fmi")
+clf = api.Classifier(index, api.default_params(mode, seg=seg))
+for _ in range(reps):
+    hits = clf.classify(seqs, off)
+    st = clf.stats()
+    print(f"{mode} seg={seg} n={len(reads)}: translate {st.ms_translate:.2f} seg {st.ms_seg:.2f} [{st.n_seg_fragments}] "
+          f"search {st.ms_search:.2f} retry {st.ms_retry:.2f} [{st.n_overflow_retries}] total {st.ms_total:.2f} ms "
+          f"-> {len(reads)/st.ms_total*1e3:,.0f} reads/s", flush=True)
+print("hit fraction", float((hits['n_ids'] > 0).mean()))
