@@ -33,13 +33,30 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+    if force or needs_build():
+        cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    build_cli(force=force, verbose=verbose)
+    return LIB
+
+
+CLI_SRC = os.path.join(CSRC, "host", "kaiju_main.cpp")
+CLI = os.path.join(HERE, "bin", "kaiju")
+
+
+def build_cli(force=False, verbose=False):
+    """the drop-in `kaiju` command (host C++ over the C-ABI)"""
+    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(LIB)):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-o", CLI, CLI_SRC, "-L" + HERE, "-lkaiju_gpu", "-lz", "-lpthread",
+           "-Wl,-rpath,$ORIGIN/.."]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return CLI
 
 
 if __name__ == "__main__":

@@ -1,0 +1,60 @@
+"""The drop-in `kaiju` command (kaiju_amd/bin/kaiju) against the reference binary's output on
+the golden reads: same option letters, same lines (columns 1-5 of the -v output), input order."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import util
+from kaiju_amd import build
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(tmp_path, golden, args, name):
+    out = str(tmp_path / name)
+    cmd = [build.build_cli(), "-t", golden.nodes, "-f", golden.fmi, "-o", out, "-v"] + args
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def first5(path):
+    rows = []
+    with open(path) as f:
+        for line in f:
+            p = line.rstrip("\n").split("\t")
+            rows.append(tuple(p[:5]) if p[0] == "C" else tuple(p[:3]))
+    return rows
+
+
+@pytest.mark.parametrize("mode,seg", [("mem", 1), ("mem", 0), ("greedy", 1), ("greedy", 0)])
+def test_cli_single_end(gpu_lib, golden, tmp_path, mode, seg):
+    args = ["-i", os.path.join(golden.dir, "reads.fq"), "-a", mode, "-z", "4"] + ([] if seg else ["-X"])
+    out = run_cli(tmp_path, golden, args, "o.tsv")
+    assert first5(out) == first5(os.path.join(golden.dir, f"ref_{mode}_{seg}.tsv"))
+
+
+def test_cli_paired_gz_and_options(gpu_lib, golden, tmp_path):
+    p1, p2 = str(tmp_path / "p1.fq.gz"), str(tmp_path / "p2.fq.gz")
+    for src, dst in (("pairs_1.fq", p1), ("pairs_2.fq", p2)):
+        with open(os.path.join(golden.dir, src), "rb") as fi, gzip.open(dst, "wb") as fo:
+            shutil.copyfileobj(fi, fo)
+    out = run_cli(tmp_path, golden, ["-i", p1, "-j", p2, "-a", "greedy"], "pe.tsv")
+    assert first5(out) == first5(os.path.join(golden.dir, "ref_greedy_1_pe.tsv"))
+    out = run_cli(tmp_path, golden, ["-i", os.path.join(golden.dir, "reads.fq"), "-a", "greedy", "-e", "5", "-s", "50",
+                                     "-E", "10"], "e5.tsv")
+    assert first5(out) == first5(os.path.join(golden.dir, "ref_greedy_e5_s50.tsv"))
+
+
+def test_cli_fasta_input(gpu_lib, golden, tmp_path):
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "w") as f:
+        for n, r in zip(golden.names, golden.reads):
+            s = r.decode()
+            f.write(f">{n} some description/1\n")
+            for k in range(0, len(s), 60):          # wrapped sequence lines
+                f.write(s[k:k + 60] + "\n")
+    out = run_cli(tmp_path, golden, ["-i", fa, "-a", "mem"], "fa.tsv")
+    assert first5(out) == first5(os.path.join(golden.dir, "ref_mem_1.tsv"))
