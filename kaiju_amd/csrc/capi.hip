@@ -94,26 +94,37 @@ k_seg_apply(const ConstTables *__restrict__ g_ct, Params p, Batch b, SegQueue sq
   if (e) atomicOr(err, e);
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
-  __shared__ uint8_t s_win[kBlock * kWinStride];
+template <class P>
+__device__ __forceinline__ void mem_body(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
+                                         SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneScratch ls;
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
-  mem_lane(ix, p, b, wl, ls);
+  mem_lane<P>(ix, p, b, wl, ls);
 }
+// 32-bit suffix-array positions (indexes below 2^32 symbols: half the address arithmetic)
+__global__ void __launch_bounds__(kBlock)
+k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint32_t>(ix, p, b, wl, si_all, si_cap); }
+// 64-bit positions (refseq-scale indexes)
+__global__ void __launch_bounds__(kBlock)
+k_mem_wide(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint64_t>(ix, p, b, wl, si_all, si_cap); }
+// the same lanes over the device-side retry list, with worst-case scratch (separate symbol so
+// that profiles list the two passes separately)
+__global__ void __launch_bounds__(kBlock)
+k_mem_retry(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint64_t>(ix, p, b, wl, si_all, si_cap); }
 
 struct GreedyArrays {
   GItem *pool; uint16_t *ord; GMatch *matches; GBest *best;
   uint32_t pool_cap, match_cap;
 };
 
-__global__ void __launch_bounds__(kBlock)
-k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl,
-         GreedyArrays ga) {
-  __shared__ uint8_t s_win[kBlock * kWinStride];
+__device__ __forceinline__ void greedy_body(const DevIndex &ix, const ConstTables *__restrict__ g_ct, const Params &p,
+                                            const SegQueue &sq, const Batch &b, const WorkList &wl,
+                                            const GreedyArrays &ga) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
   __shared__ ConstTables s_ct;
   load_tables(s_ct, g_ct);
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -124,6 +135,14 @@ k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue s
   gs.best = ga.best + lane * 64;
   gs.win = s_win + threadIdx.x * kWinStride;
   greedy_lane(ix, s_ct, p, sq, b, wl, gs);
+}
+__global__ void __launch_bounds__(kBlock)
+k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays ga) {
+  greedy_body(ix, g_ct, p, sq, b, wl, ga);
+}
+__global__ void __launch_bounds__(kBlock)
+k_greedy_retry(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays ga) {
+  greedy_body(ix, g_ct, p, sq, b, wl, ga);
 }
 
 static_assert(sizeof(ConstTables) % 4 == 0, "ConstTables is copied as dwords");
@@ -215,6 +234,8 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
   DevIndex &d = ix->dev;
   if ((rc = upload(ix.get(), pk.blocks, &d.blocks))) return rc;
   if ((rc = upload(ix.get(), pk.sb, &d.sb))) return rc;
+  d.sb32 = nullptr;
+  if (!pk.sb32.empty() && (rc = upload(ix.get(), pk.sb32, &d.sb32))) return rc;
   if ((rc = upload(ix.get(), pk.sa_iseq, &d.sa_iseq))) return rc;
   if ((rc = upload(ix.get(), pk.seq_taxid, &d.seq_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.seq_valid, &d.seq_valid))) return rc;
@@ -228,6 +249,11 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
   ix->d_ct = const_cast<ConstTables *>(dct);
   for (int a = 0; a < 22; a++) d.C[a] = pk.C[a];
   d.bwtlen = pk.bwtlen; d.n_sa = pk.n_sa; d.sa_skip = pk.sa_skip; d.nseq = pk.nseq; d.chpt_exp = pk.chpt_exp;
+  d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k;
+  if (pk.kmer_k) {
+    if (!pk.kmer32.empty()) { if ((rc = upload(ix.get(), pk.kmer32, &d.kmer32))) return rc; }
+    else if ((rc = upload(ix.get(), pk.kmer64, &d.kmer64))) return rc;
+  }
   kaiju_gpu_index_info &inf = ix->info;
   memset(&inf, 0, sizeof inf);
   inf.bwtlen = (int64_t)pk.bwtlen; inf.nseq = (int32_t)pk.nseq; inf.alen = (int32_t)pk.alen;
@@ -286,7 +312,7 @@ struct kaiju_gpu_ctx {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool ev_valid = false;
   int n_cu = 0, blocks_main = 0, blocks_retry = 0;
-  DevBuf pep, frags, nfrag, counters, retry_list, seg_items, seg_recs;
+  DevBuf pep, frags, meta, counters, retry_list, seg_items, seg_recs;
   DevBuf scratch_main[5], scratch_retry[5];
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
   kaiju_gpu_stats stats{};
@@ -294,7 +320,7 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &nfrag, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits};
+    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 5; i++) { if (scratch_main[i].p) (void)hipFree(scratch_main[i].p); if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p); }
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
@@ -371,18 +397,19 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if (max_read_len == 0) max_read_len = 1024;
   const uint64_t max_pair = (uint64_t)max_read_len * (paired ? 2 : 1);
   // stage buffers
-  const uint64_t pep_bytes = 2 * seq_bytes + 24ull * n + 8 + 64;
+  const uint64_t pep_bytes = 2 * seq_bytes + 32ull * n + 16 + 192;   // pep_base() + window over-read slack
   const uint64_t n_frag_slots = 2 * ((2 * seq_bytes) / (p.m + 1) + 7ull * n) + 8;
   int rc;
   if ((rc = ensure(c->pep, pep_bytes))) return rc;
   if ((rc = ensure(c->frags, n_frag_slots * sizeof(Frag)))) return rc;
-  if ((rc = ensure(c->nfrag, (size_t)n * 4 + 16))) return rc;
+  if (n_frag_slots >= 0xffffffffull) return fail(KAIJU_GPU_ERR_UNSUPPORTED, "batch too large: split it (fragment slots exceed 2^32)");
+  if ((rc = ensure(c->meta, (size_t)n * sizeof(ReadMeta) + 16))) return rc;
   if ((rc = ensure(c->counters, 64))) return rc;
   if ((rc = ensure(c->retry_list, (size_t)n * 4 + 16))) return rc;
   Batch b;
   b.seqs = static_cast<const uint8_t *>(d_seqs); b.off = d_off; b.n_reads = n; b.paired = paired ? 1 : 0;
   b.pep = static_cast<uint8_t *>(c->pep.p); b.frags = static_cast<Frag *>(c->frags.p);
-  b.nfrag = static_cast<uint32_t *>(c->nfrag.p); b.hits = reinterpret_cast<Hit *>(d_out);
+  b.meta = static_cast<ReadMeta *>(c->meta.p); b.hits = reinterpret_cast<Hit *>(d_out);
   uint32_t *cnt = static_cast<uint32_t *>(c->counters.p);
   // SEG work list: at most one entry per original fragment
   const uint64_t seg_cap = p.seg ? std::min<uint64_t>(n_frag_slots / 2 + 8, 0x00ffffffull) : 1;
@@ -425,11 +452,15 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     while (blocks_retry > 1 && (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry) > (1ull << 30)) blocks_retry /= 2;
     if ((rc = ensure(c->scratch_retry[0], (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry)))) return rc;
     if (n > 0) {
-      hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                         static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+      if (ix->dev.sb32)
+        hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+      else
+        hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
-      hipLaunchKernelGGL(k_mem, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
+      hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry);
       KJ_HIP(hipGetLastError());
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
@@ -458,7 +489,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
-      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr);
+      hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr);
       KJ_HIP(hipGetLastError());
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
   }

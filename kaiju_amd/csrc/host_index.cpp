@@ -161,6 +161,8 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       }
     }
   }
+  sb32.clear();
+  if (bwtlen < 0xffffffffull) { sb32.resize(sb.size()); for (size_t q = 0; q < sb.size(); q++) sb32[q] = (uint32_t)sb[q]; }
   // pass 2: rank blocks
   parallel_for(nsb, [&](uint64_t s) {
     uint32_t cnt[32] = {0};
@@ -217,20 +219,62 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     seq_valid[i] = parse_taxid(nm, id) ? 1 : 0;
     seq_taxid[i] = id;
   }
+  {
+    uint32_t k = 5;
+    if (const char *e = getenv("KAIJU_GPU_KMER")) k = (uint32_t)atoi(e);
+    build_kmer_table(k);
+  }
   return 0;
+}
+
+void PackedIndex::build_kmer_table(uint32_t k) {
+  kmer32.clear(); kmer64.clear(); kmer_k = 0;
+  if (k < 2 || k > 6 || alen != 21) return;
+  uint64_t n = 1;
+  for (uint32_t q = 0; q < k; q++) n *= 20;
+  const bool small = bwtlen < 0xffffffffull;
+  if (small) kmer32.assign((size_t)n, uint2{0, 0}); else kmer64.assign((size_t)n, ulonglong2{0, 0});
+  const DevIndex d = host_view();
+  // word index = (((c0-1)*20 + (c1-1))*20 + ...), c0 = the letter matched first (InitialSI)
+  struct Rec {
+    static void go(const DevIndex &d, PackedIndex &pk, bool small, uint32_t k, uint32_t depth, uint64_t idx,
+                   uint64_t lo, uint64_t hi) {
+      if (depth == k) {
+        if (small) pk.kmer32[(size_t)idx] = uint2{(uint32_t)lo, (uint32_t)(hi - lo)};
+        else pk.kmer64[(size_t)idx] = ulonglong2{lo, hi - lo};
+        return;
+      }
+      for (uint32_t c = 1; c <= 20; c++) {
+        uint64_t nlo = 0, nhi = 0;
+        if (lo < hi) { nlo = rank_c(d, c, lo); nhi = rank_c(d, c, hi); if (nlo >= nhi) nlo = nhi = 0; }
+        go(d, pk, small, k, depth + 1, idx * 20 + (c - 1), nlo, nhi);
+      }
+    }
+  };
+  parallel_for(400, [&](uint64_t t) {
+    const uint32_t c0 = (uint32_t)(t / 20) + 1, c1 = (uint32_t)(t % 20) + 1;
+    uint64_t lo = C[c0], hi = C[c0 + 1];                       // InitialSI
+    uint64_t nlo = 0, nhi = 0;
+    if (lo < hi) { nlo = rank_c(d, c1, lo); nhi = rank_c(d, c1, hi); if (nlo >= nhi) nlo = nhi = 0; }
+    Rec::go(d, *this, small, k, 2, (uint64_t)(c0 - 1) * 20 + (c1 - 1), nlo, nhi);
+  });
+  kmer_k = k;
 }
 
 uint64_t PackedIndex::bytes() const {
   return blocks.size() * sizeof(RankBlock) + sb.size() * 8 + sa_iseq.size() * 4 + seq_taxid.size() * 8 +
-         seq_valid.size() + term_pos.size() * 8;
+         seq_valid.size() + term_pos.size() * 8 + kmer32.size() * 8 + kmer64.size() * 16 + sb32.size() * 4;
 }
 
 DevIndex PackedIndex::host_view() const {
   DevIndex d;
-  d.blocks = blocks.data(); d.sb = sb.data(); d.sa_iseq = sa_iseq.data();
+  d.blocks = blocks.data(); d.sb = sb.data(); d.sb32 = sb32.empty() ? nullptr : sb32.data(); d.sa_iseq = sa_iseq.data();
   d.seq_taxid = seq_taxid.data(); d.seq_valid = seq_valid.data(); d.term_pos = term_pos.data();
   for (int a = 0; a < 22; a++) d.C[a] = C[a];
   d.bwtlen = bwtlen; d.n_sa = n_sa; d.sa_skip = sa_skip; d.nseq = nseq; d.chpt_exp = chpt_exp;
+  d.kmer32 = kmer32.empty() ? nullptr : kmer32.data();
+  d.kmer64 = kmer64.empty() ? nullptr : kmer64.data();
+  d.kmer_k = kmer_k;
   return d;
 }
 

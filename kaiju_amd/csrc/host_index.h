@@ -53,11 +53,17 @@ struct FmiFile {
 struct PackedIndex {
   std::vector<RankBlock> blocks;
   std::vector<uint64_t> sb;
+  std::vector<uint32_t> sb32;       // copy of sb in 32 bits when bwtlen < 2^32
   std::vector<uint32_t> sa_iseq;
   std::vector<uint64_t> seq_taxid;
   std::vector<uint8_t> seq_valid;
   std::vector<uint64_t> term_pos;
   std::vector<std::string> names;   // sequence names (for the verbose columns)
+  std::vector<uint2> kmer32;        // k-mer table (see DevIndex), one of the two is filled
+  std::vector<ulonglong2> kmer64;
+  uint32_t kmer_k = 0;
+  // builds the k-mer table with k letters (0 = none); needs blocks/sb/C
+  void build_kmer_table(uint32_t k);
   uint64_t C[22] = {0};
   uint64_t bwtlen = 0, n_sa = 0, sa_skip = 0;
   uint32_t nseq = 0, chpt_exp = 0, alen = 0;

@@ -26,6 +26,8 @@
 #else
 #define KJ_HD inline
 #define KJ_HD_NOINLINE inline
+struct uint2 { uint32_t x, y; };
+struct ulonglong2 { uint64_t x, y; };
 #endif
 
 namespace kj {
@@ -54,6 +56,7 @@ static_assert(sizeof(RankBlock) == 128, "RankBlock must be one 128-byte line");
 struct DevIndex {
   const RankBlock *blocks;   // [(bwtlen >> 7) + 1]
   const uint64_t *sb;        // [nsb][20]: C[c] + occurrences of c before the superblock
+  const uint32_t *sb32;      // the same in 32 bits when bwtlen < 2^32 (else nullptr)
   const uint32_t *sa_iseq;   // sequence number of every sampled SA row (rows >= nseq)
   const uint64_t *seq_taxid; // taxon id per sequence (rule of ConsumerThread.cpp:809-833)
   const uint8_t *seq_valid;  // 0 where strtoul gave ULONG_MAX
@@ -64,6 +67,13 @@ struct DevIndex {
   uint64_t sa_skip;          // ((nseq-1) >> e) + 1, see get_suffix bwt.c:115-116
   uint32_t nseq;
   uint32_t chpt_exp;
+  // k-mer table: suffix interval of every k-letter word, i.e. the result of InitialSI + (k-1)
+  // UpdateSI, so that a search from an end position starts k letters in with ONE lookup.  Exact:
+  // an empty entry means the match is shorter than k < min(m, seed_length), which is never
+  // recorded and never satisfies the "match starts at position <= 1" break of the reference.
+  const uint2 *kmer32;       // {lo, len} when bwtlen < 2^32
+  const ulonglong2 *kmer64;  // {lo, len} otherwise
+  uint32_t kmer_k;           // 0 = no table
 };
 
 struct Params {
@@ -131,6 +141,12 @@ struct ConstTables {
   int8_t diag_idx[32];       // BLOSUM62 diagonal by index-alphabet code (blosum62diag, :61-80)
 };
 
+struct ReadMeta {            // written by stage 1 (16 bytes): saves the search lanes the layout arithmetic
+  uint64_t pep;              // offset of the read's peptide area in Batch::pep
+  uint32_t frag;             // first fragment slot in Batch::frags
+  uint32_t nfrag;            // number of fragments (| kNfragSegPending)
+};
+
 struct Batch {
   const uint8_t *seqs;       // ASCII nucleotides
   const uint64_t *off;       // [2n+1]
@@ -138,13 +154,13 @@ struct Batch {
   int32_t paired;
   uint8_t *pep;              // six-frame translations, index-alphabet codes, 0 = stop
   Frag *frags;               // canonical fragment lists
-  uint32_t *nfrag;           // [n]
+  ReadMeta *meta;            // [n] where read r's peptides / fragment list live
   Hit *hits;                 // [n]
 };
 
 // layout helpers (closed form, no prefix sums needed) -------------------------
 // peptide area of read r: <= 2*(len1+len2) + 12 bytes of strings after 8 bytes of front padding
-KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return 2 * off[2 * (uint64_t)r] + 24ull * r + 8; }
+KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return ((2 * off[2 * (uint64_t)r] + 3) & ~3ull) + 32ull * r + 8; }
 // fragment slots of read r: a read has at most (2*(len1+len2)+12)/(m+1) disjoint fragments;
 // twice that is reserved so that SEG pieces can sit next to their parents
 KJ_HD uint64_t frag_base(const uint64_t *off, uint32_t r, uint32_t m) {
@@ -159,8 +175,10 @@ KJ_HD uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 // ----------------------------------------------------------------------------
 // rank / LF on the packed index
 // ----------------------------------------------------------------------------
-// C[c] + #{ i < k : bwt[i] == c }  for c in 1..20  (== FMindex, compactfmi.c:267-307)
-KJ_HD uint64_t rank_c(const DevIndex &ix, uint32_t c, uint64_t k) {
+// C[c] + #{ i < k : bwt[i] == c }  for c in 1..20  (== FMindex, compactfmi.c:267-307).
+// P = uint32_t for indexes below 2^32 symbols (half the address/count arithmetic), else uint64_t.
+template <class P>
+KJ_HD P rank_p(const DevIndex &ix, uint32_t c, P k) {
   const RankBlock *b = ix.blocks + (k >> kBlkShift);
   const uint32_t r = (uint32_t)k & 127u;
   uint64_t m0 = ~0ull, m1 = ~0ull;
@@ -172,8 +190,11 @@ KJ_HD uint64_t rank_c(const DevIndex &ix, uint32_t c, uint64_t k) {
   }
   const uint64_t lm0 = r >= 64 ? ~0ull : ((1ull << r) - 1);
   const uint64_t lm1 = r > 64 ? ((1ull << (r - 64)) - 1) : 0ull;
-  return ix.sb[(k >> kSbShift) * 20 + (c - 1)] + b->cnt[c - 1] + popc64(m0 & lm0) + popc64(m1 & lm1);
+  const uint32_t in_blk = b->cnt[c - 1] + popc64(m0 & lm0) + popc64(m1 & lm1);
+  if (sizeof(P) == 4) return (P)(ix.sb32[(uint32_t)(k >> kSbShift) * 20u + (c - 1)] + in_blk);
+  return (P)(ix.sb[(uint64_t)(k >> kSbShift) * 20 + (c - 1)] + in_blk);
 }
+KJ_HD uint64_t rank_c(const DevIndex &ix, uint32_t c, uint64_t k) { return rank_p<uint64_t>(ix, c, k); }
 
 KJ_HD uint32_t symbol_at(const DevIndex &ix, uint64_t k) {
   const RankBlock *b = ix.blocks + (k >> kBlkShift);
@@ -192,6 +213,13 @@ KJ_HD uint64_t rank_term(const DevIndex &ix, uint64_t k) {
     if (ix.term_pos[mid] < k) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+// k-mer table lookup: letters w[0] (matched first, i.e. the rightmost residue) .. w[k-1]
+KJ_HD uint32_t kmer_index(uint32_t idx, uint32_t c) { return idx * 20u + (c - 1u); }
+KJ_HD void kmer_lookup(const DevIndex &ix, uint32_t idx, uint64_t &lo, uint64_t &hi) {
+  if (ix.kmer32) { const uint2 e = ix.kmer32[idx]; lo = e.x; hi = (uint64_t)e.x + e.y; }
+  else { const ulonglong2 e = ix.kmer64[idx]; lo = e.x; hi = e.x + e.y; }
 }
 
 // nucleotide triplet -> aa2int code (255 = stop).  Any non-ACGTU base gives a stop
@@ -576,8 +604,9 @@ template <class Coop>
 KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const Params &p, const SegQueue &sq,
                        uint32_t slot) {
   const SegWork wk = sq.items[slot];
-  const Frag f = b.frags[frag_base(b.off, wk.read, p.m) + wk.frag];
-  const uint8_t *pep = b.pep + pep_base(b.off, wk.read);
+  const ReadMeta rm = b.meta[wk.read];
+  const Frag f = b.frags[rm.frag + wk.frag];
+  const uint8_t *pep = b.pep + rm.pep;
   int32_t left[kSegMaxRegions], right[kSegMaxRegions];
   bool ov = false;
   const int n = seg_regions(cx, coop, pep + f.start, (int)f.len, left, right, ov);
@@ -649,7 +678,8 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
       }
     }
   }
-  b.nfrag[r] = n | pending;
+  ReadMeta rm; rm.pep = pep_base(b.off, r); rm.frag = (uint32_t)frag_base(b.off, r, p.m); rm.nfrag = n | pending;
+  b.meta[r] = rm;
 }
 
 // MEM only: apply the SEG results eagerly (equivalent to the lazy split): split
@@ -657,12 +687,13 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
 // left to right
 KJ_HD void seg_apply_mem(const ConstTables &t, const Params &p, const Batch &b, const SegQueue &sq, uint32_t r,
                          uint32_t *err_flags) {
-  const uint32_t raw = b.nfrag[r];
+  const ReadMeta rm = b.meta[r];
+  const uint32_t raw = rm.nfrag;
   if (!(raw & kNfragSegPending)) return;
   const uint32_t n_orig = raw & ~kNfragSegPending;
-  Frag *list = b.frags + frag_base(b.off, r, p.m);
+  Frag *list = b.frags + rm.frag;
   const uint32_t cap = frag_cap(b.off, r, p.m);
-  const uint8_t *pep = b.pep + pep_base(b.off, r);
+  const uint8_t *pep = b.pep + rm.pep;
   uint32_t np = 0;
   for (uint32_t k = 0; k < n_orig; k++) {
     const Frag f = list[k];
@@ -680,23 +711,28 @@ KJ_HD void seg_apply_mem(const ConstTables &t, const Params &p, const Batch &b, 
   // at least one parent was dropped, so w <= n_orig - 1 and the insertion below never
   // overwrites a piece that has not been read yet
   for (uint32_t q = 0; q < np; q++) { const Frag pc = list[n_orig + q]; frag_insert(list, w, cap, pc); }
-  b.nfrag[r] = w;
+  b.meta[r].nfrag = w;
 }
 
 // ----------------------------------------------------------------------------
 // per-lane peptide window (LDS on the device): 64 residues of the current fragment
 // ----------------------------------------------------------------------------
 struct LaneWin {
-  uint8_t *w;                // kWin bytes
+  uint8_t *w;                // kWin bytes, 4-byte aligned
   int32_t q;                 // fragment position of w[0]
 };
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+// always copies kWin bytes starting at fragment position q (bytes behind the fragment end are
+// never looked at; the peptide buffer is padded so that the read stays inside it)
 KJ_HD void win_fill(LaneWin &lw, const uint8_t *fs, int flen, int top) {
+  (void)flen;
   int q = top - (kWin - 1);
   if (q < 0) q = 0;
   lw.q = q;
-  int n = flen - q;
-  if (n > kWin) n = kWin;
-  for (int t = 0; t < n; t++) lw.w[t] = fs[q + t];
+  const u32_unaligned *src = reinterpret_cast<const u32_unaligned *>(fs + q);
+  uint32_t *dst = reinterpret_cast<uint32_t *>(lw.w);
+#pragma unroll
+  for (int t = 0; t < kWin / 4; t++) dst[t] = src[t];
 }
 KJ_HD uint32_t win_get(LaneWin &lw, const uint8_t *fs, int flen, int pos) {
   if (pos < lw.q || pos >= lw.q + kWin) win_fill(lw, fs, flen, pos);
@@ -738,12 +774,14 @@ KJ_HD void add_id(const DevIndex &ix, Hit *hit, uint32_t &nids, uint32_t iseq) {
 // ----------------------------------------------------------------------------
 // MEM lane: classify_length (ConsumerThread.cpp:543-628) + greedyExact (bwt.c:347-380)
 // ----------------------------------------------------------------------------
+// States below MS_STEP are bookkeeping (no index access) and are resolved in the inner loop;
+// the three states from MS_STEP on each cost exactly one dependent index access.
 enum MemState : int {
-  MS_FETCH, MS_NEXT_FRAG, MS_START_J, MS_END_MATCH, MS_LOC_INIT, MS_LOC_NEXT_GROUP,
-  MS_LOC_NEXT_SI, MS_LOC_ROW, MS_LF_CHECK, MS_ADD_ID, MS_LOC_DONE,
-  MS_STEP, MS_LF, MS_EXIT
+  MS_FETCH, MS_NEXT_FRAG, MS_END_MATCH, MS_LOC_INIT, MS_LOC_NEXT_SI, MS_LOC_ROW, MS_ADD_ID, MS_LOC_DONE,
+  MS_STEP, MS_LF, MS_KMER, MS_EXIT
 };
 
+template <class P>
 KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
                     const LaneScratch &ls) {
   int st = MS_FETCH;
@@ -751,28 +789,60 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
   const Frag *F = nullptr;
   const uint8_t *pep = nullptr, *fs = nullptr;
   int flen = 0, j = 0, i = 0;
-  uint64_t lo = 0, hi = 0;
+  P lo = 0, hi = 0;
   uint32_t L = p.m, nsi = 0;
   bool found = false, ovf = false;
   // locate state
   uint32_t gs = 0, ge = 0, cur = 0, nids = 0, flags = 0, iseq = 0;
-  uint64_t row = 0, rowend = 0, k = 0;
+  P row = 0, rowend = 0, k = 0;
   Hit *hit = nullptr;
   LaneWin lw{ls.win, 0};
-  const uint64_t check = (1ull << ix.chpt_exp) - 1;
+  const P check = (P)((1ull << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m) ? ix.kmer_k : 0;   // matches shorter than m never count
+  uint32_t kidx = 0;
+
+  // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356): set up the search
+  // from end position j, or leave the fragment
+  auto start_j = [&]() {
+    if (j < (int)L - 1) { st = MS_NEXT_FRAG; return; }
+    if (kk && j >= (int)kk - 1) {            // start kk letters in with one table lookup
+      kidx = 0;
+      for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, win_get(lw, fs, flen, j - (int)q));
+      st = MS_KMER;
+      return;
+    }
+    const uint32_t c = win_get(lw, fs, flen, j);
+    lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];    // InitialSI, bwt.c:146-152
+    i = j;
+    st = i > 0 ? MS_STEP : MS_END_MATCH;
+  };
+  // next SA row of the located matches -> LF walk or sampled row (get_suffix, bwt.c:105-121)
+  auto lf_check = [&]() {
+    for (;;) {
+      if ((k & check) != 0) { st = MS_LF; return; }
+      const uint64_t idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+      if (idx < ix.n_sa) { iseq = ix.sa_iseq[idx]; st = MS_ADD_ID; return; }
+      // (the reference reads out of bounds here): skip the row
+      row++;
+      if (row >= rowend) { st = MS_LOC_NEXT_SI; return; }
+      if (nids > p.max_match_ids) { flags |= kHitIdCap; st = MS_LOC_DONE; return; }
+      k = row;
+    }
+  };
 
   for (;;) {
-    // ---- transitions that need no index access ----
+    // ---- bookkeeping that needs no index access ----
     while (st < MS_STEP) {
       switch (st) {
         case MS_FETCH: {
           const uint32_t item = fetch_work(wl.counter);
           if (item >= n_items) { st = MS_EXIT; break; }
           r = wl.reads ? wl.reads[item] : item;
-          nf = b.nfrag[r] & ~kNfragSegPending;
-          F = b.frags + frag_base(b.off, r, p.m);
-          pep = b.pep + pep_base(b.off, r);
+          const ReadMeta rm = b.meta[r];
+          nf = rm.nfrag & ~kNfragSegPending;
+          F = b.frags + rm.frag;
+          pep = b.pep + rm.pep;
           f = 0; L = p.m; nsi = 0; found = false; ovf = false;
           st = MS_NEXT_FRAG;
           break;
@@ -786,16 +856,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
           fs = pep + d.start; flen = (int)d.len;
           j = flen - 1;
           win_fill(lw, fs, flen, j);
-          st = MS_START_J;
-          break;
-        }
-        case MS_START_J: {
-          // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356)
-          if (j < (int)L - 1) { st = MS_NEXT_FRAG; break; }
-          const uint32_t c = win_get(lw, fs, flen, j);
-          lo = ix.C[c]; hi = ix.C[c + 1];          // InitialSI, bwt.c:146-152
-          i = j;
-          st = i > 0 ? MS_STEP : MS_END_MATCH;
+          start_j();
           break;
         }
         case MS_END_MATCH: {
@@ -810,7 +871,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
             found = true;
           }
           if (i <= 1) st = MS_NEXT_FRAG;                   // bwt.c:376
-          else { j--; st = MS_START_J; }
+          else { j--; start_j(); }
           break;
         }
         case MS_LOC_INIT: {
@@ -824,40 +885,31 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
             else flags = kHitInternalOverflow;
             st = MS_LOC_DONE; break;
           }
-          ge = 0;
-          st = MS_LOC_NEXT_GROUP;
-          break;
-        }
-        case MS_LOC_NEXT_GROUP: {
-          // matches of one fragment were found for descending j but are visited for ascending j
-          // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845)
-          gs = ge;
-          if (gs >= nsi) { st = MS_LOC_DONE; break; }
-          const uint32_t fr = ls.si[gs].frag;
-          ge = gs + 1;
-          while (ge < nsi && ls.si[ge].frag == fr) ge++;
-          cur = ge;
+          gs = ge = cur = 0;
           st = MS_LOC_NEXT_SI;
           break;
         }
         case MS_LOC_NEXT_SI: {
-          if (cur == gs) { st = MS_LOC_NEXT_GROUP; break; }
+          // matches of one fragment were found for descending j but are visited for ascending j
+          // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845)
+          if (cur == gs) {
+            gs = ge;
+            if (gs >= nsi) { st = MS_LOC_DONE; break; }
+            const uint32_t fr = ls.si[gs].frag;
+            ge = gs + 1;
+            while (ge < nsi && ls.si[ge].frag == fr) ge++;
+            cur = ge;
+          }
           cur--;
-          row = ls.si[cur].lo; rowend = row + (uint64_t)(int64_t)(int32_t)ls.si[cur].len;
+          row = (P)ls.si[cur].lo; rowend = row + (P)(int32_t)ls.si[cur].len;
           st = MS_LOC_ROW;
           break;
         }
         case MS_LOC_ROW: {
-          if ((int64_t)row >= (int64_t)rowend) { st = MS_LOC_NEXT_SI; break; }
+          if (row >= rowend) { st = MS_LOC_NEXT_SI; break; }
           if (nids > p.max_match_ids) { flags |= kHitIdCap; st = MS_LOC_DONE; break; }   // :805-807
           k = row;
-          st = MS_LF_CHECK;
-          break;
-        }
-        case MS_LF_CHECK: {
-          if ((k & check) == 0) {
-            if (sa_lookup(ix, k, iseq)) st = MS_ADD_ID; else { row++; st = MS_LOC_ROW; }
-          } else st = MS_LF;
+          lf_check();
           break;
         }
         case MS_ADD_ID: {
@@ -878,18 +930,24 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
     if (st == MS_STEP) {
       // UpdateSI(str[i-1]) (bwt.c:160-173)
       const uint32_t c = win_get(lw, fs, flen, i - 1);
-      const uint64_t nlo = rank_c(ix, c, lo), nhi = rank_c(ix, c, hi);
+      const P nlo = rank_p<P>(ix, c, lo), nhi = rank_p<P>(ix, c, hi);
       if (nlo >= nhi) st = MS_END_MATCH;
       else { lo = nlo; hi = nhi; i--; if (i == 0) st = MS_END_MATCH; }
+    } else if (st == MS_KMER) {
+      // InitialSI + (kk-1) UpdateSI in one lookup
+      uint64_t l64, h64;
+      kmer_lookup(ix, kidx, l64, h64);
+      lo = (P)l64; hi = (P)h64;
+      if (lo >= hi) { i = j; st = MS_END_MATCH; }          // match shorter than kk: never recorded, i > 1
+      else { i = j - (int)kk + 1; st = i > 0 ? MS_STEP : MS_END_MATCH; }
     } else {
       // one LF step of get_suffix (bwt.c:109-112): FMindexCurrent
       const uint32_t c = symbol_at(ix, k);
       if (c == 0) { iseq = (uint32_t)rank_term(ix, k); st = MS_ADD_ID; }
-      else { k = rank_c(ix, c, k); st = MS_LF_CHECK; }
+      else { k = rank_p<P>(ix, c, k); lf_check(); }
     }
   }
 }
-
 
 // ----------------------------------------------------------------------------
 // Greedy lane: classify_greedyblosum (ConsumerThread.cpp:424-541), maxMatches /
@@ -973,7 +1031,7 @@ KJ_HD uint32_t gwin_get(LaneWin &lw, const uint8_t *pep, const GItem &t, int pos
 enum GState : int {
   GS_FETCH, GS_POP, GS_START_J, GS_END_MATCH, GS_AFTER_SEARCH, GS_VAR_NEXT_MATCH, GS_VAR_NEXT_SUB,
   GS_EVAL, GS_FINISH, GS_LOC_NEXT_SI, GS_LOC_ROW, GS_LF_CHECK, GS_ADD_ID, GS_LOC_DONE,
-  GS_STEP, GS_VSTEP, GS_LF, GS_EXIT
+  GS_STEP, GS_VSTEP, GS_LF, GS_KMER, GS_EXIT
 };
 
 KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
@@ -1002,6 +1060,9 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
   LaneWin lw{gs.win, 0};
   const uint64_t check = (1ull << ix.chpt_exp) - 1;
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
+  // seeds shorter than seed_length are never recorded
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3) ? ix.kmer_k : 0;
+  uint32_t kidx = 0;
 
   for (;;) {
     while (state < GS_STEP) {
@@ -1010,9 +1071,10 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           const uint32_t item = fetch_work(wl.counter);
           if (item >= n_items) { state = GS_EXIT; break; }
           r = wl.reads ? wl.reads[item] : item;
-          pep = b.pep + pep_base(b.off, r);
-          const Frag *F = b.frags + frag_base(b.off, r, p.m);
-          const uint32_t nf = b.nfrag[r] & ~kNfragSegPending;
+          const ReadMeta rm = b.meta[r];
+          pep = b.pep + rm.pep;
+          const Frag *F = b.frags + rm.frag;
+          const uint32_t nf = rm.nfrag & ~kNfragSegPending;
           q.head = q.tail = q.npool = 0; q.overflow = false;
           for (uint32_t f = 0; f < nf; f++) gq_push(gs, q, gitem_from_frag(F[f]));   // already in queue order
           best = 0; nbest = 0; flags = 0; m_ovf = false;
@@ -1056,6 +1118,16 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
         }
         case GS_START_J: {
           if (j < (int)p.seed_length - 1) { state = GS_AFTER_SEARCH; break; }
+          if (kk && j >= (int)kk - 1) {
+            kidx = 0; acc = 0;
+            for (uint32_t q = 0; q < kk; q++) {
+              const uint32_t cq = gwin_get(lw, pep, t, j - (int)q);
+              kidx = kmer_index(kidx, cq);
+              acc += (uint32_t)ct.diag_idx[cq];
+            }
+            state = GS_KMER;
+            break;
+          }
           const uint32_t c = gwin_get(lw, pep, t, j);
           lo = ix.C[c]; hi = ix.C[c + 1];
           acc = (uint32_t)ct.diag_idx[c];
@@ -1268,10 +1340,14 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
       }
       vsub++;
       state = GS_VAR_NEXT_SUB;
-    } else {
+    } else if (state == GS_LF) {
       const uint32_t c = symbol_at(ix, k);
       if (c == 0) { iseq = (uint32_t)rank_term(ix, k); state = GS_ADD_ID; }
       else { k = rank_c(ix, c, k); state = GS_LF_CHECK; }
+    } else {
+      kmer_lookup(ix, kidx, lo, hi);
+      if (lo >= hi) { i = j; state = GS_END_MATCH; }       // seed shorter than kk: never recorded, i > 1
+      else { i = j - (int)kk + 1; state = i > 0 ? GS_STEP : GS_END_MATCH; }
     }
   }
 }

@@ -6,6 +6,7 @@
 // machine without a GPU.  This library is built and loaded by tests only; the product
 // library (libkaiju_gpu.so) contains no CPU path and fails loudly without a HIP device.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -73,12 +74,12 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   if (p.mismatches > (uint32_t)kMaxMismatch) return KAIJU_GPU_ERR_UNSUPPORTED;
   Batch b;
   b.seqs = (const uint8_t *)seqs; b.off = off; b.n_reads = n; b.paired = paired;
-  std::vector<uint8_t> pep((size_t)pep_base(off, n) + 64, 0);
+  std::vector<uint8_t> pep((size_t)pep_base(off, n) + 256, 0);
   std::vector<Frag> frags((size_t)frag_base(off, n, p.m) + 8);
-  std::vector<uint32_t> nfrag(n);
+  std::vector<ReadMeta> meta(n);
   std::vector<Hit> hits(n);
   memset(hits.data(), 0, sizeof(Hit) * n);
-  b.pep = pep.data(); b.frags = frags.data(); b.nfrag = nfrag.data(); b.hits = hits.data();
+  b.pep = pep.data(); b.frags = frags.data(); b.meta = meta.data(); b.hits = hits.data();
   uint32_t err = 0;
   // stage 1 -> SEG pass -> (MEM) apply, exactly the kernel sequence of capi.hip
   uint32_t seg_count = 0;
@@ -96,11 +97,11 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     const char *alpha = ix->packed.alphabet.c_str();
     uint64_t w = 0;
     for (uint32_t r = 0; r < n; r++) {
-      const Frag *F = frags.data() + frag_base(off, r, p.m);
-      const uint8_t *pp = pep.data() + pep_base(off, r);
+      const Frag *F = frags.data() + meta[r].frag;
+      const uint8_t *pp = pep.data() + meta[r].pep;
       if (w + 4 >= frag_dump_cap) return KAIJU_GPU_ERR_NOMEM;
       frag_dump[w++] = '#'; frag_dump[w++] = '\n';
-      for (uint32_t f = 0; f < (nfrag[r] & ~kNfragSegPending); f++) {
+      for (uint32_t f = 0; f < (meta[r].nfrag & ~kNfragSegPending); f++) {
         char tmp[32];
         int l = snprintf(tmp, sizeof tmp, "%u:", F[f].key);
         if (w + (uint64_t)l + F[f].len + 2 >= frag_dump_cap) return KAIJU_GPU_ERR_NOMEM;
@@ -114,7 +115,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   // first pass with the given scratch sizes, overflowing reads go to the retry list
   std::vector<uint32_t> retry(n);
   uint32_t counter = 0, retry_count = 0;
-  uint8_t win[kWin];
+  alignas(16) uint8_t win[kWin];
   std::vector<SIEntry> si(si_cap);
   std::vector<GItem> pool(pool_cap);
   std::vector<uint16_t> ord(pool_cap);
@@ -145,7 +146,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     }
     if (p.mode == 0) {
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
-      mem_lane(d, p, b, wl, ls);
+      if (d.sb32 && !getenv("KAIJU_EMU_WIDE") && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls);
+      else mem_lane<uint64_t>(d, p, b, wl, ls);
     } else {
       GreedyScratch gs;
       gs.pool = pool.data(); gs.pool_cap = (uint32_t)pool.size(); gs.ord = ord.data();
