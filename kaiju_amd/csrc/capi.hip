@@ -404,7 +404,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if ((rc = ensure(c->frags, n_frag_slots * sizeof(Frag)))) return rc;
   if (n_frag_slots >= 0xffffffffull) return fail(KAIJU_GPU_ERR_UNSUPPORTED, "batch too large: split it (fragment slots exceed 2^32)");
   if ((rc = ensure(c->meta, (size_t)n * sizeof(ReadMeta) + 16))) return rc;
-  if ((rc = ensure(c->counters, 64))) return rc;
+  if ((rc = ensure(c->counters, 256))) return rc;
   if ((rc = ensure(c->retry_list, (size_t)n * 4 + 16))) return rc;
   Batch b;
   b.seqs = static_cast<const uint8_t *>(d_seqs); b.off = d_off; b.n_reads = n; b.paired = paired ? 1 : 0;
@@ -418,7 +418,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   SegQueue sq;
   sq.items = static_cast<SegWork *>(c->seg_items.p); sq.recs = static_cast<SegRec *>(c->seg_recs.p);
   sq.count = cnt + 4; sq.cap = (uint32_t)seg_cap;
-  KJ_HIP(hipMemsetAsync(cnt, 0, 64, s));
+  KJ_HIP(hipMemsetAsync(cnt, 0, 256, s));
   if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
@@ -560,6 +560,12 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
   KJ_HIP(hipEventElapsedTime(&t34, ctx->ev[3], ctx->ev[4]));
   uint32_t cnt[8] = {0};
   KJ_HIP(hipMemcpy(cnt, ctx->counters.p, sizeof cnt, hipMemcpyDeviceToHost));
+  if (getenv("KAIJU_GPU_PRINT_STATS")) {
+    unsigned long long acc[6] = {0};
+    KJ_HIP(hipMemcpy(acc, static_cast<uint32_t *>(ctx->counters.p) + 8, sizeof acc, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[kj stats] lane-iters %llu step %llu kmer %llu lf %llu | sum over waves of max iters %llu, max passes %llu\n",
+            acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+  }
   stats->n_reads = ctx->last_n;
   stats->n_overflow_retries = cnt[2];
   stats->n_seg_fragments = cnt[4];

@@ -801,6 +801,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
   const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m) ? ix.kmer_k : 0;   // matches shorter than m never count
   uint32_t kidx = 0;
+  uint64_t klo64 = 0, khi64 = 0;
 
   // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356): set up the search
   // from end position j, or leave the fragment
@@ -809,6 +810,9 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
     if (kk && j >= (int)kk - 1) {            // start kk letters in with one table lookup
       kidx = 0;
       for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, win_get(lw, fs, flen, j - (int)q));
+      // issued here, consumed (untouched until then) in the MS_KMER step: overlaps with the other lanes' loads
+      if (ix.kmer32) { const uint2 e = ix.kmer32[kidx]; klo64 = e.x; khi64 = e.y; }
+      else { const ulonglong2 e = ix.kmer64[kidx]; klo64 = e.x; khi64 = e.y; }
       st = MS_KMER;
       return;
     }
@@ -831,101 +835,113 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
     }
   };
 
+#if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
+  uint32_t stat_iters = 0, stat_step = 0, stat_kmer = 0, stat_lf = 0, stat_passes = 0;
+#define KJ_STAT(x) x
+#else
+#define KJ_STAT(x)
+#endif
   for (;;) {
     // ---- bookkeeping that needs no index access ----
+    // The blocks are ordered along the usual flow (match ended -> next end position / next
+    // fragment -> locate -> hit record -> next read -> first fragment) so that a lane normally gets
+    // from one index access to the next in a single pass; only the rare back edges (another SA row,
+    // another match) take a further pass of the loop.
     while (st < MS_STEP) {
-      switch (st) {
-        case MS_FETCH: {
-          const uint32_t item = fetch_work(wl.counter);
-          if (item >= n_items) { st = MS_EXIT; break; }
-          r = wl.reads ? wl.reads[item] : item;
-          const ReadMeta rm = b.meta[r];
-          nf = rm.nfrag & ~kNfragSegPending;
-          F = b.frags + rm.frag;
-          pep = b.pep + rm.pep;
-          f = 0; L = p.m; nsi = 0; found = false; ovf = false;
-          st = MS_NEXT_FRAG;
-          break;
+      KJ_STAT({ const unsigned long long bal = __ballot(1); if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)bal) - 1)) stat_passes++; })
+      if (st == MS_ADD_ID) {
+        add_id(ix, hit, nids, iseq);
+        row++;
+        st = MS_LOC_ROW;
+      }
+      if (st == MS_END_MATCH) {
+        const uint32_t l = (uint32_t)(j - i + 1);
+        if (l >= L) {
+          if (l > L) { nsi = 0; ovf = false; L = l; }      // shorter matches are dropped (bwt.c:366-370, :577-582)
+          if (nsi < ls.si_cap) {
+            SIEntry e; e.lo = lo; e.len = (uint32_t)(int32_t)(hi - lo); e.frag = fcur;
+            ls.si[nsi] = e;
+          } else ovf = true;
+          nsi++;
+          found = true;
         }
-        case MS_NEXT_FRAG: {
+        if (i <= 1) st = MS_NEXT_FRAG;                     // bwt.c:376
+        else { j--; start_j(); }
+      }
+      for (int again = 0; again < 2; again++) {            // second round: lanes that just fetched a read
+        if (st == MS_NEXT_FRAG) {
           // getNextFragment(longest): stop when the best remaining key < longest (:550, :279)
-          if (f >= nf) { st = MS_LOC_INIT; break; }
-          const Frag d = F[f];
-          if (found && d.key < L) { st = MS_LOC_INIT; break; }
-          fcur = f; f++;
-          fs = pep + d.start; flen = (int)d.len;
-          j = flen - 1;
-          win_fill(lw, fs, flen, j);
-          start_j();
-          break;
-        }
-        case MS_END_MATCH: {
-          const uint32_t l = (uint32_t)(j - i + 1);
-          if (l >= L) {
-            if (l > L) { nsi = 0; ovf = false; L = l; }    // shorter matches are dropped (bwt.c:366-370, :577-582)
-            if (nsi < ls.si_cap) {
-              SIEntry e; e.lo = lo; e.len = (uint32_t)(int32_t)(hi - lo); e.frag = fcur;
-              ls.si[nsi] = e;
-            } else ovf = true;
-            nsi++;
-            found = true;
+          bool more = f < nf;
+          Frag d; d.start = d.len = d.key = d.flags = 0;
+          if (more) { d = F[f]; if (found && d.key < L) more = false; }
+          if (!more) st = MS_LOC_INIT;
+          else {
+            fcur = f; f++;
+            fs = pep + d.start; flen = (int)d.len;
+            j = flen - 1;
+            win_fill(lw, fs, flen, j);
+            start_j();
           }
-          if (i <= 1) st = MS_NEXT_FRAG;                   // bwt.c:376
-          else { j--; start_j(); }
-          break;
         }
-        case MS_LOC_INIT: {
+        if (again) break;
+        if (st == MS_LOC_INIT) {
           hit = b.hits + r;
           nids = 0; flags = 0;
           hit->best = found ? L : 0u;
           hit->reserved = 0;
-          if (!found) { st = MS_LOC_DONE; break; }
-          if (ovf) {
+          if (!found) st = MS_LOC_DONE;
+          else if (ovf) {
             if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
             else flags = kHitInternalOverflow;
-            st = MS_LOC_DONE; break;
-          }
-          gs = ge = cur = 0;
-          st = MS_LOC_NEXT_SI;
-          break;
+            st = MS_LOC_DONE;
+          } else { gs = ge = cur = 0; st = MS_LOC_NEXT_SI; }
         }
-        case MS_LOC_NEXT_SI: {
+        if (st == MS_LOC_NEXT_SI) {
           // matches of one fragment were found for descending j but are visited for ascending j
           // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845)
+          bool any = true;
           if (cur == gs) {
             gs = ge;
-            if (gs >= nsi) { st = MS_LOC_DONE; break; }
-            const uint32_t fr = ls.si[gs].frag;
-            ge = gs + 1;
-            while (ge < nsi && ls.si[ge].frag == fr) ge++;
-            cur = ge;
+            if (gs >= nsi) { st = MS_LOC_DONE; any = false; }
+            else {
+              const uint32_t fr = ls.si[gs].frag;
+              ge = gs + 1;
+              while (ge < nsi && ls.si[ge].frag == fr) ge++;
+              cur = ge;
+            }
           }
-          cur--;
-          row = (P)ls.si[cur].lo; rowend = row + (P)(int32_t)ls.si[cur].len;
-          st = MS_LOC_ROW;
-          break;
+          if (any) {
+            cur--;
+            row = (P)ls.si[cur].lo; rowend = row + (P)(int32_t)ls.si[cur].len;
+            st = MS_LOC_ROW;
+          }
         }
-        case MS_LOC_ROW: {
-          if (row >= rowend) { st = MS_LOC_NEXT_SI; break; }
-          if (nids > p.max_match_ids) { flags |= kHitIdCap; st = MS_LOC_DONE; break; }   // :805-807
-          k = row;
-          lf_check();
-          break;
+        if (st == MS_LOC_ROW) {
+          if (row >= rowend) st = MS_LOC_NEXT_SI;
+          else if (nids > p.max_match_ids) { flags |= kHitIdCap; st = MS_LOC_DONE; }   // :805-807
+          else { k = row; lf_check(); }
         }
-        case MS_ADD_ID: {
-          add_id(ix, hit, nids, iseq);
-          row++;
-          st = MS_LOC_ROW;
-          break;
-        }
-        case MS_LOC_DONE: {
+        if (st == MS_LOC_DONE) {
           hit->n_ids = nids; hit->flags = flags;
           st = MS_FETCH;
-          break;
+        }
+        if (st == MS_FETCH) {
+          const uint32_t item = fetch_work(wl.counter);
+          if (item >= n_items) st = MS_EXIT;
+          else {
+            r = wl.reads ? wl.reads[item] : item;
+            const ReadMeta rm = b.meta[r];
+            nf = rm.nfrag & ~kNfragSegPending;
+            F = b.frags + rm.frag;
+            pep = b.pep + rm.pep;
+            f = 0; L = p.m; nsi = 0; found = false; ovf = false;
+            st = MS_NEXT_FRAG;
+          }
         }
       }
     }
     if (st == MS_EXIT) break;
+    KJ_STAT(stat_iters++; if (st == MS_STEP) stat_step++; else if (st == MS_KMER) stat_kmer++; else stat_lf++;)
     // ---- one dependent index access ----
     if (st == MS_STEP) {
       // UpdateSI(str[i-1]) (bwt.c:160-173)
@@ -935,9 +951,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
       else { lo = nlo; hi = nhi; i--; if (i == 0) st = MS_END_MATCH; }
     } else if (st == MS_KMER) {
       // InitialSI + (kk-1) UpdateSI in one lookup
-      uint64_t l64, h64;
-      kmer_lookup(ix, kidx, l64, h64);
-      lo = (P)l64; hi = (P)h64;
+      lo = (P)klo64; hi = (P)(klo64 + khi64);
       if (lo >= hi) { i = j; st = MS_END_MATCH; }          // match shorter than kk: never recorded, i > 1
       else { i = j - (int)kk + 1; st = i > 0 ? MS_STEP : MS_END_MATCH; }
     } else {
@@ -947,6 +961,19 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
       else { k = rank_p<P>(ix, c, k); lf_check(); }
     }
   }
+#if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
+  {
+    // experiment only: per-wave loop statistics into the spare counter slots
+    uint32_t mx = stat_iters, mxp = stat_passes;
+    for (int o = 32; o > 0; o >>= 1) { uint32_t a = __shfl_xor(mx, o, 64); if (a > mx) mx = a; mxp += __shfl_xor(mxp, o, 64); }
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(wl.counter) & ~(uintptr_t)63) + 32);
+    atomicAdd(acc + 0, (unsigned long long)stat_iters);
+    atomicAdd(acc + 1, (unsigned long long)stat_step);
+    atomicAdd(acc + 2, (unsigned long long)stat_kmer);
+    atomicAdd(acc + 3, (unsigned long long)stat_lf);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(acc + 4, (unsigned long long)mx); atomicAdd(acc + 5, (unsigned long long)mxp); }
+  }
+#endif
 }
 
 // ----------------------------------------------------------------------------
