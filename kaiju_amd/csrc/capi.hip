@@ -105,9 +105,20 @@ __device__ __forceinline__ void mem_body(const DevIndex &ix, const Params &p, co
   ls.win = s_win + threadIdx.x * kWinStride;
   mem_lane<P>(ix, p, b, wl, ls);
 }
-// 32-bit suffix-array positions (indexes below 2^32 symbols: half the address arithmetic)
+// second-generation lane (kj_core.h:mem_lane2): indexes below 2^32 symbols with a k-mer table
+__global__ void __launch_bounds__(kBlock, 4)
+k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  mem_lane2(ix, p, b, wl, ls);
+}
+// first-generation lane with 32-bit positions (kept for A/B measurements: KAIJU_GPU_MEM_LANE=v1)
 __global__ void __launch_bounds__(kBlock)
-k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint32_t>(ix, p, b, wl, si_all, si_cap); }
+k_mem_v1(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint32_t>(ix, p, b, wl, si_all, si_cap); }
 // 64-bit positions (refseq-scale indexes)
 __global__ void __launch_bounds__(kBlock)
 k_mem_wide(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint64_t>(ix, p, b, wl, si_all, si_cap); }
@@ -204,7 +215,7 @@ struct kaiju_gpu_index {
 template <class T>
 static int upload(kaiju_gpu_index *ix, const std::vector<T> &v, const T **dst) {
   void *p = nullptr;
-  const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+  const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16) + 32;   // slack: 16-byte loads of 8-byte entries
   KJ_HIP(hipMalloc(&p, bytes));
   ix->allocs.push_back(p);
   if (!v.empty()) KJ_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -236,6 +247,9 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
   if ((rc = upload(ix.get(), pk.sb, &d.sb))) return rc;
   d.sb32 = nullptr;
   if (!pk.sb32.empty() && (rc = upload(ix.get(), pk.sb32, &d.sb32))) return rc;
+  d.blocks64 = nullptr;
+  if (!pk.blocks64.empty() && (rc = upload(ix.get(), pk.blocks64, &d.blocks64))) return rc;
+  if ((rc = upload(ix.get(), pk.sa_taxid, &d.sa_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.sa_iseq, &d.sa_iseq))) return rc;
   if ((rc = upload(ix.get(), pk.seq_taxid, &d.seq_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.seq_valid, &d.seq_valid))) return rc;
@@ -452,8 +466,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     while (blocks_retry > 1 && (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry) > (1ull << 30)) blocks_retry /= 2;
     if ((rc = ensure(c->scratch_retry[0], (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry)))) return rc;
     if (n > 0) {
-      if (ix->dev.sb32)
+      const char *lane_env = getenv("KAIJU_GPU_MEM_LANE");
+      const bool v1 = lane_env && !strcmp(lane_env, "v1");
+      if (ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1)
         hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+      else if (ix->dev.sb32)
+        hipLaunchKernelGGL(k_mem_v1, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                            static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       else
         hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,

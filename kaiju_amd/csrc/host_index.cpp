@@ -180,6 +180,28 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       }
     }
   });
+  // 64-symbol blocks with absolute 32-bit counts for the MEM kernel
+  blocks64.clear();
+  if (bwtlen < 0xffffffffull) {
+    const uint64_t nb64 = (bwtlen >> 6) + 1;
+    blocks64.assign((size_t)nb64, RankBlock64{});
+    parallel_for(nsb, [&](uint64_t s) {
+      uint64_t cnt[32];
+      for (int a = 1; a < 21; a++) cnt[a] = sb[(size_t)s * 20 + (a - 1)];
+      const uint64_t b0 = s << (kSbShift - 6), b1 = std::min<uint64_t>(nb64, b0 + (1ull << (kSbShift - 6)));
+      for (uint64_t bi = b0; bi < b1; bi++) {
+        RankBlock64 &rb = blocks64[(size_t)bi];
+        for (int a = 1; a < 21; a++) rb.cnt[a - 1] = (uint32_t)cnt[a];
+        const uint64_t k0 = bi << 6;
+        for (uint32_t t = 0; t < 64; t++) {
+          const uint64_t k = k0 + t;
+          const uint32_t c = k < bwtlen ? lcode[bwt[k]] : 31u;
+          if (k < bwtlen && c >= 1 && c <= 20) cnt[c]++;
+          for (int pl = 0; pl < 5; pl++) if ((c >> pl) & 1u) rb.plane[pl] |= 1ull << t;
+        }
+      }
+    });
+  }
   // terminator positions (rows whose BWT letter is 0): rank_term
   term_pos.clear();
   term_pos.reserve(nseq);
@@ -218,6 +240,11 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     uint64_t id = 0;
     seq_valid[i] = parse_taxid(nm, id) ? 1 : 0;
     seq_taxid[i] = id;
+  }
+  sa_taxid.assign((size_t)n_sa + 2, ~0ull);
+  for (uint64_t q = 0; q < n_sa; q++) {
+    const uint32_t is = sa_iseq[(size_t)q];
+    if (is < nseq && seq_valid[is]) sa_taxid[(size_t)q] = seq_taxid[is];
   }
   {
     uint32_t k = 5;
@@ -263,11 +290,13 @@ void PackedIndex::build_kmer_table(uint32_t k) {
 
 uint64_t PackedIndex::bytes() const {
   return blocks.size() * sizeof(RankBlock) + sb.size() * 8 + sa_iseq.size() * 4 + seq_taxid.size() * 8 +
-         seq_valid.size() + term_pos.size() * 8 + kmer32.size() * 8 + kmer64.size() * 16 + sb32.size() * 4;
+         seq_valid.size() + term_pos.size() * 8 + kmer32.size() * 8 + kmer64.size() * 16 + sb32.size() * 4 +
+         blocks64.size() * sizeof(RankBlock64) + sa_taxid.size() * 8;
 }
 
 DevIndex PackedIndex::host_view() const {
   DevIndex d;
+  d.blocks64 = blocks64.empty() ? nullptr : blocks64.data(); d.sa_taxid = sa_taxid.data();
   d.blocks = blocks.data(); d.sb = sb.data(); d.sb32 = sb32.empty() ? nullptr : sb32.data(); d.sa_iseq = sa_iseq.data();
   d.seq_taxid = seq_taxid.data(); d.seq_valid = seq_valid.data(); d.term_pos = term_pos.data();
   for (int a = 0; a < 22; a++) d.C[a] = C[a];

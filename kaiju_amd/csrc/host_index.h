@@ -52,6 +52,8 @@ struct FmiFile {
 // the packed index in host memory, ready for upload
 struct PackedIndex {
   std::vector<RankBlock> blocks;
+  std::vector<RankBlock64> blocks64;   // MEM kernel layout, only when bwtlen < 2^32
+  std::vector<uint64_t> sa_taxid;      // taxon id per sampled SA row (~0: unusable name)
   std::vector<uint64_t> sb;
   std::vector<uint32_t> sb32;       // copy of sb in 32 bits when bwtlen < 2^32
   std::vector<uint32_t> sa_iseq;

@@ -53,7 +53,19 @@ struct alignas(128) RankBlock {
 };
 static_assert(sizeof(RankBlock) == 128, "RankBlock must be one 128-byte line");
 
+// Layout used by the MEM kernel for indexes below 2^32 symbols: 64 symbols per 128-byte line,
+// five 64-bit planes + ABSOLUTE 32-bit counts (C[c] folded in) of letters 1..20 before the block.
+// One rank query = 4 load instructions (16+16+8 bytes of planes, 4 bytes of count), no superblock.
+struct alignas(128) RankBlock64 {
+  uint64_t plane[5];
+  uint32_t cnt[20];
+  uint32_t pad[2];
+};
+static_assert(sizeof(RankBlock64) == 128, "RankBlock64 must be one 128-byte line");
+
 struct DevIndex {
+  const RankBlock64 *blocks64; // [(bwtlen >> 6) + 1] or nullptr (bwtlen >= 2^32)
+  const uint64_t *sa_taxid;  // taxon id of every sampled SA row (~0 = unusable name), for the MEM kernel
   const RankBlock *blocks;   // [(bwtlen >> 7) + 1]
   const uint64_t *sb;        // [nsb][20]: C[c] + occurrences of c before the superblock
   const uint32_t *sb32;      // the same in 32 bits when bwtlen < 2^32 (else nullptr)
@@ -171,6 +183,17 @@ KJ_HD uint32_t frag_cap(const uint64_t *off, uint32_t r, uint32_t m) {
 }
 
 KJ_HD uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+
+// wave-level helpers (the host emulation runs one lane at a time)
+#if defined(__HIP_DEVICE_COMPILE__)
+KJ_HD uint64_t kj_ballot(bool p) { return __ballot(p); }
+KJ_HD uint32_t kj_lane() { return threadIdx.x & 63u; }
+KJ_HD uint32_t kj_bcast(uint32_t v, uint32_t src_lane) { return (uint32_t)__shfl((int)v, (int)src_lane, 64); }
+#else
+KJ_HD uint64_t kj_ballot(bool p) { return p ? 1ull : 0ull; }
+KJ_HD uint32_t kj_lane() { return 0; }
+KJ_HD uint32_t kj_bcast(uint32_t v, uint32_t) { return v; }
+#endif
 
 // ----------------------------------------------------------------------------
 // rank / LF on the packed index
@@ -974,6 +997,333 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
     if ((threadIdx.x & 63) == 0) { atomicAdd(acc + 4, (unsigned long long)mx); atomicAdd(acc + 5, (unsigned long long)mxp); }
   }
 #endif
+}
+
+// ----------------------------------------------------------------------------
+// MEM lane, second generation (indexes below 2^32 symbols, RankBlock64 layout).
+//
+// Same algorithm and results as mem_lane above; what changes is the shape of the loop.  Profiling
+// of the first version showed that a wavefront iteration contained ~5 *serialised* memory round
+// trips (the compiler waits for every load where it is first used, and uses were spread over the
+// bookkeeping and the three access kinds) and that the texture-address unit, which takes ~64
+// cycles per divergent wave-level load instruction, was the next limit.  Here every iteration has
+//   1. ONE branch-free load phase: two rank blocks (4 loads each: 16+16+8 B of planes, 4 B count),
+//      one generic 16-byte load (k-mer entry, read meta, fragment descriptor or SA sample), and -
+//      only when some lane of the wave needs it - the 64-byte peptide window of a new fragment;
+//      lanes that need less load a hot dummy line;
+//   2. one wait (implicit, at the first use);
+//   3. the per-kind compute and the bookkeeping, which touch no device memory on the hot paths.
+// Every kind of step therefore costs one iteration: STEP (UpdateSI), KMER (table start), LF1/LF2
+// (letter, then rank, of one LF step), SA (sampled row -> taxon id), META / FRAG / FILL (read meta,
+// first fragment descriptor, peptide window + next descriptor).  Work is handed out to wavefronts
+// in chunks of consecutive reads (one atomic per chunk, guided chunk size), lanes take reads
+// from the wave's chunk with a ballot/prefix count.
+// ----------------------------------------------------------------------------
+enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT };
+enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
+
+struct u128 { uint64_t x, y; };
+typedef u128 u128_unaligned __attribute__((aligned(1)));
+
+#if defined(__HIP_DEVICE_COMPILE__)
+KJ_HD uint32_t kj_nwaves() { return (gridDim.x * blockDim.x) >> 6; }
+KJ_HD uint32_t kj_fetch_chunk(uint32_t *counter, uint32_t n) { return atomicAdd(counter, n); }
+#else
+KJ_HD uint32_t kj_nwaves() { return 1; }
+KJ_HD uint32_t kj_fetch_chunk(uint32_t *counter, uint32_t n) { const uint32_t v = *counter; *counter += n; return v; }
+#endif
+
+KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
+                     const LaneScratch &ls) {
+  typedef uint32_t P;
+  int kind = K_IDLE;
+  // read
+  uint32_t r = 0, nf = 0, f = 0, fcur = 0, fbase = 0;
+  uint64_t pepoff = 0;
+  Frag dnext; dnext.start = dnext.len = dnext.key = dnext.flags = 0;
+  // fragment / search
+  uint64_t fsoff = 0;
+  int flen = 0, j = 0, i = 0;
+  P lo = 0, hi = 0;
+  uint32_t c = 1, L = p.m, nsi = 0, kidx = 0;
+  bool found = false, ovf = false;
+  int fill_top = 0;
+  bool fill_newfrag = false, fill_step = false;
+  // first two maximal matches live in registers, further ones in the lane's scratch
+  P s0lo = 0, s1lo = 0; uint32_t s0len = 0, s1len = 0, s0frag = 0, s1frag = 0;
+  // locate
+  uint32_t gs = 0, ge = 0, cur = 0, nids = 0, flags = 0;
+  P row = 0, rowend = 0, k = 0;
+  uint64_t id0 = 0, sa_idx = 0;
+  bool fresh = true;                          // k is the first row of its walk (the id cap is tested there)
+  Hit *hit = nullptr;
+  LaneWin lw{ls.win, 0};
+  const P check = (P)((1u << ix.chpt_exp) - 1);
+  const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m && ix.kmer32) ? ix.kmer_k : 0;
+  const uint32_t nwaves = kj_nwaves();
+  uint32_t wnext = 0, wend = 0;                 // the wave's chunk of work items (wave-uniform)
+  const RankBlock64 *const blk0 = ix.blocks64;
+
+  auto si_lo = [&](uint32_t e) -> P { return e == 0 ? s0lo : e == 1 ? s1lo : (P)ls.si[e].lo; };
+  auto si_len = [&](uint32_t e) -> uint32_t { return e == 0 ? s0len : e == 1 ? s1len : ls.si[e].len; };
+  auto si_frag = [&](uint32_t e) -> uint32_t { return e == 0 ? s0frag : e == 1 ? s1frag : ls.si[e].frag; };
+  auto in_win = [&](int pos) -> bool { return pos >= lw.q && pos < lw.q + kWin; };
+
+  for (;;) {
+    // ---- (0) hand out reads to the lanes that finished one (wave-uniform control flow) ----
+    {
+      const bool need = kind == K_IDLE;
+      const uint64_t mask = kj_ballot(need);
+      if (mask) {
+        const uint32_t n = popc64(mask);
+        const uint32_t rank = popc64(mask & ((1ull << kj_lane()) - 1ull));
+        const uint32_t avail = wend - wnext;
+        uint32_t newbase = 0, ch = 0;
+        if (n > avail) {
+          // guided chunk size: large while much work is left, small near the end of the batch
+          const uint32_t left = n_items > wend ? n_items - wend : 0;
+          ch = left / (nwaves * 4u);
+          if (ch > 128u) ch = 128u;
+          if (ch < 8u) ch = 8u;
+          if (ch < n - avail) ch = n - avail;
+          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+          uint32_t got = 0;
+          if (kj_lane() == leader) got = kj_fetch_chunk(wl.counter, ch);
+          newbase = kj_bcast(got, leader);
+        }
+        if (need) {
+          const uint32_t item = rank < avail ? wnext + rank : newbase + (rank - avail);
+          if (item >= n_items) kind = K_EXIT;
+          else { r = wl.reads ? wl.reads[item] : item; kind = K_META; }
+        }
+        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
+        else wnext += n;
+      }
+      if (kj_ballot(kind != K_EXIT) == 0) break;
+    }
+
+    // ---- (1) load phase: no branches between the loads and their first use ----
+    const bool is_step = kind == K_STEP, is_lf = kind == K_LF1 || kind == K_LF2;
+    const P posA = is_step ? lo : is_lf ? k : 0;
+    const P posB = is_step ? hi : posA;
+    const uint32_t cc = (is_step || kind == K_LF2) ? c : 1u;
+    const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
+    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
+    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
+    const uint64_t a4 = pa->plane[4];
+    const uint32_t ca = pa->cnt[cc - 1];
+    const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
+    const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
+    const uint64_t b4 = pb->plane[4];
+    const uint32_t cb = pb->cnt[cc - 1];
+    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
+    if (kind == K_KMER) gaddr = reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
+    else if (kind == K_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
+    else if (kind == K_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
+    else if (kind == K_FILL && fill_newfrag && f < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + f);
+    const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
+    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
+    int fq = 0;
+    if (kj_ballot(kind == K_FILL)) {                       // wave-uniform
+      fq = fill_top - (kWin - 1);
+      if (fq < 0) fq = 0;
+      const uint8_t *src = kind == K_FILL ? b.pep + fsoff + fq : reinterpret_cast<const uint8_t *>(blk0);
+      const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
+      w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
+    }
+
+    // ---- (2) compute ----
+    int bk = BK_NONE;
+    if (is_step || kind == K_LF2) {
+      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
+                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
+      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
+      const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
+      if (is_step) {
+        // UpdateSI(str[i-1]) (bwt.c:160-173)
+        const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
+        const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
+        if (ra >= rb) bk = BK_END_MATCH;
+        else {
+          lo = ra; hi = rb; i--;
+          if (i == 0) bk = BK_END_MATCH;
+          else if (in_win(i - 1)) c = lw.w[i - 1 - lw.q];
+          else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
+        }
+      } else {
+        // second half of an LF step (FMindexCurrent, compactfmi.c:312-336): k = C[c] + rank(c, k)
+        k = ra; fresh = false;
+        bk = BK_LOC_ROW;                                   // re-enters at the checkpoint test
+      }
+    } else if (kind == K_KMER) {
+      // InitialSI + (kk-1) UpdateSI in one lookup
+      const uint64_t e = ghalf ? gv.y : gv.x;
+      lo = (P)e; hi = (P)e + (P)(e >> 32);
+      if (lo >= hi) { i = j; bk = BK_END_MATCH; }          // match shorter than kk: never recorded, i > 1
+      else {
+        i = j - (int)kk + 1;
+        if (i == 0) bk = BK_END_MATCH;
+        else if (in_win(i - 1)) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
+        else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
+      }
+    } else if (kind == K_LF1) {
+      // first half of an LF step: the BWT letter of row k
+      const uint32_t sft = k & 63u;
+      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
+          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
+      if (c != 0) kind = K_LF2;
+      else {
+        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+        const uint32_t iseq = (uint32_t)rank_term(ix, k);
+        if (iseq < ix.nseq && ix.seq_valid[iseq]) {
+          const uint64_t tax = ix.seq_taxid[iseq];
+          bool dup = false;
+          if (nids >= 1 && tax == id0) dup = true;
+          for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+          if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+        }
+        row++;
+        k = row; fresh = true;
+        bk = BK_LOC_ROW;
+      }
+    } else if (kind == K_SA) {
+      const uint64_t tax = ghalf ? gv.y : gv.x;
+      if (tax != ~0ull) {
+        bool dup = false;
+        if (nids >= 1 && tax == id0) dup = true;
+        for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+        if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+      }
+      row++;
+      k = row; fresh = true;
+      bk = BK_LOC_ROW;
+    } else if (kind == K_META) {
+      pepoff = gv.x;
+      fbase = (uint32_t)gv.y;
+      nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
+      f = 0; L = p.m; nsi = 0; found = false; ovf = false;
+      hit = b.hits + r;
+      if (nf == 0) bk = BK_LOC_INIT; else kind = K_FRAG;
+    } else if (kind == K_FRAG) {
+      dnext.start = (uint32_t)gv.x; dnext.len = (uint32_t)(gv.x >> 32);
+      dnext.key = (uint32_t)gv.y; dnext.flags = (uint32_t)(gv.y >> 32);
+      bk = BK_NEXT_FRAG;
+    } else if (kind == K_FILL) {
+      lw.q = fq;
+      uint32_t *d32 = reinterpret_cast<uint32_t *>(lw.w);   // 4-byte aligned LDS: written as dwords
+      d32[0] = (uint32_t)w0.x; d32[1] = (uint32_t)(w0.x >> 32); d32[2] = (uint32_t)w0.y; d32[3] = (uint32_t)(w0.y >> 32);
+      d32[4] = (uint32_t)w1.x; d32[5] = (uint32_t)(w1.x >> 32); d32[6] = (uint32_t)w1.y; d32[7] = (uint32_t)(w1.y >> 32);
+      d32[8] = (uint32_t)w2.x; d32[9] = (uint32_t)(w2.x >> 32); d32[10] = (uint32_t)w2.y; d32[11] = (uint32_t)(w2.y >> 32);
+      d32[12] = (uint32_t)w3.x; d32[13] = (uint32_t)(w3.x >> 32); d32[14] = (uint32_t)w3.y; d32[15] = (uint32_t)(w3.y >> 32);
+      if (fill_newfrag) {
+        if (f < nf) {
+          dnext.start = (uint32_t)gv.x; dnext.len = (uint32_t)(gv.x >> 32);
+          dnext.key = (uint32_t)gv.y; dnext.flags = (uint32_t)(gv.y >> 32);
+        }
+        bk = BK_START_J;
+      } else if (fill_step) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
+      else bk = BK_START_J;
+    }
+
+    // ---- (3) bookkeeping, blocks ordered along the usual flow (see mem_lane) ----
+    while (bk != BK_NONE) {
+      if (bk == BK_END_MATCH) {
+        const uint32_t l = (uint32_t)(j - i + 1);
+        if (l >= L) {
+          if (l > L) { nsi = 0; ovf = false; L = l; }      // shorter matches are dropped (bwt.c:366-370, :577-582)
+          const uint32_t ilen = (uint32_t)(int32_t)(hi - lo);
+          if (nsi == 0) { s0lo = lo; s0len = ilen; s0frag = fcur; }
+          else if (nsi == 1) { s1lo = lo; s1len = ilen; s1frag = fcur; }
+          else if (nsi < ls.si_cap) { SIEntry e; e.lo = lo; e.len = ilen; e.frag = fcur; ls.si[nsi] = e; }
+          else ovf = true;
+          nsi++;
+          found = true;
+        }
+        if (i <= 1) bk = BK_NEXT_FRAG;                     // bwt.c:376
+        else { j--; bk = BK_START_J; }
+      }
+      if (bk == BK_START_J) {
+        // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356)
+        if (j < (int)L - 1) bk = BK_NEXT_FRAG;
+        else if (kk && j >= (int)kk - 1) {
+          if (in_win(j) && in_win(j - (int)kk + 1)) {
+            kidx = 0;
+            for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
+            kind = K_KMER; bk = BK_NONE;
+          } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
+        } else if (in_win(j)) {
+          c = lw.w[j - lw.q];
+          lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];            // InitialSI, bwt.c:146-152
+          i = j;
+          if (i == 0) bk = BK_END_MATCH;
+          else if (in_win(i - 1)) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; bk = BK_NONE; }
+          else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; bk = BK_NONE; }
+        } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
+      }
+      if (bk == BK_NEXT_FRAG) {
+        // getNextFragment(longest): stop when the best remaining key < longest (:550, :279);
+        // dnext is the prefetched descriptor of fragment f
+        if (f >= nf || (found && dnext.key < L)) bk = BK_LOC_INIT;
+        else {
+          fcur = f; f++;
+          fsoff = pepoff + dnext.start; flen = (int)dnext.len;
+          j = flen - 1;
+          fill_top = j; fill_newfrag = true; fill_step = false;
+          kind = K_FILL; bk = BK_NONE;
+        }
+      }
+      if (bk == BK_LOC_INIT) {
+        nids = 0; flags = 0;
+        hit->best = found ? L : 0u;
+        hit->reserved = 0;
+        if (!found) bk = BK_FINISH;
+        else if (ovf) {
+          if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+          else flags = kHitInternalOverflow;
+          bk = BK_FINISH;
+        } else { gs = ge = cur = 0; bk = BK_LOC_NEXT_SI; }
+      }
+      if (bk == BK_LOC_NEXT_SI) {
+        // matches of one fragment were found for descending j but are visited for ascending j
+        // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845)
+        bool any = true;
+        if (cur == gs) {
+          gs = ge;
+          if (gs >= nsi) { bk = BK_FINISH; any = false; }
+          else {
+            const uint32_t fr = si_frag(gs);
+            ge = gs + 1;
+            while (ge < nsi && si_frag(ge) == fr) ge++;
+            cur = ge;
+          }
+        }
+        if (any) {
+          cur--;
+          row = si_lo(cur); rowend = row + (P)(int32_t)si_len(cur);
+          k = row; fresh = true;
+          bk = BK_LOC_ROW;
+        }
+      }
+      if (bk == BK_LOC_ROW) {
+        // k is either a fresh row (k == row) or the row reached by the LF walk so far
+        if (row >= rowend) bk = BK_LOC_NEXT_SI;
+        else if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = BK_FINISH; }   // :805-807
+        else if ((k & check) != 0) { kind = K_LF1; bk = BK_NONE; }
+        else {
+          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+          if (sa_idx < ix.n_sa) { kind = K_SA; bk = BK_NONE; }
+          else { row++; k = row; fresh = true; }           // (the reference reads out of bounds here): skip the row
+        }
+      }
+      if (bk == BK_FINISH) {
+        hit->n_ids = nids; hit->flags = flags;
+        kind = K_IDLE; bk = BK_NONE;
+      }
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------

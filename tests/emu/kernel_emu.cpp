@@ -146,7 +146,9 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     }
     if (p.mode == 0) {
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
-      if (d.sb32 && !getenv("KAIJU_EMU_WIDE") && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls);
+      const char *v = getenv("KAIJU_EMU_LANE");        // "v1", "wide" or default (v2 where possible)
+      if (d.blocks64 && d.kmer32 && !v && pass == 0) mem_lane2(d, p, b, wl, ls);
+      else if (d.sb32 && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls);
       else mem_lane<uint64_t>(d, p, b, wl, ls);
     } else {
       GreedyScratch gs;

@@ -75,11 +75,14 @@ def test_lanes_vs_oracle_paired(oracle, emu, golden, handles, mode, seg):
 
 
 @pytest.mark.parametrize("mode,seg", CASES)
-def test_retry_pass(oracle, emu, golden, handles, mode, seg):
+def test_retry_pass(oracle, emu, golden, handles, mode, seg, monkeypatch):
     """scratch far too small in the main pass: every overflowing read must come out right
     from the retry pass"""
     h, ix, tax = handles
     oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), golden.seqs, golden.off)
+    # the second-generation MEM lane keeps two matches in registers; the first-generation lane
+    # (which is also what the retry pass itself runs) overflows with a 1-entry buffer
+    monkeypatch.setenv("KAIJU_EMU_LANE", "v1")
     gh, nretry = emu.classify(h, util.gp(mode, seg=seg), golden.seqs, golden.off, caps=(1, 12, 2))
     assert nretry > 0
     bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
@@ -127,3 +130,20 @@ def test_golden_tsv_through_host_seam(emu, golden, handles):
                         assert tuple(sorted(int(x) for x in gh[i]["taxid"][:gh[i]["n_ids"]])) == r[3]
                     else:
                         assert res[i]["classified"] == 0, (mode, seg, pe, n)
+
+
+@pytest.mark.parametrize("lane", ["v1", "wide", None])
+def test_mem_lane_generations_agree(oracle, emu, golden, handles, lane, monkeypatch):
+    """first-generation (32/64-bit positions) and second-generation MEM lanes give identical records"""
+    h, ix, tax = handles
+    if lane:
+        monkeypatch.setenv("KAIJU_EMU_LANE", lane)
+    for seg in (1, 0):
+        oh = oracle.classify(ix, tax, oracle.params("mem", seg=seg), golden.seqs, golden.off)
+        gh, _ = emu.classify(h, util.gp("mem", seg=seg), golden.seqs, golden.off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (lane, seg, bad[:5])
+        oh = oracle.classify(ix, tax, oracle.params("mem", seg=seg), golden.pseqs, golden.poff, paired=True)
+        gh, _ = emu.classify(h, util.gp("mem", seg=seg), golden.pseqs, golden.poff, paired=True)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (lane, seg, "paired", bad[:5])
