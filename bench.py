@@ -152,6 +152,7 @@ def main():
     n = args.reads
     reads = synth.make_reads(db, n, seed=777 + rank)
     L = reads.shape[1]
+    clf.set_max_read_length(L)
     d_seqs = torch.from_numpy(reads.reshape(-1)).to(dev)
     chunk = min(args.chunk, n)
     bounds = [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]

@@ -158,6 +158,10 @@ int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_
 int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d_seqs, uint64_t seq_bytes,
                                     const uint64_t *d_off, uint32_t n_reads, int paired,
                                     kaiju_gpu_hit *d_out, void *stream);
+/* Upper bound of the read (mate) lengths of the batches handed to classify_batch_device; it sizes
+   per-lane scratch and selects the LDS-staged translation kernel for short reads.  The host-buffer
+   entry point measures it itself.  Default 1024. */
+int kaiju_gpu_set_max_read_length(kaiju_gpu_ctx *ctx, uint32_t max_read_len);
 int kaiju_gpu_synchronize(kaiju_gpu_ctx *ctx);
 int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats);
 

@@ -75,6 +75,7 @@ def lib():
     L.kaiju_gpu_classify_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
     L.kaiju_gpu_classify_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
                                                   C.c_int, C.c_void_p, C.c_void_p]
+    L.kaiju_gpu_set_max_read_length.argtypes = [C.c_void_p, C.c_uint32]
     L.kaiju_gpu_synchronize.argtypes = [C.c_void_p]
     L.kaiju_gpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.kaiju_taxonomy_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
@@ -170,6 +171,10 @@ class Classifier:
         _check(lib().kaiju_gpu_classify_batch(self._h, seqs.ctypes.data, off.ctypes.data, n,
                                               1 if paired else 0, hits.ctypes.data))
         return hits
+
+    def set_max_read_length(self, n: int):
+        """upper bound of the read lengths given to classify_device (sizes scratch, picks the staged kernel)"""
+        _check(lib().kaiju_gpu_set_max_read_length(self._h, int(n)))
 
     def classify_device(self, d_seqs_ptr: int, seq_bytes: int, d_off_ptr: int, n: int, d_out_ptr: int,
                         paired=False, stream: int = 0):

@@ -40,16 +40,28 @@ __device__ __forceinline__ void load_tables(ConstTables &s_ct, const ConstTables
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(kBlock)
-k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err) {
+// Stage 1, one lane per read, 64-thread blocks.  stage_bytes > 0: the six frame strings of every
+// lane are staged in LDS (dword-interleaved over the wavefront) and copied out with 16-byte
+// stores; 0: reads too long for LDS, strings are written in place.
+constexpr int kFragBlock = 64;
+__global__ void __launch_bounds__(kFragBlock)
+k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err,
+            uint32_t stage_bytes) {
   __shared__ ConstTables s_ct;
   __shared__ int64_t s_entg[13];
+  extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];
   if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
-  load_tables(s_ct, g_ct);
-  const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
+    for (uint32_t i = threadIdx.x; i < sizeof(ConstTables) / 4; i += kFragBlock) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t r = blockIdx.x * kFragBlock + threadIdx.x;
   if (r >= b.n_reads) return;
   uint32_t e = 0;
-  build_fragments(s_ct, p, seg_ctx(st, s_entg, nullptr), b, sq, r, &e);
+  build_fragments(s_ct, p, seg_ctx(st, s_entg, nullptr), b, sq, r, &e,
+                  stage_bytes ? s_stage + 4 * threadIdx.x : nullptr, 4 * kFragBlock);
   if (e) atomicOr(err, e);
 }
 
@@ -67,19 +79,22 @@ struct CoopWave {
   }
 };
 
-// SEG pass: one wavefront per fragment that stage 1 flagged (count lives in device memory)
-__global__ void __launch_bounds__(kBlock)
+// SEG pass: one wavefront (= one 64-thread block at a time) per fragment that stage 1 flagged; the
+// fragment is copied to LDS first.  The number of fragments lives in device memory.
+constexpr int kSegBlock = 64, kSegStage = 2048;
+__global__ void __launch_bounds__(kSegBlock)
 k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   __shared__ int64_t s_entg[13];
   __shared__ double s_lnf[kSegLnf];
+  __shared__ __attribute__((aligned(16))) uint8_t s_frag[kSegStage];
   if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
   if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
   __syncthreads();
   const SegCtx cx = seg_ctx(st, s_entg, s_lnf);
   const CoopWave coop;
   const uint32_t n = min(*sq.count, sq.cap);
-  const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
-  for (uint32_t s = wave; s < n; s += nwaves) seg_compute(cx, coop, b, p, sq, s);
+  for (uint32_t s = blockIdx.x; s < n; s += gridDim.x)       // trip count is uniform over the block
+    seg_compute(cx, coop, b, p, sq, s, s_frag, kSegStage, [] { __syncthreads(); });
 }
 
 // MEM: apply the SEG records to the fragment lists
@@ -331,6 +346,7 @@ struct kaiju_gpu_ctx {
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
   kaiju_gpu_stats stats{};
   uint32_t last_n = 0;
+  uint32_t max_read_len = 1024;
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
@@ -411,7 +427,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if (max_read_len == 0) max_read_len = 1024;
   const uint64_t max_pair = (uint64_t)max_read_len * (paired ? 2 : 1);
   // stage buffers
-  const uint64_t pep_bytes = 2 * seq_bytes + 32ull * n + 16 + 192;   // pep_base() + window over-read slack
+  const uint64_t pep_bytes = 2 * seq_bytes + 80ull * n + 32 + 256;   // pep_base() + window over-read slack
   const uint64_t n_frag_slots = 2 * ((2 * seq_bytes) / (p.m + 1) + 7ull * n) + 8;
   int rc;
   if ((rc = ensure(c->pep, pep_bytes))) return rc;
@@ -437,12 +453,16 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
   if (n > 0) {
-    hipLaunchKernelGGL(k_fragments, grid_reads, blk, 0, s, ix->d_ct, p, ix->st, b, sq, cnt + 3);
+    // LDS staging area per lane: all frame strings of a read (or pair), rounded to 16 bytes
+    uint32_t per_lane = (uint32_t)((2 * max_pair + 12 + 15) & ~15ull);
+    if ((uint64_t)per_lane * kFragBlock > 60000) per_lane = 0;        // long reads: write in place
+    hipLaunchKernelGGL(k_fragments, dim3((n + kFragBlock - 1) / kFragBlock), dim3(kFragBlock),
+                       (size_t)per_lane * kFragBlock, s, ix->d_ct, p, ix->st, b, sq, cnt + 3, per_lane);
     KJ_HIP(hipGetLastError());
   }
   KJ_HIP(hipEventRecord(c->ev[1], s));
   if (n > 0 && p.seg) {
-    hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 4), blk, 0, s, p, ix->st, b, sq);
+    hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 32), dim3(kSegBlock), 0, s, p, ix->st, b, sq);
     KJ_HIP(hipGetLastError());
     if (p.mode == 0) {
       hipLaunchKernelGGL(k_seg_apply, grid_reads, blk, 0, s, ix->d_ct, p, b, sq, cnt + 3);
@@ -524,9 +544,7 @@ extern "C" int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d
   if (!ctx || (!d_seqs && seq_bytes) || !d_off || (!d_out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   KJ_HIP(hipSetDevice(ctx->ix->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-  uint32_t max_len = 0;
-  if (const char *e = getenv("KAIJU_GPU_MAX_READ_LEN")) max_len = (uint32_t)atoi(e);
-  return launch_batch(ctx, d_seqs, seq_bytes, d_off, n_reads, paired, max_len, d_out, s);
+  return launch_batch(ctx, d_seqs, seq_bytes, d_off, n_reads, paired, ctx->max_read_len, d_out, s);
 }
 
 extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off,
@@ -556,6 +574,12 @@ extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, co
   if (rc) return rc;
   KJ_HIP(hipMemcpyAsync(out, ctx->h_hits.p, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyDeviceToHost, s));
   KJ_HIP(hipStreamSynchronize(s));
+  return KAIJU_GPU_OK;
+}
+
+extern "C" int kaiju_gpu_set_max_read_length(kaiju_gpu_ctx *ctx, uint32_t max_read_len) {
+  if (!ctx || max_read_len == 0 || max_read_len > 0x3fffffffu) return fail(KAIJU_GPU_ERR_ARG, "bad max_read_len");
+  ctx->max_read_len = max_read_len;
   return KAIJU_GPU_OK;
 }
 

@@ -32,6 +32,10 @@ struct ulonglong2 { uint64_t x, y; };
 
 namespace kj {
 
+struct u128 { uint64_t x, y; };
+typedef u128 u128_unaligned __attribute__((aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
 // ----------------------------------------------------------------------------
 // constants shared with the host
 // ----------------------------------------------------------------------------
@@ -172,7 +176,7 @@ struct Batch {
 
 // layout helpers (closed form, no prefix sums needed) -------------------------
 // peptide area of read r: <= 2*(len1+len2) + 12 bytes of strings after 8 bytes of front padding
-KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return ((2 * off[2 * (uint64_t)r] + 3) & ~3ull) + 32ull * r + 8; }
+KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return ((2 * off[2 * (uint64_t)r] + 15) & ~15ull) + 80ull * r + 16; }
 // fragment slots of read r: a read has at most (2*(len1+len2)+12)/(m+1) disjoint fragments;
 // twice that is reserved so that SEG pieces can sit next to their parents
 KJ_HD uint64_t frag_base(const uint64_t *off, uint32_t r, uint32_t m) {
@@ -316,11 +320,13 @@ KJ_HD void segwin_add(SegWin &w, const SegCtx &cx, uint32_t a, int d) {
   if (a < 16) w.c0 += (uint64_t)(int64_t)d << (4 * a);
   else w.c1 += (uint64_t)(int64_t)d << (4 * (a - 16));
 }
-KJ_HD void segwin_open(SegWin &w, const SegCtx &cx, const uint8_t *s, int start) {
+template <class S>
+KJ_HD void segwin_open(SegWin &w, const SegCtx &cx, const S &s, int start) {
   w.c0 = w.c1 = 0; w.score = 0;
   for (int i = 0; i < kSegWindow; i++) segwin_add(w, cx, KJ_SL(s, start + i), +1);
 }
-KJ_HD void segwin_shift(SegWin &w, const SegCtx &cx, const uint8_t *s, int start) {   // start -> start+1
+template <class S>
+KJ_HD void segwin_shift(SegWin &w, const SegCtx &cx, const S &s, int start) {   // start -> start+1
   segwin_add(w, cx, KJ_SL(s, start), -1);
   segwin_add(w, cx, KJ_SL(s, start + kSegWindow), +1);
 }
@@ -537,7 +543,27 @@ KJ_HD uint32_t append_slot(uint32_t *counter) { return (*counter)++; }
 // (getAllFragmentsBits ConsumerThread.cpp:190-270; for MEM also the SEG split of
 //  getNextFragment :272-342 applied eagerly, which SURVEY.md §8a shows equivalent)
 // ----------------------------------------------------------------------------
-KJ_HD uint32_t diag_score(const ConstTables &t, const uint8_t *pep, uint32_t start, uint32_t len) {
+// Where stage 1 keeps the peptides of a read while it works on them: byte p lives at
+// base[(p >> 2) * row + (p & 3)].  row = 4 is plain linear memory; on the device the kernel stages
+// the six frame strings in LDS, interleaved dword-wise over the 64 lanes of the wavefront
+// (row = 256: conflict-free for lanes at the same position), and copies them out with 16-byte
+// stores at the end, so that HBM only ever sees full 32-byte sectors instead of a trickle of byte
+// stores that each cost a read-modify-write.
+struct PepBuf {
+  uint8_t *base;
+  uint32_t row;
+  KJ_HD uint8_t get(uint32_t p) const { return base[(size_t)(p >> 2) * row + (p & 3u)]; }
+  KJ_HD void put(uint32_t p, uint8_t v) const { base[(size_t)(p >> 2) * row + (p & 3u)] = v; }
+  KJ_HD uint32_t get32(uint32_t p) const { return *reinterpret_cast<const uint32_t *>(base + (size_t)(p >> 2) * row); }
+};
+struct PepView {             // a fragment inside a PepBuf, indexable like a byte string
+  PepBuf b;
+  uint32_t off;
+  KJ_HD uint8_t operator[](int i) const { return b.get(off + (uint32_t)i); }
+};
+
+template <class S>
+KJ_HD uint32_t diag_score(const ConstTables &t, const S &pep, uint32_t start, uint32_t len) {
   uint32_t s = 0;
   for (uint32_t i = 0; i < len; i++) { const uint32_t a = t.idx_to_aa[pep[start + i]]; s += (uint32_t)t.b62[a][a]; }
   return s;
@@ -552,65 +578,93 @@ KJ_HD void frag_insert(Frag *list, uint32_t &n, uint32_t cap, const Frag &f) {
   n++;
 }
 
-KJ_HD void emit_run(const ConstTables &t, const Params &p, const uint8_t *pep, Frag *list, uint32_t &n,
+KJ_HD void emit_run(const ConstTables &t, const Params &p, const PepBuf &pep, Frag *list, uint32_t &n,
                     uint32_t cap, uint32_t start, uint32_t len) {
   if (len < p.m) return;
   Frag f; f.start = start; f.len = len; f.flags = 0;
   if (p.mode == 1) {
-    f.key = diag_score(t, pep, start, len);
+    f.key = diag_score(t, PepView{pep, 0}, start, len);
     if (f.key < p.min_score) return;
   } else f.key = len;
   frag_insert(list, n, cap, f);
 }
 
+// nucleotide at position pos of a read, fetched four at a time
+struct NucReader {
+  const uint8_t *s;
+  uint32_t len, word, wq;
+  KJ_HD uint32_t at(uint32_t pos) {
+    const uint32_t q = pos >> 2;
+    if (q != wq) {
+      wq = q;
+      if (4 * q + 4 <= len) word = *reinterpret_cast<const u32_unaligned *>(s + 4 * q);
+      else { word = 0; for (uint32_t x = 4 * q; x < len; x++) word |= (uint32_t)s[x] << (8 * (x & 3u)); }
+    }
+    return (word >> (8 * (pos & 3u))) & 255u;
+  }
+};
+
 // translate one mate into six frame strings at pep[base..] and emit its fragments
 KJ_HD void translate_mate(const ConstTables &t, const Params &p, const uint8_t *s, uint32_t len,
-                          uint8_t *pep, uint32_t base, Frag *list, uint32_t &n, uint32_t cap) {
+                          const PepBuf &pep, uint32_t base, Frag *list, uint32_t &n, uint32_t cap) {
   const uint32_t fcap = len / 3 + 1;         // room of one frame string incl. closing stop
   uint32_t run_start[3], run_len[3];
-  // forward strand, ConsumerThread.cpp:196-233
+  NucReader nr{s, len, 0, 0xffffffffu};
+  // forward strand, ConsumerThread.cpp:196-233 (codon_to_int :869-871: any base that is not
+  // ACGTU makes the codon a stop)
   for (uint32_t f = 0; f < 3; f++) { run_start[f] = base + f * fcap; run_len[f] = 0; }
-  for (uint32_t count = 0; count + 2 < len; count++) {
-    const uint32_t f = count % 3, pos = base + f * fcap + count / 3;
-    const uint32_t aa = codon_fwd(t, s + count);
-    if (aa == 255u) {
-      pep[pos] = 0;
-      emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-      run_start[f] = pos + 1; run_len[f] = 0;
-    } else { pep[pos] = t.aa_to_idx[aa]; run_len[f]++; }
+  {
+    uint32_t a = t.nuc[nr.at(0)], bb = t.nuc[nr.at(1)];
+    uint32_t f = 0, tpos = 0;                // frame and residue index of the current codon
+    for (uint32_t count = 0; count + 2 < len; count++) {
+      const uint32_t c = t.nuc[nr.at(count + 2)];
+      const uint32_t pos = base + f * fcap + tpos;
+      const uint32_t aa = (a | bb | c) > 3u ? 255u : t.codon_aa[a * 16 + bb * 4 + c];
+      if (aa == 255u) {
+        pep.put(pos, 0);
+        emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
+        run_start[f] = pos + 1; run_len[f] = 0;
+      } else { pep.put(pos, t.aa_to_idx[aa]); run_len[f]++; }
+      a = bb; bb = c;
+      if (++f == 3) { f = 0; tpos++; }
+    }
   }
   for (uint32_t f = 0; f < 3; f++) {
     emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-    pep[run_start[f] + run_len[f]] = 0;
+    pep.put(run_start[f] + run_len[f], 0);
   }
   // reverse strand, :235-268: count runs len-3 .. 0, frame = count % 3, residues are appended
   // in visiting order (the count = len-2 iteration of the reference only sees the string
-  // terminator on an empty frame and is a no-op)
+  // terminator on an empty frame and is a no-op); revcomp_codon_to_int :873-875
   const uint32_t rbase = base + 3 * fcap, top = len - 3;
-  uint32_t cmax[3];
-  for (uint32_t f = 0; f < 3; f++) {
-    run_start[f] = rbase + f * fcap; run_len[f] = 0;
-    cmax[f] = top - ((top + 3 - f) % 3);      // largest count <= top with count % 3 == f
-  }
-  for (int64_t cnt = (int64_t)top; cnt >= 0; cnt--) {
-    const uint32_t count = (uint32_t)cnt, f = count % 3;
-    const uint32_t pos = rbase + f * fcap + (cmax[f] - count) / 3;
-    const uint32_t aa = codon_rev(t, s + count);
-    if (aa == 255u) {
-      pep[pos] = 0;
-      emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-      run_start[f] = pos + 1; run_len[f] = 0;
-    } else { pep[pos] = t.aa_to_idx[aa]; run_len[f]++; }
+  uint32_t wpos[3];                          // next write position of each frame string
+  for (uint32_t f = 0; f < 3; f++) { run_start[f] = rbase + f * fcap; run_len[f] = 0; wpos[f] = rbase + f * fcap; }
+  {
+    uint32_t x = t.nuc[nr.at(len - 1)], y = t.nuc[nr.at(len - 2)];
+    uint32_t f = top % 3;
+    for (int64_t cnt = (int64_t)top; cnt >= 0; cnt--) {
+      const uint32_t z = t.nuc[nr.at((uint32_t)cnt)];
+      const uint32_t pos = wpos[f]++;
+      const uint32_t aa = (x | y | z) > 3u ? 255u : t.codon_aa[(3 - x) * 16 + (3 - y) * 4 + (3 - z)];
+      if (aa == 255u) {
+        pep.put(pos, 0);
+        emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
+        run_start[f] = pos + 1; run_len[f] = 0;
+      } else { pep.put(pos, t.aa_to_idx[aa]); run_len[f]++; }
+      x = y; y = z;
+      f = f == 0 ? 2 : f - 1;
+    }
   }
   for (uint32_t f = 0; f < 3; f++) {
     emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-    pep[run_start[f] + run_len[f]] = 0;
+    pep.put(run_start[f] + run_len[f], 0);
   }
 }
 
 // does any 12-window of the fragment reach the trigger entropy (H <= locut)?  Exactly then
 // SeqBufferSeg reports at least one region (s_SegSeq, blast_seg.c:2061).
-KJ_HD bool seg_triggers(const SegCtx &cx, const uint8_t *s, int len) {
+template <class S>
+KJ_HD bool seg_triggers(const SegCtx &cx, const S &s, int len) {
   if (len < kSegWindow) return false;
   SegWin w{0, 0, 0};
   segwin_open(w, cx, s, 0);
@@ -623,16 +677,25 @@ KJ_HD bool seg_triggers(const SegCtx &cx, const uint8_t *s, int len) {
 }
 
 // the SEG pass proper: regions of one flagged fragment -> record (written by lane 0 of the team)
-template <class Coop>
+// `stage` (optional, `stage_cap` bytes, shared by the lanes of the team) receives a copy of the
+// fragment so that the scan does not go to device memory for every residue.
+template <class Coop, class Sync>
 KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const Params &p, const SegQueue &sq,
-                       uint32_t slot) {
+                       uint32_t slot, uint8_t *stage, uint32_t stage_cap, Sync &&team_sync) {
   const SegWork wk = sq.items[slot];
   const ReadMeta rm = b.meta[wk.read];
   const Frag f = b.frags[rm.frag + wk.frag];
   const uint8_t *pep = b.pep + rm.pep;
+  const uint8_t *src = pep + f.start;
+  if (stage && f.len <= stage_cap) {
+    team_sync();                                            // the previous fragment is no longer read
+    for (uint32_t x = (uint32_t)coop.lane(); x < f.len; x += (uint32_t)coop.width()) stage[x] = src[x];
+    team_sync();
+    src = stage;
+  }
   int32_t left[kSegMaxRegions], right[kSegMaxRegions];
   bool ov = false;
-  const int n = seg_regions(cx, coop, pep + f.start, (int)f.len, left, right, ov);
+  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov);
   if (coop.lane() != 0) return;
   SegRec rec;
   rec.overflow = (ov || n > kSegRecRegions || f.len > 65535u) ? 1 : 0;
@@ -672,15 +735,19 @@ struct FragAppend {
   KJ_HD void operator()(const Frag &q) const { if (*n < cap) dst[(*n)++] = q; }
 };
 
-// stage 1 for read r: translation, fragment list in queue order, SEG trigger detection
+// stage 1 for read r: translation, fragment list in queue order, SEG trigger detection.
+// `stage` is the lane's staging area (LDS on the device) or nullptr (peptides are written
+// straight to their place: long reads, host emulation of that path).
 KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &cx, const Batch &b,
-                           const SegQueue &sq, uint32_t r, uint32_t *err_flags) {
+                           const SegQueue &sq, uint32_t r, uint32_t *err_flags, uint8_t *stage, uint32_t stage_row) {
   const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
   const uint32_t len1 = (uint32_t)(o1 - o0), len2 = (uint32_t)(o2 - o1);
   const uint32_t m3 = p.m * 3;
   Frag *list = b.frags + frag_base(b.off, r, p.m);
   const uint32_t cap = frag_cap(b.off, r, p.m);
-  uint8_t *pep = b.pep + pep_base(b.off, r);
+  const uint64_t pbase = pep_base(b.off, r);
+  PepBuf pep;
+  if (stage) { pep.base = stage; pep.row = stage_row; } else { pep.base = b.pep + pbase; pep.row = 4; }
   uint32_t n = 0, pending = 0;
   // length gate, ConsumerThread.cpp:647-654
   const bool skip = b.paired ? (len1 < m3 && len2 < m3) : (len1 < m3);
@@ -689,7 +756,7 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
     if (b.paired && len2 >= m3) translate_mate(t, p, b.seqs + o1, len2, pep, 6 * (len1 / 3 + 1), list, n, cap);
     if (p.seg) {
       for (uint32_t k = 0; k < n; k++) {
-        if (seg_triggers(cx, pep + list[k].start, (int)list[k].len)) {
+        if (seg_triggers(cx, PepView{pep, list[k].start}, (int)list[k].len)) {
           const uint32_t slot = append_slot(sq.count);
           if (slot < sq.cap) {
             SegWork wk; wk.read = r; wk.frag = k;
@@ -700,8 +767,19 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
         } else list[k].flags |= kFragChecked;      // SEG would report nothing for this fragment
       }
     }
+    if (stage) {
+      // copy the strings out with 16-byte stores (the area of a read is 16-byte aligned)
+      const uint32_t used = 6 * (len1 / 3 + 1) + (b.paired ? 6 * (len2 / 3 + 1) : 0);
+      u128 *dst = reinterpret_cast<u128 *>(b.pep + pbase);
+      for (uint32_t q = 0; q * 16 < used; q++) {
+        u128 v;
+        v.x = (uint64_t)pep.get32(16 * q) | (uint64_t)pep.get32(16 * q + 4) << 32;
+        v.y = (uint64_t)pep.get32(16 * q + 8) | (uint64_t)pep.get32(16 * q + 12) << 32;
+        dst[q] = v;
+      }
+    }
   }
-  ReadMeta rm; rm.pep = pep_base(b.off, r); rm.frag = (uint32_t)frag_base(b.off, r, p.m); rm.nfrag = n | pending;
+  ReadMeta rm; rm.pep = pbase; rm.frag = (uint32_t)frag_base(b.off, r, p.m); rm.nfrag = n | pending;
   b.meta[r] = rm;
 }
 
@@ -744,7 +822,6 @@ struct LaneWin {
   uint8_t *w;                // kWin bytes, 4-byte aligned
   int32_t q;                 // fragment position of w[0]
 };
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 // always copies kWin bytes starting at fragment position q (bytes behind the fragment end are
 // never looked at; the peptide buffer is padded so that the read stays inside it)
 KJ_HD void win_fill(LaneWin &lw, const uint8_t *fs, int flen, int top) {
@@ -1022,8 +1099,6 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT };
 enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
 
-struct u128 { uint64_t x, y; };
-typedef u128 u128_unaligned __attribute__((aligned(1)));
 
 #if defined(__HIP_DEVICE_COMPILE__)
 KJ_HD uint32_t kj_nwaves() { return (gridDim.x * blockDim.x) >> 6; }

@@ -74,12 +74,18 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   if (p.mismatches > (uint32_t)kMaxMismatch) return KAIJU_GPU_ERR_UNSUPPORTED;
   Batch b;
   b.seqs = (const uint8_t *)seqs; b.off = off; b.n_reads = n; b.paired = paired;
-  std::vector<uint8_t> pep((size_t)pep_base(off, n) + 256, 0);
+  std::vector<uint8_t> pep((size_t)pep_base(off, n) + 512, 0);
   std::vector<Frag> frags((size_t)frag_base(off, n, p.m) + 8);
   std::vector<ReadMeta> meta(n);
   std::vector<Hit> hits(n);
   memset(hits.data(), 0, sizeof(Hit) * n);
   b.pep = pep.data(); b.frags = frags.data(); b.meta = meta.data(); b.hits = hits.data();
+  uint32_t maxlen = 0;
+  for (uint32_t r = 0; r < n; r++) {
+    uint32_t l1 = (uint32_t)(off[2 * r + 1] - off[2 * r]), l2 = (uint32_t)(off[2 * r + 2] - off[2 * r + 1]);
+    if (l1 > maxlen) maxlen = l1;
+    if (l2 > maxlen) maxlen = l2;
+  }
   uint32_t err = 0;
   // stage 1 -> SEG pass -> (MEM) apply, exactly the kernel sequence of capi.hip
   uint32_t seg_count = 0;
@@ -88,9 +94,14 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   std::vector<SegRec> seg_recs(seg_cap);
   SegQueue sq{seg_items.data(), seg_recs.data(), &seg_count, seg_cap};
   const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact);
-  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, cx, b, sq, r, &err);
+  // peptides are staged (here: linear scratch) and copied out, as the kernel does with its LDS area
+  std::vector<uint8_t> stage((size_t)4 * maxlen + 256);
+  const bool staged = !getenv("KAIJU_EMU_NOSTAGE");
+  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, cx, b, sq, r, &err, staged ? stage.data() : nullptr, 4);
   if (p.seg) {
-    for (uint32_t s = 0; s < seg_count && s < seg_cap; s++) seg_compute(cx, CoopSerial{}, b, p, sq, s);
+    std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
+    for (uint32_t s = 0; s < seg_count && s < seg_cap; s++)
+      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), [] {});
     if (p.mode == 0) for (uint32_t r = 0; r < n; r++) seg_apply_mem(ix->ct, p, b, sq, r, &err);
   }
   if (frag_dump) {
@@ -120,12 +131,6 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   std::vector<GItem> pool(pool_cap);
   std::vector<uint16_t> ord(pool_cap);
   std::vector<GMatch> matches(match_cap);
-  uint32_t maxlen = 0;
-  for (uint32_t r = 0; r < n; r++) {
-    uint32_t l1 = (uint32_t)(off[2 * r + 1] - off[2 * r]), l2 = (uint32_t)(off[2 * r + 2] - off[2 * r + 1]);
-    if (l1 > maxlen) maxlen = l1;
-    if (l2 > maxlen) maxlen = l2;
-  }
   std::vector<GBest> bestv(64);
   for (int pass = 0; pass < 2; pass++) {
     WorkList wl;
