@@ -499,10 +499,12 @@ KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len
 }
 
 // SeqBufferSeg (blast_seg.c:2278-2332).  Writes the merged regions in ascending order.
+// `work` = 2 * kSegMaxRegions ints of scratch (LDS shared by the team on the device: every lane of
+// the team computes the same values, so one copy serves all and no registers are spent on it).
 template <class Coop>
 KJ_HD int seg_regions(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len,
-                      int32_t *left, int32_t *right, bool &overflow) {
-  int32_t b[kSegMaxRegions], e[kSegMaxRegions];
+                      int32_t *left, int32_t *right, bool &overflow, int32_t *work) {
+  int32_t *b = work, *e = work + kSegMaxRegions;
   const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, kSegMaxRegions, overflow);
   if (n == 0) return 0;
   // the reference's list is in reverse creation order; s_MergeSegs (:2122-2152, hilenmin 0)
@@ -681,7 +683,7 @@ KJ_HD bool seg_triggers(const SegCtx &cx, const S &s, int len) {
 // fragment so that the scan does not go to device memory for every residue.
 template <class Coop, class Sync>
 KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const Params &p, const SegQueue &sq,
-                       uint32_t slot, uint8_t *stage, uint32_t stage_cap, Sync &&team_sync) {
+                       uint32_t slot, uint8_t *stage, uint32_t stage_cap, int32_t *work, Sync &&team_sync) {
   const SegWork wk = sq.items[slot];
   const ReadMeta rm = b.meta[wk.read];
   const Frag f = b.frags[rm.frag + wk.frag];
@@ -693,9 +695,10 @@ KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const
     team_sync();
     src = stage;
   }
-  int32_t left[kSegMaxRegions], right[kSegMaxRegions];
+  // scratch of the team: [0, 2R) scan lists, [2R, 4R) merged regions (R = kSegMaxRegions)
+  int32_t *left = work + 2 * kSegMaxRegions, *right = work + 3 * kSegMaxRegions;
   bool ov = false;
-  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov);
+  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov, work);
   if (coop.lane() != 0) return;
   SegRec rec;
   rec.overflow = (ov || n > kSegRecRegions || f.len > 65535u) ? 1 : 0;

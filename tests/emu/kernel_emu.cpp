@@ -57,7 +57,8 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   for (int i = 0; i < len; i++) codes[(size_t)i] = ix->packed.trans[(unsigned char)aa[i] & 127];
   bool ov = false;
   const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact);
-  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov);
+  int32_t work[2 * kSegMaxRegions];
+  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov, work);
   return ov ? -1 : n;
 }
 
@@ -99,9 +100,10 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   const bool staged = !getenv("KAIJU_EMU_NOSTAGE");
   for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, cx, b, sq, r, &err, staged ? stage.data() : nullptr, 4);
   if (p.seg) {
+    int32_t segwork[4 * kSegMaxRegions];
     std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
     for (uint32_t s = 0; s < seg_count && s < seg_cap; s++)
-      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), [] {});
+      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), segwork, [] {});
     if (p.mode == 0) for (uint32_t r = 0; r < n; r++) seg_apply_mem(ix->ct, p, b, sq, r, &err);
   }
   if (frag_dump) {
