@@ -172,6 +172,28 @@ k_greedy_retry(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQ
   greedy_body(ix, g_ct, p, sq, b, wl, ga);
 }
 
+// second-generation Greedy lane (kj_core.h:greedy_lane2): indexes below 2^32 symbols with a k-mer table.
+// Dynamic LDS: one row of kGLdsStride dwords per lane, then the constant tables.
+struct GreedyArrays2 {
+  u128 *pool; uint32_t *prio_ext; GMatch2 *matches; uint16_t *mq_ext; GBest2 *best;
+};
+constexpr size_t kGreedy2Lds = (size_t)kBlock * kGLdsStride * 4 + sizeof(ConstTables);
+__global__ void __launch_bounds__(kBlock, 2)
+k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_dyn + kBlock * kGLdsStride);
+  load_tables(s_ct, g_ct);
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  GreedyScratch2 gs;
+  gs.lds = s_dyn + threadIdx.x * kGLdsStride;
+  gs.pool = ga.pool + lane * (4 * kGSlotsAll);
+  gs.prio_ext = ga.prio_ext + lane * (kGSlotsAll - kGSlots);
+  gs.matches = ga.matches + lane * kGMaxMAll;
+  gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
+  gs.best = ga.best + lane * 64;
+  greedy_lane2(ix, s_ct, p, sq, b, wl, gs);
+}
+
 static_assert(sizeof(ConstTables) % 4 == 0, "ConstTables is copied as dwords");
 static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");
 
@@ -343,7 +365,8 @@ struct kaiju_gpu_ctx {
   bool ev_valid = false;
   int n_cu = 0, blocks_main = 0, blocks_retry = 0;
   DevBuf pep, frags, meta, counters, retry_list, seg_items, seg_recs;
-  DevBuf scratch_main[5], scratch_retry[5];
+  DevBuf scratch_main[10], scratch_retry[5];
+  bool greedy2 = false;
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
   kaiju_gpu_stats stats{};
   uint32_t last_n = 0;
@@ -353,7 +376,8 @@ struct kaiju_gpu_ctx {
     (void)hipSetDevice(ix->device);
     DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
-    for (int i = 0; i < 5; i++) { if (scratch_main[i].p) (void)hipFree(scratch_main[i].p); if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p); }
+    for (int i = 0; i < 10; i++) if (scratch_main[i].p) (void)hipFree(scratch_main[i].p);
+    for (int i = 0; i < 5; i++) if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -405,7 +429,16 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   c->n_cu = prop.multiProcessorCount;
   int occ = 0;
   if (p->mode == 0) KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mem, kBlock, 0));
-  else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy, kBlock, 0));
+  else {
+    c->greedy2 = ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p->seed_length &&
+                 p->seed_length >= 3;
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) if (!strcmp(e, "v1")) c->greedy2 = false;
+    if (c->greedy2) {
+      KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kGreedy2Lds));
+      KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy2, kBlock, kGreedy2Lds));
+    } else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy, kBlock, 0));
+  }
   if (occ < 1) occ = 1;
   if (occ > 8) occ = 8;
   if (const char *e = getenv("KAIJU_GPU_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }
@@ -508,10 +541,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     const uint32_t frag_max = max_read_len / 3 + 4;
     GreedyArrays ga;
     ga.pool_cap = 192; ga.match_cap = 64;
-    if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
-    if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
-    if ((rc = ensure(c->scratch_main[2], lanes_main * ga.match_cap * sizeof(GMatch)))) return rc;
-    if ((rc = ensure(c->scratch_main[4], lanes_main * 64 * sizeof(GBest)))) return rc;
+    if (!c->greedy2) {
+      if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
+      if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
+      if ((rc = ensure(c->scratch_main[2], lanes_main * ga.match_cap * sizeof(GMatch)))) return rc;
+      if ((rc = ensure(c->scratch_main[4], lanes_main * 64 * sizeof(GBest)))) return rc;
+    }
     ga.pool = static_cast<GItem *>(c->scratch_main[0].p); ga.ord = static_cast<uint16_t *>(c->scratch_main[1].p);
     ga.matches = static_cast<GMatch *>(c->scratch_main[2].p);
     ga.best = static_cast<GBest *>(c->scratch_main[4].p);
@@ -525,8 +560,22 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     gr.pool = static_cast<GItem *>(c->scratch_retry[0].p); gr.ord = static_cast<uint16_t *>(c->scratch_retry[1].p);
     gr.matches = static_cast<GMatch *>(c->scratch_retry[2].p);
     gr.best = static_cast<GBest *>(c->scratch_retry[4].p);
+    GreedyArrays2 g2{};
+    if (c->greedy2) {
+      if ((rc = ensure(c->scratch_main[5], lanes_main * (4 * kGSlotsAll) * sizeof(u128)))) return rc;
+      if ((rc = ensure(c->scratch_main[6], lanes_main * (kGSlotsAll - kGSlots) * sizeof(uint32_t)))) return rc;
+      if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
+      if ((rc = ensure(c->scratch_main[8], lanes_main * (kGMaxMAll - kGMaxM) * sizeof(uint16_t)))) return rc;
+      if ((rc = ensure(c->scratch_main[9], lanes_main * 64 * sizeof(GBest2)))) return rc;
+      g2.pool = static_cast<u128 *>(c->scratch_main[5].p); g2.prio_ext = static_cast<uint32_t *>(c->scratch_main[6].p);
+      g2.matches = static_cast<GMatch2 *>(c->scratch_main[7].p); g2.mq_ext = static_cast<uint16_t *>(c->scratch_main[8].p);
+      g2.best = static_cast<GBest2 *>(c->scratch_main[9].p);
+    }
     if (n > 0) {
-      hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga);
+      if (c->greedy2)
+        hipLaunchKernelGGL(k_greedy2, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, p, sq, b, wl_main, g2);
+      else
+        hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr);

@@ -1411,6 +1411,14 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 // ----------------------------------------------------------------------------
 constexpr int kMaxMismatch = 8;
 
+// host-side workload histograms (tests/tools only): -DKJ_HIST
+#if defined(KJ_HIST) && !defined(__HIP_DEVICE_COMPILE__)
+extern unsigned long long kj_hist[8][64];
+#define KJ_HISTO(h, v) kj_hist[h][(v) < 63 ? (v) : 63]++
+#else
+#define KJ_HISTO(h, v)
+#endif
+
 struct GItem {               // one queue entry: a fragment or a substitution variant (80 bytes)
   uint64_t si0, si1;         // resume interval (variants)
   uint32_t key, start, len;  // start: peptide offset of the underlying fragment
@@ -1453,6 +1461,8 @@ KJ_HD void gq_push(const GreedyScratch &gs, GQueue &q, const GItem &it) {
   const uint32_t id = q.npool++;
   gs.pool[id] = it;
   uint32_t pos = q.tail;
+  KJ_HISTO(2, q.tail - q.head);
+  KJ_HISTO(3, (q.tail > q.head && gs.pool[gs.ord[q.tail - 1]].key < it.key) ? 1 : 0);
   while (pos > q.head && gs.pool[gs.ord[pos - 1]].key < it.key) { gs.ord[pos] = gs.ord[pos - 1]; pos--; }
   gs.ord[pos] = (uint16_t)id;
   q.tail++;
@@ -1622,6 +1632,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           break;
         }
         case GS_AFTER_SEARCH: {
+          KJ_HISTO(t.num_mm == 0 ? 0 : 1, nm);
           if (nm == 0 || m_ovf) { state = GS_POP; break; }   // (overflow: the read is redone in the retry pass)
           // order in which `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the
           // sorted list built by insert_SI_sorted (bwt.c:225-252): heads of the length classes in
@@ -1716,10 +1727,12 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
               }
             }
           }
+          KJ_HISTO(4, nbest);
           state = GS_POP;
           break;
         }
         case GS_FINISH: {
+          KJ_HISTO(5, q.npool); KJ_HISTO(6, nbest);
           hit = b.hits + r;
           nids = 0;
           hit->reserved = 0;
@@ -1803,6 +1816,596 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
       kmer_lookup(ix, kidx, lo, hi);
       if (lo >= hi) { i = j; state = GS_END_MATCH; }       // seed shorter than kk: never recorded, i > 1
       else { i = j - (int)kk + 1; state = i > 0 ? GS_STEP : GS_END_MATCH; }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Greedy lane, second generation (indexes below 2^32 rows).  Same results as greedy_lane, laid
+// out like mem_lane2: every iteration of the lane loop has ONE branch-free load phase (two
+// rank-block reads, one 16-byte read of "something else", four 16-byte reads of a window or a
+// queue item), then the arithmetic on what arrived, then the bookkeeping.  What the lane must
+// remember between iterations lives in registers and in its LDS row:
+//   * the peptide window (64 bytes), with the substitutions of the current variant patched in;
+//   * the lengths of the matches of the current fragment (the order in which the reference walks
+//     its sorted SI list is recomputed from them; the match records themselves go to the lane's
+//     global scratch and come back one 16-byte read at a time);
+//   * the priorities of the queued variants / SEG pieces, (key << 16 | 0xffff - sequence number):
+//     the multimap of the reference pops the largest key, earliest insertion first, which is the
+//     largest priority.  The originals of the read are NOT queued: stage 1 wrote them in queue
+//     order, so they are merged in from their list (an original precedes queued entries of the
+//     same key, having been inserted before them).
+// A read that does not fit these bounds (more than kGMaxMAll seeds in one fragment, more than
+// kGSlotsAll live queue entries, keys >= 2^16) is sent to the retry pass (greedy_lane).
+// ----------------------------------------------------------------------------
+constexpr int kGMaxM = 24, kGMaxMAll = 256;      // matches of one fragment: lengths in LDS / in LDS + global spill
+constexpr int kGSlots = 48, kGSlotsAll = 256;    // queue slots: priorities in LDS / in LDS + global spill
+constexpr int kGLdsWin = 0, kGLdsMq = 16, kGLdsPrio = 28, kGLdsStride = 77;   // dwords; odd stride: no bank conflicts
+
+struct GMatch2 { uint32_t lo, len, qiql, dp; };          // qi | ql << 16, dsum | psum << 16
+struct GBest2 { uint32_t lo, len; };
+struct GreedyScratch2 {
+  uint32_t *lds;               // this lane's LDS row (kGLdsStride dwords)
+  u128 *pool;                  // kGSlotsAll items of 64 bytes
+  uint32_t *prio_ext;          // priorities of the slots kGSlots .. kGSlotsAll-1
+  GMatch2 *matches;            // kGMaxMAll
+  uint16_t *mq_ext;            // lengths of the matches kGMaxM .. kGMaxMAll-1
+  GBest2 *best;                // 64
+};
+
+enum GKind : int { G_STEP, G_KMER, G_VSTEP, G_LF1, G_LF2, G_SA, G_META, G_FRAG, G_FILL, G_POPITEM, G_MLOAD, G_IDLE, G_EXIT };
+enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_AFTER_SEARCH, GB_VAR_NEXT, GB_VAR_MATCH, GB_VAR_SUB,
+                 GB_EVAL_NEXT, GB_EVAL_MATCH, GB_POP, GB_FINISH, GB_LOC_NEXT_SI, GB_LOC_ROW, GB_DONE };
+enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
+
+KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
+                        const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
+  typedef uint32_t P;
+  int kind = G_IDLE;
+  // read
+  uint32_t r = 0, nf = 0, fo = 0, fbase = 0;
+  uint64_t pepoff = 0;
+  uint32_t on_start = 0, on_len = 0, on_key = 0, on_flags = 0;    // original number fo (prefetched)
+  uint32_t best = 0, nbest = 0, flags = 0, b0lo = 0, b0len = 0;
+  bool ovf = false;
+  // queue of variants and SEG pieces
+  uint32_t qn = 0, qlive = 0, qseq = 0, pslot = 0;
+  // the fragment being searched
+  uint32_t t_start = 0, t_len = 0, t_matchlen = 0, t_tot = 0, t_msum = 0, t_nmm = 0;
+  int32_t t_diff = 0;
+  uint32_t sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, sa0 = 0, sa1 = 0;  // substituted positions (16 bit) / letters (8 bit)
+  int flen = 0, j = 0, i = 0, last_qi = 0;
+  P lo = 0, hi = 0;
+  uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0;
+  bool m_ovf = false;
+  // the match at hand
+  uint32_t m_lo = 0, m_len = 0, m_qi = 0, m_ql = 0, m_dsum = 0, m_psum = 0;
+  // walk over the matches for the substitution variants / for the scores
+  int vi_v = -1, vi_x = 0, vi_phase = 2, vi_head = 0;
+  int ev_pass = 0, ev_v = 0, ev_x = -1, ev_v1 = 0;
+  bool ev_done = false;
+  uint32_t mx = 0, ml_for = 0;
+  // variant generation
+  P vlo = 0, vhi = 0;
+  uint32_t vqi = 0, vql = 0, vdsum = 0, vpsum = 0, vsub = 0, vorig = 0, vscore = 0, vlen = 0, vs = 0, vc = 1;
+  // locate
+  uint32_t cur = 0, nids = 0;
+  P row = 0, rowend = 0, k = 0;
+  uint64_t id0 = 0, sa_idx = 0;
+  bool fresh = true;
+  Hit *hit = nullptr;
+  int fill_top = 0, fill_ret = FR_START_J;
+  bool fill_pref = false;
+
+  uint8_t *const win = reinterpret_cast<uint8_t *>(gs.lds + kGLdsWin);
+  uint16_t *const mq = reinterpret_cast<uint16_t *>(gs.lds + kGLdsMq);
+  uint32_t *const prio = gs.lds + kGLdsPrio;
+  int wq = 0;                                   // fragment position of win[0]
+  const P check = (P)((1u << ix.chpt_exp) - 1);
+  const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kmer32) ? ix.kmer_k : 0;
+  const uint32_t nwaves = kj_nwaves();
+  uint32_t wnext = 0, wend = 0;
+  const RankBlock64 *const blk0 = ix.blocks64;
+  // BLOSUM62 diagonal by index-alphabet code, 4 bits each (values 4..11)
+  uint64_t dg0 = 0, dg1 = 0;
+  for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
+  for (int x = 16; x < 32; x++) dg1 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * (x - 16));
+
+  auto diag = [&](uint32_t cc) -> uint32_t { return (uint32_t)(((cc & 16u) ? dg1 : dg0) >> (4u * (cc & 15u))) & 15u; };
+  auto in_win = [&](int pos) -> bool { return pos >= wq && pos < wq + kWin; };
+  auto mq_get = [&](uint32_t x) -> int { return (int)(x < (uint32_t)kGMaxM ? mq[x] : gs.mq_ext[x - kGMaxM]); };
+  auto mq_max_below = [&](int bound) -> int {   // largest match length < bound, -1 if none
+    int v = -1;
+    for (uint32_t x = 0; x < nm; x++) { const int q = mq_get(x); if (q < bound && q > v) v = q; }
+    return v;
+  };
+  auto mq_head = [&](int v) -> uint32_t {       // first match of length v (head of its class)
+    uint32_t x = 0;
+    while (x < nm && mq_get(x) != v) x++;
+    return x;
+  };
+  auto pr_get = [&](uint32_t s) -> uint32_t { return s < (uint32_t)kGSlots ? prio[s] : gs.prio_ext[s - kGSlots]; };
+  auto pr_set = [&](uint32_t s, uint32_t v) { if (s < (uint32_t)kGSlots) prio[s] = v; else gs.prio_ext[s - kGSlots] = v; };
+  // multimap emplace of a variant / SEG piece
+  auto push_item = [&](uint32_t key, const u128 &v0, const u128 &v1, const u128 &v2, const u128 &v3)
+      __attribute__((always_inline)) {
+    KJ_HISTO(7, qlive);
+    if (key > 0xffffu || qseq >= 0xfffeu) { ovf = true; return; }
+    uint32_t slot = qn;
+    if (qlive < qn) { slot = 0; while (pr_get(slot) != 0) slot++; }
+    else if (qn >= (uint32_t)kGSlotsAll) { ovf = true; return; }
+    else qn++;
+    pr_set(slot, key << 16 | (0xffffu - qseq));
+    qseq++; qlive++;
+    u128 *dst = gs.pool + 4 * slot;
+    dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+  };
+  // eval_match_scores on one match (ConsumerThread.cpp:751-797)
+  auto eval_match = [&]() {
+    const int sc = (int)m_dsum + t_diff;                    // calcScore(seq, qi, ql, diff)
+    const uint32_t score = sc > 0 ? (uint32_t)sc : 0u;
+    if (score < p.min_score) return;
+    if (score > best) { best = score; nbest = 0; }
+    if (score == best) {
+      if (nbest < p.max_matches_SI && nbest < 64) {
+        if (nbest == 0) { b0lo = m_lo; b0len = m_len; }
+        else { GBest2 gb; gb.lo = m_lo; gb.len = m_len; gs.best[nbest] = gb; }
+        nbest++;
+      } else flags |= kHitSiCap;
+    }
+  };
+
+  for (;;) {
+    // ---- (0) hand out reads (see mem_lane2) ----
+    {
+      const bool need = kind == G_IDLE;
+      const uint64_t mask = kj_ballot(need);
+      if (mask) {
+        const uint32_t n = popc64(mask);
+        const uint32_t rank = popc64(mask & ((1ull << kj_lane()) - 1ull));
+        const uint32_t avail = wend - wnext;
+        uint32_t newbase = 0, ch = 0;
+        if (n > avail) {
+          const uint32_t left = n_items > wend ? n_items - wend : 0;
+          ch = left / (nwaves * 4u);
+          if (ch > 128u) ch = 128u;
+          if (ch < 8u) ch = 8u;
+          if (ch < n - avail) ch = n - avail;
+          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+          uint32_t got = 0;
+          if (kj_lane() == leader) got = kj_fetch_chunk(wl.counter, ch);
+          newbase = kj_bcast(got, leader);
+        }
+        if (need) {
+          const uint32_t item = rank < avail ? wnext + rank : newbase + (rank - avail);
+          if (item >= n_items) kind = G_EXIT;
+          else { r = wl.reads ? wl.reads[item] : item; kind = G_META; }
+        }
+        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
+        else wnext += n;
+      }
+      if (kj_ballot(kind != G_EXIT) == 0) break;
+    }
+
+    // ---- (1) load phase ----
+    const bool is_step = kind == G_STEP, is_vstep = kind == G_VSTEP, is_lf = kind == G_LF1 || kind == G_LF2;
+    const P posA = is_step ? lo : is_vstep ? vlo : is_lf ? k : 0;
+    const P posB = is_step ? hi : is_vstep ? vhi : posA;
+    const uint32_t cc = (is_step || kind == G_LF2) ? c : is_vstep ? vc : 1u;
+    const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
+    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
+    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
+    const uint64_t a4 = pa->plane[4];
+    const uint32_t ca = pa->cnt[cc - 1];
+    const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
+    const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
+    const uint64_t b4 = pb->plane[4];
+    const uint32_t cb = pb->cnt[cc - 1];
+    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
+    if (kind == G_KMER) gaddr = reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
+    else if (kind == G_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    else if (kind == G_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
+    else if (kind == G_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
+    else if (kind == G_FILL && fill_pref && fo < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + fo);
+    else if (kind == G_MLOAD) gaddr = reinterpret_cast<const uint8_t *>(gs.matches + mx);
+    const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
+    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
+    int fq = 0;
+    if (kj_ballot(kind == G_FILL || kind == G_POPITEM)) {   // wave-uniform
+      fq = fill_top - (kWin - 1);
+      if (fq < 0) fq = 0;
+      const uint8_t *src = kind == G_FILL ? b.pep + pepoff + t_start + fq
+                         : kind == G_POPITEM ? reinterpret_cast<const uint8_t *>(gs.pool + 4 * pslot)
+                                             : reinterpret_cast<const uint8_t *>(blk0);
+      const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
+      w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
+    }
+
+    // ---- (2) compute ----
+    int bk = GB_NONE;
+    if (is_step || is_vstep || kind == G_LF2) {
+      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
+                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
+      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
+      const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
+      const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
+      const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
+      if (is_step) {
+        // UpdateSI(str[i-1]) (bwt.c:160-173)
+        if (ra >= rb) bk = GB_END_MATCH;
+        else {
+          lo = ra; hi = rb; i--; acc += diag(c);
+          if (i == 0) bk = GB_END_MATCH;
+          else if (in_win(i - 1)) c = win[i - 1 - wq];
+          else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
+        }
+      } else if (is_vstep) {
+        // UpdateSI(trans[substitute]) on the interval of the match (ConsumerThread.cpp:372)
+        if (ra < rb) {
+          const int bos = (int)ct.b62[vorig][vs], bss = (int)ct.b62[vs][vs], boo = (int)ct.b62[vorig][vorig];
+          const uint32_t key = (uint32_t)(int32_t)(vscore + (uint32_t)(int32_t)bos);
+          u128 v0, v1, v2, v3;
+          v0.x = ra | (uint64_t)rb << 32;
+          v0.y = key | (uint64_t)t_start << 32;
+          v1.x = (vlen | (vql + 1u) << 16) | (uint64_t)(uint32_t)(t_diff + bos - bss) << 32;
+          v1.y = (vpsum - (uint32_t)boo + (uint32_t)bss) | (uint64_t)(vdsum + (uint32_t)bss) << 32;
+          uint32_t q0 = sp0, q1 = sp1, q2 = sp2, q3 = sp3, e0 = sa0, e1 = sa1;
+          const uint32_t pz = (vqi - 1u) & 0xffffu;
+          if (t_nmm < (uint32_t)kMaxMismatch) {
+            const uint32_t hs = (t_nmm & 1u) * 16u, bs = (t_nmm & 3u) * 8u;
+            const uint32_t hm = ~(0xffffu << hs), bm = ~(0xffu << bs);
+            switch (t_nmm >> 1) {
+              case 0: q0 = (q0 & hm) | pz << hs; break;
+              case 1: q1 = (q1 & hm) | pz << hs; break;
+              case 2: q2 = (q2 & hm) | pz << hs; break;
+              default: q3 = (q3 & hm) | pz << hs; break;
+            }
+            if (t_nmm < 4u) e0 = (e0 & bm) | vc << bs; else e1 = (e1 & bm) | vc << bs;
+          }
+          v2.x = (t_nmm + 1u) | (uint64_t)q0 << 32;
+          v2.y = q1 | (uint64_t)q2 << 32;
+          v3.x = q3 | (uint64_t)e0 << 32;
+          v3.y = e1;
+          if (vlen > 0xffffu || vql + 1u > 0xffffu) ovf = true; else push_item(key, v0, v1, v2, v3);
+        }
+        vsub++;
+        bk = GB_VAR_SUB;
+      } else {
+        k = ra; fresh = false;                             // second half of an LF step
+        bk = GB_LOC_ROW;
+      }
+    } else if (kind == G_KMER) {
+      const uint64_t e = ghalf ? gv.y : gv.x;
+      lo = (P)e; hi = (P)e + (P)(e >> 32);
+      if (lo >= hi) { i = j; bk = GB_END_MATCH; }          // seed shorter than kk: never recorded, i > 1
+      else {
+        i = j - (int)kk + 1;
+        if (i == 0) bk = GB_END_MATCH;
+        else if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; }
+        else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
+      }
+    } else if (kind == G_LF1) {
+      const uint32_t sft = k & 63u;
+      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
+          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
+      if (c != 0) kind = G_LF2;
+      else {
+        const uint32_t iseq = (uint32_t)rank_term(ix, k);
+        if (iseq < ix.nseq && ix.seq_valid[iseq]) {
+          const uint64_t tax = ix.seq_taxid[iseq];
+          bool dup = false;
+          if (nids >= 1 && tax == id0) dup = true;
+          for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+          if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+        }
+        row++;
+        k = row; fresh = true;
+        bk = GB_LOC_ROW;
+      }
+    } else if (kind == G_SA) {
+      const uint64_t tax = ghalf ? gv.y : gv.x;
+      if (tax != ~0ull) {
+        bool dup = false;
+        if (nids >= 1 && tax == id0) dup = true;
+        for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+        if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+      }
+      row++;
+      k = row; fresh = true;
+      bk = GB_LOC_ROW;
+    } else if (kind == G_META) {
+      pepoff = gv.x;
+      fbase = (uint32_t)gv.y;
+      nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
+      fo = 0; best = 0; nbest = 0; flags = 0; ovf = false; m_ovf = false;
+      for (uint32_t s = 0; s < qn; s++) pr_set(s, 0);
+      qn = qlive = qseq = 0;
+      hit = b.hits + r;
+      if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
+    } else if (kind == G_FRAG) {
+      on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
+      bk = GB_POP;
+    } else if (kind == G_FILL) {
+      wq = fq;
+      uint32_t *d32 = reinterpret_cast<uint32_t *>(win);
+      d32[0] = (uint32_t)w0.x; d32[1] = (uint32_t)(w0.x >> 32); d32[2] = (uint32_t)w0.y; d32[3] = (uint32_t)(w0.y >> 32);
+      d32[4] = (uint32_t)w1.x; d32[5] = (uint32_t)(w1.x >> 32); d32[6] = (uint32_t)w1.y; d32[7] = (uint32_t)(w1.y >> 32);
+      d32[8] = (uint32_t)w2.x; d32[9] = (uint32_t)(w2.x >> 32); d32[10] = (uint32_t)w2.y; d32[11] = (uint32_t)(w2.y >> 32);
+      d32[12] = (uint32_t)w3.x; d32[13] = (uint32_t)(w3.x >> 32); d32[14] = (uint32_t)w3.y; d32[15] = (uint32_t)(w3.y >> 32);
+      // the substitutions of the variant (the reference edits the fragment string, :380)
+      for (uint32_t x = 0; x < t_nmm && x < (uint32_t)kMaxMismatch; x++) {
+        const uint32_t pw = x < 2 ? sp0 : x < 4 ? sp1 : x < 6 ? sp2 : sp3;
+        const int pz = (int)((pw >> ((x & 1u) * 16u)) & 0xffffu);
+        const uint32_t aw = x < 4 ? sa0 : sa1;
+        if (pz >= wq && pz < wq + kWin && pz < (int)t_len) win[pz - wq] = (uint8_t)(aw >> ((x & 3u) * 8u));
+      }
+      if (fill_pref && fo < nf) {
+        on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
+      }
+      if (fill_ret == FR_STEP) { c = win[i - 1 - wq]; kind = G_STEP; }
+      else if (fill_ret == FR_START_J) bk = GB_START_J;
+      else bk = GB_VAR_MATCH;
+    } else if (kind == G_POPITEM) {
+      lo = (P)w0.x; hi = (P)(w0.x >> 32);
+      t_start = (uint32_t)(w0.y >> 32);
+      t_len = (uint32_t)w1.x & 0xffffu; t_matchlen = ((uint32_t)w1.x >> 16) & 0xffffu;
+      t_diff = (int32_t)(uint32_t)(w1.x >> 32);
+      t_tot = (uint32_t)w1.y; t_msum = (uint32_t)(w1.y >> 32);
+      t_nmm = (uint32_t)w2.x;
+      sp0 = (uint32_t)(w2.x >> 32); sp1 = (uint32_t)w2.y; sp2 = (uint32_t)(w2.y >> 32); sp3 = (uint32_t)w3.x;
+      sa0 = (uint32_t)(w3.x >> 32); sa1 = (uint32_t)w3.y;
+      flen = (int)t_len; nm = 0;
+      j = flen - 1;
+      if (t_nmm == 0) {
+        // a SEG piece: maxMatches like an original
+        tail = 0;
+        fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL;
+      } else {
+        // maxMatches_withStart, bwt.c:298-336
+        i = j - (int)t_matchlen + 1;
+        acc = t_msum;
+        if (i > 0) { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
+        else bk = GB_END_MATCH;
+      }
+    } else if (kind == G_MLOAD) {
+      m_lo = (uint32_t)gv.x; m_len = (uint32_t)(gv.x >> 32);
+      m_qi = (uint32_t)gv.y & 0xffffu; m_ql = ((uint32_t)gv.y >> 16) & 0xffffu;
+      m_dsum = (uint32_t)(gv.y >> 32) & 0xffffu; m_psum = (uint32_t)(gv.y >> 48) & 0xffffu;
+      bk = ml_for == 0 ? GB_VAR_MATCH : GB_EVAL_MATCH;
+    }
+
+    // ---- (3) bookkeeping ----
+    while (bk != GB_NONE) {
+      if (bk == GB_END_MATCH) {
+        const int l = j - i + 1;
+        if (t_nmm == 0) {
+          if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {        // bwt.c:276-278
+            if (nm < (uint32_t)kGMaxMAll) {
+              m_lo = lo; m_len = (uint32_t)(hi - lo); m_qi = (uint32_t)i; m_ql = (uint32_t)l; m_dsum = acc; m_psum = t_tot - tail;
+              GMatch2 mm; mm.lo = m_lo; mm.len = m_len; mm.qiql = m_qi | m_ql << 16; mm.dp = m_dsum | m_psum << 16;
+              gs.matches[nm] = mm;
+              if (nm < (uint32_t)kGMaxM) mq[nm] = (uint16_t)l; else gs.mq_ext[nm - kGMaxM] = (uint16_t)l;
+            } else m_ovf = true;
+            nm++;
+            last_qi = i;
+          }
+          if (i <= 1) bk = GB_AFTER_SEARCH;                                 // bwt.c:292
+          else { tail += diag(cj); j--; bk = GB_START_J; }
+        } else {
+          // :443-449: after the last allowed mismatch the match must reach min_fragment_length
+          const int Lreq = (t_nmm == p.mismatches) ? (int)p.m : (int)t_matchlen;
+          if (l >= Lreq) {
+            m_lo = lo; m_len = (uint32_t)(hi - lo); m_qi = (uint32_t)i; m_ql = (uint32_t)l; m_dsum = acc; m_psum = t_tot;
+            nm = 1;
+          }
+          bk = GB_AFTER_SEARCH;
+        }
+      }
+      if (bk == GB_START_J) {
+        if (j < (int)p.seed_length - 1) bk = GB_AFTER_SEARCH;
+        else if (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1))) {
+          fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;
+        } else if (kk && j >= (int)kk - 1) {
+          kidx = 0; acc = 0;
+          cj = win[j - wq];
+          for (uint32_t q = 0; q < kk; q++) {
+            const uint32_t cq = win[j - (int)q - wq];
+            kidx = kmer_index(kidx, cq);
+            acc += diag(cq);
+          }
+          kind = G_KMER; bk = GB_NONE;
+        } else {
+          c = cj = win[j - wq];
+          lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];                              // InitialSI, bwt.c:146-152
+          acc = diag(c);
+          i = j;
+          if (i == 0) bk = GB_END_MATCH;
+          else if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; bk = GB_NONE; }
+          else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; bk = GB_NONE; }
+        }
+        if (bk == GB_END_MATCH) continue;
+      }
+      if (bk == GB_AFTER_SEARCH) {
+        if (nm == 0 || m_ovf) bk = GB_POP;                 // (overflow: the read is redone in the retry pass)
+        else if (p.mismatches > 0 && t_nmm < p.mismatches) {
+          // the order in which `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the
+          // list of insert_SI_sorted (bwt.c:225-252): see greedy_lane
+          vi_phase = 0;
+          vi_v = nm == 1 ? (int)m_ql : mq_max_below(0x7fffffff);
+          bk = GB_VAR_NEXT;
+        } else { ev_pass = -1; bk = GB_EVAL_NEXT; }
+      }
+      if (bk == GB_VAR_NEXT) {
+        bool have = false;
+        if (nm == 1) {
+          if (vi_phase == 0) { vi_phase = 2; have = true; }
+        } else if (vi_phase == 0) {
+          if (vi_v >= 0) {
+            const uint32_t head = mq_head(vi_v);
+            uint32_t cnt = 0;
+            for (uint32_t x = head; x < nm; x++) if (mq_get((uint32_t)x) == vi_v) cnt++;
+            mx = head; vi_head = (int)head; have = true;
+            if (cnt >= 2) { vi_phase = 1; vi_x = (int)nm; }
+            else { vi_v = mq_max_below(vi_v); if (vi_v < 0) vi_phase = 2; }
+          }
+        } else if (vi_phase == 1) {
+          int x = vi_x - 1;
+          while (x > vi_head && mq_get(x) != vi_v) x--;
+          if (x > vi_head) { mx = (uint32_t)x; vi_x = x; have = true; }
+          else vi_phase = 2;
+        }
+        if (!have) { ev_pass = -1; bk = GB_EVAL_NEXT; }
+        else if (nm == 1) bk = GB_VAR_MATCH;
+        else { ml_for = 0; kind = G_MLOAD; bk = GB_NONE; }
+      }
+      if (bk == GB_VAR_MATCH) {
+        const uint32_t mre = m_qi + m_ql - 1u;
+        if (!(m_qi > 0 && mre + 1u >= p.m)) bk = GB_VAR_NEXT;                // :469
+        else if (!in_win((int)m_qi - 1)) {
+          fill_top = (int)m_qi - 1; fill_ret = FR_VARM; fill_pref = false; kind = G_FILL; bk = GB_NONE;
+        } else {
+          // addAllMismatchVariantsAtPosSI(t, qi-1, erase_pos, it), :346-395
+          vlen = (mre < (uint32_t)flen - 1u) ? mre + 1u : (uint32_t)flen;    // fragment.erase(erase_pos)
+          vorig = ct.idx_to_aa[win[(int)m_qi - 1 - wq]];
+          const int sc = (int)m_psum + t_diff;                               // calcScore(fragment, f->diff)
+          const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
+          vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];             // unsigned wrap as in :363
+          vlo = m_lo; vhi = m_lo + m_len; vqi = m_qi; vql = m_ql; vdsum = m_dsum; vpsum = m_psum;
+          vsub = 0;
+          bk = GB_VAR_SUB;
+        }
+        if (bk == GB_VAR_NEXT) continue;
+      }
+      if (bk == GB_VAR_SUB) {
+        bk = GB_VAR_NEXT;
+        if (vsub < 19) {
+          vs = ct.subst[vorig][vsub];
+          const int32_t after = (int32_t)(vscore + (uint32_t)(int32_t)ct.b62[vorig][vs]);
+          if (after >= (int32_t)best && after >= (int32_t)p.min_score) { vc = ct.aa_to_idx[vs]; kind = G_VSTEP; bk = GB_NONE; }
+        }                                                                    // break at the first too-low score
+        if (bk == GB_VAR_NEXT) continue;
+      }
+      if (bk == GB_EVAL_NEXT) {
+        // eval_match_scores(si, t), :751-797: the samelen chains of the classes (descending length,
+        // while >= m) in insertion order, then the class heads in ascending length
+        if (nm == 1) {
+          if (m_ql >= p.m) eval_match();
+          bk = GB_POP;
+        } else {
+          if (ev_pass < 0) {
+            ev_v1 = mq_max_below(0x7fffffff);
+            if (ev_v1 < (int)p.m) bk = GB_POP;                               // :482
+            else { ev_pass = 0; ev_v = ev_v1; ev_x = -1; ev_done = false; }
+          }
+          while (bk == GB_EVAL_NEXT) {
+            if (ev_pass == 0) {
+              const int head = (int)mq_head(ev_v);
+              int x = (ev_x > head ? ev_x : head) + 1;
+              while (x < (int)nm && mq_get((uint32_t)x) != ev_v) x++;
+              if (x < (int)nm) { ev_x = x; mx = (uint32_t)x; ml_for = 1; kind = G_MLOAD; bk = GB_NONE; }
+              else {
+                const int nv = mq_max_below(ev_v);
+                if (nv < 0 || nv < (int)p.m) ev_pass = 1;                    // ev_v is the shortest class >= m
+                else { ev_v = nv; ev_x = -1; }
+              }
+            } else if (ev_done) bk = GB_POP;
+            else {
+              mx = mq_head(ev_v); ml_for = 1; kind = G_MLOAD; bk = GB_NONE;
+              if (ev_v == ev_v1) ev_done = true;
+              else {
+                int nv = 0x7fffffff;
+                for (uint32_t x = 0; x < nm; x++) { const int q = mq_get(x); if (q > ev_v && q < nv) nv = q; }
+                ev_v = nv;
+              }
+            }
+          }
+        }
+      }
+      if (bk == GB_EVAL_MATCH) { eval_match(); bk = GB_EVAL_NEXT; continue; }
+      if (bk == GB_POP) {
+        // getNextFragment(best_match_score), ConsumerThread.cpp:272-342
+        uint32_t dbest = 0, dslot = 0;
+        for (uint32_t s = 0; s < qn; s++) { const uint32_t pr = pr_get(s); if (pr > dbest) { dbest = pr; dslot = s; } }
+        const bool have_o = fo < nf, have_d = dbest != 0;
+        const uint32_t dkey = dbest >> 16;
+        if ((!have_o && !have_d) || ovf || m_ovf) bk = GB_FINISH;
+        else {
+          const bool pick_o = have_o && (!have_d || on_key >= dkey);
+          if ((pick_o ? on_key : dkey) < best) bk = GB_FINISH;
+          else if (!pick_o) { pr_set(dslot, 0); qlive--; pslot = dslot; kind = G_POPITEM; bk = GB_NONE; }
+          else {
+            t_start = on_start; t_len = on_len; t_diff = 0; t_matchlen = 0; t_tot = on_key; t_msum = 0; t_nmm = 0;
+            const uint32_t oflags = on_flags;
+            if (on_key > 0xffffu || on_len > 0xffffu) ovf = true;
+            fo++;
+            if (p.seg && !(oflags & kFragChecked)) {
+              // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked
+              // pieces are queued, and the next fragment is popped (:291-334)
+              const uint32_t slot = oflags >> kFragSlotShift;
+              if (slot) {
+                const SegRec &rec = sq.recs[slot - 1];
+                if (rec.overflow) flags |= kHitInternalOverflow;
+                Frag f; f.start = t_start; f.len = t_len; f.key = on_key; f.flags = 0;
+                seg_split(ct, p, rec, b.pep + pepoff, f, [&](const Frag &q) {
+                  u128 v0, v1, v2, v3;
+                  v0.x = 0; v0.y = q.key | (uint64_t)q.start << 32;
+                  v1.x = q.len; v1.y = q.key;
+                  v2.x = v2.y = v3.x = v3.y = 0;
+                  if (q.len > 0xffffu) ovf = true; else push_item(q.key, v0, v1, v2, v3);
+                });
+              }
+              if (fo < nf) {
+                const Frag nx = b.frags[fbase + fo];
+                on_start = nx.start; on_len = nx.len; on_key = nx.key; on_flags = nx.flags;
+              }
+              continue;                                     // bk stays GB_POP
+            }
+            flen = (int)t_len; nm = 0;
+            j = flen - 1; tail = 0;                         // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
+            fill_top = j; fill_ret = FR_START_J; fill_pref = true; kind = G_FILL; bk = GB_NONE;
+          }
+        }
+      }
+      if (bk == GB_FINISH) {
+        nids = 0;
+        hit->reserved = 0;
+        if (ovf || m_ovf) {
+          hit->best = 0;
+          if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+          else flags = kHitInternalOverflow;
+          bk = GB_DONE;
+        } else {
+          hit->best = nbest ? best : 0u;
+          cur = 0;
+          bk = GB_LOC_NEXT_SI;
+        }
+      }
+      if (bk == GB_LOC_NEXT_SI) {
+        if (cur >= nbest) bk = GB_DONE;
+        else {
+          if (cur == 0) { row = b0lo; rowend = b0lo + b0len; }
+          else { const GBest2 gb = gs.best[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
+          cur++;
+          k = row; fresh = true;
+          bk = GB_LOC_ROW;
+        }
+      }
+      if (bk == GB_LOC_ROW) {
+        if (row >= rowend) { bk = GB_LOC_NEXT_SI; continue; }
+        else if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = GB_DONE; }   // :805-807
+        else if ((k & check) != 0) { kind = G_LF1; bk = GB_NONE; }
+        else {
+          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+          if (sa_idx < ix.n_sa) { kind = G_SA; bk = GB_NONE; }
+          else { row++; k = row; fresh = true; continue; }  // (the reference reads out of bounds here): skip the row
+        }
+      }
+      if (bk == GB_DONE) {
+        hit->n_ids = nids; hit->flags = flags;
+        kind = G_IDLE; bk = GB_NONE;
+      }
     }
   }
 }

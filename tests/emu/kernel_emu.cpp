@@ -162,7 +162,17 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       gs.pool = pool.data(); gs.pool_cap = (uint32_t)pool.size(); gs.ord = ord.data();
       gs.matches = matches.data(); gs.match_cap = (uint32_t)matches.size();
       gs.best = bestv.data(); gs.win = win;
-      greedy_lane(d, ix->ct, p, sq, b, wl, gs);
+      const char *v = getenv("KAIJU_EMU_LANE");        // "v1" or default (v2 where possible)
+      if (d.blocks64 && d.kmer32 && !v && pass == 0) {
+        std::vector<uint32_t> lds(kGLdsStride, 0xdeadbeefu);
+        std::vector<u128> pool2(4 * kGSlotsAll);
+        std::vector<uint32_t> prio_ext(kGSlotsAll - kGSlots, 0xdeadbeefu);
+        std::vector<GMatch2> matches2(kGMaxMAll);
+        std::vector<uint16_t> mq_ext(kGMaxMAll - kGMaxM, 0xdead);
+        std::vector<GBest2> best2(64);
+        GreedyScratch2 g2{lds.data(), pool2.data(), prio_ext.data(), matches2.data(), mq_ext.data(), best2.data()};
+        greedy_lane2(d, ix->ct, p, sq, b, wl, g2);
+      } else greedy_lane(d, ix->ct, p, sq, b, wl, gs);
     }
   }
   static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");
@@ -171,3 +181,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
 }
 
 }  // extern "C"
+
+#ifdef KJ_HIST
+namespace kj { unsigned long long kj_hist[8][64]; }
+extern "C" const unsigned long long *emu_hist() { return &kj::kj_hist[0][0]; }
+#endif
