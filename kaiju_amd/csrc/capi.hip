@@ -173,24 +173,31 @@ k_greedy_retry(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQ
 }
 
 // second-generation Greedy lane (kj_core.h:greedy_lane2): indexes below 2^32 symbols with a k-mer table.
-// Dynamic LDS: one row of kGLdsStride dwords per lane, then the constant tables.
+// Dynamic LDS: per lane a window row, a match-length row and a priority row, then the constant tables.
 struct GreedyArrays2 {
   u128 *pool; uint32_t *prio_ext; GMatch2 *matches; uint16_t *mq_ext; GBest2 *best;
+  uint32_t gate;
 };
-constexpr size_t kGreedy2Lds = (size_t)kBlock * kGLdsStride * 4 + sizeof(ConstTables);
+constexpr size_t kGreedy2Lds = (size_t)kBlock * (kGWinStride + kGMqStride + kGPrioStride) * 4 + sizeof(ConstTables);
 __global__ void __launch_bounds__(kBlock, 2)
 k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_dyn + kBlock * kGLdsStride);
+  uint32_t *s_prio = s_dyn;                                   // 16-byte aligned rows
+  uint32_t *s_win = s_prio + kBlock * kGPrioStride;
+  uint32_t *s_mq = s_win + kBlock * kGWinStride;
+  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_mq + kBlock * kGMqStride);
   load_tables(s_ct, g_ct);
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   GreedyScratch2 gs;
-  gs.lds = s_dyn + threadIdx.x * kGLdsStride;
-  gs.pool = ga.pool + lane * (4 * kGSlotsAll);
+  gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
+  gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
+  gs.prio = s_prio + threadIdx.x * kGPrioStride;
+  gs.pool = ga.pool + lane * (8 * kGSlotsAll);
   gs.prio_ext = ga.prio_ext + lane * (kGSlotsAll - kGSlots);
   gs.matches = ga.matches + lane * kGMaxMAll;
   gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
   gs.best = ga.best + lane * 64;
+  gs.gate = ga.gate;
   greedy_lane2(ix, s_ct, p, sq, b, wl, gs);
 }
 
@@ -367,6 +374,7 @@ struct kaiju_gpu_ctx {
   DevBuf pep, frags, meta, counters, retry_list, seg_items, seg_recs;
   DevBuf scratch_main[10], scratch_retry[5];
   bool greedy2 = false;
+  uint32_t greedy_gate = 3;
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
   kaiju_gpu_stats stats{};
   uint32_t last_n = 0;
@@ -433,6 +441,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
     c->greedy2 = ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p->seed_length &&
                  p->seed_length >= 3;
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) if (!strcmp(e, "v1")) c->greedy2 = false;
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (uint32_t)v; }
     if (c->greedy2) {
       KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kGreedy2Lds));
@@ -562,7 +571,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     gr.best = static_cast<GBest *>(c->scratch_retry[4].p);
     GreedyArrays2 g2{};
     if (c->greedy2) {
-      if ((rc = ensure(c->scratch_main[5], lanes_main * (4 * kGSlotsAll) * sizeof(u128)))) return rc;
+      if ((rc = ensure(c->scratch_main[5], (lanes_main * (8 * kGSlotsAll) + 4) * sizeof(u128)))) return rc;
       if ((rc = ensure(c->scratch_main[6], lanes_main * (kGSlotsAll - kGSlots) * sizeof(uint32_t)))) return rc;
       if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
       if ((rc = ensure(c->scratch_main[8], lanes_main * (kGMaxMAll - kGMaxM) * sizeof(uint16_t)))) return rc;
@@ -570,6 +579,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       g2.pool = static_cast<u128 *>(c->scratch_main[5].p); g2.prio_ext = static_cast<uint32_t *>(c->scratch_main[6].p);
       g2.matches = static_cast<GMatch2 *>(c->scratch_main[7].p); g2.mq_ext = static_cast<uint16_t *>(c->scratch_main[8].p);
       g2.best = static_cast<GBest2 *>(c->scratch_main[9].p);
+      g2.gate = c->greedy_gate;
     }
     if (n > 0) {
       if (c->greedy2)

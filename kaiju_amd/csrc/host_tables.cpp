@@ -71,6 +71,15 @@ int build_const_tables(const uint8_t trans[128], ConstTables &t, std::string &ms
     t.idx_to_aa[c] = (uint8_t)a;
     t.diag_idx[c] = kB62[a][a];
   }
+  for (int a = 0; a < 20; a++) {
+    for (int c = 1; c <= 20; c++) t.b62_idx[a][c - 1] = kB62[a][t.idx_to_aa[c]];
+    memset(t.subst_rank[a], 255, 20);
+    for (int k = 0; k < 19; k++) {
+      t.subst_rank[a][t.aa_to_idx[t.subst[a][k]] - 1] = (uint8_t)k;
+      // the Greedy kernel relies on the rows being sorted (probing stops at the first too-low score)
+      if (k > 0 && kB62[a][t.subst[a][k]] > kB62[a][t.subst[a][k - 1]]) { msg = "internal: substitution order"; return KAIJU_GPU_ERR_ARG; }
+    }
+  }
   return 0;
 }
 

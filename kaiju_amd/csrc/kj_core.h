@@ -155,6 +155,8 @@ struct ConstTables {
   uint8_t aa_to_idx[20];     // aa2int code -> index-alphabet code (astruct->trans)
   uint8_t idx_to_aa[32];     // index-alphabet code -> aa2int code
   int8_t diag_idx[32];       // BLOSUM62 diagonal by index-alphabet code (blosum62diag, :61-80)
+  int8_t b62_idx[20][20];    // b62[a][idx_to_aa[c]] at [a][c-1]: row of an aa2int code, columns by index-alphabet code
+  uint8_t subst_rank[20][20];// position of the letter with index code c in subst[a] at [a][c-1] (255: a itself)
 };
 
 struct ReadMeta {            // written by stage 1 (16 bytes): saves the search lanes the layout arithmetic
@@ -1821,47 +1823,65 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
 }
 
 // ----------------------------------------------------------------------------
-// Greedy lane, second generation (indexes below 2^32 rows).  Same results as greedy_lane, laid
-// out like mem_lane2: every iteration of the lane loop has ONE branch-free load phase (two
-// rank-block reads, one 16-byte read of "something else", four 16-byte reads of a window or a
-// queue item), then the arithmetic on what arrived, then the bookkeeping.  What the lane must
-// remember between iterations lives in registers and in its LDS row:
-//   * the peptide window (64 bytes), with the substitutions of the current variant patched in;
-//   * the lengths of the matches of the current fragment (the order in which the reference walks
-//     its sorted SI list is recomputed from them; the match records themselves go to the lane's
-//     global scratch and come back one 16-byte read at a time);
-//   * the priorities of the queued variants / SEG pieces, (key << 16 | 0xffff - sequence number):
-//     the multimap of the reference pops the largest key, earliest insertion first, which is the
-//     largest priority.  The originals of the read are NOT queued: stage 1 wrote them in queue
-//     order, so they are merged in from their list (an original precedes queued entries of the
-//     same key, having been inserted before them).
-// A read that does not fit these bounds (more than kGMaxMAll seeds in one fragment, more than
-// kGSlotsAll live queue entries, keys >= 2^16) is sent to the retry pass (greedy_lane).
+// Greedy lane, second generation (indexes below 2^32 rows).  Same results as greedy_lane, built
+// for the SIMT machine:
+//   * every iteration of the lane loop has ONE branch-free load phase, then the arithmetic on
+//     what arrived, then bookkeeping (mem_lane2);
+//   * the work of a read falls into a FAST part - extending matches letter by letter and walking
+//     to suffix-array samples, nine tenths of all iterations - and a SLOW part - queue, variants,
+//     scores.  64 lanes in 64 different places of the slow part would make every iteration pay for
+//     all of it, so the slow part only runs in every (gate+1)-th iteration ("heavy" iterations,
+//     wave-uniform); a lane that reaches it in between parks (G_WAIT) until then;
+//   * the 19 substitutions tried behind a match (addAllMismatchVariantsAtPosSI) all extend the
+//     same interval, i.e. read the same two rank blocks: one G_VMULTI step ranks all 20 letters
+//     and queues the surviving variants;
+//   * lane memory: registers, an LDS row (peptide window with the substitutions of the current
+//     variant patched in; the lengths of the matches of the current fragment, from which the
+//     order in which the reference walks its sorted SI list is recomputed; the priorities of the
+//     queued variants / SEG pieces, key << 16 | 0xffff - sequence number: the multimap of the
+//     reference pops the largest key, earliest insertion first = the largest priority) and global
+//     scratch (queued items of 128 bytes: state + ready-made window; match records).
+//     The originals of the read are NOT queued: stage 1 wrote them in queue order, so they are
+//     merged in from their list (an original precedes queued entries of the same key, having
+//     been inserted before them).
+// A read that does not fit the bounds (more than kGMaxMAll seeds in one fragment, more than
+// kGSlotsAll live queue entries, keys or lengths >= 2^16) is sent to the retry pass (greedy_lane).
 // ----------------------------------------------------------------------------
+#ifdef KJ_G_SMALL                                  // tests: exercise the spill and retry paths
+constexpr int kGMaxM = 2, kGMaxMAll = 5, kGSlots = 4, kGSlotsAll = 9;
+#else
 constexpr int kGMaxM = 24, kGMaxMAll = 256;      // matches of one fragment: lengths in LDS / in LDS + global spill
-constexpr int kGSlots = 48, kGSlotsAll = 256;    // queue slots: priorities in LDS / in LDS + global spill
-constexpr int kGLdsWin = 0, kGLdsMq = 16, kGLdsPrio = 28, kGLdsStride = 77;   // dwords; odd stride: no bank conflicts
+constexpr int kGSlots = 44, kGSlotsAll = 128;    // queue slots: priorities in LDS / in LDS + global spill
+#endif
+// LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
+constexpr int kGWinStride = 17, kGMqStride = 13, kGPrioStride = 44;
 
 struct GMatch2 { uint32_t lo, len, qiql, dp; };          // qi | ql << 16, dsum | psum << 16
 struct GBest2 { uint32_t lo, len; };
 struct GreedyScratch2 {
-  uint32_t *lds;               // this lane's LDS row (kGLdsStride dwords)
-  u128 *pool;                  // kGSlotsAll items of 64 bytes
+  uint8_t *win;                // LDS: peptide window, kWin bytes, 4-byte aligned
+  uint16_t *mq;                // LDS: lengths of the first kGMaxM matches
+  uint32_t *prio;              // LDS: priorities of the first kGSlots queue slots, 16-byte aligned
+  u128 *pool;                  // kGSlotsAll items of 128 bytes (+ 64 bytes of slack behind the last lane's)
   uint32_t *prio_ext;          // priorities of the slots kGSlots .. kGSlotsAll-1
   GMatch2 *matches;            // kGMaxMAll
   uint16_t *mq_ext;            // lengths of the matches kGMaxM .. kGMaxMAll-1
   GBest2 *best;                // 64
+  uint32_t gate;               // heavy iterations: (iteration & gate) == 0
 };
 
-enum GKind : int { G_STEP, G_KMER, G_VSTEP, G_LF1, G_LF2, G_SA, G_META, G_FRAG, G_FILL, G_POPITEM, G_MLOAD, G_IDLE, G_EXIT };
-enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_AFTER_SEARCH, GB_VAR_NEXT, GB_VAR_MATCH, GB_VAR_SUB,
-                 GB_EVAL_NEXT, GB_EVAL_MATCH, GB_POP, GB_FINISH, GB_LOC_NEXT_SI, GB_LOC_ROW, GB_DONE };
+enum GKind : int { G_STEP, G_KMER, G_LF1, G_LF2, G_SA,                                     // fast
+                   G_VMULTI, G_META, G_FRAG, G_FILL, G_POPITEM, G_MLOAD, G_WAIT, G_IDLE,   // heavy iterations only
+                   G_EXIT };
+enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_LOC_ROW,                            // fast
+                 GB_AFTER_SEARCH, GB_VAR_NEXT, GB_VAR_MATCH, GB_EVAL_NEXT, GB_EVAL_MATCH, GB_POP, GB_FINISH,
+                 GB_LOC_NEXT_SI, GB_DONE };
 enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 
 KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                         const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
   typedef uint32_t P;
-  int kind = G_IDLE;
+  int kind = G_IDLE, bk_pend = GB_NONE;
   // read
   uint32_t r = 0, nf = 0, fo = 0, fbase = 0;
   uint64_t pepoff = 0;
@@ -1886,8 +1906,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   bool ev_done = false;
   uint32_t mx = 0, ml_for = 0;
   // variant generation
-  P vlo = 0, vhi = 0;
-  uint32_t vqi = 0, vql = 0, vdsum = 0, vpsum = 0, vsub = 0, vorig = 0, vscore = 0, vlen = 0, vs = 0, vc = 1;
+  uint32_t vorig = 0, vscore = 0, vlen = 0;
   // locate
   uint32_t cur = 0, nids = 0;
   P row = 0, rowend = 0, k = 0;
@@ -1897,15 +1916,15 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   int fill_top = 0, fill_ret = FR_START_J;
   bool fill_pref = false;
 
-  uint8_t *const win = reinterpret_cast<uint8_t *>(gs.lds + kGLdsWin);
-  uint16_t *const mq = reinterpret_cast<uint16_t *>(gs.lds + kGLdsMq);
-  uint32_t *const prio = gs.lds + kGLdsPrio;
+  uint8_t *const win = gs.win;
+  uint16_t *const mq = gs.mq;
+  uint32_t *const prio = gs.prio;
   int wq = 0;                                   // fragment position of win[0]
   const P check = (P)((1u << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
   const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kmer32) ? ix.kmer_k : 0;
   const uint32_t nwaves = kj_nwaves();
-  uint32_t wnext = 0, wend = 0;
+  uint32_t wnext = 0, wend = 0, itc = 0;
   const RankBlock64 *const blk0 = ix.blocks64;
   // BLOSUM62 diagonal by index-alphabet code, 4 bits each (values 4..11)
   uint64_t dg0 = 0, dg1 = 0;
@@ -1927,19 +1946,17 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   };
   auto pr_get = [&](uint32_t s) -> uint32_t { return s < (uint32_t)kGSlots ? prio[s] : gs.prio_ext[s - kGSlots]; };
   auto pr_set = [&](uint32_t s, uint32_t v) { if (s < (uint32_t)kGSlots) prio[s] = v; else gs.prio_ext[s - kGSlots] = v; };
-  // multimap emplace of a variant / SEG piece
-  auto push_item = [&](uint32_t key, const u128 &v0, const u128 &v1, const u128 &v2, const u128 &v3)
-      __attribute__((always_inline)) {
+  // multimap emplace of a variant / SEG piece: returns the slot (or ~0)
+  auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
     KJ_HISTO(7, qlive);
-    if (key > 0xffffu || qseq >= 0xfffeu) { ovf = true; return; }
+    if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; return ~0u; }
     uint32_t slot = qn;
     if (qlive < qn) { slot = 0; while (pr_get(slot) != 0) slot++; }
-    else if (qn >= (uint32_t)kGSlotsAll) { ovf = true; return; }
+    else if (qn >= (uint32_t)kGSlotsAll) { ovf = true; return ~0u; }
     else qn++;
-    pr_set(slot, key << 16 | (0xffffu - qseq));
-    qseq++; qlive++;
-    u128 *dst = gs.pool + 4 * slot;
-    dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+    pr_set(slot, key << 16 | (0xffffu - seq));
+    qlive++;
+    return slot;
   };
   // eval_match_scores on one match (ConsumerThread.cpp:751-797)
   auto eval_match = [&]() {
@@ -1955,44 +1972,239 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       } else flags |= kHitSiCap;
     }
   };
+  // one row of the locate walk: k is a fresh row (k == row) or the row reached by the LF walk
+  auto loc_row = [&]() -> int {
+    for (;;) {
+      if (row >= rowend) return GB_LOC_NEXT_SI;
+      if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; return GB_DONE; }     // :805-807
+      if ((k & check) != 0) { kind = G_LF1; return GB_NONE; }
+      sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+      if (sa_idx < ix.n_sa) { kind = G_SA; return GB_NONE; }
+      row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
+    }
+  };
+  auto add_tax = [&](uint64_t tax) {
+    bool dup = false;
+    if (nids >= 1 && tax == id0) dup = true;
+    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+  };
 
   for (;;) {
-    // ---- (0) hand out reads (see mem_lane2) ----
-    {
-      const bool need = kind == G_IDLE;
-      const uint64_t mask = kj_ballot(need);
-      if (mask) {
-        const uint32_t n = popc64(mask);
-        const uint32_t rank = popc64(mask & ((1ull << kj_lane()) - 1ull));
-        const uint32_t avail = wend - wnext;
-        uint32_t newbase = 0, ch = 0;
-        if (n > avail) {
-          const uint32_t left = n_items > wend ? n_items - wend : 0;
-          ch = left / (nwaves * 4u);
-          if (ch > 128u) ch = 128u;
-          if (ch < 8u) ch = 8u;
-          if (ch < n - avail) ch = n - avail;
-          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-          uint32_t got = 0;
-          if (kj_lane() == leader) got = kj_fetch_chunk(wl.counter, ch);
-          newbase = kj_bcast(got, leader);
+    const bool heavy = (itc & gs.gate) == 0;               // wave-uniform
+    itc++;
+    if (heavy) {
+      // ---- (H0) the slow bookkeeping of the parked lanes, up to their next memory access ----
+      int bk = GB_NONE;
+      if (kind == G_WAIT) bk = bk_pend;
+      while (bk != GB_NONE) {
+        if (bk == GB_AFTER_SEARCH) {
+          if (nm == 0 || m_ovf) bk = GB_POP;               // (overflow: the read is redone in the retry pass)
+          else if (p.mismatches > 0 && t_nmm < p.mismatches) {
+            // the order in which `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the
+            // list of insert_SI_sorted (bwt.c:225-252): see greedy_lane
+            vi_phase = 0;
+            vi_v = nm == 1 ? (int)m_ql : mq_max_below(0x7fffffff);
+            bk = GB_VAR_NEXT;
+          } else { ev_pass = -1; bk = GB_EVAL_NEXT; }
         }
-        if (need) {
-          const uint32_t item = rank < avail ? wnext + rank : newbase + (rank - avail);
-          if (item >= n_items) kind = G_EXIT;
-          else { r = wl.reads ? wl.reads[item] : item; kind = G_META; }
+        if (bk == GB_VAR_NEXT) {
+          bool have = false;
+          if (nm == 1) {
+            if (vi_phase == 0) { vi_phase = 2; have = true; }
+          } else if (vi_phase == 0) {
+            if (vi_v >= 0) {
+              const uint32_t head = mq_head(vi_v);
+              uint32_t cnt = 0;
+              for (uint32_t x = head; x < nm; x++) if (mq_get(x) == vi_v) cnt++;
+              mx = head; vi_head = (int)head; have = true;
+              if (cnt >= 2) { vi_phase = 1; vi_x = (int)nm; }
+              else { vi_v = mq_max_below(vi_v); if (vi_v < 0) vi_phase = 2; }
+            }
+          } else if (vi_phase == 1) {
+            int x = vi_x - 1;
+            while (x > vi_head && mq_get((uint32_t)x) != vi_v) x--;
+            if (x > vi_head) { mx = (uint32_t)x; vi_x = x; have = true; }
+            else vi_phase = 2;
+          }
+          if (!have) { ev_pass = -1; bk = GB_EVAL_NEXT; }
+          else if (nm == 1) bk = GB_VAR_MATCH;
+          else { ml_for = 0; kind = G_MLOAD; bk = GB_NONE; }
         }
-        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
-        else wnext += n;
+        if (bk == GB_VAR_MATCH) {
+          const uint32_t mre = m_qi + m_ql - 1u;
+          if (!(m_qi > 0 && mre + 1u >= p.m)) { bk = GB_VAR_NEXT; continue; }          // :469
+          else if (!in_win((int)m_qi - 1)) {
+            fill_top = (int)m_qi - 1; fill_ret = FR_VARM; fill_pref = false; kind = G_FILL; bk = GB_NONE;
+          } else {
+            // addAllMismatchVariantsAtPosSI(t, qi-1, erase_pos, it), :346-395
+            vlen = (mre < (uint32_t)flen - 1u) ? mre + 1u : (uint32_t)flen;    // fragment.erase(erase_pos)
+            vorig = ct.idx_to_aa[win[(int)m_qi - 1 - wq]];
+            const int sc = (int)m_psum + t_diff;                               // calcScore(fragment, f->diff)
+            const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
+            vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];             // unsigned wrap as in :363
+            kind = G_VMULTI; bk = GB_NONE;
+          }
+        }
+        if (bk == GB_EVAL_NEXT) {
+          // eval_match_scores(si, t), :751-797: the samelen chains of the classes (descending length,
+          // while >= m) in insertion order, then the class heads in ascending length
+          if (nm == 1) {
+            if (m_ql >= p.m) eval_match();
+            bk = GB_POP;
+          } else {
+            if (ev_pass < 0) {
+              ev_v1 = mq_max_below(0x7fffffff);
+              if (ev_v1 < (int)p.m) bk = GB_POP;                               // :482
+              else { ev_pass = 0; ev_v = ev_v1; ev_x = -1; ev_done = false; }
+            }
+            while (bk == GB_EVAL_NEXT) {
+              if (ev_pass == 0) {
+                const int head = (int)mq_head(ev_v);
+                int x = (ev_x > head ? ev_x : head) + 1;
+                while (x < (int)nm && mq_get((uint32_t)x) != ev_v) x++;
+                if (x < (int)nm) { ev_x = x; mx = (uint32_t)x; ml_for = 1; kind = G_MLOAD; bk = GB_NONE; }
+                else {
+                  const int nv = mq_max_below(ev_v);
+                  if (nv < 0 || nv < (int)p.m) ev_pass = 1;                    // ev_v is the shortest class >= m
+                  else { ev_v = nv; ev_x = -1; }
+                }
+              } else if (ev_done) bk = GB_POP;
+              else {
+                mx = mq_head(ev_v); ml_for = 1; kind = G_MLOAD; bk = GB_NONE;
+                if (ev_v == ev_v1) ev_done = true;
+                else {
+                  int nv = 0x7fffffff;
+                  for (uint32_t x = 0; x < nm; x++) { const int q = mq_get(x); if (q > ev_v && q < nv) nv = q; }
+                  ev_v = nv;
+                }
+              }
+            }
+          }
+        }
+        if (bk == GB_EVAL_MATCH) { eval_match(); bk = GB_EVAL_NEXT; continue; }
+        if (bk == GB_POP) {
+          // getNextFragment(best_match_score), ConsumerThread.cpp:272-342
+          uint32_t dbest = 0, dslot = 0;
+          {
+            const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
+            for (uint32_t s = 0; s < nl; s++) { const uint32_t pr = prio[s]; if (pr > dbest) { dbest = pr; dslot = s; } }
+            for (uint32_t s = kGSlots; s < qn; s++) { const uint32_t pr = gs.prio_ext[s - kGSlots]; if (pr > dbest) { dbest = pr; dslot = s; } }
+          }
+          const bool have_o = fo < nf, have_d = dbest != 0;
+          const uint32_t dkey = dbest >> 16;
+          if ((!have_o && !have_d) || ovf || m_ovf) bk = GB_FINISH;
+          else {
+            const bool pick_o = have_o && (!have_d || on_key >= dkey);
+            if ((pick_o ? on_key : dkey) < best) bk = GB_FINISH;
+            else if (!pick_o) { pr_set(dslot, 0); qlive--; pslot = dslot; kind = G_POPITEM; bk = GB_NONE; }
+            else {
+              t_start = on_start; t_len = on_len; t_diff = 0; t_matchlen = 0; t_tot = on_key; t_msum = 0; t_nmm = 0;
+              const uint32_t oflags = on_flags;
+              if (on_key > 0xffffu || on_len > 0xffffu) ovf = true;
+              fo++;
+              if (p.seg && !(oflags & kFragChecked)) {
+                // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked
+                // pieces are queued, and the next fragment is popped (:291-334)
+                const uint32_t slot = oflags >> kFragSlotShift;
+                if (slot) {
+                  const SegRec &rec = sq.recs[slot - 1];
+                  if (rec.overflow) flags |= kHitInternalOverflow;
+                  Frag f; f.start = t_start; f.len = t_len; f.key = on_key; f.flags = 0;
+                  seg_split(ct, p, rec, b.pep + pepoff, f, [&](const Frag &q) {
+                    if (q.len > 0xffffu) { ovf = true; return; }
+                    const uint32_t sl = push_slot(q.key, qseq);
+                    if (sl == ~0u) return;
+                    qseq++;
+                    u128 *dst = gs.pool + 8 * sl;
+                    u128 v;
+                    v.x = 0; v.y = q.key | (uint64_t)q.start << 32; dst[0] = v;
+                    v.x = q.len; v.y = q.key; dst[1] = v;
+                    v.x = v.y = 0; dst[2] = v; dst[3] = v;   // no substitutions, no window
+                  });
+                }
+                if (fo < nf) {
+                  const Frag nx = b.frags[fbase + fo];
+                  on_start = nx.start; on_len = nx.len; on_key = nx.key; on_flags = nx.flags;
+                }
+                continue;                                   // bk stays GB_POP
+              }
+              flen = (int)t_len; nm = 0;
+              j = flen - 1; tail = 0;                       // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
+              fill_top = j; fill_ret = FR_START_J; fill_pref = true; kind = G_FILL; bk = GB_NONE;
+            }
+          }
+        }
+        if (bk == GB_FINISH) {
+          nids = 0;
+          hit->reserved = 0;
+          if (ovf || m_ovf) {
+            hit->best = 0;
+            if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+            else flags = kHitInternalOverflow;
+            bk = GB_DONE;
+          } else {
+            hit->best = nbest ? best : 0u;
+            cur = 0;
+            bk = GB_LOC_NEXT_SI;
+          }
+        }
+        if (bk == GB_LOC_NEXT_SI) {
+          if (cur >= nbest) bk = GB_DONE;
+          else {
+            if (cur == 0) { row = b0lo; rowend = b0lo + b0len; }
+            else { const GBest2 gb = gs.best[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
+            cur++;
+            k = row; fresh = true;
+            bk = loc_row();
+            if (bk == GB_LOC_NEXT_SI) continue;
+          }
+        }
+        if (bk == GB_DONE) {
+          hit->n_ids = nids; hit->flags = flags;
+          kind = G_IDLE; bk = GB_NONE;
+        }
       }
-      if (kj_ballot(kind != G_EXIT) == 0) break;
+
+      // ---- (H1) hand out reads to the lanes that finished one (see mem_lane2) ----
+      {
+        const bool need = kind == G_IDLE;
+        const uint64_t mask = kj_ballot(need);
+        if (mask) {
+          const uint32_t n = popc64(mask);
+          const uint32_t rank = popc64(mask & ((1ull << kj_lane()) - 1ull));
+          const uint32_t avail = wend - wnext;
+          uint32_t newbase = 0, ch = 0;
+          if (n > avail) {
+            const uint32_t left = n_items > wend ? n_items - wend : 0;
+            ch = left / (nwaves * 4u);
+            if (ch > 128u) ch = 128u;
+            if (ch < 8u) ch = 8u;
+            if (ch < n - avail) ch = n - avail;
+            const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+            uint32_t got = 0;
+            if (kj_lane() == leader) got = kj_fetch_chunk(wl.counter, ch);
+            newbase = kj_bcast(got, leader);
+          }
+          if (need) {
+            const uint32_t item = rank < avail ? wnext + rank : newbase + (rank - avail);
+            if (item >= n_items) kind = G_EXIT;
+            else { r = wl.reads ? wl.reads[item] : item; kind = G_META; }
+          }
+          if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
+          else wnext += n;
+        }
+        if (kj_ballot(kind != G_EXIT) == 0) break;
+      }
     }
 
     // ---- (1) load phase ----
-    const bool is_step = kind == G_STEP, is_vstep = kind == G_VSTEP, is_lf = kind == G_LF1 || kind == G_LF2;
-    const P posA = is_step ? lo : is_vstep ? vlo : is_lf ? k : 0;
-    const P posB = is_step ? hi : is_vstep ? vhi : posA;
-    const uint32_t cc = (is_step || kind == G_LF2) ? c : is_vstep ? vc : 1u;
+    KJ_HISTO(6, kind);
+    const bool is_step = kind == G_STEP, is_vm = kind == G_VMULTI, is_lf = kind == G_LF1 || kind == G_LF2;
+    const P vlo = m_lo, vhi = m_lo + m_len;
+    const P posA = is_step ? lo : is_vm ? vlo : is_lf ? k : 0;
+    const P posB = is_step ? hi : is_vm ? vhi : posA;
+    const uint32_t cc = (is_step || kind == G_LF2) ? c : 1u;
     const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
     const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
     const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
@@ -2011,29 +2223,34 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     else if (kind == G_MLOAD) gaddr = reinterpret_cast<const uint8_t *>(gs.matches + mx);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
     const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
-    u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
+    // ten 16-byte reads from two lane-chosen places: a window (G_FILL), a queued item (G_POPITEM),
+    // the 20 letter counts of both rank blocks (G_VMULTI)
+    u128 xa0{0, 0}, xa1{0, 0}, xa2{0, 0}, xa3{0, 0}, xa4{0, 0}, xb0{0, 0}, xb1{0, 0}, xb2{0, 0}, xb3{0, 0}, xb4{0, 0};
     int fq = 0;
-    if (kj_ballot(kind == G_FILL || kind == G_POPITEM)) {   // wave-uniform
+    if (heavy && kj_ballot(kind == G_FILL || kind == G_POPITEM || is_vm)) {   // wave-uniform
       fq = fill_top - (kWin - 1);
       if (fq < 0) fq = 0;
-      const uint8_t *src = kind == G_FILL ? b.pep + pepoff + t_start + fq
-                         : kind == G_POPITEM ? reinterpret_cast<const uint8_t *>(gs.pool + 4 * pslot)
-                                             : reinterpret_cast<const uint8_t *>(blk0);
-      const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
-      w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
+      const uint8_t *sa = reinterpret_cast<const uint8_t *>(blk0), *sb = sa;
+      if (kind == G_FILL) sa = b.pep + pepoff + t_start + fq;
+      else if (kind == G_POPITEM) { sa = reinterpret_cast<const uint8_t *>(gs.pool + 8 * pslot); sb = sa + 80; }
+      else if (is_vm) { sa = reinterpret_cast<const uint8_t *>(&pa->cnt[0]); sb = reinterpret_cast<const uint8_t *>(&pb->cnt[0]); }
+      const u128_unaligned *pa16 = reinterpret_cast<const u128_unaligned *>(sa);
+      const u128_unaligned *pb16 = reinterpret_cast<const u128_unaligned *>(sb);
+      xa0 = pa16[0]; xa1 = pa16[1]; xa2 = pa16[2]; xa3 = pa16[3]; xa4 = pa16[4];
+      xb0 = pb16[0]; xb1 = pb16[1]; xb2 = pb16[2]; xb3 = pb16[3]; xb4 = pb16[4];
     }
 
     // ---- (2) compute ----
     int bk = GB_NONE;
-    if (is_step || is_vstep || kind == G_LF2) {
+    if (is_step || kind == G_LF2) {
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
       const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
-      const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
-      const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
       if (is_step) {
         // UpdateSI(str[i-1]) (bwt.c:160-173)
+        const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
+        const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
         if (ra >= rb) bk = GB_END_MATCH;
         else {
           lo = ra; hi = rb; i--; acc += diag(c);
@@ -2041,37 +2258,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           else if (in_win(i - 1)) c = win[i - 1 - wq];
           else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
         }
-      } else if (is_vstep) {
-        // UpdateSI(trans[substitute]) on the interval of the match (ConsumerThread.cpp:372)
-        if (ra < rb) {
-          const int bos = (int)ct.b62[vorig][vs], bss = (int)ct.b62[vs][vs], boo = (int)ct.b62[vorig][vorig];
-          const uint32_t key = (uint32_t)(int32_t)(vscore + (uint32_t)(int32_t)bos);
-          u128 v0, v1, v2, v3;
-          v0.x = ra | (uint64_t)rb << 32;
-          v0.y = key | (uint64_t)t_start << 32;
-          v1.x = (vlen | (vql + 1u) << 16) | (uint64_t)(uint32_t)(t_diff + bos - bss) << 32;
-          v1.y = (vpsum - (uint32_t)boo + (uint32_t)bss) | (uint64_t)(vdsum + (uint32_t)bss) << 32;
-          uint32_t q0 = sp0, q1 = sp1, q2 = sp2, q3 = sp3, e0 = sa0, e1 = sa1;
-          const uint32_t pz = (vqi - 1u) & 0xffffu;
-          if (t_nmm < (uint32_t)kMaxMismatch) {
-            const uint32_t hs = (t_nmm & 1u) * 16u, bs = (t_nmm & 3u) * 8u;
-            const uint32_t hm = ~(0xffffu << hs), bm = ~(0xffu << bs);
-            switch (t_nmm >> 1) {
-              case 0: q0 = (q0 & hm) | pz << hs; break;
-              case 1: q1 = (q1 & hm) | pz << hs; break;
-              case 2: q2 = (q2 & hm) | pz << hs; break;
-              default: q3 = (q3 & hm) | pz << hs; break;
-            }
-            if (t_nmm < 4u) e0 = (e0 & bm) | vc << bs; else e1 = (e1 & bm) | vc << bs;
-          }
-          v2.x = (t_nmm + 1u) | (uint64_t)q0 << 32;
-          v2.y = q1 | (uint64_t)q2 << 32;
-          v3.x = q3 | (uint64_t)e0 << 32;
-          v3.y = e1;
-          if (vlen > 0xffffu || vql + 1u > 0xffffu) ovf = true; else push_item(key, v0, v1, v2, v3);
-        }
-        vsub++;
-        bk = GB_VAR_SUB;
       } else {
         k = ra; fresh = false;                             // second half of an LF step
         bk = GB_LOC_ROW;
@@ -2092,91 +2278,187 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
       if (c != 0) kind = G_LF2;
       else {
+        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
         const uint32_t iseq = (uint32_t)rank_term(ix, k);
-        if (iseq < ix.nseq && ix.seq_valid[iseq]) {
-          const uint64_t tax = ix.seq_taxid[iseq];
-          bool dup = false;
-          if (nids >= 1 && tax == id0) dup = true;
-          for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-          if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
-        }
+        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
         row++;
         k = row; fresh = true;
         bk = GB_LOC_ROW;
       }
     } else if (kind == G_SA) {
       const uint64_t tax = ghalf ? gv.y : gv.x;
-      if (tax != ~0ull) {
-        bool dup = false;
-        if (nids >= 1 && tax == id0) dup = true;
-        for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-        if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
-      }
+      if (tax != ~0ull) add_tax(tax);
       row++;
       k = row; fresh = true;
       bk = GB_LOC_ROW;
-    } else if (kind == G_META) {
-      pepoff = gv.x;
-      fbase = (uint32_t)gv.y;
-      nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
-      fo = 0; best = 0; nbest = 0; flags = 0; ovf = false; m_ovf = false;
-      for (uint32_t s = 0; s < qn; s++) pr_set(s, 0);
-      qn = qlive = qseq = 0;
-      hit = b.hits + r;
-      if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
-    } else if (kind == G_FRAG) {
-      on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
-      bk = GB_POP;
-    } else if (kind == G_FILL) {
-      wq = fq;
-      uint32_t *d32 = reinterpret_cast<uint32_t *>(win);
-      d32[0] = (uint32_t)w0.x; d32[1] = (uint32_t)(w0.x >> 32); d32[2] = (uint32_t)w0.y; d32[3] = (uint32_t)(w0.y >> 32);
-      d32[4] = (uint32_t)w1.x; d32[5] = (uint32_t)(w1.x >> 32); d32[6] = (uint32_t)w1.y; d32[7] = (uint32_t)(w1.y >> 32);
-      d32[8] = (uint32_t)w2.x; d32[9] = (uint32_t)(w2.x >> 32); d32[10] = (uint32_t)w2.y; d32[11] = (uint32_t)(w2.y >> 32);
-      d32[12] = (uint32_t)w3.x; d32[13] = (uint32_t)(w3.x >> 32); d32[14] = (uint32_t)w3.y; d32[15] = (uint32_t)(w3.y >> 32);
-      // the substitutions of the variant (the reference edits the fragment string, :380)
-      for (uint32_t x = 0; x < t_nmm && x < (uint32_t)kMaxMismatch; x++) {
-        const uint32_t pw = x < 2 ? sp0 : x < 4 ? sp1 : x < 6 ? sp2 : sp3;
-        const int pz = (int)((pw >> ((x & 1u) * 16u)) & 0xffffu);
-        const uint32_t aw = x < 4 ? sa0 : sa1;
-        if (pz >= wq && pz < wq + kWin && pz < (int)t_len) win[pz - wq] = (uint8_t)(aw >> ((x & 3u) * 8u));
-      }
-      if (fill_pref && fo < nf) {
+    } else if (heavy) {
+      if (is_vm) {
+        // UpdateSI(trans[substitute]) on the interval of the match for all substitutes at once
+        // (ConsumerThread.cpp:366-392): the ranks of the 20 letters at both ends of the interval
+        const uint64_t lowA = (1ull << (posA & 63u)) - 1ull, lowB = (1ull << (posB & 63u)) - 1ull;
+        uint64_t A01[4], A23[4], A4[2], B01[4], B23[4], B4[2];
+        A01[0] = ~a01.x & ~a01.y & lowA; A01[1] = a01.x & ~a01.y & lowA; A01[2] = ~a01.x & a01.y & lowA; A01[3] = a01.x & a01.y & lowA;
+        A23[0] = ~a23.x & ~a23.y; A23[1] = a23.x & ~a23.y; A23[2] = ~a23.x & a23.y; A23[3] = a23.x & a23.y;
+        A4[0] = ~a4; A4[1] = a4;
+        B01[0] = ~b01.x & ~b01.y & lowB; B01[1] = b01.x & ~b01.y & lowB; B01[2] = ~b01.x & b01.y & lowB; B01[3] = b01.x & b01.y & lowB;
+        B23[0] = ~b23.x & ~b23.y; B23[1] = b23.x & ~b23.y; B23[2] = ~b23.x & b23.y; B23[3] = b23.x & b23.y;
+        B4[0] = ~b4; B4[1] = b4;
+        uint32_t cntA[20], cntB[20];
+        {
+          const u128 xs[5] = {xa0, xa1, xa2, xa3, xa4}, ys[5] = {xb0, xb1, xb2, xb3, xb4};
+#pragma unroll
+          for (int q = 0; q < 5; q++) {
+            cntA[4 * q] = (uint32_t)xs[q].x; cntA[4 * q + 1] = (uint32_t)(xs[q].x >> 32);
+            cntA[4 * q + 2] = (uint32_t)xs[q].y; cntA[4 * q + 3] = (uint32_t)(xs[q].y >> 32);
+            cntB[4 * q] = (uint32_t)ys[q].x; cntB[4 * q + 1] = (uint32_t)(ys[q].x >> 32);
+            cntB[4 * q + 2] = (uint32_t)ys[q].y; cntB[4 * q + 3] = (uint32_t)(ys[q].y >> 32);
+          }
+        }
+        // the reference stops at the first substitute whose score is too low (:368-369); the
+        // substitutes are sorted by score (host_tables.cpp checks), so that is a threshold
+        const int32_t thr = (int32_t)best > (int32_t)p.min_score ? (int32_t)best : (int32_t)p.min_score;
+        const uint32_t *brow = reinterpret_cast<const uint32_t *>(ct.b62_idx[vorig]);
+        const uint32_t bw[5] = {brow[0], brow[1], brow[2], brow[3], brow[4]};
+        const uint32_t corig = ct.aa_to_idx[vorig];
+        uint32_t ra_[20], rb_[20], succ = 0;
+#pragma unroll
+        for (int cx = 1; cx <= 20; cx++) {
+          ra_[cx - 1] = cntA[cx - 1] + popc64(A01[cx & 3] & A23[(cx >> 2) & 3] & A4[cx >> 4]);
+          rb_[cx - 1] = cntB[cx - 1] + popc64(B01[cx & 3] & B23[(cx >> 2) & 3] & B4[cx >> 4]);
+          const int bos = (int)(int8_t)(bw[(cx - 1) >> 2] >> (8 * ((cx - 1) & 3)));
+          const int32_t after = (int32_t)(vscore + (uint32_t)(int32_t)bos);
+          if (ra_[cx - 1] < rb_[cx - 1] && after >= thr && (uint32_t)cx != corig) succ |= 1u << cx;
+        }
+        if (succ) {
+          const int boo = (int)ct.b62[vorig][vorig];
+          // the variants share everything but the letter: window of the fragment with the new letter
+          const uint32_t pz = m_qi - 1u;
+          const int need_fq = (int)m_qi - 2 - (kWin - 1) > 0 ? (int)m_qi - 2 - (kWin - 1) : 0;
+          const bool win_ok = need_fq == wq;                // the variant resumes at m_qi-2 (if m_qi > 1)
+          const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+          u128 wv0, wv1, wv2, wv3;
+          wv0.x = w32[0] | (uint64_t)w32[1] << 32; wv0.y = w32[2] | (uint64_t)w32[3] << 32;
+          wv1.x = w32[4] | (uint64_t)w32[5] << 32; wv1.y = w32[6] | (uint64_t)w32[7] << 32;
+          wv2.x = w32[8] | (uint64_t)w32[9] << 32; wv2.y = w32[10] | (uint64_t)w32[11] << 32;
+          wv3.x = w32[12] | (uint64_t)w32[13] << 32; wv3.y = w32[14] | (uint64_t)w32[15] << 32;
+          uint32_t q0 = sp0, q1 = sp1, q2 = sp2, q3 = sp3;
+          if (t_nmm < (uint32_t)kMaxMismatch) {
+            const uint32_t hs = (t_nmm & 1u) * 16u;
+            const uint32_t hm = ~(0xffffu << hs), pzz = (pz & 0xffffu) << hs;
+            switch (t_nmm >> 1) {
+              case 0: q0 = (q0 & hm) | pzz; break;
+              case 1: q1 = (q1 & hm) | pzz; break;
+              case 2: q2 = (q2 & hm) | pzz; break;
+              default: q3 = (q3 & hm) | pzz; break;
+            }
+          }
+          if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; succ = 0; }
+          while (succ) {
+            const uint32_t cx = (uint32_t)__builtin_ctz(succ);
+            succ &= succ - 1u;
+            uint32_t ra = 0, rb = 0;
+#pragma unroll
+            for (int q = 0; q < 20; q++) if (cx == (uint32_t)q + 1u) { ra = ra_[q]; rb = rb_[q]; }
+            const int bos = (int)ct.b62_idx[vorig][cx - 1u], bss = (int)diag(cx);
+            const uint32_t key = (uint32_t)(int32_t)(vscore + (uint32_t)(int32_t)bos);
+            const uint32_t sl = push_slot(key, qseq + ct.subst_rank[vorig][cx - 1u]);
+            if (sl == ~0u) break;
+            uint32_t e0 = sa0, e1 = sa1;
+            if (t_nmm < (uint32_t)kMaxMismatch) {
+              const uint32_t bs = (t_nmm & 3u) * 8u, bm = ~(0xffu << bs);
+              if (t_nmm < 4u) e0 = (e0 & bm) | cx << bs; else e1 = (e1 & bm) | cx << bs;
+            }
+            u128 *dst = gs.pool + 8 * sl;
+            u128 v;
+            v.x = ra | (uint64_t)rb << 32; v.y = key | (uint64_t)t_start << 32; dst[0] = v;
+            v.x = (vlen | (m_ql + 1u) << 16) | (uint64_t)(uint32_t)(t_diff + bos - bss) << 32;
+            v.y = (m_psum - (uint32_t)boo + (uint32_t)bss) | (uint64_t)(m_dsum + (uint32_t)bss) << 32; dst[1] = v;
+            v.x = (t_nmm + 1u) | (uint64_t)q0 << 32; v.y = q1 | (uint64_t)q2 << 32; dst[2] = v;
+            v.x = q3 | (uint64_t)e0 << 32; v.y = e1 | (uint64_t)(win_ok ? (uint32_t)wq + 1u : 0u) << 32; dst[3] = v;
+            if (win_ok) {
+              dst[4] = wv0; dst[5] = wv1; dst[6] = wv2; dst[7] = wv3;
+              reinterpret_cast<uint8_t *>(dst + 4)[(int)pz - wq] = (uint8_t)cx;   // pz is in the window (GB_VAR_MATCH)
+            }
+          }
+        }
+        qseq += 19;
+        bk = GB_VAR_NEXT;
+      } else if (kind == G_META) {
+        pepoff = gv.x;
+        fbase = (uint32_t)gv.y;
+        nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
+        fo = 0; best = 0; nbest = 0; flags = 0; ovf = false; m_ovf = false;
+        for (uint32_t s = 0; s < (uint32_t)kGSlots; s++) prio[s] = 0;
+        for (uint32_t s = kGSlots; s < qn; s++) gs.prio_ext[s - kGSlots] = 0;
+        qn = qlive = qseq = 0;
+        hit = b.hits + r;
+        if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
+      } else if (kind == G_FRAG) {
         on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
+        bk = GB_POP;
+      } else if (kind == G_FILL || kind == G_POPITEM) {
+        bool fill = kind == G_FILL;
+        u128 f0 = xa0, f1 = xa1, f2 = xa2, f3 = xa3;
+        int newq = fq;
+        if (!fill) {
+          lo = (P)xa0.x; hi = (P)(xa0.x >> 32);
+          t_start = (uint32_t)(xa0.y >> 32);
+          t_len = (uint32_t)xa1.x & 0xffffu; t_matchlen = ((uint32_t)xa1.x >> 16) & 0xffffu;
+          t_diff = (int32_t)(uint32_t)(xa1.x >> 32);
+          t_tot = (uint32_t)xa1.y; t_msum = (uint32_t)(xa1.y >> 32);
+          t_nmm = (uint32_t)xa2.x;
+          sp0 = (uint32_t)(xa2.x >> 32); sp1 = (uint32_t)xa2.y; sp2 = (uint32_t)(xa2.y >> 32); sp3 = (uint32_t)xa3.x;
+          sa0 = (uint32_t)(xa3.x >> 32); sa1 = (uint32_t)xa3.y;
+          const uint32_t wtag = (uint32_t)(xa3.y >> 32);
+          flen = (int)t_len; nm = 0;
+          j = flen - 1;
+          if (t_nmm == 0) {
+            // a SEG piece: maxMatches like an original
+            tail = 0;
+            fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL;
+          } else {
+            // maxMatches_withStart, bwt.c:298-336
+            i = j - (int)t_matchlen + 1;
+            acc = t_msum;
+            if (i <= 0) bk = GB_END_MATCH;
+            else if (wtag != 0) {                           // the item carries its window
+              fill = true; fill_ret = FR_STEP; fill_pref = false;
+              f0 = xa4; f1 = xb0; f2 = xb1; f3 = xb2; newq = (int)wtag - 1;
+            } else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
+          }
+        }
+        if (fill) {
+          wq = newq;
+          uint32_t *d32 = reinterpret_cast<uint32_t *>(win);
+          d32[0] = (uint32_t)f0.x; d32[1] = (uint32_t)(f0.x >> 32); d32[2] = (uint32_t)f0.y; d32[3] = (uint32_t)(f0.y >> 32);
+          d32[4] = (uint32_t)f1.x; d32[5] = (uint32_t)(f1.x >> 32); d32[6] = (uint32_t)f1.y; d32[7] = (uint32_t)(f1.y >> 32);
+          d32[8] = (uint32_t)f2.x; d32[9] = (uint32_t)(f2.x >> 32); d32[10] = (uint32_t)f2.y; d32[11] = (uint32_t)(f2.y >> 32);
+          d32[12] = (uint32_t)f3.x; d32[13] = (uint32_t)(f3.x >> 32); d32[14] = (uint32_t)f3.y; d32[15] = (uint32_t)(f3.y >> 32);
+          if (kind == G_FILL) {
+            // the substitutions of the variant (the reference edits the fragment string, :380)
+            for (uint32_t x = 0; x < t_nmm && x < (uint32_t)kMaxMismatch; x++) {
+              const uint32_t pw = x < 2 ? sp0 : x < 4 ? sp1 : x < 6 ? sp2 : sp3;
+              const int pz = (int)((pw >> ((x & 1u) * 16u)) & 0xffffu);
+              const uint32_t aw = x < 4 ? sa0 : sa1;
+              if (pz >= wq && pz < wq + kWin && pz < (int)t_len) win[pz - wq] = (uint8_t)(aw >> ((x & 3u) * 8u));
+            }
+            if (fill_pref && fo < nf) {
+              on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
+            }
+          }
+          if (fill_ret == FR_STEP) { c = win[i - 1 - wq]; kind = G_STEP; }
+          else if (fill_ret == FR_START_J) bk = GB_START_J;
+          else bk = GB_VAR_MATCH;
+        }
+      } else if (kind == G_MLOAD) {
+        m_lo = (uint32_t)gv.x; m_len = (uint32_t)(gv.x >> 32);
+        m_qi = (uint32_t)gv.y & 0xffffu; m_ql = ((uint32_t)gv.y >> 16) & 0xffffu;
+        m_dsum = (uint32_t)(gv.y >> 32) & 0xffffu; m_psum = (uint32_t)(gv.y >> 48) & 0xffffu;
+        bk = ml_for == 0 ? GB_VAR_MATCH : GB_EVAL_MATCH;
       }
-      if (fill_ret == FR_STEP) { c = win[i - 1 - wq]; kind = G_STEP; }
-      else if (fill_ret == FR_START_J) bk = GB_START_J;
-      else bk = GB_VAR_MATCH;
-    } else if (kind == G_POPITEM) {
-      lo = (P)w0.x; hi = (P)(w0.x >> 32);
-      t_start = (uint32_t)(w0.y >> 32);
-      t_len = (uint32_t)w1.x & 0xffffu; t_matchlen = ((uint32_t)w1.x >> 16) & 0xffffu;
-      t_diff = (int32_t)(uint32_t)(w1.x >> 32);
-      t_tot = (uint32_t)w1.y; t_msum = (uint32_t)(w1.y >> 32);
-      t_nmm = (uint32_t)w2.x;
-      sp0 = (uint32_t)(w2.x >> 32); sp1 = (uint32_t)w2.y; sp2 = (uint32_t)(w2.y >> 32); sp3 = (uint32_t)w3.x;
-      sa0 = (uint32_t)(w3.x >> 32); sa1 = (uint32_t)w3.y;
-      flen = (int)t_len; nm = 0;
-      j = flen - 1;
-      if (t_nmm == 0) {
-        // a SEG piece: maxMatches like an original
-        tail = 0;
-        fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL;
-      } else {
-        // maxMatches_withStart, bwt.c:298-336
-        i = j - (int)t_matchlen + 1;
-        acc = t_msum;
-        if (i > 0) { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
-        else bk = GB_END_MATCH;
-      }
-    } else if (kind == G_MLOAD) {
-      m_lo = (uint32_t)gv.x; m_len = (uint32_t)(gv.x >> 32);
-      m_qi = (uint32_t)gv.y & 0xffffu; m_ql = ((uint32_t)gv.y >> 16) & 0xffffu;
-      m_dsum = (uint32_t)(gv.y >> 32) & 0xffffu; m_psum = (uint32_t)(gv.y >> 48) & 0xffffu;
-      bk = ml_for == 0 ? GB_VAR_MATCH : GB_EVAL_MATCH;
     }
 
-    // ---- (3) bookkeeping ----
+    // ---- (3) fast bookkeeping; everything else waits for the next heavy iteration ----
     while (bk != GB_NONE) {
       if (bk == GB_END_MATCH) {
         const int l = j - i + 1;
@@ -2221,191 +2503,13 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];                              // InitialSI, bwt.c:146-152
           acc = diag(c);
           i = j;
-          if (i == 0) bk = GB_END_MATCH;
+          if (i == 0) { bk = GB_END_MATCH; continue; }
           else if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; bk = GB_NONE; }
           else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; bk = GB_NONE; }
         }
-        if (bk == GB_END_MATCH) continue;
       }
-      if (bk == GB_AFTER_SEARCH) {
-        if (nm == 0 || m_ovf) bk = GB_POP;                 // (overflow: the read is redone in the retry pass)
-        else if (p.mismatches > 0 && t_nmm < p.mismatches) {
-          // the order in which `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the
-          // list of insert_SI_sorted (bwt.c:225-252): see greedy_lane
-          vi_phase = 0;
-          vi_v = nm == 1 ? (int)m_ql : mq_max_below(0x7fffffff);
-          bk = GB_VAR_NEXT;
-        } else { ev_pass = -1; bk = GB_EVAL_NEXT; }
-      }
-      if (bk == GB_VAR_NEXT) {
-        bool have = false;
-        if (nm == 1) {
-          if (vi_phase == 0) { vi_phase = 2; have = true; }
-        } else if (vi_phase == 0) {
-          if (vi_v >= 0) {
-            const uint32_t head = mq_head(vi_v);
-            uint32_t cnt = 0;
-            for (uint32_t x = head; x < nm; x++) if (mq_get((uint32_t)x) == vi_v) cnt++;
-            mx = head; vi_head = (int)head; have = true;
-            if (cnt >= 2) { vi_phase = 1; vi_x = (int)nm; }
-            else { vi_v = mq_max_below(vi_v); if (vi_v < 0) vi_phase = 2; }
-          }
-        } else if (vi_phase == 1) {
-          int x = vi_x - 1;
-          while (x > vi_head && mq_get(x) != vi_v) x--;
-          if (x > vi_head) { mx = (uint32_t)x; vi_x = x; have = true; }
-          else vi_phase = 2;
-        }
-        if (!have) { ev_pass = -1; bk = GB_EVAL_NEXT; }
-        else if (nm == 1) bk = GB_VAR_MATCH;
-        else { ml_for = 0; kind = G_MLOAD; bk = GB_NONE; }
-      }
-      if (bk == GB_VAR_MATCH) {
-        const uint32_t mre = m_qi + m_ql - 1u;
-        if (!(m_qi > 0 && mre + 1u >= p.m)) bk = GB_VAR_NEXT;                // :469
-        else if (!in_win((int)m_qi - 1)) {
-          fill_top = (int)m_qi - 1; fill_ret = FR_VARM; fill_pref = false; kind = G_FILL; bk = GB_NONE;
-        } else {
-          // addAllMismatchVariantsAtPosSI(t, qi-1, erase_pos, it), :346-395
-          vlen = (mre < (uint32_t)flen - 1u) ? mre + 1u : (uint32_t)flen;    // fragment.erase(erase_pos)
-          vorig = ct.idx_to_aa[win[(int)m_qi - 1 - wq]];
-          const int sc = (int)m_psum + t_diff;                               // calcScore(fragment, f->diff)
-          const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
-          vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];             // unsigned wrap as in :363
-          vlo = m_lo; vhi = m_lo + m_len; vqi = m_qi; vql = m_ql; vdsum = m_dsum; vpsum = m_psum;
-          vsub = 0;
-          bk = GB_VAR_SUB;
-        }
-        if (bk == GB_VAR_NEXT) continue;
-      }
-      if (bk == GB_VAR_SUB) {
-        bk = GB_VAR_NEXT;
-        if (vsub < 19) {
-          vs = ct.subst[vorig][vsub];
-          const int32_t after = (int32_t)(vscore + (uint32_t)(int32_t)ct.b62[vorig][vs]);
-          if (after >= (int32_t)best && after >= (int32_t)p.min_score) { vc = ct.aa_to_idx[vs]; kind = G_VSTEP; bk = GB_NONE; }
-        }                                                                    // break at the first too-low score
-        if (bk == GB_VAR_NEXT) continue;
-      }
-      if (bk == GB_EVAL_NEXT) {
-        // eval_match_scores(si, t), :751-797: the samelen chains of the classes (descending length,
-        // while >= m) in insertion order, then the class heads in ascending length
-        if (nm == 1) {
-          if (m_ql >= p.m) eval_match();
-          bk = GB_POP;
-        } else {
-          if (ev_pass < 0) {
-            ev_v1 = mq_max_below(0x7fffffff);
-            if (ev_v1 < (int)p.m) bk = GB_POP;                               // :482
-            else { ev_pass = 0; ev_v = ev_v1; ev_x = -1; ev_done = false; }
-          }
-          while (bk == GB_EVAL_NEXT) {
-            if (ev_pass == 0) {
-              const int head = (int)mq_head(ev_v);
-              int x = (ev_x > head ? ev_x : head) + 1;
-              while (x < (int)nm && mq_get((uint32_t)x) != ev_v) x++;
-              if (x < (int)nm) { ev_x = x; mx = (uint32_t)x; ml_for = 1; kind = G_MLOAD; bk = GB_NONE; }
-              else {
-                const int nv = mq_max_below(ev_v);
-                if (nv < 0 || nv < (int)p.m) ev_pass = 1;                    // ev_v is the shortest class >= m
-                else { ev_v = nv; ev_x = -1; }
-              }
-            } else if (ev_done) bk = GB_POP;
-            else {
-              mx = mq_head(ev_v); ml_for = 1; kind = G_MLOAD; bk = GB_NONE;
-              if (ev_v == ev_v1) ev_done = true;
-              else {
-                int nv = 0x7fffffff;
-                for (uint32_t x = 0; x < nm; x++) { const int q = mq_get(x); if (q > ev_v && q < nv) nv = q; }
-                ev_v = nv;
-              }
-            }
-          }
-        }
-      }
-      if (bk == GB_EVAL_MATCH) { eval_match(); bk = GB_EVAL_NEXT; continue; }
-      if (bk == GB_POP) {
-        // getNextFragment(best_match_score), ConsumerThread.cpp:272-342
-        uint32_t dbest = 0, dslot = 0;
-        for (uint32_t s = 0; s < qn; s++) { const uint32_t pr = pr_get(s); if (pr > dbest) { dbest = pr; dslot = s; } }
-        const bool have_o = fo < nf, have_d = dbest != 0;
-        const uint32_t dkey = dbest >> 16;
-        if ((!have_o && !have_d) || ovf || m_ovf) bk = GB_FINISH;
-        else {
-          const bool pick_o = have_o && (!have_d || on_key >= dkey);
-          if ((pick_o ? on_key : dkey) < best) bk = GB_FINISH;
-          else if (!pick_o) { pr_set(dslot, 0); qlive--; pslot = dslot; kind = G_POPITEM; bk = GB_NONE; }
-          else {
-            t_start = on_start; t_len = on_len; t_diff = 0; t_matchlen = 0; t_tot = on_key; t_msum = 0; t_nmm = 0;
-            const uint32_t oflags = on_flags;
-            if (on_key > 0xffffu || on_len > 0xffffu) ovf = true;
-            fo++;
-            if (p.seg && !(oflags & kFragChecked)) {
-              // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked
-              // pieces are queued, and the next fragment is popped (:291-334)
-              const uint32_t slot = oflags >> kFragSlotShift;
-              if (slot) {
-                const SegRec &rec = sq.recs[slot - 1];
-                if (rec.overflow) flags |= kHitInternalOverflow;
-                Frag f; f.start = t_start; f.len = t_len; f.key = on_key; f.flags = 0;
-                seg_split(ct, p, rec, b.pep + pepoff, f, [&](const Frag &q) {
-                  u128 v0, v1, v2, v3;
-                  v0.x = 0; v0.y = q.key | (uint64_t)q.start << 32;
-                  v1.x = q.len; v1.y = q.key;
-                  v2.x = v2.y = v3.x = v3.y = 0;
-                  if (q.len > 0xffffu) ovf = true; else push_item(q.key, v0, v1, v2, v3);
-                });
-              }
-              if (fo < nf) {
-                const Frag nx = b.frags[fbase + fo];
-                on_start = nx.start; on_len = nx.len; on_key = nx.key; on_flags = nx.flags;
-              }
-              continue;                                     // bk stays GB_POP
-            }
-            flen = (int)t_len; nm = 0;
-            j = flen - 1; tail = 0;                         // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
-            fill_top = j; fill_ret = FR_START_J; fill_pref = true; kind = G_FILL; bk = GB_NONE;
-          }
-        }
-      }
-      if (bk == GB_FINISH) {
-        nids = 0;
-        hit->reserved = 0;
-        if (ovf || m_ovf) {
-          hit->best = 0;
-          if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
-          else flags = kHitInternalOverflow;
-          bk = GB_DONE;
-        } else {
-          hit->best = nbest ? best : 0u;
-          cur = 0;
-          bk = GB_LOC_NEXT_SI;
-        }
-      }
-      if (bk == GB_LOC_NEXT_SI) {
-        if (cur >= nbest) bk = GB_DONE;
-        else {
-          if (cur == 0) { row = b0lo; rowend = b0lo + b0len; }
-          else { const GBest2 gb = gs.best[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
-          cur++;
-          k = row; fresh = true;
-          bk = GB_LOC_ROW;
-        }
-      }
-      if (bk == GB_LOC_ROW) {
-        if (row >= rowend) { bk = GB_LOC_NEXT_SI; continue; }
-        else if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = GB_DONE; }   // :805-807
-        else if ((k & check) != 0) { kind = G_LF1; bk = GB_NONE; }
-        else {
-          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-          if (sa_idx < ix.n_sa) { kind = G_SA; bk = GB_NONE; }
-          else { row++; k = row; fresh = true; continue; }  // (the reference reads out of bounds here): skip the row
-        }
-      }
-      if (bk == GB_DONE) {
-        hit->n_ids = nids; hit->flags = flags;
-        kind = G_IDLE; bk = GB_NONE;
-      }
+      if (bk == GB_LOC_ROW) bk = loc_row();
+      if (bk > GB_LOC_ROW) { bk_pend = bk; kind = G_WAIT; bk = GB_NONE; }
     }
   }
 }

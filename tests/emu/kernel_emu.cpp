@@ -164,13 +164,18 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       gs.best = bestv.data(); gs.win = win;
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1" or default (v2 where possible)
       if (d.blocks64 && d.kmer32 && !v && pass == 0) {
-        std::vector<uint32_t> lds(kGLdsStride, 0xdeadbeefu);
-        std::vector<u128> pool2(4 * kGSlotsAll);
+        alignas(16) uint32_t lds_win[kGWinStride], lds_mq[kGMqStride], lds_prio[kGPrioStride];
+        for (auto &x : lds_win) x = 0xdeadbeefu;
+        for (auto &x : lds_mq) x = 0xdeadbeefu;
+        for (auto &x : lds_prio) x = 0xdeadbeefu;
+        std::vector<u128> pool2(8 * kGSlotsAll + 4);
         std::vector<uint32_t> prio_ext(kGSlotsAll - kGSlots, 0xdeadbeefu);
         std::vector<GMatch2> matches2(kGMaxMAll);
         std::vector<uint16_t> mq_ext(kGMaxMAll - kGMaxM, 0xdead);
         std::vector<GBest2> best2(64);
-        GreedyScratch2 g2{lds.data(), pool2.data(), prio_ext.data(), matches2.data(), mq_ext.data(), best2.data()};
+        const char *ge = getenv("KAIJU_EMU_GATE");
+        GreedyScratch2 g2{reinterpret_cast<uint8_t *>(lds_win), reinterpret_cast<uint16_t *>(lds_mq), lds_prio, pool2.data(),
+                          prio_ext.data(), matches2.data(), mq_ext.data(), best2.data(), ge ? (uint32_t)atoi(ge) : 3u};
         greedy_lane2(d, ix->ct, p, sq, b, wl, g2);
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs);
     }

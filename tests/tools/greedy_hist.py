@@ -40,4 +40,6 @@ for i, nm in enumerate(names):
     nz = np.nonzero(row)[0]
     print(f"{nm}: total {tot}")
     print("   " + " ".join(f"{k}:{row[k] / max(tot, 1):.4f}" for k in nz[:64]))
+kinds = "STEP KMER VSTEP LF1 LF2 SA META FRAG FILL POPITEM MLOAD IDLE EXIT".split()
+print("v2 iterations per read by kind:", {k: round(float(hist[6][i]) / n, 1) for i, k in enumerate(kinds)}, "total", round(float(hist[6][:13].sum()) / n, 1))
 print("retries", nretry, "classified", int((out['n_ids'] > 0).sum()))
