@@ -1848,7 +1848,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
 // kGSlotsAll live queue entries, keys or lengths >= 2^16) is sent to the retry pass (greedy_lane).
 // ----------------------------------------------------------------------------
 #ifdef KJ_G_SMALL                                  // tests: exercise the spill and retry paths
-constexpr int kGMaxM = 2, kGMaxMAll = 5, kGSlots = 4, kGSlotsAll = 9;
+constexpr int kGMaxM = 1, kGMaxMAll = 2, kGSlots = 1, kGSlotsAll = 3;
 #else
 constexpr int kGMaxM = 24, kGMaxMAll = 256;      // matches of one fragment: lengths in LDS / in LDS + global spill
 constexpr int kGSlots = 44, kGSlotsAll = 128;    // queue slots: priorities in LDS / in LDS + global spill

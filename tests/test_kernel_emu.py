@@ -147,3 +147,41 @@ def test_mem_lane_generations_agree(oracle, emu, golden, handles, lane, monkeypa
         gh, _ = emu.classify(h, util.gp("mem", seg=seg), golden.pseqs, golden.poff, paired=True)
         bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
         assert not bad, (lane, seg, "paired", bad[:5])
+
+
+@pytest.mark.parametrize("lane,gate", [("v1", None), (None, "0"), (None, "1"), (None, None), (None, "7")])
+def test_greedy_lane_generations_agree(oracle, emu, golden, handles, lane, gate, monkeypatch):
+    """first-generation Greedy lane and the second-generation lane (any period of its slow part) == oracle"""
+    h, ix, tax = handles
+    if lane:
+        monkeypatch.setenv("KAIJU_EMU_LANE", lane)
+    if gate:
+        monkeypatch.setenv("KAIJU_EMU_GATE", gate)
+    for seg in (1, 0):
+        for mm in (3, 1, 0):
+            g = util.gp("greedy", seg=seg, mismatches=mm)
+            oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg, mismatches=mm), golden.seqs, golden.off)
+            gh, _ = emu.classify(h, g, golden.seqs, golden.off)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+            assert not bad, (lane, gate, seg, mm, bad[:5])
+        oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg), golden.pseqs, golden.poff, paired=True)
+        gh, _ = emu.classify(h, util.gp("greedy", seg=seg), golden.pseqs, golden.poff, paired=True)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (lane, gate, seg, "paired", bad[:5])
+
+
+def test_greedy_lane2_spill_and_retry(oracle, golden, handles):
+    """the second-generation Greedy lane built with tiny bounds (-DKJ_G_SMALL): match lengths and queue
+    priorities spill from the LDS rows to global scratch, reads beyond the bounds take the retry pass"""
+    import os
+    small = util.Emu(so=os.path.join(util.EMU_DIR, "libkaiju_kernel_emu_small.so"), defines=("KJ_G_SMALL",))
+    _, ix, tax = handles
+    h = small.load(golden.fmi)
+    total_retry = 0
+    for seg in (1, 0):
+        oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg), golden.seqs, golden.off)
+        gh, nretry = small.classify(h, util.gp("greedy", seg=seg), golden.seqs, golden.off)
+        total_retry += nretry
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (seg, bad[:5])
+    assert total_retry > 0

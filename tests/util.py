@@ -31,20 +31,22 @@ def gp(mode, m=11, mismatches=3, min_score=65, seed_length=7, seg=1, use_evalue=
     return GP(md, m, mismatches, min_score, seed_length, seg, use_evalue, min_evalue, 20, 20)
 
 
-def build_emu():
+def build_emu(so=None, defines=()):
+    so = so or EMU_SO
     srcs = [os.path.join(EMU_DIR, "kernel_emu.cpp")] + [os.path.join(CSRC, f) for f in
                                                         ("host_index.cpp", "host_tables.cpp", "taxonomy.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("kj_core.h", "host_index.h", "host_tables.h")]
-    if os.path.exists(EMU_SO) and all(os.path.getmtime(d) <= os.path.getmtime(EMU_SO) for d in deps):
+    if os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
         return
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-pthread",
-                    "-o", EMU_SO] + srcs, check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-pthread"]
+                   + ["-D" + d for d in defines] + ["-o", so] + srcs, check=True)
 
 
 class Emu:
-    def __init__(self):
-        build_emu()
-        E = self.lib = C.CDLL(EMU_SO)
+    def __init__(self, so=None, defines=()):
+        so = so or EMU_SO
+        build_emu(so, defines)
+        E = self.lib = C.CDLL(so)
         E.emu_index_load.restype = C.c_void_p
         E.emu_index_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         E.emu_index_free.argtypes = [C.c_void_p]
