@@ -61,7 +61,7 @@ k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch 
   if (r >= b.n_reads) return;
   uint32_t e = 0;
   build_fragments(s_ct, p, seg_ctx(st, s_entg, nullptr), b, sq, r, &e,
-                  stage_bytes ? s_stage + 4 * threadIdx.x : nullptr, 4 * kFragBlock);
+                  stage_bytes ? s_stage + 4 * threadIdx.x : nullptr, 4 * kFragBlock, stage_bytes / 4);
   if (e) atomicOr(err, e);
 }
 

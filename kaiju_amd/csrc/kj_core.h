@@ -582,6 +582,9 @@ KJ_HD void frag_insert(Frag *list, uint32_t &n, uint32_t cap, const Frag &f) {
   n++;
 }
 
+// a run of residues between two stops becomes a fragment if it is long enough (and, Greedy, scores
+// enough): appended in emission order; build_fragments sorts the list afterwards (stable, by
+// descending key: the order of the reference's multimap)
 KJ_HD void emit_run(const ConstTables &t, const Params &p, const PepBuf &pep, Frag *list, uint32_t &n,
                     uint32_t cap, uint32_t start, uint32_t len) {
   if (len < p.m) return;
@@ -590,7 +593,8 @@ KJ_HD void emit_run(const ConstTables &t, const Params &p, const PepBuf &pep, Fr
     f.key = diag_score(t, PepView{pep, 0}, start, len);
     if (f.key < p.min_score) return;
   } else f.key = len;
-  frag_insert(list, n, cap, f);
+  if (n >= cap) return;               // cannot happen: cap is a proven bound
+  list[n++] = f;
 }
 
 // nucleotide at position pos of a read, fetched four at a time
@@ -608,60 +612,78 @@ struct NucReader {
   }
 };
 
-// translate one mate into six frame strings at pep[base..] and emit its fragments
+// translate one mate into six frame strings at pep[base..] and append its fragments.  The loops
+// are unrolled over the three frames so that the per-frame state stays in registers.
 KJ_HD void translate_mate(const ConstTables &t, const Params &p, const uint8_t *s, uint32_t len,
                           const PepBuf &pep, uint32_t base, Frag *list, uint32_t &n, uint32_t cap) {
   const uint32_t fcap = len / 3 + 1;         // room of one frame string incl. closing stop
   uint32_t run_start[3], run_len[3];
   NucReader nr{s, len, 0, 0xffffffffu};
   // forward strand, ConsumerThread.cpp:196-233 (codon_to_int :869-871: any base that is not
-  // ACGTU makes the codon a stop)
-  for (uint32_t f = 0; f < 3; f++) { run_start[f] = base + f * fcap; run_len[f] = 0; }
+  // ACGTU makes the codon a stop): codon `count` belongs to frame count % 3
+#pragma unroll
+  for (int f = 0; f < 3; f++) { run_start[f] = base + (uint32_t)f * fcap; run_len[f] = 0; }
   {
     uint32_t a = t.nuc[nr.at(0)], bb = t.nuc[nr.at(1)];
-    uint32_t f = 0, tpos = 0;                // frame and residue index of the current codon
-    for (uint32_t count = 0; count + 2 < len; count++) {
-      const uint32_t c = t.nuc[nr.at(count + 2)];
-      const uint32_t pos = base + f * fcap + tpos;
-      const uint32_t aa = (a | bb | c) > 3u ? 255u : t.codon_aa[a * 16 + bb * 4 + c];
-      if (aa == 255u) {
-        pep.put(pos, 0);
-        emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-        run_start[f] = pos + 1; run_len[f] = 0;
-      } else { pep.put(pos, t.aa_to_idx[aa]); run_len[f]++; }
-      a = bb; bb = c;
-      if (++f == 3) { f = 0; tpos++; }
+    uint32_t tpos = 0;                       // residue index of the current codons
+    for (uint32_t count = 0; count + 2 < len; count += 3, tpos++) {
+#pragma unroll
+      for (int f = 0; f < 3; f++) {
+        if (count + (uint32_t)f + 2 < len) {
+          const uint32_t c = t.nuc[nr.at(count + (uint32_t)f + 2)];
+          const uint32_t pos = base + (uint32_t)f * fcap + tpos;
+          const uint32_t aa = (a | bb | c) > 3u ? 255u : t.codon_aa[a * 16 + bb * 4 + c];
+          if (aa == 255u) {
+            pep.put(pos, 0);
+            emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
+            run_start[f] = pos + 1; run_len[f] = 0;
+          } else { pep.put(pos, t.aa_to_idx[aa]); run_len[f]++; }
+          a = bb; bb = c;
+        }
+      }
     }
   }
-  for (uint32_t f = 0; f < 3; f++) {
+#pragma unroll
+  for (int f = 0; f < 3; f++) {
     emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
     pep.put(run_start[f] + run_len[f], 0);
   }
   // reverse strand, :235-268: count runs len-3 .. 0, frame = count % 3, residues are appended
   // in visiting order (the count = len-2 iteration of the reference only sees the string
-  // terminator on an empty frame and is a no-op); revcomp_codon_to_int :873-875
-  const uint32_t rbase = base + 3 * fcap, top = len - 3;
-  uint32_t wpos[3];                          // next write position of each frame string
-  for (uint32_t f = 0; f < 3; f++) { run_start[f] = rbase + f * fcap; run_len[f] = 0; wpos[f] = rbase + f * fcap; }
+  // terminator on an empty frame and is a no-op); revcomp_codon_to_int :873-875.
+  // Step g of the unrolled loop works on frame (top - g) % 3: the state is kept per g.
+  const uint32_t rbase = base + 3 * fcap, top = len - 3, f0 = top % 3;
+  uint32_t wpos[3];                          // next write position of the frame string of step g
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    const uint32_t f = (f0 + 3u - (uint32_t)g) % 3u;
+    run_start[g] = wpos[g] = rbase + f * fcap; run_len[g] = 0;
+  }
   {
     uint32_t x = t.nuc[nr.at(len - 1)], y = t.nuc[nr.at(len - 2)];
-    uint32_t f = top % 3;
-    for (int64_t cnt = (int64_t)top; cnt >= 0; cnt--) {
-      const uint32_t z = t.nuc[nr.at((uint32_t)cnt)];
-      const uint32_t pos = wpos[f]++;
-      const uint32_t aa = (x | y | z) > 3u ? 255u : t.codon_aa[(3 - x) * 16 + (3 - y) * 4 + (3 - z)];
-      if (aa == 255u) {
-        pep.put(pos, 0);
-        emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-        run_start[f] = pos + 1; run_len[f] = 0;
-      } else { pep.put(pos, t.aa_to_idx[aa]); run_len[f]++; }
-      x = y; y = z;
-      f = f == 0 ? 2 : f - 1;
+    for (int64_t cnt = (int64_t)top; cnt >= 0; cnt -= 3) {
+#pragma unroll
+      for (int g = 0; g < 3; g++) {
+        if (cnt - g >= 0) {
+          const uint32_t z = t.nuc[nr.at((uint32_t)(cnt - g))];
+          const uint32_t pos = wpos[g]++;
+          const uint32_t aa = (x | y | z) > 3u ? 255u : t.codon_aa[(3 - x) * 16 + (3 - y) * 4 + (3 - z)];
+          if (aa == 255u) {
+            pep.put(pos, 0);
+            emit_run(t, p, pep, list, n, cap, run_start[g], run_len[g]);
+            run_start[g] = pos + 1; run_len[g] = 0;
+          } else { pep.put(pos, t.aa_to_idx[aa]); run_len[g]++; }
+          x = y; y = z;
+        }
+      }
     }
   }
-  for (uint32_t f = 0; f < 3; f++) {
-    emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-    pep.put(run_start[f] + run_len[f], 0);
+  for (uint32_t f = 0; f < 3; f++) {         // the closing runs in frame order
+    const uint32_t g = (f0 + 3u - f) % 3u;
+    const uint32_t rs = g == 0 ? run_start[0] : g == 1 ? run_start[1] : run_start[2];
+    const uint32_t rl = g == 0 ? run_len[0] : g == 1 ? run_len[1] : run_len[2];
+    emit_run(t, p, pep, list, n, cap, rs, rl);
+    pep.put(rs + rl, 0);
   }
 }
 
@@ -744,7 +766,8 @@ struct FragAppend {
 // `stage` is the lane's staging area (LDS on the device) or nullptr (peptides are written
 // straight to their place: long reads, host emulation of that path).
 KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &cx, const Batch &b,
-                           const SegQueue &sq, uint32_t r, uint32_t *err_flags, uint8_t *stage, uint32_t stage_row) {
+                           const SegQueue &sq, uint32_t r, uint32_t *err_flags, uint8_t *stage, uint32_t stage_row,
+                           uint32_t stage_words) {
   const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
   const uint32_t len1 = (uint32_t)(o1 - o0), len2 = (uint32_t)(o2 - o1);
   const uint32_t m3 = p.m * 3;
@@ -759,17 +782,11 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
   if (!skip) {
     if (len1 >= m3) translate_mate(t, p, b.seqs + o0, len1, pep, 0, list, n, cap);
     if (b.paired && len2 >= m3) translate_mate(t, p, b.seqs + o1, len2, pep, 6 * (len1 / 3 + 1), list, n, cap);
+    // SEG trigger detection on the fragments in emission order (the strings are still staged)
     if (p.seg) {
       for (uint32_t k = 0; k < n; k++) {
-        if (seg_triggers(cx, PepView{pep, list[k].start}, (int)list[k].len)) {
-          const uint32_t slot = append_slot(sq.count);
-          if (slot < sq.cap) {
-            SegWork wk; wk.read = r; wk.frag = k;
-            sq.items[slot] = wk;
-            list[k].flags |= (slot + 1) << kFragSlotShift;
-            pending = kNfragSegPending;
-          } else { list[k].flags |= kFragChecked; if (err_flags) *err_flags |= 2u; }
-        } else list[k].flags |= kFragChecked;      // SEG would report nothing for this fragment
+        const Frag f = list[k];
+        list[k].flags = seg_triggers(cx, PepView{pep, f.start}, (int)f.len) ? 0u : kFragChecked;   // checked: SEG would report nothing
       }
     }
     if (stage) {
@@ -781,6 +798,47 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
         v.x = (uint64_t)pep.get32(16 * q) | (uint64_t)pep.get32(16 * q + 4) << 32;
         v.y = (uint64_t)pep.get32(16 * q + 8) | (uint64_t)pep.get32(16 * q + 12) << 32;
         dst[q] = v;
+      }
+    }
+    // queue order: std::multimap<unsigned, Fragment*, std::greater>::emplace puts a fragment behind
+    // every key >= its own, i.e. a stable sort by descending key of the emission order
+    if (stage && n <= stage_words / 2 && n <= 128) {
+      // rank by counting in the (now free) staging row: dword k = key << 7 | 127 - k, dword half+k = start, len
+      uint32_t *row = reinterpret_cast<uint32_t *>(stage);
+      const uint32_t rw = stage_row / 4, half = stage_words / 2;
+      for (uint32_t k = 0; k < n; k++) {
+        const Frag f = list[k];
+        const uint32_t key = f.key < (1u << 24) ? f.key : (1u << 24) - 1u;      // (keys are far below 2^24 here)
+        row[(size_t)k * rw] = (key << 7 | (127u - k)) << 1 | ((f.flags & kFragChecked) ? 1u : 0u);
+        row[(size_t)(half + k) * rw] = f.start << 16 | f.len;
+      }
+      for (uint32_t k = 0; k < n; k++) {
+        const uint32_t ck = row[(size_t)k * rw];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; q++) rank += row[(size_t)q * rw] > ck ? 1u : 0u;
+        const uint32_t sl = row[(size_t)(half + k) * rw];
+        Frag f; f.start = sl >> 16; f.len = sl & 0xffffu; f.key = ck >> 8; f.flags = (ck & 1u) ? kFragChecked : 0u;
+        list[rank] = f;
+      }
+    } else {
+      for (uint32_t k = 1; k < n; k++) {                    // insertion sort in place (long reads)
+        const Frag f = list[k];
+        uint32_t pos = k;
+        while (pos > 0 && list[pos - 1].key < f.key) { list[pos] = list[pos - 1]; pos--; }
+        list[pos] = f;
+      }
+    }
+    // the flagged fragments go to the SEG pass
+    if (p.seg) {
+      for (uint32_t k = 0; k < n; k++) {
+        if (list[k].flags & kFragChecked) continue;
+        const uint32_t slot = append_slot(sq.count);
+        if (slot < sq.cap) {
+          SegWork wk; wk.read = r; wk.frag = k;
+          sq.items[slot] = wk;
+          list[k].flags = (slot + 1) << kFragSlotShift;
+          pending = kNfragSegPending;
+        } else { list[k].flags = kFragChecked; if (err_flags) *err_flags |= 2u; }
       }
     }
   }
