@@ -48,9 +48,9 @@ __global__ void __launch_bounds__(kFragBlock)
 k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err,
             uint32_t stage_bytes) {
   __shared__ ConstTables s_ct;
-  __shared__ int64_t s_entg[13];
+  __shared__ int32_t s_entg[13];
   extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];
-  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
+  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g32[threadIdx.x];
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
     uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
@@ -60,7 +60,7 @@ k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch 
   const uint32_t r = blockIdx.x * kFragBlock + threadIdx.x;
   if (r >= b.n_reads) return;
   uint32_t e = 0;
-  build_fragments(s_ct, p, seg_ctx(st, s_entg, nullptr), b, sq, r, &e,
+  build_fragments(s_ct, p, TrigCtx{s_entg, st.ent_locut32}, b, sq, r, &e,
                   stage_bytes ? s_stage + 4 * threadIdx.x : nullptr, 4 * kFragBlock, stage_bytes / 4);
   if (e) atomicOr(err, e);
 }

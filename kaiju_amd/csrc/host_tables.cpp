@@ -71,6 +71,7 @@ int build_const_tables(const uint8_t trans[128], ConstTables &t, std::string &ms
     t.idx_to_aa[c] = (uint8_t)a;
     t.diag_idx[c] = kB62[a][a];
   }
+  for (int i = 0; i < 64; i++) t.codon_idx[i] = t.codon_aa[i] == 255 ? 0 : t.aa_to_idx[t.codon_aa[i]];
   for (int a = 0; a < 20; a++) {
     for (int c = 1; c <= 20; c++) t.b62_idx[a][c - 1] = kB62[a][t.idx_to_aa[c]];
     memset(t.subst_rank[a], 255, 20);
@@ -103,6 +104,9 @@ bool check_partitions(int remaining, int maxpart, int *sv, int n, const SegTable
     const bool lo_ref = H <= 2.2, hi_ref = H > 2.5;   // kSegLocut / kSegHicut, blast_seg.c:48-50
     const bool lo_int = score <= st.ent_locut, hi_int = score > st.ent_hicut;
     if (lo_ref != lo_int || hi_ref != hi_int) { msg = "integer SEG entropy classification disagrees with libm"; return false; }
+    int32_t score32 = 0;
+    for (int i = 0; i < n; i++) score32 += st.ent_g32[sv[i]];
+    if (lo_ref != (score32 <= st.ent_locut32)) { msg = "32-bit SEG trigger classification disagrees with libm"; return false; }
     return true;
   }
   for (int p = remaining < maxpart ? remaining : maxpart; p >= 1; p--) {
@@ -133,6 +137,10 @@ int build_seg_tables(std::vector<double> &lnfact_host, SegTables &st, std::strin
   for (int c = 1; c <= 12; c++) st.ent_g[c] = (int64_t)llround(scale * ((double)c / 12.0) * log2(12.0 / (double)c));
   st.ent_locut = (int64_t)floor(scale * 2.2);
   st.ent_hicut = (int64_t)floor(scale * 2.5);
+  const double scale32 = 67108864.0;          // 2^26: a window scores below 3.6 * 2^26 < 2^31
+  st.ent_g32[0] = 0;
+  for (int c = 1; c <= 12; c++) st.ent_g32[c] = (int32_t)llround(scale32 * ((double)c / 12.0) * log2(12.0 / (double)c));
+  st.ent_locut32 = (int32_t)floor(scale32 * 2.2);
   int sv[16];
   if (!check_partitions(12, 12, sv, 0, st, msg)) return KAIJU_GPU_ERR_ARG;
   return 0;

@@ -144,6 +144,8 @@ struct SegTables {
   uint32_t lnfact_n;
   int64_t ent_g[13];         // fixed-point entropy contribution of a letter seen c times in a 12-window
   int64_t ent_locut, ent_hicut;   // thresholds in the same fixed-point scale
+  int32_t ent_g32[13];       // the same at a 32-bit scale: enough to decide H <= locut (stage 1's trigger test)
+  int32_t ent_locut32;
 };
 
 // Constant tables (ConsumerThread.cpp:6-187); the kernels keep a copy in LDS.
@@ -157,6 +159,7 @@ struct ConstTables {
   int8_t diag_idx[32];       // BLOSUM62 diagonal by index-alphabet code (blosum62diag, :61-80)
   int8_t b62_idx[20][20];    // b62[a][idx_to_aa[c]] at [a][c-1]: row of an aa2int code, columns by index-alphabet code
   uint8_t subst_rank[20][20];// position of the letter with index code c in subst[a] at [a][c-1] (255: a itself)
+  uint8_t codon_idx[64];     // codon -> index-alphabet code of the amino acid, 0 = stop
 };
 
 struct ReadMeta {            // written by stage 1 (16 bytes): saves the search lanes the layout arithmetic
@@ -582,21 +585,6 @@ KJ_HD void frag_insert(Frag *list, uint32_t &n, uint32_t cap, const Frag &f) {
   n++;
 }
 
-// a run of residues between two stops becomes a fragment if it is long enough (and, Greedy, scores
-// enough): appended in emission order; build_fragments sorts the list afterwards (stable, by
-// descending key: the order of the reference's multimap)
-KJ_HD void emit_run(const ConstTables &t, const Params &p, const PepBuf &pep, Frag *list, uint32_t &n,
-                    uint32_t cap, uint32_t start, uint32_t len) {
-  if (len < p.m) return;
-  Frag f; f.start = start; f.len = len; f.flags = 0;
-  if (p.mode == 1) {
-    f.key = diag_score(t, PepView{pep, 0}, start, len);
-    if (f.key < p.min_score) return;
-  } else f.key = len;
-  if (n >= cap) return;               // cannot happen: cap is a proven bound
-  list[n++] = f;
-}
-
 // nucleotide at position pos of a read, fetched four at a time
 struct NucReader {
   const uint8_t *s;
@@ -612,78 +600,119 @@ struct NucReader {
   }
 };
 
-// translate one mate into six frame strings at pep[base..] and append its fragments.  The loops
-// are unrolled over the three frames so that the per-frame state stays in registers.
-KJ_HD void translate_mate(const ConstTables &t, const Params &p, const uint8_t *s, uint32_t len,
-                          const PepBuf &pep, uint32_t base, Frag *list, uint32_t &n, uint32_t cap) {
+// SEG trigger test of stage 1, incremental: the 12-window ending at the newest residue of a run.
+// Counts of the 20 letters in nibbles, the last 12 letters in a 60-bit shift register, the entropy
+// score at the 32-bit scale (host_tables.cpp checks that it classifies every window like libm).
+struct TrigCtx { const int32_t *g32; int32_t locut32; };
+struct TrigWin { uint64_t c0, c1, hist; int32_t score; };
+KJ_HD void trig_reset(TrigWin &w) { w.c0 = w.c1 = w.hist = 0; w.score = 0; }
+KJ_HD void trig_count(TrigWin &w, const TrigCtx &tc, uint32_t x, int d) {
+  const uint32_t sh = 4u * (x & 15u);
+  const uint32_t old = (uint32_t)((x < 16u ? w.c0 : w.c1) >> sh) & 15u;
+  w.score += tc.g32[(int)old + d] - tc.g32[old];
+  const uint64_t inc = (uint64_t)(int64_t)d << sh;
+  if (x < 16u) w.c0 += inc; else w.c1 += inc;
+}
+// residue with index-alphabet code a joins a run that now has run_len residues: does the 12-window
+// ending here reach the trigger entropy (H <= locut)?
+KJ_HD bool trig_push(TrigWin &w, const TrigCtx &tc, uint32_t a, uint32_t run_len) {
+  const uint32_t x = a - 1u;
+  trig_count(w, tc, x, +1);
+  if (run_len > (uint32_t)kSegWindow) trig_count(w, tc, (uint32_t)(w.hist >> 55) & 31u, -1);
+  w.hist = (w.hist << 5 | x) & ((1ull << 60) - 1ull);
+  return run_len >= (uint32_t)kSegWindow && w.score <= tc.locut32;
+}
+
+// a run of residues between two stops becomes a fragment if it is long enough (and, Greedy, scores
+// enough).  Fragments are appended as they are found, flags = seq << 1 | trig, where seq is the
+// moment at which the reference's getAllFragmentsBits would have emitted the run; build_fragments
+// sorts by (key descending, seq ascending) = the order of the reference's multimap.
+KJ_HD void emit_run(const Params &p, Frag *list, uint32_t &n, uint32_t cap, uint32_t start, uint32_t len,
+                    uint32_t sum, uint32_t seq, bool trig) {
+  if (len < p.m) return;
+  Frag f; f.start = start; f.len = len; f.flags = seq << 1 | (trig ? 1u : 0u);
+  if (p.mode == 1) {
+    f.key = sum;                       // BLOSUM62 diagonal over the run
+    if (f.key < p.min_score) return;
+  } else f.key = len;
+  if (n >= cap) return;               // cannot happen: cap is a proven bound
+  list[n++] = f;
+}
+
+// Translate one mate into its six frame strings at pep[base..] and append its fragments.  ONE pass
+// over the codon positions serves both strands: position cnt yields residue cnt/3 of forward frame
+// cnt%3 (ConsumerThread.cpp:196-233) and, from the complemented codon read backwards, residue
+// (top-cnt)/3 of reverse frame cnt%3 (:235-268, which walks cnt downwards: the reverse strings are
+// filled from their end here).  codon_to_int / revcomp_codon_to_int (:869-875): a base that is not
+// ACGTU makes the codon a stop.  The loop is unrolled over the three frames, all per-frame state is
+// in registers, the SEG trigger test rides along.
+KJ_HD void translate_mate(const ConstTables &t, const Params &p, const TrigCtx &tc, const uint8_t *s, uint32_t len,
+                          uint32_t seq_base, const PepBuf &pep, uint32_t base, Frag *list, uint32_t &n, uint32_t cap) {
   const uint32_t fcap = len / 3 + 1;         // room of one frame string incl. closing stop
-  uint32_t run_start[3], run_len[3];
-  NucReader nr{s, len, 0, 0xffffffffu};
-  // forward strand, ConsumerThread.cpp:196-233 (codon_to_int :869-871: any base that is not
-  // ACGTU makes the codon a stop): codon `count` belongs to frame count % 3
-#pragma unroll
-  for (int f = 0; f < 3; f++) { run_start[f] = base + (uint32_t)f * fcap; run_len[f] = 0; }
-  {
-    uint32_t a = t.nuc[nr.at(0)], bb = t.nuc[nr.at(1)];
-    uint32_t tpos = 0;                       // residue index of the current codons
-    for (uint32_t count = 0; count + 2 < len; count += 3, tpos++) {
-#pragma unroll
-      for (int f = 0; f < 3; f++) {
-        if (count + (uint32_t)f + 2 < len) {
-          const uint32_t c = t.nuc[nr.at(count + (uint32_t)f + 2)];
-          const uint32_t pos = base + (uint32_t)f * fcap + tpos;
-          const uint32_t aa = (a | bb | c) > 3u ? 255u : t.codon_aa[a * 16 + bb * 4 + c];
-          if (aa == 255u) {
-            pep.put(pos, 0);
-            emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-            run_start[f] = pos + 1; run_len[f] = 0;
-          } else { pep.put(pos, t.aa_to_idx[aa]); run_len[f]++; }
-          a = bb; bb = c;
-        }
-      }
-    }
+  const uint32_t top = len - 3, rbase = base + 3 * fcap;
+  // emission moments: forward stop at cnt -> cnt, closing runs -> len + f; then the reverse walk,
+  // stop visited at cnt -> (top - cnt), closing runs -> len + f
+  const uint32_t seqF = seq_base, seqR = seq_base + len + 3;
+  uint64_t dg0 = 0, dg1 = 0;                 // BLOSUM62 diagonal by index-alphabet code, 4 bits each
+  if (p.mode == 1) {
+    for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)t.diag_idx[x] & 15u) << (4 * x);
+    for (int x = 16; x < 32; x++) dg1 |= (uint64_t)((uint32_t)t.diag_idx[x] & 15u) << (4 * (x - 16));
   }
-#pragma unroll
-  for (int f = 0; f < 3; f++) {
-    emit_run(t, p, pep, list, n, cap, run_start[f], run_len[f]);
-    pep.put(run_start[f] + run_len[f], 0);
-  }
-  // reverse strand, :235-268: count runs len-3 .. 0, frame = count % 3, residues are appended
-  // in visiting order (the count = len-2 iteration of the reference only sees the string
-  // terminator on an empty frame and is a no-op); revcomp_codon_to_int :873-875.
-  // Step g of the unrolled loop works on frame (top - g) % 3: the state is kept per g.
-  const uint32_t rbase = base + 3 * fcap, top = len - 3, f0 = top % 3;
-  uint32_t wpos[3];                          // next write position of the frame string of step g
+  uint32_t F_start[3], F_len[3], F_sum[3], R_len[3], R_sum[3], R_pend[3], R0[3];
+  bool F_trig[3], R_trig[3];
+  TrigWin Fw[3], Rw[3];
 #pragma unroll
   for (int g = 0; g < 3; g++) {
-    const uint32_t f = (f0 + 3u - (uint32_t)g) % 3u;
-    run_start[g] = wpos[g] = rbase + f * fcap; run_len[g] = 0;
+    F_start[g] = base + (uint32_t)g * fcap; F_len[g] = F_sum[g] = 0; F_trig[g] = false; trig_reset(Fw[g]);
+    R_len[g] = R_sum[g] = 0; R_trig[g] = false; trig_reset(Rw[g]);
+    R_pend[g] = seqR + len + (uint32_t)g;    // the run at the end of the string is closed after the walk
+    R0[g] = (top - (uint32_t)g) / 3;         // string index of the reverse residue of position g (len >= 3m: top >= 2)
   }
-  {
-    uint32_t x = t.nuc[nr.at(len - 1)], y = t.nuc[nr.at(len - 2)];
-    for (int64_t cnt = (int64_t)top; cnt >= 0; cnt -= 3) {
+  NucReader nr{s, len, 0, 0xffffffffu};
+  uint32_t a = t.nuc[nr.at(0)], bb = t.nuc[nr.at(1)];
+  uint32_t q = 0;
+  for (uint32_t cnt = 0; cnt <= top; cnt += 3, q++) {
 #pragma unroll
-      for (int g = 0; g < 3; g++) {
-        if (cnt - g >= 0) {
-          const uint32_t z = t.nuc[nr.at((uint32_t)(cnt - g))];
-          const uint32_t pos = wpos[g]++;
-          const uint32_t aa = (x | y | z) > 3u ? 255u : t.codon_aa[(3 - x) * 16 + (3 - y) * 4 + (3 - z)];
-          if (aa == 255u) {
-            pep.put(pos, 0);
-            emit_run(t, p, pep, list, n, cap, run_start[g], run_len[g]);
-            run_start[g] = pos + 1; run_len[g] = 0;
-          } else { pep.put(pos, t.aa_to_idx[aa]); run_len[g]++; }
-          x = y; y = z;
+    for (int g = 0; g < 3; g++) {
+      if (cnt + (uint32_t)g <= top) {
+        const uint32_t c = t.nuc[nr.at(cnt + (uint32_t)g + 2)];
+        const bool bad = (a | bb | c) > 3u;
+        const uint32_t af = bad ? 0u : t.codon_idx[(a * 16 + bb * 4 + c) & 63u];
+        const uint32_t ar = bad ? 0u : t.codon_idx[(63u - (c * 16 + bb * 4 + a)) & 63u];
+        const uint32_t fpos = base + (uint32_t)g * fcap + q;
+        const uint32_t rpos = rbase + (uint32_t)g * fcap + (R0[g] - q);
+        pep.put(fpos, (uint8_t)af);
+        pep.put(rpos, (uint8_t)ar);
+        if (af == 0) {
+          emit_run(p, list, n, cap, F_start[g], F_len[g], F_sum[g], seqF + cnt + (uint32_t)g, F_trig[g]);
+          F_start[g] = fpos + 1; F_len[g] = F_sum[g] = 0; F_trig[g] = false; trig_reset(Fw[g]);
+        } else {
+          F_len[g]++;
+          if (p.mode == 1) F_sum[g] += (uint32_t)(((af & 16u) ? dg1 : dg0) >> (4u * (af & 15u))) & 15u;
+          if (p.seg && !F_trig[g]) F_trig[g] = trig_push(Fw[g], tc, af, F_len[g]);
         }
+        if (ar == 0) {
+          // the run behind this stop (string indices rpos+1 ..) is complete; the reference emits it
+          // when its walk reaches the stop in front of it, or after the walk
+          emit_run(p, list, n, cap, rpos + 1, R_len[g], R_sum[g], R_pend[g], R_trig[g]);
+          R_pend[g] = seqR + (top - (cnt + (uint32_t)g));
+          R_len[g] = R_sum[g] = 0; R_trig[g] = false; trig_reset(Rw[g]);
+        } else {
+          R_len[g]++;
+          if (p.mode == 1) R_sum[g] += (uint32_t)(((ar & 16u) ? dg1 : dg0) >> (4u * (ar & 15u))) & 15u;
+          if (p.seg && !R_trig[g]) R_trig[g] = trig_push(Rw[g], tc, ar, R_len[g]);
+        }
+        a = bb; bb = c;
       }
     }
   }
-  for (uint32_t f = 0; f < 3; f++) {         // the closing runs in frame order
-    const uint32_t g = (f0 + 3u - f) % 3u;
-    const uint32_t rs = g == 0 ? run_start[0] : g == 1 ? run_start[1] : run_start[2];
-    const uint32_t rl = g == 0 ? run_len[0] : g == 1 ? run_len[1] : run_len[2];
-    emit_run(t, p, pep, list, n, cap, rs, rl);
-    pep.put(rs + rl, 0);
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    const uint32_t nres = R0[g] + 1;         // codons of frame g
+    emit_run(p, list, n, cap, F_start[g], F_len[g], F_sum[g], seqF + len + (uint32_t)g, F_trig[g]);
+    pep.put(base + (uint32_t)g * fcap + nres, 0);
+    emit_run(p, list, n, cap, rbase + (uint32_t)g * fcap, R_len[g], R_sum[g], R_pend[g], R_trig[g]);
+    pep.put(rbase + (uint32_t)g * fcap + nres, 0);
   }
 }
 
@@ -763,9 +792,9 @@ struct FragAppend {
 };
 
 // stage 1 for read r: translation, fragment list in queue order, SEG trigger detection.
-// `stage` is the lane's staging area (LDS on the device) or nullptr (peptides are written
-// straight to their place: long reads, host emulation of that path).
-KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &cx, const Batch &b,
+// `stage` is the lane's staging area (LDS on the device, stage_words dwords) or nullptr (peptides
+// are written straight to their place: long reads, host emulation of that path).
+KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx &tc, const Batch &b,
                            const SegQueue &sq, uint32_t r, uint32_t *err_flags, uint8_t *stage, uint32_t stage_row,
                            uint32_t stage_words) {
   const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
@@ -780,15 +809,9 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
   // length gate, ConsumerThread.cpp:647-654
   const bool skip = b.paired ? (len1 < m3 && len2 < m3) : (len1 < m3);
   if (!skip) {
-    if (len1 >= m3) translate_mate(t, p, b.seqs + o0, len1, pep, 0, list, n, cap);
-    if (b.paired && len2 >= m3) translate_mate(t, p, b.seqs + o1, len2, pep, 6 * (len1 / 3 + 1), list, n, cap);
-    // SEG trigger detection on the fragments in emission order (the strings are still staged)
-    if (p.seg) {
-      for (uint32_t k = 0; k < n; k++) {
-        const Frag f = list[k];
-        list[k].flags = seg_triggers(cx, PepView{pep, f.start}, (int)f.len) ? 0u : kFragChecked;   // checked: SEG would report nothing
-      }
-    }
+    const uint32_t seq2 = 2 * len1 + 6, seq_end = seq2 + 2 * len2 + 6;
+    if (len1 >= m3) translate_mate(t, p, tc, b.seqs + o0, len1, 0, pep, 0, list, n, cap);
+    if (b.paired && len2 >= m3) translate_mate(t, p, tc, b.seqs + o1, len2, seq2, pep, 6 * (len1 / 3 + 1), list, n, cap);
     if (stage) {
       // copy the strings out with 16-byte stores (the area of a read is 16-byte aligned)
       const uint32_t used = 6 * (len1 / 3 + 1) + (b.paired ? 6 * (len2 / 3 + 1) : 0);
@@ -801,15 +824,30 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
       }
     }
     // queue order: std::multimap<unsigned, Fragment*, std::greater>::emplace puts a fragment behind
-    // every key >= its own, i.e. a stable sort by descending key of the emission order
-    if (stage && n <= stage_words / 2 && n <= 128) {
-      // rank by counting in the (now free) staging row: dword k = key << 7 | 127 - k, dword half+k = start, len
+    // every key >= its own: by descending key, equal keys in the order of emission
+    uint32_t sb = 1;
+    while ((1u << sb) <= seq_end) sb++;
+    const uint32_t kbound = 11u * ((len1 > len2 ? len1 : len2) / 3u + 1u);     // no key exceeds this
+    // bit 0 of the flags so far: some 12-window reaches the trigger entropy, i.e. SeqBufferSeg would
+    // report at least one region (s_SegSeq, blast_seg.c:2061): those fragments go to the SEG pass
+    auto final_flags = [&](uint32_t trig, uint32_t k) -> uint32_t {
+      if (!p.seg) return 0u;
+      if (!trig) return kFragChecked;                        // SEG would report nothing for this fragment
+      const uint32_t slot = append_slot(sq.count);
+      if (slot >= sq.cap) { if (err_flags) *err_flags |= 2u; return kFragChecked; }
+      SegWork wk; wk.read = r; wk.frag = k;
+      sq.items[slot] = wk;
+      pending = kNfragSegPending;
+      return (slot + 1) << kFragSlotShift;
+    };
+    if (stage && n <= stage_words / 2 && sb <= 20 && kbound < (1u << (31 - sb))) {
+      // rank by counting in the (now free) staging row:
+      // dword k = key << (sb+1) | (2^sb - 1 - seq) << 1 | trig, dword half+k = start << 16 | len
       uint32_t *row = reinterpret_cast<uint32_t *>(stage);
-      const uint32_t rw = stage_row / 4, half = stage_words / 2;
+      const uint32_t rw = stage_row / 4, half = stage_words / 2, smax = (1u << sb) - 1u;
       for (uint32_t k = 0; k < n; k++) {
         const Frag f = list[k];
-        const uint32_t key = f.key < (1u << 24) ? f.key : (1u << 24) - 1u;      // (keys are far below 2^24 here)
-        row[(size_t)k * rw] = (key << 7 | (127u - k)) << 1 | ((f.flags & kFragChecked) ? 1u : 0u);
+        row[(size_t)k * rw] = f.key << (sb + 1) | (smax - (f.flags >> 1)) << 1 | (f.flags & 1u);
         row[(size_t)(half + k) * rw] = f.start << 16 | f.len;
       }
       for (uint32_t k = 0; k < n; k++) {
@@ -817,29 +855,19 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const SegCtx &
         uint32_t rank = 0;
         for (uint32_t q = 0; q < n; q++) rank += row[(size_t)q * rw] > ck ? 1u : 0u;
         const uint32_t sl = row[(size_t)(half + k) * rw];
-        Frag f; f.start = sl >> 16; f.len = sl & 0xffffu; f.key = ck >> 8; f.flags = (ck & 1u) ? kFragChecked : 0u;
+        Frag f; f.start = sl >> 16; f.len = sl & 0xffffu; f.key = ck >> (sb + 1); f.flags = final_flags(ck & 1u, rank);
         list[rank] = f;
       }
     } else {
       for (uint32_t k = 1; k < n; k++) {                    // insertion sort in place (long reads)
         const Frag f = list[k];
         uint32_t pos = k;
-        while (pos > 0 && list[pos - 1].key < f.key) { list[pos] = list[pos - 1]; pos--; }
+        while (pos > 0 && (list[pos - 1].key < f.key || (list[pos - 1].key == f.key && list[pos - 1].flags > f.flags))) {
+          list[pos] = list[pos - 1]; pos--;
+        }
         list[pos] = f;
       }
-    }
-    // the flagged fragments go to the SEG pass
-    if (p.seg) {
-      for (uint32_t k = 0; k < n; k++) {
-        if (list[k].flags & kFragChecked) continue;
-        const uint32_t slot = append_slot(sq.count);
-        if (slot < sq.cap) {
-          SegWork wk; wk.read = r; wk.frag = k;
-          sq.items[slot] = wk;
-          list[k].flags = (slot + 1) << kFragSlotShift;
-          pending = kNfragSegPending;
-        } else { list[k].flags = kFragChecked; if (err_flags) *err_flags |= 2u; }
-      }
+      for (uint32_t k = 0; k < n; k++) list[k].flags = final_flags(list[k].flags & 1u, k);
     }
   }
   ReadMeta rm; rm.pep = pbase; rm.frag = (uint32_t)frag_base(b.off, r, p.m); rm.nfrag = n | pending;

@@ -98,7 +98,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   // peptides are staged (here: linear scratch) and copied out, as the kernel does with its LDS area
   std::vector<uint8_t> stage((size_t)4 * maxlen + 256);
   const bool staged = !getenv("KAIJU_EMU_NOSTAGE");
-  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, cx, b, sq, r, &err, staged ? stage.data() : nullptr, 4, (uint32_t)(stage.size() / 4));
+  for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq, r, &err, staged ? stage.data() : nullptr, 4, (uint32_t)(stage.size() / 4));
   if (p.seg) {
     int32_t segwork[4 * kSegMaxRegions];
     std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
