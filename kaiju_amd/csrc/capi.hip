@@ -48,9 +48,9 @@ __global__ void __launch_bounds__(kFragBlock)
 k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err,
             uint32_t stage_bytes) {
   __shared__ ConstTables s_ct;
-  __shared__ int32_t s_entg[13];
+  __shared__ int32_t s_entg[17];
   extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];
-  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g32[threadIdx.x];
+  if (threadIdx.x < 17) s_entg[threadIdx.x] = st.ent_g32[threadIdx.x];
   {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
     uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
@@ -201,6 +201,39 @@ k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue 
   greedy_lane2(ix, s_ct, p, sq, b, wl, gs);
 }
 
+// Index load: the k-mer table one letter deeper.  child[idx * 20 + c - 1] = UpdateSI(parent[idx], c)
+// (bwt.c:160-173) for all 20 letters from the two rank blocks at the ends of the parent's interval;
+// empty intervals stay {0, 0}.  One thread per parent, 160 contiguous bytes of children each.
+__global__ void __launch_bounds__(256)
+k_kmer_extend(const RankBlock64 *__restrict__ blk, const uint2 *__restrict__ parent, uint2 *__restrict__ child,
+              uint64_t n_parent) {
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < n_parent; idx += (uint64_t)gridDim.x * 256) {
+    const uint2 e = parent[idx];
+    uint32_t out[40];
+#pragma unroll
+    for (int x = 0; x < 40; x++) out[x] = 0;
+    if (e.y != 0) {
+      const uint32_t lo = e.x, hi = e.x + e.y;
+      const RankBlock64 &A = blk[lo >> 6], &B = blk[hi >> 6];
+      const uint64_t lowA = (1ull << (lo & 63u)) - 1ull, lowB = (1ull << (hi & 63u)) - 1ull;
+#pragma unroll
+      for (int c = 1; c <= 20; c++) {
+        uint64_t ma = lowA, mb = lowB;
+#pragma unroll
+        for (int bit = 0; bit < 5; bit++) {
+          ma &= ((c >> bit) & 1) ? A.plane[bit] : ~A.plane[bit];
+          mb &= ((c >> bit) & 1) ? B.plane[bit] : ~B.plane[bit];
+        }
+        const uint32_t ra = A.cnt[c - 1] + (uint32_t)__popcll(ma), rb = B.cnt[c - 1] + (uint32_t)__popcll(mb);
+        if (ra < rb) { out[2 * (c - 1)] = ra; out[2 * (c - 1) + 1] = rb - ra; }
+      }
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(child + idx * 20);
+#pragma unroll
+    for (int x = 0; x < 10; x++) dst[x] = make_uint4(out[4 * x], out[4 * x + 1], out[4 * x + 2], out[4 * x + 3]);
+  }
+}
+
 static_assert(sizeof(ConstTables) % 4 == 0, "ConstTables is copied as dwords");
 static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");
 
@@ -309,16 +342,44 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
   for (int a = 0; a < 22; a++) d.C[a] = pk.C[a];
   d.bwtlen = pk.bwtlen; d.n_sa = pk.n_sa; d.sa_skip = pk.sa_skip; d.nseq = pk.nseq; d.chpt_exp = pk.chpt_exp;
   d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k;
+  uint64_t kmer_bytes = 0;
   if (pk.kmer_k) {
     if (!pk.kmer32.empty()) { if ((rc = upload(ix.get(), pk.kmer32, &d.kmer32))) return rc; }
     else if ((rc = upload(ix.get(), pk.kmer64, &d.kmer64))) return rc;
+    // Deeper tables are grown on the device, one letter at a time.  Depth: KAIJU_GPU_KMER, or the
+    // largest k <= 7 whose table (20^k entries of 8 bytes) has at most 8 entries per index row -
+    // 10 GB for a viruses-size index, which is what 288 GB of HBM are for.
+    uint32_t want = pk.kmer_k;
+    if (const char *e = getenv("KAIJU_GPU_KMER")) want = (uint32_t)atoi(e);
+    else { uint64_t nn = 1; for (uint32_t q = 0; q < pk.kmer_k; q++) nn *= 20; while (want < 7 && nn * 20 <= 8 * pk.bwtlen) { nn *= 20; want++; } }
+    if (want > 7) want = 7;
+    if (d.kmer32 && d.blocks64 && want > d.kmer_k) {
+      uint64_t np = 1;
+      for (uint32_t q = 0; q < d.kmer_k; q++) np *= 20;
+      const uint2 *cur = d.kmer32;
+      void *cur_alloc = ix->allocs.back();
+      while (d.kmer_k < want) {
+        void *child = nullptr;
+        if (hipMalloc(&child, np * 20 * sizeof(uint2) + 64) != hipSuccess) { (void)hipGetLastError(); break; }   // keep the table we have
+        const uint64_t blocks = std::min<uint64_t>((np + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(k_kmer_extend, dim3((unsigned)blocks), dim3(256), 0, 0, d.blocks64, cur, static_cast<uint2 *>(child), np);
+        KJ_HIP(hipGetLastError());
+        KJ_HIP(hipDeviceSynchronize());
+        (void)hipFree(cur_alloc);
+        ix->allocs.back() = child;
+        cur_alloc = child; cur = static_cast<const uint2 *>(child);
+        np *= 20; d.kmer_k++;
+      }
+      d.kmer32 = cur;
+      kmer_bytes = np * sizeof(uint2) - pk.kmer32.size() * sizeof(uint2);
+    }
   }
   kaiju_gpu_index_info &inf = ix->info;
   memset(&inf, 0, sizeof inf);
   inf.bwtlen = (int64_t)pk.bwtlen; inf.nseq = (int32_t)pk.nseq; inf.alen = (int32_t)pk.alen;
   inf.chpt_exp = (int32_t)pk.chpt_exp;
   inf.db_length = (double)((int64_t)pk.bwtlen - (int64_t)pk.nseq);   // Config.cpp:20
-  inf.device_bytes = pk.bytes();
+  inf.device_bytes = pk.bytes() + kmer_bytes;
   inf.warnings = pk.warnings;
   snprintf(inf.alphabet, sizeof inf.alphabet, "%s", pk.alphabet.c_str());
   ix->names.swap(pk.names);
@@ -431,6 +492,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   c->kp.mode = p->mode; c->kp.m = p->min_fragment_length; c->kp.mismatches = p->mismatches;
   c->kp.min_score = p->min_score; c->kp.seed_length = p->seed_length; c->kp.seg = p->seg ? 1 : 0;
   c->kp.max_matches_SI = p->max_matches_SI; c->kp.max_match_ids = p->max_match_ids;
+  if (const char *e = getenv("KAIJU_GPU_DEBUG")) c->kp.debug = (uint32_t)atoi(e);
   KJ_HIP(hipSetDevice(ix->device));
   hipDeviceProp_t prop;
   KJ_HIP(hipGetDeviceProperties(&prop, ix->device));

@@ -247,8 +247,9 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     if (is < nseq && seq_valid[is]) sa_taxid[(size_t)q] = seq_taxid[is];
   }
   {
+    // the host builds at most 5 letters; the device grows the table further (capi.hip)
     uint32_t k = 5;
-    if (const char *e = getenv("KAIJU_GPU_KMER")) k = (uint32_t)atoi(e);
+    if (const char *e = getenv("KAIJU_GPU_KMER")) { k = (uint32_t)atoi(e); if (k > 5) k = 5; }
     build_kmer_table(k);
   }
   return 0;

@@ -138,7 +138,7 @@ int build_seg_tables(std::vector<double> &lnfact_host, SegTables &st, std::strin
   st.ent_locut = (int64_t)floor(scale * 2.2);
   st.ent_hicut = (int64_t)floor(scale * 2.5);
   const double scale32 = 67108864.0;          // 2^26: a window scores below 3.6 * 2^26 < 2^31
-  st.ent_g32[0] = 0;
+  memset(st.ent_g32, 0, sizeof st.ent_g32);
   for (int c = 1; c <= 12; c++) st.ent_g32[c] = (int32_t)llround(scale32 * ((double)c / 12.0) * log2(12.0 / (double)c));
   st.ent_locut32 = (int32_t)floor(scale32 * 2.2);
   int sv[16];

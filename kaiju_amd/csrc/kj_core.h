@@ -98,6 +98,7 @@ struct Params {
   uint32_t mismatches, min_score, seed_length;
   int32_t seg;
   uint32_t max_matches_SI, max_match_ids;
+  uint32_t debug = 0;        // developer timing experiments only (KAIJU_GPU_DEBUG): parts of stage 1 skipped, results wrong
 };
 
 // fragment descriptor (16 bytes)
@@ -144,7 +145,7 @@ struct SegTables {
   uint32_t lnfact_n;
   int64_t ent_g[13];         // fixed-point entropy contribution of a letter seen c times in a 12-window
   int64_t ent_locut, ent_hicut;   // thresholds in the same fixed-point scale
-  int32_t ent_g32[13];       // the same at a 32-bit scale: enough to decide H <= locut (stage 1's trigger test)
+  int32_t ent_g32[17];       // (13 used) the same at a 32-bit scale: enough to decide H <= locut (stage 1's trigger test)
   int32_t ent_locut32;
 };
 
@@ -585,18 +586,34 @@ KJ_HD void frag_insert(Frag *list, uint32_t &n, uint32_t cap, const Frag &f) {
   n++;
 }
 
-// nucleotide at position pos of a read, fetched four at a time
+// nucleotides of a read for a walk with ascending positions: 16 bytes at a time, the next 16 already
+// in flight (one lane reads one read: the loads of a wavefront touch 64 lines, better few and early)
 struct NucReader {
   const uint8_t *s;
-  uint32_t len, word, wq;
-  KJ_HD uint32_t at(uint32_t pos) {
-    const uint32_t q = pos >> 2;
-    if (q != wq) {
-      wq = q;
-      if (4 * q + 4 <= len) word = *reinterpret_cast<const u32_unaligned *>(s + 4 * q);
-      else { word = 0; for (uint32_t x = 4 * q; x < len; x++) word |= (uint32_t)s[x] << (8 * (x & 3u)); }
+  uint32_t len, wq;
+  u128 cur, nxt;
+  KJ_HD u128 chunk(uint32_t q) const {                    // bytes [16q, 16q+16) of the read, zeros behind its end
+    u128 v{0, 0};
+    if (16 * q + 16 <= len) v = *reinterpret_cast<const u128_unaligned *>(s + 16 * q);
+    else if (16 * q < len) {
+      if (len >= 16) {
+        // the last 16 bytes of the read, shifted down to where the chunk starts
+        v = *reinterpret_cast<const u128_unaligned *>(s + len - 16);
+        const uint32_t k = 16 * q + 16 - len;               // 1..15 bytes too far
+        if (k >= 8) { v.x = v.y >> (8 * (k - 8)); v.y = 0; }
+        else { v.x = (v.x >> (8 * k)) | (v.y << (64 - 8 * k)); v.y >>= 8 * k; }
+      } else for (uint32_t x = 16 * q; x < len; x++) {
+        if ((x & 15u) < 8) v.x |= (uint64_t)s[x] << (8 * (x & 7u)); else v.y |= (uint64_t)s[x] << (8 * (x & 7u));
+      }
     }
-    return (word >> (8 * (pos & 3u))) & 255u;
+    return v;
+  }
+  KJ_HD void open(const uint8_t *seq, uint32_t n) { s = seq; len = n; wq = 0; cur = chunk(0); nxt = chunk(1); }
+  KJ_HD uint32_t at(uint32_t pos) {
+    const uint32_t q = pos >> 4;
+    if (q != wq) { wq = q; cur = nxt; nxt = chunk(q + 1); }
+    const uint64_t w = (pos & 8u) ? cur.y : cur.x;
+    return (uint32_t)(w >> (8u * (pos & 7u))) & 255u;
   }
 };
 
@@ -636,7 +653,8 @@ KJ_HD void emit_run(const Params &p, Frag *list, uint32_t &n, uint32_t cap, uint
     if (f.key < p.min_score) return;
   } else f.key = len;
   if (n >= cap) return;               // cannot happen: cap is a proven bound
-  list[n++] = f;
+  if (!(p.debug & 1u)) list[n] = f;
+  n++;
 }
 
 // Translate one mate into its six frame strings at pep[base..] and append its fragments.  ONE pass
@@ -668,41 +686,95 @@ KJ_HD void translate_mate(const ConstTables &t, const Params &p, const TrigCtx &
     R_pend[g] = seqR + len + (uint32_t)g;    // the run at the end of the string is closed after the walk
     R0[g] = (top - (uint32_t)g) / 3;         // string index of the reverse residue of position g (len >= 3m: top >= 2)
   }
-  NucReader nr{s, len, 0, 0xffffffffu};
+  NucReader nr;
+  nr.open(s, len);
   uint32_t a = t.nuc[nr.at(0)], bb = t.nuc[nr.at(1)];
   uint32_t q = 0;
+  // Three positions (one per frame) per iteration, written in phases so that the table lookups of
+  // a phase are in flight together: nucleotide codes, the six codons, the entropy table entries of
+  // the six windows; only then the updates, and the (rare) stops last.
   for (uint32_t cnt = 0; cnt <= top; cnt += 3, q++) {
+    bool ok[3];
+    uint32_t cN[3];
 #pragma unroll
     for (int g = 0; g < 3; g++) {
-      if (cnt + (uint32_t)g <= top) {
-        const uint32_t c = t.nuc[nr.at(cnt + (uint32_t)g + 2)];
-        const bool bad = (a | bb | c) > 3u;
-        const uint32_t af = bad ? 0u : t.codon_idx[(a * 16 + bb * 4 + c) & 63u];
-        const uint32_t ar = bad ? 0u : t.codon_idx[(63u - (c * 16 + bb * 4 + a)) & 63u];
+      ok[g] = cnt + (uint32_t)g <= top;
+      cN[g] = (p.debug & 32u) ? ((cnt * 7u + (uint32_t)g * 3u) >> 2) & 3u
+                              : t.nuc[nr.at(cnt + (uint32_t)g + 2)];        // (positions past the end read as 0 bytes: not ACGTU)
+    }
+    const uint32_t n0[3] = {a, bb, cN[0]}, n1[3] = {bb, cN[0], cN[1]}, n2[3] = {cN[0], cN[1], cN[2]};
+    uint32_t aa[6];                                         // [g]: forward, [3+g]: reverse
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      const bool bad = (n0[g] | n1[g] | n2[g]) > 3u;
+      const uint32_t vf = t.codon_idx[(n0[g] * 16 + n1[g] * 4 + n2[g]) & 63u];
+      const uint32_t vr = t.codon_idx[(63u - (n2[g] * 16 + n1[g] * 4 + n0[g])) & 63u];
+      aa[g] = bad ? 0u : vf;
+      aa[3 + g] = bad ? 0u : vr;
+    }
+    a = cN[1]; bb = cN[2];
+    // entropy of the 12-windows: letter x joins, letter y (12 back) leaves once the run is longer than 12
+    int32_t dsc[6];
+    uint32_t xs[6], ys[6];
+    bool rem[6];
+    if (p.seg) {
+#pragma unroll
+      for (int h = 0; h < 6; h++) {
+        const TrigWin &w = h < 3 ? Fw[h] : Rw[h - 3];
+        const uint32_t rl = (h < 3 ? F_len[h] : R_len[h - 3]) + 1u;
+        const uint32_t x = (aa[h] - 1u) & 31u, y = (uint32_t)(w.hist >> 55) & 31u;
+        const uint32_t cx = (uint32_t)((x < 16u ? w.c0 : w.c1) >> (4u * (x & 15u))) & 15u;
+        const uint32_t cy = (uint32_t)((y < 16u ? w.c0 : w.c1) >> (4u * (y & 15u))) & 15u;
+        rem[h] = rl > (uint32_t)kSegWindow;
+        const int32_t dA = tc.g32[cx + 1u] - tc.g32[cx];
+        const int32_t dR = tc.g32[(cy - 1u) & 15u] - tc.g32[cy];
+        const bool same = rem[h] && x == y;                 // the same letter joins and leaves: nothing changes
+        dsc[h] = same ? 0 : dA + (rem[h] ? dR : 0);
+        xs[h] = x; ys[h] = y;
+        if (same) rem[h] = false;
+        if (same) xs[h] = 32u;                               // (32: no count changes)
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 6; h++) {
+      const int g = h % 3;
+      const bool fwd = h < 3;
+      uint32_t &rlen = fwd ? F_len[g] : R_len[g];
+      uint32_t &rsum = fwd ? F_sum[g] : R_sum[g];
+      bool &trig = fwd ? F_trig[g] : R_trig[g];
+      TrigWin &w = fwd ? Fw[g] : Rw[g];
+      const uint32_t fpos = base + (uint32_t)g * fcap + q, rpos = rbase + (uint32_t)g * fcap + (R0[g] - q);
+      const uint32_t pos = fwd ? fpos : rpos;
+      if (ok[g]) {
+        if (!(p.debug & 2u)) pep.put(pos, (uint8_t)aa[h]);
+        if (aa[h] != 0) {
+          rlen++;
+          if (p.mode == 1) rsum += (uint32_t)(((aa[h] & 16u) ? dg1 : dg0) >> (4u * (aa[h] & 15u))) & 15u;
+          if (p.seg) {
+            w.score += dsc[h];
+            if (xs[h] < 32u) { const uint64_t inc = 1ull << (4u * (xs[h] & 15u)); if (xs[h] < 16u) w.c0 += inc; else w.c1 += inc; }
+            if (rem[h]) { const uint64_t dec = 1ull << (4u * (ys[h] & 15u)); if (ys[h] < 16u) w.c0 -= dec; else w.c1 -= dec; }
+            w.hist = (w.hist << 5 | ((aa[h] - 1u) & 31u)) & ((1ull << 60) - 1ull);
+            trig = trig || (rlen >= (uint32_t)kSegWindow && w.score <= tc.locut32);
+          }
+        }
+      }
+    }
+    // stops close runs
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      if (ok[g] && aa[g] == 0) {
         const uint32_t fpos = base + (uint32_t)g * fcap + q;
+        emit_run(p, list, n, cap, F_start[g], F_len[g], F_sum[g], seqF + cnt + (uint32_t)g, F_trig[g]);
+        F_start[g] = fpos + 1; F_len[g] = F_sum[g] = 0; F_trig[g] = false; trig_reset(Fw[g]);
+      }
+      if (ok[g] && aa[3 + g] == 0) {
+        // the run behind this stop (string indices rpos+1 ..) is complete; the reference emits it
+        // when its walk reaches the stop in front of it, or after the walk
         const uint32_t rpos = rbase + (uint32_t)g * fcap + (R0[g] - q);
-        pep.put(fpos, (uint8_t)af);
-        pep.put(rpos, (uint8_t)ar);
-        if (af == 0) {
-          emit_run(p, list, n, cap, F_start[g], F_len[g], F_sum[g], seqF + cnt + (uint32_t)g, F_trig[g]);
-          F_start[g] = fpos + 1; F_len[g] = F_sum[g] = 0; F_trig[g] = false; trig_reset(Fw[g]);
-        } else {
-          F_len[g]++;
-          if (p.mode == 1) F_sum[g] += (uint32_t)(((af & 16u) ? dg1 : dg0) >> (4u * (af & 15u))) & 15u;
-          if (p.seg && !F_trig[g]) F_trig[g] = trig_push(Fw[g], tc, af, F_len[g]);
-        }
-        if (ar == 0) {
-          // the run behind this stop (string indices rpos+1 ..) is complete; the reference emits it
-          // when its walk reaches the stop in front of it, or after the walk
-          emit_run(p, list, n, cap, rpos + 1, R_len[g], R_sum[g], R_pend[g], R_trig[g]);
-          R_pend[g] = seqR + (top - (cnt + (uint32_t)g));
-          R_len[g] = R_sum[g] = 0; R_trig[g] = false; trig_reset(Rw[g]);
-        } else {
-          R_len[g]++;
-          if (p.mode == 1) R_sum[g] += (uint32_t)(((ar & 16u) ? dg1 : dg0) >> (4u * (ar & 15u))) & 15u;
-          if (p.seg && !R_trig[g]) R_trig[g] = trig_push(Rw[g], tc, ar, R_len[g]);
-        }
-        a = bb; bb = c;
+        emit_run(p, list, n, cap, rpos + 1, R_len[g], R_sum[g], R_pend[g], R_trig[g]);
+        R_pend[g] = seqR + (top - (cnt + (uint32_t)g));
+        R_len[g] = R_sum[g] = 0; R_trig[g] = false; trig_reset(Rw[g]);
       }
     }
   }
@@ -812,7 +884,7 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
     const uint32_t seq2 = 2 * len1 + 6, seq_end = seq2 + 2 * len2 + 6;
     if (len1 >= m3) translate_mate(t, p, tc, b.seqs + o0, len1, 0, pep, 0, list, n, cap);
     if (b.paired && len2 >= m3) translate_mate(t, p, tc, b.seqs + o1, len2, seq2, pep, 6 * (len1 / 3 + 1), list, n, cap);
-    if (stage) {
+    if (stage && !(p.debug & 8u)) {
       // copy the strings out with 16-byte stores (the area of a read is 16-byte aligned)
       const uint32_t used = 6 * (len1 / 3 + 1) + (b.paired ? 6 * (len2 / 3 + 1) : 0);
       u128 *dst = reinterpret_cast<u128 *>(b.pep + pbase);
@@ -823,6 +895,7 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
         dst[q] = v;
       }
     }
+    if (p.debug & 16u) n = 0;
     // queue order: std::multimap<unsigned, Fragment*, std::greater>::emplace puts a fragment behind
     // every key >= its own: by descending key, equal keys in the order of emission
     uint32_t sb = 1;
@@ -845,10 +918,18 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
       // dword k = key << (sb+1) | (2^sb - 1 - seq) << 1 | trig, dword half+k = start << 16 | len
       uint32_t *row = reinterpret_cast<uint32_t *>(stage);
       const uint32_t rw = stage_row / 4, half = stage_words / 2, smax = (1u << sb) - 1u;
-      for (uint32_t k = 0; k < n; k++) {
-        const Frag f = list[k];
-        row[(size_t)k * rw] = f.key << (sb + 1) | (smax - (f.flags >> 1)) << 1 | (f.flags & 1u);
-        row[(size_t)(half + k) * rw] = f.start << 16 | f.len;
+      for (uint32_t k0 = 0; k0 < n; k0 += 4) {               // four entries in flight at a time
+        Frag f[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) f[x] = list[k0 + (uint32_t)x < n ? k0 + (uint32_t)x : k0];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+          const uint32_t k = k0 + (uint32_t)x;
+          if (k < n) {
+            row[(size_t)k * rw] = f[x].key << (sb + 1) | (smax - (f[x].flags >> 1)) << 1 | (f[x].flags & 1u);
+            row[(size_t)(half + k) * rw] = f[x].start << 16 | f[x].len;
+          }
+        }
       }
       for (uint32_t k = 0; k < n; k++) {
         const uint32_t ck = row[(size_t)k * rw];
@@ -1199,6 +1280,12 @@ KJ_HD uint32_t kj_nwaves() { return 1; }
 KJ_HD uint32_t kj_fetch_chunk(uint32_t *counter, uint32_t n) { const uint32_t v = *counter; *counter += n; return v; }
 #endif
 
+#if defined(KJ_HIST) && !defined(__HIP_DEVICE_COMPILE__)
+extern unsigned long long kj_hist[8][64];
+#define KJ_HISTO(h, v) kj_hist[h][(v) < 63 ? (v) : 63]++
+#else
+#define KJ_HISTO(h, v)
+#endif
 KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
                      const LaneScratch &ls) {
   typedef uint32_t P;
@@ -1270,6 +1357,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     }
 
     // ---- (1) load phase: no branches between the loads and their first use ----
+    KJ_HISTO(5, kind);
+    if (kind == K_STEP) KJ_HISTO(4, (uint32_t)(j - i + 1));   // match length before this step
     const bool is_step = kind == K_STEP, is_lf = kind == K_LF1 || kind == K_LF2;
     const P posA = is_step ? lo : is_lf ? k : 0;
     const P posB = is_step ? hi : posA;
@@ -1499,13 +1588,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 // ----------------------------------------------------------------------------
 constexpr int kMaxMismatch = 8;
 
-// host-side workload histograms (tests/tools only): -DKJ_HIST
-#if defined(KJ_HIST) && !defined(__HIP_DEVICE_COMPILE__)
-extern unsigned long long kj_hist[8][64];
-#define KJ_HISTO(h, v) kj_hist[h][(v) < 63 ? (v) : 63]++
-#else
-#define KJ_HISTO(h, v)
-#endif
+// (host-side workload histograms, tests/tools only: -DKJ_HIST, see KJ_HISTO above)
 
 struct GItem {               // one queue entry: a fragment or a substitution variant (80 bytes)
   uint64_t si0, si1;         // resume interval (variants)
