@@ -372,7 +372,20 @@ KJ_HD double seg_window_prob_packed(const SegCtx &cx, const uint8_t *s, int l, i
   double ans1 = cx.lnf[20];
   double ans2 = kj_lnfact(cx, l);
   int nz = 0, rem = l;
-  for (int v = l; v >= 1 && rem > 0; v--) {       // descending count value
+  // the largest count: counts below 32 leave the top bit of their field free, so
+  // "some field >= t" is a carry test; bisect (values above it would only be skipped one by one)
+  int vtop = l;
+  if (l < 32) {
+    const uint64_t HI = 0x820820820820820ull;
+    int lo = 1, hi = l;                            // invariant: some count >= lo, none > hi
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      const uint64_t T = REP * (uint64_t)(32 - mid);
+      if (((c0 + T) | (c1 + T)) & HI) lo = mid; else hi = mid - 1;
+    }
+    vtop = lo;
+  }
+  for (int v = vtop; v >= 1 && rem > 0; v--) {    // descending count value
     const uint64_t V = REP * (uint64_t)v;
     const int n = zero_fields6(c0 ^ V) + zero_fields6(c1 ^ V);   // letters occurring exactly v times
     if (n) {
@@ -439,42 +452,62 @@ KJ_HD void seg_trim(const SegCtx &cx, const Coop &coop, const uint8_t *s, int le
   lend_out = lend; rend_out = rend;
 }
 
+// Entropy class of every 12-window of s[0..len), spread over the lanes of the team: bit 0: H <= locut
+// (the window triggers), bit 1: H <= hicut (the window extends a segment).  cls[t] is the window
+// starting at residue t.
+template <class Coop>
+KJ_HD void seg_classes(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len, uint8_t *cls) {
+  const int nwin = len - kSegWindow + 1;
+  for (int t = coop.lane(); t < nwin; t += coop.width()) {
+    SegWin w{0, 0, 0};
+    segwin_open(w, cx, s, t);
+    cls[t] = (uint8_t)((w.score <= cx.ent_locut ? 1 : 0) | (w.score <= cx.ent_hicut ? 2 : 0));
+  }
+}
+
 // One level of s_SegSeq (blast_seg.c:2027-2113) on s[0..len).  At the top level
 // (`TOP`) a trigger window lying left of its trimmed segment starts a second scan of
 // the left remainder, of which only the LAST segment survives (:2093-2097: the head of
 // the nested list is linked in, its tail is dropped); the nested scan therefore never
 // needs to recurse itself.  Segments are appended in creation order.
+// `cls` (optional): the classes of the windows of s as computed by seg_classes on the top-level
+// string, cls[0] being the window that starts at s[0].
 template <bool TOP, class Coop>
 KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len, int offset,
-                   int32_t *beg, int32_t *end, int n, int cap, bool &overflow) {
+                   int32_t *beg, int32_t *end, int n, int cap, bool &overflow, const uint8_t *cls) {
   if (len < kSegWindow) return n;
   const int first = kSegDown, last = len - kSegUp;
   int lowlim = first;
   SegWin w{0, 0, 0};
   int wi = -1000;                        // position the window w is centred at
   for (int i = first; i <= last; i++) {
-    if (wi + 1 == i) segwin_shift(w, cx, s, wi - first);
-    else if (wi != i) segwin_open(w, cx, s, i - first);
-    wi = i;
-    if (w.score > cx.ent_locut) continue;                 // H > locut: no trigger
-    // s_FindLow (:1810-1822): down from i to lowlim while H <= hicut
-    int loi = i;
-    {
-      SegWin b;
-      while (loi - 1 >= lowlim) {
-        segwin_open(b, cx, s, loi - 1 - first);
-        if (b.score > cx.ent_hicut) break;
-        loi--;
+    int loi = i, hii = i;
+    if (cls) {
+      if (!(cls[i - first] & 1)) continue;                  // H > locut: no trigger
+      while (loi - 1 >= lowlim && (cls[loi - 1 - first] & 2)) loi--;      // s_FindLow (:1810-1822)
+      while (hii + 1 <= last && (cls[hii + 1 - first] & 2)) hii++;        // s_FindHigh (:1833-1845)
+    } else {
+      if (wi + 1 == i) segwin_shift(w, cx, s, wi - first);
+      else if (wi != i) segwin_open(w, cx, s, i - first);
+      wi = i;
+      if (w.score > cx.ent_locut) continue;                 // H > locut: no trigger
+      // s_FindLow (:1810-1822): down from i to lowlim while H <= hicut
+      {
+        SegWin b;
+        while (loi - 1 >= lowlim) {
+          segwin_open(b, cx, s, loi - 1 - first);
+          if (b.score > cx.ent_hicut) break;
+          loi--;
+        }
       }
-    }
-    // s_FindHigh (:1833-1845): up from i to last while H <= hicut
-    int hii = i;
-    {
-      SegWin f = w;
-      while (hii + 1 <= last) {
-        segwin_shift(f, cx, s, hii - first);
-        if (f.score > cx.ent_hicut) break;
-        hii++;
+      // s_FindHigh (:1833-1845): up from i to last while H <= hicut
+      {
+        SegWin f = w;
+        while (hii + 1 <= last) {
+          segwin_shift(f, cx, s, hii - first);
+          if (f.score > cx.ent_hicut) break;
+          hii++;
+        }
       }
     }
     const int rawleft = loi - kSegDown, rawright = hii + kSegUp - 1;
@@ -487,7 +520,8 @@ KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len
         // its most recent segment, which is all that survives in the reference
         int32_t tb[1], te[1];
         bool ov = false;
-        const int k = seg_scan<false>(cx, coop, s + rawleft, leftend - rawleft, offset + rawleft, tb, te, 0, 1, ov);
+        const int k = seg_scan<false>(cx, coop, s + rawleft, leftend - rawleft, offset + rawleft, tb, te, 0, 1, ov,
+                                      cls ? cls + rawleft : nullptr);
         if (k > 0) {
           if (n < cap) { beg[n] = tb[0]; end[n] = te[0]; n++; } else overflow = true;
         }
@@ -507,11 +541,17 @@ KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len
 // SeqBufferSeg (blast_seg.c:2278-2332).  Writes the merged regions in ascending order.
 // `work` = 2 * kSegMaxRegions ints of scratch (LDS shared by the team on the device: every lane of
 // the team computes the same values, so one copy serves all and no registers are spent on it).
-template <class Coop>
+// `cls` (optional): len bytes shared by the team for the window classes; `team_sync` makes them
+// visible to all its lanes.
+template <class Coop, class Sync>
 KJ_HD int seg_regions(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len,
-                      int32_t *left, int32_t *right, bool &overflow, int32_t *work) {
+                      int32_t *left, int32_t *right, bool &overflow, int32_t *work, uint8_t *cls, Sync &&team_sync) {
   int32_t *b = work, *e = work + kSegMaxRegions;
-  const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, kSegMaxRegions, overflow);
+  if (cls && len >= kSegWindow) {
+    seg_classes(cx, coop, s, len, cls);
+    team_sync();
+  }
+  const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, kSegMaxRegions, overflow, cls);
   if (n == 0) return 0;
   // the reference's list is in reverse creation order; s_MergeSegs (:2122-2152, hilenmin 0)
   // walks it from the head and merges a node with its successor while they overlap
@@ -808,7 +848,7 @@ KJ_HD bool seg_triggers(const SegCtx &cx, const S &s, int len) {
 // fragment so that the scan does not go to device memory for every residue.
 template <class Coop, class Sync>
 KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const Params &p, const SegQueue &sq,
-                       uint32_t slot, uint8_t *stage, uint32_t stage_cap, int32_t *work, Sync &&team_sync) {
+                       uint32_t slot, uint8_t *stage, uint32_t stage_cap, int32_t *work, uint8_t *cls, Sync &&team_sync) {
   const SegWork wk = sq.items[slot];
   const ReadMeta rm = b.meta[wk.read];
   const Frag f = b.frags[rm.frag + wk.frag];
@@ -823,7 +863,8 @@ KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const
   // scratch of the team: [0, 2R) scan lists, [2R, 4R) merged regions (R = kSegMaxRegions)
   int32_t *left = work + 2 * kSegMaxRegions, *right = work + 3 * kSegMaxRegions;
   bool ov = false;
-  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov, work);
+  // (cls holds stage_cap bytes; the previous fragment's classes are no longer read: the syncs above)
+  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov, work, (stage && f.len <= stage_cap) ? cls : nullptr, team_sync);
   if (coop.lane() != 0) return;
   SegRec rec;
   rec.overflow = (ov || n > kSegRecRegions || f.len > 65535u) ? 1 : 0;

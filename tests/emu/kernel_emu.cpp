@@ -58,7 +58,9 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   bool ov = false;
   const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact);
   int32_t work[2 * kSegMaxRegions];
-  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov, work);
+  std::vector<uint8_t> cls((size_t)len + 1);
+  const bool use_cls = !getenv("KAIJU_EMU_SEG_NOCLS");
+  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov, work, use_cls ? cls.data() : nullptr, [] {});
   return ov ? -1 : n;
 }
 
@@ -102,8 +104,9 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   if (p.seg) {
     int32_t segwork[4 * kSegMaxRegions];
     std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
+    std::vector<uint8_t> segcls(64);
     for (uint32_t s = 0; s < seg_count && s < seg_cap; s++)
-      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), segwork, [] {});
+      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
     if (p.mode == 0) for (uint32_t r = 0; r < n; r++) seg_apply_mem(ix->ct, p, b, sq, r, &err);
   }
   if (frag_dump) {

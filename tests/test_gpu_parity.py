@@ -58,6 +58,26 @@ def test_golden_single(gpu_lib, golden, gidx, oracle, ohandles, mode, seg):
     assert not bad, bad[:3]
 
 
+@pytest.mark.parametrize("k", ["0", "3", "6", "7"])
+def test_kmer_table_depths(gpu_lib, golden, oracle, ohandles, k, monkeypatch):
+    """the k-mer table that starts every backward search: none, host-built, grown on the device to 6 and 7
+    letters (the depth a viruses-size index gets); records identical in all cases"""
+    api = gpu_lib
+    monkeypatch.setenv("KAIJU_GPU_KMER", k)
+    idx = api.Index(golden.fmi)
+    ix, tax = ohandles
+    for mode, seg in (("mem", 1), ("greedy", 1)):
+        clf = api.Classifier(idx, api.default_params(mode, seg=seg))
+        hits = clf.classify(golden.seqs, golden.off)
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), golden.seqs, golden.off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+        assert not bad, (k, mode, bad[:5])
+        hits = clf.classify(golden.pseqs, golden.poff, paired=True)
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), golden.pseqs, golden.poff, paired=True)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+        assert not bad, (k, mode, "paired", bad[:5])
+
+
 @pytest.mark.parametrize("mode,seg", CASES)
 def test_golden_paired(gpu_lib, golden, gidx, mode, seg):
     api = gpu_lib
