@@ -25,6 +25,7 @@
  *                               ids_from_SI :799-845 (everything up to, not including, lca_from_ids)
  *   kaiju_taxonomy_load         parseNodesDmp util.cpp:79-99
  *   kaiju_taxonomy_lca          lca_from_ids util.cpp:194-263
+ *   kaiju_gpu_lca_batch_device  the same on the device (kaiju_gpu_taxonomy_upload: the tree in HBM)
  *   kaiju_finalize_hits         E-value gate ConsumerThread.cpp:500-513, LCA call :538,:625 and the
  *                               C/U decision :724-739
  */
@@ -173,6 +174,27 @@ uint64_t kaiju_taxonomy_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n);
 /* E-value gate + LCA + C/U decision for a batch.  len1/len2 are the nucleotide
    lengths (query_len = len1/3.0 [+ len2/3.0], ConsumerThread.cpp:698,704); pass
    off as given to classify_batch.  db_length from kaiju_gpu_index_get_info. */
+/* ---- LCA on the device: 16-byte records instead of 184-byte ones ------- */
+/* (what crosses PCIe / xGMI when the matched ids themselves are not needed, i.e. without -v;
+   SURVEY.md 8f-3.  lca_from_ids util.cpp:194-263 on a device copy of the tree.) */
+typedef struct kaiju_gpu_taxonomy kaiju_gpu_taxonomy;
+typedef struct {
+  uint64_t lca;        /* LCA of the ids of the hit; 0 = no hit, or none of its ids is in nodes.dmp */
+  uint32_t best;       /* as kaiju_gpu_hit.best                                                    */
+  uint32_t info;       /* kaiju_gpu_hit.flags << 8 | n_ids                                         */
+} kaiju_gpu_compact;
+int kaiju_gpu_taxonomy_upload(const kaiju_taxonomy *t, int device_id, kaiju_gpu_taxonomy **out);
+void kaiju_gpu_taxonomy_free(kaiju_gpu_taxonomy *t);
+/* d_hits: n records written by kaiju_gpu_classify_batch_device; asynchronous on stream */
+int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *d_hits,
+                               uint32_t n_reads, kaiju_gpu_compact *d_out, void *stream);
+/* the same with host buffers (blocking) */
+int kaiju_gpu_lca_batch(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *hits,
+                        uint32_t n_reads, kaiju_gpu_compact *out);
+/* kaiju_finalize_hits for compact records (E-value gate, C/U decision; the LCA is already in them) */
+int kaiju_finalize_compact(const kaiju_gpu_params *p, double db_length, const kaiju_gpu_compact *recs,
+                           const uint64_t *off, uint32_t n_reads, int paired, kaiju_result *out);
+
 int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p, double db_length,
                         const kaiju_gpu_hit *hits, const uint64_t *off, uint32_t n_reads,
                         int paired, kaiju_result *out);

@@ -45,7 +45,8 @@ class Stats(C.Structure):
 HIT_DTYPE = np.dtype([("best", "<u4"), ("n_ids", "<u4"), ("flags", "<u4"), ("reserved", "<u4"),
                       ("taxid", "<u8", (MAX_IDS,))])
 RESULT_DTYPE = np.dtype([("taxon", "<u8"), ("best", "<u4"), ("classified", "u1"), ("pad", "u1", (3,))])
-assert HIT_DTYPE.itemsize == 184 and RESULT_DTYPE.itemsize == 16
+COMPACT_DTYPE = np.dtype([("lca", "<u8"), ("best", "<u4"), ("info", "<u4")])     # kaiju_gpu_compact
+assert HIT_DTYPE.itemsize == 184 and RESULT_DTYPE.itemsize == 16 and COMPACT_DTYPE.itemsize == 16
 
 
 class KaijuGpuError(RuntimeError):
@@ -84,6 +85,12 @@ def lib():
     L.kaiju_taxonomy_lca.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.kaiju_finalize_hits.argtypes = [C.c_void_p, C.POINTER(Params), C.c_double, C.c_void_p, C.c_void_p,
                                       C.c_uint32, C.c_int, C.c_void_p]
+    L.kaiju_gpu_taxonomy_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.kaiju_gpu_taxonomy_free.argtypes = [C.c_void_p]
+    L.kaiju_gpu_lca_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.kaiju_gpu_lca_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.kaiju_finalize_compact.argtypes = [C.POINTER(Params), C.c_double, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                         C.c_void_p]
     _lib = L
     return L
 
@@ -153,6 +160,25 @@ class Taxonomy:
             pass
 
 
+class DeviceTaxonomy:
+    """nodes.dmp in HBM for the LCA kernel (kaiju_gpu_taxonomy_upload)."""
+
+    def __init__(self, tax: Taxonomy, device: int = 0):
+        self._h = C.c_void_p()
+        _check(lib().kaiju_gpu_taxonomy_upload(tax._h, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().kaiju_gpu_taxonomy_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Classifier:
     """One classification stream on one GPU (the ConsumerThread of the reference)."""
 
@@ -198,6 +224,27 @@ class Classifier:
         res = np.zeros(n, dtype=RESULT_DTYPE)
         _check(lib().kaiju_finalize_hits(tax._h, C.byref(self.params), self.index.db_length, hits.ctypes.data,
                                          off.ctypes.data, n, 1 if paired else 0, res.ctypes.data))
+        return res
+
+    def lca_device(self, dtax: "DeviceTaxonomy", d_hits_ptr: int, n: int, d_out_ptr: int, stream: int = 0):
+        """hit records -> 16-byte compact records (LCA on the device); asynchronous on ``stream``."""
+        _check(lib().kaiju_gpu_lca_batch_device(self._h, dtax._h, d_hits_ptr, n, d_out_ptr, stream))
+
+    def lca(self, dtax: "DeviceTaxonomy", hits: np.ndarray) -> np.ndarray:
+        """host hit records -> compact records through the LCA kernel (blocking)"""
+        hits = np.ascontiguousarray(hits)
+        out = np.zeros(len(hits), dtype=COMPACT_DTYPE)
+        _check(lib().kaiju_gpu_lca_batch(self._h, dtax._h, hits.ctypes.data, len(hits), out.ctypes.data))
+        return out
+
+    def finalize_compact(self, recs: np.ndarray, off: np.ndarray, paired=False) -> np.ndarray:
+        """E-value gate + C/U decision for compact records (their LCA was computed on the device)."""
+        recs = np.ascontiguousarray(recs)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(recs)
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        _check(lib().kaiju_finalize_compact(C.byref(self.params), self.index.db_length, recs.ctypes.data,
+                                            off.ctypes.data, n, 1 if paired else 0, res.ctypes.data))
         return res
 
     def close(self):

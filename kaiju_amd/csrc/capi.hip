@@ -25,6 +25,7 @@
 #include "host_index.h"
 #include "host_tables.h"
 #include "kj_core.h"
+#include "taxonomy.h"
 
 using namespace kj;
 
@@ -704,6 +705,89 @@ extern "C" int kaiju_gpu_set_max_read_length(kaiju_gpu_ctx *ctx, uint32_t max_re
   if (!ctx || max_read_len == 0 || max_read_len > 0x3fffffffu) return fail(KAIJU_GPU_ERR_ARG, "bad max_read_len");
   ctx->max_read_len = max_read_len;
   return KAIJU_GPU_OK;
+}
+
+// ---- LCA on the device ---------------------------------------------------------------------------
+struct kaiju_gpu_taxonomy {
+  int device = 0;
+  DevTaxonomy dev{};
+  std::vector<void *> allocs;
+  ~kaiju_gpu_taxonomy() {
+    (void)hipSetDevice(device);
+    for (void *p : allocs) (void)hipFree(p);
+  }
+};
+
+__global__ void __launch_bounds__(256)
+k_lca(DevTaxonomy t, const Hit *__restrict__ hits, uint32_t n, CompactHit *__restrict__ out) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  out[r] = compact_hit(t, hits[r]);
+}
+
+extern "C" int kaiju_gpu_taxonomy_upload(const kaiju_taxonomy *t, int device_id, kaiju_gpu_taxonomy **out) {
+  if (!t || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(KAIJU_GPU_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+  if (device_id < 0 || device_id >= ndev) return fail(KAIJU_GPU_ERR_ARG, "device_id out of range");
+  std::vector<uint64_t> key, parent_id;
+  std::vector<uint32_t> parent_slot, depth;
+  kj_taxonomy_table(t, key, parent_id, parent_slot, depth);
+  std::unique_ptr<kaiju_gpu_taxonomy> g(new kaiju_gpu_taxonomy());
+  g->device = device_id;
+  KJ_HIP(hipSetDevice(device_id));
+  auto up = [&](const void *src, size_t bytes, const void **dst) -> int {
+    void *p = nullptr;
+    KJ_HIP(hipMalloc(&p, bytes + 16));
+    g->allocs.push_back(p);
+    KJ_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *dst = p;
+    return 0;
+  };
+  int rc;
+  if ((rc = up(key.data(), key.size() * 8, (const void **)&g->dev.key))) return rc;
+  if ((rc = up(parent_id.data(), parent_id.size() * 8, (const void **)&g->dev.parent_id))) return rc;
+  if ((rc = up(parent_slot.data(), parent_slot.size() * 4, (const void **)&g->dev.parent_slot))) return rc;
+  if ((rc = up(depth.data(), depth.size() * 4, (const void **)&g->dev.depth))) return rc;
+  g->dev.cap_mask = (uint32_t)(key.size() - 1);
+  *out = g.release();
+  return KAIJU_GPU_OK;
+}
+
+extern "C" void kaiju_gpu_taxonomy_free(kaiju_gpu_taxonomy *t) { delete t; }
+
+static_assert(sizeof(CompactHit) == sizeof(kaiju_gpu_compact) && sizeof(CompactHit) == 16, "compact record layout");
+
+extern "C" int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *d_hits,
+                                          uint32_t n_reads, kaiju_gpu_compact *d_out, void *stream) {
+  if (!ctx || !t || (!d_hits && n_reads) || (!d_out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (t->device != ctx->ix->device) return fail(KAIJU_GPU_ERR_ARG, "taxonomy lives on another device");
+  if (n_reads == 0) return KAIJU_GPU_OK;
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  hipLaunchKernelGGL(k_lca, dim3((n_reads + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), t->dev,
+                     reinterpret_cast<const Hit *>(d_hits), n_reads, reinterpret_cast<CompactHit *>(d_out));
+  KJ_HIP(hipGetLastError());
+  return KAIJU_GPU_OK;
+}
+
+// host buffers in and out (blocking): upload the hit records, k_lca, download the compact records
+extern "C" int kaiju_gpu_lca_batch(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *hits,
+                                   uint32_t n_reads, kaiju_gpu_compact *out) {
+  if (!ctx || !t || (!hits && n_reads) || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (n_reads == 0) return KAIJU_GPU_OK;
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  void *d_in = nullptr, *d_out = nullptr;
+  KJ_HIP(hipMalloc(&d_in, (size_t)n_reads * sizeof(kaiju_gpu_hit)));
+  if (hipMalloc(&d_out, (size_t)n_reads * sizeof(kaiju_gpu_compact)) != hipSuccess) { (void)hipFree(d_in); return fail(KAIJU_GPU_ERR_NOMEM, "hipMalloc"); }
+  int rc = KAIJU_GPU_OK;
+  if (hipMemcpy(d_in, hits, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyHostToDevice) != hipSuccess) rc = KAIJU_GPU_ERR_HIP;
+  if (rc == KAIJU_GPU_OK) rc = kaiju_gpu_lca_batch_device(ctx, t, static_cast<const kaiju_gpu_hit *>(d_in), n_reads,
+                                                          static_cast<kaiju_gpu_compact *>(d_out), nullptr);
+  if (rc == KAIJU_GPU_OK && hipMemcpy(out, d_out, (size_t)n_reads * sizeof(kaiju_gpu_compact), hipMemcpyDeviceToHost) != hipSuccess) rc = KAIJU_GPU_ERR_HIP;
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return rc == KAIJU_GPU_OK ? rc : fail(rc, "kaiju_gpu_lca_batch");
 }
 
 extern "C" int kaiju_gpu_synchronize(kaiju_gpu_ctx *ctx) {

@@ -2724,4 +2724,72 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   }
 }
 
+// ----------------------------------------------------------------------------
+// LCA on the device (lca_from_ids, util.cpp:194-263): the nodes.dmp tree as an open-addressing
+// hash table taxon id -> slot, per slot the parent's id and slot and the depth as the reference
+// computes it (1 + number of parent steps to a node that is its own parent or unknown).
+// ----------------------------------------------------------------------------
+struct DevTaxonomy {
+  const uint64_t *key;       // [cap] taxon id of the slot, ~0 = empty
+  const uint64_t *parent_id; // [cap]
+  const uint32_t *parent_slot; // [cap] slot of the parent, ~0 if the parent is not in the tree
+  const uint32_t *depth;     // [cap]
+  uint32_t cap_mask;         // cap - 1 (cap is a power of two)
+};
+struct CompactHit {          // == kaiju_gpu_compact (16 bytes)
+  uint64_t lca;              // LCA of the ids of the hit, 0: no hit / none of the ids is in the tree
+  uint32_t best;
+  uint32_t info;             // flags << 8 | n_ids
+};
+KJ_HD uint32_t tax_hash(uint64_t id) {
+  id ^= id >> 33; id *= 0xff51afd7ed558ccdULL; id ^= id >> 33; id *= 0xc4ceb9fe1a85ec53ULL; id ^= id >> 33;
+  return (uint32_t)id;
+}
+KJ_HD uint32_t tax_find(const DevTaxonomy &t, uint64_t id) {
+  uint32_t s = tax_hash(id) & t.cap_mask;
+  for (;;) {
+    const uint64_t k = t.key[s];
+    if (k == id) return s;
+    if (k == ~0ull) return ~0u;
+    s = (s + 1) & t.cap_mask;
+  }
+}
+KJ_HD uint64_t tax_lca(const DevTaxonomy &t, const uint64_t *ids, uint32_t n) {
+  if (n == 0) return 0;
+  if (n == 1) return ids[0];                                  // util.cpp:197-199 (no lookup at all)
+  uint64_t leaf[kMaxIds];
+  uint32_t slot[kMaxIds], dep[kMaxIds];
+  uint32_t m = 0, shallowest = 0xffffffffu;
+  for (uint32_t i = 0; i < n && i < (uint32_t)kMaxIds; i++) {
+    const uint32_t s = tax_find(t, ids[i]);
+    if (s == ~0u) continue;                                   // not in the tree: dropped (:206-210)
+    leaf[m] = ids[i]; slot[m] = s; dep[m] = t.depth[s];
+    if (dep[m] < shallowest) shallowest = dep[m];
+    m++;
+  }
+  if (m == 0) return 0;
+  // a node outside the tree is its own parent (it is never looked up again)
+  for (uint32_t i = 0; i < m; i++)
+    for (uint32_t d = dep[i]; d > shallowest; d--)
+      if (slot[i] != ~0u) { leaf[i] = t.parent_id[slot[i]]; slot[i] = t.parent_slot[slot[i]]; }
+  // lock-step climb (:245-262).  After `shallowest` + 1 steps every path has reached its end, so
+  // paths that have not met by then never will (the reference would loop forever; 0 here)
+  for (uint32_t step = 0; step <= shallowest + 1; step++) {
+    const uint64_t first = leaf[0];
+    bool same = true;
+    for (uint32_t i = 0; i < m; i++) {
+      if (leaf[i] != first) same = false;
+      if (slot[i] != ~0u) { leaf[i] = t.parent_id[slot[i]]; slot[i] = t.parent_slot[slot[i]]; }
+    }
+    if (same) return first;
+  }
+  return 0;
+}
+KJ_HD CompactHit compact_hit(const DevTaxonomy &t, const Hit &h) {
+  CompactHit c;
+  c.best = h.best; c.info = h.flags << 8 | (h.n_ids & 255u);
+  c.lca = (h.n_ids == 0 || h.best == 0) ? 0 : tax_lca(t, h.taxid, h.n_ids);
+  return c;
+}
+
 }  // namespace kj

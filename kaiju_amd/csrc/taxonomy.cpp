@@ -15,10 +15,7 @@
 
 #include "../../include/kaiju_gpu.h"
 
-struct kaiju_taxonomy {
-  struct Node { uint64_t parent; uint32_t depth; };
-  std::unordered_map<uint64_t, Node> nodes;
-};
+#include "taxonomy.h"
 
 extern "C" int kaiju_taxonomy_load(const char *path, kaiju_taxonomy **out) {
   if (!path || !out) return KAIJU_GPU_ERR_ARG;
@@ -127,6 +124,57 @@ extern "C" int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p,
     }
     const uint64_t lca = h.n_ids == 1 ? h.taxid[0] : kaiju_taxonomy_lca(t, h.taxid, h.n_ids);
     if (lca > 0) { o.taxon = lca; o.classified = 1; }
+  }
+  return KAIJU_GPU_OK;
+}
+
+
+// the tree as the open-addressing table of kj_core.h:DevTaxonomy (host arrays; capi.hip uploads them)
+void kj_taxonomy_table(const kaiju_taxonomy *t, std::vector<uint64_t> &key, std::vector<uint64_t> &parent_id,
+                       std::vector<uint32_t> &parent_slot, std::vector<uint32_t> &depth) {
+  size_t cap = 16;
+  while (cap < 2 * t->nodes.size() + 2) cap <<= 1;
+  key.assign(cap, ~0ull); parent_id.assign(cap, 0); parent_slot.assign(cap, ~0u); depth.assign(cap, 0);
+  const uint32_t mask = (uint32_t)(cap - 1);
+  auto hash = [](uint64_t id) {
+    id ^= id >> 33; id *= 0xff51afd7ed558ccdULL; id ^= id >> 33; id *= 0xc4ceb9fe1a85ec53ULL; id ^= id >> 33;
+    return (uint32_t)id;
+  };
+  auto find = [&](uint64_t id) -> uint32_t {
+    uint32_t s = hash(id) & mask;
+    while (key[s] != ~0ull && key[s] != id) s = (s + 1) & mask;
+    return s;
+  };
+  for (const auto &kv : t->nodes) {
+    const uint32_t s = find(kv.first);
+    key[s] = kv.first; parent_id[s] = kv.second.parent; depth[s] = kv.second.depth;
+  }
+  for (size_t s = 0; s < cap; s++) {
+    if (key[s] == ~0ull) continue;
+    const uint32_t ps = find(parent_id[s]);
+    parent_slot[s] = key[ps] == parent_id[s] ? ps : ~0u;
+  }
+}
+
+extern "C" int kaiju_finalize_compact(const kaiju_gpu_params *p, double db_length, const kaiju_gpu_compact *recs,
+                                      const uint64_t *off, uint32_t n_reads, int paired, kaiju_result *out) {
+  if (!p || !recs || !off || !out) return KAIJU_GPU_ERR_ARG;
+  const double LN_2 = 0.6931471805, LAMBDA = 0.3176, LN_K = -2.009915479;   // ConsumerThread.hpp:41-44
+  for (uint32_t r = 0; r < n_reads; r++) {
+    const kaiju_gpu_compact &h = recs[r];
+    kaiju_result &o = out[r];
+    o.taxon = 0; o.best = h.best; o.classified = 0; o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    if ((h.info & 255u) == 0 || h.best == 0) continue;
+    if (p->mode == 1 && p->use_evalue) {
+      const uint64_t len1 = off[2 * (uint64_t)r + 1] - off[2 * (uint64_t)r];
+      const uint64_t len2 = off[2 * (uint64_t)r + 2] - off[2 * (uint64_t)r + 1];
+      double query_len = static_cast<double>(len1) / 3.0;                    // :698
+      if (paired) query_len += static_cast<double>(len2) / 3.0;             // :704
+      const double bitscore = (LAMBDA * h.best - LN_K) / LN_2;
+      const double Evalue = db_length * query_len * pow(2, -1 * bitscore);
+      if (Evalue > p->min_evalue) continue;
+    }
+    if (h.lca > 0) { o.taxon = h.lca; o.classified = 1; }
   }
   return KAIJU_GPU_OK;
 }

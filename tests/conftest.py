@@ -4,6 +4,8 @@ import sys
 
 import pytest
 
+collect_ignore_glob = ["tools/*", "emu/*"]   # helper scripts, not tests
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))

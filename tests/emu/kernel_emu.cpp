@@ -190,6 +190,17 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
 
 }  // extern "C"
 
+// LCA of the device path on the host arrays of the table (tests/test_capi.py)
+#include "../../kaiju_amd/csrc/taxonomy.h"
+extern "C" uint64_t emu_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n) {
+  static kaiju_taxonomy *cached = nullptr;
+  static std::vector<uint64_t> key, parent_id;
+  static std::vector<uint32_t> parent_slot, depth;
+  if (cached != t) { kj_taxonomy_table(t, key, parent_id, parent_slot, depth); cached = t; }
+  DevTaxonomy d{key.data(), parent_id.data(), parent_slot.data(), depth.data(), (uint32_t)(key.size() - 1)};
+  return tax_lca(d, ids, n);
+}
+
 #ifdef KJ_HIST
 namespace kj { unsigned long long kj_hist[8][64]; }
 extern "C" const unsigned long long *emu_hist() { return &kj::kj_hist[0][0]; }

@@ -87,3 +87,33 @@ def test_taxonomy_depth_rules(tmp_path):
     assert tax.lca([11, 12]) == 10
     assert tax.lca([3, 424242]) == 3          # ids missing from the tree are dropped
     assert tax.lca([424242, 434343]) == 0
+
+
+def test_device_lca_logic_matches_host_lca(tmp_path):
+    """tax_lca of kj_core.h (what k_lca runs) on the hash-table form of the tree == kaiju_taxonomy_lca, including ids
+    outside the tree, nodes below an unknown parent and separate roots"""
+    import ctypes as C
+    import util
+    from kaiju_amd import api
+    emu = util.Emu()
+    emu.lib.emu_lca.restype = C.c_uint64
+    emu.lib.emu_lca.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    rng = np.random.default_rng(5)
+    # a forest: root 1 with a random tree, a second root 5000, a node whose parent is missing
+    lines = ["1\t|\t1\t|\tno rank\t|\n", "5000\t|\t5000\t|\tno rank\t|\n", "6000\t|\t777777\t|\tspecies\t|\n",
+             "6001\t|\t6000\t|\tspecies\t|\n"]
+    for i in range(2, 3000):
+        lines.append(f"{i}\t|\t{int(rng.integers(1, i))}\t|\tclade\t|\n")
+    for i in range(5001, 5050):
+        lines.append(f"{i}\t|\t{int(rng.integers(5000, i))}\t|\tclade\t|\n")
+    path = tmp_path / "nodes.dmp"
+    path.write_text("".join(lines))
+    tax = api.Taxonomy(str(path))
+    pool = list(range(1, 3000)) + list(range(5000, 5050)) + [6000, 6001, 777777, 424242]
+    for case in range(20000):
+        n = int(rng.integers(1, 22))
+        if case % 3 == 0:
+            ids = rng.integers(1, 3000, n).astype(np.uint64)       # one tree
+        else:
+            ids = rng.choice(pool, n).astype(np.uint64)
+        assert tax.lca(ids) == emu.lib.emu_lca(tax._h, ids.ctypes.data, n), ids

@@ -58,6 +58,26 @@ def test_golden_single(gpu_lib, golden, gidx, oracle, ohandles, mode, seg):
     assert not bad, bad[:3]
 
 
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
+    """k_lca: hit records -> 16-byte records on the device; finalize_compact == finalize_hits == reference lines"""
+    api = gpu_lib
+    tax = api.Taxonomy(golden.nodes)
+    dtax = api.DeviceTaxonomy(tax, 0)
+    clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
+    for seqs, off, names, pe, tsv in ((golden.seqs, golden.off, golden.names, False, f"ref_{mode}_{seg}.tsv"),
+                                      (golden.pseqs, golden.poff, golden.pnames, True, f"ref_{mode}_{seg}_pe.tsv")):
+        hits = clf.classify(seqs, off, paired=pe)
+        recs = clf.lca(dtax, hits)
+        a = clf.finalize(tax, hits, off, pe)
+        b = clf.finalize_compact(recs, off, pe)
+        assert (a == b).all()
+        assert (recs["best"] == hits["best"]).all() and ((recs["info"] & 255) == hits["n_ids"]).all()
+        ref = golden.tsv(tsv)
+        for n, r in zip(names, b):
+            assert (ref[n][0] == "C") == bool(r["classified"]) and (not r["classified"] or int(r["taxon"]) == ref[n][1]), n
+
+
 @pytest.mark.parametrize("k", ["0", "3", "6", "7"])
 def test_kmer_table_depths(gpu_lib, golden, oracle, ohandles, k, monkeypatch):
     """the k-mer table that starts every backward search: none, host-built, grown on the device to 6 and 7
