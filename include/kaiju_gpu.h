@@ -188,7 +188,10 @@ void kaiju_gpu_taxonomy_free(kaiju_gpu_taxonomy *t);
 /* d_hits: n records written by kaiju_gpu_classify_batch_device; asynchronous on stream */
 int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *d_hits,
                                uint32_t n_reads, kaiju_gpu_compact *d_out, void *stream);
-/* the same with host buffers (blocking) */
+/* kaiju_gpu_classify_batch followed by the LCA on the device: host buffers in, 16-byte records out */
+int kaiju_gpu_classify_batch_compact(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const char *seqs,
+                                     const uint64_t *off, uint32_t n_reads, int paired, kaiju_gpu_compact *out);
+/* LCA of host hit records through the device (blocking) */
 int kaiju_gpu_lca_batch(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *hits,
                         uint32_t n_reads, kaiju_gpu_compact *out);
 /* kaiju_finalize_hits for compact records (E-value gate, C/U decision; the LCA is already in them) */

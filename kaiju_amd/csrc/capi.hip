@@ -435,7 +435,7 @@ struct kaiju_gpu_ctx {
   bool ev_valid = false;
   int n_cu = 0, blocks_main = 0, blocks_retry = 0;
   DevBuf pep, frags, meta, counters, retry_list, seg_items, seg_recs;
-  DevBuf scratch_main[10], scratch_retry[5];
+  DevBuf scratch_main[10], scratch_retry[5], h_compact;
   bool greedy2 = false;
   uint32_t greedy_gate = 3;
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
@@ -445,7 +445,7 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits};
+    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 10; i++) if (scratch_main[i].p) (void)hipFree(scratch_main[i].p);
     for (int i = 0; i < 5; i++) if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p);
@@ -671,10 +671,8 @@ extern "C" int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d
   return launch_batch(ctx, d_seqs, seq_bytes, d_off, n_reads, paired, ctx->max_read_len, d_out, s);
 }
 
-extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off,
-                                        uint32_t n_reads, int paired, kaiju_gpu_hit *out) {
-  if (!ctx || !off || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
-  if (n_reads == 0) return KAIJU_GPU_OK;
+// host buffers -> device, kernels queued on the context's stream; the hit records stay in ctx->h_hits
+static int classify_host_buffers(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads, int paired) {
   KJ_HIP(hipSetDevice(ctx->ix->device));
   if (off[0] != 0) return fail(KAIJU_GPU_ERR_ARG, "off[0] must be 0");
   const uint64_t seq_bytes = off[2 * (uint64_t)n_reads];
@@ -693,9 +691,17 @@ extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, co
   hipStream_t s = ctx->stream;
   if (seq_bytes) KJ_HIP(hipMemcpyAsync(ctx->h_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, s));
   KJ_HIP(hipMemcpyAsync(ctx->h_off.p, off, (2 * (size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-  rc = launch_batch(ctx, ctx->h_seqs.p, seq_bytes, static_cast<const uint64_t *>(ctx->h_off.p), n_reads, paired,
-                    max_len ? max_len : 1, static_cast<kaiju_gpu_hit *>(ctx->h_hits.p), s);
+  return launch_batch(ctx, ctx->h_seqs.p, seq_bytes, static_cast<const uint64_t *>(ctx->h_off.p), n_reads, paired,
+                      max_len ? max_len : 1, static_cast<kaiju_gpu_hit *>(ctx->h_hits.p), s);
+}
+
+extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off,
+                                        uint32_t n_reads, int paired, kaiju_gpu_hit *out) {
+  if (!ctx || !off || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (n_reads == 0) return KAIJU_GPU_OK;
+  const int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
   if (rc) return rc;
+  hipStream_t s = ctx->stream;
   KJ_HIP(hipMemcpyAsync(out, ctx->h_hits.p, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyDeviceToHost, s));
   KJ_HIP(hipStreamSynchronize(s));
   return KAIJU_GPU_OK;
@@ -769,6 +775,24 @@ extern "C" int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_ta
   hipLaunchKernelGGL(k_lca, dim3((n_reads + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), t->dev,
                      reinterpret_cast<const Hit *>(d_hits), n_reads, reinterpret_cast<CompactHit *>(d_out));
   KJ_HIP(hipGetLastError());
+  return KAIJU_GPU_OK;
+}
+
+// classify host buffers and return 16-byte records only (the 184-byte hit records never leave the device)
+extern "C" int kaiju_gpu_classify_batch_compact(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const char *seqs,
+                                                const uint64_t *off, uint32_t n_reads, int paired, kaiju_gpu_compact *out) {
+  if (!ctx || !t || !off || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (t->device != ctx->ix->device) return fail(KAIJU_GPU_ERR_ARG, "taxonomy lives on another device");
+  if (n_reads == 0) return KAIJU_GPU_OK;
+  int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
+  if (rc) return rc;
+  if ((rc = ensure(ctx->h_compact, (size_t)n_reads * sizeof(kaiju_gpu_compact)))) return rc;
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k_lca, dim3((n_reads + 255) / 256), dim3(256), 0, s, t->dev,
+                     static_cast<const Hit *>(ctx->h_hits.p), n_reads, static_cast<CompactHit *>(ctx->h_compact.p));
+  KJ_HIP(hipGetLastError());
+  KJ_HIP(hipMemcpyAsync(out, ctx->h_compact.p, (size_t)n_reads * sizeof(kaiju_gpu_compact), hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipStreamSynchronize(s));
   return KAIJU_GPU_OK;
 }
 

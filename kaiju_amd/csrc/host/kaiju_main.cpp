@@ -4,14 +4,20 @@
 // (/root/reference/src/kaiju.cpp:52-452): FASTA/FASTQ (optionally gzip) single or paired input,
 // names cut at the first of " /\t\r", sequences strip()'d of non-letters, one output line per
 // read  "C\tname\ttaxon" / "U\tname\t0"  in input order (the reference's -z 1 order).  What
-// differs is the mechanics: reads are parsed in blocks into the batch layout of the C-ABI by a
-// producer thread and classified on the GPU batch-wise, instead of one ReadItem per mutex hand-off
-// (kaiju.cpp:288-394, ProducerConsumerQueue.tpp:38-84).
+// differs is the mechanics: instead of one ReadItem per mutex hand-off
+// (kaiju.cpp:288-394, ProducerConsumerQueue.tpp:38-84) the input is cut into blocks of whole
+// records by one reader thread per file (gzip or plain), the blocks are parsed in parallel into the
+// batch layout of the C-ABI, classified on the GPU batch-wise by two contexts that ping-pong (copies
+// of one batch overlap with the kernels of the other), and formatted in parallel; a writer puts
+// the text out in input order.  Without -v only 16-byte records (LCA computed on the device) come
+// back from the GPU.
 //
 // -v prints columns 4 (match length / score) and 5 (matching taxon ids); the accession and
 // peptide columns of the reference's verbose mode are not produced yet.  -p (protein input)
 // is not supported.
 #include <getopt.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -26,6 +32,8 @@
 #include <thread>
 #include <vector>
 #include <algorithm>
+#include <atomic>
+#include <map>
 
 #include "../../../include/kaiju_gpu.h"
 
@@ -65,111 +73,258 @@ std::string now() {
   return buf;
 }
 
-// line reader over zlib (reads plain files transparently)
-struct LineReader {
-  gzFile fp = nullptr;
-  std::vector<char> buf;
-  size_t pos = 0, len = 0;
-  bool eof = false;
-  explicit LineReader(const std::string &path) : buf(1 << 22) {
-    fp = gzopen(path.c_str(), "rb");
-    if (fp) gzbuffer(fp, 1 << 20);
-  }
-  ~LineReader() { if (fp) gzclose(fp); }
-  bool fill() {
-    if (eof) return false;
-    const int n = gzread(fp, buf.data(), (unsigned)buf.size());
-    if (n <= 0) { eof = true; len = pos = 0; return false; }
-    len = (size_t)n; pos = 0;
-    return true;
-  }
-  int peek() {
-    if (pos >= len && !fill()) return EOF;
-    return (unsigned char)buf[pos];
-  }
-  // std::getline semantics: false only if nothing could be read
-  bool getline(std::string &line) {
-    line.clear();
-    bool any = false;
-    for (;;) {
-      if (pos >= len && !fill()) return any;
-      any = true;
-      const char *p = buf.data() + pos;
-      const char *nl = (const char *)memchr(p, '\n', len - pos);
-      if (nl) { line.append(p, (size_t)(nl - p)); pos = (size_t)(nl - buf.data()) + 1; return true; }
-      line.append(p, len - pos);
-      pos = len;
-    }
-  }
-  void skipline() { std::string tmp; getline(tmp); }
+// ---------------------------------------------------------------------------------------------
+// stage 1: a reader thread per input file cuts the (decompressed) text into blocks of whole records
+// ---------------------------------------------------------------------------------------------
+struct RawBlock {
+  const char *text = nullptr;  // whole records (a last line may lack its '\n')
+  size_t size = 0;
+  std::vector<char> own;       // backing store unless the file is memory-mapped
+  uint32_t n_records = 0;
+  bool fastq = false;
 };
 
+// Hands out blocks of `want` whole records.  Plain files are memory-mapped (blocks point into the
+// mapping), gzip files are inflated through zlib into a growing buffer.  Record boundaries as the
+// reference finds them (kaiju.cpp:288-331): empty lines before a header are skipped; FASTQ = header +
+// 3 lines; FASTA = header + every line up to the next one starting with '>'.
+struct BlockReader {
+  std::string path;
+  bool ok = false, mapped = false;
+  // mapped
+  const char *map = nullptr;
+  size_t map_size = 0;
+  // streamed
+  gzFile fp = nullptr;
+  std::vector<char> buf;
+  // common view of the text not yet handed out: [data + pos, data + size)
+  const char *data = nullptr;
+  size_t size = 0, pos = 0;
+  bool eof = false, first = true, fastq = false;
+  static constexpr size_t NEED_MORE = ~(size_t)0, NONE = ~(size_t)0 - 1;
+
+  explicit BlockReader(const std::string &p) : path(p) {
+    unsigned char magic[2] = {0, 0};
+    FILE *f = fopen(p.c_str(), "rb");
+    if (!f) return;
+    const size_t got = fread(magic, 1, 2, f);
+    const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    struct stat st;
+    const bool regular = fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode);
+    if (!gz && regular && st.st_size > 0) {
+      void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+      if (m != MAP_FAILED) {
+        madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        map = static_cast<const char *>(m); map_size = (size_t)st.st_size;
+        mapped = true; data = map; size = map_size; eof = true; ok = true;
+      }
+    }
+    fclose(f);
+    if (!mapped) {
+      fp = gzopen(p.c_str(), "rb");
+      if (fp) { gzbuffer(fp, 1 << 20); ok = true; }
+    }
+  }
+  ~BlockReader() {
+    if (fp) gzclose(fp);
+    // (a mapping stays until the process ends: blocks still point into it)
+  }
+  bool more() {                // streamed files: append more text; false at end of file
+    if (eof) return false;
+    if (pos > 0) { buf.erase(buf.begin(), buf.begin() + (long)pos); pos = 0; }
+    const size_t old = buf.size(), chunk = 1 << 24;
+    buf.resize(old + chunk);
+    const int n = gzread(fp, buf.data() + old, (unsigned)chunk);
+    buf.resize(old + (size_t)(n > 0 ? n : 0));
+    if (n <= 0) eof = true;
+    data = buf.data(); size = buf.size();
+    return n > 0;
+  }
+  // one past the '\n' of the line starting at p; at end of file a last line without '\n' ends at size
+  size_t line_end(size_t p) const {
+    if (p >= size) return NEED_MORE;
+    const void *nl = memchr(data + p, '\n', size - p);
+    if (nl) return (size_t)((const char *)nl - data) + 1;
+    return eof ? size : NEED_MORE;
+  }
+  // end of the record that starts at the first non-empty line at or after p
+  size_t record_end(size_t p) {
+    size_t q = p, e;
+    for (;;) {
+      if (q >= size) return eof ? NONE : NEED_MORE;
+      e = line_end(q);
+      if (e == NEED_MORE) return NEED_MORE;
+      if (e - q == 1 && data[q] == '\n') { q = e; continue; }      // getline gave an empty line
+      break;
+    }
+    if (first) {
+      if (data[q] == '@') fastq = true;
+      else if (data[q] != '>') die("Auto-detection of file type for file " + path + " failed.");
+      first = false;
+    }
+    size_t r = e;
+    if (fastq) {
+      for (int lines = 0; lines < 3; lines++) {
+        if (r >= size) { if (eof) break; return NEED_MORE; }      // fewer lines at the end of the file are fine
+        const size_t e2 = line_end(r);
+        if (e2 == NEED_MORE) return NEED_MORE;
+        r = e2;
+      }
+      return r;
+    }
+    for (;;) {
+      if (r >= size) return eof ? r : NEED_MORE;
+      if (data[r] == '>') return r;
+      const size_t e2 = line_end(r);
+      if (e2 == NEED_MORE) return NEED_MORE;
+      r = e2;
+    }
+  }
+  // false when the file is exhausted and nothing was produced
+  bool next(RawBlock &out, uint32_t want) {
+    out.n_records = 0; out.own.clear();
+    size_t p = pos;
+    while (out.n_records < want) {
+      const size_t e = record_end(p);
+      if (e == NEED_MORE) {
+        const size_t keep = p - pos;
+        more();                               // (at end of file this only sets eof: the record is rescanned)
+        p = pos + keep;
+        continue;
+      }
+      if (e == NONE) { p = size; break; }     // nothing but empty lines left
+      p = e; out.n_records++;
+    }
+    if (out.n_records == 0) { pos = p; return false; }
+    if (mapped) { out.text = data + pos; out.size = p - pos; }
+    else { out.own.assign(data + pos, data + p); out.text = out.own.data(); out.size = out.own.size(); }
+    out.fastq = fastq;
+    pos = p;
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// stage 2: parse blocks into the batch layout (parallel)
+// ---------------------------------------------------------------------------------------------
 struct Batch {
   std::vector<char> seqs;
   std::vector<uint64_t> off{0};
-  std::vector<std::string> names;
-  bool last = false;
-  size_t n() const { return names.size(); }
+  std::vector<char> names;                 // concatenated
+  std::vector<uint32_t> name_off{0};
+  size_t n() const { return name_off.size() - 1; }
+  // results
+  std::vector<kaiju_gpu_hit> hits;         // -v only
+  std::vector<kaiju_gpu_compact> compact;
+  std::string text;
 };
 
-inline void append_stripped(std::vector<char> &dst, const std::string &s) {   // strip(), util.cpp:25-32
-  for (char c : s) if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) dst.push_back(c);
+inline void append_stripped(std::vector<char> &dst, const char *s, size_t n) {   // strip(), util.cpp:25-32
+  const size_t old = dst.size();
+  dst.resize(old + n);
+  char *d = dst.data() + old;
+  size_t k = 0;
+  for (size_t i = 0; i < n; i++) { const char c = s[i]; if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) d[k++] = c; }
+  dst.resize(old + k);
 }
 
-// one record of one file, kaiju.cpp:288-331 / :333-386.  Returns false at end of file.
-struct RecordReader {
-  LineReader in;
-  std::string path, line;
-  bool first = true, fastq = false;
-  explicit RecordReader(const std::string &p) : in(p), path(p) {}
-  bool next(std::string &name, std::vector<char> &dst) {
-    do { if (!in.getline(line)) return false; } while (line.empty());
-    if (first) {
-      if (line[0] == '@') fastq = true;
-      else if (line[0] != '>') die("Auto-detection of file type for file " + path + " failed.");
-      first = false;
-    }
-    line.erase(0, 1);
-    const size_t cut = line.find_first_of(" /\t\r");
-    if (cut != std::string::npos) line.erase(cut);
-    name = line;
-    if (fastq) {
-      in.getline(line);
-      append_stripped(dst, line);
-      in.skipline();
-      in.skipline();
+// walks the records of a block exactly like the reference's loop (kaiju.cpp:288-331 / :333-386)
+struct BlockCursor {
+  const RawBlock &b;
+  size_t p = 0;
+  explicit BlockCursor(const RawBlock &blk) : b(blk) {}
+  bool line(const char *&s, size_t &n) {   // next line without its '\n'
+    if (p >= b.size) return false;
+    const char *base = b.text;
+    const void *nl = memchr(base + p, '\n', b.size - p);
+    const size_t e = nl ? (size_t)((const char *)nl - base) : b.size;
+    s = base + p; n = e - p; p = e + 1;
+    return true;
+  }
+  // name (cut at the first of " /\t\r") and stripped sequence of the next record
+  bool next(const char *&name, size_t &name_len, std::vector<char> &seqs) {
+    const char *s; size_t n;
+    do { if (!line(s, n)) return false; } while (n == 0);
+    s++; n--;                               // erase(0,1)
+    size_t cut = 0;
+    while (cut < n && s[cut] != ' ' && s[cut] != '/' && s[cut] != '\t' && s[cut] != '\r') cut++;
+    name = s; name_len = cut;
+    if (b.fastq) {
+      if (line(s, n)) append_stripped(seqs, s, n);
+      line(s, n); line(s, n);
     } else {
-      for (;;) {
-        const int c = in.peek();
-        if (c == '>' || c == EOF) break;
-        in.getline(line);
-        append_stripped(dst, line);
-      }
+      while (p < b.size && b.text[p] != '>') { line(s, n); append_stripped(seqs, s, n); }
     }
     return true;
   }
 };
 
-struct Queue {
-  std::mutex m;
-  std::condition_variable cv_full, cv_empty;
-  std::deque<std::unique_ptr<Batch>> q;
-  size_t cap = 3;
-  void push(std::unique_ptr<Batch> b) {
-    std::unique_lock<std::mutex> lk(m);
-    cv_full.wait(lk, [&] { return q.size() < cap; });
-    q.push_back(std::move(b));
-    cv_empty.notify_one();
+void parse_blocks(const RawBlock &b1, const RawBlock *b2, const std::string &fn1, const std::string &fn2, Batch &out) {
+  out.seqs.reserve(b1.size / 2 + (b2 ? b2->size / 2 : 0));
+  BlockCursor c1(b1);
+  std::unique_ptr<BlockCursor> c2;
+  if (b2) c2.reset(new BlockCursor(*b2));
+  const char *nm; size_t nl;
+  while (c1.next(nm, nl, out.seqs)) {
+    out.off.push_back(out.seqs.size());
+    if (b2) {
+      const char *nm2; size_t nl2;
+      if (!c2->next(nm2, nl2, out.seqs)) die("File " + fn1 + " contains more reads then file " + fn2);
+      if (nl != nl2 || memcmp(nm, nm2, nl) != 0)
+        die("Read names are not identical between the two input files. Probably reads are not in the same order in both files.");
+    }
+    out.off.push_back(out.seqs.size());
+    out.names.insert(out.names.end(), nm, nm + nl);
+    out.name_off.push_back((uint32_t)out.names.size());
   }
-  std::unique_ptr<Batch> pop() {
+}
+
+// ---------------------------------------------------------------------------------------------
+// ordered hand-over between the stages: items carry their sequence number
+// ---------------------------------------------------------------------------------------------
+template <class T>
+struct OrderedQueue {
+  std::mutex m;
+  std::condition_variable cv;
+  std::map<uint64_t, T> items;
+  uint64_t end = ~0ull;                     // number of items of the whole run, once known
+  size_t cap;
+  uint64_t taken = 0;                       // items handed out so far (unordered consumers)
+  explicit OrderedQueue(size_t c) : cap(c) {}
+  void put(uint64_t seq, T v) {
     std::unique_lock<std::mutex> lk(m);
-    cv_empty.wait(lk, [&] { return !q.empty(); });
-    auto b = std::move(q.front());
-    q.pop_front();
-    cv_full.notify_one();
-    return b;
+    // the item everyone is waiting for must never be blocked by the capacity
+    cv.wait(lk, [&] { return items.size() < cap || items.empty() || seq < items.begin()->first; });
+    items.emplace(seq, std::move(v));
+    cv.notify_all();
+  }
+  void finish(uint64_t n_items) { std::lock_guard<std::mutex> lk(m); end = n_items; cv.notify_all(); }
+  // in order: blocks until item `seq` is there; false when seq >= end
+  bool take(uint64_t seq, T &v) {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return items.count(seq) || seq >= end; });
+    if (!items.count(seq)) return false;
+    v = std::move(items[seq]); items.erase(seq);
+    cv.notify_all();
+    return true;
+  }
+  // any order (parallel consumers): the smallest item present
+  bool take_any(uint64_t &seq, T &v) {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return !items.empty() || taken >= end; });
+    if (items.empty()) return false;
+    auto it = items.begin();
+    seq = it->first; v = std::move(it->second); items.erase(it); taken++;
+    cv.notify_all();
+    return true;
   }
 };
+
+inline void append_u64(std::string &s, unsigned long long v) {
+  char tmp[24]; int k = 0;
+  do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+  while (k) s.push_back(tmp[--k]);
+}
 
 }  // namespace
 
@@ -207,26 +362,45 @@ int main(int argc, char **argv) {
       default: usage(argv[0]);
     }
   }
+  if (getenv("KAIJU_GPU_PARSE_ONLY")) { if (nodes_fn.empty()) nodes_fn = "-"; if (fmi_fn.empty()) fmi_fn = "-"; }
   if (nodes_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the nodes.dmp file, using the -t option.\n\n"); usage(argv[0]); }
   if (fmi_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the FMI file, using the -f option.\n\n"); usage(argv[0]); }
   if (in1_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the input file, using the -i option.\n\n"); usage(argv[0]); }
   if (protein) die("Protein input (-p) is not supported by the GPU path.");
   if (params.use_evalue && params.mode == 0) die("E-value calculation is only possible in Greedy run mode.");
 
+  // developer/test switch: run the ingest stages only and print "name<TAB>mate1<TAB>mate2" per read
+  const bool parse_only = getenv("KAIJU_GPU_PARSE_ONLY") != nullptr;
   if (verbose) fprintf(stderr, "%s Reading database\n", now().c_str());
-  kaiju_taxonomy *tax = nullptr;
-  if (kaiju_taxonomy_load(nodes_fn.c_str(), &tax) != 0) die("Could not open file " + nodes_fn);
   int device = 0;
   if (const char *e = getenv("KAIJU_GPU_DEVICE")) device = atoi(e);
+  // nodes.dmp is parsed while the index loads
+  kaiju_taxonomy *tax = nullptr;
   kaiju_gpu_index *index = nullptr;
-  int rc = kaiju_gpu_index_load(fmi_fn.c_str(), device, &index);
-  if (rc != 0) die(std::string("Could not load ") + fmi_fn + ": " + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
   kaiju_gpu_index_info info;
-  kaiju_gpu_index_get_info(index, &info);
-  if (info.warnings && verbose) fprintf(stderr, " Warning: the index triggers a latent bug of the reference (flags %u)\n", info.warnings);
-  kaiju_gpu_ctx *ctx = nullptr;
-  rc = kaiju_gpu_create(&ctx, index, &params);
-  if (rc != 0) die(std::string("kaiju_gpu_create: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
+  memset(&info, 0, sizeof info);
+  kaiju_gpu_taxonomy *dtax = nullptr;
+  const int n_ctx = 2;                      // ping-pong: copies of one batch overlap with kernels of the other
+  kaiju_gpu_ctx *ctx[n_ctx] = {nullptr, nullptr};
+  int rc = 0;
+  if (!parse_only) {
+    int tax_rc = 0;
+    std::thread tax_loader([&] { tax_rc = kaiju_taxonomy_load(nodes_fn.c_str(), &tax); });
+    rc = kaiju_gpu_index_load(fmi_fn.c_str(), device, &index);
+    tax_loader.join();
+    if (tax_rc != 0) die("Could not open file " + nodes_fn);
+    if (rc != 0) die(std::string("Could not load ") + fmi_fn + ": " + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
+    kaiju_gpu_index_get_info(index, &info);
+    if (info.warnings && verbose) fprintf(stderr, " Warning: the index triggers a latent bug of the reference (flags %u)\n", info.warnings);
+    if (!verbose) {
+      rc = kaiju_gpu_taxonomy_upload(tax, device, &dtax);
+      if (rc != 0) die(std::string("kaiju_gpu_taxonomy_upload: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
+    }
+    for (int k = 0; k < n_ctx; k++) {
+      rc = kaiju_gpu_create(&ctx[k], index, &params);
+      if (rc != 0) die(std::string("kaiju_gpu_create: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
+    }
+  }
 
   FILE *out = stdout;
   if (!out_fn.empty()) {
@@ -235,74 +409,154 @@ int main(int argc, char **argv) {
   }
   setvbuf(out, nullptr, _IOFBF, 1 << 22);
 
-  size_t batch_reads = 1000000;
-  if (const char *e = getenv("KAIJU_GPU_BATCH")) batch_reads = (size_t)std::max(1L, atol(e));
+  uint32_t batch_reads = 500000;
+  if (const char *e = getenv("KAIJU_GPU_BATCH")) batch_reads = (uint32_t)std::max(1L, atol(e));
+  unsigned n_workers = std::max(2u, std::min(16u, std::thread::hardware_concurrency() / 2));
+  if (const char *e = getenv("KAIJU_GPU_HOST_THREADS")) n_workers = (unsigned)std::max(1, atoi(e));
   if (verbose) fprintf(stderr, "%s Start classification on GPU %d\n", now().c_str(), device);
 
-  Queue queue;
-  std::thread producer([&]() {
-    RecordReader r1(in1_fn);
-    if (!r1.in.fp) die("Could not open file " + in1_fn);
-    std::unique_ptr<RecordReader> r2;
-    if (paired) { r2.reset(new RecordReader(in2_fn)); if (!r2->in.fp) die("Could not open file " + in2_fn); }
-    std::unique_ptr<Batch> b(new Batch());
-    std::string name, name2;
-    for (;;) {
-      if (!r1.next(name, b->seqs)) break;
-      b->off.push_back(b->seqs.size());
-      if (paired) {
-        if (!r2->next(name2, b->seqs)) die("File " + in1_fn + " contains more reads then file " + in2_fn);
-        if (name != name2) die("Read names are not identical between the two input files. Probably reads are not in the same order in both files.");
-      }
-      b->off.push_back(b->seqs.size());
-      b->names.push_back(name);
-      if (b->n() >= batch_reads) { queue.push(std::move(b)); b.reset(new Batch()); }
+  struct RawPair { std::unique_ptr<RawBlock> a, b; };
+  OrderedQueue<RawPair> q_raw(8);
+  OrderedQueue<std::unique_ptr<Batch>> q_parsed(6), q_done(6), q_text(8);
+
+  // stage 1: readers (file 2 is read by its own thread, blocks are paired up here)
+  std::thread reader([&] {
+    BlockReader r1(in1_fn);
+    if (!r1.ok) die("Could not open file " + in1_fn);
+    std::unique_ptr<BlockReader> r2;
+    OrderedQueue<std::unique_ptr<RawBlock>> q2(4);
+    std::thread reader2;
+    if (paired) {
+      r2.reset(new BlockReader(in2_fn));
+      if (!r2->ok) die("Could not open file " + in2_fn);
+      reader2 = std::thread([&] {
+        uint64_t k = 0;
+        for (;;) {
+          std::unique_ptr<RawBlock> b(new RawBlock());
+          if (!r2->next(*b, batch_reads)) break;
+          q2.put(k++, std::move(b));
+        }
+        q2.finish(k);
+      });
     }
-    if (paired && r2->next(name2, b->seqs))
-      fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
-    b->last = true;
-    queue.push(std::move(b));
+    uint64_t seq = 0;
+    for (;;) {
+      RawPair pr;
+      pr.a.reset(new RawBlock());
+      if (!r1.next(*pr.a, batch_reads)) break;
+      if (paired) {
+        if (!q2.take(seq, pr.b)) die("File " + in1_fn + " contains more reads then file " + in2_fn);
+        if (pr.b->n_records < pr.a->n_records) die("File " + in1_fn + " contains more reads then file " + in2_fn);
+      }
+      q_raw.put(seq++, std::move(pr));
+    }
+    if (paired) {
+      std::unique_ptr<RawBlock> extra;
+      if (q2.take(seq, extra)) fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
+      // drain so that reader 2 can finish
+      for (uint64_t k = seq + 1; q2.take(k, extra); k++) {}
+      reader2.join();
+    }
+    q_raw.finish(seq);
+    q_parsed.finish(seq); q_done.finish(seq); q_text.finish(seq);
   });
 
-  std::vector<kaiju_gpu_hit> hits;
-  std::vector<kaiju_result> res;
-  std::string text;
-  for (;;) {
-    std::unique_ptr<Batch> b = queue.pop();
-    const uint32_t n = (uint32_t)b->n();
-    if (n) {
-      hits.resize(n);
-      res.resize(n);
-      rc = kaiju_gpu_classify_batch(ctx, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, hits.data());
-      if (rc != 0) die(std::string("classification failed: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
-      kaiju_finalize_hits(tax, &params, info.db_length, hits.data(), b->off.data(), n, paired ? 1 : 0, res.data());
-      text.clear();
-      char num[32];
-      for (uint32_t r = 0; r < n; r++) {
-        if (res[r].classified) {
-          text += "C\t"; text += b->names[r]; text += '\t';
-          snprintf(num, sizeof num, "%llu", (unsigned long long)res[r].taxon); text += num;
-          if (verbose) {
-            snprintf(num, sizeof num, "\t%u\t", res[r].best); text += num;
-            uint64_t ids[KAIJU_GPU_MAX_IDS];
-            const uint32_t k = hits[r].n_ids;
-            for (uint32_t q = 0; q < k; q++) ids[q] = hits[r].taxid[q];
-            std::sort(ids, ids + k);                       // std::set iteration order, :527-536
-            for (uint32_t q = 0; q < k; q++) { snprintf(num, sizeof num, "%llu,", (unsigned long long)ids[q]); text += num; }
-          }
-          text += '\n';
-        } else { text += "U\t"; text += b->names[r]; text += "\t0\n"; }
+  // stage 2: parsers
+  std::vector<std::thread> parsers;
+  for (unsigned w = 0; w < n_workers; w++)
+    parsers.emplace_back([&] {
+      uint64_t seq; RawPair pr;
+      while (q_raw.take_any(seq, pr)) {
+        std::unique_ptr<Batch> b(new Batch());
+        parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b);
+        if (paired && pr.b->n_records > pr.a->n_records)
+          fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
+        q_parsed.put(seq, std::move(b));
       }
-      fwrite(text.data(), 1, text.size(), out);
-    }
-    if (b->last) break;
+    });
+
+  // stage 3: the GPU, one thread per context, batches alternate between them
+  std::vector<std::thread> gpu_threads;
+  for (int k = 0; k < n_ctx; k++)
+    gpu_threads.emplace_back([&, k] {
+      std::unique_ptr<Batch> b;
+      for (uint64_t seq = (uint64_t)k; q_parsed.take(seq, b); seq += n_ctx) {
+        const uint32_t n = (uint32_t)b->n();
+        int r = 0;
+        if (parse_only) { q_done.put(seq, std::move(b)); continue; }
+        if (verbose) {
+          b->hits.resize(n);
+          r = kaiju_gpu_classify_batch(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data());
+        } else {
+          b->compact.resize(n);
+          r = kaiju_gpu_classify_batch_compact(ctx[k], dtax, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
+        }
+        if (r != 0) die(std::string("classification failed: ") + kaiju_gpu_strerror(r) + " (" + kaiju_gpu_last_error() + ")");
+        std::vector<char>().swap(b->seqs);
+        q_done.put(seq, std::move(b));
+      }
+    });
+
+  // stage 4: E-value gate, (LCA,) C/U decision and text, in parallel
+  std::vector<std::thread> formatters;
+  for (unsigned w = 0; w < n_workers; w++)
+    formatters.emplace_back([&] {
+      uint64_t seq; std::unique_ptr<Batch> b;
+      std::vector<kaiju_result> res;
+      while (q_done.take_any(seq, b)) {
+        const uint32_t n = (uint32_t)b->n();
+        if (parse_only) {
+          std::string &text = b->text;
+          for (uint32_t r = 0; r < n; r++) {
+            text.append(b->names.data() + b->name_off[r], b->name_off[r + 1] - b->name_off[r]); text += '\t';
+            text.append(b->seqs.data() + b->off[2 * r], b->off[2 * r + 1] - b->off[2 * r]); text += '\t';
+            text.append(b->seqs.data() + b->off[2 * r + 1], b->off[2 * r + 2] - b->off[2 * r + 1]); text += '\n';
+          }
+          q_text.put(seq, std::move(b));
+          continue;
+        }
+        res.resize(n);
+        if (verbose) kaiju_finalize_hits(tax, &params, info.db_length, b->hits.data(), b->off.data(), n, paired ? 1 : 0, res.data());
+        else kaiju_finalize_compact(&params, info.db_length, b->compact.data(), b->off.data(), n, paired ? 1 : 0, res.data());
+        std::string &text = b->text;
+        text.clear();
+        text.reserve((size_t)n * 24 + b->names.size());
+        for (uint32_t r = 0; r < n; r++) {
+          const char *nm = b->names.data() + b->name_off[r];
+          const size_t nl = b->name_off[r + 1] - b->name_off[r];
+          if (res[r].classified) {
+            text += "C\t"; text.append(nm, nl); text += '\t';
+            append_u64(text, res[r].taxon);
+            if (verbose) {
+              text += '\t'; append_u64(text, res[r].best); text += '\t';
+              uint64_t ids[KAIJU_GPU_MAX_IDS];
+              const uint32_t k = b->hits[r].n_ids;
+              for (uint32_t q = 0; q < k; q++) ids[q] = b->hits[r].taxid[q];
+              std::sort(ids, ids + k);                       // std::set iteration order, :527-536
+              for (uint32_t q = 0; q < k; q++) { append_u64(text, ids[q]); text += ','; }
+            }
+            text += '\n';
+          } else { text += "U\t"; text.append(nm, nl); text += "\t0\n"; }
+        }
+        q_text.put(seq, std::move(b));
+      }
+    });
+
+  // stage 5: write in input order
+  {
+    std::unique_ptr<Batch> b;
+    for (uint64_t seq = 0; q_text.take(seq, b); seq++) fwrite(b->text.data(), 1, b->text.size(), out);
   }
-  producer.join();
+  reader.join();
+  for (auto &t : parsers) t.join();
+  for (auto &t : gpu_threads) t.join();
+  for (auto &t : formatters) t.join();
   if (verbose) fprintf(stderr, "%s Finished.\n", now().c_str());
   fflush(out);
   if (out != stdout) fclose(out);
-  kaiju_gpu_destroy(ctx);
-  kaiju_gpu_index_free(index);
-  kaiju_taxonomy_free(tax);
+  for (int k = 0; k < n_ctx; k++) if (ctx[k]) kaiju_gpu_destroy(ctx[k]);
+  if (dtax) kaiju_gpu_taxonomy_free(dtax);
+  if (index) kaiju_gpu_index_free(index);
+  if (tax) kaiju_taxonomy_free(tax);
   return EXIT_SUCCESS;
 }

@@ -1,0 +1,139 @@
+"""Ingest stages of the drop-in CLI (block reader, parallel parser) against a restatement of the reference's
+reading loop (kaiju.cpp:288-386): FASTA/FASTQ, gzip, blank lines, CRLF, multi-line FASTA, missing final
+newline, truncated last record, pairs.  Runs the CLI with KAIJU_GPU_PARSE_ONLY (no GPU work at all)."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+CLI = os.path.join(util.ROOT, "kaiju_amd", "bin", "kaiju")
+
+
+def ref_records(text: bytes):
+    """the reference's loop on one file: list of (name, stripped sequence)"""
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    i, out, fastq, first = 0, [], False, True
+
+    def strip(s):
+        return bytes(c for c in s if (65 <= c <= 90) or (97 <= c <= 122))
+
+    while True:
+        while i < len(lines) and lines[i] == b"":
+            i += 1
+        if i >= len(lines):
+            break
+        line = lines[i]
+        i += 1
+        if first:
+            fastq = line[:1] == b"@"
+            first = False
+        name = line[1:]
+        for k, c in enumerate(name):
+            if c in b" /\t\r":
+                name = name[:k]
+                break
+        if fastq:
+            seq = strip(lines[i]) if i < len(lines) else b""
+            i += 3
+        else:
+            seq = b""
+            while i < len(lines) and lines[i][:1] != b">":
+                seq += strip(lines[i])
+                i += 1
+        out.append((name, seq))
+    return out
+
+
+def run_cli(tmp_path, f1, f2=None, batch=None):
+    env = dict(os.environ, KAIJU_GPU_PARSE_ONLY="1")
+    if batch:
+        env["KAIJU_GPU_BATCH"] = str(batch)
+    cmd = [CLI, "-i", str(f1)] + (["-j", str(f2)] if f2 else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    return [tuple(l.split(b"\t")) for l in r.stdout.split(b"\n") if l]
+
+
+def make_fastq(rng, n, crlf=False, blanks=False, final_newline=True):
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(0, 200))
+        seq = bytes(rng.choice(list(b"ACGTNacgt-*"), L).tolist())
+        name = f"@read{i} extra/1".encode() if i % 3 else f"@r{i}/1".encode()
+        qual = b"@" + b"I" * max(L - 1, 0) if i % 5 == 0 else b"+" * L       # quality lines that look like headers / separators
+        eol = b"\r\n" if crlf else b"\n"
+        recs.append(name + eol + seq + eol + b"+" + eol + qual + eol)
+        if blanks and i % 7 == 0:
+            recs.append(b"\n\n")
+    t = b"".join(recs)
+    return t if final_newline else t.rstrip(b"\n")
+
+
+def make_fasta(rng, n, width=60):
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(0, 400))
+        seq = bytes(rng.choice(list(b"ACGTNacgt"), L).tolist())
+        recs.append(f">seq{i}\tdescr".encode() + b"\n")
+        for k in range(0, L, width):
+            recs.append(seq[k:k + width] + b"\n")
+        if i % 11 == 0:
+            recs.append(b"\n")                       # empty line inside / after a record
+    return b"".join(recs)
+
+
+@pytest.fixture(scope="module")
+def have_cli():
+    from kaiju_amd import build
+    build.build()
+    assert os.path.exists(CLI)
+
+
+@pytest.mark.parametrize("variant", ["plain", "crlf", "blanks", "nofinal", "gz", "truncated"])
+def test_fastq_ingest(have_cli, tmp_path, variant):
+    rng = np.random.default_rng(11)
+    text = make_fastq(rng, 3000, crlf=variant == "crlf", blanks=variant == "blanks", final_newline=variant != "nofinal")
+    if variant == "truncated":
+        text = text[: len(text) - 150]              # the last record loses lines
+    path = tmp_path / ("r.fq.gz" if variant == "gz" else "r.fq")
+    if variant == "gz":
+        with gzip.open(path, "wb") as f:
+            f.write(text)
+    else:
+        path.write_bytes(text)
+    want = ref_records(text)
+    for batch in (None, 1, 7, 1000):
+        got = run_cli(tmp_path, path, batch=batch)
+        assert len(got) == len(want)
+        assert [(g[0], g[1]) for g in got] == want, batch
+
+
+def test_fasta_ingest(have_cli, tmp_path):
+    rng = np.random.default_rng(12)
+    text = make_fasta(rng, 2000)
+    path = tmp_path / "r.fa"
+    path.write_bytes(text)
+    want = ref_records(text)
+    for batch in (None, 3, 500):
+        got = run_cli(tmp_path, path, batch=batch)
+        assert [(g[0], g[1]) for g in got] == want, batch
+    with gzip.open(tmp_path / "r.fa.gz", "wb") as f:
+        f.write(text)
+    assert [(g[0], g[1]) for g in run_cli(tmp_path, tmp_path / "r.fa.gz", batch=64)] == want
+
+
+def test_paired_ingest(have_cli, tmp_path):
+    rng = np.random.default_rng(13)
+    t1 = make_fastq(rng, 1500)
+    t2 = make_fastq(np.random.default_rng(14), 1500).replace(b"/1", b"/2")
+    (tmp_path / "a.fq").write_bytes(t1)
+    (tmp_path / "b.fq").write_bytes(t2)
+    w1, w2 = ref_records(t1), ref_records(t2)
+    got = run_cli(tmp_path, tmp_path / "a.fq", tmp_path / "b.fq", batch=97)
+    assert [(g[0], g[1], g[2]) for g in got] == [(a[0], a[1], b[1]) for a, b in zip(w1, w2)]
