@@ -78,6 +78,23 @@ def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
             assert (ref[n][0] == "C") == bool(r["classified"]) and (not r["classified"] or int(r["taxon"]) == ref[n][1]), n
 
 
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_long_reads(gpu_lib, gidx, oracle, ohandles, mode):
+    """reads of 400..3000 nt (alone and mixed with short ones): in-place stage 1, window refills, spills"""
+    api = gpu_lib
+    ix, tax = ohandles
+    reads = util.long_reads()
+    for batch in (reads, reads[:40] + [b"ACGT" * 40, b"", b"ACG"] + reads[40:80]):
+        seqs, off = util.pack(batch)
+        for seg in (1, 0):
+            clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
+            hits = clf.classify(seqs, off)
+            assert clf.stats().error_flags == 0
+            oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), seqs, off)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+            assert not bad, (mode, seg, bad[:5])
+
+
 @pytest.mark.parametrize("k", ["0", "3", "6", "7"])
 def test_kmer_table_depths(gpu_lib, golden, oracle, ohandles, k, monkeypatch):
     """the k-mer table that starts every backward search: none, host-built, grown on the device to 6 and 7

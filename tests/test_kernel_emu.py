@@ -185,3 +185,17 @@ def test_greedy_lane2_spill_and_retry(oracle, golden, handles):
         bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
         assert not bad, (seg, bad[:5])
     assert total_retry > 0
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_long_reads(oracle, emu, handles, mode):
+    """reads of 400..3000 nt: fragments longer than the 64-residue window, stage 1 written in place, match
+    lists beyond the LDS rows (second-generation Greedy lane spills / retries)"""
+    h, ix, tax = handles
+    reads = util.long_reads()
+    seqs, off = util.pack(reads)
+    for seg in (1, 0):
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), seqs, off)
+        gh, _ = emu.classify(h, util.gp(mode, seg=seg), seqs, off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (mode, seg, bad[:5], len(reads[bad[0]]))

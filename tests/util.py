@@ -173,3 +173,51 @@ def same_hit(o, g, mask=3):
     return (int(o["best"]) == int(g["best"]) and int(o["n_ids"]) == int(g["n_ids"]) and
             list(o["taxid"][:o["n_ids"]]) == list(g["taxid"][:g["n_ids"]]) and
             (int(o["flags"]) & mask) == (int(g["flags"]) & mask))
+
+
+def long_reads(n=120, seed=5, lo=400, hi=3000):
+    """long reads (stage 1 writes in place, windows refill, k-mer starts cross window borders): back-translated
+    stretches of the golden proteins with substitutions, low-complexity inserts, N runs, plus random reads;
+    odd lengths on purpose"""
+    rng = np.random.default_rng(seed)
+    prots = []
+    with open(os.path.join(GOLD, "db.faa")) as f:
+        cur = []
+        for line in f:
+            if line.startswith(">"):
+                if cur:
+                    prots.append("".join(cur))
+                cur = []
+            else:
+                cur.append(line.strip())
+        if cur:
+            prots.append("".join(cur))
+    codon = {"A": "GCT", "R": "CGT", "N": "AAT", "D": "GAT", "C": "TGT", "Q": "CAA", "E": "GAA", "G": "GGT", "H": "CAT",
+             "I": "ATT", "L": "CTT", "K": "AAA", "M": "ATG", "F": "TTT", "P": "CCT", "S": "TCT", "T": "ACT", "W": "TGG",
+             "Y": "TAT", "V": "GTT"}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    out = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        if i % 5 == 4:
+            s = "".join(rng.choice(list("ACGT"), L))
+        else:
+            parts = []
+            while sum(len(p) for p in parts) < L:
+                p = prots[int(rng.integers(0, len(prots)))]
+                a = int(rng.integers(0, max(1, len(p) - 30)))
+                b = min(len(p), a + int(rng.integers(20, 400)))
+                nt = "".join(codon[c] for c in p[a:b] if c in codon)
+                if rng.random() < 0.3:
+                    nt += "GCT" * int(rng.integers(5, 30))          # poly-A peptide: SEG material
+                if rng.random() < 0.2:
+                    nt += "N" * int(rng.integers(1, 5))
+                parts.append(nt + "A" * int(rng.integers(0, 3)))    # frame shifts
+            s = list("".join(parts)[:L])
+            for _ in range(int(rng.integers(0, 6))):
+                s[int(rng.integers(0, len(s)))] = "ACGT"[int(rng.integers(0, 4))]
+            s = "".join(s)
+            if rng.random() < 0.5:
+                s = "".join(comp[c] for c in reversed(s))
+        out.append(s.encode())
+    return out
