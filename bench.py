@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("KAIJU_BENCH_READS", 10_000_000)),
                     help="reads per GPU per step")
+    ap.add_argument("--contexts", type=int, default=2, help="classification contexts that ping-pong the chunks")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 2_500_000)))
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
     ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"])
@@ -174,33 +175,56 @@ def main():
     dtax = api.DeviceTaxonomy(api.Taxonomy(nodes), local_rank)
     d_compact = torch.zeros(n * COMPACT_BYTES, dtype=torch.uint8, device=dev)
     log(rank, f"{n} reads/GPU resident in HBM ({time.time()-t0:.1f}s), index {index.info.device_bytes/1e6:.0f} MB in HBM")
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # Two classification contexts ping-pong the chunks on two HIP streams (the "two host threads per GPU
+    # on separate streams" of SURVEY.md 8b): while one chunk is in its HBM-bound search kernel the next one
+    # runs its ALU/latency-bound stage 1 and SEG pass.  --contexts 1 = strictly one chunk after the other.
+    nctx = max(1, args.contexts)
+    clfs = [clf] + [api.Classifier(index, params) for _ in range(nctx - 1)]
+    for c in clfs:
+        c.set_max_read_length(L)
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nctx - 1)]
 
-    kern_ms = []          # k_mem / k_greedy main-pass durations (HIP events on the launch stream)
+    kern_ms = []          # k_mem / k_greedy2 main-pass durations (HIP events on the launch stream)
     stage_ms = {"translate": 0.0, "seg": 0.0, "search": 0.0, "retry": 0.0}
     retries = 0
 
-    def one_step(record):
+    def collect(c, m, record):
         nonlocal retries
+        st = c.stats()                  # HIP events of that context's last chunk (blocks until its kernels are done)
+        if st.error_flags:
+            raise SystemExit(f"device-side capacity error flags {st.error_flags}")
+        if record:
+            kern_ms.append((st.ms_search, m))
+            stage_ms["translate"] += st.ms_translate
+            stage_ms["seg"] += st.ms_seg
+            stage_ms["search"] += st.ms_search
+            stage_ms["retry"] += st.ms_retry
+            retries += st.n_overflow_retries
+
+    def one_step(record, nctx=nctx):
         g = kdist.HitGatherer(world, rank, keep_results=False)
-        for (lo, hi), d_off in zip(bounds, d_offs):
+        pending = [None] * nctx
+        main = torch.cuda.current_stream(dev)
+        for s in streams[1:]:
+            s.wait_stream(main)
+        for k, ((lo, hi), d_off) in enumerate(zip(bounds, d_offs)):
+            c, s = clfs[k % nctx], streams[k % nctx]
+            if pending[k % nctx] is not None:
+                collect(c, pending[k % nctx], record)
             m = hi - lo
             out_view = d_out[lo * HIT_BYTES: hi * HIT_BYTES]
-            clf.classify_device(d_seqs.data_ptr() + lo * L, m * L, d_off.data_ptr(), m, out_view.data_ptr(),
-                                paired=False, stream=stream)
             cview = d_compact[lo * COMPACT_BYTES: hi * COMPACT_BYTES]
-            clf.lca_device(dtax, out_view.data_ptr(), m, cview.data_ptr(), stream=stream)
-            g.gather(cview)
-            st = clf.stats()            # HIP events of this chunk (blocks until its kernels are done)
-            if st.error_flags:
-                raise SystemExit(f"device-side capacity error flags {st.error_flags}")
-            if record:
-                kern_ms.append((st.ms_search, m))
-                stage_ms["translate"] += st.ms_translate
-                stage_ms["seg"] += st.ms_seg
-                stage_ms["search"] += st.ms_search
-                stage_ms["retry"] += st.ms_retry
-                retries += st.n_overflow_retries
+            with torch.cuda.stream(s):
+                c.classify_device(d_seqs.data_ptr() + lo * L, m * L, d_off.data_ptr(), m, out_view.data_ptr(),
+                                  paired=False, stream=s.cuda_stream)
+                c.lca_device(dtax, out_view.data_ptr(), m, cview.data_ptr(), stream=s.cuda_stream)
+                g.gather(cview)
+            pending[k % nctx] = m
+        for k in range(nctx):
+            if pending[k] is not None:
+                collect(clfs[k], pending[k], record)
+        for s in streams[1:]:
+            main.wait_stream(s)
         g.wait()
 
     for _ in range(args.warmup):
@@ -214,6 +238,18 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     elapsed = kdist.max_over_ranks(elapsed, device=dev)
+
+    # one more, untimed, pass with the chunks strictly one after the other: the kernel durations without
+    # the other chunk's kernels competing for the CUs (reported next to the live figures)
+    live = (list(kern_ms), dict(stage_ms))
+    kern_ms.clear()
+    for k in stage_ms:
+        stage_ms[k] = 0.0
+    one_step(True, 1)
+    torch.cuda.synchronize(dev)
+    excl_kern = list(kern_ms)
+    kern_ms[:] = live[0]
+    stage_ms.update(live[1])
 
     # sanity: the fraction of reads with a hit must be what the generator plants (70 % DB reads)
     hits = np.frombuffer(d_out[: min(n, 1_000_000) * HIT_BYTES].cpu().numpy().tobytes(), dtype=api.HIT_DTYPE)
@@ -232,7 +268,7 @@ def main():
                                f"{os.path.getsize(fmi)/1e6:.0f} MB, e=3); {n} synthetic {L}-bp reads per GPU per step "
                                f"(70% back-translated DB windows, 30% random); kaiju -a {args.mode} -m 11"
                                f"{'' if seg else ' -X'} (SEG {'on' if seg else 'off'})",
-                   "reads_per_gpu_per_step": n, "chunk": chunk, "index_replicated": True,
+                   "reads_per_gpu_per_step": n, "chunk": chunk, "contexts_in_flight": nctx, "index_replicated": True,
                    "gather": ("one async RCCL gather of 16-B records (device LCA of the 184-B hit records) per chunk to rank 0"
                               if world > 1 else "none (1 GPU); device LCA to 16-B records still runs"),
                    "fraction_reads_with_hit": round(frac_hit, 4), "overflow_retries_per_step": retries / max(args.steps, 1)},
@@ -274,6 +310,10 @@ def main():
                           "algorithmic_bytes_per_read": bytes_per_read,
                           "ops_per_read": ops, "reads_per_launch": tot_reads / max(len(kern_ms), 1),
                           "avg_launch_ms": avg_ms,
+                          "exclusive": (lambda e: {"avg_launch_ms": e, "achieved": bytes_per_read * tot_reads_per_launch(excl_kern) / (e * 1e-3) / 1e9,
+                                                   "frac": bytes_per_read * tot_reads_per_launch(excl_kern) / (e * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   "note": "same kernel, chunks strictly one after the other (untimed extra pass)"})(
+                              sum(ms for ms, _ in excl_kern) / max(len(excl_kern), 1)) if excl_kern else None,
                           "stage_ms_per_step": {k: v / max(args.steps, 1) for k, v in stage_ms.items()}}
     if cb is not None:
         result["cpu_baseline"] = cb
