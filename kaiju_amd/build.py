@@ -48,7 +48,9 @@ CLI = os.path.join(HERE, "bin", "kaiju")
 
 def build_cli(force=False, verbose=False):
     """the drop-in `kaiju` command (host C++ over the C-ABI)"""
-    if not force and os.path.exists(CLI) and os.path.getmtime(CLI) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(LIB)):
+    multi = os.path.join(os.path.dirname(CLI), "kaiju-multi")
+    if (not force and os.path.exists(CLI) and os.path.exists(multi) and
+            os.path.getmtime(CLI) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(LIB))):
         return CLI
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-o", CLI, CLI_SRC, "-L" + HERE, "-lkaiju_gpu", "-lz", "-lpthread",
@@ -56,6 +58,9 @@ def build_cli(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    # kaiju-multi is the same program (it looks at its name): comma separated file lists, one index load
+    import shutil as _sh
+    _sh.copy2(CLI, multi)
     return CLI
 
 

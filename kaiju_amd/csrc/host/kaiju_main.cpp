@@ -402,158 +402,187 @@ int main(int argc, char **argv) {
     }
   }
 
-  FILE *out = stdout;
-  if (!out_fn.empty()) {
-    out = fopen(out_fn.c_str(), "w");
-    if (!out) die("Could not open file " + out_fn + " for writing");
+  // kaiju-multi (kaiju-multi.cpp:221-334): comma separated lists of input / output files, one index load
+  const bool multi = std::string(argv[0]).find("multi") != std::string::npos;
+  auto split_list = [](const std::string &v) {
+    std::vector<std::string> out;
+    size_t begin = 0, pos;
+    while ((pos = v.find(',', begin)) != std::string::npos) { if (pos > begin) out.push_back(v.substr(begin, pos - begin)); begin = pos + 1; }
+    if (begin < v.size()) out.push_back(v.substr(begin));
+    return out;
+  };
+  std::vector<std::string> list1{in1_fn}, list2, list_out;
+  if (paired) list2.push_back(in2_fn);
+  if (!out_fn.empty()) list_out.push_back(out_fn);
+  if (multi) {
+    list1 = split_list(in1_fn); list2 = split_list(in2_fn); list_out = split_list(out_fn);
+    if ((!out_fn.empty() && ((paired && (list1.size() != list2.size() || list1.size() != list_out.size())) ||
+                             (!paired && list1.size() != list_out.size()))) ||
+        (out_fn.empty() && paired && list1.size() != list2.size()))
+      die("Length of input/output file lists differs");
+    for (const auto &f : list1) { FILE *t = fopen(f.c_str(), "r"); if (!t) die("Could not open file " + f); fclose(t); }
+    for (const auto &f : list2) { FILE *t = fopen(f.c_str(), "r"); if (!t) die("Could not open file " + f); fclose(t); }
   }
-  setvbuf(out, nullptr, _IOFBF, 1 << 22);
 
-  uint32_t batch_reads = 500000;
-  if (const char *e = getenv("KAIJU_GPU_BATCH")) batch_reads = (uint32_t)std::max(1L, atol(e));
-  unsigned n_workers = std::max(2u, std::min(16u, std::thread::hardware_concurrency() / 2));
-  if (const char *e = getenv("KAIJU_GPU_HOST_THREADS")) n_workers = (unsigned)std::max(1, atoi(e));
-  if (verbose) fprintf(stderr, "%s Start classification on GPU %d\n", now().c_str(), device);
-
-  struct RawPair { std::unique_ptr<RawBlock> a, b; };
-  OrderedQueue<RawPair> q_raw(8);
-  OrderedQueue<std::unique_ptr<Batch>> q_parsed(6), q_done(6), q_text(8);
-
-  // stage 1: readers (file 2 is read by its own thread, blocks are paired up here)
-  std::thread reader([&] {
-    BlockReader r1(in1_fn);
-    if (!r1.ok) die("Could not open file " + in1_fn);
-    std::unique_ptr<BlockReader> r2;
-    OrderedQueue<std::unique_ptr<RawBlock>> q2(4);
-    std::thread reader2;
-    if (paired) {
-      r2.reset(new BlockReader(in2_fn));
-      if (!r2->ok) die("Could not open file " + in2_fn);
-      reader2 = std::thread([&] {
-        uint64_t k = 0;
-        for (;;) {
-          std::unique_ptr<RawBlock> b(new RawBlock());
-          if (!r2->next(*b, batch_reads)) break;
-          q2.put(k++, std::move(b));
-        }
-        q2.finish(k);
-      });
+  auto run_sample = [&](const std::string &in1_fn, const std::string &in2_fn, const std::string &out_fn) {
+    FILE *out = stdout;
+    if (!out_fn.empty()) {
+      out = fopen(out_fn.c_str(), "w");
+      if (!out) die("Could not open file " + out_fn + " for writing");
     }
-    uint64_t seq = 0;
-    for (;;) {
-      RawPair pr;
-      pr.a.reset(new RawBlock());
-      if (!r1.next(*pr.a, batch_reads)) break;
+    setvbuf(out, nullptr, _IOFBF, 1 << 22);
+
+    uint32_t batch_reads = 500000;
+    if (const char *e = getenv("KAIJU_GPU_BATCH")) batch_reads = (uint32_t)std::max(1L, atol(e));
+    unsigned n_workers = std::max(2u, std::min(16u, std::thread::hardware_concurrency() / 2));
+    if (const char *e = getenv("KAIJU_GPU_HOST_THREADS")) n_workers = (unsigned)std::max(1, atoi(e));
+    if (verbose) fprintf(stderr, "%s Start classification on GPU %d\n", now().c_str(), device);
+
+    struct RawPair { std::unique_ptr<RawBlock> a, b; };
+    OrderedQueue<RawPair> q_raw(8);
+    OrderedQueue<std::unique_ptr<Batch>> q_parsed(6), q_done(6), q_text(8);
+
+    // stage 1: readers (file 2 is read by its own thread, blocks are paired up here)
+    std::thread reader([&] {
+      BlockReader r1(in1_fn);
+      if (!r1.ok) die("Could not open file " + in1_fn);
+      std::unique_ptr<BlockReader> r2;
+      OrderedQueue<std::unique_ptr<RawBlock>> q2(4);
+      std::thread reader2;
       if (paired) {
-        if (!q2.take(seq, pr.b)) die("File " + in1_fn + " contains more reads then file " + in2_fn);
-        if (pr.b->n_records < pr.a->n_records) die("File " + in1_fn + " contains more reads then file " + in2_fn);
+        r2.reset(new BlockReader(in2_fn));
+        if (!r2->ok) die("Could not open file " + in2_fn);
+        reader2 = std::thread([&] {
+          uint64_t k = 0;
+          for (;;) {
+            std::unique_ptr<RawBlock> b(new RawBlock());
+            if (!r2->next(*b, batch_reads)) break;
+            q2.put(k++, std::move(b));
+          }
+          q2.finish(k);
+        });
       }
-      q_raw.put(seq++, std::move(pr));
-    }
-    if (paired) {
-      std::unique_ptr<RawBlock> extra;
-      if (q2.take(seq, extra)) fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
-      // drain so that reader 2 can finish
-      for (uint64_t k = seq + 1; q2.take(k, extra); k++) {}
-      reader2.join();
-    }
-    q_raw.finish(seq);
-    q_parsed.finish(seq); q_done.finish(seq); q_text.finish(seq);
-  });
-
-  // stage 2: parsers
-  std::vector<std::thread> parsers;
-  for (unsigned w = 0; w < n_workers; w++)
-    parsers.emplace_back([&] {
-      uint64_t seq; RawPair pr;
-      while (q_raw.take_any(seq, pr)) {
-        std::unique_ptr<Batch> b(new Batch());
-        parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b);
-        if (paired && pr.b->n_records > pr.a->n_records)
-          fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
-        q_parsed.put(seq, std::move(b));
-      }
-    });
-
-  // stage 3: the GPU, one thread per context, batches alternate between them
-  std::vector<std::thread> gpu_threads;
-  for (int k = 0; k < n_ctx; k++)
-    gpu_threads.emplace_back([&, k] {
-      std::unique_ptr<Batch> b;
-      for (uint64_t seq = (uint64_t)k; q_parsed.take(seq, b); seq += n_ctx) {
-        const uint32_t n = (uint32_t)b->n();
-        int r = 0;
-        if (parse_only) { q_done.put(seq, std::move(b)); continue; }
-        if (verbose) {
-          b->hits.resize(n);
-          r = kaiju_gpu_classify_batch(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data());
-        } else {
-          b->compact.resize(n);
-          r = kaiju_gpu_classify_batch_compact(ctx[k], dtax, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
+      uint64_t seq = 0;
+      for (;;) {
+        RawPair pr;
+        pr.a.reset(new RawBlock());
+        if (!r1.next(*pr.a, batch_reads)) break;
+        if (paired) {
+          if (!q2.take(seq, pr.b)) die("File " + in1_fn + " contains more reads then file " + in2_fn);
+          if (pr.b->n_records < pr.a->n_records) die("File " + in1_fn + " contains more reads then file " + in2_fn);
         }
-        if (r != 0) die(std::string("classification failed: ") + kaiju_gpu_strerror(r) + " (" + kaiju_gpu_last_error() + ")");
-        std::vector<char>().swap(b->seqs);
-        q_done.put(seq, std::move(b));
+        q_raw.put(seq++, std::move(pr));
       }
+      if (paired) {
+        std::unique_ptr<RawBlock> extra;
+        if (q2.take(seq, extra)) fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
+        // drain so that reader 2 can finish
+        for (uint64_t k = seq + 1; q2.take(k, extra); k++) {}
+        reader2.join();
+      }
+      q_raw.finish(seq);
+      q_parsed.finish(seq); q_done.finish(seq); q_text.finish(seq);
     });
 
-  // stage 4: E-value gate, (LCA,) C/U decision and text, in parallel
-  std::vector<std::thread> formatters;
-  for (unsigned w = 0; w < n_workers; w++)
-    formatters.emplace_back([&] {
-      uint64_t seq; std::unique_ptr<Batch> b;
-      std::vector<kaiju_result> res;
-      while (q_done.take_any(seq, b)) {
-        const uint32_t n = (uint32_t)b->n();
-        if (parse_only) {
+    // stage 2: parsers
+    std::vector<std::thread> parsers;
+    for (unsigned w = 0; w < n_workers; w++)
+      parsers.emplace_back([&] {
+        uint64_t seq; RawPair pr;
+        while (q_raw.take_any(seq, pr)) {
+          std::unique_ptr<Batch> b(new Batch());
+          parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b);
+          if (paired && pr.b->n_records > pr.a->n_records)
+            fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
+          q_parsed.put(seq, std::move(b));
+        }
+      });
+
+    // stage 3: the GPU, one thread per context, batches alternate between them
+    std::vector<std::thread> gpu_threads;
+    for (int k = 0; k < n_ctx; k++)
+      gpu_threads.emplace_back([&, k] {
+        std::unique_ptr<Batch> b;
+        for (uint64_t seq = (uint64_t)k; q_parsed.take(seq, b); seq += n_ctx) {
+          const uint32_t n = (uint32_t)b->n();
+          int r = 0;
+          if (parse_only) { q_done.put(seq, std::move(b)); continue; }
+          if (verbose) {
+            b->hits.resize(n);
+            r = kaiju_gpu_classify_batch(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data());
+          } else {
+            b->compact.resize(n);
+            r = kaiju_gpu_classify_batch_compact(ctx[k], dtax, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
+          }
+          if (r != 0) die(std::string("classification failed: ") + kaiju_gpu_strerror(r) + " (" + kaiju_gpu_last_error() + ")");
+          std::vector<char>().swap(b->seqs);
+          q_done.put(seq, std::move(b));
+        }
+      });
+
+    // stage 4: E-value gate, (LCA,) C/U decision and text, in parallel
+    std::vector<std::thread> formatters;
+    for (unsigned w = 0; w < n_workers; w++)
+      formatters.emplace_back([&] {
+        uint64_t seq; std::unique_ptr<Batch> b;
+        std::vector<kaiju_result> res;
+        while (q_done.take_any(seq, b)) {
+          const uint32_t n = (uint32_t)b->n();
+          if (parse_only) {
+            std::string &text = b->text;
+            for (uint32_t r = 0; r < n; r++) {
+              text.append(b->names.data() + b->name_off[r], b->name_off[r + 1] - b->name_off[r]); text += '\t';
+              text.append(b->seqs.data() + b->off[2 * r], b->off[2 * r + 1] - b->off[2 * r]); text += '\t';
+              text.append(b->seqs.data() + b->off[2 * r + 1], b->off[2 * r + 2] - b->off[2 * r + 1]); text += '\n';
+            }
+            q_text.put(seq, std::move(b));
+            continue;
+          }
+          res.resize(n);
+          if (verbose) kaiju_finalize_hits(tax, &params, info.db_length, b->hits.data(), b->off.data(), n, paired ? 1 : 0, res.data());
+          else kaiju_finalize_compact(&params, info.db_length, b->compact.data(), b->off.data(), n, paired ? 1 : 0, res.data());
           std::string &text = b->text;
+          text.clear();
+          text.reserve((size_t)n * 24 + b->names.size());
           for (uint32_t r = 0; r < n; r++) {
-            text.append(b->names.data() + b->name_off[r], b->name_off[r + 1] - b->name_off[r]); text += '\t';
-            text.append(b->seqs.data() + b->off[2 * r], b->off[2 * r + 1] - b->off[2 * r]); text += '\t';
-            text.append(b->seqs.data() + b->off[2 * r + 1], b->off[2 * r + 2] - b->off[2 * r + 1]); text += '\n';
+            const char *nm = b->names.data() + b->name_off[r];
+            const size_t nl = b->name_off[r + 1] - b->name_off[r];
+            if (res[r].classified) {
+              text += "C\t"; text.append(nm, nl); text += '\t';
+              append_u64(text, res[r].taxon);
+              if (verbose) {
+                text += '\t'; append_u64(text, res[r].best); text += '\t';
+                uint64_t ids[KAIJU_GPU_MAX_IDS];
+                const uint32_t k = b->hits[r].n_ids;
+                for (uint32_t q = 0; q < k; q++) ids[q] = b->hits[r].taxid[q];
+                std::sort(ids, ids + k);                       // std::set iteration order, :527-536
+                for (uint32_t q = 0; q < k; q++) { append_u64(text, ids[q]); text += ','; }
+              }
+              text += '\n';
+            } else { text += "U\t"; text.append(nm, nl); text += "\t0\n"; }
           }
           q_text.put(seq, std::move(b));
-          continue;
         }
-        res.resize(n);
-        if (verbose) kaiju_finalize_hits(tax, &params, info.db_length, b->hits.data(), b->off.data(), n, paired ? 1 : 0, res.data());
-        else kaiju_finalize_compact(&params, info.db_length, b->compact.data(), b->off.data(), n, paired ? 1 : 0, res.data());
-        std::string &text = b->text;
-        text.clear();
-        text.reserve((size_t)n * 24 + b->names.size());
-        for (uint32_t r = 0; r < n; r++) {
-          const char *nm = b->names.data() + b->name_off[r];
-          const size_t nl = b->name_off[r + 1] - b->name_off[r];
-          if (res[r].classified) {
-            text += "C\t"; text.append(nm, nl); text += '\t';
-            append_u64(text, res[r].taxon);
-            if (verbose) {
-              text += '\t'; append_u64(text, res[r].best); text += '\t';
-              uint64_t ids[KAIJU_GPU_MAX_IDS];
-              const uint32_t k = b->hits[r].n_ids;
-              for (uint32_t q = 0; q < k; q++) ids[q] = b->hits[r].taxid[q];
-              std::sort(ids, ids + k);                       // std::set iteration order, :527-536
-              for (uint32_t q = 0; q < k; q++) { append_u64(text, ids[q]); text += ','; }
-            }
-            text += '\n';
-          } else { text += "U\t"; text.append(nm, nl); text += "\t0\n"; }
-        }
-        q_text.put(seq, std::move(b));
-      }
-    });
+      });
 
-  // stage 5: write in input order
-  {
-    std::unique_ptr<Batch> b;
-    for (uint64_t seq = 0; q_text.take(seq, b); seq++) fwrite(b->text.data(), 1, b->text.size(), out);
+    // stage 5: write in input order
+    {
+      std::unique_ptr<Batch> b;
+      for (uint64_t seq = 0; q_text.take(seq, b); seq++) fwrite(b->text.data(), 1, b->text.size(), out);
+    }
+    reader.join();
+    for (auto &t : parsers) t.join();
+    for (auto &t : gpu_threads) t.join();
+    for (auto &t : formatters) t.join();
+    fflush(out);
+    if (out != stdout) fclose(out);
+  };
+  for (size_t i = 0; i < list1.size(); i++) {
+    if (verbose && multi)
+      fprintf(stderr, "%s Processing input file %s%s%s\n", now().c_str(), list1[i].c_str(), paired ? " and " : "", paired ? list2[i].c_str() : "");
+    run_sample(list1[i], paired ? list2[i] : std::string(), i < list_out.size() ? list_out[i] : std::string());
   }
-  reader.join();
-  for (auto &t : parsers) t.join();
-  for (auto &t : gpu_threads) t.join();
-  for (auto &t : formatters) t.join();
   if (verbose) fprintf(stderr, "%s Finished.\n", now().c_str());
-  fflush(out);
-  if (out != stdout) fclose(out);
   for (int k = 0; k < n_ctx; k++) if (ctx[k]) kaiju_gpu_destroy(ctx[k]);
   if (dtax) kaiju_gpu_taxonomy_free(dtax);
   if (index) kaiju_gpu_index_free(index);

@@ -137,3 +137,25 @@ def test_paired_ingest(have_cli, tmp_path):
     w1, w2 = ref_records(t1), ref_records(t2)
     got = run_cli(tmp_path, tmp_path / "a.fq", tmp_path / "b.fq", batch=97)
     assert [(g[0], g[1], g[2]) for g in got] == [(a[0], a[1], b[1]) for a, b in zip(w1, w2)]
+
+
+def test_multi_file_lists(have_cli, tmp_path):
+    """kaiju-multi: comma separated lists of inputs / outputs (kaiju-multi.cpp:221-334), one pass per sample"""
+    rng = np.random.default_rng(21)
+    texts = [make_fastq(rng, 300), make_fasta(rng, 200), make_fastq(rng, 50)]
+    ins, outs = [], []
+    for i, t in enumerate(texts):
+        f = tmp_path / f"s{i}.txt"
+        f.write_bytes(t)
+        ins.append(str(f))
+        outs.append(str(tmp_path / f"o{i}.tsv"))
+    env = dict(os.environ, KAIJU_GPU_PARSE_ONLY="1", KAIJU_GPU_BATCH="64")
+    multi = os.path.join(os.path.dirname(CLI), "kaiju-multi")
+    r = subprocess.run([multi, "-i", ",".join(ins), "-o", ",".join(outs)], env=env, capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    for t, o in zip(texts, outs):
+        got = [tuple(l.split(b"\t")) for l in open(o, "rb").read().split(b"\n") if l]
+        assert [(g[0], g[1]) for g in got] == ref_records(t)
+    # list lengths must agree
+    r = subprocess.run([multi, "-i", ",".join(ins), "-o", outs[0]], env=env, capture_output=True, timeout=120)
+    assert r.returncode != 0 and b"Length of input/output file lists differs" in r.stderr

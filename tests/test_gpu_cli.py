@@ -58,3 +58,29 @@ def test_cli_fasta_input(gpu_lib, golden, tmp_path):
                 f.write(s[k:k + 60] + "\n")
     out = run_cli(tmp_path, golden, ["-i", fa, "-a", "mem"], "fa.tsv")
     assert first5(out) == first5(os.path.join(golden.dir, "ref_mem_1.tsv"))
+
+
+def test_cli_non_verbose_uses_compact_records(gpu_lib, golden, tmp_path):
+    """without -v the CLI gets 16-byte records (LCA on the device): columns 1-3 must be the reference's"""
+    out = str(tmp_path / "nv.tsv")
+    subprocess.run([build.build_cli(), "-t", golden.nodes, "-f", golden.fmi, "-o", out, "-i",
+                    os.path.join(golden.dir, "reads.fq"), "-a", "greedy"], check=True)
+    got = [tuple(l.rstrip("\n").split("\t")) for l in open(out)]
+    want = [r[:3] for r in first5(os.path.join(golden.dir, "ref_greedy_1.tsv"))]
+    assert got == want
+
+
+def test_kaiju_multi(gpu_lib, golden, tmp_path):
+    """kaiju-multi: several samples, one index load (kaiju-multi.cpp:307-334)"""
+    build.build_cli()
+    multi = os.path.join(os.path.dirname(build.CLI), "kaiju-multi")
+    r1, p1, p2 = (os.path.join(golden.dir, f) for f in ("reads.fq", "pairs_1.fq", "pairs_2.fq"))
+    o1, o2 = str(tmp_path / "a.tsv"), str(tmp_path / "b.tsv")
+    subprocess.run([multi, "-t", golden.nodes, "-f", golden.fmi, "-a", "mem", "-v", "-i", f"{r1},{r1}", "-o", f"{o1},{o2}"],
+                   check=True)
+    ref = first5(os.path.join(golden.dir, "ref_mem_1.tsv"))
+    assert first5(o1) == ref and first5(o2) == ref
+    subprocess.run([multi, "-t", golden.nodes, "-f", golden.fmi, "-a", "mem", "-v", "-i", f"{p1},{p1}", "-j", f"{p2},{p2}",
+                    "-o", f"{o1},{o2}"], check=True)
+    ref = first5(os.path.join(golden.dir, "ref_mem_1_pe.tsv"))
+    assert first5(o1) == ref and first5(o2) == ref
