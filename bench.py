@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("KAIJU_BENCH_READS", 10_000_000)),
                     help="reads per GPU per step")
     ap.add_argument("--contexts", type=int, default=2, help="classification contexts that ping-pong the chunks")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 2_500_000)))
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 5_000_000)))
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
     ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"])
     ap.add_argument("--no-seg", action="store_true")
