@@ -174,6 +174,25 @@ uint64_t kaiju_taxonomy_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n);
 /* E-value gate + LCA + C/U decision for a batch.  len1/len2 are the nucleotide
    lengths (query_len = len1/3.0 [+ len2/3.0], ConsumerThread.cpp:698,704); pass
    off as given to classify_batch.  db_length from kaiju_gpu_index_get_info. */
+/* ---- verbose output: columns 6 and 7 of kaiju -v ------------------------- */
+/* ConsumerThread.cpp:527-536 (Greedy), :614-623 (MEM), :820-824 (accessions).  Per read: the
+   sequences whose names give the accession set of column 6 (first 20 distinct ones in the order the
+   reference visits the rows; the caller prints the sorted set of kaiju_gpu_index_seq_name() prefixes
+   up to the last '_') and the text of column 7 ("PEPTIDE,PEPTIDE,").  Runs the first-generation
+   search kernels (a few times slower than the default path). */
+#define KAIJU_GPU_MAX_ACC 20
+typedef struct {
+  uint32_t n_acc;
+  uint32_t text_len;                      /* bytes at text + r * text_stride, 0-terminated */
+  uint32_t truncated;                     /* the peptides did not fit */
+  uint32_t acc_iseq[KAIJU_GPU_MAX_ACC];
+} kaiju_gpu_verbose;
+int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
+                                     int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, char *text,
+                                     uint32_t text_stride);
+/* name of database sequence iseq as stored in the .fmi ("accession_taxid"), NULL if out of range */
+const char *kaiju_gpu_index_seq_name(const kaiju_gpu_index *index, uint32_t iseq);
+
 /* ---- LCA on the device: 16-byte records instead of 184-byte ones ------- */
 /* (what crosses PCIe / xGMI when the matched ids themselves are not needed, i.e. without -v;
    SURVEY.md 8f-3.  lca_from_ids util.cpp:194-263 on a device copy of the tree.) */

@@ -45,6 +45,7 @@ class Stats(C.Structure):
 HIT_DTYPE = np.dtype([("best", "<u4"), ("n_ids", "<u4"), ("flags", "<u4"), ("reserved", "<u4"),
                       ("taxid", "<u8", (MAX_IDS,))])
 RESULT_DTYPE = np.dtype([("taxon", "<u8"), ("best", "<u4"), ("classified", "u1"), ("pad", "u1", (3,))])
+VERBOSE_DTYPE = np.dtype([("n_acc", "<u4"), ("text_len", "<u4"), ("truncated", "<u4"), ("acc_iseq", "<u4", (20,))])  # kaiju_gpu_verbose
 COMPACT_DTYPE = np.dtype([("lca", "<u8"), ("best", "<u4"), ("info", "<u4")])     # kaiju_gpu_compact
 assert HIT_DTYPE.itemsize == 184 and RESULT_DTYPE.itemsize == 16 and COMPACT_DTYPE.itemsize == 16
 
@@ -88,6 +89,10 @@ def lib():
     L.kaiju_gpu_taxonomy_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.kaiju_gpu_taxonomy_free.argtypes = [C.c_void_p]
     L.kaiju_gpu_lca_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.kaiju_gpu_classify_batch_verbose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_uint32]
+    L.kaiju_gpu_index_seq_name.restype = C.c_char_p
+    L.kaiju_gpu_index_seq_name.argtypes = [C.c_void_p, C.c_uint32]
     L.kaiju_gpu_lca_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.kaiju_finalize_compact.argtypes = [C.POINTER(Params), C.c_double, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
                                          C.c_void_p]
@@ -229,6 +234,29 @@ class Classifier:
     def lca_device(self, dtax: "DeviceTaxonomy", d_hits_ptr: int, n: int, d_out_ptr: int, stream: int = 0):
         """hit records -> 16-byte compact records (LCA on the device); asynchronous on ``stream``."""
         _check(lib().kaiju_gpu_lca_batch_device(self._h, dtax._h, d_hits_ptr, n, d_out_ptr, stream))
+
+    def classify_verbose(self, seqs: np.ndarray, off: np.ndarray, paired=False):
+        """kaiju -v: (hit records, per read the sorted accession list of column 6, the text of column 7)"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = (len(off) - 1) // 2
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        v = np.zeros(n, dtype=VERBOSE_DTYPE)
+        maxpair = int((off[2::2] - off[0:-1:2]).max()) if n else 0
+        stride = min(20 * (maxpair // 3 + 2), 8192) + 1
+        text = np.zeros(n * stride, dtype=np.uint8)
+        _check(lib().kaiju_gpu_classify_batch_verbose(self._h, seqs.ctypes.data, off.ctypes.data, n, 1 if paired else 0,
+                                                      hits.ctypes.data, v.ctypes.data, text.ctypes.data, stride))
+        accs, peps = [], []
+        for r in range(n):
+            names = set()
+            for q in range(int(v[r]["n_acc"])):
+                nm = lib().kaiju_gpu_index_seq_name(self.index._h, int(v[r]["acc_iseq"][q]))
+                if nm and b"_" in nm:
+                    names.add(nm[: nm.rindex(b"_")].decode())
+            accs.append(sorted(names))
+            peps.append(bytes(text[r * stride: r * stride + int(v[r]["text_len"])]).decode())
+        return hits, accs, peps
 
     def lca(self, dtax: "DeviceTaxonomy", hits: np.ndarray) -> np.ndarray:
         """host hit records -> compact records through the LCA kernel (blocking)"""

@@ -114,14 +114,14 @@ k_seg_apply(const ConstTables *__restrict__ g_ct, Params p, Batch b, SegQueue sq
 
 template <class P>
 __device__ __forceinline__ void mem_body(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
-                                         SIEntry *si_all, uint32_t si_cap) {
+                                         SIEntry *si_all, uint32_t si_cap, const VerboseOut &vb) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneScratch ls;
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
-  mem_lane<P>(ix, p, b, wl, ls);
+  mem_lane<P>(ix, p, b, wl, ls, vb);
 }
 // second-generation lane (kj_core.h:mem_lane2): indexes below 2^32 symbols with a k-mer table
 __global__ void __launch_bounds__(kBlock, 4)
@@ -136,23 +136,24 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
 }
 // first-generation lane with 32-bit positions (kept for A/B measurements: KAIJU_GPU_MEM_LANE=v1)
 __global__ void __launch_bounds__(kBlock)
-k_mem_v1(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint32_t>(ix, p, b, wl, si_all, si_cap); }
+k_mem_v1(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap, VerboseOut vb) { mem_body<uint32_t>(ix, p, b, wl, si_all, si_cap, vb); }
 // 64-bit positions (refseq-scale indexes)
 __global__ void __launch_bounds__(kBlock)
-k_mem_wide(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint64_t>(ix, p, b, wl, si_all, si_cap); }
+k_mem_wide(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap, VerboseOut vb) { mem_body<uint64_t>(ix, p, b, wl, si_all, si_cap, vb); }
 // the same lanes over the device-side retry list, with worst-case scratch (separate symbol so
 // that profiles list the two passes separately)
 __global__ void __launch_bounds__(kBlock)
-k_mem_retry(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) { mem_body<uint64_t>(ix, p, b, wl, si_all, si_cap); }
+k_mem_retry(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap, VerboseOut vb) { mem_body<uint64_t>(ix, p, b, wl, si_all, si_cap, vb); }
 
 struct GreedyArrays {
   GItem *pool; uint16_t *ord; GMatch *matches; GBest *best;
   uint32_t pool_cap, match_cap;
+  GBestV *bestv;                 // verbose output only (else nullptr)
 };
 
 __device__ __forceinline__ void greedy_body(const DevIndex &ix, const ConstTables *__restrict__ g_ct, const Params &p,
                                             const SegQueue &sq, const Batch &b, const WorkList &wl,
-                                            const GreedyArrays &ga) {
+                                            const GreedyArrays &ga, const VerboseOut &vb) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
   __shared__ ConstTables s_ct;
   load_tables(s_ct, g_ct);
@@ -163,15 +164,18 @@ __device__ __forceinline__ void greedy_body(const DevIndex &ix, const ConstTable
   gs.matches = ga.matches + lane * ga.match_cap; gs.match_cap = ga.match_cap;
   gs.best = ga.best + lane * 64;
   gs.win = s_win + threadIdx.x * kWinStride;
-  greedy_lane(ix, s_ct, p, sq, b, wl, gs);
+  gs.bestv = ga.bestv ? ga.bestv + lane * 64 : nullptr;
+  greedy_lane(ix, s_ct, p, sq, b, wl, gs, vb);
 }
 __global__ void __launch_bounds__(kBlock)
-k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays ga) {
-  greedy_body(ix, g_ct, p, sq, b, wl, ga);
+k_greedy(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays ga,
+         VerboseOut vb) {
+  greedy_body(ix, g_ct, p, sq, b, wl, ga, vb);
 }
 __global__ void __launch_bounds__(kBlock)
-k_greedy_retry(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays ga) {
-  greedy_body(ix, g_ct, p, sq, b, wl, ga);
+k_greedy_retry(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays ga,
+               VerboseOut vb) {
+  greedy_body(ix, g_ct, p, sq, b, wl, ga, vb);
 }
 
 // second-generation Greedy lane (kj_core.h:greedy_lane2): indexes below 2^32 symbols with a k-mer table.
@@ -438,6 +442,9 @@ struct kaiju_gpu_ctx {
   DevBuf scratch_main[10], scratch_retry[5], h_compact;
   bool greedy2 = false;
   uint32_t greedy_gate = 3;
+  bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
+  uint32_t vb_text_cap = 0;
+  DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
   kaiju_gpu_stats stats{};
   uint32_t last_n = 0;
@@ -445,7 +452,8 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact};
+    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact,
+                     &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 10; i++) if (scratch_main[i].p) (void)hipFree(scratch_main[i].p);
     for (int i = 0; i < 5; i++) if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p);
@@ -584,6 +592,20 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   wl_retry.counter = cnt + 1; wl_retry.reads = static_cast<const uint32_t *>(c->retry_list.p);
   wl_retry.n_items_ptr = cnt + 2; wl_retry.n_items = 0; wl_retry.retry_list = nullptr; wl_retry.retry_count = nullptr;
   const uint64_t lanes_main = (uint64_t)c->blocks_main * kBlock;
+  VerboseOut vb{nullptr, nullptr, nullptr, nullptr, 0};
+  if (c->verbose) {
+    // columns 6/7: per read kVbAcc sequence numbers and room for 20 matched peptides
+    c->vb_text_cap = (uint32_t)std::min<uint64_t>(20ull * (max_pair / 3 + 2), 8192);
+    if ((rc = ensure(c->vb_nacc, (size_t)n * 4 + 16))) return rc;
+    if ((rc = ensure(c->vb_acc, (size_t)n * kVbAcc * 4 + 16))) return rc;
+    if ((rc = ensure(c->vb_tlen, (size_t)n * 4 + 16))) return rc;
+    if ((rc = ensure(c->vb_text, (size_t)n * c->vb_text_cap + 16))) return rc;
+    vb.n_acc = static_cast<uint32_t *>(c->vb_nacc.p); vb.acc = static_cast<uint32_t *>(c->vb_acc.p);
+    vb.text_len = static_cast<uint32_t *>(c->vb_tlen.p); vb.text = static_cast<uint8_t *>(c->vb_text.p);
+    vb.text_cap = c->vb_text_cap;
+    KJ_HIP(hipMemsetAsync(c->vb_nacc.p, 0, (size_t)n * 4, s));
+    KJ_HIP(hipMemsetAsync(c->vb_tlen.p, 0, (size_t)n * 4, s));
+  }
   if (p.mode == 0) {
     const uint32_t si_cap = 16;
     if ((rc = ensure(c->scratch_main[0], lanes_main * si_cap * sizeof(SIEntry)))) return rc;
@@ -595,26 +617,27 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     if (n > 0) {
       const char *lane_env = getenv("KAIJU_GPU_MEM_LANE");
       const bool v1 = lane_env && !strcmp(lane_env, "v1");
-      if (ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1)
+      if (ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 && !c->verbose)
         hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                            static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       else if (ix->dev.sb32)
         hipLaunchKernelGGL(k_mem_v1, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap, vb);
       else
         hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap, vb);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
       hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
-                         static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry);
+                         static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
   } else {
     const uint32_t frag_max = max_read_len / 3 + 4;
     GreedyArrays ga;
     ga.pool_cap = 192; ga.match_cap = 64;
-    if (!c->greedy2) {
+    const bool use_g2 = c->greedy2 && !c->verbose;
+    if (!use_g2) {
       if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
       if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
       if ((rc = ensure(c->scratch_main[2], lanes_main * ga.match_cap * sizeof(GMatch)))) return rc;
@@ -623,6 +646,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     ga.pool = static_cast<GItem *>(c->scratch_main[0].p); ga.ord = static_cast<uint16_t *>(c->scratch_main[1].p);
     ga.matches = static_cast<GMatch *>(c->scratch_main[2].p);
     ga.best = static_cast<GBest *>(c->scratch_main[4].p);
+    ga.bestv = nullptr;
+    if (c->verbose) {
+      if ((rc = ensure(c->vb_bestv, lanes_main * 64 * sizeof(GBestV)))) return rc;
+      ga.bestv = static_cast<GBestV *>(c->vb_bestv.p);
+    }
     GreedyArrays gr;
     gr.pool_cap = 65535; gr.match_cap = frag_max + 8;
     const uint64_t lanes_retry = (uint64_t)c->blocks_retry * kBlock;
@@ -633,8 +661,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     gr.pool = static_cast<GItem *>(c->scratch_retry[0].p); gr.ord = static_cast<uint16_t *>(c->scratch_retry[1].p);
     gr.matches = static_cast<GMatch *>(c->scratch_retry[2].p);
     gr.best = static_cast<GBest *>(c->scratch_retry[4].p);
+    gr.bestv = nullptr;
+    if (c->verbose) {
+      if ((rc = ensure(c->vb_bestv_retry, lanes_retry * 64 * sizeof(GBestV)))) return rc;
+      gr.bestv = static_cast<GBestV *>(c->vb_bestv_retry.p);
+    }
     GreedyArrays2 g2{};
-    if (c->greedy2) {
+    if (use_g2) {
       if ((rc = ensure(c->scratch_main[5], (lanes_main * (8 * kGSlotsAll) + 4) * sizeof(u128)))) return rc;
       if ((rc = ensure(c->scratch_main[6], lanes_main * (kGSlotsAll - kGSlots) * sizeof(uint32_t)))) return rc;
       if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
@@ -646,13 +679,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       g2.gate = c->greedy_gate;
     }
     if (n > 0) {
-      if (c->greedy2)
+      if (use_g2)
         hipLaunchKernelGGL(k_greedy2, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, p, sq, b, wl_main, g2);
       else
-        hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga);
+        hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga, vb);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
-      hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr);
+      hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
   }
@@ -776,6 +809,49 @@ extern "C" int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_ta
                      reinterpret_cast<const Hit *>(d_hits), n_reads, reinterpret_cast<CompactHit *>(d_out));
   KJ_HIP(hipGetLastError());
   return KAIJU_GPU_OK;
+}
+
+// Verbose classification (the reference's -v): hit records plus, per read, the sequences that give
+// column 6 and the text of column 7.  Runs the first-generation lanes.
+extern "C" int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
+                                                int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, char *text,
+                                                uint32_t text_stride) {
+  if (!ctx || !off || (n_reads && (!out || !vout || !text))) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (n_reads == 0) return KAIJU_GPU_OK;
+  ctx->verbose = true;
+  int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
+  ctx->verbose = false;
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  std::vector<uint32_t> nacc(n_reads), tlen(n_reads), acc((size_t)n_reads * kVbAcc);
+  std::vector<uint8_t> codes((size_t)n_reads * ctx->vb_text_cap);
+  KJ_HIP(hipMemcpyAsync(out, ctx->h_hits.p, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(nacc.data(), ctx->vb_nacc.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(tlen.data(), ctx->vb_tlen.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(acc.data(), ctx->vb_acc.p, acc.size() * 4, hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(codes.data(), ctx->vb_text.p, codes.size(), hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipStreamSynchronize(s));
+  const char *alpha = ctx->ix->info.alphabet;
+  const size_t alen = strlen(alpha);
+  for (uint32_t r = 0; r < n_reads; r++) {
+    kaiju_gpu_verbose &v = vout[r];
+    v.n_acc = nacc[r] > (uint32_t)kVbAcc ? (uint32_t)kVbAcc : nacc[r];
+    for (uint32_t q = 0; q < (uint32_t)KAIJU_GPU_MAX_ACC; q++) v.acc_iseq[q] = q < v.n_acc ? acc[(size_t)r * kVbAcc + q] : 0;
+    const uint32_t have = tlen[r] < ctx->vb_text_cap ? tlen[r] : ctx->vb_text_cap;
+    v.truncated = (tlen[r] > ctx->vb_text_cap || have + 1 > text_stride) ? 1u : 0u;
+    const uint32_t w = have + 1 <= text_stride ? have : (text_stride ? text_stride - 1 : 0);
+    char *dst = text + (size_t)r * text_stride;
+    const uint8_t *src = codes.data() + (size_t)r * ctx->vb_text_cap;
+    for (uint32_t x = 0; x < w; x++) dst[x] = src[x] == 255 ? ',' : (src[x] < alen ? alpha[src[x]] : '?');
+    if (text_stride) dst[w] = 0;
+    v.text_len = w;
+  }
+  return KAIJU_GPU_OK;
+}
+
+extern "C" const char *kaiju_gpu_index_seq_name(const kaiju_gpu_index *ix, uint32_t iseq) {
+  if (!ix || iseq >= ix->names.size()) return nullptr;
+  return ix->names[iseq].c_str();
 }
 
 // classify host buffers and return 16-byte records only (the 184-byte hit records never leave the device)

@@ -12,9 +12,8 @@
 // the text out in input order.  Without -v only 16-byte records (LCA computed on the device) come
 // back from the GPU.
 //
-// -v prints columns 4 (match length / score) and 5 (matching taxon ids); the accession and
-// peptide columns of the reference's verbose mode are not produced yet.  -p (protein input)
-// is not supported.
+// -v prints the reference's columns 4-7 (match length / score, matching taxon ids, accessions,
+// matched peptides).  -p (protein input) is not supported.
 #include <getopt.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -215,6 +214,9 @@ struct Batch {
   size_t n() const { return name_off.size() - 1; }
   // results
   std::vector<kaiju_gpu_hit> hits;         // -v only
+  std::vector<kaiju_gpu_verbose> vrec;     // -v only: columns 6/7
+  std::vector<char> vtext;
+  uint32_t vstride = 0;
   std::vector<kaiju_gpu_compact> compact;
   std::string text;
 };
@@ -509,7 +511,13 @@ int main(int argc, char **argv) {
           if (parse_only) { q_done.put(seq, std::move(b)); continue; }
           if (verbose) {
             b->hits.resize(n);
-            r = kaiju_gpu_classify_batch(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data());
+            b->vrec.resize(n);
+            uint64_t maxpair = 0;
+            for (uint32_t q = 0; q < n; q++) maxpair = std::max<uint64_t>(maxpair, b->off[2 * (size_t)q + 2] - b->off[2 * (size_t)q]);
+            b->vstride = (uint32_t)std::min<uint64_t>(20 * (maxpair / 3 + 2), 8192) + 1;
+            b->vtext.resize((size_t)n * b->vstride);
+            r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data(),
+                                                 b->vrec.data(), b->vtext.data(), b->vstride);
           } else {
             b->compact.resize(n);
             r = kaiju_gpu_classify_batch_compact(ctx[k], dtax, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
@@ -557,6 +565,21 @@ int main(int argc, char **argv) {
                 for (uint32_t q = 0; q < k; q++) ids[q] = b->hits[r].taxid[q];
                 std::sort(ids, ids + k);                       // std::set iteration order, :527-536
                 for (uint32_t q = 0; q < k; q++) { append_u64(text, ids[q]); text += ','; }
+                // column 6: the set of accessions (name up to its last '_'), column 7: the matched peptides
+                text += '\t';
+                const kaiju_gpu_verbose &v = b->vrec[r];
+                std::string acc[KAIJU_GPU_MAX_ACC];
+                uint32_t na = 0;
+                for (uint32_t q = 0; q < v.n_acc; q++) {
+                  const char *nm2 = kaiju_gpu_index_seq_name(index, v.acc_iseq[q]);
+                  const char *us = nm2 ? strrchr(nm2, '_') : nullptr;
+                  if (us) acc[na++].assign(nm2, (size_t)(us - nm2));
+                }
+                std::sort(acc, acc + na);
+                for (uint32_t q = 0; q < na; q++) if (q == 0 || acc[q] != acc[q - 1]) { text += acc[q]; text += ','; }
+                text += '\t';
+                text.append(b->vtext.data() + (size_t)r * b->vstride, v.text_len);
+                if (v.truncated) fprintf(stderr, "Warning: matched peptides of read %.*s truncated\n", (int)nl, nm);
               }
               text += '\n';
             } else { text += "U\t"; text.append(nm, nl); text += "\t0\n"; }

@@ -238,7 +238,8 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     const char *nm = v.ids[i] ? v.ids[i] : "";
     names[i] = nm;
     uint64_t id = 0;
-    seq_valid[i] = parse_taxid(nm, id) ? 1 : 0;
+    // bit 0: usable taxon id; bit 1: the name has an accession part in front of the last '_' (verbose column 6)
+    seq_valid[i] = parse_taxid(nm, id) ? (uint8_t)(strrchr(nm, '_') ? 3 : 1) : 0;
     seq_taxid[i] = id;
   }
   sa_taxid.assign((size_t)n_sa + 2, ~0ull);

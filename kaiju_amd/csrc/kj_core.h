@@ -1053,6 +1053,49 @@ struct WorkList {
 };
 
 // ----------------------------------------------------------------------------
+// verbose output (-v columns 6 and 7, ConsumerThread.cpp:527-536, :614-623, :820-824): produced by the
+// first-generation lanes only.  Column 6: the sequences whose names contribute an accession, first
+// kVbAcc distinct ones in the order ids_from_SI visits the rows (the host turns them into the sorted
+// set of name prefixes).  Column 7: the matched peptides, written as index-alphabet codes each followed
+// by 255 (MEM: the head match of every fragment that holds a longest match, :580-590; Greedy: every
+// best SI with the substitutions of its variant applied, :780-790).
+// ----------------------------------------------------------------------------
+constexpr int kVbAcc = 20;
+struct VerboseOut {           // all pointers null: verbose output off
+  uint32_t *n_acc;            // [n]
+  uint32_t *acc;              // [n][kVbAcc] sequence numbers
+  uint32_t *text_len;         // [n] bytes the peptides need (more than text_cap: truncated)
+  uint8_t *text;              // [n][text_cap]
+  uint32_t text_cap;
+};
+KJ_HD void vb_reset(const VerboseOut &vb, uint32_t r) { if (vb.n_acc) { vb.n_acc[r] = 0; vb.text_len[r] = 0; } }
+KJ_HD void vb_acc(const VerboseOut &vb, const DevIndex &ix, uint32_t r, uint32_t iseq) {
+  if (!vb.n_acc || iseq >= ix.nseq || (ix.seq_valid[iseq] & 3u) != 3u) return;
+  const uint32_t n = vb.n_acc[r];
+  if (n >= (uint32_t)kVbAcc) return;                       // match_dbnames.size() < max_match_acc, :822
+  uint32_t *a = vb.acc + (size_t)r * kVbAcc;
+  for (uint32_t q = 0; q < n; q++) if (a[q] == iseq) return;
+  a[n] = iseq; vb.n_acc[r] = n + 1;
+}
+// peptide pep[0..len) with up to nsub substitutions (positions relative to pep[0])
+KJ_HD void vb_text(const VerboseOut &vb, uint32_t r, const uint8_t *pep, uint32_t len, uint32_t nsub,
+                   const uint16_t *sub_pos, const uint8_t *sub_aa, int sub_shift) {
+  if (!vb.text) return;
+  uint32_t w = vb.text_len[r];
+  uint8_t *dst = vb.text + (size_t)r * vb.text_cap;
+  for (uint32_t x = 0; x < len; x++, w++) {
+    uint8_t c = pep[x];
+    for (uint32_t q = 0; q < nsub; q++) if ((int)sub_pos[q] - sub_shift == (int)x) c = sub_aa[q];
+    if (w < vb.text_cap) dst[w] = c;
+  }
+  if (w < vb.text_cap) dst[w] = 255;
+  vb.text_len[r] = w + 1;
+}
+// the query position of a match rides in the top bits of SIEntry::lo (rows need 40 bits)
+constexpr int kSiQiShift = 40;
+constexpr uint64_t kSiLoMask = (1ull << kSiQiShift) - 1ull;
+
+// ----------------------------------------------------------------------------
 // the locate half shared by MEM and Greedy (ids_from_SI ConsumerThread.cpp:799-845,
 // get_suffix bwt.c:105-121): one LF step per memory step
 // ----------------------------------------------------------------------------
@@ -1081,7 +1124,7 @@ enum MemState : int {
 
 template <class P>
 KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
-                    const LaneScratch &ls) {
+                    const LaneScratch &ls, const VerboseOut &vb = VerboseOut{nullptr, nullptr, nullptr, nullptr, 0}) {
   int st = MS_FETCH;
   uint32_t r = 0, nf = 0, f = 0, fcur = 0;
   const Frag *F = nullptr;
@@ -1148,6 +1191,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
     while (st < MS_STEP) {
       KJ_STAT({ const unsigned long long bal = __ballot(1); if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)bal) - 1)) stat_passes++; })
       if (st == MS_ADD_ID) {
+        vb_acc(vb, ix, r, iseq);                            // (before the id: :822-824, then :834)
         add_id(ix, hit, nids, iseq);
         row++;
         st = MS_LOC_ROW;
@@ -1157,7 +1201,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
         if (l >= L) {
           if (l > L) { nsi = 0; ovf = false; L = l; }      // shorter matches are dropped (bwt.c:366-370, :577-582)
           if (nsi < ls.si_cap) {
-            SIEntry e; e.lo = lo; e.len = (uint32_t)(int32_t)(hi - lo); e.frag = fcur;
+            SIEntry e; e.lo = (uint64_t)lo | (uint64_t)(uint32_t)i << kSiQiShift; e.len = (uint32_t)(int32_t)(hi - lo); e.frag = fcur;
             ls.si[nsi] = e;
           } else ovf = true;
           nsi++;
@@ -1206,11 +1250,13 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
               ge = gs + 1;
               while (ge < nsi && ls.si[ge].frag == fr) ge++;
               cur = ge;
+              // verbose: the head of the fragment's list (the match found last) gives the peptide
+              if (vb.text) vb_text(vb, r, pep + F[fr].start + (uint32_t)(ls.si[ge - 1].lo >> kSiQiShift), L, 0, nullptr, nullptr, 0);
             }
           }
           if (any) {
             cur--;
-            row = (P)ls.si[cur].lo; rowend = row + (P)(int32_t)ls.si[cur].len;
+            row = (P)(ls.si[cur].lo & kSiLoMask); rowend = row + (P)(int32_t)ls.si[cur].len;
             st = MS_LOC_ROW;
           }
         }
@@ -1233,6 +1279,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
             F = b.frags + rm.frag;
             pep = b.pep + rm.pep;
             f = 0; L = p.m; nsi = 0; found = false; ovf = false;
+            vb_reset(vb, r);
             st = MS_NEXT_FRAG;
           }
         }
@@ -1641,6 +1688,11 @@ struct GMatch {              // one SI of the current fragment (bwt.h:25-34), 32
 };
 
 struct GBest { uint64_t lo; uint32_t len; uint32_t pad; };
+struct GBestV {              // verbose: where the peptide of a best SI comes from
+  uint32_t start, qi, ql, num_mm;
+  uint16_t sub_pos[kMaxMismatch];
+  uint8_t sub_aa[kMaxMismatch];
+};
 
 struct GreedyScratch {
   GItem *pool;  uint32_t pool_cap;       // append-only item pool of the current read
@@ -1648,6 +1700,7 @@ struct GreedyScratch {
   GMatch *matches; uint32_t match_cap;
   GBest *best;                           // [64]
   uint8_t *win;
+  GBestV *bestv = nullptr;               // [64], verbose output only
 };
 
 struct GQueue { uint32_t head, tail, npool; bool overflow; };
@@ -1697,7 +1750,8 @@ enum GState : int {
 };
 
 KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
-                       const Batch &b, const WorkList &wl, const GreedyScratch &gs) {
+                       const Batch &b, const WorkList &wl, const GreedyScratch &gs,
+                       const VerboseOut &vb = VerboseOut{nullptr, nullptr, nullptr, nullptr, 0}) {
   int state = GS_FETCH;
   uint32_t r = 0;
   const uint8_t *pep = nullptr;
@@ -1740,6 +1794,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           q.head = q.tail = q.npool = 0; q.overflow = false;
           for (uint32_t f = 0; f < nf; f++) gq_push(gs, q, gitem_from_frag(F[f]));   // already in queue order
           best = 0; nbest = 0; flags = 0; m_ovf = false;
+          vb_reset(vb, r);
           state = GS_POP;
           break;
         }
@@ -1907,7 +1962,15 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
                 if (score < p.min_score) continue;
                 if (score > best) { best = score; nbest = 0; }
                 if (score == best) {
-                  if (nbest < p.max_matches_SI && nbest < 64) { GBest gb; gb.lo = mm.lo; gb.len = mm.len; gb.pad = 0; gs.best[nbest++] = gb; }
+                  if (nbest < p.max_matches_SI && nbest < 64) {
+                    GBest gb; gb.lo = mm.lo; gb.len = mm.len; gb.pad = 0;
+                    if (vb.text && gs.bestv) {             // verbose: what frag->seq.substr(qi, ql) will need (:783,:789)
+                      GBestV bv; bv.start = t.start; bv.qi = (uint32_t)mm.qi; bv.ql = (uint32_t)mm.ql; bv.num_mm = t.num_mm;
+                      for (int x = 0; x < kMaxMismatch; x++) { bv.sub_pos[x] = t.sub_pos[x]; bv.sub_aa[x] = t.sub_aa[x]; }
+                      gs.bestv[nbest] = bv;
+                    }
+                    gs.best[nbest++] = gb;
+                  }
                   else flags |= kHitSiCap;
                 }
               }
@@ -1940,6 +2003,12 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
             state = GS_LOC_DONE; break;
           }
           hit->best = nbest ? best : 0u;
+          if (vb.text && gs.bestv)
+            for (uint32_t x = 0; x < nbest; x++) {
+              const GBestV bv = gs.bestv[x];
+              vb_text(vb, r, pep + bv.start + bv.qi, bv.ql, bv.num_mm < (uint32_t)kMaxMismatch ? bv.num_mm : (uint32_t)kMaxMismatch,
+                      bv.sub_pos, bv.sub_aa, (int)bv.qi);
+            }
           cur = 0;
           state = GS_LOC_NEXT_SI;
           break;
@@ -1965,6 +2034,7 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           break;
         }
         case GS_ADD_ID: {
+          vb_acc(vb, ix, r, iseq);
           add_id(ix, hit, nids, iseq);
           row++;
           state = GS_LOC_ROW;

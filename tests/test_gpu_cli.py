@@ -1,5 +1,5 @@
 """The drop-in `kaiju` command (kaiju_amd/bin/kaiju) against the reference binary's output on
-the golden reads: same option letters, same lines (columns 1-5 of the -v output), input order."""
+the golden reads: same option letters, same lines (all seven columns of the -v output), input order."""
 import gzip
 import os
 import shutil
@@ -21,11 +21,12 @@ def run_cli(tmp_path, golden, args, name):
 
 
 def first5(path):
+    """all columns of the -v output (1-3 for unclassified reads); kept under its old name"""
     rows = []
     with open(path) as f:
         for line in f:
             p = line.rstrip("\n").split("\t")
-            rows.append(tuple(p[:5]) if p[0] == "C" else tuple(p[:3]))
+            rows.append(tuple(p[:7]) if p[0] == "C" else tuple(p[:3]))
     return rows
 
 

@@ -78,6 +78,31 @@ def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
             assert (ref[n][0] == "C") == bool(r["classified"]) and (not r["classified"] or int(r["taxon"]) == ref[n][1]), n
 
 
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_verbose_columns(gpu_lib, golden, gidx, mode, seg):
+    """kaiju -v columns 6 (accessions) and 7 (matched peptides) == the reference's lines, single and paired"""
+    api = gpu_lib
+    clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
+    tax = api.Taxonomy(golden.nodes)
+    for seqs, off, names, pe, tsv in ((golden.seqs, golden.off, golden.names, False, f"ref_{mode}_{seg}.tsv"),
+                                      (golden.pseqs, golden.poff, golden.pnames, True, f"ref_{mode}_{seg}_pe.tsv")):
+        hits, accs, peps = clf.classify_verbose(seqs, off, paired=pe)
+        plain = clf.classify(seqs, off, paired=pe)
+        assert all(util.same_hit(a, b) for a, b in zip(plain, hits))          # first-generation lanes == default lanes
+        res = clf.finalize(tax, hits, off, pe)
+        lines = {}
+        with open(os.path.join(golden.dir, tsv)) as f:
+            for line in f:
+                p = line.rstrip("\n").split("\t")
+                lines[p[1]] = p
+        for n, r, a, t in zip(names, res, accs, peps):
+            ref = lines[n]
+            if r["classified"]:
+                assert ref[0] == "C" and ref[5] == "".join(x + "," for x in a) and ref[6] == t, (n, ref[5:], a, t)
+            else:
+                assert ref[0] == "U"
+
+
 @pytest.mark.parametrize("mode", ["mem", "greedy"])
 def test_long_reads(gpu_lib, gidx, oracle, ohandles, mode):
     """reads of 400..3000 nt (alone and mixed with short ones): in-place stage 1, window refills, spills"""

@@ -1,0 +1,33 @@
+"""-v output of the drop-in CLI vs the reference binary on a prepared workload (GPU box):
+   cli_verbose_check.py <workdir from prof_prepare.py> <nreads>"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+W, n = sys.argv[1], int(sys.argv[2])
+reads = np.load(f"{W}/reads.npy")[:n]
+n, L = reads.shape
+fq = f"{W}/v_{n}.fq"
+with open(fq, "wb") as f:
+    f.write(b"".join(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + b"I" * L + b"\n" for i in range(n)))
+cli = os.path.join(ROOT, "kaiju_amd", "bin", "kaiju")
+ref = os.path.join(ROOT, "oracle", "_ref", "kaiju")
+for mode in ("mem", "greedy"):
+    for seg in ([], ["-X"]):
+        t = time.time()
+        subprocess.run([cli, "-t", f"{W}/nodes.dmp", "-f", f"{W}/db.fmi", "-i", fq, "-o", f"{W}/vg.tsv", "-a", mode, "-v"] + seg, check=True)
+        tg = time.time() - t
+        t = time.time()
+        subprocess.run([ref, "-z", str(os.cpu_count()), "-t", f"{W}/nodes.dmp", "-f", f"{W}/db.fmi", "-i", fq, "-o", f"{W}/vr.tsv",
+                        "-a", mode, "-v"] + seg, check=True)
+        tr = time.time() - t
+        a = sorted(open(f"{W}/vg.tsv").read().split("\n"))
+        b = sorted(open(f"{W}/vr.tsv").read().split("\n"))
+        bad = [(x, y) for x, y in zip(a, b) if x != y]
+        print(f"-a {mode} {' '.join(seg)} -v: {n} reads, GPU {tg:.1f}s, reference {tr:.1f}s, differing lines: {len(bad) + abs(len(a) - len(b))}", flush=True)
+        for x, y in bad[:3]:
+            print("  gpu:", x[:300]); print("  ref:", y[:300])
