@@ -64,6 +64,17 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   return ov ? -1 : n;
 }
 
+// verbose output (columns 6/7) of the next emu_classify calls: first-generation lanes write here
+static VerboseOut g_vb{nullptr, nullptr, nullptr, nullptr, 0};
+void emu_set_verbose(uint32_t *n_acc, uint32_t *acc, uint32_t *text_len, uint8_t *text, uint32_t text_cap) {
+  g_vb = VerboseOut{n_acc, acc, text_len, text, text_cap};
+}
+const char *emu_seq_name(void *h, uint32_t iseq) {
+  EmuIndex *ix = (EmuIndex *)h;
+  return iseq < ix->packed.names.size() ? ix->packed.names[iseq].c_str() : nullptr;
+}
+const char *emu_alphabet(void *h) { return ((EmuIndex *)h)->packed.alphabet.c_str(); }
+
 // fragments of one batch (stage 1): returns per-read lists as ASCII for comparison
 // frag_dump receives, per read, a "#" line followed by one "key:PEPTIDE" line per fragment
 int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const uint64_t *off, uint32_t n,
@@ -157,16 +168,18 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     if (p.mode == 0) {
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1", "wide" or default (v2 where possible)
-      if (d.blocks64 && d.kmer32 && !v && pass == 0) mem_lane2(d, p, b, wl, ls);
-      else if (d.sb32 && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls);
-      else mem_lane<uint64_t>(d, p, b, wl, ls);
+      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) mem_lane2(d, p, b, wl, ls);
+      else if (d.sb32 && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls, g_vb);
+      else mem_lane<uint64_t>(d, p, b, wl, ls, g_vb);
     } else {
       GreedyScratch gs;
       gs.pool = pool.data(); gs.pool_cap = (uint32_t)pool.size(); gs.ord = ord.data();
       gs.matches = matches.data(); gs.match_cap = (uint32_t)matches.size();
       gs.best = bestv.data(); gs.win = win;
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1" or default (v2 where possible)
-      if (d.blocks64 && d.kmer32 && !v && pass == 0) {
+      std::vector<GBestV> bestvv(64);
+      gs.bestv = g_vb.n_acc ? bestvv.data() : nullptr;
+      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) {
         alignas(16) uint32_t lds_win[kGWinStride], lds_mq[kGMqStride], lds_prio[kGPrioStride];
         for (auto &x : lds_win) x = 0xdeadbeefu;
         for (auto &x : lds_mq) x = 0xdeadbeefu;
@@ -180,7 +193,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         GreedyScratch2 g2{reinterpret_cast<uint8_t *>(lds_win), reinterpret_cast<uint16_t *>(lds_mq), lds_prio, pool2.data(),
                           prio_ext.data(), matches2.data(), mq_ext.data(), best2.data(), ge ? (uint32_t)atoi(ge) : 3u};
         greedy_lane2(d, ix->ct, p, sq, b, wl, g2);
-      } else greedy_lane(d, ix->ct, p, sq, b, wl, gs);
+      } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }
   static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");

@@ -199,3 +199,49 @@ def test_long_reads(oracle, emu, handles, mode):
         gh, _ = emu.classify(h, util.gp(mode, seg=seg), seqs, off)
         bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
         assert not bad, (mode, seg, bad[:5], len(reads[bad[0]]))
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_verbose_columns(emu, golden, handles, mode):
+    """columns 6 (accessions) and 7 (matched peptides) of kaiju -v from the first-generation lanes == the
+    reference's lines (single and paired, SEG on and off)"""
+    import ctypes as C
+    import os
+    from kaiju_amd import api
+    h = handles[0]
+    E = emu.lib
+    E.emu_set_verbose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    E.emu_seq_name.restype = C.c_char_p
+    E.emu_seq_name.argtypes = [C.c_void_p, C.c_uint32]
+    E.emu_alphabet.restype = C.c_char_p
+    E.emu_alphabet.argtypes = [C.c_void_p]
+    alpha = E.emu_alphabet(h)
+    tax = api.Taxonomy(golden.nodes)
+    cap = 8192
+    try:
+        for seg in (1, 0):
+            for seqs, off, names, pe, tsv in ((golden.seqs, golden.off, golden.names, False, f"ref_{mode}_{seg}.tsv"),
+                                              (golden.pseqs, golden.poff, golden.pnames, True, f"ref_{mode}_{seg}_pe.tsv")):
+                n = len(names)
+                nacc = np.zeros(n, dtype=np.uint32); acc = np.zeros(n * 20, dtype=np.uint32)
+                tlen = np.zeros(n, dtype=np.uint32); text = np.zeros(n * cap, dtype=np.uint8)
+                E.emu_set_verbose(nacc.ctypes.data, acc.ctypes.data, tlen.ctypes.data, text.ctypes.data, cap)
+                gh, _ = emu.classify(h, util.gp(mode, seg=seg), seqs, off, paired=pe)
+                lines = {}
+                with open(os.path.join(golden.dir, tsv)) as f:
+                    for line in f:
+                        p = line.rstrip("\n").split("\t")
+                        lines[p[1]] = p
+                for r, nm in enumerate(names):
+                    ref = lines[nm]
+                    if ref[0] != "C":
+                        continue
+                    accs = set()
+                    for q in range(int(nacc[r])):
+                        s = E.emu_seq_name(h, int(acc[r * 20 + q]))
+                        if s and b"_" in s:
+                            accs.add(s[: s.rindex(b"_")].decode())
+                    t = "".join("," if c == 255 else chr(alpha[c]) for c in text[r * cap: r * cap + int(tlen[r])])
+                    assert ref[5] == "".join(x + "," for x in sorted(accs)) and ref[6] == t, (mode, seg, pe, nm, ref[5:], accs, t)
+    finally:
+        E.emu_set_verbose(None, None, None, None, 0)
