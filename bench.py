@@ -114,7 +114,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("KAIJU_BENCH_READS", 10_000_000)),
                     help="reads per GPU per step")
-    ap.add_argument("--contexts", type=int, default=2, help="classification contexts that ping-pong the chunks")
+    ap.add_argument("--contexts", type=int, default=0,
+                    help="classification contexts that ping-pong the chunks (default: 2 for mem, 1 for greedy)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 5_000_000)))
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
     ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"])
@@ -178,7 +179,8 @@ def main():
     # Two classification contexts ping-pong the chunks on two HIP streams (the "two host threads per GPU
     # on separate streams" of SURVEY.md 8b): while one chunk is in its HBM-bound search kernel the next one
     # runs its ALU/latency-bound stage 1 and SEG pass.  --contexts 1 = strictly one chunk after the other.
-    nctx = max(1, args.contexts)
+    # (two overlapping Greedy kernels only slow each other down: both are bound by instruction issue)
+    nctx = args.contexts if args.contexts > 0 else (2 if args.mode == "mem" else 1)
     clfs = [clf] + [api.Classifier(index, params) for _ in range(nctx - 1)]
     for c in clfs:
         c.set_max_read_length(L)

@@ -692,6 +692,30 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   KJ_HIP(hipEventRecord(c->ev[4], s));
   c->ev_valid = true;
   c->last_n = n;
+  if (const char *dump = getenv("KAIJU_GPU_DUMP_FRAGS")) {
+    // developer aid: the fragment lists as the search kernels saw them, "#" per read then "key:PEPTIDE flags"
+    KJ_HIP(hipStreamSynchronize(s));
+    std::vector<ReadMeta> hm(n);
+    KJ_HIP(hipMemcpy(hm.data(), c->meta.p, (size_t)n * sizeof(ReadMeta), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> hp(c->pep.cap);
+    KJ_HIP(hipMemcpy(hp.data(), c->pep.p, c->pep.cap, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> hf(c->frags.cap);
+    KJ_HIP(hipMemcpy(hf.data(), c->frags.p, c->frags.cap, hipMemcpyDeviceToHost));
+    const Frag *F = reinterpret_cast<const Frag *>(hf.data());
+    if (FILE *fp = fopen(dump, "a")) {
+      const char *alpha = ix->info.alphabet;
+      for (uint32_t r = 0; r < n; r++) {
+        fprintf(fp, "#\n");
+        for (uint32_t k = 0; k < (hm[r].nfrag & ~kNfragSegPending); k++) {
+          const Frag &f = F[hm[r].frag + k];
+          fprintf(fp, "%u:", f.key);
+          for (uint32_t x = 0; x < f.len; x++) fputc(alpha[hp[hm[r].pep + f.start + x] % 21], fp);
+          fprintf(fp, "\n");
+        }
+      }
+      fclose(fp);
+    }
+  }
   return KAIJU_GPU_OK;
 }
 

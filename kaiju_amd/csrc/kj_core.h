@@ -661,10 +661,24 @@ struct NucReader {
 // Counts of the 20 letters in nibbles, the last 12 letters in a 60-bit shift register, the entropy
 // score at the 32-bit scale (host_tables.cpp checks that it classifies every window like libm).
 struct TrigCtx { const int32_t *g32; int32_t locut32; };
-// All of it in 32-bit registers: counts of the letters 0..7 / 8..15 / 16..19 in c0 / c1 / c2, the last six
-// letters in h0 and the six before them in h1 (5 bits each).
-struct TrigWin { uint32_t c0, c1, c2, h0, h1; int32_t score; };
-KJ_HD void trig_reset(TrigWin &w) { w.c0 = w.c1 = w.c2 = w.h0 = w.h1 = 0; w.score = 0; }
+struct TrigWin { uint64_t c0, c1, hist; int32_t score; };
+KJ_HD void trig_reset(TrigWin &w) { w.c0 = w.c1 = w.hist = 0; w.score = 0; }
+KJ_HD void trig_count(TrigWin &w, const TrigCtx &tc, uint32_t x, int d) {
+  const uint32_t sh = 4u * (x & 15u);
+  const uint32_t old = (uint32_t)((x < 16u ? w.c0 : w.c1) >> sh) & 15u;
+  w.score += tc.g32[(int)old + d] - tc.g32[old];
+  const uint64_t inc = (uint64_t)(int64_t)d << sh;
+  if (x < 16u) w.c0 += inc; else w.c1 += inc;
+}
+// residue with index-alphabet code a joins a run that now has run_len residues: does the 12-window
+// ending here reach the trigger entropy (H <= locut)?
+KJ_HD bool trig_push(TrigWin &w, const TrigCtx &tc, uint32_t a, uint32_t run_len) {
+  const uint32_t x = a - 1u;
+  trig_count(w, tc, x, +1);
+  if (run_len > (uint32_t)kSegWindow) trig_count(w, tc, (uint32_t)(w.hist >> 55) & 31u, -1);
+  w.hist = (w.hist << 5 | x) & ((1ull << 60) - 1ull);
+  return run_len >= (uint32_t)kSegWindow && w.score <= tc.locut32;
+}
 
 // a run of residues between two stops becomes a fragment if it is long enough (and, Greedy, scores
 // enough).  Fragments are appended as they are found, flags = seq << 1 | trig, where seq is the
@@ -739,24 +753,26 @@ KJ_HD void translate_mate(const ConstTables &t, const Params &p, const TrigCtx &
       aa[3 + g] = bad ? 0u : vr;
     }
     a = cN[1]; bb = cN[2];
-    // entropy of the 12-windows: letter x joins, letter y (12 back) leaves once the run is longer than 12.
-    // The score is a sum over the letters, so the two changes are independent unless x == y (no change).
+    // entropy of the 12-windows: letter x joins, letter y (12 back) leaves once the run is longer than 12
     int32_t dsc[6];
-    uint32_t incx[6], decy[6];
+    uint32_t xs[6], ys[6];
+    bool rem[6];
     if (p.seg) {
 #pragma unroll
       for (int h = 0; h < 6; h++) {
         const TrigWin &w = h < 3 ? Fw[h] : Rw[h - 3];
         const uint32_t rl = (h < 3 ? F_len[h] : R_len[h - 3]) + 1u;
-        const uint32_t x = (aa[h] - 1u) & 31u, y = w.h1 >> 25;
-        const uint32_t wx = (x & 16u) ? w.c2 : (x & 8u) ? w.c1 : w.c0, wy = (y & 16u) ? w.c2 : (y & 8u) ? w.c1 : w.c0;
-        const uint32_t cx = (wx >> (4u * (x & 7u))) & 15u, cy = (wy >> (4u * (y & 7u))) & 15u;
-        const bool rem = rl > (uint32_t)kSegWindow, same = rem && x == y;
+        const uint32_t x = (aa[h] - 1u) & 31u, y = (uint32_t)(w.hist >> 55) & 31u;
+        const uint32_t cx = (uint32_t)((x < 16u ? w.c0 : w.c1) >> (4u * (x & 15u))) & 15u;
+        const uint32_t cy = (uint32_t)((y < 16u ? w.c0 : w.c1) >> (4u * (y & 15u))) & 15u;
+        rem[h] = rl > (uint32_t)kSegWindow;
         const int32_t dA = tc.g32[cx + 1u] - tc.g32[cx];
         const int32_t dR = tc.g32[(cy - 1u) & 15u] - tc.g32[cy];
-        dsc[h] = same ? 0 : dA + (rem ? dR : 0);
-        incx[h] = same ? 0u : 1u << (4u * (x & 7u));
-        decy[h] = (rem && !same) ? 1u << (4u * (y & 7u)) : 0u;
+        const bool same = rem[h] && x == y;                 // the same letter joins and leaves: nothing changes
+        dsc[h] = same ? 0 : dA + (rem[h] ? dR : 0);
+        xs[h] = x; ys[h] = y;
+        if (same) rem[h] = false;
+        if (same) xs[h] = 32u;                               // (32: no count changes)
       }
     }
 #pragma unroll
@@ -769,20 +785,19 @@ KJ_HD void translate_mate(const ConstTables &t, const Params &p, const TrigCtx &
       TrigWin &w = fwd ? Fw[g] : Rw[g];
       const uint32_t fpos = base + (uint32_t)g * fcap + q, rpos = rbase + (uint32_t)g * fcap + (R0[g] - q);
       const uint32_t pos = fwd ? fpos : rpos;
-      const bool res = ok[g] && aa[h] != 0;                  // a residue joins the run
-      if (ok[g] && !(p.debug & 2u)) pep.put(pos, (uint8_t)aa[h]);
-      rlen += res ? 1u : 0u;
-      if (p.mode == 1) rsum += res ? (uint32_t)(((aa[h] & 16u) ? dg1 : dg0) >> (4u * (aa[h] & 15u))) & 15u : 0u;
-      if (p.seg) {
-        const uint32_t x = (aa[h] - 1u) & 31u, y = w.h1 >> 25;
-        w.score += res ? dsc[h] : 0;
-        const uint32_t ix = res ? incx[h] : 0u, dy = res ? decy[h] : 0u;
-        w.c0 += ((x & 24u) == 0u ? ix : 0u) - ((y & 24u) == 0u ? dy : 0u);
-        w.c1 += ((x & 24u) == 8u ? ix : 0u) - ((y & 24u) == 8u ? dy : 0u);
-        w.c2 += ((x & 16u) ? ix : 0u) - ((y & 16u) ? dy : 0u);
-        const uint32_t nh1 = ((w.h1 << 5) | (w.h0 >> 25)) & 0x3fffffffu, nh0 = ((w.h0 << 5) | x) & 0x3fffffffu;
-        w.h1 = res ? nh1 : w.h1; w.h0 = res ? nh0 : w.h0;
-        trig = trig || (res && rlen >= (uint32_t)kSegWindow && w.score <= tc.locut32);
+      if (ok[g]) {
+        if (!(p.debug & 2u)) pep.put(pos, (uint8_t)aa[h]);
+        if (aa[h] != 0) {
+          rlen++;
+          if (p.mode == 1) rsum += (uint32_t)(((aa[h] & 16u) ? dg1 : dg0) >> (4u * (aa[h] & 15u))) & 15u;
+          if (p.seg) {
+            w.score += dsc[h];
+            if (xs[h] < 32u) { const uint64_t inc = 1ull << (4u * (xs[h] & 15u)); if (xs[h] < 16u) w.c0 += inc; else w.c1 += inc; }
+            if (rem[h]) { const uint64_t dec = 1ull << (4u * (ys[h] & 15u)); if (ys[h] < 16u) w.c0 -= dec; else w.c1 -= dec; }
+            w.hist = (w.hist << 5 | ((aa[h] - 1u) & 31u)) & ((1ull << 60) - 1ull);
+            trig = trig || (rlen >= (uint32_t)kSegWindow && w.score <= tc.locut32);
+          }
+        }
       }
     }
     // stops close runs
