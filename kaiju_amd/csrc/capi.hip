@@ -937,8 +937,13 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
   if (getenv("KAIJU_GPU_PRINT_STATS")) {
     unsigned long long acc[6] = {0};
     KJ_HIP(hipMemcpy(acc, static_cast<uint32_t *>(ctx->counters.p) + 8, sizeof acc, hipMemcpyDeviceToHost));
-    fprintf(stderr, "[kj stats] lane-iters %llu step %llu kmer %llu lf %llu | sum over waves of max iters %llu, max passes %llu\n",
-            acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+    if (ctx->params.mode == 0)
+      fprintf(stderr, "[kj stats] lane-iters %llu step %llu kmer %llu lf %llu | sum over waves of max iters %llu, max passes %llu\n",
+              acc[0], acc[1], acc[2], acc[3], acc[4], acc[5]);
+    else
+      fprintf(stderr, "[kj stats] greedy lane loop, cycles summed over waves: heavy chain %llu, load issue %llu, fast compute+book %llu, "
+                      "slow compute %llu, loop head %llu | iterations (sum of last-wave counters) %llu heavy %llu\n",
+              acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] >> 32, acc[5] & 0xffffffffull);
   }
   stats->n_reads = ctx->last_n;
   stats->n_overflow_retries = cnt[2];

@@ -1405,6 +1405,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0;                 // the wave's chunk of work items (wave-uniform)
   const RankBlock64 *const blk0 = ix.blocks64;
+  // the k-mer index of end position j-1 follows from that of j: drop the first letter, append one
+  uint32_t kpow = 1;                            // 20^(kk-1)
+  for (uint32_t q = 1; q < kk; q++) kpow *= 20u;
+  uint32_t kfirst = 1;                          // first letter of the k-mer kidx stands for
+  bool kroll = false;                           // kidx is the k-mer of end position j+1 of this fragment
 
   auto si_lo = [&](uint32_t e) -> P { return e == 0 ? s0lo : e == 1 ? s1lo : (P)ls.si[e].lo; };
   auto si_len = [&](uint32_t e) -> uint32_t { return e == 0 ? s0len : e == 1 ? s1len : ls.si[e].len; };
@@ -1593,8 +1598,12 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (j < (int)L - 1) bk = BK_NEXT_FRAG;
         else if (kk && j >= (int)kk - 1) {
           if (in_win(j) && in_win(j - (int)kk + 1)) {
-            kidx = 0;
-            for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
+            if (kroll) kidx = (kidx - (kfirst - 1u) * kpow) * 20u + ((uint32_t)lw.w[j - (int)kk + 1 - lw.q] - 1u);
+            else {
+              kidx = 0;
+              for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
+            }
+            kfirst = lw.w[j - lw.q]; kroll = true;
             kind = K_KMER; bk = BK_NONE;
           } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
         } else if (in_win(j)) {
@@ -1613,7 +1622,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         else {
           fcur = f; f++;
           fsoff = pepoff + dnext.start; flen = (int)dnext.len;
-          j = flen - 1;
+          j = flen - 1; kroll = false;
           fill_top = j; fill_newfrag = true; fill_step = false;
           kind = K_FILL; bk = BK_NONE;
         }
@@ -2206,6 +2215,11 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0, itc = 0;
   const RankBlock64 *const blk0 = ix.blocks64;
+  // the k-mer index (and diagonal sum) of end position j-1 follows from that of j
+  uint32_t kpow = 1;
+  for (uint32_t q = 1; q < kk; q++) kpow *= 20u;
+  uint32_t kacc = 0;
+  bool kroll = false;                           // kidx / kacc / cj describe end position j+1 of this search
   // BLOSUM62 diagonal by index-alphabet code, 4 bits each (values 4..11)
   uint64_t dg0 = 0, dg1 = 0;
   for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
@@ -2270,9 +2284,16 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
   };
 
+#if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long st_t = clock64(), st_heavy = 0, st_load = 0, st_fast = 0, st_slow = 0, st_book = 0, st_nheavy = 0;
+#define KJ_TICK(acc) { const unsigned long long _n = clock64(); acc += _n - st_t; st_t = _n; }
+#else
+#define KJ_TICK(acc)
+#endif
   for (;;) {
     const bool heavy = (itc & gs.gate) == 0;               // wave-uniform
     itc++;
+    KJ_TICK(st_book)
     if (heavy) {
       // ---- (H0) the slow bookkeeping of the parked lanes, up to their next memory access ----
       int bk = GB_NONE;
@@ -2409,7 +2430,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                 }
                 continue;                                   // bk stays GB_POP
               }
-              flen = (int)t_len; nm = 0;
+              flen = (int)t_len; nm = 0; kroll = false;
               j = flen - 1; tail = 0;                       // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
               fill_top = j; fill_ret = FR_START_J; fill_pref = true; kind = G_FILL; bk = GB_NONE;
             }
@@ -2479,6 +2500,10 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     }
 
     // ---- (1) load phase ----
+    KJ_TICK(st_heavy)
+#if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
+    if (heavy) st_nheavy++;
+#endif
     KJ_HISTO(6, kind);
     const bool is_step = kind == G_STEP, is_vm = kind == G_VMULTI, is_lf = kind == G_LF1 || kind == G_LF2;
     const P vlo = m_lo, vhi = m_lo + m_len;
@@ -2521,6 +2546,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     }
 
     // ---- (2) compute ----
+    KJ_TICK(st_load)
     int bk = GB_NONE;
     if (is_step || kind == G_LF2) {
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
@@ -2572,6 +2598,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       k = row; fresh = true;
       bk = GB_LOC_ROW;
     } else if (heavy) {
+      KJ_TICK(st_fast)
       if (is_vm) {
         // UpdateSI(trans[substitute]) on the interval of the match for all substitutes at once
         // (ConsumerThread.cpp:366-392): the ranks of the 20 letters at both ends of the interval
@@ -2690,7 +2717,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           sp0 = (uint32_t)(xa2.x >> 32); sp1 = (uint32_t)xa2.y; sp2 = (uint32_t)(xa2.y >> 32); sp3 = (uint32_t)xa3.x;
           sa0 = (uint32_t)(xa3.x >> 32); sa1 = (uint32_t)xa3.y;
           const uint32_t wtag = (uint32_t)(xa3.y >> 32);
-          flen = (int)t_len; nm = 0;
+          flen = (int)t_len; nm = 0; kroll = false;
           j = flen - 1;
           if (t_nmm == 0) {
             // a SEG piece: maxMatches like an original
@@ -2739,6 +2766,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     }
 
     // ---- (3) fast bookkeeping; everything else waits for the next heavy iteration ----
+    if (heavy) { KJ_TICK(st_slow) } else { KJ_TICK(st_fast) }
     while (bk != GB_NONE) {
       if (bk == GB_END_MATCH) {
         const int l = j - i + 1;
@@ -2770,16 +2798,22 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         else if (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1))) {
           fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;
         } else if (kk && j >= (int)kk - 1) {
-          kidx = 0; acc = 0;
-          cj = win[j - wq];
-          for (uint32_t q = 0; q < kk; q++) {
-            const uint32_t cq = win[j - (int)q - wq];
-            kidx = kmer_index(kidx, cq);
-            acc += diag(cq);
+          if (kroll) {
+            const uint32_t cn = win[j - (int)kk + 1 - wq];
+            kidx = (kidx - (cj - 1u) * kpow) * 20u + (cn - 1u);
+            kacc = kacc - diag(cj) + diag(cn);
+          } else {
+            kidx = 0; kacc = 0;
+            for (uint32_t q = 0; q < kk; q++) {
+              const uint32_t cq = win[j - (int)q - wq];
+              kidx = kmer_index(kidx, cq);
+              kacc += diag(cq);
+            }
           }
+          cj = win[j - wq]; acc = kacc; kroll = true;
           kind = G_KMER; bk = GB_NONE;
         } else {
-          c = cj = win[j - wq];
+          c = cj = win[j - wq]; kroll = false;
           lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];                              // InitialSI, bwt.c:146-152
           acc = diag(c);
           i = j;
@@ -2792,6 +2826,14 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       if (bk > GB_LOC_ROW) { bk_pend = bk; kind = G_WAIT; bk = GB_NONE; }
     }
   }
+#if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
+  if ((threadIdx.x & 63u) == 0) {
+    // experiment only: cycles per section of the lane loop, summed over the wavefronts
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(wl.counter) & ~(uintptr_t)63) + 32);
+    atomicAdd(acc + 0, st_heavy); atomicAdd(acc + 1, st_load); atomicAdd(acc + 2, st_fast);
+    atomicAdd(acc + 3, st_slow); atomicAdd(acc + 4, st_book); atomicAdd(acc + 5, (unsigned long long)itc << 32 | st_nheavy);
+  }
+#endif
 }
 
 // ----------------------------------------------------------------------------
