@@ -138,6 +138,11 @@ int kaiju_gpu_device_count(void);
 /* ---- index ---------------------------------------------------------- */
 int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_gpu_index **out);
 int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *view, int device_id, kaiju_gpu_index **out);
+/* Device image of an index: the arrays of the HBM layout, packed once on the host and
+   written to a file; kaiju_gpu_index_load() recognises such a file by its magic and uploads it without
+   parsing or packing anything.  Needs no GPU. */
+int kaiju_gpu_index_write_image(const char *fmi_path, const char *image_path);
+
 int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info);
 void kaiju_gpu_index_free(kaiju_gpu_index *ix);
 

@@ -144,6 +144,13 @@ class Index:
             pass
 
 
+def write_index_image(fmi_path: str, image_path: str):
+    """pack a .fmi once into the HBM layout and write it as a device image (loads with Index(image_path))"""
+    L = lib()
+    L.kaiju_gpu_index_write_image.argtypes = [C.c_char_p, C.c_char_p]
+    _check(L.kaiju_gpu_index_write_image(fmi_path.encode(), image_path.encode()))
+
+
 class Taxonomy:
     def __init__(self, nodes_dmp: str):
         self._h = C.c_void_p()

@@ -307,6 +307,8 @@ static int upload(kaiju_gpu_index *ix, const std::vector<T> &v, const T **dst) {
   return 0;
 }
 
+static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out);
+
 static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_index **out) {
   if (!out) return fail(KAIJU_GPU_ERR_ARG, "out is NULL");
   *out = nullptr;
@@ -318,6 +320,13 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
   PackedIndex pk;
   int rc = pk.build(v, msg);
   if (rc) return fail(rc, msg);
+  return index_from_packed(pk, device_id, out);
+}
+
+// upload of the packed arrays (from a freshly packed .fmi or from an image file)
+static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out) {
+  std::string msg;
+  int rc;
   std::unique_ptr<kaiju_gpu_index> ix(new kaiju_gpu_index());
   ix->device = device_id;
   rc = build_const_tables(pk.trans, ix->ct_host, msg);
@@ -394,11 +403,43 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
   return KAIJU_GPU_OK;
 }
 
+// does the file start with the magic of an index image?
+static bool is_image_file(const char *path) {
+  char m[8] = {0};
+  FILE *fp = fopen(path, "rb");
+  if (!fp) return false;
+  const bool ok = fread(m, 1, 8, fp) == 8 && memcmp(m, "KJGPUIM", 7) == 0;
+  fclose(fp);
+  return ok;
+}
+
+extern "C" int kaiju_gpu_index_write_image(const char *fmi_path, const char *image_path) {
+  if (!fmi_path || !image_path) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  FmiFile f;
+  std::string msg;
+  int rc = f.load(fmi_path, msg);
+  if (rc) return fail(rc, msg);
+  PackedIndex pk;
+  if ((rc = pk.build(f.view(), msg))) return fail(rc, msg);
+  if ((rc = pk.write_image(image_path, msg))) return fail(rc, msg);
+  return KAIJU_GPU_OK;
+}
+
 extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_gpu_index **out) {
   if (!fmi_path || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(KAIJU_GPU_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+  if (device_id < 0 || device_id >= ndev) return fail(KAIJU_GPU_ERR_ARG, "device_id out of range");
+  if (is_image_file(fmi_path)) {
+    // a pre-packed image (kaiju_gpu_index_write_image): no parsing, no packing
+    PackedIndex pk;
+    std::string msg;
+    const int rc = pk.read_image(fmi_path, msg);
+    if (rc) return fail(rc, msg);
+    return index_from_packed(pk, device_id, out);
+  }
   FmiFile f;
   std::string msg;
   int rc = f.load(fmi_path, msg);

@@ -290,6 +290,88 @@ void PackedIndex::build_kmer_table(uint32_t k) {
   kmer_k = k;
 }
 
+// ---- device image file: header, then every array as (u64 element count, raw elements) ----
+namespace {
+const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '2'};
+struct ImgHeader {
+  char magic[8];
+  uint64_t sizes[8];          // sizeof RankBlock, RankBlock64, uint2, ulonglong2 (layout guard) + spare
+  uint64_t C[22];
+  uint64_t bwtlen, n_sa, sa_skip;
+  uint32_t nseq, chpt_exp, alen, warnings, kmer_k, pad;
+  uint8_t trans[128];
+  char alphabet[64];
+};
+template <class T> bool put_vec(FILE *fp, const std::vector<T> &v) {
+  const uint64_t n = v.size();
+  return fwrite(&n, 8, 1, fp) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, fp) == n);
+}
+template <class T> bool get_vec(FILE *fp, std::vector<T> &v) {
+  uint64_t n = 0;
+  if (fread(&n, 8, 1, fp) != 1 || n > (1ull << 40)) return false;
+  v.resize((size_t)n);
+  return n == 0 || fread(v.data(), sizeof(T), n, fp) == n;
+}
+}  // namespace
+
+int PackedIndex::write_image(const char *path, std::string &msg) const {
+  FILE *fp = fopen(path, "wb");
+  if (!fp) { msg = std::string("cannot write ") + path; return KAIJU_GPU_ERR_IO; }
+  ImgHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, kImageMagic, 8);
+  h.sizes[0] = sizeof(RankBlock); h.sizes[1] = sizeof(RankBlock64); h.sizes[2] = sizeof(uint2); h.sizes[3] = sizeof(ulonglong2);
+  memcpy(h.C, C, sizeof C);
+  h.bwtlen = bwtlen; h.n_sa = n_sa; h.sa_skip = sa_skip; h.nseq = nseq; h.chpt_exp = chpt_exp; h.alen = alen;
+  h.warnings = warnings; h.kmer_k = kmer_k;
+  memcpy(h.trans, trans, 128);
+  snprintf(h.alphabet, sizeof h.alphabet, "%s", alphabet.c_str());
+  bool ok = fwrite(&h, sizeof h, 1, fp) == 1;
+  ok = ok && put_vec(fp, blocks) && put_vec(fp, blocks64) && put_vec(fp, sa_taxid) && put_vec(fp, sb) && put_vec(fp, sb32) &&
+       put_vec(fp, sa_iseq) && put_vec(fp, seq_taxid) && put_vec(fp, seq_valid) && put_vec(fp, term_pos) &&
+       put_vec(fp, kmer32) && put_vec(fp, kmer64);
+  // names: lengths then the characters
+  std::vector<uint32_t> nl(names.size());
+  std::vector<char> nc;
+  for (size_t i = 0; i < names.size(); i++) { nl[i] = (uint32_t)names[i].size(); nc.insert(nc.end(), names[i].begin(), names[i].end()); }
+  ok = ok && put_vec(fp, nl) && put_vec(fp, nc);
+  ok = (fclose(fp) == 0) && ok;
+  if (!ok) { msg = std::string("short write to ") + path; return KAIJU_GPU_ERR_IO; }
+  return 0;
+}
+
+int PackedIndex::read_image(const char *path, std::string &msg) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
+  ImgHeader h;
+  bool ok = fread(&h, sizeof h, 1, fp) == 1 && memcmp(h.magic, kImageMagic, 8) == 0 && h.sizes[0] == sizeof(RankBlock) &&
+            h.sizes[1] == sizeof(RankBlock64) && h.sizes[2] == sizeof(uint2) && h.sizes[3] == sizeof(ulonglong2);
+  if (!ok) { fclose(fp); msg = "not a kaiju GPU index image (or written by another version)"; return KAIJU_GPU_ERR_FORMAT; }
+  memcpy(C, h.C, sizeof C);
+  bwtlen = h.bwtlen; n_sa = h.n_sa; sa_skip = h.sa_skip; nseq = h.nseq; chpt_exp = h.chpt_exp; alen = h.alen;
+  warnings = h.warnings; kmer_k = h.kmer_k;
+  memcpy(trans, h.trans, 128);
+  h.alphabet[sizeof h.alphabet - 1] = 0;
+  alphabet = h.alphabet;
+  std::vector<uint32_t> nl;
+  std::vector<char> nc;
+  ok = get_vec(fp, blocks) && get_vec(fp, blocks64) && get_vec(fp, sa_taxid) && get_vec(fp, sb) && get_vec(fp, sb32) &&
+       get_vec(fp, sa_iseq) && get_vec(fp, seq_taxid) && get_vec(fp, seq_valid) && get_vec(fp, term_pos) &&
+       get_vec(fp, kmer32) && get_vec(fp, kmer64) && get_vec(fp, nl) && get_vec(fp, nc);
+  fclose(fp);
+  uint64_t total = 0;
+  for (uint32_t l : nl) total += l;
+  // consistency of what the kernels will index
+  ok = ok && total == nc.size() && nl.size() == nseq && seq_taxid.size() == nseq && seq_valid.size() == nseq &&
+       blocks.size() == (size_t)(bwtlen >> 7) + 1 && (blocks64.empty() || blocks64.size() == (size_t)(bwtlen >> 6) + 1) &&
+       sa_iseq.size() >= n_sa && sa_taxid.size() >= n_sa;
+  if (!ok) { msg = "truncated or inconsistent index image"; return KAIJU_GPU_ERR_FORMAT; }
+  names.resize(nl.size());
+  size_t o = 0;
+  for (size_t i = 0; i < nl.size(); i++) { names[i].assign(nc.data() + o, nl[i]); o += nl[i]; }
+  return 0;
+}
+
 uint64_t PackedIndex::bytes() const {
   return blocks.size() * sizeof(RankBlock) + sb.size() * 8 + sa_iseq.size() * 4 + seq_taxid.size() * 8 +
          seq_valid.size() + term_pos.size() * 8 + kmer32.size() * 8 + kmer64.size() * 16 + sb32.size() * 4 +

@@ -77,6 +77,9 @@ struct PackedIndex {
   uint64_t bytes() const;
   // DevIndex whose pointers refer to THIS object's host vectors (used by the test emulation)
   DevIndex host_view() const;
+  // the packed arrays as one file ("device image": written once, loaded instead of parsing and packing the .fmi)
+  int write_image(const char *path, std::string &msg) const;
+  int read_image(const char *path, std::string &msg);
 };
 
 // name -> taxon id with the rule of ids_from_SI (ConsumerThread.cpp:809-833)

@@ -203,6 +203,24 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
 
 }  // extern "C"
 
+// device image of an index: pack, write, read back; 0 if every array survives unchanged
+extern "C" int emu_image_roundtrip(const char *fmi, const char *image) {
+  FmiFile f; std::string msg;
+  if (f.load(fmi, msg)) return -1;
+  PackedIndex a, b;
+  if (a.build(f.view(), msg)) return -2;
+  if (a.write_image(image, msg)) return -3;
+  if (b.read_image(image, msg)) return -4;
+  auto same = [](const auto &x, const auto &y) { return x.size() == y.size() && (x.empty() || !memcmp(x.data(), y.data(), x.size() * sizeof(x[0]))); };
+  if (!same(a.blocks, b.blocks) || !same(a.blocks64, b.blocks64) || !same(a.sa_taxid, b.sa_taxid) || !same(a.sb, b.sb) ||
+      !same(a.sb32, b.sb32) || !same(a.sa_iseq, b.sa_iseq) || !same(a.seq_taxid, b.seq_taxid) || !same(a.seq_valid, b.seq_valid) ||
+      !same(a.term_pos, b.term_pos) || !same(a.kmer32, b.kmer32) || !same(a.kmer64, b.kmer64)) return 1;
+  if (a.names != b.names || a.alphabet != b.alphabet || memcmp(a.C, b.C, sizeof a.C) || memcmp(a.trans, b.trans, 128)) return 2;
+  if (a.bwtlen != b.bwtlen || a.n_sa != b.n_sa || a.sa_skip != b.sa_skip || a.nseq != b.nseq || a.chpt_exp != b.chpt_exp ||
+      a.alen != b.alen || a.warnings != b.warnings || a.kmer_k != b.kmer_k) return 3;
+  return 0;
+}
+
 // LCA of the device path on the host arrays of the table (tests/test_capi.py)
 #include "../../kaiju_amd/csrc/taxonomy.h"
 extern "C" uint64_t emu_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n) {

@@ -117,3 +117,21 @@ def test_device_lca_logic_matches_host_lca(tmp_path):
         else:
             ids = rng.choice(pool, n).astype(np.uint64)
         assert tax.lca(ids) == emu.lib.emu_lca(tax._h, ids.ctypes.data, n), ids
+
+
+def test_index_image_roundtrip(golden, tmp_path):
+    """device image of an index (kaiju_gpu_index_write_image): every packed array survives the file; a truncated or
+    foreign file is refused"""
+    import ctypes as C
+    import util
+    from kaiju_amd import api
+    emu = util.Emu()
+    emu.lib.emu_image_roundtrip.argtypes = [C.c_char_p, C.c_char_p]
+    img = str(tmp_path / "db.kjimg")
+    assert emu.lib.emu_image_roundtrip(golden.fmi.encode(), img.encode()) == 0
+    L = api.lib()
+    L.kaiju_gpu_index_write_image.argtypes = [C.c_char_p, C.c_char_p]
+    img2 = str(tmp_path / "db2.kjimg")
+    assert L.kaiju_gpu_index_write_image(golden.fmi.encode(), img2.encode()) == 0
+    assert open(img, "rb").read() == open(img2, "rb").read()
+    assert L.kaiju_gpu_index_write_image(b"/nonexistent.fmi", img2.encode()) != 0

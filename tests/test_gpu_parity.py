@@ -78,6 +78,25 @@ def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
             assert (ref[n][0] == "C") == bool(r["classified"]) and (not r["classified"] or int(r["taxon"]) == ref[n][1]), n
 
 
+def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
+    """an index loaded from its device image classifies exactly like the one packed from the .fmi"""
+    api = gpu_lib
+    img = str(tmp_path / "db.kjimg")
+    api.write_index_image(golden.fmi, img)
+    idx2 = api.Index(img)
+    assert idx2.info.bwtlen == gidx.info.bwtlen and idx2.info.nseq == gidx.info.nseq
+    for mode in ("mem", "greedy"):
+        a = api.Classifier(gidx, api.default_params(mode, seg=1)).classify(golden.seqs, golden.off)
+        b = api.Classifier(idx2, api.default_params(mode, seg=1)).classify(golden.seqs, golden.off)
+        assert (a == b).all()
+    # a damaged image is refused
+    data = open(img, "rb").read()
+    bad = str(tmp_path / "bad.kjimg")
+    open(bad, "wb").write(data[: len(data) // 2])
+    with pytest.raises(Exception):
+        api.Index(bad)
+
+
 @pytest.mark.parametrize("mode,seg", CASES)
 def test_verbose_columns(gpu_lib, golden, gidx, mode, seg):
     """kaiju -v columns 6 (accessions) and 7 (matched peptides) == the reference's lines, single and paired"""
