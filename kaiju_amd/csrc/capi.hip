@@ -132,7 +132,18 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
-  mem_lane2(ix, p, b, wl, ls);
+  mem_lane2<false>(ix, p, b, wl, ls);
+}
+// the same lane with 64-bit positions: indexes of 2^32 rows and more (counts relative to mb_base, 16-byte k-mer entries)
+__global__ void __launch_bounds__(kBlock, 3)
+k_mem_wide2(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  mem_lane2<true>(ix, p, b, wl, ls);
 }
 // first-generation lane with 32-bit positions (kept for A/B measurements: KAIJU_GPU_MEM_LANE=v1)
 __global__ void __launch_bounds__(kBlock)
@@ -240,6 +251,35 @@ k_kmer_extend(const RankBlock64 *__restrict__ blk, const uint2 *__restrict__ par
   }
 }
 
+// the same for indexes with 64-bit positions: 16-byte entries {lo, len}, counts relative to mb_base
+__global__ void __launch_bounds__(256)
+k_kmer_extend_wide(const RankBlock64 *__restrict__ blk, const uint64_t *__restrict__ mb_base, uint32_t mb_shift,
+                   const ulonglong2 *__restrict__ parent, ulonglong2 *__restrict__ child, uint64_t n_parent) {
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < n_parent; idx += (uint64_t)gridDim.x * 256) {
+    const ulonglong2 e = parent[idx];
+    ulonglong2 *dst = child + idx * 20;
+    if (e.y == 0) {
+      for (int c = 0; c < 20; c++) dst[c] = make_ulonglong2(0, 0);
+      continue;
+    }
+    const uint64_t lo = e.x, hi = e.x + e.y;
+    const RankBlock64 &A = blk[lo >> 6], &B = blk[hi >> 6];
+    const uint64_t *ma0 = mb_base + (lo >> mb_shift) * 20, *mb0 = mb_base + (hi >> mb_shift) * 20;
+    const uint64_t lowA = (1ull << (lo & 63u)) - 1ull, lowB = (1ull << (hi & 63u)) - 1ull;
+#pragma unroll
+    for (int c = 1; c <= 20; c++) {
+      uint64_t ma = lowA, mb = lowB;
+#pragma unroll
+      for (int bit = 0; bit < 5; bit++) {
+        ma &= ((c >> bit) & 1) ? A.plane[bit] : ~A.plane[bit];
+        mb &= ((c >> bit) & 1) ? B.plane[bit] : ~B.plane[bit];
+      }
+      const uint64_t ra = ma0[c - 1] + A.cnt[c - 1] + (uint64_t)__popcll(ma), rb = mb0[c - 1] + B.cnt[c - 1] + (uint64_t)__popcll(mb);
+      dst[c - 1] = ra < rb ? make_ulonglong2(ra, rb - ra) : make_ulonglong2(0, 0);
+    }
+  }
+}
+
 static_assert(sizeof(ConstTables) % 4 == 0, "ConstTables is copied as dwords");
 static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");
 
@@ -342,6 +382,8 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   if (!pk.sb32.empty() && (rc = upload(ix.get(), pk.sb32, &d.sb32))) return rc;
   d.blocks64 = nullptr;
   if (!pk.blocks64.empty() && (rc = upload(ix.get(), pk.blocks64, &d.blocks64))) return rc;
+  d.mb_base = nullptr; d.mb_shift = pk.mb_shift;
+  if (!pk.mb_base.empty() && (rc = upload(ix.get(), pk.mb_base, &d.mb_base))) return rc;
   if ((rc = upload(ix.get(), pk.sa_taxid, &d.sa_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.sa_iseq, &d.sa_iseq))) return rc;
   if ((rc = upload(ix.get(), pk.seq_taxid, &d.seq_taxid))) return rc;
@@ -387,6 +429,27 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
       }
       d.kmer32 = cur;
       kmer_bytes = np * sizeof(uint2) - pk.kmer32.size() * sizeof(uint2);
+    }
+    if (d.kmer64 && d.blocks64 && d.mb_base && want > d.kmer_k) {
+      uint64_t np = 1;
+      for (uint32_t q = 0; q < d.kmer_k; q++) np *= 20;
+      const ulonglong2 *cur = d.kmer64;
+      void *cur_alloc = ix->allocs.back();
+      while (d.kmer_k < want) {
+        void *child = nullptr;
+        if (hipMalloc(&child, np * 20 * sizeof(ulonglong2) + 64) != hipSuccess) { (void)hipGetLastError(); break; }
+        const uint64_t blocks = std::min<uint64_t>((np + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(k_kmer_extend_wide, dim3((unsigned)blocks), dim3(256), 0, 0, d.blocks64, d.mb_base, d.mb_shift, cur,
+                           static_cast<ulonglong2 *>(child), np);
+        KJ_HIP(hipGetLastError());
+        KJ_HIP(hipDeviceSynchronize());
+        (void)hipFree(cur_alloc);
+        ix->allocs.back() = child;
+        cur_alloc = child; cur = static_cast<const ulonglong2 *>(child);
+        np *= 20; d.kmer_k++;
+      }
+      d.kmer64 = cur;
+      kmer_bytes = np * sizeof(ulonglong2) - pk.kmer64.size() * sizeof(ulonglong2);
     }
   }
   kaiju_gpu_index_info &inf = ix->info;
@@ -660,6 +723,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       const bool v1 = lane_env && !strcmp(lane_env, "v1");
       if (ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 && !c->verbose)
         hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+      else if (ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 &&
+               !c->verbose)
+        hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                            static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       else if (ix->dev.sb32)
         hipLaunchKernelGGL(k_mem_v1, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,

@@ -162,7 +162,13 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     }
   }
   sb32.clear();
-  if (bwtlen < 0xffffffffull) { sb32.resize(sb.size()); for (size_t q = 0; q < sb.size(); q++) sb32[q] = (uint32_t)sb[q]; }
+  // KAIJU_GPU_FORCE_WIDE=<shift>: treat the index as one with 64-bit positions (tests of that path on small
+  // indexes; the value is the log2 of the rows per count base, 16..31)
+  wide = bwtlen >= 0xffffffffull;
+  mb_shift = 31;
+  if (const char *e = getenv("KAIJU_GPU_FORCE_WIDE")) { wide = true; const int v = atoi(e); if (v >= (int)kSbShift && v <= 31) mb_shift = (uint32_t)v; }
+  sb32.clear();
+  if (!wide) { sb32.resize(sb.size()); for (size_t q = 0; q < sb.size(); q++) sb32[q] = (uint32_t)sb[q]; }
   // pass 2: rank blocks
   parallel_for(nsb, [&](uint64_t s) {
     uint32_t cnt[32] = {0};
@@ -181,13 +187,23 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     }
   });
   // 64-symbol blocks with absolute 32-bit counts for the MEM kernel
-  blocks64.clear();
-  if (bwtlen < 0xffffffffull) {
+  blocks64.clear(); mb_base.clear();
+  {
     const uint64_t nb64 = (bwtlen >> 6) + 1;
     blocks64.assign((size_t)nb64, RankBlock64{});
+    if (wide) {
+      // counts relative to the start of every 2^mb_shift rows (a multiple of the superblock size)
+      const uint64_t nmb = (bwtlen >> mb_shift) + 1;
+      mb_base.assign((size_t)nmb * 20, 0);
+      for (uint64_t m = 0; m < nmb; m++)
+        for (int a = 0; a < 20; a++) mb_base[(size_t)m * 20 + a] = sb[(size_t)(m << (mb_shift - kSbShift)) * 20 + a];
+    }
     parallel_for(nsb, [&](uint64_t s) {
       uint64_t cnt[32];
-      for (int a = 1; a < 21; a++) cnt[a] = sb[(size_t)s * 20 + (a - 1)];
+      for (int a = 1; a < 21; a++) {
+        cnt[a] = sb[(size_t)s * 20 + (a - 1)];
+        if (wide) cnt[a] -= mb_base[(size_t)((s << kSbShift) >> mb_shift) * 20 + (a - 1)];
+      }
       const uint64_t b0 = s << (kSbShift - 6), b1 = std::min<uint64_t>(nb64, b0 + (1ull << (kSbShift - 6)));
       for (uint64_t bi = b0; bi < b1; bi++) {
         RankBlock64 &rb = blocks64[(size_t)bi];
@@ -261,7 +277,7 @@ void PackedIndex::build_kmer_table(uint32_t k) {
   if (k < 2 || k > 6 || alen != 21) return;
   uint64_t n = 1;
   for (uint32_t q = 0; q < k; q++) n *= 20;
-  const bool small = bwtlen < 0xffffffffull;
+  const bool small = !wide;
   if (small) kmer32.assign((size_t)n, uint2{0, 0}); else kmer64.assign((size_t)n, ulonglong2{0, 0});
   const DevIndex d = host_view();
   // word index = (((c0-1)*20 + (c1-1))*20 + ...), c0 = the letter matched first (InitialSI)
@@ -292,13 +308,13 @@ void PackedIndex::build_kmer_table(uint32_t k) {
 
 // ---- device image file: header, then every array as (u64 element count, raw elements) ----
 namespace {
-const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '2'};
+const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '3'};
 struct ImgHeader {
   char magic[8];
   uint64_t sizes[8];          // sizeof RankBlock, RankBlock64, uint2, ulonglong2 (layout guard) + spare
   uint64_t C[22];
   uint64_t bwtlen, n_sa, sa_skip;
-  uint32_t nseq, chpt_exp, alen, warnings, kmer_k, pad;
+  uint32_t nseq, chpt_exp, alen, warnings, kmer_k, mb_shift_wide;   // mb_shift | wide << 8
   uint8_t trans[128];
   char alphabet[64];
 };
@@ -323,13 +339,13 @@ int PackedIndex::write_image(const char *path, std::string &msg) const {
   h.sizes[0] = sizeof(RankBlock); h.sizes[1] = sizeof(RankBlock64); h.sizes[2] = sizeof(uint2); h.sizes[3] = sizeof(ulonglong2);
   memcpy(h.C, C, sizeof C);
   h.bwtlen = bwtlen; h.n_sa = n_sa; h.sa_skip = sa_skip; h.nseq = nseq; h.chpt_exp = chpt_exp; h.alen = alen;
-  h.warnings = warnings; h.kmer_k = kmer_k;
+  h.warnings = warnings; h.kmer_k = kmer_k; h.mb_shift_wide = mb_shift | (wide ? 256u : 0u);
   memcpy(h.trans, trans, 128);
   snprintf(h.alphabet, sizeof h.alphabet, "%s", alphabet.c_str());
   bool ok = fwrite(&h, sizeof h, 1, fp) == 1;
   ok = ok && put_vec(fp, blocks) && put_vec(fp, blocks64) && put_vec(fp, sa_taxid) && put_vec(fp, sb) && put_vec(fp, sb32) &&
        put_vec(fp, sa_iseq) && put_vec(fp, seq_taxid) && put_vec(fp, seq_valid) && put_vec(fp, term_pos) &&
-       put_vec(fp, kmer32) && put_vec(fp, kmer64);
+       put_vec(fp, kmer32) && put_vec(fp, kmer64) && put_vec(fp, mb_base);
   // names: lengths then the characters
   std::vector<uint32_t> nl(names.size());
   std::vector<char> nc;
@@ -349,7 +365,7 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   if (!ok) { fclose(fp); msg = "not a kaiju GPU index image (or written by another version)"; return KAIJU_GPU_ERR_FORMAT; }
   memcpy(C, h.C, sizeof C);
   bwtlen = h.bwtlen; n_sa = h.n_sa; sa_skip = h.sa_skip; nseq = h.nseq; chpt_exp = h.chpt_exp; alen = h.alen;
-  warnings = h.warnings; kmer_k = h.kmer_k;
+  warnings = h.warnings; kmer_k = h.kmer_k; mb_shift = h.mb_shift_wide & 255u; wide = (h.mb_shift_wide & 256u) != 0;
   memcpy(trans, h.trans, 128);
   h.alphabet[sizeof h.alphabet - 1] = 0;
   alphabet = h.alphabet;
@@ -357,7 +373,7 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   std::vector<char> nc;
   ok = get_vec(fp, blocks) && get_vec(fp, blocks64) && get_vec(fp, sa_taxid) && get_vec(fp, sb) && get_vec(fp, sb32) &&
        get_vec(fp, sa_iseq) && get_vec(fp, seq_taxid) && get_vec(fp, seq_valid) && get_vec(fp, term_pos) &&
-       get_vec(fp, kmer32) && get_vec(fp, kmer64) && get_vec(fp, nl) && get_vec(fp, nc);
+       get_vec(fp, kmer32) && get_vec(fp, kmer64) && get_vec(fp, mb_base) && get_vec(fp, nl) && get_vec(fp, nc);
   fclose(fp);
   uint64_t total = 0;
   for (uint32_t l : nl) total += l;
@@ -385,6 +401,7 @@ DevIndex PackedIndex::host_view() const {
   d.seq_taxid = seq_taxid.data(); d.seq_valid = seq_valid.data(); d.term_pos = term_pos.data();
   for (int a = 0; a < 22; a++) d.C[a] = C[a];
   d.bwtlen = bwtlen; d.n_sa = n_sa; d.sa_skip = sa_skip; d.nseq = nseq; d.chpt_exp = chpt_exp;
+  d.mb_base = mb_base.empty() ? nullptr : mb_base.data(); d.mb_shift = mb_shift;
   d.kmer32 = kmer32.empty() ? nullptr : kmer32.data();
   d.kmer64 = kmer64.empty() ? nullptr : kmer64.data();
   d.kmer_k = kmer_k;

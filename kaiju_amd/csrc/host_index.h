@@ -52,7 +52,10 @@ struct FmiFile {
 // the packed index in host memory, ready for upload
 struct PackedIndex {
   std::vector<RankBlock> blocks;
-  std::vector<RankBlock64> blocks64;   // MEM kernel layout, only when bwtlen < 2^32
+  std::vector<RankBlock64> blocks64;   // second-generation lanes: absolute counts (bwtlen < 2^32) or relative to mb_base
+  std::vector<uint64_t> mb_base;       // wide layout: [nmb][20], counts at the start of every 2^mb_shift rows
+  uint32_t mb_shift = 0;
+  bool wide = false;                   // 64-bit positions (bwtlen >= 2^32, or forced for tests)
   std::vector<uint64_t> sa_taxid;      // taxon id per sampled SA row (~0: unusable name)
   std::vector<uint64_t> sb;
   std::vector<uint32_t> sb32;       // copy of sb in 32 bits when bwtlen < 2^32

@@ -17,6 +17,7 @@
 // Reference behaviour reproduced (file:line in /root/reference/src) is cited at
 // each function.
 #pragma once
+#include <type_traits>
 #include <stdint.h>
 
 #if defined(__HIPCC__)
@@ -68,7 +69,9 @@ struct alignas(128) RankBlock64 {
 static_assert(sizeof(RankBlock64) == 128, "RankBlock64 must be one 128-byte line");
 
 struct DevIndex {
-  const RankBlock64 *blocks64; // [(bwtlen >> 6) + 1] or nullptr (bwtlen >= 2^32)
+  const RankBlock64 *blocks64; // [(bwtlen >> 6) + 1]; counts absolute (bwtlen < 2^32) or relative to mb_base
+  const uint64_t *mb_base;   // "wide" layout (any bwtlen): [nmb][20] counts (C[c] folded in) at the start of every
+  uint32_t mb_shift;         //   2^mb_shift rows; nullptr / 0 when the counts in blocks64 are absolute
   const uint64_t *sa_taxid;  // taxon id of every sampled SA row (~0 = unusable name), for the MEM kernel
   const RankBlock *blocks;   // [(bwtlen >> 7) + 1]
   const uint64_t *sb;        // [nsb][20]: C[c] + occurrences of c before the superblock
@@ -1374,9 +1377,11 @@ extern unsigned long long kj_hist[8][64];
 #else
 #define KJ_HISTO(h, v)
 #endif
+template <bool WIDE>
 KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
                      const LaneScratch &ls) {
-  typedef uint32_t P;
+  // WIDE: 64-bit positions, block counts relative to mb_base, 16-byte k-mer entries (indexes >= 2^32 rows)
+  typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   int kind = K_IDLE;
   // read
   uint32_t r = 0, nf = 0, f = 0, fcur = 0, fbase = 0;
@@ -1399,9 +1404,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   bool fresh = true;                          // k is the first row of its walk (the id cap is tested there)
   Hit *hit = nullptr;
   LaneWin lw{ls.win, 0};
-  const P check = (P)((1u << ix.chpt_exp) - 1);
+  const P check = (P)((1ull << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
-  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m && ix.kmer32) ? ix.kmer_k : 0;
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m && (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kmer32)) ? ix.kmer_k : 0;
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0;                 // the wave's chunk of work items (wave-uniform)
   const RankBlock64 *const blk0 = ix.blocks64;
@@ -1465,8 +1470,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
     const uint64_t b4 = pb->plane[4];
     const uint32_t cb = pb->cnt[cc - 1];
+    uint64_t mba = 0, mbb = 0;                             // WIDE: counts at the start of the 2^mb_shift rows
+    if (WIDE) {
+      mba = ix.mb_base[(size_t)((uint64_t)posA >> ix.mb_shift) * 20 + (cc - 1)];
+      mbb = ix.mb_base[(size_t)((uint64_t)posB >> ix.mb_shift) * 20 + (cc - 1)];
+    }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == K_KMER) gaddr = reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
+    if (kind == K_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
     else if (kind == K_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == K_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
@@ -1489,11 +1499,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
-      const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
+      const P ra = (P)(mba + ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull)));
       if (is_step) {
         // UpdateSI(str[i-1]) (bwt.c:160-173)
         const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
-        const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
+        const P rb = (P)(mbb + cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull)));
         if (ra >= rb) bk = BK_END_MATCH;
         else {
           lo = ra; hi = rb; i--;
@@ -1508,8 +1518,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       }
     } else if (kind == K_KMER) {
       // InitialSI + (kk-1) UpdateSI in one lookup
-      const uint64_t e = ghalf ? gv.y : gv.x;
-      lo = (P)e; hi = (P)e + (P)(e >> 32);
+      if (WIDE) { lo = (P)gv.x; hi = (P)(gv.x + gv.y); }
+      else { const uint64_t e = ghalf ? gv.y : gv.x; lo = (P)e; hi = (P)((uint32_t)e + (uint32_t)(e >> 32)); }
       if (lo >= hi) { i = j; bk = BK_END_MATCH; }          // match shorter than kk: never recorded, i > 1
       else {
         i = j - (int)kk + 1;

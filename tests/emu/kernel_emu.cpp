@@ -168,7 +168,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     if (p.mode == 0) {
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1", "wide" or default (v2 where possible)
-      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) mem_lane2(d, p, b, wl, ls);
+      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) mem_lane2<false>(d, p, b, wl, ls);
+      else if (d.blocks64 && d.mb_base && d.kmer64 && !v && pass == 0 && !g_vb.n_acc) mem_lane2<true>(d, p, b, wl, ls);
       else if (d.sb32 && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls, g_vb);
       else mem_lane<uint64_t>(d, p, b, wl, ls, g_vb);
     } else {
@@ -214,10 +215,10 @@ extern "C" int emu_image_roundtrip(const char *fmi, const char *image) {
   auto same = [](const auto &x, const auto &y) { return x.size() == y.size() && (x.empty() || !memcmp(x.data(), y.data(), x.size() * sizeof(x[0]))); };
   if (!same(a.blocks, b.blocks) || !same(a.blocks64, b.blocks64) || !same(a.sa_taxid, b.sa_taxid) || !same(a.sb, b.sb) ||
       !same(a.sb32, b.sb32) || !same(a.sa_iseq, b.sa_iseq) || !same(a.seq_taxid, b.seq_taxid) || !same(a.seq_valid, b.seq_valid) ||
-      !same(a.term_pos, b.term_pos) || !same(a.kmer32, b.kmer32) || !same(a.kmer64, b.kmer64)) return 1;
+      !same(a.term_pos, b.term_pos) || !same(a.kmer32, b.kmer32) || !same(a.kmer64, b.kmer64) || !same(a.mb_base, b.mb_base)) return 1;
   if (a.names != b.names || a.alphabet != b.alphabet || memcmp(a.C, b.C, sizeof a.C) || memcmp(a.trans, b.trans, 128)) return 2;
   if (a.bwtlen != b.bwtlen || a.n_sa != b.n_sa || a.sa_skip != b.sa_skip || a.nseq != b.nseq || a.chpt_exp != b.chpt_exp ||
-      a.alen != b.alen || a.warnings != b.warnings || a.kmer_k != b.kmer_k) return 3;
+      a.alen != b.alen || a.warnings != b.warnings || a.kmer_k != b.kmer_k || a.mb_shift != b.mb_shift || a.wide != b.wide) return 3;
   return 0;
 }
 

@@ -78,6 +78,26 @@ def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
             assert (ref[n][0] == "C") == bool(r["classified"]) and (not r["classified"] or int(r["taxon"]) == ref[n][1]), n
 
 
+@pytest.mark.parametrize("shift", ["16", "20", "31"])
+def test_wide_index_path(gpu_lib, golden, oracle, ohandles, shift, monkeypatch):
+    """indexes of 2^32 rows and more: 64-bit positions, rank counts relative to a base every 2^shift rows, 16-byte
+    k-mer entries grown on the device - forced here on the small golden index (KAIJU_GPU_FORCE_WIDE)"""
+    api = gpu_lib
+    monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
+    monkeypatch.setenv("KAIJU_GPU_KMER", "6")
+    idx = api.Index(golden.fmi)
+    ix, tax = ohandles
+    reads = util.long_reads(n=40)
+    lseqs, loff = util.pack(reads)
+    for mode in ("mem", "greedy"):
+        for seqs, off, pe in ((golden.seqs, golden.off, False), (golden.pseqs, golden.poff, True), (lseqs, loff, False)):
+            clf = api.Classifier(idx, api.default_params(mode, seg=1))
+            hits = clf.classify(seqs, off, paired=pe)
+            oh = oracle.classify(ix, tax, oracle.params(mode, seg=1, use_evalue=0), seqs, off, paired=pe)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+            assert not bad, (shift, mode, pe, bad[:5])
+
+
 def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
     """an index loaded from its device image classifies exactly like the one packed from the .fmi"""
     api = gpu_lib

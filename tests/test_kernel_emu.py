@@ -245,3 +245,20 @@ def test_verbose_columns(emu, golden, handles, mode):
                     assert ref[5] == "".join(x + "," for x in sorted(accs)) and ref[6] == t, (mode, seg, pe, nm, ref[5:], accs, t)
     finally:
         E.emu_set_verbose(None, None, None, None, 0)
+
+
+@pytest.mark.parametrize("shift", ["16", "19"])
+def test_wide_mem_lane(oracle, emu, golden, handles, shift, monkeypatch):
+    """second-generation MEM lane with 64-bit positions (indexes of 2^32 rows and more), forced on the golden index:
+    rank counts relative to a base every 2^shift rows, 16-byte k-mer entries"""
+    monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
+    h = emu.load(golden.fmi)
+    _, ix, tax = handles
+    reads = util.long_reads(n=30)
+    lseqs, loff = util.pack(reads)
+    for seg in (1, 0):
+        for seqs, off, pe in ((golden.seqs, golden.off, False), (golden.pseqs, golden.poff, True), (lseqs, loff, False)):
+            oh = oracle.classify(ix, tax, oracle.params("mem", seg=seg), seqs, off, paired=pe)
+            gh, _ = emu.classify(h, util.gp("mem", seg=seg), seqs, off, paired=pe)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+            assert not bad, (shift, seg, pe, bad[:5])
