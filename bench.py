@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
     ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"])
     ap.add_argument("--no-seg", action="store_true")
+    ap.add_argument("--paired", action="store_true", help="2 x 150-bp pairs (BASELINE config 4 shape) instead of single reads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--work", default=os.environ.get("KAIJU_BENCH_WORK", "/tmp/kaiju_amd_bench"))
@@ -157,9 +158,16 @@ def main():
     clf = api.Classifier(index, params)
     t0 = time.time()
     n = args.reads
-    reads = synth.make_reads(db, n, seed=777 + rank)
-    L = reads.shape[1]
-    clf.set_max_read_length(L)
+    if args.paired:
+        # pair r = mate 1 followed by mate 2 in the sequence buffer
+        m1, m2 = synth.make_pairs(db, n, seed=778 + rank)
+        reads = np.concatenate([m1, m2], axis=1)
+        Lm = m1.shape[1]
+    else:
+        reads = synth.make_reads(db, n, seed=777 + rank)
+        Lm = reads.shape[1]
+    L = reads.shape[1]                       # bytes per read (pair) in the buffer
+    clf.set_max_read_length(Lm)
     d_seqs = torch.from_numpy(reads.reshape(-1)).to(dev)
     chunk = min(args.chunk, n)
     bounds = [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]
@@ -169,7 +177,7 @@ def main():
         m = hi - lo
         o = np.empty(2 * m + 1, dtype=np.int64)
         o[0::2] = np.arange(m + 1, dtype=np.int64) * L
-        o[1::2] = o[2::2]
+        o[1::2] = o[2::2] if not args.paired else o[0:-1:2] + Lm
         d_offs.append(torch.from_numpy(o).to(dev))
     d_out = torch.zeros(n * HIT_BYTES, dtype=torch.uint8, device=dev)
     # what leaves the GPU: 16-byte records (LCA computed on the device), not the 184-byte id lists
@@ -218,7 +226,7 @@ def main():
             cview = d_compact[lo * COMPACT_BYTES: hi * COMPACT_BYTES]
             with torch.cuda.stream(s):
                 c.classify_device(d_seqs.data_ptr() + lo * L, m * L, d_off.data_ptr(), m, out_view.data_ptr(),
-                                  paired=False, stream=s.cuda_stream)
+                                  paired=args.paired, stream=s.cuda_stream)
                 c.lca_device(dtax, out_view.data_ptr(), m, cview.data_ptr(), stream=s.cuda_stream)
                 g.gather(cview)
             pending[k % nctx] = m
@@ -267,7 +275,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"viruses-like synthetic index ({db.nseq} proteins, {db.total_aa} aa, .fmi "
-                               f"{os.path.getsize(fmi)/1e6:.0f} MB, e=3); {n} synthetic {L}-bp reads per GPU per step "
+                               f"{os.path.getsize(fmi)/1e6:.0f} MB, e=3); {n} synthetic {'2x' if args.paired else ''}{Lm}-bp reads{' (pairs)' if args.paired else ''} per GPU per step "
                                f"(70% back-translated DB windows, 30% random); kaiju -a {args.mode} -m 11"
                                f"{'' if seg else ' -X'} (SEG {'on' if seg else 'off'})",
                    "reads_per_gpu_per_step": n, "chunk": chunk, "contexts_in_flight": nctx, "index_replicated": True,
@@ -278,7 +286,7 @@ def main():
     # ---------------- roofline of the dominant kernel + CPU baseline ----------------
     ops = None
     cb = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and world == 1 and not args.paired:   # (the CPU leg and the op counts are for single reads)
         try:
             r = cpu_baseline(W, fmi, nodes, reads, args.mode, seg, args.cpu_sample, 30000)
             ops, cb = r["ops"], r["baseline"]
