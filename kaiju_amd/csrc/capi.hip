@@ -618,6 +618,8 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
                  p->seed_length >= 3;
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) if (!strcmp(e, "v1")) c->greedy2 = false;
     if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (uint32_t)v; }
+    // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate |= (uint32_t)v << 8; }
     if (c->greedy2) {
       KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kGreedy2Lds));

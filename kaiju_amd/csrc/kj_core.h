@@ -2301,8 +2301,11 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
 #define KJ_TICK(acc)
 #endif
   for (;;) {
-    const bool heavy = (itc & gs.gate) == 0;               // wave-uniform
-    itc++;
+    // wave-uniform: every (gate+1)-th iteration, or as soon as many lanes wait for the slow part
+    bool heavy = (itc & (gs.gate & 0xffu)) == 0;
+    if (!heavy && (gs.gate >> 8) != 0)
+      heavy = popc64(kj_ballot(kind >= G_VMULTI && kind <= G_IDLE)) >= (gs.gate >> 8);
+    itc = heavy ? 1u : itc + 1u;
     KJ_TICK(st_book)
     if (heavy) {
       // ---- (H0) the slow bookkeeping of the parked lanes, up to their next memory access ----
