@@ -315,3 +315,12 @@ def test_planted_reads_hit_their_source(gpu_lib, big):
     src = db.taxids[seq].astype(np.uint64)
     found = (hits["taxid"] == src[:, None]).any(axis=1) | ((hits["flags"] & 1) == 1)
     assert found.all()
+
+
+def test_randomised_databases_and_parameters(gpu_lib):
+    """a few rounds of tests/tools/fuzz_gpu.py through the C-ABI (random databases, reads, parameters)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "tools", "fuzz_gpu.py"), "12", "5"],
+                       capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"FUZZ_OK" in r.stdout, r.stdout[-2000:].decode() + r.stderr[-2000:].decode()

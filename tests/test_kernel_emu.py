@@ -262,3 +262,14 @@ def test_wide_mem_lane(oracle, emu, golden, handles, shift, monkeypatch):
             gh, _ = emu.classify(h, util.gp("mem", seg=seg), seqs, off, paired=pe)
             bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
             assert not bad, (shift, seg, pe, bad[:5])
+
+
+def test_randomised_databases_and_parameters():
+    """a few rounds of tests/tools/fuzz_emu.py: random databases with repeats and low-complexity stretches, reads
+    with Ns / lower case / odd lengths / pairs, random parameters (the long hunts run from the command line)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_emu", os.path.join(util.ROOT, "tests", "tools", "fuzz_emu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main(rounds=5, seed=99, first=0) == 0

@@ -1,0 +1,128 @@
+"""Randomised parity hunt on the CPU: random small databases (with repeats and low-complexity stretches), reads with
+Ns / lower case / odd lengths / pairs, random parameters; host emulation of the kernel logic vs the oracle.
+   fuzz_emu.py [rounds] [seed]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import util  # noqa: E402
+import pyoracle as po  # noqa: E402
+from kaiju_amd import mkfmi  # noqa: E402
+
+AA = "ARNDCQEGHILKMFPSTWYV"
+CODON = {"A": ["GCT", "GCC", "GCA", "GCG"], "R": ["CGT", "AGA", "CGG"], "N": ["AAT", "AAC"], "D": ["GAT", "GAC"], "C": ["TGT", "TGC"],
+         "Q": ["CAA", "CAG"], "E": ["GAA", "GAG"], "G": ["GGT", "GGC", "GGA"], "H": ["CAT", "CAC"], "I": ["ATT", "ATC", "ATA"],
+         "L": ["CTT", "TTA", "CTG"], "K": ["AAA", "AAG"], "M": ["ATG"], "F": ["TTT", "TTC"], "P": ["CCT", "CCC"], "S": ["TCT", "AGC"],
+         "T": ["ACT", "ACA"], "W": ["TGG"], "Y": ["TAT", "TAC"], "V": ["GTT", "GTA"]}
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a", "n": "n"}
+
+
+def make_db(rng, path, nodes_path):
+    nseq = int(rng.integers(20, 400))
+    ntax = int(rng.integers(2, 40))
+    with open(nodes_path, "w") as f:
+        f.write("1\t|\t1\t|\tno rank\t|\n")
+        for t in range(2, ntax + 2):
+            f.write(f"{t}\t|\t{int(rng.integers(1, t))}\t|\tclade\t|\n")
+    seqs = []
+    letters = list(AA)
+    p = rng.dirichlet(np.ones(20) * float(rng.choice([0.3, 1.0, 5.0])))
+    for i in range(nseq):
+        L = int(rng.integers(15, 500))
+        if seqs and rng.random() < 0.4:                       # mutated copy: multi-taxon hits
+            s = list(seqs[int(rng.integers(0, len(seqs)))])
+            for _ in range(int(rng.integers(0, 6))):
+                s[int(rng.integers(0, len(s)))] = letters[int(rng.integers(0, 20))]
+            s = "".join(s)
+        else:
+            s = "".join(rng.choice(letters, L, p=p))
+        if rng.random() < 0.2:                                # low-complexity insert
+            k = int(rng.integers(0, len(s)))
+            s = s[:k] + letters[int(rng.integers(0, 20))] * int(rng.integers(8, 40)) + s[k:]
+        seqs.append(s)
+    with open(path, "w") as f:
+        for i, s in enumerate(seqs):
+            name = f"ACC{i}.1_{int(rng.integers(1, ntax + 4))}" if rng.random() < 0.9 else str(int(rng.integers(1, ntax + 2)))
+            f.write(f">{name}\n{s}\n")
+    return seqs
+
+
+def make_read(rng, seqs):
+    L = int(rng.choice([0, 5, 32, 33, 34, 60, 100, 150, 151, 250, 400, 700]))
+    if L == 0:
+        return b""
+    if rng.random() < 0.25:
+        s = "".join(rng.choice(list("ACGT"), L))
+    else:
+        parts = []
+        while sum(len(x) for x in parts) < L:
+            p = seqs[int(rng.integers(0, len(seqs)))]
+            a = int(rng.integers(0, max(1, len(p) - 12)))
+            b = min(len(p), a + int(rng.integers(8, 120)))
+            parts.append("".join(CODON[c][int(rng.integers(0, len(CODON[c])))] for c in p[a:b]) + "ACGT"[: int(rng.integers(0, 3))])
+        s = list("".join(parts)[:L])
+        for _ in range(int(rng.integers(0, 5))):
+            s[int(rng.integers(0, len(s)))] = "ACGTN"[int(rng.integers(0, 5))]
+        s = "".join(s)
+        if rng.random() < 0.5:
+            s = "".join(COMP[c] for c in reversed(s))
+    if rng.random() < 0.1:
+        s = s.lower()
+    return s.encode()
+
+
+def main(rounds=None, seed=None, first=None):
+    rounds = rounds if rounds is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+    seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    emu = util.Emu()
+    orc = po.Oracle()
+    total = 0
+    first = first if first is not None else (int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    for rnd in range(first, first + rounds):
+        rng = np.random.default_rng(seed * 1000 + rnd)
+        with tempfile.TemporaryDirectory() as d:
+            faa, fmi, nodes = f"{d}/db.faa", f"{d}/db.fmi", f"{d}/nodes.dmp"
+            seqs = make_db(rng, faa, nodes)
+            mkfmi.build_fmi(faa, fmi, threads=2, exponent=int(rng.choice([1, 3, 5])))
+            h = emu.load(fmi)
+            if emu.lib.emu_index_warnings(h):
+                print(f"round {rnd}: index hits a latent bug of the reference (parity undefined there), skipped", flush=True)
+                continue
+            ix = orc.load_fmi(fmi); tax = orc.load_nodes(nodes)
+            n = int(rng.integers(50, 400))
+            r1 = [make_read(rng, seqs) for _ in range(n)]
+            paired = rng.random() < 0.4
+            r2 = [make_read(rng, seqs) for _ in range(n)] if paired else None
+            sq, off = util.pack(r1, r2)
+            for mode in ("mem", "greedy"):
+                kw = dict(seg=int(rng.integers(0, 2)))
+                if mode == "mem":
+                    kw["min_fragment_length"] = int(rng.choice([7, 9, 11, 11, 15, 20]))
+                    gp = util.gp(mode, m=kw["min_fragment_length"], seg=kw["seg"])
+                else:
+                    kw["mismatches"] = int(rng.choice([0, 1, 3, 3, 5]))
+                    kw["min_score"] = int(rng.choice([30, 65, 65, 90]))
+                    kw["seed_length"] = int(rng.choice([7, 7, 8, 10]))
+                    kw["min_fragment_length"] = int(rng.choice([9, 11, 11, 13]))
+                    gp = util.gp(mode, m=kw["min_fragment_length"], mismatches=kw["mismatches"], min_score=kw["min_score"],
+                                 seed_length=kw["seed_length"], seg=kw["seg"])
+                oh = orc.classify(ix, tax, orc.params(mode, use_evalue=0, **kw), sq, off, paired=paired)
+                gh, nretry = emu.classify(h, gp, sq, off, paired=paired)
+                bad = [i for i in range(n) if not util.same_hit(oh[i], gh[i])]
+                total += n
+                if bad:
+                    print("MISMATCH round", rnd, "seed", seed, mode, kw, "paired", paired, "reads", bad[:5], flush=True)
+                    i = bad[0]
+                    print("  oracle", oh[i]["best"], oh[i]["n_ids"], list(oh[i]["taxid"][:4]), "emu", gh[i]["best"], gh[i]["n_ids"], list(gh[i]["taxid"][:4]))
+                    print("  read", r1[i][:120], (r2[i][:60] if paired else b""))
+                    return 1
+        print(f"round {rnd}: ok ({total} read-classifications so far)", flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
