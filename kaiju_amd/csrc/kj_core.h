@@ -1410,11 +1410,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0;                 // the wave's chunk of work items (wave-uniform)
   const RankBlock64 *const blk0 = ix.blocks64;
-  // the k-mer index of end position j-1 follows from that of j: drop the first letter, append one
-  uint32_t kpow = 1;                            // 20^(kk-1)
-  for (uint32_t q = 1; q < kk; q++) kpow *= 20u;
-  uint32_t kfirst = 1;                          // first letter of the k-mer kidx stands for
-  bool kroll = false;                           // kidx is the k-mer of end position j+1 of this fragment
 
   auto si_lo = [&](uint32_t e) -> P { return e == 0 ? s0lo : e == 1 ? s1lo : (P)ls.si[e].lo; };
   auto si_len = [&](uint32_t e) -> uint32_t { return e == 0 ? s0len : e == 1 ? s1len : ls.si[e].len; };
@@ -1608,12 +1603,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (j < (int)L - 1) bk = BK_NEXT_FRAG;
         else if (kk && j >= (int)kk - 1) {
           if (in_win(j) && in_win(j - (int)kk + 1)) {
-            if (kroll) kidx = (kidx - (kfirst - 1u) * kpow) * 20u + ((uint32_t)lw.w[j - (int)kk + 1 - lw.q] - 1u);
-            else {
-              kidx = 0;
-              for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
-            }
-            kfirst = lw.w[j - lw.q]; kroll = true;
+            // (a rolling update of the index from end position j+1 was tried: it costs a register too many here)
+            kidx = 0;
+            for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
             kind = K_KMER; bk = BK_NONE;
           } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
         } else if (in_win(j)) {
@@ -1632,7 +1624,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         else {
           fcur = f; f++;
           fsoff = pepoff + dnext.start; flen = (int)dnext.len;
-          j = flen - 1; kroll = false;
+          j = flen - 1;
           fill_top = j; fill_newfrag = true; fill_step = false;
           kind = K_FILL; bk = BK_NONE;
         }
