@@ -78,7 +78,9 @@ def make_read(rng, seqs):
 def main(rounds=None, seed=None, first=None):
     rounds = rounds if rounds is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
     seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    emu = util.Emu()
+    # FUZZ_SMALL=1: the emulation built with tiny bounds of the second-generation Greedy lane (spill / retry paths)
+    emu = (util.Emu(so=os.path.join(util.EMU_DIR, "libkaiju_kernel_emu_small.so"), defines=("KJ_G_SMALL",))
+           if os.environ.get("FUZZ_SMALL") else util.Emu())
     orc = po.Oracle()
     total = 0
     first = first if first is not None else (int(sys.argv[3]) if len(sys.argv) > 3 else 0)
