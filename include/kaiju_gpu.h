@@ -138,6 +138,12 @@ int kaiju_gpu_device_count(void);
 /* ---- index ---------------------------------------------------------- */
 int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_gpu_index **out);
 int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *view, int device_id, kaiju_gpu_index **out);
+/* kaijux / kaijup semantics (ConsumerThreadx.cpp:261-287, README "KaijuX and KaijuP"): a hit collects the
+   database SEQUENCES it matches instead of their taxa.  With KAIJU_GPU_IDS_SEQUENCE the ids in kaiju_gpu_hit are
+   sequence numbers (kaiju_gpu_index_seq_name() gives the names), first-seen order, capped like taxon ids. */
+enum { KAIJU_GPU_IDS_TAXON = 0, KAIJU_GPU_IDS_SEQUENCE = 1 };
+int kaiju_gpu_index_load_ex(const char *fmi_or_image_path, int device_id, int id_mode, kaiju_gpu_index **out);
+
 /* Device image of an index: the arrays of the HBM layout, packed once on the host and
    written to a file; kaiju_gpu_index_load() recognises such a file by its magic and uploads it without
    parsing or packing anything.  Needs no GPU. */

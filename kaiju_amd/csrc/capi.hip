@@ -348,6 +348,7 @@ static int upload(kaiju_gpu_index *ix, const std::vector<T> &v, const T **dst) {
 }
 
 static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out);
+static thread_local int tl_id_mode = 0;     // kaiju_gpu_index_load_ex: 1 = hits collect sequence numbers
 
 static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_index **out) {
   if (!out) return fail(KAIJU_GPU_ERR_ARG, "out is NULL");
@@ -367,6 +368,7 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
 static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out) {
   std::string msg;
   int rc;
+  if (tl_id_mode == 1) pk.to_sequence_ids();
   std::unique_ptr<kaiju_gpu_index> ix(new kaiju_gpu_index());
   ix->device = device_id;
   rc = build_const_tables(pk.trans, ix->ct_host, msg);
@@ -508,6 +510,14 @@ extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_g
   int rc = f.load(fmi_path, msg);
   if (rc) return fail(rc, msg);
   return index_from_view(f.view(), device_id, out);
+}
+
+extern "C" int kaiju_gpu_index_load_ex(const char *fmi_path, int device_id, int id_mode, kaiju_gpu_index **out) {
+  if (id_mode != KAIJU_GPU_IDS_TAXON && id_mode != KAIJU_GPU_IDS_SEQUENCE) return fail(KAIJU_GPU_ERR_ARG, "id_mode");
+  tl_id_mode = id_mode;
+  const int rc = kaiju_gpu_index_load(fmi_path, device_id, out);
+  tl_id_mode = 0;
+  return rc;
 }
 
 extern "C" int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *hv, int device_id, kaiju_gpu_index **out) {

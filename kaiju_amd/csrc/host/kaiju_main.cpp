@@ -365,12 +365,20 @@ int main(int argc, char **argv) {
     }
   }
   if (getenv("KAIJU_GPU_PARSE_ONLY")) { if (nodes_fn.empty()) nodes_fn = "-"; if (fmi_fn.empty()) fmi_fn = "-"; }
+  // which program this is (kaiju, kaiju-multi, kaijux) is decided by the name it was started under
+  std::string prog = argv[0];
+  if (prog.find('/') != std::string::npos) prog = prog.substr(prog.rfind('/') + 1);
+  if (prog.find("kaijux") != std::string::npos && nodes_fn.empty()) nodes_fn = "-";
   if (nodes_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the nodes.dmp file, using the -t option.\n\n"); usage(argv[0]); }
   if (fmi_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the FMI file, using the -f option.\n\n"); usage(argv[0]); }
   if (in1_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the input file, using the -i option.\n\n"); usage(argv[0]); }
   if (protein) die("Protein input (-p) is not supported by the GPU path.");
   if (params.use_evalue && params.mode == 0) die("E-value calculation is only possible in Greedy run mode.");
 
+  // kaijux (kaijux.cpp, ConsumerThreadx.cpp): the same search, but a read is reported with the database sequences it
+  // matches (no taxonomy, no nodes.dmp): "C<TAB>name<TAB>score<TAB>seqname,...<TAB>[peptides with -v]" / "U<TAB>name"
+  const bool xmode = prog.find("kaijux") != std::string::npos;
+  if (xmode && nodes_fn.empty()) nodes_fn = "-";
   // developer/test switch: run the ingest stages only and print "name<TAB>mate1<TAB>mate2" per read
   const bool parse_only = getenv("KAIJU_GPU_PARSE_ONLY") != nullptr;
   if (verbose) fprintf(stderr, "%s Reading database\n", now().c_str());
@@ -387,14 +395,14 @@ int main(int argc, char **argv) {
   int rc = 0;
   if (!parse_only) {
     int tax_rc = 0;
-    std::thread tax_loader([&] { tax_rc = kaiju_taxonomy_load(nodes_fn.c_str(), &tax); });
-    rc = kaiju_gpu_index_load(fmi_fn.c_str(), device, &index);
+    std::thread tax_loader([&] { if (!xmode) tax_rc = kaiju_taxonomy_load(nodes_fn.c_str(), &tax); });
+    rc = kaiju_gpu_index_load_ex(fmi_fn.c_str(), device, xmode ? KAIJU_GPU_IDS_SEQUENCE : KAIJU_GPU_IDS_TAXON, &index);
     tax_loader.join();
     if (tax_rc != 0) die("Could not open file " + nodes_fn);
     if (rc != 0) die(std::string("Could not load ") + fmi_fn + ": " + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
     kaiju_gpu_index_get_info(index, &info);
     if (info.warnings && verbose) fprintf(stderr, " Warning: the index triggers a latent bug of the reference (flags %u)\n", info.warnings);
-    if (!verbose) {
+    if (!verbose && !xmode) {
       rc = kaiju_gpu_taxonomy_upload(tax, device, &dtax);
       if (rc != 0) die(std::string("kaiju_gpu_taxonomy_upload: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
     }
@@ -405,7 +413,7 @@ int main(int argc, char **argv) {
   }
 
   // kaiju-multi (kaiju-multi.cpp:221-334): comma separated lists of input / output files, one index load
-  const bool multi = std::string(argv[0]).find("multi") != std::string::npos;
+  const bool multi = prog.find("multi") != std::string::npos;
   auto split_list = [](const std::string &v) {
     std::vector<std::string> out;
     size_t begin = 0, pos;
@@ -518,6 +526,9 @@ int main(int argc, char **argv) {
             b->vtext.resize((size_t)n * b->vstride);
             r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data(),
                                                  b->vrec.data(), b->vtext.data(), b->vstride);
+          } else if (xmode) {
+            b->hits.resize(n);
+            r = kaiju_gpu_classify_batch(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data());
           } else {
             b->compact.resize(n);
             r = kaiju_gpu_classify_batch_compact(ctx[k], dtax, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
@@ -547,6 +558,31 @@ int main(int argc, char **argv) {
             continue;
           }
           res.resize(n);
+          if (xmode) {
+            // E-value gate and C/U decision as for kaiju; the ids are sequence numbers: names in sequence order
+            // (the reference iterates a std::set<char *> of the names, i.e. in the order they were allocated)
+            b->compact.resize(n);
+            for (uint32_t r = 0; r < n; r++) { b->compact[r].lca = b->hits[r].n_ids ? 1 : 0; b->compact[r].best = b->hits[r].best; b->compact[r].info = b->hits[r].n_ids; }
+            kaiju_finalize_compact(&params, info.db_length, b->compact.data(), b->off.data(), n, paired ? 1 : 0, res.data());
+            std::string &text = b->text;
+            text.clear();
+            for (uint32_t r = 0; r < n; r++) {
+              const char *nm = b->names.data() + b->name_off[r];
+              const size_t nl = b->name_off[r + 1] - b->name_off[r];
+              if (!res[r].classified) { text += "U\t"; text.append(nm, nl); text += '\n'; continue; }
+              text += "C\t"; text.append(nm, nl); text += '\t'; append_u64(text, res[r].best); text += '\t';
+              uint64_t ids[KAIJU_GPU_MAX_IDS];
+              const uint32_t k = b->hits[r].n_ids;
+              for (uint32_t q = 0; q < k; q++) ids[q] = b->hits[r].taxid[q];
+              std::sort(ids, ids + k);
+              for (uint32_t q = 0; q < k; q++) { const char *sn = kaiju_gpu_index_seq_name(index, (uint32_t)ids[q]); if (sn) text += sn; text += ','; }
+              text += '\t';
+              if (verbose) text.append(b->vtext.data() + (size_t)r * b->vstride, b->vrec[r].text_len);
+              text += '\n';
+            }
+            q_text.put(seq, std::move(b));
+            continue;
+          }
           if (verbose) kaiju_finalize_hits(tax, &params, info.db_length, b->hits.data(), b->off.data(), n, paired ? 1 : 0, res.data());
           else kaiju_finalize_compact(&params, info.db_length, b->compact.data(), b->off.data(), n, paired ? 1 : 0, res.data());
           std::string &text = b->text;

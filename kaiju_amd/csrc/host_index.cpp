@@ -306,6 +306,11 @@ void PackedIndex::build_kmer_table(uint32_t k) {
   kmer_k = k;
 }
 
+void PackedIndex::to_sequence_ids() {
+  for (uint32_t i = 0; i < nseq; i++) { seq_taxid[i] = i; seq_valid[i] = 3; }
+  for (uint64_t q = 0; q < n_sa; q++) sa_taxid[(size_t)q] = sa_iseq[(size_t)q] < nseq ? (uint64_t)sa_iseq[(size_t)q] : ~0ull;
+}
+
 // ---- device image file: header, then every array as (u64 element count, raw elements) ----
 namespace {
 const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '3'};

@@ -80,6 +80,9 @@ struct PackedIndex {
   uint64_t bytes() const;
   // DevIndex whose pointers refer to THIS object's host vectors (used by the test emulation)
   DevIndex host_view() const;
+  // kaijux / kaijup semantics (ConsumerThreadx.cpp:261-287): what a hit collects are database SEQUENCES, not taxa.
+  // Afterwards the "taxon id" of sequence i is i itself and every name is usable.
+  void to_sequence_ids();
   // the packed arrays as one file ("device image": written once, loaded instead of parsing and packing the .fmi)
   int write_image(const char *path, std::string &msg) const;
   int read_image(const char *path, std::string &msg);

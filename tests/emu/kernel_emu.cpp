@@ -38,6 +38,12 @@ void *emu_index_load(const char *path, char *err, int errlen) {
   if (rc != 0) { snprintf(err, (size_t)errlen, "%s", msg.c_str()); delete ix; return nullptr; }
   return ix;
 }
+// kaijux semantics: ids are sequence numbers
+void *emu_index_load_x(const char *path, char *err, int errlen) {
+  EmuIndex *ix = (EmuIndex *)emu_index_load(path, err, errlen);
+  if (ix) ix->packed.to_sequence_ids();
+  return ix;
+}
 void emu_index_free(void *h) { delete (EmuIndex *)h; }
 uint32_t emu_index_warnings(void *h) { return ((EmuIndex *)h)->packed.warnings; }
 

@@ -85,3 +85,22 @@ def test_kaiju_multi(gpu_lib, golden, tmp_path):
                     "-o", f"{o1},{o2}"], check=True)
     ref = first5(os.path.join(golden.dir, "ref_mem_1_pe.tsv"))
     assert first5(o1) == ref and first5(o2) == ref
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_kaijux(gpu_lib, golden, tmp_path, mode):
+    """kaijux (database sequences instead of taxa, no nodes.dmp) == the reference's kaijux lines, with and without -v,
+    single and paired"""
+    build.build_cli()
+    kaijux = os.path.join(os.path.dirname(build.CLI), "kaijux")
+    for pe in (False, True):
+        for v in (False, True):
+            out = str(tmp_path / "x.tsv")
+            cmd = [kaijux, "-f", golden.fmi, "-a", mode, "-o", out]
+            cmd += ["-i", os.path.join(golden.dir, "pairs_1.fq"), "-j", os.path.join(golden.dir, "pairs_2.fq")] if pe else \
+                   ["-i", os.path.join(golden.dir, "reads.fq")]
+            if v:
+                cmd.append("-v")
+            subprocess.run(cmd, check=True)
+            ref = os.path.join(golden.dir, f"refx_{mode}{'_pe' if pe else ''}{'_v' if v else ''}.tsv")
+            assert open(out).read() == open(ref).read(), (mode, pe, v)

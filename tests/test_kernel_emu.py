@@ -273,3 +273,48 @@ def test_randomised_databases_and_parameters():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main(rounds=5, seed=99, first=0) == 0
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_kaijux_semantics(emu, golden, mode):
+    """kaijux (ConsumerThreadx.cpp): hits collect database sequences instead of taxa - the same kernels on an index whose
+    "taxon id" of sequence i is i; score, names (in sequence order) and the C/U decision == the reference's kaijux lines"""
+    import ctypes as C
+    import os
+    from kaiju_amd import api
+    E = emu.lib
+    E.emu_index_load_x.restype = C.c_void_p
+    E.emu_index_load_x.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    E.emu_seq_name.restype = C.c_char_p
+    E.emu_seq_name.argtypes = [C.c_void_p, C.c_uint32]
+    err = C.create_string_buffer(256)
+    h = E.emu_index_load_x(golden.fmi.encode(), err, 256)
+    assert h, err.value
+    with open(golden.fmi, "rb") as f:
+        hdr = np.frombuffer(f.read(12), dtype=np.uint8)
+    db_length = float(int(hdr[:8].view("<i8")[0]) - int(hdr[8:12].view("<i4")[0]))
+    L = api.lib()
+    p = api.default_params(mode, seg=1)
+    for seqs, off, names, pe, tsv in ((golden.seqs, golden.off, golden.names, False, f"refx_{mode}.tsv"),
+                                      (golden.pseqs, golden.poff, golden.pnames, True, f"refx_{mode}_pe.tsv")):
+        gh, _ = emu.classify(h, util.gp(mode, seg=1), seqs, off, paired=pe)
+        recs = np.zeros(len(gh), dtype=api.COMPACT_DTYPE)
+        recs["lca"] = (gh["n_ids"] > 0).astype(np.uint64)
+        recs["best"] = gh["best"]
+        recs["info"] = gh["n_ids"]
+        res = np.zeros(len(gh), dtype=api.RESULT_DTYPE)
+        assert L.kaiju_finalize_compact(C.byref(p), db_length, recs.ctypes.data, np.ascontiguousarray(off).ctypes.data, len(gh),
+                                        1 if pe else 0, res.ctypes.data) == 0
+        lines = {}
+        with open(os.path.join(golden.dir, tsv)) as f:
+            for line in f:
+                q = line.rstrip("\n").split("\t")
+                lines[q[1]] = q
+        for r, nm in enumerate(names):
+            ref = lines[nm]
+            if res[r]["classified"]:
+                ids = sorted(int(x) for x in gh[r]["taxid"][:gh[r]["n_ids"]])
+                got = "".join(E.emu_seq_name(h, i).decode() + "," for i in ids)
+                assert ref[0] == "C" and int(ref[2]) == int(gh[r]["best"]) and ref[3] == got, (mode, pe, nm, ref, got)
+            else:
+                assert ref[0] == "U", (mode, pe, nm, ref)
