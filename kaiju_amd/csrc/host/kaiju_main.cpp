@@ -379,6 +379,9 @@ int main(int argc, char **argv) {
   // matches (no taxonomy, no nodes.dmp): "C<TAB>name<TAB>score<TAB>seqname,...<TAB>[peptides with -v]" / "U<TAB>name"
   const bool xmode = prog.find("kaijux") != std::string::npos;
   if (xmode && nodes_fn.empty()) nodes_fn = "-";
+  if (xmode && params.mode == 0)
+    fprintf(stderr, "Note: kaijux -a mem searches like kaiju -a mem (greedyExact); the reference's kaijux uses maxMatches(.., 1) "
+                    "there, so results can differ from it in rare cases (matched peptides of -v more often).\n");
   // developer/test switch: run the ingest stages only and print "name<TAB>mate1<TAB>mate2" per read
   const bool parse_only = getenv("KAIJU_GPU_PARSE_ONLY") != nullptr;
   if (verbose) fprintf(stderr, "%s Reading database\n", now().c_str());
@@ -569,7 +572,14 @@ int main(int argc, char **argv) {
             for (uint32_t r = 0; r < n; r++) {
               const char *nm = b->names.data() + b->name_off[r];
               const size_t nl = b->name_off[r + 1] - b->name_off[r];
-              if (!res[r].classified) { text += "U\t"; text.append(nm, nl); text += '\n'; continue; }
+              if (!res[r].classified) {
+                // reads below the length gate get the three-column line of kaiju (ConsumerThreadx.cpp:202-207), others "U<TAB>name"
+                const uint64_t l1 = b->off[2 * (size_t)r + 1] - b->off[2 * (size_t)r], l2 = b->off[2 * (size_t)r + 2] - b->off[2 * (size_t)r + 1];
+                const uint64_t m3 = 3ull * params.min_fragment_length;
+                const bool gated = paired ? (l1 < m3 && l2 < m3) : (l1 < m3);
+                text += "U\t"; text.append(nm, nl); text += gated ? "\t0\n" : "\n";
+                continue;
+              }
               text += "C\t"; text.append(nm, nl); text += '\t'; append_u64(text, res[r].best); text += '\t';
               uint64_t ids[KAIJU_GPU_MAX_IDS];
               const uint32_t k = b->hits[r].n_ids;
