@@ -179,9 +179,103 @@ struct BlockReader {
       r = e2;
     }
   }
+  // ---- memory-mapped files: the record boundaries of the whole file, found by several threads -----------------
+  // Thread t guesses a record start at or behind byte t*size/T (FASTA: a line starting with '>'; FASTQ: a line starting
+  // with '@' whose second next line starts with '+') and walks the records from there with the very state machine of
+  // record_end().  The guess of thread t+1 is confirmed if thread t's walk arrives exactly there; otherwise (a quality
+  // line that looks like a header, a file that is not made of four-line records ...) everything is redone
+  // sequentially, so the boundaries are always those of the sequential walk.
+  std::vector<size_t> rec_start;        // start offset of every record (leading empty lines included), then the end
+  bool prescanned = false;
+  size_t next_rec = 0;
+  // header position of the record at/after p (empty lines skipped), NONE if only empty lines are left
+  size_t header_at(size_t p) const {
+    for (;;) {
+      if (p >= size) return NONE;
+      const size_t e = line_end(p);
+      if (e - p == 1 && data[p] == '\n') { p = e; continue; }
+      return p;
+    }
+  }
+  size_t guess_start(size_t from) const {
+    size_t q = from;
+    if (q > 0) { const void *nl = memchr(data + q - 1, '\n', size - (q - 1)); if (!nl) return size; q = (size_t)((const char *)nl - data) + 1; }
+    while (q < size) {
+      const size_t e1 = line_end(q);
+      if (!fastq) { if (data[q] == '>') return q; }
+      else if (data[q] == '@' && e1 < size) {
+        const size_t e2 = line_end(e1);
+        if (e2 < size && data[e2] == '+') return q;
+      }
+      q = e1;
+    }
+    return size;
+  }
+  void prescan(unsigned threads) {
+    // opt-in (KAIJU_GPU_PRESCAN=1): on the 8-core build box the streaming walk, which overlaps with parsing, is as fast;
+    // meant for hosts with many cores and files in the page cache
+    if (!mapped || prescanned || !getenv("KAIJU_GPU_PRESCAN")) return;
+    if (record_end(pos) == NONE) { rec_start.assign(1, size); prescanned = true; return; }   // (also settles fastq / fasta)
+    size_t min_bytes = 32u << 20;
+    if (const char *e = getenv("KAIJU_GPU_PRESCAN_MIN")) min_bytes = (size_t)atol(e);     // (tests: several threads on small files)
+    unsigned T = size >= min_bytes ? std::max(1u, threads) : 1u;
+    std::vector<size_t> guess(T + 1, size);
+    guess[0] = pos;
+    for (unsigned t = 1; t < T; t++) guess[t] = guess_start((size_t)((unsigned __int128)size * t / T));
+    for (unsigned t = 1; t < T; t++) if (guess[t] < guess[t - 1]) guess[t] = guess[t - 1];
+    std::vector<std::vector<size_t>> starts(T);
+    std::vector<size_t> stop(T, 0);
+    auto walk = [&](unsigned t) {
+      size_t p = guess[t];
+      const size_t limit = guess[t + 1];
+      while (p < limit) {
+        const size_t h = header_at(p);
+        if (h == NONE || h >= limit) break;
+        starts[t].push_back(p);
+        p = record_end(p);                     // (const for mapped files once the type is known)
+      }
+      stop[t] = p;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(walk, t);
+    walk(0);
+    for (auto &x : th) x.join();
+    bool good = true;
+    for (unsigned t = 0; t + 1 < T && good; t++) {
+      // thread t must have stopped in front of thread t+1's first record with nothing but empty lines in between
+      const size_t h = header_at(stop[t]);
+      const size_t want_h = starts[t + 1].empty() ? header_at(guess[t + 1]) : header_at(starts[t + 1][0]);
+      if (stop[t] > guess[t + 1] || h != want_h) good = false;
+    }
+    rec_start.clear();
+    if (good) {
+      // a record starts where the one before it ended (empty lines in front of a header belong to its record)
+      size_t prev_end = pos;
+      for (unsigned t = 0; t < T; t++) {
+        for (size_t k = 0; k < starts[t].size(); k++) rec_start.push_back(k == 0 ? prev_end : starts[t][k]);
+        if (!starts[t].empty()) prev_end = stop[t];
+      }
+      rec_start.push_back(size);
+    } else {
+      size_t p = pos;
+      for (;;) { const size_t e = record_end(p); if (e == NONE) break; rec_start.push_back(p); p = e; }
+      rec_start.push_back(size);
+    }
+    prescanned = true;
+  }
+
   // false when the file is exhausted and nothing was produced
   bool next(RawBlock &out, uint32_t want) {
     out.n_records = 0; out.own.clear();
+    if (prescanned) {
+      const size_t n = rec_start.size() - 1;
+      if (next_rec >= n) return false;
+      const size_t last = std::min(n, next_rec + want);
+      out.text = data + rec_start[next_rec]; out.size = rec_start[last] - rec_start[next_rec];
+      out.n_records = (uint32_t)(last - next_rec); out.fastq = fastq;
+      next_rec = last;
+      return true;
+    }
     size_t p = pos;
     while (out.n_records < want) {
       const size_t e = record_end(p);
@@ -465,6 +559,7 @@ int main(int argc, char **argv) {
       if (paired) {
         r2.reset(new BlockReader(in2_fn));
         if (!r2->ok) die("Could not open file " + in2_fn);
+      r2->prescan(n_workers);
         reader2 = std::thread([&] {
           uint64_t k = 0;
           for (;;) {

@@ -50,8 +50,12 @@ def ref_records(text: bytes):
     return out
 
 
-def run_cli(tmp_path, f1, f2=None, batch=None):
+def run_cli(tmp_path, f1, f2=None, batch=None, prescan_threads=None):
     env = dict(os.environ, KAIJU_GPU_PARSE_ONLY="1")
+    if prescan_threads:                       # several boundary-scan threads even on these small files
+        env["KAIJU_GPU_PRESCAN"] = "1"
+        env["KAIJU_GPU_PRESCAN_MIN"] = "0"
+        env["KAIJU_GPU_HOST_THREADS"] = str(prescan_threads)
     if batch:
         env["KAIJU_GPU_BATCH"] = str(batch)
     cmd = [CLI, "-i", str(f1)] + (["-j", str(f2)] if f2 else [])
@@ -112,6 +116,9 @@ def test_fastq_ingest(have_cli, tmp_path, variant):
         got = run_cli(tmp_path, path, batch=batch)
         assert len(got) == len(want)
         assert [(g[0], g[1]) for g in got] == want, batch
+    for threads in (2, 5, 13):
+        got = run_cli(tmp_path, path, batch=97, prescan_threads=threads)
+        assert [(g[0], g[1]) for g in got] == want, threads
 
 
 def test_fasta_ingest(have_cli, tmp_path):
@@ -123,6 +130,9 @@ def test_fasta_ingest(have_cli, tmp_path):
     for batch in (None, 3, 500):
         got = run_cli(tmp_path, path, batch=batch)
         assert [(g[0], g[1]) for g in got] == want, batch
+    for threads in (3, 8):
+        got = run_cli(tmp_path, path, batch=50, prescan_threads=threads)
+        assert [(g[0], g[1]) for g in got] == want, threads
     with gzip.open(tmp_path / "r.fa.gz", "wb") as f:
         f.write(text)
     assert [(g[0], g[1]) for g in run_cli(tmp_path, tmp_path / "r.fa.gz", batch=64)] == want
@@ -136,6 +146,8 @@ def test_paired_ingest(have_cli, tmp_path):
     (tmp_path / "b.fq").write_bytes(t2)
     w1, w2 = ref_records(t1), ref_records(t2)
     got = run_cli(tmp_path, tmp_path / "a.fq", tmp_path / "b.fq", batch=97)
+    assert [(g[0], g[1], g[2]) for g in got] == [(a[0], a[1], b[1]) for a, b in zip(w1, w2)]
+    got = run_cli(tmp_path, tmp_path / "a.fq", tmp_path / "b.fq", batch=97, prescan_threads=6)
     assert [(g[0], g[1], g[2]) for g in got] == [(a[0], a[1], b[1]) for a, b in zip(w1, w2)]
 
 
@@ -159,3 +171,23 @@ def test_multi_file_lists(have_cli, tmp_path):
     # list lengths must agree
     r = subprocess.run([multi, "-i", ",".join(ins), "-o", outs[0]], env=env, capture_output=True, timeout=120)
     assert r.returncode != 0 and b"Length of input/output file lists differs" in r.stderr
+
+
+def test_prescan_false_start_is_caught(have_cli, tmp_path):
+    """a quality line that starts with '@' in front of a record whose sequence line starts with '+': the boundary guess of a
+    scan thread can land on it; the walk of the thread before does not arrive there, everything is redone sequentially"""
+    rng = np.random.default_rng(31)
+    recs = []
+    for i in range(4000):
+        L = int(rng.integers(20, 120))
+        seq = bytes(rng.choice(list(b"ACGT"), L).tolist())
+        if i % 2:
+            seq = b"+" + seq[1:]                       # (strip() drops the '+')
+        recs.append(b"@r%d\n" % i + seq + b"\n+\n" + b"@" + b"I" * (L - 1) + b"\n")
+    text = b"".join(recs)
+    path = tmp_path / "adv.fq"
+    path.write_bytes(text)
+    want = ref_records(text)
+    for threads in (2, 7, 16):
+        got = run_cli(tmp_path, path, batch=333, prescan_threads=threads)
+        assert [(g[0], g[1]) for g in got] == want, threads
