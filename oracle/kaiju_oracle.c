@@ -342,13 +342,14 @@ void ko_get_suffix(ko_index *f, int64_t i, int32_t *iseq, int64_t *pos) {
 typedef struct SI {
   int64_t start;
   int len, qi, ql;
+  int count;                 /* rows in this node, its samelen chain and everything behind it (max_matches bookkeeping) */
   struct SI *next, *samelen;
 } SI;
 
 static SI *alloc_SI(const int64_t si[2], int qi, int ql) {
   SI *r = (SI *)malloc(sizeof(SI));
   r->start = si[0]; r->len = (int)(si[1] - si[0]);
-  r->qi = qi; r->ql = ql; r->next = NULL; r->samelen = NULL;
+  r->qi = qi; r->ql = ql; r->count = 0; r->next = NULL; r->samelen = NULL;
   return r;
 }
 static void free_SI_rec(SI *si) {
@@ -407,6 +408,61 @@ static SI *maxMatches(ko_index *f, const uint8_t *str, int len, int L) {
       if (!cur || i < cur->qi) {
         cur = alloc_SI(si, i, l);
         first = insert_SI_sorted(first, cur);
+      }
+    }
+    if (i <= 1) break;
+  }
+  return first;
+}
+
+/* insert_SI_sorted with the ->count bookkeeping, bwt.c:225-252 */
+static SI *insert_SI_sorted_cnt(SI *base, SI *nw) {
+  nw->count = nw->len;
+  if (!base) return nw;
+  if (base->ql < nw->ql) { nw->next = base; nw->count += base->count; return nw; }
+  SI *tmp = base;
+  while (tmp->next && tmp->next->ql >= nw->ql) { tmp->count += nw->len; tmp = tmp->next; }
+  tmp->count += nw->len;
+  if (tmp->ql == nw->ql) {
+    nw->samelen = tmp->samelen;
+    if (tmp->samelen) nw->count += tmp->samelen->count;
+    tmp->samelen = nw;
+  } else {
+    nw->next = tmp->next;
+    if (tmp->next) nw->count += tmp->next->count;
+    tmp->next = nw;
+  }
+  return base;
+}
+/* free_until_max_SI, bwt.c:204-219: drop the shortest length classes while at least max rows stay */
+static int free_until_max_SI(SI *si, int max) {
+  if (!si || si->count <= max) return 0;
+  int n = si->count;
+  SI *cur = si;
+  while (cur->next && n - cur->next->count < max) cur = cur->next;
+  if (cur->next) {
+    n = cur->next->count;
+    free_SI_rec(cur->next);
+    cur->next = NULL;
+    while (si) { si->count -= n; si = si->next; }
+  }
+  return cur->ql;
+}
+/* maxMatches with max_matches > 0, bwt.c:261-296 (kaijux's MEM search, ConsumerThreadx.cpp:135) */
+static SI *maxMatches_limited(ko_index *f, const uint8_t *str, int len, int L, int max_matches) {
+  SI *first = NULL, *cur = NULL;
+  int64_t si[2];
+  for (int j = len - 1; j >= L - 1; j--) {
+    ko_initial_si(f, str[j], si);
+    int i = extend_left(f, str, j, si);
+    int l = j - i + 1;
+    if (l >= L) {
+      if (!cur || i < cur->qi) {
+        cur = alloc_SI(si, i, l);
+        first = insert_SI_sorted_cnt(first, cur);
+        int k = free_until_max_SI(first, max_matches);
+        if (k > L) L = k;
+        if (l < k) cur = NULL;
       }
     }
     if (i <= 1) break;
@@ -835,6 +891,7 @@ static void ids_from_SI(Ctx *c, IdSet *ids, int64_t start, int len) {
     ko_get_suffix(c->ix, k, &iseq, &pos);
     int ok;
     uint64_t id = ko_seq_taxid(c->ix, iseq, &ok);
+    if (c->p->kaijux) { id = (uint64_t)iseq; ok = 1; }      /* ConsumerThreadx.cpp:261-287: the sequence itself */
     if (!ok) continue;
     int seen = 0;
     for (int i = 0; i < ids->n; i++) if (ids->id[i] == id) { seen = 1; break; }
@@ -854,7 +911,7 @@ static void classify_length(Ctx *c, ko_hit *out, IdSet *ids) {
     g_cnt.fragments_searched++;
     uint8_t *seq = to_numbers(c->ix, t->seq, t->len);
     unsigned L = c->p->min_fragment_length > longest ? c->p->min_fragment_length : longest;
-    SI *si = greedyExact(c->ix, seq, t->len, (int)L);
+    SI *si = c->p->kaijux ? maxMatches_limited(c->ix, seq, t->len, (int)L, 1) : greedyExact(c->ix, seq, t->len, (int)L);
     free(seq);
     frag_free(t);
     if (!si) continue;
@@ -1092,6 +1149,7 @@ void ko_default_params(ko_params *p, int mode) {
   p->min_evalue = 0.01;
   p->max_matches_SI = 20;
   p->max_match_ids = 20;
+  p->kaijux = 0; p->pad_ = 0;
 }
 
 void ko_classify(ko_index *ix, ko_taxonomy *tax, const ko_params *p,
@@ -1116,6 +1174,7 @@ void ko_classify(ko_index *ix, ko_taxonomy *tax, const ko_params *p,
   if (ids.cap_hit) out->flags |= 1;
   for (int i = 0; i < ids.n; i++) out->taxid[i] = ids.id[i];
   if (ids.n == 0) { if (!(out->flags & 4) && p->mode == 0) { /* keep best */ } return; }
+  if (p->kaijux) { out->classified = 1; return; }          /* no taxonomy: reported with its sequences */
   if (tax) {
     out->lca = (ids.n == 1) ? ids.id[0] : ko_lca(tax, ids.id, ids.n);
     out->classified = out->lca > 0;

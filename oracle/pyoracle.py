@@ -21,6 +21,7 @@ ORACLE_SO = os.path.join(HERE, "libkaiju_oracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 REF_SO = os.path.join(REF_DIR, "libkaijuref.so")
 REF_KAIJU = os.path.join(REF_DIR, "kaiju")
+REF_KAIJUX = os.path.join(REF_DIR, "kaijux")
 REF_MKBWT = os.path.join(REF_DIR, "kaiju-mkbwt")
 REF_MKFMI = os.path.join(REF_DIR, "kaiju-mkfmi")
 
@@ -32,7 +33,8 @@ class KoParams(C.Structure):
                 ("mismatches", C.c_uint32), ("min_score", C.c_uint32),
                 ("seed_length", C.c_uint32), ("seg", C.c_int32),
                 ("use_evalue", C.c_int32), ("min_evalue", C.c_double),
-                ("max_matches_SI", C.c_uint32), ("max_match_ids", C.c_uint32)]
+                ("max_matches_SI", C.c_uint32), ("max_match_ids", C.c_uint32),
+                ("kaijux", C.c_int32), ("pad_", C.c_int32)]
 
 
 class KoHit(C.Structure):
@@ -250,6 +252,18 @@ def ref_build_index(faa_path, out_prefix, threads=8, exponent=3):
 def ref_kaiju(nodes, fmi, reads, out, mode="mem", reads2=None, seg=True, threads=1, extra=()):
     cmd = [REF_KAIJU, "-t", nodes, "-f", fmi, "-i", reads, "-o", out, "-z", str(threads), "-v"]
     cmd += ["-a", mode]
+    if reads2:
+        cmd += ["-j", reads2]
+    if not seg:
+        cmd += ["-X"]
+    cmd += list(extra)
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    return out
+
+
+def ref_kaijux(fmi, reads, out, mode="greedy", reads2=None, seg=True, threads=1, extra=()):
+    """the reference's kaijux (no taxonomy; lines name database sequences)"""
+    cmd = [REF_KAIJUX, "-f", fmi, "-i", reads, "-o", out, "-z", str(threads), "-a", mode]
     if reads2:
         cmd += ["-j", reads2]
     if not seg:

@@ -92,3 +92,26 @@ def test_fragment_order(oracle):
     # a base that is not ACGTU terminates the frame like a stop codon
     fr2 = oracle.fragments(p, read.replace(b"GGT", b"GNT", 1))
     assert not any(s.startswith(b"MAAKGSAPEELFKGTA") for _, s in fr2)
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_kaijux_lines(oracle, golden, ox, mode):
+    """kaijux semantics of the oracle (ids = database sequences; MEM searched with maxMatches(.., 1) as
+    ConsumerThreadx.cpp:135 does) == the lines of the reference's kaijux binary, single and paired"""
+    ix, _ = ox
+    for seqs, off, names, pe, tsv in ((golden.seqs, golden.off, golden.names, False, f"refx_{mode}.tsv"),
+                                      (golden.pseqs, golden.poff, golden.pnames, True, f"refx_{mode}_pe.tsv")):
+        hits = oracle.classify(ix, None, oracle.params(mode, seg=1, kaijux=1), seqs, off, paired=pe)
+        lines = {}
+        with open(os.path.join(golden.dir, tsv)) as f:
+            for line in f:
+                q = line.rstrip("\n").split("\t")
+                lines[q[1]] = q
+        for h, nm in zip(hits, names):
+            ref = lines[nm]
+            if h["classified"]:
+                ids = sorted(int(x) for x in h["taxid"][:h["n_ids"]])
+                got = "".join(oracle.lib.ko_seq_name(ix, i).decode() + "," for i in ids)
+                assert ref[0] == "C" and int(ref[2]) == int(h["best"]) and ref[3] == got, (mode, pe, nm, ref, got)
+            else:
+                assert ref[0] == "U", (mode, pe, nm, ref)

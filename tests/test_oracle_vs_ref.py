@@ -74,3 +74,32 @@ def test_end_to_end(oracle, data, mode, seg):
         mine = ("C", int(h["lca"]), int(h["best"]), tuple(sorted(int(x) for x in h["taxid"][:h["n_ids"]]))) \
             if h["classified"] else ("U", 0, None, ())
         assert mine == ref[f"r{i}"], i
+
+
+@pytest.mark.skipif(not os.path.exists(po.REF_KAIJUX), reason="oracle/_ref/kaijux not built")
+@pytest.mark.parametrize("mode,seg", [("mem", True), ("mem", False), ("greedy", True)])
+def test_end_to_end_kaijux(oracle, data, mode, seg):
+    """kaijux mode of the oracle (ids = database sequences, MEM through maxMatches(.., 1)) against the
+    reference's kaijux on the same random data"""
+    W, db, reads = data
+    out = f"{W}/refx_{mode}_{int(seg)}.tsv"
+    po.ref_kaijux(f"{W}/db.fmi", f"{W}/reads.fq", out, mode=mode, seg=seg)
+    ref = {}
+    with open(out) as f:
+        for line in f:
+            q = line.rstrip("\n").split("\t")
+            ref[q[1]] = q
+    ix = oracle.load_fmi(f"{W}/db.fmi")
+    seqs, off = synth.pack_reads(reads)
+    hits = oracle.classify(ix, None, oracle.params(mode, seg=int(seg), kaijux=1), seqs, off)
+    nc = 0
+    for i, h in enumerate(hits):
+        r = ref[f"r{i}"]
+        if h["classified"]:
+            nc += 1
+            ids = sorted(int(x) for x in h["taxid"][:h["n_ids"]])
+            got = "".join(oracle.lib.ko_seq_name(ix, j).decode() + "," for j in ids)
+            assert r[0] == "C" and int(r[2]) == int(h["best"]) and r[3] == got, (i, r, got)
+        else:
+            assert r[0] == "U", (i, r)
+    assert nc > len(hits) // 4
