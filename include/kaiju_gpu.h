@@ -67,6 +67,7 @@ typedef struct {
   uint32_t seed_length;         /* -l, default 7 (Greedy)                            */
   int32_t seg;                  /* -x / -X, default on                               */
   int32_t use_evalue;           /* Greedy default on; "-a mem" turns it off          */
+  int32_t input_is_protein;     /* -p (Config.hpp:42) and kaijup: reads are protein sequences; unpaired only */
   double min_evalue;            /* -E, default 0.01                                  */
   uint32_t max_matches_SI;      /* 20                                                */
   uint32_t max_match_ids;       /* 20                                                */
@@ -83,6 +84,10 @@ typedef struct {
 
 #define KAIJU_HIT_ID_CAP 1u     /* the 21-id cap ended the traversal (order sensitive case)   */
 #define KAIJU_HIT_SI_CAP 2u     /* Greedy: > max_matches_SI equal-score matches existed       */
+#define KAIJU_HIT_INEXACT 0x80000000u /* a device-side capacity bound was exceeded for this read (a fragment with more
+                                   than 15 SEG regions or longer than 65535 residues, or search scratch exhausted even in
+                                   the retry pass): the record is NOT guaranteed to equal the reference's.  MEM reports
+                                   the SEG case per batch only: kaiju_gpu_stats.error_flags                    */
 
 /* what the host seam turns a hit into: one output line "C/U \t name \t taxon" */
 typedef struct {
@@ -211,7 +216,7 @@ typedef struct kaiju_gpu_taxonomy kaiju_gpu_taxonomy;
 typedef struct {
   uint64_t lca;        /* LCA of the ids of the hit; 0 = no hit, or none of its ids is in nodes.dmp */
   uint32_t best;       /* as kaiju_gpu_hit.best                                                    */
-  uint32_t info;       /* kaiju_gpu_hit.flags << 8 | n_ids                                         */
+  uint32_t info;       /* kaiju_gpu_hit.flags << 8 | n_ids; bit 31 = KAIJU_HIT_INEXACT               */
 } kaiju_gpu_compact;
 int kaiju_gpu_taxonomy_upload(const kaiju_taxonomy *t, int device_id, kaiju_gpu_taxonomy **out);
 void kaiju_gpu_taxonomy_free(kaiju_gpu_taxonomy *t);

@@ -24,7 +24,7 @@ class Params(C.Structure):
     _fields_ = [("mode", C.c_int32), ("min_fragment_length", C.c_uint32),
                 ("mismatches", C.c_uint32), ("min_score", C.c_uint32),
                 ("seed_length", C.c_uint32), ("seg", C.c_int32),
-                ("use_evalue", C.c_int32), ("min_evalue", C.c_double),
+                ("use_evalue", C.c_int32), ("input_is_protein", C.c_int32), ("min_evalue", C.c_double),
                 ("max_matches_SI", C.c_uint32), ("max_match_ids", C.c_uint32)]
 
 
@@ -118,12 +118,18 @@ def device_count() -> int:
     return lib().kaiju_gpu_device_count()
 
 
+IDS_TAXON, IDS_SEQUENCE = 0, 1     # kaiju_gpu_index_load_ex
+
+
 class Index:
     """FM-index resident in HBM (readFMI + Config::init of the reference)."""
 
-    def __init__(self, fmi_path: str, device: int = 0):
+    def __init__(self, fmi_path: str, device: int = 0, id_mode: int = 0):
+        """id_mode IDS_SEQUENCE: hits collect database sequence numbers instead of taxon ids (kaijux / kaijup)"""
         self._h = C.c_void_p()
-        _check(lib().kaiju_gpu_index_load(fmi_path.encode(), device, C.byref(self._h)))
+        L = lib()
+        L.kaiju_gpu_index_load_ex.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        _check(L.kaiju_gpu_index_load_ex(fmi_path.encode(), device, id_mode, C.byref(self._h)))
         self.info = IndexInfo()
         _check(lib().kaiju_gpu_index_get_info(self._h, C.byref(self.info)))
         self.device = device

@@ -50,6 +50,7 @@ def build_cli(force=False, verbose=False):
     """the drop-in `kaiju` command (host C++ over the C-ABI)"""
     multi = os.path.join(os.path.dirname(CLI), "kaiju-multi")
     if (not force and os.path.exists(CLI) and os.path.exists(multi) and os.path.exists(os.path.join(os.path.dirname(CLI), "kaijux")) and
+            os.path.exists(os.path.join(os.path.dirname(CLI), "kaijup")) and
             os.path.getmtime(CLI) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(LIB))):
         return CLI
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
@@ -62,6 +63,7 @@ def build_cli(force=False, verbose=False):
     import shutil as _sh
     _sh.copy2(CLI, multi)
     _sh.copy2(CLI, os.path.join(os.path.dirname(CLI), "kaijux"))      # kaijux: database sequences instead of taxa
+    _sh.copy2(CLI, os.path.join(os.path.dirname(CLI), "kaijup"))      # kaijup: kaijux for protein reads
     return CLI
 
 

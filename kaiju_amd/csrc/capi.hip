@@ -66,6 +66,29 @@ k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch 
   if (e) atomicOr(err, e);
 }
 
+// Stage 1 for protein reads (kaiju -p, kaijup): one lane per read, peptides written in place
+__global__ void __launch_bounds__(kFragBlock)
+k_fragments_protein(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err) {
+  __shared__ ConstTables s_ct;
+  __shared__ int32_t s_entg[17];
+  __shared__ uint8_t s_code[256];
+  if (threadIdx.x < 17) s_entg[threadIdx.x] = st.ent_g32[threadIdx.x];
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
+    for (uint32_t i = threadIdx.x; i < sizeof(ConstTables) / 4; i += kFragBlock) dst[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < 256; i += kFragBlock) s_code[i] = 0;
+    __syncthreads();
+    if (threadIdx.x < 20) protein_code_entry(s_ct, threadIdx.x, s_code);
+    __syncthreads();
+  }
+  const uint32_t r = blockIdx.x * kFragBlock + threadIdx.x;
+  if (r >= b.n_reads) return;
+  uint32_t e = 0;
+  build_fragments_protein(s_ct, s_code, p, TrigCtx{s_entg, st.ent_locut32}, b, sq, r, &e);
+  if (e) atomicOr(err, e);
+}
+
 // one wavefront per fragment: lanes share the sub-windows of s_Trim
 struct CoopWave {
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
@@ -144,6 +167,28 @@ k_mem_wide2(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
   mem_lane2<true>(ix, p, b, wl, ls);
+}
+// kaijux (ids = database sequences): the matches of a fragment are visited in the list order of maxMatches(.., 1)
+// (kj_core.h: XORDER); the first-generation lanes take the same switch from Params::flags
+__global__ void __launch_bounds__(kBlock, 4)
+k_mem_x(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  mem_lane2<false, true>(ix, p, b, wl, ls);
+}
+__global__ void __launch_bounds__(kBlock, 3)
+k_mem_wide2_x(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  mem_lane2<true, true>(ix, p, b, wl, ls);
 }
 // first-generation lane with 32-bit positions (kept for A/B measurements: KAIJU_GPU_MEM_LANE=v1)
 __global__ void __launch_bounds__(kBlock)
@@ -330,6 +375,7 @@ struct kaiju_gpu_index {
   std::vector<void *> allocs;
   kaiju_gpu_index_info info{};
   std::vector<std::string> names;
+  int id_mode = 0;                // KAIJU_GPU_IDS_TAXON / KAIJU_GPU_IDS_SEQUENCE
   ~kaiju_gpu_index() {
     (void)hipSetDevice(device);
     for (void *p : allocs) (void)hipFree(p);
@@ -371,6 +417,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   if (tl_id_mode == 1) pk.to_sequence_ids();
   std::unique_ptr<kaiju_gpu_index> ix(new kaiju_gpu_index());
   ix->device = device_id;
+  ix->id_mode = tl_id_mode;
   rc = build_const_tables(pk.trans, ix->ct_host, msg);
   if (rc) return fail(rc, msg);
   std::vector<double> lnfact;
@@ -597,6 +644,7 @@ extern "C" void kaiju_gpu_default_params(kaiju_gpu_params *p, int mode) {
   p->min_evalue = 0.01;
   p->max_matches_SI = 20;
   p->max_match_ids = 20;
+  p->input_is_protein = 0;
 }
 
 extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, const kaiju_gpu_params *p) {
@@ -617,6 +665,10 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   c->kp.min_score = p->min_score; c->kp.seed_length = p->seed_length; c->kp.seg = p->seg ? 1 : 0;
   c->kp.max_matches_SI = p->max_matches_SI; c->kp.max_match_ids = p->max_match_ids;
   if (const char *e = getenv("KAIJU_GPU_DEBUG")) c->kp.debug = (uint32_t)atoi(e);
+  // kaijux: the MEM search of ConsumerThreadx.cpp:135 (maxMatches(.., 1)) finds the same longest matches as
+  // greedyExact but lists them in another order, which shows where the id cap cuts and in the peptides of -v
+  if (ix->id_mode == KAIJU_GPU_IDS_SEQUENCE && p->mode == 0) c->kp.flags |= kParamXOrder;
+  if (p->input_is_protein) c->kp.flags |= kParamProtein;
   KJ_HIP(hipSetDevice(ix->device));
   hipDeviceProp_t prop;
   KJ_HIP(hipGetDeviceProperties(&prop, ix->device));
@@ -656,6 +708,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   const kaiju_gpu_index *ix = c->ix;
   const Params &p = c->kp;
   if (max_read_len == 0) max_read_len = 1024;
+  const bool protein = (p.flags & kParamProtein) != 0;
+  if (protein) {
+    // a protein read is its own (single) frame: fragments are up to max_read_len long, not a third of it
+    if (paired) return fail(KAIJU_GPU_ERR_ARG, "protein input has no paired mode (kaiju.cpp:201)");
+    if (max_read_len > 0x10000000u) return fail(KAIJU_GPU_ERR_UNSUPPORTED, "protein read longer than 2^28");
+    max_read_len *= 3;
+  }
   const uint64_t max_pair = (uint64_t)max_read_len * (paired ? 2 : 1);
   // stage buffers
   const uint64_t pep_bytes = 2 * seq_bytes + 80ull * n + 32 + 256;   // pep_base() + window over-read slack
@@ -687,8 +746,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     // LDS staging area per lane: all frame strings of a read (or pair), rounded to 16 bytes
     uint32_t per_lane = (uint32_t)((2 * max_pair + 12 + 15) & ~15ull);
     if ((uint64_t)per_lane * kFragBlock > 60000) per_lane = 0;        // long reads: write in place
-    hipLaunchKernelGGL(k_fragments, dim3((n + kFragBlock - 1) / kFragBlock), dim3(kFragBlock),
-                       (size_t)per_lane * kFragBlock, s, ix->d_ct, p, ix->st, b, sq, cnt + 3, per_lane);
+    if (protein)
+      hipLaunchKernelGGL(k_fragments_protein, dim3((n + kFragBlock - 1) / kFragBlock), dim3(kFragBlock), 0, s,
+                         ix->d_ct, p, ix->st, b, sq, cnt + 3);
+    else
+      hipLaunchKernelGGL(k_fragments, dim3((n + kFragBlock - 1) / kFragBlock), dim3(kFragBlock),
+                         (size_t)per_lane * kFragBlock, s, ix->d_ct, p, ix->st, b, sq, cnt + 3, per_lane);
     KJ_HIP(hipGetLastError());
   }
   KJ_HIP(hipEventRecord(c->ev[1], s));
@@ -733,13 +796,18 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     if (n > 0) {
       const char *lane_env = getenv("KAIJU_GPU_MEM_LANE");
       const bool v1 = lane_env && !strcmp(lane_env, "v1");
+      const bool xo = (p.flags & kParamXOrder) != 0;
       if (ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 && !c->verbose)
-        hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+        if (xo) hipLaunchKernelGGL(k_mem_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                                   static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+        else hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                                static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       else if (ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 &&
                !c->verbose)
-        hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+        if (xo) hipLaunchKernelGGL(k_mem_wide2_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                                   static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+        else hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                                static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       else if (ix->dev.sb32)
         hipLaunchKernelGGL(k_mem_v1, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                            static_cast<SIEntry *>(c->scratch_main[0].p), si_cap, vb);

@@ -13,7 +13,10 @@
 // back from the GPU.
 //
 // -v prints the reference's columns 4-7 (match length / score, matching taxon ids, accessions,
-// matched peptides).  -p (protein input) is not supported.
+// matched peptides).  -p: the reads are protein sequences (kaiju.cpp:94, ConsumerThread.cpp:640-696).
+// Started under the name kaijux the program reports database sequences instead of taxa (kaijux.cpp), under
+// kaijup it does that for protein reads (kaijup.cpp, ConsumerThreadp.cpp), under kaiju-multi it takes comma
+// separated file lists (kaiju-multi.cpp).
 #include <getopt.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -56,6 +59,7 @@ void usage(const char *prog) {
   fprintf(stderr, "   -E FLOAT      Minimum E-value in Greedy mode (default: 0.01)\n");
   fprintf(stderr, "   -x            Enable SEG low complexity filter (enabled by default)\n");
   fprintf(stderr, "   -X            Disable SEG low complexity filter\n");
+  fprintf(stderr, "   -p            Input sequences are protein sequences\n");
   fprintf(stderr, "   -v            Enable verbose output\n");
   exit(EXIT_FAILURE);
 }
@@ -315,6 +319,9 @@ struct Batch {
   std::string text;
 };
 
+// kaijup keeps the whole header line as the read name (kaijup.cpp:249-262 has no suffix cutting)
+bool g_keep_names = false;
+
 inline void append_stripped(std::vector<char> &dst, const char *s, size_t n) {   // strip(), util.cpp:25-32
   const size_t old = dst.size();
   dst.resize(old + n);
@@ -343,7 +350,8 @@ struct BlockCursor {
     do { if (!line(s, n)) return false; } while (n == 0);
     s++; n--;                               // erase(0,1)
     size_t cut = 0;
-    while (cut < n && s[cut] != ' ' && s[cut] != '/' && s[cut] != '\t' && s[cut] != '\r') cut++;
+    if (g_keep_names) cut = n;
+    else while (cut < n && s[cut] != ' ' && s[cut] != '/' && s[cut] != '\t' && s[cut] != '\r') cut++;
     name = s; name_len = cut;
     if (b.fastq) {
       if (line(s, n)) append_stripped(seqs, s, n);
@@ -424,7 +432,23 @@ inline void append_u64(std::string &s, unsigned long long v) {
 
 }  // namespace
 
+// kaijup's choice between "U<TAB>name<TAB>0" and "U<TAB>name" (ConsumerThreadp.cpp:22-71): does the protein read yield
+// any fragment, i.e. a run of at least -m amino-acid letters that (Greedy) scores at least -s on the BLOSUM62 diagonal?
+bool protein_has_fragment(const char *s, uint64_t len, const kaiju_gpu_params &p) {
+  static const int8_t diag[26] = {4, 0, 9, 6, 5, 6, 6, 8, 4, 0, 5, 4, 5, 6, 0, 7, 5, 5, 4, 5, 0, 4, 11, 0, 7, 0};   // A..Z, 0: no amino acid
+  uint64_t run = 0; uint32_t score = 0;
+  for (uint64_t i = 0; i <= len; i++) {
+    int d = 0;
+    if (i < len) { const int c = s[i] & ~32; if (c >= 'A' && c <= 'Z' && ((s[i] >= 'a' && s[i] <= 'z') || (s[i] >= 'A' && s[i] <= 'Z'))) d = diag[c - 'A']; }
+    if (d) { run++; score += (uint32_t)d; continue; }
+    if (run >= p.min_fragment_length && (p.mode == 0 || score >= p.min_score)) return true;
+    run = 0; score = 0;
+  }
+  return false;
+}
+
 int main(int argc, char **argv) {
+  std::atomic<uint64_t> inexact_batches{0}, inexact_reads{0};
   kaiju_gpu_params params;
   kaiju_gpu_default_params(&params, 1);
   std::string nodes_fn, fmi_fn, in1_fn, in2_fn, out_fn;
@@ -462,20 +486,21 @@ int main(int argc, char **argv) {
   // which program this is (kaiju, kaiju-multi, kaijux) is decided by the name it was started under
   std::string prog = argv[0];
   if (prog.find('/') != std::string::npos) prog = prog.substr(prog.rfind('/') + 1);
-  if (prog.find("kaijux") != std::string::npos && nodes_fn.empty()) nodes_fn = "-";
+  if ((prog.find("kaijux") != std::string::npos || prog.find("kaijup") != std::string::npos) && nodes_fn.empty()) nodes_fn = "-";
   if (nodes_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the nodes.dmp file, using the -t option.\n\n"); usage(argv[0]); }
   if (fmi_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the FMI file, using the -f option.\n\n"); usage(argv[0]); }
   if (in1_fn.empty()) { fprintf(stderr, "Error: Please specify the location of the input file, using the -i option.\n\n"); usage(argv[0]); }
-  if (protein) die("Protein input (-p) is not supported by the GPU path.");
+  // kaijup (kaijup.cpp, ConsumerThreadp.cpp): kaijux for protein reads
+  const bool pmode = prog.find("kaijup") != std::string::npos;
+  if (pmode) { protein = true; g_keep_names = true; if (nodes_fn.empty()) nodes_fn = "-"; }
+  if (paired && protein) { fprintf(stderr, "Error: Protein input only supports one input file.\n\n"); usage(argv[0]); }
+  params.input_is_protein = protein ? 1 : 0;
   if (params.use_evalue && params.mode == 0) die("E-value calculation is only possible in Greedy run mode.");
 
   // kaijux (kaijux.cpp, ConsumerThreadx.cpp): the same search, but a read is reported with the database sequences it
   // matches (no taxonomy, no nodes.dmp): "C<TAB>name<TAB>score<TAB>seqname,...<TAB>[peptides with -v]" / "U<TAB>name"
-  const bool xmode = prog.find("kaijux") != std::string::npos;
+  const bool xmode = prog.find("kaijux") != std::string::npos || prog.find("kaijup") != std::string::npos;
   if (xmode && nodes_fn.empty()) nodes_fn = "-";
-  if (xmode && params.mode == 0)
-    fprintf(stderr, "Note: kaijux -a mem searches like kaiju -a mem (greedyExact); the reference's kaijux uses maxMatches(.., 1) "
-                    "there, so results can differ from it in rare cases (matched peptides of -v more often).\n");
   // developer/test switch: run the ingest stages only and print "name<TAB>mate1<TAB>mate2" per read
   const bool parse_only = getenv("KAIJU_GPU_PARSE_ONLY") != nullptr;
   if (verbose) fprintf(stderr, "%s Reading database\n", now().c_str());
@@ -620,7 +645,7 @@ int main(int argc, char **argv) {
             b->vrec.resize(n);
             uint64_t maxpair = 0;
             for (uint32_t q = 0; q < n; q++) maxpair = std::max<uint64_t>(maxpair, b->off[2 * (size_t)q + 2] - b->off[2 * (size_t)q]);
-            b->vstride = (uint32_t)std::min<uint64_t>(20 * (maxpair / 3 + 2), 8192) + 1;
+            b->vstride = (uint32_t)std::min<uint64_t>(20 * ((protein ? maxpair : maxpair / 3) + 2), 8192) + 1;
             b->vtext.resize((size_t)n * b->vstride);
             r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data(),
                                                  b->vrec.data(), b->vtext.data(), b->vstride);
@@ -632,7 +657,16 @@ int main(int argc, char **argv) {
             r = kaiju_gpu_classify_batch_compact(ctx[k], dtax, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
           }
           if (r != 0) die(std::string("classification failed: ") + kaiju_gpu_strerror(r) + " (" + kaiju_gpu_last_error() + ")");
-          std::vector<char>().swap(b->seqs);
+          // reads for which a capacity bound of the kernels was exceeded (KAIJU_HIT_INEXACT, kaiju_gpu_stats.error_flags)
+          {
+            kaiju_gpu_stats st;
+            if (kaiju_gpu_get_stats(ctx[k], &st) == 0 && st.error_flags) inexact_batches++;
+            uint64_t ni = 0;
+            if (!b->hits.empty()) { for (uint32_t q = 0; q < n; q++) ni += (b->hits[q].flags & KAIJU_HIT_INEXACT) ? 1 : 0; }
+            else for (uint32_t q = 0; q < n; q++) ni += (b->compact[q].info & KAIJU_HIT_INEXACT) ? 1 : 0;
+            if (ni) inexact_reads += ni;
+          }
+          if (!pmode) std::vector<char>().swap(b->seqs);
           q_done.put(seq, std::move(b));
         }
       });
@@ -650,7 +684,10 @@ int main(int argc, char **argv) {
             for (uint32_t r = 0; r < n; r++) {
               text.append(b->names.data() + b->name_off[r], b->name_off[r + 1] - b->name_off[r]); text += '\t';
               text.append(b->seqs.data() + b->off[2 * r], b->off[2 * r + 1] - b->off[2 * r]); text += '\t';
-              text.append(b->seqs.data() + b->off[2 * r + 1], b->off[2 * r + 2] - b->off[2 * r + 1]); text += '\n';
+              text.append(b->seqs.data() + b->off[2 * r + 1], b->off[2 * r + 2] - b->off[2 * r + 1]);
+              // (kaijup: a fourth column, the decision behind its two kinds of U lines)
+              if (pmode) { text += '\t'; text += protein_has_fragment(b->seqs.data() + b->off[2 * r], b->off[2 * r + 1] - b->off[2 * r], params) ? '1' : '0'; }
+              text += '\n';
             }
             q_text.put(seq, std::move(b));
             continue;
@@ -671,7 +708,9 @@ int main(int argc, char **argv) {
                 // reads below the length gate get the three-column line of kaiju (ConsumerThreadx.cpp:202-207), others "U<TAB>name"
                 const uint64_t l1 = b->off[2 * (size_t)r + 1] - b->off[2 * (size_t)r], l2 = b->off[2 * (size_t)r + 2] - b->off[2 * (size_t)r + 1];
                 const uint64_t m3 = 3ull * params.min_fragment_length;
-                const bool gated = paired ? (l1 < m3 && l2 < m3) : (l1 < m3);
+                bool gated = paired ? (l1 < m3 && l2 < m3) : (l1 < m3);
+                // kaijup: the same line for reads shorter than -m and for reads without any fragment (ConsumerThreadp.cpp:17-21,67-71)
+                if (pmode) gated = l1 < params.min_fragment_length || !protein_has_fragment(b->seqs.data() + b->off[2 * (size_t)r], l1, params);
                 text += "U\t"; text.append(nm, nl); text += gated ? "\t0\n" : "\n";
                 continue;
               }
@@ -747,6 +786,14 @@ int main(int argc, char **argv) {
     run_sample(list1[i], paired ? list2[i] : std::string(), i < list_out.size() ? list_out[i] : std::string());
   }
   if (verbose) fprintf(stderr, "%s Finished.\n", now().c_str());
+  if (inexact_batches.load() || inexact_reads.load()) {
+    // the reference has no such bounds: say so instead of printing lines that may differ from its output silently
+    fprintf(stderr, "%s: a capacity bound of the GPU kernels was exceeded (%llu reads flagged, %llu batches with a fragment of more than "
+                    "15 low-complexity regions or longer than 65535 residues): their lines may differ from the reference's.\n",
+            getenv("KAIJU_GPU_ALLOW_INEXACT") ? "Warning" : "Error", (unsigned long long)inexact_reads.load(),
+            (unsigned long long)inexact_batches.load());
+    if (!getenv("KAIJU_GPU_ALLOW_INEXACT")) return 3;
+  }
   for (int k = 0; k < n_ctx; k++) if (ctx[k]) kaiju_gpu_destroy(ctx[k]);
   if (dtax) kaiju_gpu_taxonomy_free(dtax);
   if (index) kaiju_gpu_index_free(index);

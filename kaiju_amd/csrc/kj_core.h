@@ -102,7 +102,11 @@ struct Params {
   int32_t seg;
   uint32_t max_matches_SI, max_match_ids;
   uint32_t debug = 0;        // developer timing experiments only (KAIJU_GPU_DEBUG): parts of stage 1 skipped, results wrong
+  uint32_t flags = 0;        // kParamXOrder | kParamProtein
 };
+// Params::flags
+constexpr uint32_t kParamXOrder = 1u;    // kaijux: MEM matches of a fragment are visited in maxMatches' list order (see mem_lane)
+constexpr uint32_t kParamProtein = 2u;   // reads are protein sequences (kaiju -p, kaijup): stage 1 = k_fragments_protein
 
 // fragment descriptor (16 bytes)
 struct Frag {
@@ -999,6 +1003,83 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
   b.meta[r] = rm;
 }
 
+// ----------------------------------------------------------------------------
+// stage 1 for protein input (kaiju -p: ConsumerThread.cpp:640-646,659-696; kaijup: ConsumerThreadp.cpp:17-63):
+// the read is upper-cased and split at every character that is not one of the 20 amino acids; runs of at
+// least m residues (Greedy: scoring at least min_score) become the fragments, in left-to-right order behind
+// equal keys.  No translation, one strand: the "peptide area" of the read holds the read itself as
+// index-alphabet codes (0 at separators).  The mate of a pair does not exist here (kaiju.cpp:201).
+// ----------------------------------------------------------------------------
+// ASCII -> index-alphabet code of the amino acid (either case), 0 for every other byte
+KJ_HD void protein_code_entry(const ConstTables &t, uint32_t a, uint8_t *tbl) {
+  const char letters[21] = "ARNDCQEGHILKMFPSTWYV";        // aa2int order, ConsumerThread.cpp:40-60
+  const uint8_t ch = (uint8_t)letters[a];
+  tbl[ch] = tbl[ch | 32u] = t.aa_to_idx[a];
+}
+KJ_HD void build_fragments_protein(const ConstTables &t, const uint8_t *aa_code, const Params &p, const TrigCtx &tc,
+                                   const Batch &b, const SegQueue &sq, uint32_t r, uint32_t *err_flags) {
+  const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1];
+  const uint32_t len = (uint32_t)(o1 - o0);
+  Frag *list = b.frags + frag_base(b.off, r, p.m);
+  const uint32_t cap = frag_cap(b.off, r, p.m);
+  const uint64_t pbase = pep_base(b.off, r);
+  uint8_t *pep = b.pep + pbase;
+  uint32_t n = 0, pending = 0;
+  if (len >= p.m) {                                         // length gate, ConsumerThread.cpp:640-646
+    NucReader rd;
+    rd.open(b.seqs + o0, len);
+    uint32_t run_start = 0, run_len = 0, sum = 0, seq = 0;
+    bool trig = false;
+    TrigWin w;
+    trig_reset(w);
+    for (uint32_t x = 0; x < len; x++) {
+      const uint32_t a = aa_code[rd.at(x)];
+      pep[x] = (uint8_t)a;
+      if (a) {
+        if (run_len == 0) run_start = x;
+        run_len++;
+        sum += (uint32_t)t.diag_idx[a];
+        if (trig_push(w, tc, a, run_len)) trig = true;
+      } else {
+        emit_run(p, list, n, cap, run_start, run_len, sum, seq++, trig);
+        run_len = 0; sum = 0; trig = false;
+        trig_reset(w);
+      }
+    }
+    pep[len] = 0;
+    emit_run(p, list, n, cap, run_start, run_len, sum, seq, trig);     // the remaining sequence, :683-694
+    // queue order (std::multimap<unsigned, Fragment*, std::greater>): descending key, equal keys as emitted
+    for (uint32_t k = 1; k < n; k++) {
+      const Frag f = list[k];
+      uint32_t pos = k;
+      while (pos > 0 && (list[pos - 1].key < f.key || (list[pos - 1].key == f.key && list[pos - 1].flags > f.flags))) {
+        list[pos] = list[pos - 1]; pos--;
+      }
+      list[pos] = f;
+    }
+    for (uint32_t k = 0; k < n; k++) {
+      // (flags so far: emission number << 1 | some 12-window reaches the SEG trigger entropy; see build_fragments)
+      uint32_t fl = 0;
+      if (p.seg) {
+        fl = kFragChecked;
+        if (list[k].flags & 1u) {
+          const uint32_t slot = append_slot(sq.count);
+          if (slot >= sq.cap) { if (err_flags) *err_flags |= 2u; }
+          else {
+            SegWork wk; wk.read = r; wk.frag = k;
+            sq.items[slot] = wk;
+            pending = kNfragSegPending;
+            fl = (slot + 1) << kFragSlotShift;
+          }
+        }
+      }
+      list[k].flags = fl;
+    }
+  }
+  ReadMeta rm; rm.pep = pbase; rm.frag = (uint32_t)frag_base(b.off, r, p.m); rm.nfrag = n | pending;
+  b.meta[r] = rm;
+}
+
 // MEM only: apply the SEG results eagerly (equivalent to the lazy split): split
 // parents are dropped and their pieces re-inserted behind all equal keys, in parent order,
 // left to right
@@ -1159,6 +1240,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
   const P check = (P)((1ull << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
   const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m) ? ix.kmer_k : 0;   // matches shorter than m never count
+  const uint32_t xo = (p.flags & kParamXOrder) ? 1u : 0u;
   uint32_t kidx = 0;
   uint64_t klo64 = 0, khi64 = 0;
 
@@ -1254,27 +1336,31 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
             if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
             else flags = kHitInternalOverflow;
             st = MS_LOC_DONE;
-          } else { gs = ge = cur = 0; st = MS_LOC_NEXT_SI; }
+          } else { gs = ge = 0; cur = xo; st = MS_LOC_NEXT_SI; }
         }
         if (st == MS_LOC_NEXT_SI) {
           // matches of one fragment were found for descending j but are visited for ascending j
-          // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845)
+          // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845).
+          // kParamXOrder (kaijux: maxMatches(.., 1), ConsumerThreadx.cpp:135): the head is the match found first, the
+          // others follow newest first (insert_SI_sorted, bwt.c:241-245): gs, ge-1, .., gs+1 (cur == ge stands for gs)
           bool any = true;
-          if (cur == gs) {
+          if (cur == gs + xo) {
             gs = ge;
             if (gs >= nsi) { st = MS_LOC_DONE; any = false; }
             else {
               const uint32_t fr = ls.si[gs].frag;
               ge = gs + 1;
               while (ge < nsi && ls.si[ge].frag == fr) ge++;
-              cur = ge;
-              // verbose: the head of the fragment's list (the match found last) gives the peptide
-              if (vb.text) vb_text(vb, r, pep + F[fr].start + (uint32_t)(ls.si[ge - 1].lo >> kSiQiShift), L, 0, nullptr, nullptr, 0);
+              cur = ge + xo;
+              // verbose: the head of the fragment's list gives the peptide (greedyExact: the match found last;
+              // maxMatches: the one found first)
+              if (vb.text) vb_text(vb, r, pep + F[fr].start + (uint32_t)(ls.si[xo ? gs : ge - 1].lo >> kSiQiShift), L, 0, nullptr, nullptr, 0);
             }
           }
           if (any) {
             cur--;
-            row = (P)(ls.si[cur].lo & kSiLoMask); rowend = row + (P)(int32_t)ls.si[cur].len;
+            const uint32_t e = (xo && cur == ge) ? gs : cur;
+            row = (P)(ls.si[e].lo & kSiLoMask); rowend = row + (P)(int32_t)ls.si[e].len;
             st = MS_LOC_ROW;
           }
         }
@@ -1377,7 +1463,7 @@ extern unsigned long long kj_hist[8][64];
 #else
 #define KJ_HISTO(h, v)
 #endif
-template <bool WIDE>
+template <bool WIDE, bool XORDER = false>
 KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
                      const LaneScratch &ls) {
   // WIDE: 64-bit positions, block counts relative to mb_base, 16-byte k-mer entries (indexes >= 2^32 rows)
@@ -1638,25 +1724,29 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
           else flags = kHitInternalOverflow;
           bk = BK_FINISH;
-        } else { gs = ge = cur = 0; bk = BK_LOC_NEXT_SI; }
+        } else { gs = ge = 0; cur = XORDER ? 1u : 0u; bk = BK_LOC_NEXT_SI; }
       }
       if (bk == BK_LOC_NEXT_SI) {
         // matches of one fragment were found for descending j but are visited for ascending j
-        // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845)
+        // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845).
+        // XORDER (kaijux, whose classify_length searches with maxMatches(.., 1), ConsumerThreadx.cpp:135): the list
+        // head is the match found FIRST, the others follow newest first (insert_SI_sorted, bwt.c:241-245), i.e. the
+        // visiting order is gs, ge-1, ge-2, .., gs+1; cur runs from ge+1 down to gs+1 and cur == ge stands for gs
         bool any = true;
-        if (cur == gs) {
+        if (cur == gs + (XORDER ? 1u : 0u)) {
           gs = ge;
           if (gs >= nsi) { bk = BK_FINISH; any = false; }
           else {
             const uint32_t fr = si_frag(gs);
             ge = gs + 1;
             while (ge < nsi && si_frag(ge) == fr) ge++;
-            cur = ge;
+            cur = ge + (XORDER ? 1u : 0u);
           }
         }
         if (any) {
           cur--;
-          row = si_lo(cur); rowend = row + (P)(int32_t)si_len(cur);
+          const uint32_t e = (XORDER && cur == ge) ? gs : cur;
+          row = si_lo(e); rowend = row + (P)(int32_t)si_len(e);
           k = row; fresh = true;
           bk = BK_LOC_ROW;
         }
@@ -2904,7 +2994,7 @@ KJ_HD uint64_t tax_lca(const DevTaxonomy &t, const uint64_t *ids, uint32_t n) {
 }
 KJ_HD CompactHit compact_hit(const DevTaxonomy &t, const Hit &h) {
   CompactHit c;
-  c.best = h.best; c.info = h.flags << 8 | (h.n_ids & 255u);
+  c.best = h.best; c.info = h.flags << 8 | (h.flags & kHitInternalOverflow) | (h.n_ids & 255u);
   c.lca = (h.n_ids == 0 || h.best == 0) ? 0 : tax_lca(t, h.taxid, h.n_ids);
   return c;
 }

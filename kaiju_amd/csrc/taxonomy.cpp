@@ -118,6 +118,7 @@ extern "C" int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p,
       const uint64_t len2 = off[2 * (uint64_t)r + 2] - off[2 * (uint64_t)r + 1];
       double query_len = static_cast<double>(len1) / 3.0;                    // :698
       if (paired) query_len += static_cast<double>(len2) / 3.0;             // :704
+      if (p->input_is_protein) query_len = static_cast<double>(len1);       // :660
       const double bitscore = (LAMBDA * h.best - LN_K) / LN_2;
       const double Evalue = db_length * query_len * pow(2, -1 * bitscore);
       if (Evalue > p->min_evalue) continue;
@@ -170,6 +171,7 @@ extern "C" int kaiju_finalize_compact(const kaiju_gpu_params *p, double db_lengt
       const uint64_t len2 = off[2 * (uint64_t)r + 2] - off[2 * (uint64_t)r + 1];
       double query_len = static_cast<double>(len1) / 3.0;                    // :698
       if (paired) query_len += static_cast<double>(len2) / 3.0;             // :704
+      if (p->input_is_protein) query_len = static_cast<double>(len1);       // :660
       const double bitscore = (LAMBDA * h.best - LN_K) / LN_2;
       const double Evalue = db_length * query_len * pow(2, -1 * bitscore);
       if (Evalue > p->min_evalue) continue;

@@ -813,11 +813,29 @@ static void get_all_fragments(Ctx *c, const char *line, int len) {
   for (int i = 0; i < 3; i++) free(tr[i]);
 }
 
+/* protein input, ConsumerThread.cpp:659-696 (= ConsumerThreadp.cpp:22-63): upper case, split at every
+   character that is not one of the 20 amino acids, runs of at least min_fragment_length (Greedy:
+   scoring at least min_score) become fragments, left to right */
+static void get_protein_fragments(Ctx *c, const char *line, int len) {
+  static const char AA20[] = "ACDEFGHIKLMNPQRSTVWY";
+  char *up = (char *)malloc((size_t)len + 1);
+  for (int i = 0; i < len; i++) { char ch = line[i]; up[i] = (ch >= 'a' && ch <= 'z') ? (char)(ch - 32) : ch; }   /* toupper, C locale */
+  int start = 0;
+  for (int pos = 0; pos < len; pos++) {
+    if (up[pos] != 0 && strchr(AA20, up[pos])) continue;
+    emit_fragment(c, up + start, pos - start);              /* (pos-start >= min_fragment_length is tested inside) */
+    start = pos + 1;
+  }
+  emit_fragment(c, up + start, len - start);                /* the remaining sequence */
+  free(up);
+}
+
 int ko_fragments(const ko_params *p, const char *read, int len,
                  char *buf, int bufsize, uint32_t *keys, int max_frags) {
   init_tables();
   Ctx c; memset(&c, 0, sizeof c); c.p = p;
-  if (len >= 3) get_all_fragments(&c, read, len);
+  if (p->protein) get_protein_fragments(&c, read, len);
+  else if (len >= 3) get_all_fragments(&c, read, len);
   int n = 0, off = 0;
   for (int i = 0; i < c.q.n && n < max_frags; i++) {
     Fragment *f = c.q.a[i].f;
@@ -1149,7 +1167,7 @@ void ko_default_params(ko_params *p, int mode) {
   p->min_evalue = 0.01;
   p->max_matches_SI = 20;
   p->max_match_ids = 20;
-  p->kaijux = 0; p->pad_ = 0;
+  p->kaijux = 0; p->protein = 0;
 }
 
 void ko_classify(ko_index *ix, ko_taxonomy *tax, const ko_params *p,
@@ -1158,13 +1176,21 @@ void ko_classify(ko_index *ix, ko_taxonomy *tax, const ko_params *p,
   init_tables();
   memset(out, 0, sizeof *out);
   const unsigned m3 = p->min_fragment_length * 3;
-  if ((!paired && (unsigned)len1 < m3) || (paired && (unsigned)len1 < m3 && (unsigned)len2 < m3)) return;
   Ctx c; memset(&c, 0, sizeof c); c.ix = ix; c.p = p;
-  double query_len = (double)len1 / 3.0;
-  if ((unsigned)len1 >= m3) get_all_fragments(&c, seq1, len1);
-  if (paired) {
-    query_len += (double)len2 / 3.0;
-    if ((unsigned)len2 >= m3) get_all_fragments(&c, seq2, len2);
+  double query_len;
+  if (p->protein) {
+    /* :640-646, :660; the mate is ignored (kaiju.cpp:201 refuses -j with -p) */
+    if ((unsigned)len1 < p->min_fragment_length) return;
+    query_len = (double)len1;
+    get_protein_fragments(&c, seq1, len1);
+  } else {
+    if ((!paired && (unsigned)len1 < m3) || (paired && (unsigned)len1 < m3 && (unsigned)len2 < m3)) return;
+    query_len = (double)len1 / 3.0;
+    if ((unsigned)len1 >= m3) get_all_fragments(&c, seq1, len1);
+    if (paired) {
+      query_len += (double)len2 / 3.0;
+      if ((unsigned)len2 >= m3) get_all_fragments(&c, seq2, len2);
+    }
   }
   IdSet ids; memset(&ids, 0, sizeof ids);
   if (p->mode == 0) classify_length(&c, out, &ids);

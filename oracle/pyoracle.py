@@ -34,7 +34,7 @@ class KoParams(C.Structure):
                 ("seed_length", C.c_uint32), ("seg", C.c_int32),
                 ("use_evalue", C.c_int32), ("min_evalue", C.c_double),
                 ("max_matches_SI", C.c_uint32), ("max_match_ids", C.c_uint32),
-                ("kaijux", C.c_int32), ("pad_", C.c_int32)]
+                ("kaijux", C.c_int32), ("protein", C.c_int32)]
 
 
 class KoHit(C.Structure):

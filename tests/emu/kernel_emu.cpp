@@ -24,6 +24,7 @@ struct EmuIndex {
   ConstTables ct;
   SegTables st;
   std::vector<double> lnfact;
+  bool xmode = false;         // ids are sequence numbers (kaijux)
 };
 
 extern "C" {
@@ -41,7 +42,7 @@ void *emu_index_load(const char *path, char *err, int errlen) {
 // kaijux semantics: ids are sequence numbers
 void *emu_index_load_x(const char *path, char *err, int errlen) {
   EmuIndex *ix = (EmuIndex *)emu_index_load(path, err, errlen);
-  if (ix) ix->packed.to_sequence_ids();
+  if (ix) { ix->packed.to_sequence_ids(); ix->xmode = true; }
   return ix;
 }
 void emu_index_free(void *h) { delete (EmuIndex *)h; }
@@ -92,6 +93,9 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   p.mode = gp->mode; p.m = gp->min_fragment_length; p.mismatches = gp->mismatches; p.min_score = gp->min_score;
   p.seed_length = gp->seed_length; p.seg = gp->seg; p.max_matches_SI = gp->max_matches_SI; p.max_match_ids = gp->max_match_ids;
   if (p.mismatches > (uint32_t)kMaxMismatch) return KAIJU_GPU_ERR_UNSUPPORTED;
+  // as kaiju_gpu_create does
+  if (ix->xmode && p.mode == 0 && !getenv("KAIJU_EMU_NO_XORDER")) p.flags |= kParamXOrder;   // (switch: shows that a test sees the order)
+  if (gp->input_is_protein) { p.flags |= kParamProtein; if (paired) return KAIJU_GPU_ERR_ARG; }
   Batch b;
   b.seqs = (const uint8_t *)seqs; b.off = off; b.n_reads = n; b.paired = paired;
   std::vector<uint8_t> pep((size_t)pep_base(off, n) + 512, 0);
@@ -117,6 +121,12 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   // peptides are staged (here: linear scratch) and copied out, as the kernel does with its LDS area
   std::vector<uint8_t> stage((size_t)4 * maxlen + 256);
   const bool staged = !getenv("KAIJU_EMU_NOSTAGE");
+  if (p.flags & kParamProtein) {
+    uint8_t code[256];
+    memset(code, 0, sizeof code);
+    for (uint32_t a = 0; a < 20; a++) protein_code_entry(ix->ct, a, code);
+    for (uint32_t r = 0; r < n; r++) build_fragments_protein(ix->ct, code, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq, r, &err);
+  } else
   for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq, r, &err, staged ? stage.data() : nullptr, 4, (uint32_t)(stage.size() / 4));
   if (p.seg) {
     int32_t segwork[4 * kSegMaxRegions];
@@ -174,8 +184,9 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     if (p.mode == 0) {
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1", "wide" or default (v2 where possible)
-      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) mem_lane2<false>(d, p, b, wl, ls);
-      else if (d.blocks64 && d.mb_base && d.kmer64 && !v && pass == 0 && !g_vb.n_acc) mem_lane2<true>(d, p, b, wl, ls);
+      const bool xo = (p.flags & kParamXOrder) != 0;
+      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) { if (xo) mem_lane2<false, true>(d, p, b, wl, ls); else mem_lane2<false>(d, p, b, wl, ls); }
+      else if (d.blocks64 && d.mb_base && d.kmer64 && !v && pass == 0 && !g_vb.n_acc) { if (xo) mem_lane2<true, true>(d, p, b, wl, ls); else mem_lane2<true>(d, p, b, wl, ls); }
       else if (d.sb32 && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls, g_vb);
       else mem_lane<uint64_t>(d, p, b, wl, ls, g_vb);
     } else {

@@ -191,3 +191,38 @@ def test_prescan_false_start_is_caught(have_cli, tmp_path):
     for threads in (2, 7, 16):
         got = run_cli(tmp_path, path, batch=333, prescan_threads=threads)
         assert [(g[0], g[1]) for g in got] == want, threads
+
+
+def test_kaijup_names_and_u_line_decision(tmp_path):
+    """kaijup keeps the whole header line as the name (kaijup.cpp:249-262) and prints "U<TAB>name<TAB>0" exactly for reads
+    shorter than -m or without any fragment (ConsumerThreadp.cpp:17-21,67-71): the parse-only dump of the kaijup
+    personality carries that decision in a fourth column; compared with the reference's kaijup lines"""
+    kaijup = os.path.join(util.ROOT, "kaiju_amd", "bin", "kaijup")
+    names, reads = util.read_fasta(os.path.join(util.GOLD, "prot.fa"), keep_names=True)
+    for mode in ("mem", "greedy"):
+        r = subprocess.run([kaijup, "-f", "-", "-i", os.path.join(util.GOLD, "prot.fa"), "-a", mode],
+                           env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1"), capture_output=True, check=True)
+        got = [line.split(b"\t") for line in r.stdout.split(b"\n") if line]
+        assert [g[0].decode() for g in got] == names and [g[1] for g in got] == reads
+        ref = {}
+        with open(os.path.join(util.GOLD, f"refpx_{mode}.tsv")) as f:
+            for line in f:
+                q = line.rstrip("\n").split("\t")
+                ref[q[1]] = q
+        n3 = 0
+        for g, nm, s in zip(got, names, reads):
+            q = ref[nm]
+            if q[0] == "U":
+                three = len(q) == 3
+                n3 += three
+                assert three == (len(s) < 11 or g[3] == b"0"), (mode, nm, q, g[3])
+            else:
+                assert g[3] == b"1"
+        assert n3 > 20
+    # the kaiju personality cuts the names and refuses -j with -p
+    r = subprocess.run([CLI, "-p", "-t", "-", "-f", "-", "-i", os.path.join(util.GOLD, "prot.fa")],
+                       env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1"), capture_output=True, check=True)
+    assert [line.split(b"\t")[0].decode() for line in r.stdout.split(b"\n") if line] == util.read_fasta(os.path.join(util.GOLD, "prot.fa"))[0]
+    r = subprocess.run([CLI, "-p", "-t", "-", "-f", "-", "-i", os.path.join(util.GOLD, "prot.fa"), "-j", os.path.join(util.GOLD, "prot.fa")],
+                       env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1"), capture_output=True)
+    assert r.returncode != 0 and b"Protein input only supports one input file" in r.stderr

@@ -87,16 +87,15 @@ def test_kaiju_multi(gpu_lib, golden, tmp_path):
     assert first5(o1) == ref and first5(o2) == ref
 
 
-@pytest.mark.parametrize("mode", ["mem", "greedy"])
-def test_kaijux(gpu_lib, golden, tmp_path, mode):
-    """kaijux (database sequences instead of taxa, no nodes.dmp) == the reference's kaijux lines, single and paired.
-    Greedy: with and without -v.  MEM: the reference's kaijux searches with maxMatches(..., 1) instead of kaiju's
-    greedyExact (ConsumerThreadx.cpp:135), which this path does not restate: scores and names agree on the golden
-    reads, the matched peptides of -v do not always (documented deviation) - so -v is only compared for Greedy."""
+def test_kaijux(gpu_lib, golden, tmp_path):
+    """kaijux (database sequences instead of taxa, no nodes.dmp) == the reference's kaijux lines, single and paired, with
+    and without -v (Greedy here; MEM, whose match order follows the reference's maxMatches(.., 1), in
+    test_gpu_zz_protein_kaijux_mem.py)"""
+    mode = "greedy"
     build.build_cli()
     kaijux = os.path.join(os.path.dirname(build.CLI), "kaijux")
     for pe in (False, True):
-        for v in ((False, True) if mode == "greedy" else (False,)):
+        for v in (False, True):
             out = str(tmp_path / "x.tsv")
             cmd = [kaijux, "-f", golden.fmi, "-a", mode, "-o", out]
             cmd += ["-i", os.path.join(golden.dir, "pairs_1.fq"), "-j", os.path.join(golden.dir, "pairs_2.fq")] if pe else \

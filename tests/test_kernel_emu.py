@@ -318,3 +318,174 @@ def test_kaijux_semantics(emu, golden, mode):
                 assert ref[0] == "C" and int(ref[2]) == int(gh[r]["best"]) and ref[3] == got, (mode, pe, nm, ref, got)
             else:
                 assert ref[0] == "U", (mode, pe, nm, ref)
+
+
+def _verbose_buffers(E, n, cap=8192):
+    import ctypes as C
+    E.emu_set_verbose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    E.emu_seq_name.restype = C.c_char_p
+    E.emu_seq_name.argtypes = [C.c_void_p, C.c_uint32]
+    E.emu_alphabet.restype = C.c_char_p
+    E.emu_alphabet.argtypes = [C.c_void_p]
+    nacc = np.zeros(n, dtype=np.uint32); acc = np.zeros(n * 20, dtype=np.uint32)
+    tlen = np.zeros(n, dtype=np.uint32); text = np.zeros(n * cap, dtype=np.uint8)
+    E.emu_set_verbose(nacc.ctypes.data, acc.ctypes.data, tlen.ctypes.data, text.ctypes.data, cap)
+    return nacc, acc, tlen, text, cap
+
+
+def _tsv_lines(path):
+    lines = {}
+    with open(path) as f:
+        for line in f:
+            q = line.rstrip("\n").split("\t")
+            lines[q[1]] = q
+    return lines
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_protein_input(oracle, emu, golden, handles, mode):
+    """protein reads (kaiju -p): stage 1 = build_fragments_protein, the rest of the kernel sequence unchanged; hit records
+    == the oracle's (whose protein mode is pinned on the reference's lines), verbose columns == the reference's"""
+    import os
+    h, ix, tax = handles
+    E = emu.lib
+    for seg in (1, 0):
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, protein=1, use_evalue=0), golden.prot_seqs, golden.prot_off)
+        gh, _ = emu.classify(h, util.gp(mode, seg=seg, protein=1), golden.prot_seqs, golden.prot_off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (mode, seg, bad[:5])
+        assert sum(1 for g in gh if g["n_ids"]) > 150
+        # first-generation lanes
+        for lane in ("v1", "wide"):
+            os.environ["KAIJU_EMU_LANE"] = lane
+            try:
+                g1, _ = emu.classify(h, util.gp(mode, seg=seg, protein=1), golden.prot_seqs, golden.prot_off)
+            finally:
+                del os.environ["KAIJU_EMU_LANE"]
+            assert all(util.same_hit(a, b) for a, b in zip(gh, g1)), (mode, seg, lane)
+        # columns 6/7 of kaiju -p -v
+        n = len(golden.prot_names)
+        nacc, acc, tlen, text, cap = _verbose_buffers(E, n)
+        try:
+            emu.classify(h, util.gp(mode, seg=seg, protein=1), golden.prot_seqs, golden.prot_off)
+        finally:
+            E.emu_set_verbose(None, None, None, None, 0)
+        alpha = E.emu_alphabet(h)
+        lines = _tsv_lines(os.path.join(golden.dir, f"refp_{mode}_{seg}.tsv"))
+        for r, nm in enumerate(golden.prot_names):
+            ref = lines[nm]
+            if ref[0] != "C":
+                continue
+            accs = set()
+            for q in range(int(nacc[r])):
+                s = E.emu_seq_name(h, int(acc[r * 20 + q]))
+                if s and b"_" in s:
+                    accs.add(s[: s.rindex(b"_")].decode())
+            t = "".join("," if c == 255 else chr(alpha[c]) for c in text[r * cap: r * cap + int(tlen[r])])
+            assert ref[5] == "".join(x + "," for x in sorted(accs)) and ref[6] == t, (mode, seg, nm, ref[5:], accs, t)
+    # paired protein input does not exist (kaiju.cpp:201)
+    assert E.emu_classify(h, util.gp(mode, protein=1), golden.pseqs.ctypes.data, golden.poff.ctypes.data, 4, 1, None, 16, 192, 64,
+                          None, None, 0) != 0
+
+
+@pytest.mark.parametrize("prot", [False, True])
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_kaijux_verbose_and_kaijup(emu, golden, mode, prot):
+    """kaijux -v / kaijup -v: score, database sequences and the matched peptides == the reference's lines; in MEM mode the
+    reference searches with maxMatches(.., 1) (ConsumerThreadx.cpp:135), whose list starts with the match found first:
+    the lanes visit the matches in that order (kParamXOrder)"""
+    import ctypes as C
+    import os
+    E = emu.lib
+    E.emu_index_load_x.restype = C.c_void_p
+    E.emu_index_load_x.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    err = C.create_string_buffer(256)
+    h = E.emu_index_load_x(golden.fmi.encode(), err, 256)
+    assert h, err.value
+    try:
+        if prot:
+            cases = [(golden.prot_seqs, golden.prot_off, golden.prot_fullnames, False, f"refpx_{mode}_v.tsv")]
+        else:
+            cases = [(golden.seqs, golden.off, golden.names, False, f"refx_{mode}_v.tsv"),
+                     (golden.pseqs, golden.poff, golden.pnames, True, f"refx_{mode}_pe_v.tsv")]
+        for seqs, off, names, pe, tsv in cases:
+            n = len(names)
+            nacc, acc, tlen, text, cap = _verbose_buffers(E, n)
+            try:
+                gh, _ = emu.classify(h, util.gp(mode, seg=1, protein=int(prot)), seqs, off, paired=pe)
+            finally:
+                E.emu_set_verbose(None, None, None, None, 0)
+            # the second-generation lanes (no verbose output) agree with what the verbose pass found
+            g2, _ = emu.classify(h, util.gp(mode, seg=1, protein=int(prot)), seqs, off, paired=pe)
+            assert all(util.same_hit(a, b) for a, b in zip(gh, g2)), (mode, prot, pe)
+            alpha = E.emu_alphabet(h)
+            lines = _tsv_lines(os.path.join(golden.dir, tsv))
+            nc = 0
+            for r, nm in enumerate(names):
+                ref = lines[nm]
+                if ref[0] != "C":
+                    continue
+                nc += 1
+                ids = sorted(int(x) for x in gh[r]["taxid"][:gh[r]["n_ids"]])
+                got = "".join(E.emu_seq_name(h, i).decode() + "," for i in ids)
+                t = "".join("," if c == 255 else chr(alpha[c]) for c in text[r * cap: r * cap + int(tlen[r])])
+                assert int(ref[2]) == int(gh[r]["best"]) and ref[3] == got and ref[4] == t, (mode, prot, pe, nm, ref[2:], got, t)
+            assert nc > 100
+    finally:
+        E.emu_index_free(h)
+
+
+def test_kaijux_mem_order_under_the_id_cap(oracle, emu, tmp_path):
+    """a database of near-identical sequences: the collected sequences depend on the order in which the matches of a
+    fragment are visited (the 21-id cap cuts the traversal); == the oracle's kaijux mode (maxMatches_limited), ids in
+    traversal order, for both generations of the MEM lane"""
+    import ctypes as C
+    import os
+    from kaiju_amd import mkfmi
+    faa, fmi = str(tmp_path / "rep.faa"), str(tmp_path / "rep.fmi")
+    reads = util.repetitive_db(faa)
+    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+    E = emu.lib
+    E.emu_index_load_x.restype = C.c_void_p
+    E.emu_index_load_x.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    err = C.create_string_buffer(256)
+    h = E.emu_index_load_x(fmi.encode(), err, 256)
+    assert h, err.value
+    assert not E.emu_index_warnings(h)
+    seqs, off = util.pack(reads)
+    ix = oracle.load_fmi(fmi)
+    oh = oracle.classify(ix, None, oracle.params("mem", seg=0, kaijux=1), seqs, off)
+    assert sum(1 for o in oh if o["flags"] & 1) > 20
+    for lane in (None, "v1", "wide"):
+        if lane:
+            os.environ["KAIJU_EMU_LANE"] = lane
+        try:
+            gh, _ = emu.classify(h, util.gp("mem", seg=0), seqs, off)
+        finally:
+            os.environ.pop("KAIJU_EMU_LANE", None)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (lane, bad[:5])
+    # the order matters: the plain kaiju order (greedyExact) gives other sets for some of these reads
+    h0 = emu.load(fmi)
+    g0, _ = emu.classify(h0, util.gp("mem", seg=0), seqs, off)
+    o0 = oracle.classify(ix, None, oracle.params("mem", seg=0), seqs, off)
+    assert all(int(a["best"]) == int(b["best"]) for a, b in zip(g0, gh))
+    E.emu_index_free(h); E.emu_index_free(h0)
+
+
+def test_protein_long(oracle, emu, golden, handles):
+    """proteins of several thousand residues (windows refill, fragments as long as the read) == oracle"""
+    h, ix, tax = handles
+    rng = np.random.default_rng(3)
+    prots = [s for s in golden.prot_reads if len(s) > 100]
+    reads = []
+    for _ in range(40):
+        parts = [prots[int(rng.integers(0, len(prots)))] for _ in range(int(rng.integers(3, 12)))]
+        reads.append(b"X".join(parts) if rng.random() < 0.5 else b"".join(parts))
+    assert max(len(r) for r in reads) > 4000
+    seqs, off = util.pack(reads)
+    for mode in ("mem", "greedy"):
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=1, protein=1, use_evalue=0), seqs, off)
+        gh, _ = emu.classify(h, util.gp(mode, seg=1, protein=1), seqs, off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (mode, bad[:5])

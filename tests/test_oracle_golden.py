@@ -115,3 +115,37 @@ def test_kaijux_lines(oracle, golden, ox, mode):
                 assert ref[0] == "C" and int(ref[2]) == int(h["best"]) and ref[3] == got, (mode, pe, nm, ref, got)
             else:
                 assert ref[0] == "U", (mode, pe, nm, ref)
+
+
+@pytest.mark.parametrize("mode,seg,kw", CASES)
+def test_protein_input(oracle, golden, ox, mode, seg, kw):
+    """protein reads (kaiju -p, ConsumerThread.cpp:640-646,659-696): the oracle's protein mode == the reference's lines"""
+    ix, tax = ox
+    ref = golden.tsv(f"refp_{mode}_{seg}.tsv")
+    hits = oracle.classify(ix, tax, oracle.params(mode, seg=seg, protein=1), golden.prot_seqs, golden.prot_off)
+    got = util.oracle_records(hits)
+    assert len(ref) == len(golden.prot_names)
+    bad = [(n, g, ref[n]) for n, g in zip(golden.prot_names, got) if g != ref[n]]
+    assert not bad, bad[:3]
+    assert sum(1 for g in got if g[0] == "C") > 150
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_kaijup_lines(oracle, golden, ox, mode):
+    """kaijup (ConsumerThreadp.cpp): protein reads, database sequences instead of taxa"""
+    ix, _ = ox
+    hits = oracle.classify(ix, None, oracle.params(mode, seg=1, kaijux=1, protein=1), golden.prot_seqs, golden.prot_off)
+    lines = {}
+    with open(os.path.join(golden.dir, f"refpx_{mode}.tsv")) as f:
+        for line in f:
+            q = line.rstrip("\n").split("\t")
+            lines[q[1]] = q
+    assert len(lines) == len(golden.prot_fullnames)
+    for h, nm in zip(hits, golden.prot_fullnames):
+        ref = lines[nm]
+        if h["classified"]:
+            ids = sorted(int(x) for x in h["taxid"][:h["n_ids"]])
+            got = "".join(oracle.lib.ko_seq_name(ix, i).decode() + "," for i in ids)
+            assert ref[0] == "C" and int(ref[2]) == int(h["best"]) and ref[3] == got, (mode, nm, ref, got)
+        else:
+            assert ref[0] == "U", (mode, nm, ref)

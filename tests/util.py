@@ -20,15 +20,15 @@ GPU_HIT = np.dtype([("best", "<u4"), ("n_ids", "<u4"), ("flags", "<u4"), ("reser
 class GP(C.Structure):      # kaiju_gpu_params
     _fields_ = [("mode", C.c_int32), ("min_fragment_length", C.c_uint32), ("mismatches", C.c_uint32),
                 ("min_score", C.c_uint32), ("seed_length", C.c_uint32), ("seg", C.c_int32),
-                ("use_evalue", C.c_int32), ("min_evalue", C.c_double), ("max_matches_SI", C.c_uint32),
-                ("max_match_ids", C.c_uint32)]
+                ("use_evalue", C.c_int32), ("input_is_protein", C.c_int32), ("min_evalue", C.c_double),
+                ("max_matches_SI", C.c_uint32), ("max_match_ids", C.c_uint32)]
 
 
-def gp(mode, m=11, mismatches=3, min_score=65, seed_length=7, seg=1, use_evalue=None, min_evalue=0.01):
+def gp(mode, m=11, mismatches=3, min_score=65, seed_length=7, seg=1, use_evalue=None, min_evalue=0.01, protein=0):
     md = 0 if mode in ("mem", 0) else 1
     if use_evalue is None:
         use_evalue = md
-    return GP(md, m, mismatches, min_score, seed_length, seg, use_evalue, min_evalue, 20, 20)
+    return GP(md, m, mismatches, min_score, seed_length, seg, use_evalue, protein, min_evalue, 20, 20)
 
 
 def build_emu(so=None, defines=()):
@@ -77,7 +77,9 @@ class Emu:
         assert n >= 0
         return [(l[i], r[i]) for i in range(n)]
 
-    def classify(self, h, params, seqs, off, paired=False, caps=(16, 192, 64), want_frags=False):
+    def classify(self, h, params, seqs, off, paired=False, caps=(16, 192, 64), want_frags=False, allow_capacity=False):
+        """allow_capacity: return (None, 0) instead of failing when a capacity bound of the kernels was hit
+        (kaiju_gpu_stats.error_flags on the device: a fragment with more than 15 SEG regions, ...)"""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         n = (len(off) - 1) // 2
@@ -87,6 +89,8 @@ class Emu:
         rc = self.lib.emu_classify(h, C.byref(params), seqs.ctypes.data, off.ctypes.data, n, 1 if paired else 0,
                                    out.ctypes.data, caps[0], caps[1], caps[2], C.byref(nretry), dump,
                                    len(dump) if dump else 0)
+        if rc == -100 and allow_capacity:
+            return None, 0
         assert rc == 0, rc
         if want_frags:
             return out, nretry.value, dump.value.decode()
@@ -105,6 +109,28 @@ def read_fastq(path):
             f.readline()
             names.append(h[1:].strip().decode())
             seqs.append(s)
+    return names, seqs
+
+
+def read_fasta(path, keep_names=False):
+    """FASTA records as the reference drivers read them: multi-line records joined, sequences strip()'d of everything
+    that is no letter (util.cpp:25-32), names cut at the first of " /\\t\\r" (kaiju.cpp:303-331) unless keep_names
+    (kaijup.cpp:249-262)"""
+    names, seqs = [], []
+    with open(path, "rb") as f:
+        for line in f:
+            line = line.rstrip(b"\n")
+            if line.startswith(b">"):
+                nm = line[1:]
+                if not keep_names:
+                    for i, ch in enumerate(nm):
+                        if ch in b" /\t\r":
+                            nm = nm[:i]
+                            break
+                names.append(nm.decode())
+                seqs.append(b"")
+            elif names:
+                seqs[-1] += bytes(c for c in line if chr(c).isalpha())
     return names, seqs
 
 
@@ -152,6 +178,11 @@ class Golden:
         _, self.p2 = read_fastq(os.path.join(GOLD, "pairs_2.fq"))
         self.seqs, self.off = pack(self.reads)
         self.pseqs, self.poff = pack(self.p1, self.p2)
+        # protein reads (kaiju -p, kaijup): tests/golden/make_golden_protein.py
+        self.prot_fa = os.path.join(GOLD, "prot.fa")
+        self.prot_names, self.prot_reads = read_fasta(self.prot_fa)
+        self.prot_fullnames, _ = read_fasta(self.prot_fa, keep_names=True)
+        self.prot_seqs, self.prot_off = pack(self.prot_reads)
 
     def tsv(self, name):
         return parse_tsv(os.path.join(GOLD, name))
@@ -173,6 +204,34 @@ def same_hit(o, g, mask=3):
     return (int(o["best"]) == int(g["best"]) and int(o["n_ids"]) == int(g["n_ids"]) and
             list(o["taxid"][:o["n_ids"]]) == list(g["taxid"][:g["n_ids"]]) and
             (int(o["flags"]) & mask) == (int(g["flags"]) & mask))
+
+
+BACK = {"A": "GCT", "R": "CGT", "N": "AAT", "D": "GAT", "C": "TGT", "Q": "CAA", "E": "GAA", "G": "GGT", "H": "CAT", "I": "ATT",
+        "L": "CTT", "K": "AAA", "M": "ATG", "F": "TTT", "P": "CCT", "S": "TCT", "T": "ACT", "W": "TGG", "Y": "TAT", "V": "GTT"}
+
+
+def repetitive_db(faa, nseq=201, seed=8):
+    """a database in which the order of a fragment's matches decides which sequences get through the 21-id cap: motif A
+    sits in the first half of the sequences, motif B in the second half (flanks random, never W).  Returns reads whose
+    fragments hold both motifs separated by W: two matches of equal length with disjoint, large intervals."""
+    rng = np.random.default_rng(seed)
+    AA = "ARNDCQEGHILKMFPSTYV"                      # no W
+    A = "".join(rng.choice(list(AA), 20))
+    B = "".join(rng.choice(list(AA), 20))
+    with open(faa, "w") as f:
+        for i in range(nseq):
+            pre = "".join(rng.choice(list(AA), int(rng.integers(5, 40))))
+            suf = "".join(rng.choice(list(AA), int(rng.integers(5, 40))))
+            f.write(f">S{i}_7\n{pre}{A if i < nseq // 2 else B}{suf}\n")
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for k, pep in enumerate(("AWB", "BWA", "AWBWA", "BWAWB", "AWA", "BWB", "A", "B") * 6):
+        s = "".join(BACK[c] for c in "W".join({"A": A, "B": B}[x] for x in pep.split("W")))
+        s = "ACGT"[: k % 3] + s
+        if k % 2:
+            s = "".join(comp[c] for c in reversed(s))
+        reads.append(s.encode())
+    return reads
 
 
 def long_reads(n=120, seed=5, lo=400, hi=3000):
