@@ -162,7 +162,8 @@ void kaiju_gpu_default_params(kaiju_gpu_params *p, int mode);
 int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, const kaiju_gpu_params *p);
 void kaiju_gpu_destroy(kaiju_gpu_ctx *ctx);
 
-/* Host buffers.  seqs: concatenated, already strip()'d ASCII nucleotides;
+/* Host buffers.  seqs: concatenated, already strip()'d ASCII nucleotides (protein letters, either case, when the
+   context was created with input_is_protein; such reads have no mate and paired must be 0);
    off[2*n+1]: read r is seqs[off[2r], off[2r+1]) and its mate seqs[off[2r+1], off[2r+2])
    (empty when unpaired).  paired selects the length gate of ConsumerThread.cpp:647-654.
    Blocks until out[0..n) is filled. */

@@ -103,3 +103,76 @@ def test_end_to_end_kaijux(oracle, data, mode, seg):
         else:
             assert r[0] == "U", (i, r)
     assert nc > len(hits) // 4
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(po.REF_DIR, "kaijup")), reason="oracle/_ref/kaijup not built")
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_end_to_end_protein(oracle, data, mode, tmp_path):
+    """protein mode of the oracle against the reference's `kaiju -p` and `kaijup` on fresh random data: protein reads cut
+    from the database with substitutions, separators (letters that are no amino acid) and lower case"""
+    import subprocess
+    W, db, reads = data
+    rng = np.random.default_rng(77)
+    AA = synth.AA
+    prots = []
+    with open(f"{W}/db.faa") as f:
+        for line in f:
+            if not line.startswith(">"):
+                prots.append(line.strip())
+    preads = []
+    for i in range(3000):
+        L = int(rng.choice([9, 11, 12, 30, 80, 200, 600]))
+        parts = []
+        while sum(len(x) for x in parts) < L:
+            p = prots[int(rng.integers(0, len(prots)))]
+            a = int(rng.integers(0, max(1, len(p) - 12)))
+            parts.append(p[a: a + int(rng.integers(8, 150))])
+            if rng.random() < 0.3:
+                parts.append("BJOUXZ"[int(rng.integers(0, 6))])
+        s = list("".join(parts)[:L])
+        for _ in range(int(rng.integers(0, 4))):
+            s[int(rng.integers(0, len(s)))] = AA[int(rng.integers(0, 20))]
+        s = "".join(s)
+        preads.append((s.lower() if rng.random() < 0.1 else s).encode())
+    fa = str(tmp_path / "prot.fa")
+    with open(fa, "wb") as f:
+        for i, s in enumerate(preads):
+            f.write(b">q%d\n%s\n" % (i, s))
+    ix = oracle.load_fmi(f"{W}/db.fmi")
+    tax = oracle.load_nodes(f"{W}/nodes.dmp")
+    off = np.zeros(2 * len(preads) + 1, dtype=np.uint64)
+    pos = 0
+    for i, s in enumerate(preads):
+        pos += len(s)
+        off[2 * i + 1] = off[2 * i + 2] = pos
+    seqs = np.frombuffer(b"".join(preads), dtype=np.uint8)
+    # kaiju -p
+    out = str(tmp_path / "p.tsv")
+    po.ref_kaiju(f"{W}/nodes.dmp", f"{W}/db.fmi", fa, out, mode=mode, extra=("-p",))
+    ref = po.parse_kaiju_tsv(out)
+    hits = oracle.classify(ix, tax, oracle.params(mode, protein=1), seqs, off)
+    nc = 0
+    for i, h in enumerate(hits):
+        mine = ("C", int(h["lca"]), int(h["best"]), tuple(sorted(int(x) for x in h["taxid"][:h["n_ids"]]))) \
+            if h["classified"] else ("U", 0, None, ())
+        nc += mine[0] == "C"
+        assert mine == ref[f"q{i}"], i
+    assert nc > 1000
+    # kaijup
+    out = str(tmp_path / "px.tsv")
+    subprocess.run([os.path.join(po.REF_DIR, "kaijup"), "-f", f"{W}/db.fmi", "-i", fa, "-o", out, "-z", "1", "-a", mode],
+                   check=True, stderr=subprocess.DEVNULL)
+    lines = {}
+    with open(out) as f:
+        for line in f:
+            q = line.rstrip("\n").split("\t")
+            lines[q[1]] = q
+    hits = oracle.classify(ix, None, oracle.params(mode, protein=1, kaijux=1), seqs, off)
+    for i, h in enumerate(hits):
+        r = lines[f"q{i}"]
+        if h["classified"]:
+            ids = sorted(int(x) for x in h["taxid"][:h["n_ids"]])
+            got = "".join(oracle.lib.ko_seq_name(ix, j).decode() + "," for j in ids)
+            assert r[0] == "C" and int(r[2]) == int(h["best"]) and r[3] == got, (i, r, got)
+        else:
+            assert r[0] == "U", (i, r)
