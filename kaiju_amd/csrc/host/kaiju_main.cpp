@@ -18,9 +18,13 @@
 // kaijup it does that for protein reads (kaijup.cpp, ConsumerThreadp.cpp), under kaiju-multi it takes comma
 // separated file lists (kaiju-multi.cpp).
 #include <getopt.h>
+#include <malloc.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <condition_variable>
 #include <cstdio>
@@ -91,6 +95,36 @@ struct RawBlock {
 // mapping), gzip files are inflated through zlib into a growing buffer.  Record boundaries as the
 // reference finds them (kaiju.cpp:288-331): empty lines before a header are skipped; FASTQ = header +
 // 3 lines; FASTA = header + every line up to the next one starting with '>'.
+// newline positions of a stretch of text, found 16 bytes at a time: the sequential walk over a memory-mapped file asks
+// for four line ends per FASTQ record, and one memchr call per line costs more than the bytes it looks at
+struct NewlineScan {
+  std::vector<size_t> nl;                  // positions of the '\n' bytes in [from, scanned_to), ascending
+  size_t idx = 0, scanned_to = 0;
+  void refill(const char *data, size_t from, size_t size) {
+    nl.clear(); idx = 0;
+    const size_t to = std::min(size, from + (256u << 10));
+    size_t p = from;
+#if defined(__SSE2__)
+    const __m128i nlv = _mm_set1_epi8('\n');
+    for (; p + 16 <= to; p += 16) {
+      unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(data + p)), nlv));
+      while (m) { nl.push_back(p + (size_t)__builtin_ctz(m)); m &= m - 1; }
+    }
+#endif
+    for (; p < to; p++) if (data[p] == '\n') nl.push_back(p);
+    scanned_to = to;
+  }
+  // one past the first '\n' at or behind p; `size` when the text ends without one (p < size)
+  size_t line_end(const char *data, size_t p, size_t size) {
+    for (;;) {
+      while (idx < nl.size() && nl[idx] < p) idx++;
+      if (idx < nl.size()) return nl[idx] + 1;
+      if (scanned_to >= size && p <= scanned_to) return size;
+      refill(data, std::max(p, scanned_to), size);
+    }
+  }
+};
+
 struct BlockReader {
   std::string path;
   bool ok = false, mapped = false;
@@ -151,7 +185,13 @@ struct BlockReader {
     return eof ? size : NEED_MORE;
   }
   // end of the record that starts at the first non-empty line at or after p
-  size_t record_end(size_t p) {
+  size_t record_end(size_t p) { return record_end_with(p, [this](size_t q) { return line_end(q); }); }
+  NewlineScan scan;                          // the streaming walk over a mapped file (one thread)
+  size_t record_end_scan(size_t p) {
+    return record_end_with(p, [this](size_t q) { return q >= size ? NEED_MORE : scan.line_end(data, q, size); });
+  }
+  template <class LineEnd>
+  size_t record_end_with(size_t p, LineEnd &&line_end) {
     size_t q = p, e;
     for (;;) {
       if (q >= size) return eof ? NONE : NEED_MORE;
@@ -282,7 +322,7 @@ struct BlockReader {
     }
     size_t p = pos;
     while (out.n_records < want) {
-      const size_t e = record_end(p);
+      const size_t e = mapped ? record_end_scan(p) : record_end(p);
       if (e == NEED_MORE) {
         const size_t keep = p - pos;
         more();                               // (at end of file this only sets eof: the record is rescanned)
@@ -317,6 +357,40 @@ struct Batch {
   uint32_t vstride = 0;
   std::vector<kaiju_gpu_compact> compact;
   std::string text;
+  void reset() {                           // empty, capacities kept
+    seqs.clear(); off.assign(1, 0); names.clear(); name_off.assign(1, 0);
+    hits.clear(); vrec.clear(); vtext.clear(); vstride = 0; compact.clear(); text.clear();
+  }
+};
+
+// batches are recycled: their buffers (hundreds of megabytes per batch) are faulted in once, not per batch
+struct BatchPool {
+  std::mutex m;
+  std::vector<std::unique_ptr<Batch>> free_list;
+  std::unique_ptr<Batch> get() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      if (!free_list.empty()) { std::unique_ptr<Batch> b = std::move(free_list.back()); free_list.pop_back(); return b; }
+    }
+    return std::unique_ptr<Batch>(new Batch());
+  }
+  void put(std::unique_ptr<Batch> b) {
+    b->reset();
+    std::lock_guard<std::mutex> lk(m);
+    if (free_list.size() < 32) free_list.push_back(std::move(b));
+  }
+};
+
+// CPU time per pipeline stage (KAIJU_GPU_STAGE_TIMES=1 prints it): where the host side spends its time
+std::atomic<uint64_t> g_ns_read{0}, g_ns_parse{0}, g_ns_gpu{0}, g_ns_format{0}, g_ns_write{0};
+struct StageTimer {
+  std::atomic<uint64_t> &acc;
+  timespec t0;
+  explicit StageTimer(std::atomic<uint64_t> &a) : acc(a) { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t0); }
+  ~StageTimer() {
+    timespec t1; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t1);
+    acc += (uint64_t)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+  }
 };
 
 // kaijup keeps the whole header line as the read name (kaijup.cpp:249-262 has no suffix cutting)
@@ -326,8 +400,21 @@ inline void append_stripped(std::vector<char> &dst, const char *s, size_t n) {  
   const size_t old = dst.size();
   dst.resize(old + n);
   char *d = dst.data() + old;
+  // almost every line consists of letters only: test that eight bytes at a time, copy wholesale
+  bool all = true;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w; memcpy(&w, s + i, 8);
+    const uint64_t H = 0x8080808080808080ull;
+    // per byte (high bit of the input clear): (c | 0x20 | 0x80) - 'a' = 0x80 + ((c | 32) - 'a'), no borrow between bytes;
+    // a letter gives 0x80..0x99: high bit set, and the low seven bits + 0x66 stay below 0x80
+    const uint64_t l = (w | 0x2020202020202020ull | H) - 0x6161616161616161ull;
+    if ((w & H) || (l & H) != H || (((l & ~H) + 0x6666666666666666ull) & H)) { all = false; break; }
+  }
+  if (all) for (; i < n; i++) { const unsigned char c = (unsigned char)(s[i] | 32); if (c < 'a' || c > 'z') { all = false; break; } }
+  if (all) { memcpy(d, s, n); return; }
   size_t k = 0;
-  for (size_t i = 0; i < n; i++) { const char c = s[i]; if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) d[k++] = c; }
+  for (i = 0; i < n; i++) { const char c = s[i]; if ((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) d[k++] = c; }
   dst.resize(old + k);
 }
 
@@ -448,6 +535,10 @@ bool protein_has_fragment(const char *s, uint64_t len, const kaiju_gpu_params &p
 }
 
 int main(int argc, char **argv) {
+  // batches come and go by the hundred megabytes: keep that memory in the heap instead of mapping and unmapping (and
+  // page-faulting) it for every batch
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
   std::atomic<uint64_t> inexact_batches{0}, inexact_reads{0};
   kaiju_gpu_params params;
   kaiju_gpu_default_params(&params, 1);
@@ -571,6 +662,7 @@ int main(int argc, char **argv) {
     if (verbose) fprintf(stderr, "%s Start classification on GPU %d\n", now().c_str(), device);
 
     struct RawPair { std::unique_ptr<RawBlock> a, b; };
+    BatchPool pool;
     OrderedQueue<RawPair> q_raw(8);
     OrderedQueue<std::unique_ptr<Batch>> q_parsed(6), q_done(6), q_text(8);
 
@@ -578,13 +670,14 @@ int main(int argc, char **argv) {
     std::thread reader([&] {
       BlockReader r1(in1_fn);
       if (!r1.ok) die("Could not open file " + in1_fn);
+      { StageTimer tm(g_ns_read); r1.prescan(n_workers); }
       std::unique_ptr<BlockReader> r2;
       OrderedQueue<std::unique_ptr<RawBlock>> q2(4);
       std::thread reader2;
       if (paired) {
         r2.reset(new BlockReader(in2_fn));
         if (!r2->ok) die("Could not open file " + in2_fn);
-      r2->prescan(n_workers);
+        r2->prescan(n_workers);
         reader2 = std::thread([&] {
           uint64_t k = 0;
           for (;;) {
@@ -599,7 +692,7 @@ int main(int argc, char **argv) {
       for (;;) {
         RawPair pr;
         pr.a.reset(new RawBlock());
-        if (!r1.next(*pr.a, batch_reads)) break;
+        { StageTimer tm(g_ns_read); if (!r1.next(*pr.a, batch_reads)) break; }
         if (paired) {
           if (!q2.take(seq, pr.b)) die("File " + in1_fn + " contains more reads then file " + in2_fn);
           if (pr.b->n_records < pr.a->n_records) die("File " + in1_fn + " contains more reads then file " + in2_fn);
@@ -623,8 +716,8 @@ int main(int argc, char **argv) {
       parsers.emplace_back([&] {
         uint64_t seq; RawPair pr;
         while (q_raw.take_any(seq, pr)) {
-          std::unique_ptr<Batch> b(new Batch());
-          parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b);
+          std::unique_ptr<Batch> b = pool.get();
+          { StageTimer tm(g_ns_parse); parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b); }
           if (paired && pr.b->n_records > pr.a->n_records)
             fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
           q_parsed.put(seq, std::move(b));
@@ -640,6 +733,7 @@ int main(int argc, char **argv) {
           const uint32_t n = (uint32_t)b->n();
           int r = 0;
           if (parse_only) { q_done.put(seq, std::move(b)); continue; }
+          StageTimer tm(g_ns_gpu);
           if (verbose) {
             b->hits.resize(n);
             b->vrec.resize(n);
@@ -666,7 +760,7 @@ int main(int argc, char **argv) {
             else for (uint32_t q = 0; q < n; q++) ni += (b->compact[q].info & KAIJU_HIT_INEXACT) ? 1 : 0;
             if (ni) inexact_reads += ni;
           }
-          if (!pmode) std::vector<char>().swap(b->seqs);
+
           q_done.put(seq, std::move(b));
         }
       });
@@ -678,6 +772,7 @@ int main(int argc, char **argv) {
         uint64_t seq; std::unique_ptr<Batch> b;
         std::vector<kaiju_result> res;
         while (q_done.take_any(seq, b)) {
+          StageTimer tm(g_ns_format);
           const uint32_t n = (uint32_t)b->n();
           if (parse_only) {
             std::string &text = b->text;
@@ -771,7 +866,7 @@ int main(int argc, char **argv) {
     // stage 5: write in input order
     {
       std::unique_ptr<Batch> b;
-      for (uint64_t seq = 0; q_text.take(seq, b); seq++) fwrite(b->text.data(), 1, b->text.size(), out);
+      for (uint64_t seq = 0; q_text.take(seq, b); seq++) { StageTimer tm(g_ns_write); fwrite(b->text.data(), 1, b->text.size(), out); pool.put(std::move(b)); }
     }
     reader.join();
     for (auto &t : parsers) t.join();
@@ -786,6 +881,10 @@ int main(int argc, char **argv) {
     run_sample(list1[i], paired ? list2[i] : std::string(), i < list_out.size() ? list_out[i] : std::string());
   }
   if (verbose) fprintf(stderr, "%s Finished.\n", now().c_str());
+  if (getenv("KAIJU_GPU_STAGE_TIMES"))
+    fprintf(stderr, "[CPU time per stage, summed over its threads] read %.3f s, parse %.3f s, gpu calls %.3f s, format %.3f s, "
+                    "write %.3f s\n", g_ns_read.load() * 1e-9, g_ns_parse.load() * 1e-9, g_ns_gpu.load() * 1e-9,
+            g_ns_format.load() * 1e-9, g_ns_write.load() * 1e-9);
   if (inexact_batches.load() || inexact_reads.load()) {
     // the reference has no such bounds: say so instead of printing lines that may differ from its output silently
     fprintf(stderr, "%s: a capacity bound of the GPU kernels was exceeded (%llu reads flagged, %llu batches with a fragment of more than "
