@@ -84,10 +84,12 @@ typedef struct {
 
 #define KAIJU_HIT_ID_CAP 1u     /* the 21-id cap ended the traversal (order sensitive case)   */
 #define KAIJU_HIT_SI_CAP 2u     /* Greedy: > max_matches_SI equal-score matches existed       */
-#define KAIJU_HIT_INEXACT 0x80000000u /* a device-side capacity bound was exceeded for this read (a fragment with more
-                                   than 15 SEG regions or longer than 65535 residues, or search scratch exhausted even in
-                                   the retry pass): the record is NOT guaranteed to equal the reference's.  MEM reports
-                                   the SEG case per batch only: kaiju_gpu_stats.error_flags                    */
+#define KAIJU_HIT_INEXACT 0x80000000u /* a device-side capacity bound was exceeded for this read (search scratch exhausted
+                                   even in the retry pass; the region pool of the exact pass for fragments with more
+                                   than 15 SEG regions exhausted): the record is NOT guaranteed to equal the
+                                   reference's.  kaiju_gpu_stats.error_flags reports the batch-wide cases: 2 = SEG queue
+                                   full, 4 = region pool of the exact pass exhausted, 8 = more than 65536 reads needed
+                                   the exact pass                                                              */
 
 /* what the host seam turns a hit into: one output line "C/U \t name \t taxon" */
 typedef struct {

@@ -26,6 +26,7 @@
 #include "host_tables.h"
 #include "kj_core.h"
 #include "taxonomy.h"
+#include "exact_pass.h"
 
 using namespace kj;
 
@@ -601,6 +602,7 @@ struct kaiju_gpu_ctx {
   int n_cu = 0, blocks_main = 0, blocks_retry = 0;
   DevBuf pep, frags, meta, counters, retry_list, seg_items, seg_recs;
   DevBuf scratch_main[10], scratch_retry[5], h_compact;
+  DevBuf redo_bitmap, redo_list, redo_items, redo_index, redo_pool, redo_work, redo_cls;    // the exact pass
   bool greedy2 = false;
   uint32_t greedy_gate = 3;
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
@@ -614,7 +616,8 @@ struct kaiju_gpu_ctx {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact,
-                     &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry};
+                     &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry,
+                     &redo_bitmap, &redo_list, &redo_items, &redo_index, &redo_pool, &redo_work, &redo_cls};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 10; i++) if (scratch_main[i].p) (void)hipFree(scratch_main[i].p);
     for (int i = 0; i < 5; i++) if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p);
@@ -771,6 +774,34 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   wl_retry.counter = cnt + 1; wl_retry.reads = static_cast<const uint32_t *>(c->retry_list.p);
   wl_retry.n_items_ptr = cnt + 2; wl_retry.n_items = 0; wl_retry.retry_list = nullptr; wl_retry.retry_count = nullptr;
   const uint64_t lanes_main = (uint64_t)c->blocks_main * kBlock;
+  // the exact pass (kj_core.h: BigSeg; kernels in exact_pass.hip): reads with a fragment whose SEG regions did not fit
+  // a SegRec are classified again behind the retry pass, with region lists of any length.  Counters: [5] listed reads,
+  // [6] fragments of its queue, [7] its work counter, [20] pairs handed out of its pool
+  constexpr uint32_t kRedoReads = 1u << 16, kRedoFrags = 1u << 18, kRedoPairs = 1u << 22;
+  const bool exact_pass = n > 0 && p.seg;
+  ExactPassLaunch xp{};
+  if (exact_pass) {
+    const uint64_t max_frag = protein ? max_read_len / 3 : max_read_len / 3 + 2;     // (max_read_len was tripled for protein reads)
+    xp.cap_ints = (uint32_t)(2 * max_frag + 4);
+    xp.cls_bytes = (uint32_t)((max_frag + 64) & ~63ull);
+    const uint64_t per_block = 16ull * xp.cap_ints + xp.cls_bytes;
+    xp.seg_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, (256ull << 20) / per_block));
+    if ((rc = ensure(c->redo_bitmap, ((size_t)n / 32 + 2) * 4))) return rc;
+    if ((rc = ensure(c->redo_list, (size_t)kRedoReads * 4))) return rc;
+    if ((rc = ensure(c->redo_items, (size_t)kRedoFrags * sizeof(SegWork)))) return rc;
+    if ((rc = ensure(c->redo_index, (size_t)kRedoFrags * sizeof(uint2)))) return rc;
+    if ((rc = ensure(c->redo_pool, (size_t)kRedoPairs * 8))) return rc;
+    if ((rc = ensure(c->redo_work, (size_t)xp.seg_blocks * 16 * xp.cap_ints))) return rc;
+    if ((rc = ensure(c->redo_cls, (size_t)xp.seg_blocks * xp.cls_bytes))) return rc;
+    KJ_HIP(hipMemsetAsync(c->redo_bitmap.p, 0, ((size_t)n / 32 + 2) * 4, s));
+    xp.ix = ix->dev; xp.d_ct = ix->d_ct; xp.st = ix->st; xp.p = p; xp.b = b; xp.sq = sq; xp.cnt = cnt;
+    xp.bitmap = static_cast<uint32_t *>(c->redo_bitmap.p); xp.list = static_cast<uint32_t *>(c->redo_list.p);
+    xp.list_cap = kRedoReads;
+    xp.sq2 = SegQueue{static_cast<SegWork *>(c->redo_items.p), nullptr, cnt + 6, kRedoFrags};
+    xp.big = BigSeg{static_cast<uint2 *>(c->redo_index.p), static_cast<int32_t *>(c->redo_pool.p), cnt + 20, kRedoPairs};
+    xp.work = static_cast<int32_t *>(c->redo_work.p); xp.cls = static_cast<uint8_t *>(c->redo_cls.p);
+    xp.n_cu = c->n_cu; xp.stream = s;
+  }
   VerboseOut vb{nullptr, nullptr, nullptr, nullptr, 0};
   if (c->verbose) {
     // columns 6/7: per read kVbAcc sequence numbers and room for 20 matched peptides
@@ -819,6 +850,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
+      if (exact_pass) {
+        xp.si = static_cast<SIEntry *>(c->scratch_retry[0].p); xp.si_cap = si_cap_retry; xp.blocks_search = blocks_retry;
+        xp.vb = vb;
+        KJ_HIP(kj_launch_exact_pass(xp));
+      }
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
   } else {
     const uint32_t frag_max = max_read_len / 3 + 4;
@@ -875,6 +911,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       KJ_HIP(hipEventRecord(c->ev[3], s));
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
+      if (exact_pass) {
+        xp.g_pool = gr.pool; xp.g_ord = gr.ord; xp.g_matches = gr.matches; xp.g_best = gr.best; xp.g_bestv = gr.bestv;
+        xp.g_pool_cap = gr.pool_cap; xp.g_match_cap = gr.match_cap; xp.blocks_search = c->blocks_retry;
+        xp.vb = vb;
+        KJ_HIP(kj_launch_exact_pass(xp));
+      }
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
   }
   KJ_HIP(hipEventRecord(c->ev[4], s));
@@ -1136,7 +1178,9 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
   stats->n_reads = ctx->last_n;
   stats->n_overflow_retries = cnt[2];
   stats->n_seg_fragments = cnt[4];
-  stats->error_flags = cnt[3];
+  // bit 0 (a SegRec overflowed in the MEM split of the main pass) is settled by the exact pass, which reports its own
+  // failures: 4 = region pool exhausted, 8 = more reads than its list holds
+  stats->error_flags = ctx->kp.seg ? (cnt[3] & ~1u) : cnt[3];
   stats->ms_translate = t01;
   stats->ms_seg = t12;
   stats->ms_search = t23;

@@ -887,8 +887,8 @@ int main(int argc, char **argv) {
             g_ns_format.load() * 1e-9, g_ns_write.load() * 1e-9);
   if (inexact_batches.load() || inexact_reads.load()) {
     // the reference has no such bounds: say so instead of printing lines that may differ from its output silently
-    fprintf(stderr, "%s: a capacity bound of the GPU kernels was exceeded (%llu reads flagged, %llu batches with a fragment of more than "
-                    "15 low-complexity regions or longer than 65535 residues): their lines may differ from the reference's.\n",
+    fprintf(stderr, "%s: a capacity bound of the GPU kernels was exceeded (%llu reads flagged; %llu batches in which the exact pass for "
+                    "fragments with many low-complexity regions ran out of room): their lines may differ from the reference's.\n",
             getenv("KAIJU_GPU_ALLOW_INEXACT") ? "Warning" : "Error", (unsigned long long)inexact_reads.load(),
             (unsigned long long)inexact_batches.load());
     if (!getenv("KAIJU_GPU_ALLOW_INEXACT")) return 3;

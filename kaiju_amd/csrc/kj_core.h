@@ -552,13 +552,15 @@ KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len
 // visible to all its lanes.
 template <class Coop, class Sync>
 KJ_HD int seg_regions(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len,
-                      int32_t *left, int32_t *right, bool &overflow, int32_t *work, uint8_t *cls, Sync &&team_sync) {
-  int32_t *b = work, *e = work + kSegMaxRegions;
+                      int32_t *left, int32_t *right, bool &overflow, int32_t *work, uint8_t *cls, Sync &&team_sync,
+                      int cap = kSegMaxRegions) {
+  // (cap: capacity of the two scan lists in `work` and of left/right; the exact pass of long fragments passes more)
+  int32_t *b = work, *e = work + cap;
   if (cls && len >= kSegWindow) {
     seg_classes(cx, coop, s, len, cls);
     team_sync();
   }
-  const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, kSegMaxRegions, overflow, cls);
+  const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, cap, overflow, cls);
   if (n == 0) return 0;
   // the reference's list is in reverse creation order; s_MergeSegs (:2122-2152, hilenmin 0)
   // walks it from the head and merges a node with its successor while they overlap
@@ -905,6 +907,73 @@ KJ_HD void seg_split(const ConstTables &t, const Params &p, const SegRec &rec, c
     if (r < nreg) start = (uint64_t)rec.lr[r][1] + 1;
   }
 }
+// the same from a list of any length (exact pass): (left, right) pairs
+struct BigRegs { const int32_t *lr; int cnt; };
+template <class Sink>
+KJ_HD void seg_split_regs(const ConstTables &t, const Params &p, const BigRegs &regs, const uint8_t *pep,
+                          const Frag &f, Sink &&sink) {
+  const int nreg = regs.cnt;
+  uint64_t start = 0;
+  for (int r = 0; r <= nreg; r++) {
+    const uint64_t length = (r < nreg ? (uint64_t)(uint32_t)regs.lr[2 * r] : (uint64_t)f.len) - start;
+    if (length > p.m) {
+      const uint64_t avail = start <= f.len ? f.len - start : 0;
+      const uint32_t take = (uint32_t)(length < avail ? length : avail);
+      Frag q; q.start = f.start + (uint32_t)start; q.len = take; q.flags = kFragChecked;
+      if (p.mode == 1) {
+        q.key = diag_score(t, pep, q.start, take);
+        if (q.key >= p.min_score) sink(q);
+      } else { q.key = (uint32_t)length; sink(q); }
+    }
+    if (r < nreg) start = (uint64_t)(uint32_t)regs.lr[2 * r + 1] + 1;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// The exact pass.  A SegRec holds 15 regions and 16-bit positions; a fragment that needs more (long,
+// low-complexity-rich proteins or contigs) is marked `overflow` by the SEG pass.  Reads with such a fragment
+// are done again after the main and retry passes by a few small kernels (capi.hip: k_redo_*): stage 1 into a
+// queue of its own, SEG with lists of any length into a pool of (left, right) pairs, the split from those,
+// the search by the first-generation lanes.  Nothing of this is on the hot path: the kernels of the main
+// pass are untouched, the exact pass finds an empty list for all but unusual inputs.
+// ----------------------------------------------------------------------------
+struct BigSeg {
+  uint2 *index;              // [slot of the exact pass's queue] -> (first pair in lr, number of regions)
+  int32_t *lr;               // pool of (left, right) pairs
+  uint32_t *count;           // pairs handed out
+  uint32_t cap;              // pairs in the pool
+};
+constexpr uint32_t kBigSegLost = 0xffffffffu;     // index[slot].y: the pool was too small (reported, KAIJU_HIT_INEXACT)
+#if defined(__HIP_DEVICE_COMPILE__)
+KJ_HD uint32_t append_many(uint32_t *counter, uint32_t n) { return atomicAdd(counter, n); }
+#else
+KJ_HD uint32_t append_many(uint32_t *counter, uint32_t n) { const uint32_t v = *counter; *counter += n; return v; }
+#endif
+// SEG of one queued fragment with lists of any length; `work` = 4 * cap ints and `cls` = f.len bytes of scratch of the
+// team (device memory), cap > 2 * f.len
+template <class Coop, class Sync>
+KJ_HD void seg_compute_big(const SegCtx &cx, const Coop &coop, const Batch &b, const SegQueue &sq, const BigSeg &big,
+                           uint32_t slot, int32_t *work, int cap, uint8_t *cls, uint32_t *err_flags, Sync &&team_sync) {
+  const SegWork wk = sq.items[slot];
+  const ReadMeta rm = b.meta[wk.read];
+  const Frag f = b.frags[rm.frag + wk.frag];
+  const uint8_t *src = b.pep + rm.pep + f.start;
+  int32_t *left = work + 2 * cap, *right = work + 3 * cap;
+  bool ov = false;
+  team_sync();                                              // the previous fragment's lists are no longer read
+  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov, work, cls, team_sync, cap);
+  if (coop.lane() != 0) return;
+  uint2 ent; ent.x = 0; ent.y = kBigSegLost;
+  if (!ov) {
+    const uint32_t off = append_many(big.count, (uint32_t)n);
+    if ((uint64_t)off + (uint32_t)n <= big.cap) {
+      for (int k = 0; k < n; k++) { big.lr[2 * ((size_t)off + k)] = left[k]; big.lr[2 * ((size_t)off + k) + 1] = right[k]; }
+      ent.x = off; ent.y = (uint32_t)n;
+    }
+  }
+  if (ent.y == kBigSegLost && err_flags) *err_flags |= 4u;
+  big.index[slot] = ent;
+}
 
 struct FragAppend {
   Frag *dst; uint32_t *n; uint32_t cap;
@@ -1101,6 +1170,35 @@ KJ_HD void seg_apply_mem(const ConstTables &t, const Params &p, const Batch &b, 
     if (rec.overflow && err_flags) *err_flags |= 1u;
     uint32_t cnt = n_orig + np;
     seg_split(t, p, rec, pep, f, FragAppend{list, &cnt, cap});
+    np = cnt - n_orig;
+    list[k].flags |= kFragRemoved;
+  }
+  uint32_t w = 0;
+  for (uint32_t k = 0; k < n_orig; k++) if (!(list[k].flags & kFragRemoved)) list[w++] = list[k];
+  // at least one parent was dropped, so w <= n_orig - 1 and the insertion below never
+  // overwrites a piece that has not been read yet
+  for (uint32_t q = 0; q < np; q++) { const Frag pc = list[n_orig + q]; frag_insert(list, w, cap, pc); }
+  b.meta[r].nfrag = w;
+}
+
+// the same in the exact pass: the regions come from the pool (a lost list leaves the fragment unsplit; reported)
+KJ_HD void seg_apply_mem_big(const ConstTables &t, const Params &p, const Batch &b, const BigSeg &big, uint32_t r) {
+  const ReadMeta rm = b.meta[r];
+  const uint32_t raw = rm.nfrag;
+  if (!(raw & kNfragSegPending)) return;
+  const uint32_t n_orig = raw & ~kNfragSegPending;
+  Frag *list = b.frags + rm.frag;
+  const uint32_t cap = frag_cap(b.off, r, p.m);
+  const uint8_t *pep = b.pep + rm.pep;
+  uint32_t np = 0;
+  for (uint32_t k = 0; k < n_orig; k++) {
+    const Frag f = list[k];
+    const uint32_t slot1 = f.flags >> kFragSlotShift;
+    if (!slot1) continue;
+    const uint2 ent = big.index[slot1 - 1];
+    if (ent.y == kBigSegLost) continue;
+    uint32_t cnt = n_orig + np;
+    seg_split_regs(t, p, BigRegs{big.lr + 2 * (size_t)ent.x, (int)ent.y}, pep, f, FragAppend{list, &cnt, cap});
     np = cnt - n_orig;
     list[k].flags |= kFragRemoved;
   }
@@ -1867,7 +1965,9 @@ enum GState : int {
 
 KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                        const Batch &b, const WorkList &wl, const GreedyScratch &gs,
-                       const VerboseOut &vb = VerboseOut{nullptr, nullptr, nullptr, nullptr, 0}) {
+                       const VerboseOut &vb = VerboseOut{nullptr, nullptr, nullptr, nullptr, 0},
+                       const BigSeg *big = nullptr) {
+  // (big: the exact pass - `sq` is its queue, the regions of a fragment come from the pool)
   int state = GS_FETCH;
   uint32_t r = 0;
   const uint8_t *pep = nullptr;
@@ -1910,6 +2010,8 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
           q.head = q.tail = q.npool = 0; q.overflow = false;
           for (uint32_t f = 0; f < nf; f++) gq_push(gs, q, gitem_from_frag(F[f]));   // already in queue order
           best = 0; nbest = 0; flags = 0; m_ovf = false;
+          // (substitution positions are kept in 16 bits: no protein is that long, but say so if one is)
+          for (uint32_t f = 0; f < nf; f++) if (F[f].len > 65535u) flags |= kHitInternalOverflow;
           vb_reset(vb, r);
           state = GS_POP;
           break;
@@ -1923,7 +2025,11 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
             // SEG found regions in this fragment (computed by the SEG pass): the parent is dropped,
             // its unmasked pieces are queued, and the next fragment is popped (:291-334)
             Frag f; f.start = t.start; f.len = t.len; f.key = t.key; f.flags = 0;
-            if (t.matchlen) {
+            if (t.matchlen && big) {
+              const uint2 ent = big->index[t.matchlen - 1];
+              if (ent.y == kBigSegLost) flags |= kHitInternalOverflow;
+              else seg_split_regs(ct, p, BigRegs{big->lr + 2 * (size_t)ent.x, (int)ent.y}, pep, f, GSink{&gs, &q});
+            } else if (t.matchlen) {
               const SegRec rec = sq.recs[t.matchlen - 1];
               if (rec.overflow) flags |= kHitInternalOverflow;
               seg_split(ct, p, rec, pep, f, GSink{&gs, &q});

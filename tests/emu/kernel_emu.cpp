@@ -214,6 +214,64 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }
+  // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
+  if (p.seg && n > 0) {
+    std::vector<uint32_t> redo;
+    std::vector<char> seen(n, 0);
+    for (uint32_t s2 = 0; s2 < seg_count && s2 < seg_cap; s2++) {
+      if (!seg_recs[s2].overflow) continue;
+      const uint32_t r = seg_items[s2].read;
+      if (!seen[r]) { seen[r] = 1; redo.push_back(r); }
+    }
+    err &= ~1u;                                            // (kaiju_gpu_get_stats: settled by the exact pass)
+    if (!redo.empty()) {
+      const bool protein = (p.flags & kParamProtein) != 0;
+      uint32_t count2 = 0, pairs = 0;
+      const uint32_t cap2 = 1u << 12;
+      const char *pe = getenv("KAIJU_EMU_REDO_POOL");       // (tests: a pool that is too small)
+      const uint32_t pool_cap = pe ? (uint32_t)atoi(pe) : (1u << 20);
+      std::vector<SegWork> items2(cap2);
+      std::vector<uint2> index2(cap2);
+      std::vector<int32_t> pool2((size_t)2 * pool_cap + 2);
+      SegQueue sq2{items2.data(), nullptr, &count2, cap2};
+      BigSeg big{index2.data(), pool2.data(), &pairs, pool_cap};
+      uint8_t code[256];
+      memset(code, 0, sizeof code);
+      for (uint32_t a = 0; a < 20; a++) protein_code_entry(ix->ct, a, code);
+      for (uint32_t r : redo) {
+        memset(&hits[r], 0, sizeof(Hit));
+        if (protein) build_fragments_protein(ix->ct, code, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq2, r, &err);
+        else build_fragments(ix->ct, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq2, r, &err, nullptr, 4, 0);
+      }
+      const uint32_t max_frag = protein ? maxlen : maxlen / 3 + 2;
+      const int cap_ints = (int)(2 * max_frag + 4);
+      std::vector<int32_t> work2((size_t)4 * cap_ints);
+      std::vector<uint8_t> cls2((size_t)max_frag + 64);
+      for (uint32_t s2 = 0; s2 < count2 && s2 < cap2; s2++)
+        seg_compute_big(cx, CoopSerial{}, b, sq2, big, s2, work2.data(), cap_ints, cls2.data(), &err, [] {});
+      if (p.mode == 0) for (uint32_t r : redo) seg_apply_mem_big(ix->ct, p, b, big, r);
+      WorkList wl;
+      uint32_t rcount = (uint32_t)redo.size();
+      counter = 0;
+      wl.counter = &counter; wl.n_items = rcount; wl.n_items_ptr = nullptr; wl.reads = redo.data();
+      wl.retry_list = nullptr; wl.retry_count = &retry_count;
+      si.assign(2 * (size_t)maxlen + 64, SIEntry{});
+      pool.assign(65535, GItem{}); ord.assign(65535, 0);
+      matches.assign((size_t)maxlen + 8, GMatch{});
+      if (p.mode == 0) {
+        LaneScratch ls{si.data(), (uint32_t)si.size(), win};
+        mem_lane<uint64_t>(d, p, b, wl, ls, g_vb);
+      } else {
+        GreedyScratch gs;
+        gs.pool = pool.data(); gs.pool_cap = (uint32_t)pool.size(); gs.ord = ord.data();
+        gs.matches = matches.data(); gs.match_cap = (uint32_t)matches.size();
+        gs.best = bestv.data(); gs.win = win;
+        std::vector<GBestV> bestvv(64);
+        gs.bestv = g_vb.n_acc ? bestvv.data() : nullptr;
+        greedy_lane(d, ix->ct, p, sq2, b, wl, gs, g_vb, &big);
+      }
+    }
+  }
   static_assert(sizeof(Hit) == sizeof(kaiju_gpu_hit), "hit layout");
   memcpy(out, hits.data(), sizeof(Hit) * n);
   return err ? -100 : 0;

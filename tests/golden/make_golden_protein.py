@@ -5,9 +5,14 @@
                             low-complexity inserts, lengths around the -m gate, multi-line FASTA records, names with
                             blanks (kaiju cuts them, kaijup keeps them)
   refp_<mode>_<seg>.tsv     `kaiju -p -v -z 1`
-  refpx_<mode>[_v].tsv      `kaijup -z 1 [-v]`"""
+  refpx_<mode>[_v].tsv      `kaijup -z 1 [-v]`
+  regions_prot.fa, regions_nuc.fa   reads whose single fragment holds more low-complexity regions than a record of the SEG
+                            pass (15): the exact pass of the kernels (tests/util.py: many_region_reads)
+  refr_prot_<mode>.tsv, refr_nuc_<mode>.tsv   `kaiju [-p] -v -z 1` on them"""
 import os
 import subprocess
+
+import sys
 
 import numpy as np
 
@@ -88,5 +93,25 @@ def main():
             print(out, sum(1 for _ in open(out)))
 
 
+def regions():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    prot, nuc = util.many_region_reads()
+    for name, reads in (("prot", prot), ("nuc", nuc)):
+        with open(f"{HERE}/regions_{name}.fa", "wb") as f:
+            for i, s in enumerate(reads):
+                f.write(b">g%d\n%s\n" % (i, s))
+        for mode in ("mem", "greedy"):
+            out = f"{HERE}/refr_{name}_{mode}.tsv"
+            cmd = [f"{REF}/kaiju", "-t", f"{HERE}/nodes.dmp", "-f", f"{HERE}/db.fmi", "-i", f"{HERE}/regions_{name}.fa", "-a", mode,
+                   "-z", "1", "-v", "-o", out] + (["-p"] if name == "prot" else [])
+            subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+            print(out, sum(1 for _ in open(out)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "regions":
+        regions()
+        sys.exit(0)
     main()
+    regions()

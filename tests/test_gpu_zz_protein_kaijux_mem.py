@@ -1,5 +1,6 @@
-"""GPU tests of the paths added last in round 1 - protein input (kaiju -p, kaijup: k_fragments_protein) and the list
-order of the reference's kaijux MEM search (k_mem_x, kParamXOrder).  They were developed against the host emulation of
+"""GPU tests of the paths added last in round 1 - protein input (kaiju -p, kaijup: k_fragments_protein), the list
+order of the reference's kaijux MEM search (k_mem_x, kParamXOrder) and the exact pass for fragments with more SEG regions
+than a record of the SEG pass holds (exact_pass.hip).  They were developed against the host emulation of
 the kernels (tests/test_kernel_emu.py runs the same checks there) after the round's GPU budget was spent, so this file
 is named to run after every test that had already been run on the device."""
 import os
@@ -61,9 +62,9 @@ def test_protein_long_and_batched(gpu_lib, golden, gidx, oracle):
         clf = api.Classifier(gidx, api.default_params(mode, seg=1, input_is_protein=1))
         hits = clf.classify(seqs, off)
         oh = oracle.classify(ix, tax, oracle.params(mode, seg=1, protein=1, use_evalue=0), seqs, off)
-        bad = [i for i in range(len(oh)) if not (int(hits[i]["flags"]) & 0x80000000) and not util.same_hit(oh[i], hits[i])]
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
         assert not bad, (mode, bad[:5])
-        assert int((hits["flags"] & 0x80000000 != 0).sum()) <= 2       # (more than 15 SEG regions in one fragment: flagged)
+        assert not (hits["flags"] & 0x80000000).any() and clf.stats().error_flags == 0
 
 
 def cli(name):
@@ -131,3 +132,35 @@ def test_kaijux_mem_order_under_the_id_cap(gpu_lib, oracle, tmp_path):
     assert sum(1 for h in oh if h["flags"] & 1) > 20                     # the cap is hit
     bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_exact_pass_many_seg_regions(gpu_lib, golden, gidx, oracle, mode):
+    """a fragment with more low-complexity regions than a record of the SEG pass holds (15): the read is classified again
+    by the exact pass and equals the oracle; protein and nucleotide reads, alone and mixed into a batch of ordinary reads"""
+    api = gpu_lib
+    prot, nuc = util.many_region_reads()
+    ix, tax = oracle.load_fmi(golden.fmi), oracle.load_nodes(golden.nodes)
+    for reads, protein in ((prot, 1), (nuc, 0), (list(golden.prot_reads) * 3 + prot, 1), (list(golden.reads) * 3 + nuc, 0)):
+        seqs, off = util.pack(reads)
+        clf = api.Classifier(gidx, api.default_params(mode, seg=1, input_is_protein=protein))
+        hits = clf.classify(seqs, off)
+        assert clf.stats().error_flags == 0 and not (hits["flags"] & 0xC0000000).any()
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=1, protein=protein, use_evalue=0), seqs, off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+        assert not bad, (mode, protein, bad[:5])
+
+
+@pytest.mark.parametrize("kind", ["prot", "nuc"])
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_cli_exact_pass(gpu_lib, golden, tmp_path, mode, kind):
+    """the command line on reads that go through the exact pass: all seven columns == the reference's lines, exit status 0"""
+    out = str(tmp_path / "r.tsv")
+    cmd = [cli("kaiju"), "-t", golden.nodes, "-f", golden.fmi, "-i", os.path.join(golden.dir, f"regions_{kind}.fa"), "-a", mode,
+           "-v", "-o", out] + (["-p"] if kind == "prot" else [])
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    assert open(out).read() == open(os.path.join(golden.dir, f"refr_{kind}_{mode}.tsv")).read()
+    cmd.remove("-v")
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    want = ["\t".join(line.rstrip("\n").split("\t")[:3]) for line in open(os.path.join(golden.dir, f"refr_{kind}_{mode}.tsv"))]
+    assert [line.rstrip("\n") for line in open(out)] == want

@@ -489,3 +489,61 @@ def test_protein_long(oracle, emu, golden, handles):
         gh, _ = emu.classify(h, util.gp(mode, seg=1, protein=1), seqs, off)
         bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
         assert not bad, (mode, bad[:5])
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_exact_pass_many_seg_regions(oracle, emu, golden, handles, mode, monkeypatch):
+    """a fragment with more low-complexity regions than a record of the SEG pass holds (15): the read is classified
+    again by the exact pass (region lists of any length) and equals the oracle; protein and nucleotide reads"""
+    h, ix, tax = handles
+    prot, nuc = util.many_region_reads()
+    assert max(len(oracle.seg(s)) for s in prot) > 18
+    for reads, protein in ((prot, 1), (nuc, 0), (list(golden.prot_reads[:60]) + prot, 1)):
+        seqs, off = util.pack(reads)
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=1, protein=protein, use_evalue=0), seqs, off)
+        gh, _ = emu.classify(h, util.gp(mode, seg=1, protein=protein), seqs, off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (mode, protein, bad[:5])
+        assert not (gh["flags"] & 0x80000000).any()
+    # a region pool that is too small is reported, not passed over
+    monkeypatch.setenv("KAIJU_EMU_REDO_POOL", "8")
+    seqs, off = util.pack(prot)
+    gh, _ = emu.classify(h, util.gp(mode, seg=1, protein=1), seqs, off, allow_capacity=True)
+    assert gh is None
+
+
+@pytest.mark.parametrize("kind", ["prot", "nuc"])
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_exact_pass_verbose_columns(emu, golden, handles, mode, kind):
+    """reads that go through the exact pass, verbose run: columns 4-7 == the reference's lines"""
+    import os
+    from kaiju_amd import api
+    h = handles[0]
+    E = emu.lib
+    names, reads = util.read_fasta(os.path.join(golden.dir, f"regions_{kind}.fa"))
+    seqs, off = util.pack(reads)
+    n = len(names)
+    nacc, acc, tlen, text, cap = _verbose_buffers(E, n)
+    try:
+        gh, _ = emu.classify(h, util.gp(mode, seg=1, protein=int(kind == "prot")), seqs, off)
+    finally:
+        E.emu_set_verbose(None, None, None, None, 0)
+    alpha = E.emu_alphabet(h)
+    lines = _tsv_lines(os.path.join(golden.dir, f"refr_{kind}_{mode}.tsv"))
+    nc = 0
+    for r, nm in enumerate(names):
+        ref = lines[nm]
+        if ref[0] != "C":
+            assert gh[r]["n_ids"] == 0 or mode == "greedy"
+            continue
+        nc += 1
+        ids = ",".join(str(x) for x in sorted(int(x) for x in gh[r]["taxid"][:gh[r]["n_ids"]])) + ","
+        accs = set()
+        for q in range(int(nacc[r])):
+            s = E.emu_seq_name(h, int(acc[r * 20 + q]))
+            if s and b"_" in s:
+                accs.add(s[: s.rindex(b"_")].decode())
+        t = "".join("," if c == 255 else chr(alpha[c]) for c in text[r * cap: r * cap + int(tlen[r])])
+        assert int(ref[3]) == int(gh[r]["best"]) and ref[4] == ids, (mode, kind, nm, ref[3:5], gh[r])
+        assert ref[5] == "".join(x + "," for x in sorted(accs)) and ref[6] == t, (mode, kind, nm, ref[5:], accs, t)
+    assert nc >= 10

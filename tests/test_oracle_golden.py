@@ -149,3 +149,18 @@ def test_kaijup_lines(oracle, golden, ox, mode):
             assert ref[0] == "C" and int(ref[2]) == int(h["best"]) and ref[3] == got, (mode, nm, ref, got)
         else:
             assert ref[0] == "U", (mode, nm, ref)
+
+
+@pytest.mark.parametrize("kind", ["prot", "nuc"])
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_many_seg_regions(oracle, golden, ox, mode, kind):
+    """reads whose single fragment holds more than 15 low-complexity regions (the case the kernels' exact pass exists
+    for): oracle == the reference's lines"""
+    ix, tax = ox
+    names, reads = util.read_fasta(os.path.join(golden.dir, f"regions_{kind}.fa"))
+    seqs, off = util.pack(reads)
+    ref = golden.tsv(f"refr_{kind}_{mode}.tsv")
+    got = util.oracle_records(oracle.classify(ix, tax, oracle.params(mode, seg=1, protein=int(kind == "prot")), seqs, off))
+    bad = [(n, g, ref[n]) for n, g in zip(names, got) if g != ref[n]]
+    assert not bad, bad[:3]
+    assert sum(1 for g in got if g[0] == "C") >= 10

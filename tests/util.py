@@ -280,3 +280,28 @@ def long_reads(n=120, seed=5, lo=400, hi=3000):
                 s = "".join(comp[c] for c in reversed(s))
         out.append(s.encode())
     return out
+
+
+def many_region_reads(n=12, seed=6, islands=24):
+    """proteins (and their back-translations) whose single fragment holds far more low-complexity regions than a record of
+    the SEG pass (15): stretches of the golden proteins alternating with short low-complexity islands"""
+    rng = np.random.default_rng(seed)
+    prots = []
+    with open(os.path.join(GOLD, "db.faa")) as f:
+        for line in f:
+            if not line.startswith(">"):
+                prots.append(line.strip())
+    AA = "ARNDCQEGHILKMFPSTWYV"
+    out_p, out_n = [], []
+    for _ in range(n):
+        parts = []
+        for _ in range(islands):
+            p = prots[int(rng.integers(0, len(prots)))]
+            a = int(rng.integers(0, max(1, len(p) - 40)))
+            parts.append(p[a: a + int(rng.integers(25, 40))])
+            x, y = AA[int(rng.integers(0, 20))], AA[int(rng.integers(0, 20))]
+            parts.append("".join(rng.choice([x, x, x, y], int(rng.integers(12, 20)))))
+        s = "".join(parts)
+        out_p.append(s.encode())
+        out_n.append("".join(BACK[c] for c in s).encode())
+    return out_p, out_n
