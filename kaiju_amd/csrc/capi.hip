@@ -606,6 +606,7 @@ struct kaiju_gpu_ctx {
   bool greedy2 = false;
   uint32_t greedy_gate = 3;
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
+  bool exact_pass = true;          // KAIJU_GPU_EXACT_PASS=0 switches the exact pass off (its reads stay flagged)
   uint32_t vb_text_cap = 0;
   DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
@@ -668,6 +669,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   c->kp.min_score = p->min_score; c->kp.seed_length = p->seed_length; c->kp.seg = p->seg ? 1 : 0;
   c->kp.max_matches_SI = p->max_matches_SI; c->kp.max_match_ids = p->max_match_ids;
   if (const char *e = getenv("KAIJU_GPU_DEBUG")) c->kp.debug = (uint32_t)atoi(e);
+  if (const char *e = getenv("KAIJU_GPU_EXACT_PASS")) c->exact_pass = atoi(e) != 0;
   // kaijux: the MEM search of ConsumerThreadx.cpp:135 (maxMatches(.., 1)) finds the same longest matches as
   // greedyExact but lists them in another order, which shows where the id cap cuts and in the peptides of -v
   if (ix->id_mode == KAIJU_GPU_IDS_SEQUENCE && p->mode == 0) c->kp.flags |= kParamXOrder;
@@ -778,7 +780,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   // a SegRec are classified again behind the retry pass, with region lists of any length.  Counters: [5] listed reads,
   // [6] fragments of its queue, [7] its work counter, [20] pairs handed out of its pool
   constexpr uint32_t kRedoReads = 1u << 16, kRedoFrags = 1u << 18, kRedoPairs = 1u << 22;
-  const bool exact_pass = n > 0 && p.seg;
+  const bool exact_pass = n > 0 && p.seg && c->exact_pass;
   ExactPassLaunch xp{};
   if (exact_pass) {
     const uint64_t max_frag = protein ? max_read_len / 3 : max_read_len / 3 + 2;     // (max_read_len was tripled for protein reads)
@@ -1180,7 +1182,7 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
   stats->n_seg_fragments = cnt[4];
   // bit 0 (a SegRec overflowed in the MEM split of the main pass) is settled by the exact pass, which reports its own
   // failures: 4 = region pool exhausted, 8 = more reads than its list holds
-  stats->error_flags = ctx->kp.seg ? (cnt[3] & ~1u) : cnt[3];
+  stats->error_flags = (ctx->kp.seg && ctx->exact_pass) ? (cnt[3] & ~1u) : cnt[3];
   stats->ms_translate = t01;
   stats->ms_seg = t12;
   stats->ms_search = t23;
