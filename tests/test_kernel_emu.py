@@ -547,3 +547,37 @@ def test_exact_pass_verbose_columns(emu, golden, handles, mode, kind):
         assert int(ref[3]) == int(gh[r]["best"]) and ref[4] == ids, (mode, kind, nm, ref[3:5], gh[r])
         assert ref[5] == "".join(x + "," for x in sorted(accs)) and ref[6] == t, (mode, kind, nm, ref[5:], accs, t)
     assert nc >= 10
+
+
+@pytest.mark.parametrize("shift", ["16", "20"])
+def test_wide_index_with_kaijux_order_and_protein(oracle, emu, golden, handles, tmp_path, shift, monkeypatch):
+    """the 64-bit MEM lane (indexes of 2^32 rows and more, forced here) combined with what came later: the match order of
+    kaijux (mem_lane2<true, true>) and protein reads"""
+    import ctypes as C
+    from kaiju_amd import mkfmi
+    monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
+    E = emu.lib
+    E.emu_index_load_x.restype = C.c_void_p
+    E.emu_index_load_x.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    # kaijux order under the id cap
+    faa, fmi = str(tmp_path / "rep.faa"), str(tmp_path / "rep.fmi")
+    reads = util.repetitive_db(faa)
+    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+    err = C.create_string_buffer(256)
+    h = E.emu_index_load_x(fmi.encode(), err, 256)
+    assert h, err.value
+    seqs, off = util.pack(reads)
+    ix = oracle.load_fmi(fmi)
+    oh = oracle.classify(ix, None, oracle.params("mem", seg=0, kaijux=1), seqs, off)
+    gh, _ = emu.classify(h, util.gp("mem", seg=0), seqs, off)
+    assert all(util.same_hit(a, b) for a, b in zip(oh, gh))
+    E.emu_index_free(h)
+    # protein reads on the golden index
+    hw = emu.load(golden.fmi)
+    _, gix, tax = handles
+    for mode in ("mem", "greedy"):
+        oh = oracle.classify(gix, tax, oracle.params(mode, seg=1, protein=1, use_evalue=0), golden.prot_seqs, golden.prot_off)
+        gh, _ = emu.classify(hw, util.gp(mode, seg=1, protein=1), golden.prot_seqs, golden.prot_off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (shift, mode, bad[:5])
+    E.emu_index_free(hw)
