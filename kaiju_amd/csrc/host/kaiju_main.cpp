@@ -816,7 +816,10 @@ int main(int argc, char **argv) {
               std::sort(ids, ids + k);
               for (uint32_t q = 0; q < k; q++) { const char *sn = kaiju_gpu_index_seq_name(index, (uint32_t)ids[q]); if (sn) text += sn; text += ','; }
               text += '\t';
-              if (verbose) text.append(b->vtext.data() + (size_t)r * b->vstride, b->vrec[r].text_len);
+              if (verbose) {
+                text.append(b->vtext.data() + (size_t)r * b->vstride, b->vrec[r].text_len);
+                if (b->vrec[r].truncated) { fprintf(stderr, "Warning: matched peptides of read %.*s truncated\n", (int)nl, nm); inexact_reads++; }
+              }
               text += '\n';
             }
             q_text.put(seq, std::move(b));
@@ -854,7 +857,7 @@ int main(int argc, char **argv) {
                 for (uint32_t q = 0; q < na; q++) if (q == 0 || acc[q] != acc[q - 1]) { text += acc[q]; text += ','; }
                 text += '\t';
                 text.append(b->vtext.data() + (size_t)r * b->vstride, v.text_len);
-                if (v.truncated) fprintf(stderr, "Warning: matched peptides of read %.*s truncated\n", (int)nl, nm);
+                if (v.truncated) { fprintf(stderr, "Warning: matched peptides of read %.*s truncated\n", (int)nl, nm); inexact_reads++; }
               }
               text += '\n';
             } else { text += "U\t"; text.append(nm, nl); text += "\t0\n"; }
