@@ -581,3 +581,28 @@ def test_wide_index_with_kaijux_order_and_protein(oracle, emu, golden, handles, 
         bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
         assert not bad, (shift, mode, bad[:5])
     E.emu_index_free(hw)
+
+
+@pytest.mark.parametrize("seg", [1, 0])
+def test_protein_evalue_gate_and_lca(emu, golden, handles, seg):
+    """host seam for protein reads: kaiju_finalize_hits with input_is_protein (E-value with query_len = read length,
+    ConsumerThread.cpp:660, LCA, C/U) on the emulated hit records == the reference's `kaiju -p -a greedy` lines"""
+    import ctypes as C
+    from kaiju_amd import api
+    h = handles[0]
+    gh, _ = emu.classify(h, util.gp("greedy", seg=seg, protein=1), golden.prot_seqs, golden.prot_off)
+    with open(golden.fmi, "rb") as f:
+        hdr = np.frombuffer(f.read(12), dtype=np.uint8)
+    db_length = float(int(hdr[:8].view("<i8")[0]) - int(hdr[8:12].view("<i4")[0]))
+    p = api.default_params("greedy", seg=seg, input_is_protein=1)
+    tax = api.Taxonomy(golden.nodes)
+    res = np.zeros(len(gh), dtype=api.RESULT_DTYPE)
+    hits = np.ascontiguousarray(gh)
+    off = np.ascontiguousarray(golden.prot_off, dtype=np.uint64)
+    assert api.lib().kaiju_finalize_hits(tax._h, C.byref(p), db_length, hits.ctypes.data, off.ctypes.data, len(gh), 0,
+                                        res.ctypes.data) == 0
+    ref = golden.tsv(f"refp_greedy_{seg}.tsv")
+    for nm, g, r in zip(golden.prot_names, gh, res):
+        got = ("C", int(r["taxon"]), int(r["best"]), tuple(sorted(int(x) for x in g["taxid"][:g["n_ids"]]))) if r["classified"] \
+            else ("U", 0, None, ())
+        assert got == ref[nm], (nm, got, ref[nm])
