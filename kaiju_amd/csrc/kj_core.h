@@ -1101,9 +1101,11 @@ KJ_HD void build_fragments_protein(const ConstTables &t, const uint8_t *aa_code,
     bool trig = false;
     TrigWin w;
     trig_reset(w);
+    uint64_t wacc = 0;                                      // eight codes per store (the area is 16-byte aligned)
     for (uint32_t x = 0; x < len; x++) {
       const uint32_t a = aa_code[rd.at(x)];
-      pep[x] = (uint8_t)a;
+      wacc |= (uint64_t)a << (8u * (x & 7u));
+      if ((x & 7u) == 7u) { *reinterpret_cast<uint64_t *>(pep + (x & ~7u)) = wacc; wacc = 0; }
       if (a) {
         if (run_len == 0) run_start = x;
         run_len++;
@@ -1115,7 +1117,7 @@ KJ_HD void build_fragments_protein(const ConstTables &t, const uint8_t *aa_code,
         trig_reset(w);
       }
     }
-    pep[len] = 0;
+    *reinterpret_cast<uint64_t *>(pep + (len & ~7u)) = wacc;           // the rest and the closing 0
     emit_run(p, list, n, cap, run_start, run_len, sum, seq, trig);     // the remaining sequence, :683-694
     // queue order (std::multimap<unsigned, Fragment*, std::greater>): descending key, equal keys as emitted
     for (uint32_t k = 1; k < n; k++) {
