@@ -176,6 +176,29 @@ def make_reads(db: SynthDB, n, seed=777, read_len=150, frac_db=0.70, chunk=1 << 
     return out
 
 
+def make_protein_reads(db: SynthDB, n, seed=779, read_len=100, frac_db=0.70, chunk=1 << 20):
+    """Protein reads (kaiju -p / kaijup workloads): uint8 ASCII array [n, read_len]; frac_db of them windows of database
+    proteins with {0, 0, 1, 2, 5} substituted residues, the rest i.i.d. background residues."""
+    rng = np.random.default_rng(seed)
+    lens = np.diff(db.offsets)
+    elig = np.nonzero(lens >= read_len)[0]
+    letters = np.frombuffer(AA.encode(), dtype=np.uint8)
+    out = np.empty((n, read_len), dtype=np.uint8)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        seq = elig[rng.integers(0, len(elig), size=m)]
+        start = db.offsets[seq] + (rng.random(m) * (lens[seq] - read_len + 1)).astype(np.int64)
+        win = db.codes[start[:, None] + np.arange(read_len)[None, :]].copy()
+        nsub = rng.choice(np.array([0, 0, 1, 2, 5]), size=m)
+        for k in range(5):
+            sel = np.nonzero(nsub > k)[0]
+            win[sel, rng.integers(0, read_len, size=len(sel))] = rng.integers(0, 20, size=len(sel), dtype=np.uint8)
+        rnd = rng.random(m) >= frac_db
+        win[rnd] = rng.choice(20, size=(int(rnd.sum()), read_len), p=_BG).astype(np.uint8)
+        out[lo:lo + m] = letters[win]
+    return out
+
+
 def make_pairs(db: SynthDB, n, seed=778, read_len=150, insert=300):
     """Paired-end reads: mate 1 forward from the insert start, mate 2 the reverse
     complement of the insert end.  Returns two uint8 arrays [n, read_len]."""
