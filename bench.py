@@ -4,28 +4,46 @@
     python bench.py --gpus N --steps K --warmup W
 
 One *step* is one pass of the hot path (six-frame translation -> SEG -> MEM search on the protein
-FM-index -> locate/taxon ids, kaiju_gpu_classify_batch_device) over one batch of synthetic reads
-that is already resident in HBM.  The workload is BASELINE.json configs[1]: a viruses-like
-synthetic index (680 001 proteins, 190 M aa) and 10 M synthetic 150-bp reads per
-GPU, `-a mem -m 11`, SEG on (the reference's default).  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank holds a replica of the index and classifies
-its own 10 M reads (weak scaling); the per-read hit records are collected on rank 0 with one
-asynchronous gather per chunk (RCCL over xGMI).  Rank 0 prints ONE JSON line.
+FM-index -> locate / taxon ids -> LCA, kaiju_gpu_classify_batch_device + kaiju_gpu_lca_batch_device)
+over one batch of synthetic reads that is already resident in HBM.  The headline workload is
+BASELINE.json configs[1]: a viruses-like synthetic index (680 001 proteins, 190 M aa)
+and 10 M synthetic 150-bp reads per GPU, `-a mem -m 11`, SEG on (the reference's default).
 
-`roofline` is computed for the dominant search kernel (k_mem): algorithmic bytes (128 B per
-reference-equivalent UpdateSI + 64 B per LF step + 8 B per SA sample + 150 B read + 184 B hit
-record, op counts from the instrumented oracle on a sample of the same reads) divided by the
-kernel's average duration measured with HIP events on the launch stream.  `cpu_baseline` times
-the unmodified reference binary (oracle/_ref/kaiju -z <cores>) on a bounded sample of the same
-reads on this host (classification phase only).
+With N > 1 and no launcher in the environment the script re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); every rank holds a
+replica of the index and classifies its own 10 M reads (weak scaling); the per-read 16-byte records are
+collected on rank 0 with one asynchronous gather per chunk.  Rank 0 prints ONE JSON line.
+
+Besides the headline (`value`, MEM) the line carries further legs, each timed the same way with fewer
+steps: `greedy` (BASELINE configs[2], the reference's default mode), `paired` (2 x 150-bp pairs, MEM:
+the shape of configs[3] on this index), and at N = 1 `host_buffers` (kaiju_gpu_classify_batch_compact
+from page-locked host memory: the PCIe-inclusive rate, never `value`).
+
+`roofline` (per leg) is that of the dominant search kernel.  `achieved` = algorithmic bytes of THIS
+implementation per launch / the kernel's launch duration (HIP events on its stream), where the
+algorithmic bytes are counted on the device by the counting instantiation of the same lane in one extra,
+untimed launch (kaiju_gpu_set_count_ops): 128 B for every k-mer table lookup, every distinct rank-block
+line of an UpdateSI / LF step and every SA sample, 64 B per peptide window, 16 B per read / fragment
+descriptor, 184 B per hit record (+ queue items and match records for Greedy).  `work_rate` is the
+reference-equivalent figure of SURVEY.md 8(d) (128 B per UpdateSI the REFERENCE performs ...): a rate of
+work, not traffic, so it is not divided by the HBM peak.  `traffic` is the measured HBM traffic of one
+launch from committed rocprofv3 PMC passes (profiles/traffic.json names the raw CSVs), only when
+the workload matches.
+
+`cpu_baseline` (N = 1) times the unmodified reference binary (oracle/_ref/kaiju -z <cores>) on a bounded
+sample of the same reads; its output lines are then compared with the GPU's records for the same reads
+(`parity`: reads checked / mismatches, for all three legs).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -45,10 +63,10 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def fastq_bytes(reads: np.ndarray) -> bytes:
-    """fixed-width FASTQ records, fully vectorised"""
+def fastq_bytes(reads: np.ndarray, first: int = 0) -> bytes:
+    """fixed-width FASTQ records, fully vectorised; read i is named r<first + i, 8 digits>"""
     n, L = reads.shape
-    names = np.char.add("@r", np.char.zfill(np.arange(n).astype(str), 8)).astype("S10")
+    names = np.char.add("@r", np.char.zfill(np.arange(first, first + n).astype(str), 8)).astype("S10")
     rec = np.empty((n, 10 + 1 + L + 3 + L + 1), dtype=np.uint8)
     rec[:, :10] = np.frombuffer(names.tobytes(), dtype=np.uint8).reshape(n, 10)
     rec[:, 10] = 10
@@ -59,52 +77,326 @@ def fastq_bytes(reads: np.ndarray) -> bytes:
     return rec.tobytes()
 
 
-def cpu_baseline(W, fmi, nodes, reads, mode, seg, sample_reads, oracle_reads):
-    """reference binary on a bounded sample + instrumented op counts from the oracle (test
-    infrastructure used as the CPU baseline / accounting only, never on the measured path)"""
+def offsets(m: int, L: int, Lm: int, paired: bool) -> np.ndarray:
+    """off[2m+1] of m fixed-width reads (pairs: mate 1 then mate 2 in one row of L = 2 * Lm bytes)"""
+    o = np.empty(2 * m + 1, dtype=np.uint64)
+    o[0::2] = np.arange(m + 1, dtype=np.uint64) * np.uint64(L)
+    o[1::2] = o[2::2] if not paired else o[0:-1:2] + np.uint64(Lm)
+    return o
+
+
+# ----------------------------------------------------------------------------------------------
+# accounting
+# ----------------------------------------------------------------------------------------------
+def algorithmic_bytes(oc: dict, nseq: int) -> float:
+    """bytes one launch of the search kernel has to move, by the memory steps it performed"""
+    lines = oc["kmer_lookups"] + oc["update_si_lines"] + oc["lf_lines"] + oc["sa_samples"] + oc["items_read"] + oc["items_written"]
+    small = 16 * (oc["read_meta"] + oc["frag_desc"] + oc["matches_read"] + oc["matches_written"] + 2 * oc["si_spills"])
+    term = 8 * math.ceil(math.log2(max(nseq, 2))) * oc["term_searches"]
+    return 128.0 * lines + small + 64.0 * oc["window_fills"] + float(HIT_BYTES) * oc["hits"] + term
+
+
+def reference_ops(W, fmi, reads_sample, mode, seg, paired, Lm):
+    """UpdateSI / LF / SA-decode counts of the REFERENCE's algorithm per read, from the instrumented oracle
+    (test infrastructure used for accounting only, never on the measured path)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    out = {"ops": None, "baseline": None}
     O = po.Oracle()
     oix = O.load_fmi(fmi)
-    k = min(oracle_reads, len(reads))
-    seqs, off = synth.pack_reads(reads[:k])
+    k = len(reads_sample)
+    seqs = np.ascontiguousarray(reads_sample).reshape(-1)
+    off = offsets(k, reads_sample.shape[1], Lm, paired)
     O.counters(reset=True)
     t0 = time.time()
-    O.classify(oix, None, O.params(mode, seg=seg), seqs, off)
-    t_or = time.time() - t0
+    O.classify(oix, None, O.params(mode, seg=seg), seqs, off, paired=paired)
+    t = time.time() - t0
     c = O.counters(reset=True)
-    out["ops"] = {"update_si": c["update_si"] / k, "lf_steps": c["fmindex_current"] / k,
-                  "sa_decodes": c["sa_decode"] / k, "sample": k}
-    if po.have_ref():
-        cores = os.cpu_count() or 1
-        s = min(sample_reads, len(reads))
-        fq = f"{W}/cpu_sample.fq"
-        with open(fq, "wb") as f:
-            f.write(fastq_bytes(reads[:s]))
-        with open(f"{W}/cpu_one.fq", "wb") as f:
-            f.write(fastq_bytes(reads[:1]))
-        base = [po.REF_KAIJU, "-t", nodes, "-f", fmi, "-a", mode, "-z", str(cores), "-o", f"{W}/cpu_out.tsv"]
-        if not seg:
-            base.append("-X")
-        t0 = time.time()
-        subprocess.run(base + ["-i", f"{W}/cpu_one.fq"], check=True, stderr=subprocess.DEVNULL)
-        t_load = time.time() - t0
-        t0 = time.time()
-        subprocess.run(base + ["-i", fq], check=True, stderr=subprocess.DEVNULL)
-        t_all = time.time() - t0
-        t_cls = max(t_all - t_load, 1e-6)
-        out["baseline"] = {"value": s / t_cls, "unit": "reads/s", "cores": cores, "kind": "reference",
-                           "sample": f"{s} of the benchmark reads, kaiju -z {cores} -a {mode}"
-                                     f"{'' if seg else ' -X'}; wall {t_all:.1f}s minus index load {t_load:.1f}s"}
-    else:
-        out["baseline"] = {"value": k / t_or, "unit": "reads/s", "cores": 1, "kind": "port",
-                           "sample": f"{k} of the benchmark reads through oracle/libkaiju_oracle.so"}
-    return out
+    return {"update_si": c["update_si"] / k, "lf_steps": c["fmindex_current"] / k, "sa_decodes": c["sa_decode"] / k,
+            "sample": k, "oracle_reads_per_s": k / max(t, 1e-9)}
 
 
-def tot_reads_per_launch(kern_ms):
-    return sum(m for _, m in kern_ms) / max(len(kern_ms), 1)
+def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample):
+    """the unmodified reference on `sample` of the reads: (baseline dict, per-read (classified, taxon) arrays)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    if not po.have_ref():
+        return None, None
+    import pandas as pd
+    cores = os.cpu_count() or 1
+    s = min(sample, len(reads))
+    tag = f"{mode}{'_pe' if paired else ''}"
+    files = [f"{W}/cpu_{tag}_1.fq"] + ([f"{W}/cpu_{tag}_2.fq"] if paired else [])
+    one = [f"{W}/cpu_{tag}_one_1.fq"] + ([f"{W}/cpu_{tag}_one_2.fq"] if paired else [])
+    for k, (fn, fo) in enumerate(zip(files, one)):
+        part = reads[:s, k * Lm:(k + 1) * Lm]
+        with open(fn, "wb") as f:
+            f.write(fastq_bytes(part))
+        with open(fo, "wb") as f:
+            f.write(fastq_bytes(part[:1]))
+    out = f"{W}/cpu_{tag}_out.tsv"
+    base = [po.REF_KAIJU, "-t", nodes, "-f", fmi, "-a", mode, "-z", str(cores), "-o", out]
+    if not seg:
+        base.append("-X")
+
+    def inputs(fl):
+        return ["-i", fl[0]] + (["-j", fl[1]] if paired else [])
+    t0 = time.time()
+    subprocess.run(base + inputs(one), check=True, stderr=subprocess.DEVNULL)
+    t_load = time.time() - t0
+    t0 = time.time()
+    subprocess.run(base + inputs(files), check=True, stderr=subprocess.DEVNULL)
+    t_all = time.time() - t0
+    t_cls = max(t_all - t_load, 1e-6)
+    bl = {"value": s / t_cls, "unit": "reads/s" if not paired else "pairs/s", "cores": cores, "kind": "reference",
+          "sample": f"{s} of the benchmark {'pairs' if paired else 'reads'}, kaiju -z {cores} -a {mode}{'' if seg else ' -X'}; "
+                    f"wall {t_all:.1f}s minus index load {t_load:.1f}s"}
+    df = pd.read_csv(out, sep="\t", header=None, names=["c", "name", "tax"], dtype={"c": str, "name": str, "tax": np.uint64},
+                     usecols=[0, 1, 2])
+    idx = df["name"].str.slice(1).astype(np.int64).to_numpy()
+    cls = np.zeros(s, dtype=np.uint8)
+    tax = np.zeros(s, dtype=np.uint64)
+    seen = np.zeros(s, dtype=np.uint8)
+    cls[idx] = (df["c"].to_numpy() == "C").astype(np.uint8)
+    tax[idx] = df["tax"].to_numpy()
+    seen[idx] = 1
+    if not seen.all():
+        raise RuntimeError("the reference printed fewer lines than reads")
+    return bl, (cls, tax)
+
+
+# ----------------------------------------------------------------------------------------------
+# one leg = one workload timed like the headline
+# ----------------------------------------------------------------------------------------------
+class Leg:
+    def __init__(self, name, mode, paired, reads, Lm, index, dtax, dev, rank, world, seg, chunk, nctx):
+        import torch
+        self.torch = torch
+        self.name, self.mode, self.paired, self.reads, self.Lm = name, mode, paired, reads, Lm
+        self.index, self.dtax, self.dev, self.rank, self.world = index, dtax, dev, rank, world
+        self.n, self.L = reads.shape
+        self.params = api.default_params(mode, seg=seg)
+        self.nctx = nctx if nctx > 0 else (2 if mode == "mem" else 1)
+        self.clfs = [api.Classifier(index, self.params) for _ in range(self.nctx)]
+        for c in self.clfs:
+            c.set_max_read_length(Lm)
+        self.d_seqs = torch.from_numpy(reads.reshape(-1)).to(dev)
+        self.chunk = min(chunk, self.n)
+        self.bounds = [(lo, min(self.n, lo + self.chunk)) for lo in range(0, self.n, self.chunk)]
+        self.d_offs = [torch.from_numpy(offsets(hi - lo, self.L, Lm, paired).view(np.int64)).to(dev) for lo, hi in self.bounds]
+        self.d_out = torch.zeros(self.n * HIT_BYTES, dtype=torch.uint8, device=dev)
+        # what leaves the GPU: 16-byte records (LCA computed on the device), not the 184-byte id lists
+        self.d_compact = torch.zeros(self.n * COMPACT_BYTES, dtype=torch.uint8, device=dev)
+        # one HIP stream per context: kernels, the LCA and the gather of a chunk queue on the same stream (the contexts' own
+        # streams are wrapped for torch: its collectives must be ordered behind the kernels).  Which pairs of streams the
+        # runtime maps to different hardware queues decides how much of stage 1 / SEG of one chunk hides behind the tail of
+        # the other chunk's search kernel; measured on one box: ctx 139.9, torch 134.1, prio 138.1, mixed 146.6 M reads/s
+        kind = os.environ.get("KAIJU_BENCH_STREAMS", "mixed")
+        if kind == "torch":
+            self.streams = [torch.cuda.Stream(dev) for _ in range(self.nctx)]
+        elif kind == "prio":
+            self.streams = [torch.cuda.Stream(dev, priority=-(k % 2)) for k in range(self.nctx)]
+        elif kind == "mixed":
+            self.streams = [torch.cuda.ExternalStream(self.clfs[0].stream_handle(), device=dev)] + [torch.cuda.Stream(dev) for _ in range(self.nctx - 1)]
+        else:
+            self.streams = [torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in self.clfs]
+        self.kern_ms, self.stage_ms, self.retries, self.gathered = [], {"translate": 0.0, "seg": 0.0, "search": 0.0, "retry": 0.0}, 0, 0
+
+    def _collect(self, c, m, record):
+        st = c.stats()                  # HIP events of that context's last chunk (blocks until its kernels are done)
+        if st.error_flags:
+            raise SystemExit(f"device-side capacity error flags {st.error_flags}")
+        if record:
+            self.kern_ms.append((st.ms_search, m))
+            for k, v in (("translate", st.ms_translate), ("seg", st.ms_seg), ("search", st.ms_search), ("retry", st.ms_retry)):
+                self.stage_ms[k] += v
+            self.retries += st.n_overflow_retries
+
+    def step(self, record, nctx=None, only_chunk=None):
+        """Classification contexts ping-pong the chunks on their HIP streams (the "two host threads per GPU on separate
+        streams" of SURVEY.md 8b): while one chunk is in its search kernel the next one runs stage 1 and the SEG pass."""
+        torch = self.torch
+        nctx = nctx or self.nctx
+        g = kdist.HitGatherer(self.world, self.rank, keep_results=False)
+        pending = [None] * nctx
+        main = torch.cuda.current_stream(self.dev)
+        for s in self.streams:
+            s.wait_stream(main)
+        for k, ((lo, hi), d_off) in enumerate(zip(self.bounds, self.d_offs)):
+            if only_chunk is not None and k != only_chunk:
+                continue
+            c, s = self.clfs[k % nctx], self.streams[k % nctx]
+            if pending[k % nctx] is not None:
+                self._collect(c, pending[k % nctx], record)
+            m = hi - lo
+            out_view = self.d_out[lo * HIT_BYTES: hi * HIT_BYTES]
+            cview = self.d_compact[lo * COMPACT_BYTES: hi * COMPACT_BYTES]
+            with torch.cuda.stream(s):
+                c.classify_device(self.d_seqs.data_ptr() + lo * self.L, m * self.L, d_off.data_ptr(), m, out_view.data_ptr(),
+                                  paired=self.paired, stream=s.cuda_stream)
+                c.lca_device(self.dtax, out_view.data_ptr(), m, cview.data_ptr(), stream=s.cuda_stream)
+                g.gather(cview)
+            pending[k % nctx] = m
+        for k in range(nctx):
+            if pending[k] is not None:
+                self._collect(self.clfs[k], pending[k], record)
+        for s in self.streams:
+            main.wait_stream(s)
+        g.wait()
+        self.gathered += g.bytes_gathered
+
+    def run(self, steps, warmup):
+        torch = self.torch
+        for _ in range(warmup):
+            self.step(False)
+        kdist.barrier()
+        torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(True)
+        kdist.barrier()
+        torch.cuda.synchronize(self.dev)
+        mine = time.perf_counter() - t0
+        self.elapsed_rank = mine
+        self.elapsed = kdist.max_over_ranks(mine, device=self.dev)
+        self.steps = steps
+        self.gathered_timed = self.gathered
+        # one more, untimed, pass with the chunks strictly one after the other: kernel durations free of the other
+        # chunk's kernels (what rocprofv3 --kernel-trace shows for `--contexts 1`)
+        live = (list(self.kern_ms), dict(self.stage_ms))
+        self.kern_ms, self.stage_ms = [], {k: 0.0 for k in self.stage_ms}
+        self.step(True, 1)
+        torch.cuda.synchronize(self.dev)
+        self.excl_kern, self.excl_stage = self.kern_ms, self.stage_ms
+        self.kern_ms, self.stage_ms = live
+        # accounting: the counting instantiation of the lane on the first chunk (untimed)
+        c = self.clfs[0]
+        c.count_ops(True)
+        self.step(False, 1, only_chunk=0)
+        torch.cuda.synchronize(self.dev)
+        self.op_counts = c.op_counts()
+        c.count_ops(False)
+        # the records of chunk 0 were just rewritten by the counting lane: they must equal the timed lanes' (checked
+        # below through the parity leg, which reads d_compact)
+        return self
+
+    def result(self, world, ref_ops, traffic, nseq):
+        tot_units = self.n * world * self.steps
+        value = tot_units / self.elapsed
+        excl_ms = sum(ms for ms, _ in self.excl_kern) / max(len(self.excl_kern), 1)
+        live_ms = sum(ms for ms, _ in self.kern_ms) / max(len(self.kern_ms), 1)
+        per_launch = float(sum(m for _, m in self.excl_kern)) / max(len(self.excl_kern), 1)
+        first = self.bounds[0][1] - self.bounds[0][0]
+        oc = self.op_counts
+        alg = algorithmic_bytes(oc, nseq) * (per_launch / first)          # counted on chunk 0, scaled to the mean launch
+        achieved = alg / (excl_ms * 1e-3) / 1e9 if excl_ms > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_mem" if self.mode == "mem" else "k_greedy2",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg, "units_per_launch": per_launch,
+                "algorithmic_bytes_per_unit": alg / max(per_launch, 1.0),
+                "avg_launch_ms": excl_ms,
+                "avg_launch_ms_note": "HIP events around the kernel, chunks strictly one after the other (extra untimed pass; "
+                                      "rocprofv3 --kernel-trace of `bench.py --contexts 1` shows the same average)",
+                "live_avg_launch_ms": live_ms,
+                "ops_per_unit": {k: v / first for k, v in oc.items()},
+                "stage_ms_per_step_exclusive": dict(self.excl_stage),
+                "stage_ms_per_step_live": {k: v / max(self.steps, 1) for k, v in self.stage_ms.items()}}
+        if ref_ops is not None:
+            ref_bytes = 128.0 * ref_ops["update_si"] + 64.0 * ref_ops["lf_steps"] + 8.0 * ref_ops["sa_decodes"] + self.L + HIT_BYTES
+            roof["work_rate"] = {"GBps_reference_equivalent": ref_bytes * per_launch / (excl_ms * 1e-3) / 1e9 if excl_ms > 0 else 0.0,
+                                 "reference_bytes_per_unit": ref_bytes, "reference_ops_per_unit": ref_ops,
+                                 "note": "SURVEY.md 8(d): bytes the REFERENCE's algorithm would touch for this work (128 B per "
+                                         "UpdateSI ...); the k-mer table replaces most of those steps, so this is a rate of "
+                                         "work, not traffic, and is not compared with the HBM peak"}
+        return {"value": value, "unit": "pairs/s" if self.paired else "reads/s", "steps": self.steps,
+                "ms_per_step": self.elapsed / self.steps * 1e3, "units_per_gpu_per_step": self.n,
+                "contexts_in_flight": self.nctx, "chunk": self.chunk,
+                "overflow_retries_per_step": self.retries / max(self.steps, 1), "roofline": roof}
+
+    def host_records(self, k):
+        """finalised (classified, taxon) of the first k reads from the device's compact records"""
+        rec = np.frombuffer(self.d_compact[: k * COMPACT_BYTES].cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
+        off = offsets(k, self.L, self.Lm, self.paired)
+        res = self.clfs[0].finalize_compact(rec, off, paired=self.paired)
+        return res["classified"].astype(np.uint8), res["taxon"].astype(np.uint64), rec
+
+    def close(self):
+        for c in self.clfs:
+            c.close()
+        del self.d_seqs, self.d_out, self.d_compact, self.d_offs
+
+
+def host_buffers_leg(index, dtax, reads, Lm, seg, dev, calls=4, chunk=2_500_000, nthreads=2):
+    """PCIe-inclusive rate of the entry point a host caller uses: kaiju_gpu_classify_batch_compact from page-locked host
+    buffers, two contexts in two host threads (H2D / D2H of one overlap with the kernels of the other)."""
+    import torch
+    n, L = reads.shape
+    chunk = min(chunk, n)
+    params = api.default_params("mem", seg=seg)
+    clfs = [api.Classifier(index, params) for _ in range(nthreads)]
+    bufs = []
+    for t in range(nthreads):
+        seqs = torch.empty(chunk * L, dtype=torch.uint8, pin_memory=True).numpy()
+        off = torch.empty(2 * chunk + 1, dtype=torch.int64, pin_memory=True).numpy().view(np.uint64)
+        out = torch.empty(chunk * COMPACT_BYTES, dtype=torch.uint8, pin_memory=True).numpy().view(api.COMPACT_DTYPE)
+        off[:] = offsets(chunk, L, Lm, False)
+        bufs.append((seqs, off, out))
+    starts = [(k * chunk) % max(n - chunk + 1, 1) for k in range(calls * nthreads)]
+
+    def worker(t, ks, timed):
+        torch.cuda.set_device(dev)
+        seqs, off, out = bufs[t]
+        for k in ks:
+            if timed:
+                seqs[:] = reads[starts[k]: starts[k] + chunk].reshape(-1)      # the caller's own packing of a batch
+            clfs[t].classify_compact(dtax, seqs, off, out=out)
+
+    for t in range(nthreads):                       # warm-up: buffers of the contexts get allocated
+        seqs = bufs[t][0]
+        seqs[:] = reads[:chunk].reshape(-1)
+        worker(t, [0], False)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(t, list(range(t, calls * nthreads, nthreads)), True)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    el = time.perf_counter() - t0
+    # the same without the packing memcpy on the host (buffers already filled): the library's share
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(t, list(range(t, calls * nthreads, nthreads)), False)) for t in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    el2 = time.perf_counter() - t0
+    for c in clfs:
+        c.close()
+    tot = calls * nthreads * chunk
+    return {"value": tot / el2, "unit": "reads/s", "reads_per_call": chunk, "calls": calls * nthreads, "host_threads": nthreads,
+            "with_host_packing_memcpy": tot / el,
+            "bytes_per_read": {"h2d": L + 16, "d2h": COMPACT_BYTES},
+            "entry_point": "kaiju_gpu_classify_batch_compact (page-locked host buffers in, 16-B records out, blocking); "
+                           "never the headline value"}
+
+
+def load_traffic(mode, paired, seg, nseq, per_launch):
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for rec in json.load(f)["measurements"]:
+                if (rec["mode"] == mode and int(rec["seg"]) == int(seg) and rec["nseq"] == nseq and
+                        bool(rec.get("paired", False)) == bool(paired) and rec["reads_per_launch"] == int(per_launch)):
+                    return rec["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def main():
@@ -118,28 +410,45 @@ def main():
                     help="classification contexts that ping-pong the chunks (default: 2 for mem, 1 for greedy)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 5_000_000)))
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
-    ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"])
+    ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"],
+                    help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")
     ap.add_argument("--no-seg", action="store_true")
-    ap.add_argument("--paired", action="store_true", help="2 x 150-bp pairs (BASELINE config 4 shape) instead of single reads")
-    ap.add_argument("--protein", type=int, default=0, metavar="LEN",
-                    help="protein reads of LEN residues (kaiju -p workload; not the headline metric) instead of 150-bp reads")
+    ap.add_argument("--paired", action="store_true", help="headline leg on 2 x 150-bp pairs instead of single reads")
+    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host"),
+                    help="further legs in the same line: greedy, paired, host (comma separated; '' = none)")
+    ap.add_argument("--leg-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-legs", type=int, default=400_000)
     ap.add_argument("--work", default=os.environ.get("KAIJU_BENCH_WORK", "/tmp/kaiju_amd_bench"))
     args = ap.parse_args()
+
+    # ---------------- N ranks: launch them ourselves when nobody did ----------------
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] starting", args.gpus, "ranks:", " ".join(cmd), file=sys.stderr, flush=True)
+        os.execvp(cmd[0], cmd)
 
     import torch
     rank, local_rank, world = kdist.init("nccl")
     if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using {world}", file=sys.stderr)
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the Kaiju HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        assert dist.get_world_size() == world and dist.get_backend() == "nccl"
     seg = 0 if args.no_seg else 1
     W = args.work
     os.makedirs(W, exist_ok=True)
+    legs_wanted = [x for x in args.legs.split(",") if x]
 
     # ---------------- workload (untimed) ----------------
     t0 = time.time()
@@ -156,188 +465,133 @@ def main():
                   f"({time.time()-t0:.1f}s)")
     kdist.barrier()
     index = api.Index(fmi, device=local_rank)
-    if args.protein and args.paired:
-        raise SystemExit("--protein has no paired mode")
-    params = api.default_params(args.mode, seg=seg, input_is_protein=1 if args.protein else 0)
-    clf = api.Classifier(index, params)
-    t0 = time.time()
-    n = args.reads
-    if args.paired:
-        # pair r = mate 1 followed by mate 2 in the sequence buffer
-        m1, m2 = synth.make_pairs(db, n, seed=778 + rank)
-        reads = np.concatenate([m1, m2], axis=1)
-        Lm = m1.shape[1]
-    elif args.protein:
-        reads = synth.make_protein_reads(db, n, seed=779 + rank, read_len=args.protein)
-        Lm = reads.shape[1]
-    else:
-        reads = synth.make_reads(db, n, seed=777 + rank)
-        Lm = reads.shape[1]
-    L = reads.shape[1]                       # bytes per read (pair) in the buffer
-    clf.set_max_read_length(Lm)
-    d_seqs = torch.from_numpy(reads.reshape(-1)).to(dev)
-    chunk = min(args.chunk, n)
-    bounds = [(lo, min(n, lo + chunk)) for lo in range(0, n, chunk)]
-    # off[2r] = off[2r+1]... unpaired: mate 2 empty
-    d_offs = []
-    for lo, hi in bounds:
-        m = hi - lo
-        o = np.empty(2 * m + 1, dtype=np.int64)
-        o[0::2] = np.arange(m + 1, dtype=np.int64) * L
-        o[1::2] = o[2::2] if not args.paired else o[0:-1:2] + Lm
-        d_offs.append(torch.from_numpy(o).to(dev))
-    d_out = torch.zeros(n * HIT_BYTES, dtype=torch.uint8, device=dev)
-    # what leaves the GPU: 16-byte records (LCA computed on the device), not the 184-byte id lists
     dtax = api.DeviceTaxonomy(api.Taxonomy(nodes), local_rank)
-    d_compact = torch.zeros(n * COMPACT_BYTES, dtype=torch.uint8, device=dev)
-    log(rank, f"{n} reads/GPU resident in HBM ({time.time()-t0:.1f}s), index {index.info.device_bytes/1e6:.0f} MB in HBM")
-    # Two classification contexts ping-pong the chunks on two HIP streams (the "two host threads per GPU
-    # on separate streams" of SURVEY.md 8b): while one chunk is in its HBM-bound search kernel the next one
-    # runs its ALU/latency-bound stage 1 and SEG pass.  --contexts 1 = strictly one chunk after the other.
-    # (two overlapping Greedy kernels only slow each other down: both are bound by instruction issue)
-    nctx = args.contexts if args.contexts > 0 else (2 if args.mode == "mem" else 1)
-    clfs = [clf] + [api.Classifier(index, params) for _ in range(nctx - 1)]
-    for c in clfs:
-        c.set_max_read_length(L)
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(nctx - 1)]
+    n = args.reads
+    Lm = 150
 
-    kern_ms = []          # k_mem / k_greedy2 main-pass durations (HIP events on the launch stream)
-    stage_ms = {"translate": 0.0, "seg": 0.0, "search": 0.0, "retry": 0.0}
-    retries = 0
+    def make(paired, count, seed):
+        if paired:
+            m1, m2 = synth.make_pairs(db, count, seed=seed + rank)
+            return np.concatenate([m1, m2], axis=1)           # pair r = mate 1 followed by mate 2 in the sequence buffer
+        return synth.make_reads(db, count, seed=seed + rank)
 
-    def collect(c, m, record):
-        nonlocal retries
-        st = c.stats()                  # HIP events of that context's last chunk (blocks until its kernels are done)
-        if st.error_flags:
-            raise SystemExit(f"device-side capacity error flags {st.error_flags}")
-        if record:
-            kern_ms.append((st.ms_search, m))
-            stage_ms["translate"] += st.ms_translate
-            stage_ms["seg"] += st.ms_seg
-            stage_ms["search"] += st.ms_search
-            stage_ms["retry"] += st.ms_retry
-            retries += st.n_overflow_retries
+    t0 = time.time()
+    reads = make(args.paired, n, 778 if args.paired else 777)
+    log(rank, f"{n} {'pairs' if args.paired else 'reads'}/GPU generated ({time.time()-t0:.1f}s), index {index.info.device_bytes/1e6:.0f} MB in HBM")
 
-    def one_step(record, nctx=nctx):
-        g = kdist.HitGatherer(world, rank, keep_results=False)
-        pending = [None] * nctx
-        main = torch.cuda.current_stream(dev)
-        for s in streams[1:]:
-            s.wait_stream(main)
-        for k, ((lo, hi), d_off) in enumerate(zip(bounds, d_offs)):
-            c, s = clfs[k % nctx], streams[k % nctx]
-            if pending[k % nctx] is not None:
-                collect(c, pending[k % nctx], record)
-            m = hi - lo
-            out_view = d_out[lo * HIT_BYTES: hi * HIT_BYTES]
-            cview = d_compact[lo * COMPACT_BYTES: hi * COMPACT_BYTES]
-            with torch.cuda.stream(s):
-                c.classify_device(d_seqs.data_ptr() + lo * L, m * L, d_off.data_ptr(), m, out_view.data_ptr(),
-                                  paired=args.paired, stream=s.cuda_stream)
-                c.lca_device(dtax, out_view.data_ptr(), m, cview.data_ptr(), stream=s.cuda_stream)
-                g.gather(cview)
-            pending[k % nctx] = m
-        for k in range(nctx):
-            if pending[k] is not None:
-                collect(clfs[k], pending[k], record)
-        for s in streams[1:]:
-            main.wait_stream(s)
-        g.wait()
+    def do_leg(name, mode, paired, rd, steps, warmup):
+        leg = Leg(name, mode, paired, rd, Lm, index, dtax, dev, rank, world, seg, args.chunk, args.contexts)
+        leg.run(steps, warmup)
+        log(rank, f"leg {name}: {leg.n * world * steps / leg.elapsed / 1e6:.1f} M {'pairs' if paired else 'reads'}/s")
+        return leg
 
-    for _ in range(args.warmup):
-        one_step(False)
-    kdist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(True)
-    kdist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = kdist.max_over_ranks(elapsed, device=dev)
-
-    # one more, untimed, pass with the chunks strictly one after the other: the kernel durations without
-    # the other chunk's kernels competing for the CUs (reported next to the live figures)
-    live = (list(kern_ms), dict(stage_ms))
-    kern_ms.clear()
-    for k in stage_ms:
-        stage_ms[k] = 0.0
-    one_step(True, 1)
-    torch.cuda.synchronize(dev)
-    excl_kern = list(kern_ms)
-    kern_ms[:] = live[0]
-    stage_ms.update(live[1])
-
-    # sanity: the fraction of reads with a hit must be what the generator plants (70 % DB reads)
-    hits = np.frombuffer(d_out[: min(n, 1_000_000) * HIT_BYTES].cpu().numpy().tobytes(), dtype=api.HIT_DTYPE)
+    head = do_leg("headline", args.mode, args.paired, reads, args.steps, args.warmup)
+    # per-rank rates and what was gathered (rank 0 needs them)
+    per_rank = [n * args.steps / head.elapsed_rank]
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([per_rank[0]], dtype=torch.float64, device=dev)
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        per_rank = [float(x.item()) for x in outl]
+    hits = np.frombuffer(head.d_out[: min(n, 1_000_000) * HIT_BYTES].cpu().numpy().tobytes(), dtype=api.HIT_DTYPE)
     frac_hit = float((hits["n_ids"] > 0).mean())
+    del hits
+
+    # ---------------- further legs ----------------
+    extra = {}
+    keep = {"headline": (head, reads)}
+    if "greedy" in legs_wanted and not (args.mode == "greedy" and not args.paired):
+        leg = do_leg("greedy", "greedy", False, reads if not args.paired else make(False, n, 777), args.leg_steps, 1)
+        extra["greedy"] = leg
+        keep["greedy"] = (leg, leg.reads)
+    if "paired" in legs_wanted and not args.paired:
+        rd = make(True, max(n // 2, 1), 778)
+        leg = do_leg("paired", "mem", True, rd, args.leg_steps, 1)
+        extra["paired"] = leg
+        keep["paired"] = (leg, rd)
+    host = None
+    if "host" in legs_wanted and world == 1 and not args.paired:
+        try:
+            host = host_buffers_leg(index, dtax, reads, Lm, seg, dev)
+            log(rank, f"leg host_buffers: {host['value']/1e6:.1f} M reads/s")
+        except Exception as e:  # noqa: BLE001
+            log(rank, "host_buffers leg failed:", repr(e))
 
     if rank != 0:
         return
-    total_reads = n * world * args.steps
-    value = total_reads / elapsed
+
+    # ---------------- accounting legs on the host: reference baseline + parity, reference op counts ----------------
+    def cpu_leg(leg, rd, sample, oracle_sample):
+        out = {"ref_ops": None, "baseline": None, "parity": None}
+        if args.no_cpu_baseline or world != 1:
+            return out
+        try:
+            out["ref_ops"] = reference_ops(W, fmi, rd[:oracle_sample], leg.mode, seg, leg.paired, Lm)
+        except Exception as e:  # noqa: BLE001 - the accounting legs must never kill the measurement
+            log(rank, f"reference op counts ({leg.name}) failed:", repr(e))
+        try:
+            bl, ref = run_reference(W, fmi, nodes, rd, Lm, leg.paired, leg.mode, seg, sample)
+            out["baseline"] = bl
+            if ref is not None:
+                k = len(ref[0])
+                cls, tax, _ = leg.host_records(k)
+                bad = np.nonzero((cls != ref[0]) | (tax != ref[1]))[0]
+                out["parity"] = {"checked": int(k), "mismatches": int(len(bad)), "first_mismatches": [int(x) for x in bad[:5]],
+                                 "against": "output lines (C/U, taxon) of the unmodified reference binary on the same reads"}
+        except Exception as e:  # noqa: BLE001
+            log(rank, f"cpu baseline / parity ({leg.name}) failed:", repr(e))
+        return out
+
+    acc = {"headline": cpu_leg(head, reads, args.cpu_sample, 30000)}
+    for nm in ("greedy", "paired"):
+        if nm in extra:
+            acc[nm] = cpu_leg(extra[nm], keep[nm][1], args.cpu_sample_legs, 10000)
+
+    hr = head.result(world, acc["headline"]["ref_ops"],
+                     load_traffic(head.mode, head.paired, seg, db.nseq, head.bounds[0][1] - head.bounds[0][0]), db.nseq)
     result = {
-        "metric": "classified reads/sec (150 bp)" if not args.protein else f"classified protein reads/sec ({args.protein} aa)",
-        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "metric": "classified reads/sec (150 bp)",
+        "value": hr["value"], "unit": hr["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": hr["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"viruses-like synthetic index ({db.nseq} proteins, {db.total_aa} aa, .fmi "
-                               f"{os.path.getsize(fmi)/1e6:.0f} MB, e=3); {n} synthetic {'2x' if args.paired else ''}{Lm}-{'aa protein' if args.protein else 'bp'} reads{' (pairs)' if args.paired else ''} per GPU per step "
-                               f"(70% {'DB windows' if args.protein else 'back-translated DB windows'}, 30% random); kaiju {'-p ' if args.protein else ''}-a {args.mode} -m 11"
+                               f"{os.path.getsize(fmi)/1e6:.0f} MB, e=3); {n} synthetic {'2x' if args.paired else ''}{Lm}-bp reads{' (pairs)' if args.paired else ''} per GPU per step "
+                               f"(70% back-translated DB windows, 30% random); kaiju -a {args.mode} -m 11"
                                f"{'' if seg else ' -X'} (SEG {'on' if seg else 'off'})",
-                   "reads_per_gpu_per_step": n, "chunk": chunk, "contexts_in_flight": nctx, "index_replicated": True,
-                   "gather": ("one async RCCL gather of 16-B records (device LCA of the 184-B hit records) per chunk to rank 0"
+                   "reads_per_gpu_per_step": n, "chunk": head.chunk, "contexts_in_flight": head.nctx, "index_replicated": True,
+                   "ranks": world, "per_rank_units_per_s": per_rank,
+                   "gather": (f"one async RCCL gather of 16-B records (device LCA of the 184-B hit records) per chunk to rank 0; "
+                              f"{head.gathered_timed / max(args.steps, 1):.0f} B into rank 0 per step"
                               if world > 1 else "none (1 GPU); device LCA to 16-B records still runs"),
-                   "fraction_reads_with_hit": round(frac_hit, 4), "overflow_retries_per_step": retries / max(args.steps, 1)},
+                   "fraction_reads_with_hit": round(frac_hit, 4), "overflow_retries_per_step": hr["overflow_retries_per_step"],
+                   "design_note": "one READ per lane following the reference's sequential pruning (DESIGN.md 3.3), rank blocks "
+                                  "read straight from HBM as 128-byte lines - not one fragment per lane with LDS-staged Occ blocks"},
+        "roofline": hr["roofline"],
     }
-    # ---------------- roofline of the dominant kernel + CPU baseline ----------------
-    ops = None
-    cb = None
-    if not args.no_cpu_baseline and world == 1 and not args.paired and not args.protein:   # (the CPU leg and the op counts are for single reads)
-        try:
-            r = cpu_baseline(W, fmi, nodes, reads, args.mode, seg, args.cpu_sample, 30000)
-            ops, cb = r["ops"], r["baseline"]
-        except Exception as e:  # noqa: BLE001 - the baseline leg must never kill the measurement
-            log(rank, "cpu baseline failed:", repr(e))
-    if ops is None:
-        # accounting figures measured with the instrumented oracle on this workload
-        ops = ({"update_si": 461.0, "lf_steps": 5.9, "sa_decodes": 0.85, "sample": 0} if args.mode == "mem"
-               else {"update_si": 1059.0, "lf_steps": 5.5, "sa_decodes": 0.8, "sample": 0})
-    bytes_per_read = 128.0 * ops["update_si"] + 64.0 * ops["lf_steps"] + 8.0 * ops["sa_decodes"] + L + HIT_BYTES
-    tot_ms = sum(ms for ms, _ in kern_ms)
-    tot_reads = sum(m for _, m in kern_ms)
-    avg_ms = tot_ms / max(len(kern_ms), 1)
-    achieved = (bytes_per_read * tot_reads / max(len(kern_ms), 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    # HBM bytes of one launch of that kernel as measured with rocprofv3 --pmc TCC_EA0_RDREQ_sum (x 128 B per
-    # request, the gfx950 correction of the guide confirmed in profiles/r01_randbench_calibration.txt) and
-    # TCC_EA0_WRREQ_sum (x 64 B) on this very workload; PMC passes cannot run inside the timed bench, so the
-    # figure comes from the committed measurement and is only reported when the workload matches it
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            for rec in json.load(f)["measurements"]:
-                if (rec["mode"] == args.mode and int(rec["seg"]) == int(seg) and rec["nseq"] == db.nseq and
-                        rec["reads_per_launch"] == int(tot_reads_per_launch(kern_ms))):
-                    traffic = rec["hbm_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        traffic = None
-    result["roofline"] = {"bound": "hbm", "kernel": "k_mem" if args.mode == "mem" else "k_greedy2",
-                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                          "traffic": traffic,
-                          "algorithmic_bytes_per_read": bytes_per_read,
-                          "ops_per_read": ops, "reads_per_launch": tot_reads / max(len(kern_ms), 1),
-                          "avg_launch_ms": avg_ms,
-                          "exclusive": (lambda e: {"avg_launch_ms": e, "achieved": bytes_per_read * tot_reads_per_launch(excl_kern) / (e * 1e-3) / 1e9,
-                                                   "frac": bytes_per_read * tot_reads_per_launch(excl_kern) / (e * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                   "note": "same kernel, chunks strictly one after the other (untimed extra pass)"})(
-                              sum(ms for ms, _ in excl_kern) / max(len(excl_kern), 1)) if excl_kern else None,
-                          "stage_ms_per_step": {k: v / max(args.steps, 1) for k, v in stage_ms.items()}}
-    if args.protein:
-        # no op counts exist for this workload yet: the accounting figures above are those of the 150-bp reads
-        result["roofline"].update({"traffic": None, "achieved": None, "frac": None, "exclusive": None,
-                                   "note": "op counts per read not measured for protein reads: stage times only"})
-    if cb is not None:
-        result["cpu_baseline"] = cb
+    if acc["headline"]["baseline"] is not None:
+        result["cpu_baseline"] = acc["headline"]["baseline"]
+    parity = {}
+    if acc["headline"]["parity"] is not None:
+        parity["headline"] = acc["headline"]["parity"]
+    for nm in ("greedy", "paired"):
+        if nm in extra:
+            lr = extra[nm].result(world, acc[nm]["ref_ops"],
+                                  load_traffic(extra[nm].mode, extra[nm].paired, seg, db.nseq,
+                                               extra[nm].bounds[0][1] - extra[nm].bounds[0][0]), db.nseq)
+            lr["workload"] = ("the same index and reads, kaiju -a greedy -e 3 (BASELINE configs[2])" if nm == "greedy" else
+                              f"the same index, {extra[nm].n} synthetic 2x{Lm}-bp pairs per GPU per step, kaiju -a mem (shape of BASELINE configs[3])")
+            if acc[nm]["baseline"] is not None:
+                lr["cpu_baseline"] = acc[nm]["baseline"]
+            if acc[nm]["parity"] is not None:
+                parity[nm] = acc[nm]["parity"]
+            result[nm] = lr
+    if host is not None:
+        result["host_buffers"] = host
+    if parity:
+        result["parity"] = parity
+        result["parity_checked_reads"] = sum(p["checked"] for p in parity.values())
+        result["mismatches"] = sum(p["mismatches"] for p in parity.values())
     print(json.dumps(result), flush=True)
 
 

@@ -183,7 +183,22 @@ int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d_seqs, uint
    entry point measures it itself.  Default 1024. */
 int kaiju_gpu_set_max_read_length(kaiju_gpu_ctx *ctx, uint32_t max_read_len);
 int kaiju_gpu_synchronize(kaiju_gpu_ctx *ctx);
+/* the context's own HIP stream (a hipStream_t): what the device-resident entry points use when they are given NULL; a
+   caller that queues its own work behind a batch (a copy, a collective) orders it on this stream */
+int kaiju_gpu_get_stream(kaiju_gpu_ctx *ctx, void **stream);
 int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats);
+/* Accounting (bench.py's roofline, never a timed launch): with count_ops on, the main search pass of the following
+   batches runs the counting instantiation of its lane, which adds up the memory steps of the search as THIS
+   implementation performs them; kaiju_gpu_get_op_counts() returns the totals of the last batch:
+   [0] k-mer table lookups, [1] UpdateSI steps past the table (bwt.c:160-173), [2] distinct 128-byte rank lines those
+   steps (and the Greedy multi-letter steps) touched, [3] LF steps (compactfmi.c:312-336), [4] rank lines of those,
+   [5] SA samples read, [6] read descriptors, [7] fragment descriptors, [8] 64-byte peptide windows, [9] terminator
+   searches, [10] match records spilled (MEM), [11] hit records written, [12] Greedy multi-letter steps
+   (ConsumerThread.cpp:346-395 at one position), [13] queue items read, [14] match records read, [15] queue items
+   written, [16] match records written, [17] wave iterations, [18] lane iterations. */
+#define KAIJU_GPU_N_OP_COUNTS 19
+int kaiju_gpu_set_count_ops(kaiju_gpu_ctx *ctx, int on);
+int kaiju_gpu_get_op_counts(kaiju_gpu_ctx *ctx, uint64_t *out, uint32_t n_out);
 
 /* ---- host side of the seam ------------------------------------------- */
 int kaiju_taxonomy_load(const char *nodes_dmp_path, kaiju_taxonomy **out);
@@ -223,7 +238,8 @@ typedef struct {
 } kaiju_gpu_compact;
 int kaiju_gpu_taxonomy_upload(const kaiju_taxonomy *t, int device_id, kaiju_gpu_taxonomy **out);
 void kaiju_gpu_taxonomy_free(kaiju_gpu_taxonomy *t);
-/* d_hits: n records written by kaiju_gpu_classify_batch_device; asynchronous on stream */
+/* d_hits: n records written by kaiju_gpu_classify_batch_device; asynchronous on stream (NULL = the context's own
+   stream, i.e. behind a classify_batch_device call that was also given NULL) */
 int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *d_hits,
                                uint32_t n_reads, kaiju_gpu_compact *d_out, void *stream);
 /* kaiju_gpu_classify_batch followed by the LCA on the device: host buffers in, 16-byte records out */

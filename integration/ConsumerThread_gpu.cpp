@@ -63,7 +63,8 @@ void ConsumerThread::doWork() {
   size_t batch_reads = 1000000;
   if (const char *e = getenv("KAIJU_GPU_BATCH")) { long v = atol(e); if (v > 0) batch_reads = (size_t)v; }
 
-  std::vector<ReadItem *> items;
+  std::vector<ReadItem *> items;      // the batch in the order the queue delivered it
+  std::vector<int64_t> slot;          // per item: its index in the device batch, -1 = stopped by the length gate
   std::string seqs;
   std::vector<uint64_t> off;
   std::vector<kaiju_gpu_hit> hits;
@@ -72,9 +73,10 @@ void ConsumerThread::doWork() {
   ReadItem *item = NULL;
   bool more = true;
   while (more) {
-    items.clear(); seqs.clear(); off.assign(1, 0);
+    items.clear(); slot.clear(); seqs.clear(); off.assign(1, 0);
     bool paired = false;
     size_t max_pair = 0;
+    uint32_t n = 0;
     while (items.size() < batch_reads && (more = myWorkQueue->pop(&item))) {           // the reference's queue, unchanged
       assert(item != NULL);
       // length gates, ConsumerThread.cpp:640-654 (kept: such reads never reach the device)
@@ -83,12 +85,10 @@ void ConsumerThread::doWork() {
                              : ((!item->paired && item->sequence1.length() < config->min_fragment_length * 3) ||
                                 (item->paired && item->sequence1.length() < config->min_fragment_length * 3 &&
                                  item->sequence2.length() < config->min_fragment_length * 3));
-      if (gated) {
-        output << "U\t" << item->name << "\t0\n";
-        delete item;
-        continue;
-      }
       items.push_back(item);
+      slot.push_back(gated ? -1 : (int64_t)n);
+      if (gated) continue;
+      n++;
       paired = paired || item->paired;
       seqs += item->sequence1;
       off.push_back(seqs.size());
@@ -97,7 +97,6 @@ void ConsumerThread::doWork() {
       const size_t lp = item->sequence1.length() + (item->paired ? item->sequence2.length() : 0);
       if (lp > max_pair) max_pair = lp;
     }
-    const uint32_t n = (uint32_t)items.size();
     uint32_t vstride = 0;
     if (n > 0) {
       hits.resize(n);
@@ -112,9 +111,15 @@ void ConsumerThread::doWork() {
         rc = kaiju_gpu_classify_batch(ctx, seqs.data(), off.data(), n, paired ? 1 : 0, hits.data());
       if (rc != 0) shim_die("kaiju_gpu_classify_batch", rc);
     }
-    for (uint32_t r = 0; r < n; r++) {
+    for (size_t it = 0; it < items.size(); it++) {
+      item = items[it];
+      if (slot[it] < 0) {                                                         // :640-654
+        output << "U\t" << item->name << "\t0\n";
+        delete item;
+        continue;
+      }
+      const uint32_t r = (uint32_t)slot[it];
       const kaiju_gpu_hit &h = hits[r];
-      item = items[r];
       if (h.flags & KAIJU_HIT_INEXACT)
         std::cerr << "Warning: a capacity bound of the GPU kernels was exceeded for read " << item->name << std::endl;
       uint64_t lca = 0;

@@ -96,6 +96,10 @@ def lib():
     L.kaiju_gpu_lca_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.kaiju_finalize_compact.argtypes = [C.POINTER(Params), C.c_double, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
                                          C.c_void_p]
+    L.kaiju_gpu_classify_batch_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int,
+                                                   C.c_void_p]
+    L.kaiju_gpu_set_count_ops.argtypes = [C.c_void_p, C.c_int]
+    L.kaiju_gpu_get_op_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     _lib = L
     return L
 
@@ -226,6 +230,14 @@ class Classifier:
         _check(lib().kaiju_gpu_classify_batch_device(self._h, d_seqs_ptr, seq_bytes, d_off_ptr, n,
                                                      1 if paired else 0, d_out_ptr, stream))
 
+    def stream_handle(self) -> int:
+        """the context's own HIP stream (hipStream_t as an integer): wrap it with torch.cuda.ExternalStream to queue
+        torch work (a collective, a copy) behind a batch that was launched with stream=0"""
+        h = C.c_void_p()
+        lib().kaiju_gpu_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        _check(lib().kaiju_gpu_get_stream(self._h, C.byref(h)))
+        return int(h.value or 0)
+
     def synchronize(self):
         _check(lib().kaiju_gpu_synchronize(self._h))
 
@@ -270,6 +282,30 @@ class Classifier:
             accs.append(sorted(names))
             peps.append(bytes(text[r * stride: r * stride + int(v[r]["text_len"])]).decode())
         return hits, accs, peps
+
+    def classify_compact(self, dtax: "DeviceTaxonomy", seqs: np.ndarray, off: np.ndarray, paired=False, out=None) -> np.ndarray:
+        """Host buffers in, 16-byte records (LCA on the device) out; blocking (kaiju_gpu_classify_batch_compact).
+        Arrays are used as they are (no copies): pass page-locked memory for full PCIe rates."""
+        n = (len(off) - 1) // 2
+        if out is None:
+            out = np.zeros(n, dtype=COMPACT_DTYPE)
+        assert seqs.dtype == np.uint8 and off.dtype == np.uint64 and seqs.flags.c_contiguous and off.flags.c_contiguous
+        _check(lib().kaiju_gpu_classify_batch_compact(self._h, dtax._h, seqs.ctypes.data, off.ctypes.data, n,
+                                                      1 if paired else 0, out.ctypes.data))
+        return out
+
+    OP_COUNT_NAMES = ("kmer_lookups", "update_si", "update_si_lines", "lf_steps", "lf_lines", "sa_samples", "read_meta",
+                      "frag_desc", "window_fills", "term_searches", "si_spills", "hits", "multi_letter_steps", "items_read",
+                      "matches_read", "items_written", "matches_written", "wave_iterations", "lane_iterations")
+
+    def count_ops(self, on: bool):
+        """accounting: the next batches run the counting instantiation of the search lane (never a timed launch)"""
+        _check(lib().kaiju_gpu_set_count_ops(self._h, 1 if on else 0))
+
+    def op_counts(self) -> dict:
+        v = np.zeros(len(self.OP_COUNT_NAMES), dtype=np.uint64)
+        _check(lib().kaiju_gpu_get_op_counts(self._h, v.ctypes.data, len(v)))
+        return {k: int(x) for k, x in zip(self.OP_COUNT_NAMES, v)}
 
     def lca(self, dtax: "DeviceTaxonomy", hits: np.ndarray) -> np.ndarray:
         """host hit records -> compact records through the LCA kernel (blocking)"""

@@ -169,6 +169,30 @@ k_mem_wide2(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32
   ls.win = s_win + threadIdx.x * kWinStride;
   mem_lane2<true>(ix, p, b, wl, ls);
 }
+// counting instantiations (kaiju_gpu_set_count_ops): the same lanes adding up their memory steps (kj_core.h: OpCount);
+// bench.py runs them once, untimed, for the algorithmic bytes of a launch
+__global__ void __launch_bounds__(kBlock, 2)
+k_mem_count(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  if (p.flags & kParamXOrder) mem_lane2<false, true, true>(ix, p, b, wl, ls);
+  else mem_lane2<false, false, true>(ix, p, b, wl, ls);
+}
+__global__ void __launch_bounds__(kBlock, 2)
+k_mem_wide2_count(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  if (p.flags & kParamXOrder) mem_lane2<true, true, true>(ix, p, b, wl, ls);
+  else mem_lane2<true, false, true>(ix, p, b, wl, ls);
+}
 // kaijux (ids = database sequences): the matches of a fragment are visited in the list order of maxMatches(.., 1)
 // (kj_core.h: XORDER); the first-generation lanes take the same switch from Params::flags
 __global__ void __launch_bounds__(kBlock, 4)
@@ -262,6 +286,27 @@ k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue 
   gs.best = ga.best + lane * 64;
   gs.gate = ga.gate;
   greedy_lane2(ix, s_ct, p, sq, b, wl, gs);
+}
+__global__ void __launch_bounds__(kBlock, 1)
+k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  uint32_t *s_prio = s_dyn;
+  uint32_t *s_win = s_prio + kBlock * kGPrioStride;
+  uint32_t *s_mq = s_win + kBlock * kGWinStride;
+  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_mq + kBlock * kGMqStride);
+  load_tables(s_ct, g_ct);
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  GreedyScratch2 gs;
+  gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
+  gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
+  gs.prio = s_prio + threadIdx.x * kGPrioStride;
+  gs.pool = ga.pool + lane * (8 * kGSlotsAll);
+  gs.prio_ext = ga.prio_ext + lane * (kGSlotsAll - kGSlots);
+  gs.matches = ga.matches + lane * kGMaxMAll;
+  gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
+  gs.best = ga.best + lane * 64;
+  gs.gate = ga.gate;
+  greedy_lane2<true>(ix, s_ct, p, sq, b, wl, gs);
 }
 
 // Index load: the k-mer table one letter deeper.  child[idx * 20 + c - 1] = UpdateSI(parent[idx], c)
@@ -607,6 +652,9 @@ struct kaiju_gpu_ctx {
   uint32_t greedy_gate = 3;
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
   bool exact_pass = true;          // KAIJU_GPU_EXACT_PASS=0 switches the exact pass off (its reads stay flagged)
+  bool count_ops = false;          // kaiju_gpu_set_count_ops: the main pass runs the counting instantiation of its lane
+  bool mem_v1 = false;             // KAIJU_GPU_MEM_LANE=v1 (read once, at context creation)
+  const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
   DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
@@ -670,6 +718,8 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   c->kp.max_matches_SI = p->max_matches_SI; c->kp.max_match_ids = p->max_match_ids;
   if (const char *e = getenv("KAIJU_GPU_DEBUG")) c->kp.debug = (uint32_t)atoi(e);
   if (const char *e = getenv("KAIJU_GPU_EXACT_PASS")) c->exact_pass = atoi(e) != 0;
+  if (const char *e = getenv("KAIJU_GPU_MEM_LANE")) c->mem_v1 = !strcmp(e, "v1");
+  c->dump_frags = getenv("KAIJU_GPU_DUMP_FRAGS");
   // kaijux: the MEM search of ConsumerThreadx.cpp:135 (maxMatches(.., 1)) finds the same longest matches as
   // greedyExact but lists them in another order, which shows where the id cap cuts and in the peptides of -v
   if (ix->id_mode == KAIJU_GPU_IDS_SEQUENCE && p->mode == 0) c->kp.flags |= kParamXOrder;
@@ -689,6 +739,8 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
     if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate |= (uint32_t)v << 8; }
     if (c->greedy2) {
       KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kGreedy2Lds));
+      KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2_count), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kGreedy2Lds));
       KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy2, kBlock, kGreedy2Lds));
     } else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy, kBlock, 0));
@@ -729,7 +781,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if ((rc = ensure(c->frags, n_frag_slots * sizeof(Frag)))) return rc;
   if (n_frag_slots >= 0xffffffffull) return fail(KAIJU_GPU_ERR_UNSUPPORTED, "batch too large: split it (fragment slots exceed 2^32)");
   if ((rc = ensure(c->meta, (size_t)n * sizeof(ReadMeta) + 16))) return rc;
-  if ((rc = ensure(c->counters, 256))) return rc;
+  if ((rc = ensure(c->counters, 1024))) return rc;     // [0, 256) counters, [512, ..) totals of the counting lanes
   if ((rc = ensure(c->retry_list, (size_t)n * 4 + 16))) return rc;
   Batch b;
   b.seqs = static_cast<const uint8_t *>(d_seqs); b.off = d_off; b.n_reads = n; b.paired = paired ? 1 : 0;
@@ -743,7 +795,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   SegQueue sq;
   sq.items = static_cast<SegWork *>(c->seg_items.p); sq.recs = static_cast<SegRec *>(c->seg_recs.p);
   sq.count = cnt + 4; sq.cap = (uint32_t)seg_cap;
-  KJ_HIP(hipMemsetAsync(cnt, 0, 256, s));
+  KJ_HIP(hipMemsetAsync(cnt, 0, 1024, s));
   if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
@@ -827,17 +879,20 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     while (blocks_retry > 1 && (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry) > (1ull << 30)) blocks_retry /= 2;
     if ((rc = ensure(c->scratch_retry[0], (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry)))) return rc;
     if (n > 0) {
-      const char *lane_env = getenv("KAIJU_GPU_MEM_LANE");
-      const bool v1 = lane_env && !strcmp(lane_env, "v1");
+      const bool v1 = c->mem_v1;
       const bool xo = (p.flags & kParamXOrder) != 0;
       if (ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 && !c->verbose)
-        if (xo) hipLaunchKernelGGL(k_mem_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+        if (c->count_ops) hipLaunchKernelGGL(k_mem_count, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                                             static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+        else if (xo) hipLaunchKernelGGL(k_mem_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                                    static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
         else hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                                 static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
       else if (ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 &&
                !c->verbose)
-        if (xo) hipLaunchKernelGGL(k_mem_wide2_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+        if (c->count_ops) hipLaunchKernelGGL(k_mem_wide2_count, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
+                                             static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
+        else if (xo) hipLaunchKernelGGL(k_mem_wide2_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                                    static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
         else hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
                                 static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
@@ -905,7 +960,9 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       g2.gate = c->greedy_gate;
     }
     if (n > 0) {
-      if (use_g2)
+      if (use_g2 && c->count_ops)
+        hipLaunchKernelGGL(k_greedy2_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, p, sq, b, wl_main, g2);
+      else if (use_g2)
         hipLaunchKernelGGL(k_greedy2, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, p, sq, b, wl_main, g2);
       else
         hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga, vb);
@@ -924,7 +981,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   KJ_HIP(hipEventRecord(c->ev[4], s));
   c->ev_valid = true;
   c->last_n = n;
-  if (const char *dump = getenv("KAIJU_GPU_DUMP_FRAGS")) {
+  if (const char *dump = c->dump_frags) {
     // developer aid: the fragment lists as the search kernels saw them, "#" per read then "key:PEPTIDE flags"
     KJ_HIP(hipStreamSynchronize(s));
     std::vector<ReadMeta> hm(n);
@@ -1061,7 +1118,9 @@ extern "C" int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_ta
   if (t->device != ctx->ix->device) return fail(KAIJU_GPU_ERR_ARG, "taxonomy lives on another device");
   if (n_reads == 0) return KAIJU_GPU_OK;
   KJ_HIP(hipSetDevice(ctx->ix->device));
-  hipLaunchKernelGGL(k_lca, dim3((n_reads + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), t->dev,
+  // NULL = the context's own stream, as in kaiju_gpu_classify_batch_device (the LCA must queue behind the search)
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  hipLaunchKernelGGL(k_lca, dim3((n_reads + 255) / 256), dim3(256), 0, s, t->dev,
                      reinterpret_cast<const Hit *>(d_hits), n_reads, reinterpret_cast<CompactHit *>(d_out));
   KJ_HIP(hipGetLastError());
   return KAIJU_GPU_OK;
@@ -1141,9 +1200,33 @@ extern "C" int kaiju_gpu_lca_batch(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy 
   if (hipMemcpy(d_in, hits, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyHostToDevice) != hipSuccess) rc = KAIJU_GPU_ERR_HIP;
   if (rc == KAIJU_GPU_OK) rc = kaiju_gpu_lca_batch_device(ctx, t, static_cast<const kaiju_gpu_hit *>(d_in), n_reads,
                                                           static_cast<kaiju_gpu_compact *>(d_out), nullptr);
+  if (rc == KAIJU_GPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = KAIJU_GPU_ERR_HIP;   // (k_lca ran on the context's stream)
   if (rc == KAIJU_GPU_OK && hipMemcpy(out, d_out, (size_t)n_reads * sizeof(kaiju_gpu_compact), hipMemcpyDeviceToHost) != hipSuccess) rc = KAIJU_GPU_ERR_HIP;
   (void)hipFree(d_in); (void)hipFree(d_out);
   return rc == KAIJU_GPU_OK ? rc : fail(rc, "kaiju_gpu_lca_batch");
+}
+
+extern "C" int kaiju_gpu_get_stream(kaiju_gpu_ctx *ctx, void **stream) {
+  if (!ctx || !stream) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  *stream = ctx->stream;
+  return KAIJU_GPU_OK;
+}
+extern "C" int kaiju_gpu_set_count_ops(kaiju_gpu_ctx *ctx, int on) {
+  if (!ctx) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  ctx->count_ops = on != 0;
+  return KAIJU_GPU_OK;
+}
+extern "C" int kaiju_gpu_get_op_counts(kaiju_gpu_ctx *ctx, uint64_t *out, uint32_t n_out) {
+  if (!ctx || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  for (uint32_t x = 0; x < n_out; x++) out[x] = 0;
+  if (!ctx->counters.p) return KAIJU_GPU_OK;
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  KJ_HIP(hipDeviceSynchronize());
+  unsigned long long v[kOpcN];
+  static_assert(kOpcOffsetBytes + sizeof v <= 1024, "the totals fit the counter block");
+  KJ_HIP(hipMemcpy(v, static_cast<const uint8_t *>(ctx->counters.p) + kOpcOffsetBytes, sizeof v, hipMemcpyDeviceToHost));
+  for (uint32_t x = 0; x < n_out && x < (uint32_t)kOpcN; x++) out[x] = v[x];
+  return KAIJU_GPU_OK;
 }
 
 extern "C" int kaiju_gpu_synchronize(kaiju_gpu_ctx *ctx) {

@@ -1250,6 +1250,31 @@ struct WorkList {
   uint32_t *retry_list;      // reads whose match buffer overflowed are appended here (or nullptr)
   uint32_t *retry_count;
 };
+// the counting instantiations of the second-generation lanes add their totals (kOpc*) behind the batch counters:
+// `counter` of the main pass is the first word of a 1024-byte block, the totals start at byte 512
+constexpr int kOpcOffsetBytes = 512;
+KJ_HD unsigned long long *opc_of(const WorkList &wl) {
+  return reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(wl.counter) + kOpcOffsetBytes);
+}
+
+// What the counting instantiations (mem_lane2<.., COUNT>, greedy_lane2<COUNT>) add up over a batch: the memory steps
+// of THIS algorithm, from which bench.py computes the algorithmic bytes of a launch.  Never part of
+// a timed launch.
+enum OpCount : int {
+  kOpcKmer, kOpcStep, kOpcStepLines, kOpcLf, kOpcLfLines, kOpcSa, kOpcMeta, kOpcFrag, kOpcFill, kOpcTerm, kOpcSiSpill,
+  kOpcHit, kOpcVmulti, kOpcPopItem, kOpcMload, kOpcPush, kOpcMatchWr, kOpcIters, kOpcLaneIters, kOpcN
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+KJ_HD void opc_flush(unsigned long long *dst, const uint32_t *oc) {
+  for (int x = 0; x < kOpcN; x++) {
+    uint32_t v = oc[x];
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(dst + x, (unsigned long long)v);
+  }
+}
+#else
+KJ_HD void opc_flush(unsigned long long *dst, const uint32_t *oc) { for (int x = 0; x < kOpcN; x++) dst[x] += oc[x]; }
+#endif
 
 // ----------------------------------------------------------------------------
 // verbose output (-v columns 6 and 7, ConsumerThread.cpp:527-536, :614-623, :820-824): produced by the
@@ -1563,9 +1588,11 @@ extern unsigned long long kj_hist[8][64];
 #else
 #define KJ_HISTO(h, v)
 #endif
-template <bool WIDE, bool XORDER = false>
+template <bool WIDE, bool XORDER = false, bool COUNT = false>
 KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
                      const LaneScratch &ls) {
+  uint32_t oc[kOpcN];
+  if constexpr (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
   // WIDE: 64-bit positions, block counts relative to mb_base, 16-byte k-mer entries (indexes >= 2^32 rows)
   typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   int kind = K_IDLE;
@@ -1641,6 +1668,18 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     const bool is_step = kind == K_STEP, is_lf = kind == K_LF1 || kind == K_LF2;
     const P posA = is_step ? lo : is_lf ? k : 0;
     const P posB = is_step ? hi : posA;
+    if constexpr (COUNT) {
+      // one rank block line per LF step (K_LF1 and K_LF2 read the same block), one or two per UpdateSI
+      oc[kOpcLaneIters] += (kind != K_EXIT) ? 1u : 0u;
+      if (kj_lane() == 0) oc[kOpcIters]++;
+      if (kind == K_KMER) oc[kOpcKmer]++;
+      else if (kind == K_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
+      else if (kind == K_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
+      else if (kind == K_SA) oc[kOpcSa]++;
+      else if (kind == K_META) oc[kOpcMeta]++;
+      else if (kind == K_FRAG) oc[kOpcFrag]++;
+      else if (kind == K_FILL) { oc[kOpcFill]++; if (fill_newfrag && f < nf) oc[kOpcFrag]++; }
+    }
     const uint32_t cc = (is_step || kind == K_LF2) ? c : 1u;
     const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
     const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
@@ -1716,6 +1755,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (c != 0) kind = K_LF2;
       else {
         // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+        if constexpr (COUNT) oc[kOpcTerm]++;
         const uint32_t iseq = (uint32_t)rank_term(ix, k);
         if (iseq < ix.nseq && ix.seq_valid[iseq]) {
           const uint64_t tax = ix.seq_taxid[iseq];
@@ -1776,7 +1816,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           const uint32_t ilen = (uint32_t)(int32_t)(hi - lo);
           if (nsi == 0) { s0lo = lo; s0len = ilen; s0frag = fcur; }
           else if (nsi == 1) { s1lo = lo; s1len = ilen; s1frag = fcur; }
-          else if (nsi < ls.si_cap) { SIEntry e; e.lo = lo; e.len = ilen; e.frag = fcur; ls.si[nsi] = e; }
+          else if (nsi < ls.si_cap) { SIEntry e; e.lo = lo; e.len = ilen; e.frag = fcur; ls.si[nsi] = e; if constexpr (COUNT) oc[kOpcSiSpill]++; }
           else ovf = true;
           nsi++;
           found = true;
@@ -1864,10 +1904,12 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       }
       if (bk == BK_FINISH) {
         hit->n_ids = nids; hit->flags = flags;
+        if constexpr (COUNT) oc[kOpcHit]++;
         kind = K_IDLE; bk = BK_NONE;
       }
     }
   }
+  if constexpr (COUNT) opc_flush(opc_of(wl), oc);
 }
 
 // ----------------------------------------------------------------------------
@@ -2367,9 +2409,12 @@ enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_LOC_ROW,                 
                  GB_LOC_NEXT_SI, GB_DONE };
 enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 
+template <bool COUNT = false>
 KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                         const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
   typedef uint32_t P;
+  uint32_t oc[kOpcN];
+  if constexpr (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
   int kind = G_IDLE, bk_pend = GB_NONE;
   // read
   uint32_t r = 0, nf = 0, fo = 0, fbase = 0;
@@ -2450,6 +2495,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     else qn++;
     pr_set(slot, key << 16 | (0xffffu - seq));
     qlive++;
+    if constexpr (COUNT) oc[kOpcPush]++;
     return slot;
   };
   // eval_match_scores on one match (ConsumerThread.cpp:751-797)
@@ -2666,6 +2712,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         }
         if (bk == GB_DONE) {
           hit->n_ids = nids; hit->flags = flags;
+          if constexpr (COUNT) oc[kOpcHit]++;
           kind = G_IDLE; bk = GB_NONE;
         }
       }
@@ -2712,6 +2759,22 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     const P vlo = m_lo, vhi = m_lo + m_len;
     const P posA = is_step ? lo : is_vm ? vlo : is_lf ? k : 0;
     const P posB = is_step ? hi : is_vm ? vhi : posA;
+    if constexpr (COUNT) {
+      oc[kOpcLaneIters] += (kind != G_EXIT && kind != G_WAIT) ? 1u : 0u;
+      if (kj_lane() == 0) oc[kOpcIters]++;
+      if (kind == G_KMER) oc[kOpcKmer]++;
+      else if (kind == G_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
+      else if (kind == G_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
+      else if (kind == G_SA) oc[kOpcSa]++;
+      else if (heavy) {
+        if (kind == G_VMULTI) { oc[kOpcVmulti]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
+        else if (kind == G_META) oc[kOpcMeta]++;
+        else if (kind == G_FRAG) oc[kOpcFrag]++;
+        else if (kind == G_FILL) { oc[kOpcFill]++; if (fill_pref && fo < nf) oc[kOpcFrag]++; }
+        else if (kind == G_POPITEM) oc[kOpcPopItem]++;
+        else if (kind == G_MLOAD) oc[kOpcMload]++;
+      }
+    }
     const uint32_t cc = (is_step || kind == G_LF2) ? c : 1u;
     const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
     const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
@@ -2789,7 +2852,8 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       else {
         // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
         const uint32_t iseq = (uint32_t)rank_term(ix, k);
-        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+if constexpr (COUNT) oc[kOpcTerm]++;
+                if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
         row++;
         k = row; fresh = true;
         bk = GB_LOC_ROW;
@@ -2980,6 +3044,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               GMatch2 mm; mm.lo = m_lo; mm.len = m_len; mm.qiql = m_qi | m_ql << 16; mm.dp = m_dsum | m_psum << 16;
               gs.matches[nm] = mm;
               if (nm < (uint32_t)kGMaxM) mq[nm] = (uint16_t)l; else gs.mq_ext[nm - kGMaxM] = (uint16_t)l;
+              if constexpr (COUNT) oc[kOpcMatchWr]++;
             } else m_ovf = true;
             nm++;
             last_qi = i;
@@ -3029,6 +3094,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       if (bk > GB_LOC_ROW) { bk_pend = bk; kind = G_WAIT; bk = GB_NONE; }
     }
   }
+  if constexpr (COUNT) opc_flush(opc_of(wl), oc);
 #if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
   if ((threadIdx.x & 63u) == 0) {
     // experiment only: cycles per section of the lane loop, summed over the wavefronts

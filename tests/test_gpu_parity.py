@@ -324,3 +324,83 @@ def test_randomised_databases_and_parameters(gpu_lib):
     r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "tools", "fuzz_gpu.py"), "12", "5"],
                        capture_output=True, timeout=600)
     assert r.returncode == 0 and b"FUZZ_OK" in r.stdout, r.stdout[-2000:].decode() + r.stderr[-2000:].decode()
+
+
+class Hip:
+    """the few HIP runtime calls the device-buffer test needs, through ctypes on the runtime libkaiju_gpu.so is linked
+    against (torch is not used: a second HIP runtime in the test process would not see the GPU)"""
+
+    def __init__(self):
+        self.L = C.CDLL("libamdhip64.so.7")
+
+    def ck(self, rc):
+        assert rc == 0, f"HIP error {rc}"
+
+    def malloc(self, n):
+        p = C.c_void_p()
+        self.ck(self.L.hipMalloc(C.byref(p), C.c_size_t(n)))
+        return p.value
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self.ck(self.L.hipMemcpy(C.c_void_p(dptr), C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), 1))
+
+    def d2h(self, dptr, nbytes):
+        out = np.zeros(nbytes, dtype=np.uint8)
+        self.ck(self.L.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(dptr), C.c_size_t(nbytes), 2))
+        return out
+
+    def memset(self, dptr, nbytes):
+        self.ck(self.L.hipMemset(C.c_void_p(dptr), 0, C.c_size_t(nbytes)))
+
+    def stream(self):
+        s = C.c_void_p()
+        self.ck(self.L.hipStreamCreateWithFlags(C.byref(s), 1))       # hipStreamNonBlocking
+        return s.value
+
+    def free(self, dptr):
+        self.L.hipFree(C.c_void_p(dptr))
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_device_resident_entry_points(gpu_lib, golden, gidx, mode):
+    """kaiju_gpu_classify_batch_device + kaiju_gpu_lca_batch_device on device buffers (what bench.py times): with the NULL
+    stream (= the context's own stream for BOTH calls: the LCA must queue behind the search) and with an explicit HIP
+    stream; records == the host-buffer entry points'.  Also kaiju_gpu_classify_batch_compact and the counting lanes."""
+    api = gpu_lib
+    hip = Hip()
+    tax = api.Taxonomy(golden.nodes)
+    dtax = api.DeviceTaxonomy(tax, 0)
+    clf = api.Classifier(gidx, api.default_params(mode, seg=1))
+    want_hits = clf.classify(golden.seqs, golden.off)
+    want = clf.lca(dtax, want_hits)
+    n = len(want_hits)
+    seqs = np.ascontiguousarray(golden.seqs, dtype=np.uint8)
+    off = np.ascontiguousarray(golden.off, dtype=np.uint64)
+    d_seqs, d_off = hip.malloc(seqs.nbytes + 64), hip.malloc(off.nbytes)
+    d_hits, d_rec = hip.malloc(n * 184), hip.malloc(n * 16)
+    hip.h2d(d_seqs, seqs)
+    hip.h2d(d_off, off)
+    clf.set_max_read_length(int((off[1:] - off[:-1]).max()))
+    assert clf.stream_handle() != 0
+    for stream in (0, hip.stream()):
+        for counting in (False, True):
+            hip.memset(d_hits, n * 184)
+            hip.memset(d_rec, n * 16)
+            clf.count_ops(counting)
+            clf.classify_device(d_seqs, seqs.nbytes, d_off, n, d_hits, stream=stream)
+            clf.lca_device(dtax, d_hits, n, d_rec, stream=stream)
+            clf.synchronize()
+            clf.count_ops(False)
+            hits = np.frombuffer(hip.d2h(d_hits, n * 184).tobytes(), dtype=api.HIT_DTYPE)
+            rec = np.frombuffer(hip.d2h(d_rec, n * 16).tobytes(), dtype=api.COMPACT_DTYPE)
+            assert all(util.same_hit(a, b) for a, b in zip(want_hits, hits)), (stream != 0, counting)
+            assert (rec == want).all(), (stream != 0, counting)
+            if counting:
+                oc = clf.op_counts()
+                assert oc["hits"] == n and oc["read_meta"] == n and oc["lane_iterations"] > oc["wave_iterations"] > 0
+                assert oc["update_si"] <= oc["update_si_lines"] <= 2 * (oc["update_si"] + oc["multi_letter_steps"])
+    got = clf.classify_compact(dtax, seqs, off)
+    assert (got == want).all()
+    for p in (d_seqs, d_off, d_hits, d_rec):
+        hip.free(p)
