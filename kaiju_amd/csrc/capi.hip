@@ -67,6 +67,115 @@ k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch 
   if (e) atomicOr(err, e);
 }
 
+// Stage 1, fast path (kj_core.h: build_fragments_fast): mates of up to kS1MaxLen nucleotides, one lane per read, frame
+// strings stored unit by unit from registers.  LDS: the tables, the fragment list of every lane (dword-interleaved over the
+// wavefront) and, TRIG, its letter-count rows.
+constexpr int kS1Block = 64;
+template <bool TRIG>
+__global__ void __launch_bounds__(kS1Block)
+k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQueue sq, uint32_t *err) {
+  __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
+  __shared__ uint32_t s_codes[2 * kS1ListCap * kS1Block];
+  __shared__ __attribute__((aligned(4))) uint8_t s_cnt[TRIG ? kS1Block * kS1CntStride : 4];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
+    for (uint32_t i = threadIdx.x; i < sizeof(Stage1Tables) / 16; i += kS1Block) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t r = blockIdx.x * kS1Block + threadIdx.x;
+  if (r >= b.n_reads) return;
+  uint32_t e = 0;
+  S1Lane ln;
+  ln.codes = s_codes + threadIdx.x; ln.code_stride = kS1Block;
+  ln.cnt = s_cnt + (TRIG ? threadIdx.x * kS1CntStride : 0);
+  build_fragments_fast<TRIG>(s_t, p, b, sq, r, &e, ln);
+  if (e) atomicOr(err, e);
+}
+
+// ---- lazy SEG (MEM, kParamLazySeg) ----------------------------------------------------------------------
+// The search lanes looked at the fragments unsplit and left, per read with a hit, the fragment(s) holding a longest match
+// in Hit::reserved.  A read whose such fragments contain no 12-window at the SEG trigger entropy has the reference's
+// result already: SEG would leave exactly those fragments alone, and the pieces of the others are substrings of their
+// parents, which did not match longer.  The other reads are listed here and take the SEG pass.
+__global__ void __launch_bounds__(256)
+k_trigcheck(SegTables st, Batch b, uint32_t *seglist, uint32_t *segcount) {
+  __shared__ int64_t s_entg[13];
+  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
+  __syncthreads();
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= b.n_reads) return;
+  const uint32_t v = b.hits[r].reserved;
+  if (v == 0) return;
+  b.hits[r].reserved = 0;
+  bool need = v == kWinForce;
+  if (!need) {
+    const SegCtx cx = seg_ctx(st, s_entg, nullptr);
+    const ReadMeta rm = b.meta[r];
+    const Frag *F = b.frags + rm.frag;
+    const uint8_t *pep = b.pep + rm.pep;
+    if (!(v & kWinMulti)) {
+      const Frag f = F[(v & ~kWinMulti) - 1u];
+      need = seg_triggers(cx, pep + f.start, (int)f.len);
+    } else {
+      // several fragments hold a longest match: every fragment long enough to be one of them is looked at
+      const uint32_t best = b.hits[r].best, nf = rm.nfrag & ~kNfragSegPending;
+      for (uint32_t k = 0; k < nf && !need; k++) {
+        const Frag f = F[k];
+        if (f.len >= best) need = seg_triggers(cx, pep + f.start, (int)f.len);
+      }
+    }
+  }
+  if (need) seglist[atomicAdd(segcount, 1u)] = r;
+}
+// the listed reads: SEG trigger test of all their fragments (what stage 1 does eagerly elsewhere), hit record cleared
+__global__ void __launch_bounds__(256)
+k_segflag(Params p, SegTables st, Batch b, SegQueue sq, const uint32_t *seglist, const uint32_t *segcount, uint32_t *err) {
+  __shared__ int64_t s_entg[13];
+  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
+  __syncthreads();
+  const SegCtx cx = seg_ctx(st, s_entg, nullptr);
+  const uint32_t n = *segcount;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t r = seglist[i];
+    const ReadMeta rm = b.meta[r];
+    Frag *F = b.frags + rm.frag;
+    const uint8_t *pep = b.pep + rm.pep;
+    const uint32_t nf = rm.nfrag & ~kNfragSegPending;
+    uint32_t pending = 0;
+    for (uint32_t k = 0; k < nf; k++) {
+      const Frag f = F[k];
+      uint32_t fl = kFragChecked;
+      if (seg_triggers(cx, pep + f.start, (int)f.len)) {
+        const uint32_t slot = atomicAdd(sq.count, 1u);
+        if (slot >= sq.cap) atomicOr(err, 2u);
+        else {
+          SegWork wk; wk.read = r; wk.frag = k;
+          sq.items[slot] = wk;
+          pending = kNfragSegPending;
+          fl = (slot + 1) << kFragSlotShift;
+        }
+      }
+      F[k].flags = fl;
+    }
+    b.meta[r].nfrag = nf | pending;
+    uint4 *h = reinterpret_cast<uint4 *>(b.hits + r);      // 184 bytes, 8-byte aligned
+    uint64_t *h8 = reinterpret_cast<uint64_t *>(b.hits + r);
+    (void)h;
+    for (int x = 0; x < (int)(sizeof(Hit) / 8); x++) h8[x] = 0;
+  }
+}
+__global__ void __launch_bounds__(kBlock)
+k_seg_apply_list(const ConstTables *__restrict__ g_ct, Params p, Batch b, SegQueue sq, const uint32_t *seglist,
+                 const uint32_t *segcount, uint32_t *err) {
+  __shared__ ConstTables s_ct;
+  load_tables(s_ct, g_ct);
+  const uint32_t n = *segcount;
+  uint32_t e = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) seg_apply_mem(s_ct, p, b, sq, seglist[i], &e);
+  if (e) atomicOr(err, e);
+}
+
 // Stage 1 for protein reads (kaiju -p, kaijup): one lane per read, peptides written in place
 __global__ void __launch_bounds__(kFragBlock)
 k_fragments_protein(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err) {
@@ -416,6 +525,7 @@ struct kaiju_gpu_index {
   DevIndex dev{};                 // device pointers
   ConstTables ct_host{};
   ConstTables *d_ct = nullptr;
+  const Stage1Tables *d_s1 = nullptr;
   SegTables st{};                 // lnfact points to device memory
   double *d_lnfact = nullptr;
   std::vector<void *> allocs;
@@ -487,6 +597,13 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   const double *dl = nullptr;
   if ((rc = upload(ix.get(), lnfact, &dl))) return rc;
   ix->st.lnfact = dl;
+  {
+    std::vector<Stage1Tables> s1(1);
+    build_stage1_tables(ix->ct_host, ix->st, s1[0]);
+    const Stage1Tables *d1 = nullptr;
+    if ((rc = upload(ix.get(), s1, &d1))) return rc;
+    ix->d_s1 = d1;
+  }
   std::vector<ConstTables> ctv(1, ix->ct_host);
   const ConstTables *dct = nullptr;
   if ((rc = upload(ix.get(), ctv, &dct))) return rc;
@@ -654,6 +771,9 @@ struct kaiju_gpu_ctx {
   bool exact_pass = true;          // KAIJU_GPU_EXACT_PASS=0 switches the exact pass off (its reads stay flagged)
   bool count_ops = false;          // kaiju_gpu_set_count_ops: the main pass runs the counting instantiation of its lane
   bool mem_v1 = false;             // KAIJU_GPU_MEM_LANE=v1 (read once, at context creation)
+  bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
+  bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
+  DevBuf seglist;
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
   DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
@@ -664,7 +784,7 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact,
+    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist,
                      &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry,
                      &redo_bitmap, &redo_list, &redo_items, &redo_index, &redo_pool, &redo_work, &redo_cls};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
@@ -720,6 +840,8 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   if (const char *e = getenv("KAIJU_GPU_EXACT_PASS")) c->exact_pass = atoi(e) != 0;
   if (const char *e = getenv("KAIJU_GPU_MEM_LANE")) c->mem_v1 = !strcmp(e, "v1");
   c->dump_frags = getenv("KAIJU_GPU_DUMP_FRAGS");
+  if (const char *e = getenv("KAIJU_GPU_STAGE1")) c->stage1_old = !strcmp(e, "old");
+  if (const char *e = getenv("KAIJU_GPU_LAZY_SEG")) c->lazy_seg = atoi(e) != 0;
   // kaijux: the MEM search of ConsumerThreadx.cpp:135 (maxMatches(.., 1)) finds the same longest matches as
   // greedyExact but lists them in another order, which shows where the id cap cuts and in the peptides of -v
   if (ix->id_mode == KAIJU_GPU_IDS_SEQUENCE && p->mode == 0) c->kp.flags |= kParamXOrder;
@@ -774,7 +896,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   }
   const uint64_t max_pair = (uint64_t)max_read_len * (paired ? 2 : 1);
   // stage buffers
-  const uint64_t pep_bytes = 2 * seq_bytes + 80ull * n + 32 + 256;   // pep_base() + window over-read slack
+  const uint64_t pep_bytes = 2 * seq_bytes + kPepPerRead * n + 32 + 256;   // pep_base() + window over-read slack
   const uint64_t n_frag_slots = 2 * ((2 * seq_bytes) / (p.m + 1) + 7ull * n) + 8;
   int rc;
   if ((rc = ensure(c->pep, pep_bytes))) return rc;
@@ -799,6 +921,14 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
+  // which stage 1 / SEG flow: the fast stage 1 serves mates up to kS1MaxLen nucleotides; in MEM mode on the second-generation
+  // lanes SEG is then looked at lazily (kj_core.h: kParamLazySeg), everywhere else stage 1 detects the SEG trigger itself
+  const bool mem_narrow2 = ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
+  const bool mem_wide2 = ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
+  const bool mem_v2 = p.mode == 0 && (mem_narrow2 || mem_wide2) && !c->mem_v1 && !c->verbose;
+  const bool fast1 = !protein && !c->stage1_old && max_read_len <= kS1MaxLen && p.m >= 1 && p.m <= 64;
+  const bool lazy = fast1 && mem_v2 && p.seg && c->lazy_seg;
+  const bool trig1 = fast1 && p.seg && !lazy;
   if (n > 0) {
     // LDS staging area per lane: all frame strings of a read (or pair), rounded to 16 bytes
     uint32_t per_lane = (uint32_t)((2 * max_pair + 12 + 15) & ~15ull);
@@ -806,13 +936,17 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     if (protein)
       hipLaunchKernelGGL(k_fragments_protein, dim3((n + kFragBlock - 1) / kFragBlock), dim3(kFragBlock), 0, s,
                          ix->d_ct, p, ix->st, b, sq, cnt + 3);
+    else if (fast1 && trig1)
+      hipLaunchKernelGGL(k_fragments_fast<true>, dim3((n + kS1Block - 1) / kS1Block), dim3(kS1Block), 0, s, ix->d_s1, p, b, sq, cnt + 3);
+    else if (fast1)
+      hipLaunchKernelGGL(k_fragments_fast<false>, dim3((n + kS1Block - 1) / kS1Block), dim3(kS1Block), 0, s, ix->d_s1, p, b, sq, cnt + 3);
     else
       hipLaunchKernelGGL(k_fragments, dim3((n + kFragBlock - 1) / kFragBlock), dim3(kFragBlock),
                          (size_t)per_lane * kFragBlock, s, ix->d_ct, p, ix->st, b, sq, cnt + 3, per_lane);
     KJ_HIP(hipGetLastError());
   }
   KJ_HIP(hipEventRecord(c->ev[1], s));
-  if (n > 0 && p.seg) {
+  if (n > 0 && p.seg && !lazy) {
     hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 32), dim3(kSegBlock), 0, s, p, ix->st, b, sq);
     KJ_HIP(hipGetLastError());
     if (p.mode == 0) {
@@ -879,31 +1013,45 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     while (blocks_retry > 1 && (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry) > (1ull << 30)) blocks_retry /= 2;
     if ((rc = ensure(c->scratch_retry[0], (uint64_t)blocks_retry * kBlock * si_cap_retry * sizeof(SIEntry)))) return rc;
     if (n > 0) {
-      const bool v1 = c->mem_v1;
       const bool xo = (p.flags & kParamXOrder) != 0;
-      if (ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 && !c->verbose)
-        if (c->count_ops) hipLaunchKernelGGL(k_mem_count, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                                             static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
-        else if (xo) hipLaunchKernelGGL(k_mem_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                                   static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
-        else hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                                static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
-      else if (ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m && !v1 &&
-               !c->verbose)
-        if (c->count_ops) hipLaunchKernelGGL(k_mem_wide2_count, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                                             static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
-        else if (xo) hipLaunchKernelGGL(k_mem_wide2_x, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                                   static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
-        else hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                                static_cast<SIEntry *>(c->scratch_main[0].p), si_cap);
-      else if (ix->dev.sb32)
-        hipLaunchKernelGGL(k_mem_v1, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap, vb);
+      SIEntry *si_main = static_cast<SIEntry *>(c->scratch_main[0].p);
+      // the second-generation lane that serves this index (narrow: below 2^32 rows; wide: 64-bit positions)
+      auto launch_v2 = [&](const Params &pp, const WorkList &wl, bool counting) {
+        if (mem_narrow2) {
+          if (counting) hipLaunchKernelGGL(k_mem_count, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+          else if (xo) hipLaunchKernelGGL(k_mem_x, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+          else hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+        } else {
+          if (counting) hipLaunchKernelGGL(k_mem_wide2_count, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+          else if (xo) hipLaunchKernelGGL(k_mem_wide2_x, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+          else hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+        }
+      };
+      if (mem_v2) {
+        Params pm = p;
+        if (lazy) pm.flags |= kParamLazySeg;
+        launch_v2(pm, wl_main, c->count_ops);
+      } else if (ix->dev.sb32)
+        hipLaunchKernelGGL(k_mem_v1, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main, si_main, si_cap, vb);
       else
-        hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main,
-                           static_cast<SIEntry *>(c->scratch_main[0].p), si_cap, vb);
+        hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main, si_main, si_cap, vb);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
+      if (lazy) {
+        // reads whose longest matches lie in fragments that SEG would cut: listed, SEG pass for their fragments, the
+        // lists rewritten, searched again (counters: [22] listed reads, [23] work counter of that search)
+        if ((rc = ensure(c->seglist, (size_t)n * 4 + 16))) return rc;
+        uint32_t *seglist = static_cast<uint32_t *>(c->seglist.p);
+        hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->st, b, seglist, cnt + 22);
+        hipLaunchKernelGGL(k_segflag, dim3(c->n_cu * 4), dim3(256), 0, s, p, ix->st, b, sq, seglist, cnt + 22, cnt + 3);
+        hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 32), dim3(kSegBlock), 0, s, p, ix->st, b, sq);
+        hipLaunchKernelGGL(k_seg_apply_list, dim3(c->n_cu * 4), blk, 0, s, ix->d_ct, p, b, sq, seglist, cnt + 22, cnt + 3);
+        WorkList wl_seg;
+        wl_seg.counter = cnt + 23; wl_seg.reads = seglist; wl_seg.n_items_ptr = cnt + 22; wl_seg.n_items = 0;
+        wl_seg.retry_list = wl_main.retry_list; wl_seg.retry_count = wl_main.retry_count;
+        launch_v2(p, wl_seg, false);
+        KJ_HIP(hipGetLastError());
+      }
       hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());

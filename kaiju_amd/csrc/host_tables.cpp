@@ -146,4 +146,21 @@ int build_seg_tables(std::vector<double> &lnfact_host, SegTables &st, std::strin
   return 0;
 }
 
+void build_stage1_tables(const ConstTables &ct, const SegTables &st, Stage1Tables &t) {
+  memset(&t, 0, sizeof t);
+  for (int c = 0; c < 256; c++) t.nuc3[c] = ct.nuc[c] <= 3 ? ct.nuc[c] : 4;
+  for (int idx = 0; idx < 512; idx++) {
+    const int n0 = idx >> 6, n1 = (idx >> 3) & 7, n2 = idx & 7;     // n0: the first nucleotide of the codon
+    if (n0 > 3 || n1 > 3 || n2 > 3) continue;                       // codon_to_int: a base that is not ACGTU -> stop
+    t.tf[idx] = ct.codon_idx[n0 * 16 + n1 * 4 + n2];
+    t.tr[idx] = ct.codon_idx[(63 - (n2 * 16 + n1 * 4 + n0)) & 63];  // revcomp_codon_to_int, ConsumerThread.cpp:873-875
+  }
+  // a window with a stop in it must never reach the trigger entropy: every stop adds more than the threshold
+  const int32_t big = st.ent_locut32 + 1;
+  for (int c = 0; c < 12; c++) t.dtab[c] = st.ent_g32[c + 1] - st.ent_g32[c];
+  for (int c = 13; c < 26; c++) t.dtab[c] = big;
+  for (int c = 0; c < 32; c++) t.diag[c] = c >= 1 && c <= 20 ? (uint8_t)ct.diag_idx[c] : 0;
+  t.locut32 = st.ent_locut32;
+}
+
 }  // namespace kj

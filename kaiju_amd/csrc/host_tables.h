@@ -17,4 +17,7 @@ int build_const_tables(const uint8_t trans[128], ConstTables &t, std::string &ms
 // of the window.  lnfact_host receives the table the device copy is made from.
 int build_seg_tables(std::vector<double> &lnfact_host, SegTables &st, std::string &msg);
 
+// tables of the fast stage 1 (kj_core.h: Stage1Tables) from the two above
+void build_stage1_tables(const ConstTables &ct, const SegTables &st, Stage1Tables &t);
+
 }  // namespace kj

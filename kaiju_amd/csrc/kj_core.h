@@ -107,6 +107,11 @@ struct Params {
 // Params::flags
 constexpr uint32_t kParamXOrder = 1u;    // kaijux: MEM matches of a fragment are visited in maxMatches' list order (see mem_lane)
 constexpr uint32_t kParamProtein = 2u;   // reads are protein sequences (kaiju -p, kaijup): stage 1 = k_fragments_protein
+constexpr uint32_t kParamLazySeg = 4u;   // MEM: fragments are searched unsplit first; the lanes report the fragments that hold
+                                         // a longest match in Hit::reserved (kWin*) for the check pass
+// Hit::reserved between the search and the check pass of the lazy SEG flow
+constexpr uint32_t kWinMulti = 0x80000000u;   // more than one fragment holds a longest match
+constexpr uint32_t kWinForce = 0xffffffffu;   // the read has to take the SEG pass whatever its fragments look like
 
 // fragment descriptor (16 bytes)
 struct Frag {
@@ -188,8 +193,10 @@ struct Batch {
 };
 
 // layout helpers (closed form, no prefix sums needed) -------------------------
-// peptide area of read r: <= 2*(len1+len2) + 12 bytes of strings after 8 bytes of front padding
-KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return ((2 * off[2 * (uint64_t)r] + 15) & ~15ull) + 80ull * r + 16; }
+// peptide area of read r: <= 2*(len1+len2) + 12 bytes of strings after 8 bytes of front padding (build_fragments), or six
+// strings of whole 16-byte units per mate, <= 2*(len1+len2) + 192 bytes (build_fragments_fast)
+constexpr uint64_t kPepPerRead = 208;
+KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return ((2 * off[2 * (uint64_t)r] + 15) & ~15ull) + kPepPerRead * r + 16; }
 // fragment slots of read r: a read has at most (2*(len1+len2)+12)/(m+1) disjoint fragments;
 // twice that is reserved so that SEG pieces can sit next to their parents
 KJ_HD uint64_t frag_base(const uint64_t *off, uint32_t r, uint32_t m) {
@@ -206,10 +213,20 @@ KJ_HD uint32_t popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 KJ_HD uint64_t kj_ballot(bool p) { return __ballot(p); }
 KJ_HD uint32_t kj_lane() { return threadIdx.x & 63u; }
 KJ_HD uint32_t kj_bcast(uint32_t v, uint32_t src_lane) { return (uint32_t)__shfl((int)v, (int)src_lane, 64); }
+// number of lanes below this one whose bit is set in mask (v_mbcnt: no lane id, no lane mask to keep in registers)
+KJ_HD uint32_t kj_rank_below(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// value of lane src_lane, src_lane the same in all lanes (v_readlane)
+KJ_HD uint32_t kj_bcast_uniform(uint32_t v, uint32_t src_lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)src_lane));
+}
 #else
 KJ_HD uint64_t kj_ballot(bool p) { return p ? 1ull : 0ull; }
 KJ_HD uint32_t kj_lane() { return 0; }
 KJ_HD uint32_t kj_bcast(uint32_t v, uint32_t) { return v; }
+KJ_HD uint32_t kj_rank_below(uint64_t) { return 0; }
+KJ_HD uint32_t kj_bcast_uniform(uint32_t v, uint32_t) { return v; }
 #endif
 
 // ----------------------------------------------------------------------------
@@ -1073,6 +1090,282 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
 }
 
 // ----------------------------------------------------------------------------
+// stage 1, fast path (mates of up to kS1MaxLen nucleotides; build_fragments above stays the general path).
+//
+// Same results as build_fragments - six frame strings per mate (getAllFragmentsBits, ConsumerThread.cpp:190-270), the
+// fragment list in the order of the reference's multimap, optionally the SEG trigger flags - produced with a small
+// fraction of its instructions (profiles/r02_recon: the old kernel issued 430 VALU + 200 SALU wave instructions per read
+// at 1.6 waves per SIMD):
+//   * no per-residue control flow at all: a nucleotide becomes a 3-bit code (one LDS lookup), three codes index two
+//     512-byte tables (codon -> residue of the forward / reverse strand, 0 for stops and for codons with a base that is
+//     not ACGTU, codon_to_int :869-875), the residues are packed four to a register;
+//   * a frame string is a row of 16-residue UNITS and every unit is stored once, as one aligned 16-byte store straight
+//     from registers (no LDS staging, so nothing limits the occupancy but registers): forward strings start at a unit
+//     boundary, reverse strings - produced from their end, :235-268 walk the strand downwards - END at one;
+//   * stops are not acted upon inside the loop; the runs between them are taken from a bit mask per frame afterwards
+//     (bit tricks), with the emission moments of the reference in closed form, and ranked in a small LDS list;
+//   * TRIG (Greedy; MEM looks at SEG lazily, see mem_lane2): the entropy of the 12-window ending at every residue is kept
+//     incrementally with the letter counts of the window in a per-lane LDS row (two byte updates and two table lookups
+//     per residue); a stop inside the window adds a constant that no entropy reaches, so no state is ever reset.
+// ----------------------------------------------------------------------------
+struct Stage1Tables {        // built on the host (host_tables.cpp: build_stage1_tables); the kernel keeps a copy in LDS
+  uint8_t nuc3[256];         // nucleotide -> 0..3 (nuc2int, ConsumerThread.cpp:6-9), 4 = not ACGTU
+  uint8_t tf[512];           // three codes, the first nucleotide in bits 6..8 -> index-alphabet code of the codon, 0 = stop / invalid
+  uint8_t tr[512];           // ... of the reverse-complemented codon (revcomp_codon_to_int)
+  int32_t dtab[32];          // [c], c = 0..11: change of the (2^26-scaled) 12-window entropy when a letter present c times
+                             // joins (leaves with c left); [13..25]: the same for the stop "letter": kS1Big
+  uint8_t diag[32];          // BLOSUM62 diagonal by index-alphabet code (0 for the stop)
+  int32_t locut32;           // SegTables::ent_locut32
+  int32_t pad[3];
+};
+static_assert(sizeof(Stage1Tables) % 16 == 0, "Stage1Tables is copied in 16-byte pieces");
+constexpr int kS1Units = 4;                          // 16-residue units per frame string
+constexpr uint32_t kS1MaxLen = 48 * kS1Units - 1;    // len / 3 + 1 <= 16 * kS1Units
+constexpr int kS1ListCap = 24;                       // fragments ranked in LDS (two words each); a longer list is sorted in place
+constexpr int kS1CntRow = 24;                        // bytes of one letter-count row (21 used)
+constexpr int kS1CntStride = 6 * kS1CntRow + 4;      // per lane: six rows; 37 dwords apart (odd: lanes spread over the banks)
+constexpr uint32_t kS1StopCnt = 13 * 4;              // the stop's count is kept 13 higher: its dtab entries are kS1Big
+constexpr uint32_t kErrReadTooLong = 16u;            // error flag: a mate longer than kaiju_gpu_set_max_read_length() allowed
+
+struct S1Lane {              // per-lane LDS of the fast stage 1
+  uint32_t *codes;           // [2 * kS1ListCap] words of the fragment list, `code_stride` dwords apart
+  uint32_t code_stride;
+  uint8_t *cnt;              // TRIG: kS1CntStride bytes
+};
+
+// One mate: strings to dst (16-byte aligned, six strings of u = len / 48 + 1 units), masks of the residues that are no stops (ns) and
+// of the 12-windows at or below the SEG trigger entropy (tg, TRIG only), bit = processing index (the codon number along
+// the read for both strands: string index for a forward frame, distance from the string end for a reverse one).
+template <bool TRIG>
+KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_t *dst, uint64_t *ns, uint64_t *tg,
+                   uint8_t *cnt) {
+  const uint32_t top = len - 3, u = len / 48u + 1u;
+  for (int f = 0; f < 6; f++) { ns[f] = 0; tg[f] = 0; }
+  int32_t S[6] = {0, 0, 0, 0, 0, 0};
+  if (TRIG) {
+    // the window starts out as twelve stops in front of the string
+    uint32_t *c32 = reinterpret_cast<uint32_t *>(cnt);
+#pragma unroll
+    for (int f = 0; f < 6; f++) {
+#pragma unroll
+      for (int q = 0; q < kS1CntRow / 4; q++) c32[f * (kS1CntRow / 4) + q] = q == 0 ? (kS1StopCnt + 12u * 4u) : 0u;
+      S[f] = 12 * t.dtab[13];
+    }
+  }
+  NucReader nr;
+  nr.s = s; nr.len = len;
+  u128 c0 = nr.chunk(0), c1 = nr.chunk(1), c2 = nr.chunk(2), c3 = nr.chunk(3);
+  uint32_t idx = (uint32_t)t.nuc3[c0.x & 255u] << 3 | t.nuc3[(c0.x >> 8) & 255u];
+  uint32_t pf[3][4], pr[3][4];                 // the previous block's units (TRIG: the residue that leaves the window)
+#pragma unroll
+  for (int g = 0; g < 3; g++)
+#pragma unroll
+    for (int d = 0; d < 4; d++) pf[g][d] = pr[g][d] = 0;
+  for (uint32_t b = 0; b < u && 48u * b <= top; b++) {
+    const uint32_t w[13] = {(uint32_t)c0.x, (uint32_t)(c0.x >> 32), (uint32_t)c0.y, (uint32_t)(c0.y >> 32),
+                            (uint32_t)c1.x, (uint32_t)(c1.x >> 32), (uint32_t)c1.y, (uint32_t)(c1.y >> 32),
+                            (uint32_t)c2.x, (uint32_t)(c2.x >> 32), (uint32_t)c2.y, (uint32_t)(c2.y >> 32), (uint32_t)c3.x};
+    // the next block's nucleotides are requested before this block's arithmetic
+    const u128 n1 = nr.chunk(3 * b + 4), n2 = nr.chunk(3 * b + 5), n3 = nr.chunk(3 * b + 6);
+    uint32_t fu[3][4], ru[3][4], mf[3] = {0, 0, 0}, mr[3] = {0, 0, 0}, tf_[3] = {0, 0, 0}, tr_[3] = {0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 3; g++)
+#pragma unroll
+      for (int d = 0; d < 4; d++) fu[g][d] = ru[g][d] = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+#pragma unroll
+      for (int g = 0; g < 3; g++) {
+        const int q = 3 * j + g + 2;                         // byte of the block that completes this codon
+        const uint32_t byte = (w[q >> 2] >> (8 * (q & 3))) & 255u;
+        idx = ((idx << 3) | t.nuc3[byte]) & 511u;
+        const uint32_t af = t.tf[idx], ar = t.tr[idx];
+        fu[g][j >> 2] |= af << (8 * (j & 3));
+        ru[g][3 - (j >> 2)] |= ar << (8 * (3 - (j & 3)));
+        mf[g] |= (af != 0u ? 1u : 0u) << j;
+        mr[g] |= (ar != 0u ? 1u : 0u) << j;
+        if (TRIG) {
+          // the residue twelve back in the same string: four units of four residues, j - 12 or the previous block's j + 4
+          const uint32_t yf = j >= 12 ? (fu[g][(j - 12) >> 2] >> (8 * ((j - 12) & 3))) & 255u
+                                      : (pf[g][(j + 4) >> 2] >> (8 * ((j + 4) & 3))) & 255u;
+          const uint32_t yr = j >= 12 ? (ru[g][3 - ((j - 12) >> 2)] >> (8 * (3 - ((j - 12) & 3)))) & 255u
+                                      : (pr[g][3 - ((j + 4) >> 2)] >> (8 * (3 - ((j + 4) & 3)))) & 255u;
+          const uint8_t *db = reinterpret_cast<const uint8_t *>(t.dtab);
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            uint8_t *row = cnt + (h * 3 + g) * kS1CntRow;
+            const uint32_t x = h ? ar : af, y = h ? yr : yf;
+            int32_t sc = S[h * 3 + g];
+            const uint32_t cx = row[x];
+            row[x] = (uint8_t)(cx + 4u);
+            sc += *reinterpret_cast<const int32_t *>(db + cx);
+            const uint32_t cy = row[y] - 4u;
+            row[y] = (uint8_t)cy;
+            sc -= *reinterpret_cast<const int32_t *>(db + cy);
+            S[h * 3 + g] = sc;
+            if (h) tr_[g] |= (sc <= t.locut32 ? 1u : 0u) << j; else tf_[g] |= (sc <= t.locut32 ? 1u : 0u) << j;
+          }
+        }
+      }
+    }
+    // whole units, one aligned 16-byte store each
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      u128 v;
+      v.x = fu[g][0] | (uint64_t)fu[g][1] << 32; v.y = fu[g][2] | (uint64_t)fu[g][3] << 32;
+      *reinterpret_cast<u128 *>(dst + (size_t)g * (16 * u) + 16 * b) = v;
+      v.x = ru[g][0] | (uint64_t)ru[g][1] << 32; v.y = ru[g][2] | (uint64_t)ru[g][3] << 32;
+      *reinterpret_cast<u128 *>(dst + (size_t)(4 + g) * (16 * u) - 16 * (b + 1)) = v;
+      ns[g] |= (uint64_t)mf[g] << (16 * b);
+      ns[3 + g] |= (uint64_t)mr[g] << (16 * b);
+      if (TRIG) {
+        tg[g] |= (uint64_t)tf_[g] << (16 * b);
+        tg[3 + g] |= (uint64_t)tr_[g] << (16 * b);
+#pragma unroll
+        for (int d = 0; d < 4; d++) { pf[g][d] = fu[g][d]; pr[g][d] = ru[g][d]; }
+      }
+    }
+    c0 = c3; c1 = n1; c2 = n2; c3 = n3;
+  }
+}
+
+// where fragment [a, a + l) (processing indices) of string f of a mate lies in the mate's area
+KJ_HD uint32_t s1_start(int f, uint32_t u, uint32_t a, uint32_t l) {
+  return f < 3 ? (uint32_t)f * (16 * u) + a : (uint32_t)(f + 1) * (16 * u) - a - l;
+}
+
+// Fragment list of read r from the masks of its mates.  `emit` receives (start in the read's area, length, emission
+// moment, trigger flag) of every run of at least m residues, in no particular order.
+template <class Emit>
+KJ_HD void s1_runs(const uint64_t *ns, const uint64_t *tg, uint32_t len, uint32_t m, uint32_t area, uint32_t seq_base,
+                   Emit &&emit) {
+  if (m > 64u || m == 0u) return;
+  const uint32_t top = len - 3, u = len / 48u + 1u;
+  // emission moments (ConsumerThread.cpp:196-268): a forward run is emitted when the scan meets the stop behind it
+  // (position = moment), the runs that reach the end of their string after the scan (len + frame); then the reverse
+  // strand, scanned downwards: stop at position p -> len + 3 + (top - p), leftovers 2 * len + 3 + frame
+  const uint32_t seqF = seq_base, seqR = seq_base + len + 3;
+  for (int f = 0; f < 6; f++) {
+    const int g = f < 3 ? f : f - 3;
+    const uint64_t M = ns[f];
+    // E: positions where a run of m residues starts
+    uint64_t E = M;
+    uint32_t w = 1;
+    while (2 * w <= m) { E &= E >> w; w *= 2; }
+    if (w < m) E &= E >> (m - w);
+    while (E) {
+      const uint64_t low = E & (~E + 1ull);
+      const uint32_t a = (uint32_t)__builtin_ctzll(E);
+      const uint64_t E2 = E & (E + low);                     // the lowest run of E cleared
+      const uint32_t l = popc64(E ^ E2) + m - 1;
+      E = E2;
+      uint32_t seq;
+      if (f < 3) {
+        const uint32_t p = 3 * (a + l) + (uint32_t)g;        // position of the stop behind the run
+        seq = p <= top ? seqF + p : seqF + len + (uint32_t)g;
+      } else {
+        seq = a == 0 ? seqR + len + (uint32_t)g : seqR + (top - (3 * (a - 1) + (uint32_t)g));
+      }
+      const bool trig = l >= 12u && ((tg[f] >> (a + 11u)) & ((l - 11u >= 64u) ? ~0ull : ((1ull << (l - 11u)) - 1ull))) != 0;
+      emit(area + s1_start(f, u, a, l), l, seq, trig);
+    }
+  }
+}
+
+// stage 1 for read r, fast path.  TRIG: fragments whose 12-windows reach the SEG trigger entropy are queued for the SEG
+// pass (as build_fragments does); otherwise the fragment flags are 0 and SEG is looked at lazily (kParamLazySeg) or not
+// at all (-X).
+template <bool TRIG>
+KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Batch &b, const SegQueue &sq, uint32_t r,
+                                uint32_t *err_flags, const S1Lane &ln) {
+  const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
+  uint32_t len1 = (uint32_t)(o1 - o0), len2 = (uint32_t)(o2 - o1);
+  const uint32_t m3 = p.m * 3;
+  const uint32_t fbase = (uint32_t)frag_base(b.off, r, p.m);
+  Frag *list = b.frags + fbase;
+  const uint32_t cap = frag_cap(b.off, r, p.m);
+  const uint64_t pbase = pep_base(b.off, r);
+  uint32_t n = 0, pending = 0;
+  if (len1 > kS1MaxLen || len2 > kS1MaxLen) {                // the caller promised shorter reads (kaiju_gpu_set_max_read_length)
+    if (err_flags) *err_flags |= kErrReadTooLong;
+    len1 = len2 = 0;
+  }
+  // length gate, ConsumerThread.cpp:647-654
+  const bool skip = b.paired ? (len1 < m3 && len2 < m3) : (len1 < m3);
+  if (!skip) {
+    uint8_t *area = b.pep + pbase;
+    const uint32_t mate_bytes = len1 >= m3 ? 96u * (len1 / 48u + 1u) : 0u;      // where the second mate's strings start
+    // the list as it is found: two words per fragment in LDS - hi sorts by key descending, then emission moment ascending -
+    // and, should a read have more than kS1ListCap fragments, the rest in their list slots in device memory
+    auto emit = [&](uint32_t start, uint32_t l, uint32_t seq, bool trig) {
+      uint32_t key = l;
+      if (p.mode == 1) {
+        key = 0;
+        for (uint32_t x = 0; x < l; x++) key += t.diag[area[start + x]];
+        if (key < p.min_score) return;
+      }
+      if (n >= cap) return;                                   // cannot happen: cap is a proven bound
+      if (n < (uint32_t)kS1ListCap) {
+        ln.codes[(size_t)(2 * n) * ln.code_stride] = key << 11 | (2047u - seq);
+        ln.codes[(size_t)(2 * n + 1) * ln.code_stride] = start << 8 | l << 1 | (trig ? 1u : 0u);
+      } else {
+        Frag f; f.start = start; f.len = l; f.key = key; f.flags = seq << 1 | (trig ? 1u : 0u);
+        list[n] = f;
+      }
+      n++;
+    };
+    uint64_t ns[6], tg[6];
+    if (len1 >= m3) {
+      s1_mate<TRIG>(t, b.seqs + o0, len1, area, ns, tg, ln.cnt);
+      s1_runs(ns, tg, len1, p.m, 0, 0, emit);
+    }
+    if (b.paired && len2 >= m3) {
+      s1_mate<TRIG>(t, b.seqs + o1, len2, area + mate_bytes, ns, tg, ln.cnt);
+      s1_runs(ns, tg, len2, p.m, mate_bytes, 2 * len1 + 6, emit);
+    }
+    // (emission moments stay below 2 * (len1 + len2) + 12 <= 780, keys below 11 * 64, starts below 768, lengths <= 64)
+    auto final_flags = [&](uint32_t trig, uint32_t k) -> uint32_t {
+      if (!TRIG || !p.seg) return 0u;
+      if (!trig) return kFragChecked;                        // SEG would report nothing for this fragment
+      const uint32_t slot = append_slot(sq.count);
+      if (slot >= sq.cap) { if (err_flags) *err_flags |= 2u; return kFragChecked; }
+      SegWork wk; wk.read = r; wk.frag = k;
+      sq.items[slot] = wk;
+      pending = kNfragSegPending;
+      return (slot + 1) << kFragSlotShift;
+    };
+    // queue order: std::multimap<unsigned, Fragment*, std::greater>::emplace puts a fragment behind every key >= its
+    // own: by descending key, equal keys in the order of emission
+    if (n <= (uint32_t)kS1ListCap) {
+      for (uint32_t k = 0; k < n; k++) {                     // rank by counting
+        const uint32_t hi = ln.codes[(size_t)(2 * k) * ln.code_stride], lo = ln.codes[(size_t)(2 * k + 1) * ln.code_stride];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < n; q++) rank += ln.codes[(size_t)(2 * q) * ln.code_stride] > hi ? 1u : 0u;
+        Frag f; f.start = lo >> 8; f.len = (lo >> 1) & 127u; f.key = hi >> 11; f.flags = final_flags(lo & 1u, rank);
+        list[rank] = f;
+      }
+    } else {
+      for (uint32_t k = 0; k < (uint32_t)kS1ListCap; k++) {
+        const uint32_t hi = ln.codes[(size_t)(2 * k) * ln.code_stride], lo = ln.codes[(size_t)(2 * k + 1) * ln.code_stride];
+        Frag f; f.start = lo >> 8; f.len = (lo >> 1) & 127u; f.key = hi >> 11; f.flags = (2047u - (hi & 2047u)) << 1 | (lo & 1u);
+        list[k] = f;
+      }
+      for (uint32_t k = 1; k < n; k++) {                    // insertion sort in place
+        const Frag f = list[k];
+        uint32_t pos = k;
+        while (pos > 0 && (list[pos - 1].key < f.key || (list[pos - 1].key == f.key && list[pos - 1].flags > f.flags))) {
+          list[pos] = list[pos - 1]; pos--;
+        }
+        list[pos] = f;
+      }
+      for (uint32_t k = 0; k < n; k++) list[k].flags = final_flags(list[k].flags & 1u, k);
+    }
+  }
+  ReadMeta rm; rm.pep = pbase; rm.frag = fbase; rm.nfrag = n | pending;
+  b.meta[r] = rm;
+}
+
+// ----------------------------------------------------------------------------
 // stage 1 for protein input (kaiju -p: ConsumerThread.cpp:640-646,659-696; kaijup: ConsumerThreadp.cpp:17-63):
 // the read is upper-cased and split at every character that is not one of the 20 amino acids; runs of at
 // least m residues (Greedy: scoring at least min_score) become the fragments, in left-to-right order behind
@@ -1605,7 +1898,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   int flen = 0, j = 0, i = 0;
   P lo = 0, hi = 0;
   uint32_t c = 1, L = p.m, nsi = 0, kidx = 0;
-  bool found = false, ovf = false;
+  bool found = false, ovf = false, multi = false;
   int fill_top = 0;
   bool fill_newfrag = false, fill_step = false;
   // first two maximal matches live in registers, further ones in the lane's scratch
@@ -1636,7 +1929,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       const uint64_t mask = kj_ballot(need);
       if (mask) {
         const uint32_t n = popc64(mask);
-        const uint32_t rank = popc64(mask & ((1ull << kj_lane()) - 1ull));
+        const uint32_t rank = kj_rank_below(mask);
         const uint32_t avail = wend - wnext;
         uint32_t newbase = 0, ch = 0;
         if (n > avail) {
@@ -1648,8 +1941,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           if (ch < n - avail) ch = n - avail;
           const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
           uint32_t got = 0;
-          if (kj_lane() == leader) got = kj_fetch_chunk(wl.counter, ch);
-          newbase = kj_bcast(got, leader);
+          if (need && rank == 0) got = kj_fetch_chunk(wl.counter, ch);   // the lowest lane that needs work
+          newbase = kj_bcast_uniform(got, leader);
         }
         if (need) {
           const uint32_t item = rank < avail ? wnext + rank : newbase + (rank - avail);
@@ -1784,6 +2077,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       fbase = (uint32_t)gv.y;
       nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
       f = 0; L = p.m; nsi = 0; found = false; ovf = false;
+      multi = false;
       hit = b.hits + r;
       if (nf == 0) bk = BK_LOC_INIT; else kind = K_FRAG;
     } else if (kind == K_FRAG) {
@@ -1812,8 +2106,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (bk == BK_END_MATCH) {
         const uint32_t l = (uint32_t)(j - i + 1);
         if (l >= L) {
-          if (l > L) { nsi = 0; ovf = false; L = l; }      // shorter matches are dropped (bwt.c:366-370, :577-582)
+          if (l > L) { nsi = 0; ovf = false; L = l; multi = false; }   // shorter matches are dropped (bwt.c:366-370, :577-582)
           const uint32_t ilen = (uint32_t)(int32_t)(hi - lo);
+          if (nsi != 0 && fcur != s0frag) multi = true;      // (lazy SEG: longest matches in more than one fragment)
           if (nsi == 0) { s0lo = lo; s0len = ilen; s0frag = fcur; }
           else if (nsi == 1) { s1lo = lo; s1len = ilen; s1frag = fcur; }
           else if (nsi < ls.si_cap) { SIEntry e; e.lo = lo; e.len = ilen; e.frag = fcur; ls.si[nsi] = e; if constexpr (COUNT) oc[kOpcSiSpill]++; }
@@ -1858,10 +2153,14 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (bk == BK_LOC_INIT) {
         nids = 0; flags = 0;
         hit->best = found ? L : 0u;
-        hit->reserved = 0;
+        // lazy SEG (kParamLazySeg, wave-uniform): the fragment that holds the longest matches, or the note that there
+        // are several
+        hit->reserved = ((p.flags & kParamLazySeg) && found) ? (ovf ? kWinForce : ((s0frag + 1u) | (multi ? kWinMulti : 0u))) : 0u;
         if (!found) bk = BK_FINISH;
         else if (ovf) {
-          if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+          // (lazy SEG: the read takes the SEG pass first; the search behind it sends it to the retry pass)
+          if (p.flags & kParamLazySeg) flags = kHitRetry;
+          else if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
           else flags = kHitInternalOverflow;
           bk = BK_FINISH;
         } else { gs = ge = 0; cur = XORDER ? 1u : 0u; bk = BK_LOC_NEXT_SI; }
@@ -2723,7 +3022,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         const uint64_t mask = kj_ballot(need);
         if (mask) {
           const uint32_t n = popc64(mask);
-          const uint32_t rank = popc64(mask & ((1ull << kj_lane()) - 1ull));
+          const uint32_t rank = kj_rank_below(mask);
           const uint32_t avail = wend - wnext;
           uint32_t newbase = 0, ch = 0;
           if (n > avail) {

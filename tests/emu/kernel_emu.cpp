@@ -121,14 +121,33 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   // peptides are staged (here: linear scratch) and copied out, as the kernel does with its LDS area
   std::vector<uint8_t> stage((size_t)4 * maxlen + 256);
   const bool staged = !getenv("KAIJU_EMU_NOSTAGE");
+  // which flow (capi.hip: launch_batch): the fast stage 1 for mates up to kS1MaxLen nucleotides; MEM on the second-generation
+  // lanes then looks at SEG lazily
+  const char *lane_env = getenv("KAIJU_EMU_LANE");
+  const bool mem_v2 = p.mode == 0 && d.blocks64 && (d.kmer32 || (d.mb_base && d.kmer64)) && !lane_env && !g_vb.n_acc;
+  const bool fast1 = !(p.flags & kParamProtein) && !getenv("KAIJU_EMU_STAGE1_OLD") && maxlen <= kS1MaxLen && p.m >= 1 && p.m <= 64;
+  const bool lazy = fast1 && mem_v2 && p.seg && !getenv("KAIJU_EMU_LAZY_OFF");
+  const bool trig1 = fast1 && p.seg && !lazy;
   if (p.flags & kParamProtein) {
     uint8_t code[256];
     memset(code, 0, sizeof code);
     for (uint32_t a = 0; a < 20; a++) protein_code_entry(ix->ct, a, code);
     for (uint32_t r = 0; r < n; r++) build_fragments_protein(ix->ct, code, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq, r, &err);
+  } else if (fast1) {
+    Stage1Tables s1;
+    build_stage1_tables(ix->ct, ix->st, s1);
+    uint32_t codes[2 * kS1ListCap];
+    alignas(4) uint8_t cnt[kS1CntStride];
+    S1Lane ln{codes, 1, cnt};
+    for (uint32_t r = 0; r < n; r++) {
+      for (auto &x : codes) x = 0xdeadbeefu;
+      memset(cnt, 0xee, sizeof cnt);
+      if (trig1) build_fragments_fast<true>(s1, p, b, sq, r, &err, ln);
+      else build_fragments_fast<false>(s1, p, b, sq, r, &err, ln);
+    }
   } else
   for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq, r, &err, staged ? stage.data() : nullptr, 4, (uint32_t)(stage.size() / 4));
-  if (p.seg) {
+  if (p.seg && !lazy) {
     int32_t segwork[4 * kSegMaxRegions];
     std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
     std::vector<uint8_t> segcls(64);
@@ -185,8 +204,61 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1", "wide" or default (v2 where possible)
       const bool xo = (p.flags & kParamXOrder) != 0;
-      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) { if (xo) mem_lane2<false, true>(d, p, b, wl, ls); else mem_lane2<false>(d, p, b, wl, ls); }
-      else if (d.blocks64 && d.mb_base && d.kmer64 && !v && pass == 0 && !g_vb.n_acc) { if (xo) mem_lane2<true, true>(d, p, b, wl, ls); else mem_lane2<true>(d, p, b, wl, ls); }
+      auto lane_v2 = [&](const Params &pp, const WorkList &w2) {
+        if (d.kmer32) { if (xo) mem_lane2<false, true>(d, pp, b, w2, ls); else mem_lane2<false>(d, pp, b, w2, ls); }
+        else { if (xo) mem_lane2<true, true>(d, pp, b, w2, ls); else mem_lane2<true>(d, pp, b, w2, ls); }
+      };
+      if (mem_v2 && pass == 0) {
+        Params pm = p;
+        if (lazy) pm.flags |= kParamLazySeg;
+        lane_v2(pm, wl);
+        if (lazy) {
+          // k_trigcheck, k_segflag, k_seg, k_seg_apply_list and the search of the listed reads (capi.hip)
+          std::vector<uint32_t> seglist;
+          for (uint32_t r = 0; r < n; r++) {
+            const uint32_t vv = hits[r].reserved;
+            if (vv == 0) continue;
+            hits[r].reserved = 0;
+            bool need = vv == kWinForce;
+            const Frag *F = frags.data() + meta[r].frag;
+            const uint8_t *pp = pep.data() + meta[r].pep;
+            if (!need && !(vv & kWinMulti)) { const Frag f = F[(vv & ~kWinMulti) - 1u]; need = seg_triggers(cx, pp + f.start, (int)f.len); }
+            else if (!need) {
+              for (uint32_t k = 0; k < (meta[r].nfrag & ~kNfragSegPending) && !need; k++)
+                if (F[k].len >= hits[r].best) need = seg_triggers(cx, pp + F[k].start, (int)F[k].len);
+            }
+            if (need) seglist.push_back(r);
+          }
+          for (uint32_t r : seglist) {
+            Frag *F = frags.data() + meta[r].frag;
+            const uint8_t *pp = pep.data() + meta[r].pep;
+            const uint32_t nf = meta[r].nfrag & ~kNfragSegPending;
+            uint32_t pending = 0;
+            for (uint32_t k = 0; k < nf; k++) {
+              uint32_t fl = kFragChecked;
+              if (seg_triggers(cx, pp + F[k].start, (int)F[k].len)) {
+                const uint32_t slot = seg_count++;
+                if (slot >= seg_cap) err |= 2u;
+                else { seg_items[slot] = SegWork{r, k}; pending = kNfragSegPending; fl = (slot + 1) << kFragSlotShift; }
+              }
+              F[k].flags = fl;
+            }
+            meta[r].nfrag = nf | pending;
+            memset(&hits[r], 0, sizeof(Hit));
+          }
+          int32_t segwork[4 * kSegMaxRegions];
+          std::vector<uint8_t> segstage(64), segcls(64);
+          for (uint32_t s2 = 0; s2 < seg_count && s2 < seg_cap; s2++)
+            seg_compute(cx, CoopSerial{}, b, p, sq, s2, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
+          for (uint32_t r : seglist) seg_apply_mem(ix->ct, p, b, sq, r, &err);
+          uint32_t counter2 = 0, nlist = (uint32_t)seglist.size();
+          WorkList w2;
+          w2.counter = &counter2; w2.n_items = nlist; w2.n_items_ptr = nullptr; w2.reads = seglist.data();
+          w2.retry_list = retry.data(); w2.retry_count = &retry_count;
+          if (nlist) lane_v2(p, w2);
+          if (getenv("KAIJU_EMU_PRINT_LAZY")) fprintf(stderr, "[emu] lazy SEG: %u of %u reads listed\n", nlist, n);
+        }
+      }
       else if (d.sb32 && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls, g_vb);
       else mem_lane<uint64_t>(d, p, b, wl, ls, g_vb);
     } else {
