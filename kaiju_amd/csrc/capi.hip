@@ -77,6 +77,7 @@ k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQue
   __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
   __shared__ uint32_t s_codes[2 * kS1ListCap * kS1Block];
   __shared__ __attribute__((aligned(4))) uint8_t s_cnt[TRIG ? kS1Block * kS1CntStride : 4];
+  __shared__ __attribute__((aligned(4))) uint8_t s_ts[TRIG ? kS1Block * kTsBuf : 4];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
     uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
@@ -89,6 +90,7 @@ k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQue
   S1Lane ln;
   ln.codes = s_codes + threadIdx.x; ln.code_stride = kS1Block;
   ln.cnt = s_cnt + (TRIG ? threadIdx.x * kS1CntStride : 0);
+  ln.tsbuf = s_ts + (TRIG ? threadIdx.x * kTsBuf : 0);
   build_fragments_fast<TRIG>(s_t, p, b, sq, r, &e, ln);
   if (e) atomicOr(err, e);
 }
@@ -99,10 +101,16 @@ k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQue
 // result already: SEG would leave exactly those fragments alone, and the pieces of the others are substrings of their
 // parents, which did not match longer.  The other reads are listed here and take the SEG pass.
 __global__ void __launch_bounds__(256)
-k_trigcheck(SegTables st, Batch b, uint32_t *seglist, uint32_t *segcount) {
-  __shared__ int64_t s_entg[13];
-  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
-  __syncthreads();
+k_trigcheck(const Stage1Tables *__restrict__ g_t, Batch b, uint32_t *seglist, uint32_t *segcount) {
+  __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
+  __shared__ __attribute__((aligned(4))) uint8_t s_cnt[256 * kS1CntStride];
+  __shared__ __attribute__((aligned(4))) uint8_t s_ts[256 * kTsBuf];
+  {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
+    for (uint32_t i = threadIdx.x; i < sizeof(Stage1Tables) / 16; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
   if (r >= b.n_reads) return;
   const uint32_t v = b.hits[r].reserved;
@@ -110,19 +118,19 @@ k_trigcheck(SegTables st, Batch b, uint32_t *seglist, uint32_t *segcount) {
   b.hits[r].reserved = 0;
   bool need = v == kWinForce;
   if (!need) {
-    const SegCtx cx = seg_ctx(st, s_entg, nullptr);
+    uint8_t *row = s_cnt + threadIdx.x * kS1CntStride, *buf = s_ts + threadIdx.x * kTsBuf;
     const ReadMeta rm = b.meta[r];
     const Frag *F = b.frags + rm.frag;
     const uint8_t *pep = b.pep + rm.pep;
     if (!(v & kWinMulti)) {
       const Frag f = F[(v & ~kWinMulti) - 1u];
-      need = seg_triggers(cx, pep + f.start, (int)f.len);
+      need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
     } else {
       // several fragments hold a longest match: every fragment long enough to be one of them is looked at
       const uint32_t best = b.hits[r].best, nf = rm.nfrag & ~kNfragSegPending;
       for (uint32_t k = 0; k < nf && !need; k++) {
         const Frag f = F[k];
-        if (f.len >= best) need = seg_triggers(cx, pep + f.start, (int)f.len);
+        if (f.len >= best) need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
       }
     }
   }
@@ -1042,7 +1050,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         // lists rewritten, searched again (counters: [22] listed reads, [23] work counter of that search)
         if ((rc = ensure(c->seglist, (size_t)n * 4 + 16))) return rc;
         uint32_t *seglist = static_cast<uint32_t *>(c->seglist.p);
-        hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->st, b, seglist, cnt + 22);
+        hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->d_s1, b, seglist, cnt + 22);
         hipLaunchKernelGGL(k_segflag, dim3(c->n_cu * 4), dim3(256), 0, s, p, ix->st, b, sq, seglist, cnt + 22, cnt + 3);
         hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 32), dim3(kSegBlock), 0, s, p, ix->st, b, sq);
         hipLaunchKernelGGL(k_seg_apply_list, dim3(c->n_cu * 4), blk, 0, s, ix->d_ct, p, b, sq, seglist, cnt + 22, cnt + 3);

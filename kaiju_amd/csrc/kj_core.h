@@ -1104,9 +1104,8 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
 //     boundary, reverse strings - produced from their end, :235-268 walk the strand downwards - END at one;
 //   * stops are not acted upon inside the loop; the runs between them are taken from a bit mask per frame afterwards
 //     (bit tricks), with the emission moments of the reference in closed form, and ranked in a small LDS list;
-//   * TRIG (Greedy; MEM looks at SEG lazily, see mem_lane2): the entropy of the 12-window ending at every residue is kept
-//     incrementally with the letter counts of the window in a per-lane LDS row (two byte updates and two table lookups
-//     per residue); a stop inside the window adds a constant that no entropy reaches, so no state is ever reset.
+//   * TRIG (Greedy; MEM looks at SEG lazily, see mem_lane2): a second pass over the six strings of a mate, one at a time
+//     from a small per-lane LDS buffer, keeps the entropy of the 12-window ending at every residue (trig_scan).
 // ----------------------------------------------------------------------------
 struct Stage1Tables {        // built on the host (host_tables.cpp: build_stage1_tables); the kernel keeps a copy in LDS
   uint8_t nuc3[256];         // nucleotide -> 0..3 (nuc2int, ConsumerThread.cpp:6-9), 4 = not ACGTU
@@ -1122,52 +1121,35 @@ static_assert(sizeof(Stage1Tables) % 16 == 0, "Stage1Tables is copied in 16-byte
 constexpr int kS1Units = 4;                          // 16-residue units per frame string
 constexpr uint32_t kS1MaxLen = 48 * kS1Units - 1;    // len / 3 + 1 <= 16 * kS1Units
 constexpr int kS1ListCap = 24;                       // fragments ranked in LDS (two words each); a longer list is sorted in place
-constexpr int kS1CntRow = 24;                        // bytes of one letter-count row (21 used)
-constexpr int kS1CntStride = 6 * kS1CntRow + 4;      // per lane: six rows; 37 dwords apart (odd: lanes spread over the banks)
+constexpr int kS1CntRow = 24;                        // bytes of the letter-count row of a trigger scan (21 used)
+constexpr int kS1CntStride = kS1CntRow + 4;          // per lane: 7 dwords apart (odd: lanes spread over the banks)
 constexpr uint32_t kS1StopCnt = 13 * 4;              // the stop's count is kept 13 higher: its dtab entries are kS1Big
 constexpr uint32_t kErrReadTooLong = 16u;            // error flag: a mate longer than kaiju_gpu_set_max_read_length() allowed
 
 struct S1Lane {              // per-lane LDS of the fast stage 1
   uint32_t *codes;           // [2 * kS1ListCap] words of the fragment list, `code_stride` dwords apart
   uint32_t code_stride;
-  uint8_t *cnt;              // TRIG: kS1CntStride bytes
+  uint8_t *cnt;              // TRIG: letter-count row of the trigger scan, kS1CntRow bytes
+  uint8_t *tsbuf;            // TRIG: staging buffer of the trigger scan, kTsBuf bytes
 };
 
-// One mate: strings to dst (16-byte aligned, six strings of u = len / 48 + 1 units), masks of the residues that are no stops (ns) and
-// of the 12-windows at or below the SEG trigger entropy (tg, TRIG only), bit = processing index (the codon number along
-// the read for both strands: string index for a forward frame, distance from the string end for a reverse one).
-template <bool TRIG>
-KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_t *dst, uint64_t *ns, uint64_t *tg,
-                   uint8_t *cnt) {
-  const uint32_t top = len - 3, u = len / 48u + 1u;
-  for (int f = 0; f < 6; f++) { ns[f] = 0; tg[f] = 0; }
-  int32_t S[6] = {0, 0, 0, 0, 0, 0};
-  if (TRIG) {
-    // the window starts out as twelve stops in front of the string
-    uint32_t *c32 = reinterpret_cast<uint32_t *>(cnt);
-#pragma unroll
-    for (int f = 0; f < 6; f++) {
-#pragma unroll
-      for (int q = 0; q < kS1CntRow / 4; q++) c32[f * (kS1CntRow / 4) + q] = q == 0 ? (kS1StopCnt + 12u * 4u) : 0u;
-      S[f] = 12 * t.dtab[13];
-    }
-  }
+// One mate: strings to dst (16-byte aligned, six strings of u = len / 48 + 1 units) and the masks of the residues that are
+// no stops (ns), bit = processing index (the codon number along the read for both strands: string index for a forward
+// frame, distance from the string end for a reverse one).
+KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_t *dst, uint64_t *ns) {
+  const uint32_t u = len / 48u + 1u;
+  for (int f = 0; f < 6; f++) ns[f] = 0;
   NucReader nr;
   nr.s = s; nr.len = len;
   u128 c0 = nr.chunk(0), c1 = nr.chunk(1), c2 = nr.chunk(2), c3 = nr.chunk(3);
   uint32_t idx = (uint32_t)t.nuc3[c0.x & 255u] << 3 | t.nuc3[(c0.x >> 8) & 255u];
-  uint32_t pf[3][4], pr[3][4];                 // the previous block's units (TRIG: the residue that leaves the window)
-#pragma unroll
-  for (int g = 0; g < 3; g++)
-#pragma unroll
-    for (int d = 0; d < 4; d++) pf[g][d] = pr[g][d] = 0;
-  for (uint32_t b = 0; b < u && 48u * b <= top; b++) {
+  for (uint32_t b = 0; b < u; b++) {                        // (all u blocks: every unit of the strings gets written)
     const uint32_t w[13] = {(uint32_t)c0.x, (uint32_t)(c0.x >> 32), (uint32_t)c0.y, (uint32_t)(c0.y >> 32),
                             (uint32_t)c1.x, (uint32_t)(c1.x >> 32), (uint32_t)c1.y, (uint32_t)(c1.y >> 32),
                             (uint32_t)c2.x, (uint32_t)(c2.x >> 32), (uint32_t)c2.y, (uint32_t)(c2.y >> 32), (uint32_t)c3.x};
     // the next block's nucleotides are requested before this block's arithmetic
     const u128 n1 = nr.chunk(3 * b + 4), n2 = nr.chunk(3 * b + 5), n3 = nr.chunk(3 * b + 6);
-    uint32_t fu[3][4], ru[3][4], mf[3] = {0, 0, 0}, mr[3] = {0, 0, 0}, tf_[3] = {0, 0, 0}, tr_[3] = {0, 0, 0};
+    uint32_t fu[3][4], ru[3][4], mf[3] = {0, 0, 0}, mr[3] = {0, 0, 0};
 #pragma unroll
     for (int g = 0; g < 3; g++)
 #pragma unroll
@@ -1184,28 +1166,6 @@ KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_
         ru[g][3 - (j >> 2)] |= ar << (8 * (3 - (j & 3)));
         mf[g] |= (af != 0u ? 1u : 0u) << j;
         mr[g] |= (ar != 0u ? 1u : 0u) << j;
-        if (TRIG) {
-          // the residue twelve back in the same string: four units of four residues, j - 12 or the previous block's j + 4
-          const uint32_t yf = j >= 12 ? (fu[g][(j - 12) >> 2] >> (8 * ((j - 12) & 3))) & 255u
-                                      : (pf[g][(j + 4) >> 2] >> (8 * ((j + 4) & 3))) & 255u;
-          const uint32_t yr = j >= 12 ? (ru[g][3 - ((j - 12) >> 2)] >> (8 * (3 - ((j - 12) & 3)))) & 255u
-                                      : (pr[g][3 - ((j + 4) >> 2)] >> (8 * (3 - ((j + 4) & 3)))) & 255u;
-          const uint8_t *db = reinterpret_cast<const uint8_t *>(t.dtab);
-#pragma unroll
-          for (int h = 0; h < 2; h++) {
-            uint8_t *row = cnt + (h * 3 + g) * kS1CntRow;
-            const uint32_t x = h ? ar : af, y = h ? yr : yf;
-            int32_t sc = S[h * 3 + g];
-            const uint32_t cx = row[x];
-            row[x] = (uint8_t)(cx + 4u);
-            sc += *reinterpret_cast<const int32_t *>(db + cx);
-            const uint32_t cy = row[y] - 4u;
-            row[y] = (uint8_t)cy;
-            sc -= *reinterpret_cast<const int32_t *>(db + cy);
-            S[h * 3 + g] = sc;
-            if (h) tr_[g] |= (sc <= t.locut32 ? 1u : 0u) << j; else tf_[g] |= (sc <= t.locut32 ? 1u : 0u) << j;
-          }
-        }
       }
     }
     // whole units, one aligned 16-byte store each
@@ -1218,15 +1178,68 @@ KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_
       *reinterpret_cast<u128 *>(dst + (size_t)(4 + g) * (16 * u) - 16 * (b + 1)) = v;
       ns[g] |= (uint64_t)mf[g] << (16 * b);
       ns[3 + g] |= (uint64_t)mr[g] << (16 * b);
-      if (TRIG) {
-        tg[g] |= (uint64_t)tf_[g] << (16 * b);
-        tg[3 + g] |= (uint64_t)tr_[g] << (16 * b);
-#pragma unroll
-        for (int d = 0; d < 4; d++) { pf[g][d] = fu[g][d]; pr[g][d] = ru[g][d]; }
-      }
     }
     c0 = c3; c1 = n1; c2 = n2; c3 = n3;
   }
+}
+
+// The SEG trigger scan: the entropy (2^26-scaled, SegTables::ent_g32) of the window of the twelve residues ending at every
+// byte of x0[0, n), kept incrementally with the letter counts of the window in the lane's LDS row - two byte updates and two
+// table lookups per residue.  The window starts out as twelve stops; the letter that leaves is x0[k - 12], for the first
+// `lead` steps a stop whatever lies in front of x0.  A stop in the window adds a constant no entropy reaches
+// (Stage1Tables::dtab), so stops need no special handling and no state is ever reset.  Returns, MASK, bit k = the window
+// ending at x0[k] is at or below the trigger entropy H <= 2.2 (n <= 64); otherwise whether any window is.
+constexpr int kTsLead = 16;                           // zero bytes in front of a staged string
+constexpr int kTsBuf = kTsLead + 80 + 4;              // per lane: the zeros, up to five units, 25 dwords in all (odd: banks)
+template <bool MASK>
+KJ_HD uint64_t trig_scan(const Stage1Tables &t, const uint8_t *x0, uint32_t n, uint32_t lead, const uint8_t *zero, uint8_t *row) {
+  uint32_t *c32 = reinterpret_cast<uint32_t *>(row);
+#pragma unroll
+  for (int q = 0; q < kS1CntRow / 4; q++) c32[q] = q == 0 ? (kS1StopCnt + 12u * 4u) : 0u;
+  int32_t sc = 12 * t.dtab[13];
+  const uint8_t *db = reinterpret_cast<const uint8_t *>(t.dtab);
+  uint64_t mask = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t x = x0[k];
+    const uint32_t y = *(k < lead ? zero : x0 + k - 12);
+    const uint32_t cx = row[x];
+    row[x] = (uint8_t)(cx + 4u);
+    sc += *reinterpret_cast<const int32_t *>(db + cx);
+    const uint32_t cy = row[y] - 4u;
+    row[y] = (uint8_t)cy;
+    sc -= *reinterpret_cast<const int32_t *>(db + cy);
+    if (MASK) mask |= (uint64_t)(sc <= t.locut32 ? 1u : 0u) << k;
+    else mask |= sc <= t.locut32 ? 1ull : 0ull;
+  }
+  return mask;
+}
+// nu 16-byte units from device memory (16-byte aligned) behind the zeros of the lane's staging buffer
+KJ_HD void trig_stage(const uint8_t *src, uint32_t nu, uint8_t *buf) {
+  uint32_t *b32 = reinterpret_cast<uint32_t *>(buf);
+#pragma unroll
+  for (int q = 0; q < kTsLead / 4; q++) b32[q] = 0;
+  for (uint32_t k = 0; k < nu; k++) {
+    const u128 v = *reinterpret_cast<const u128 *>(src + 16 * k);
+    b32[kTsLead / 4 + 4 * k] = (uint32_t)v.x; b32[kTsLead / 4 + 4 * k + 1] = (uint32_t)(v.x >> 32);
+    b32[kTsLead / 4 + 4 * k + 2] = (uint32_t)v.y; b32[kTsLead / 4 + 4 * k + 3] = (uint32_t)(v.y >> 32);
+  }
+}
+// does SEG report a region for the fragment pep[start, start + len)?  (exactly when some 12-window reaches the trigger
+// entropy, s_SegSeq blast_seg.c:2061; same answer as seg_triggers); fragments longer than 64 residues: seg_triggers
+KJ_HD bool trig_fragment(const Stage1Tables &t, const uint8_t *pep, uint32_t start, uint32_t len, uint8_t *buf, uint8_t *row) {
+  if (len < (uint32_t)kSegWindow) return false;
+  const uint32_t a = start & 15u;
+  trig_stage(pep + (start - a), (a + len + 15u) >> 4, buf);
+  return trig_scan<false>(t, buf + kTsLead + a, len, 12, buf, row) != 0;
+}
+KJ_HD uint64_t bitrev64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brevll(v);
+#else
+  uint64_t r = 0;
+  for (int i = 0; i < 64; i++) r |= ((v >> i) & 1ull) << (63 - i);
+  return r;
+#endif
 }
 
 // where fragment [a, a + l) (processing indices) of string f of a mate lies in the mate's area
@@ -1314,13 +1327,25 @@ KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Ba
       }
       n++;
     };
-    uint64_t ns[6], tg[6];
+    uint64_t ns[6], tg[6] = {0, 0, 0, 0, 0, 0};
+    // TRIG: the trigger windows of a mate's six strings (stops and all), in memory order; for a reverse string that is
+    // the other way round: the window ending at byte o of 16u is the one that starts at processing index 16u - 1 - o
+    auto scan_mate = [&](uint8_t *dst, uint32_t len) {
+      const uint32_t u = len / 48u + 1u;
+      for (int f = 0; f < 6; f++) {
+        trig_stage(dst + (size_t)f * 16 * u, u, ln.tsbuf);
+        const uint64_t mm = trig_scan<true>(t, ln.tsbuf + kTsLead, 16 * u, 0, ln.tsbuf, ln.cnt);
+        tg[f] = f < 3 ? mm : (bitrev64(mm) >> (64 - 16 * u)) << 11;
+      }
+    };
     if (len1 >= m3) {
-      s1_mate<TRIG>(t, b.seqs + o0, len1, area, ns, tg, ln.cnt);
+      s1_mate(t, b.seqs + o0, len1, area, ns);
+      if (TRIG && p.seg) scan_mate(area, len1);
       s1_runs(ns, tg, len1, p.m, 0, 0, emit);
     }
     if (b.paired && len2 >= m3) {
-      s1_mate<TRIG>(t, b.seqs + o1, len2, area + mate_bytes, ns, tg, ln.cnt);
+      s1_mate(t, b.seqs + o1, len2, area + mate_bytes, ns);
+      if (TRIG && p.seg) scan_mate(area + mate_bytes, len2);
       s1_runs(ns, tg, len2, p.m, mate_bytes, 2 * len1 + 6, emit);
     }
     // (emission moments stay below 2 * (len1 + len2) + 12 <= 780, keys below 11 * 64, starts below 768, lengths <= 64)

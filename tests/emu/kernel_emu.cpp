@@ -128,20 +128,23 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   const bool fast1 = !(p.flags & kParamProtein) && !getenv("KAIJU_EMU_STAGE1_OLD") && maxlen <= kS1MaxLen && p.m >= 1 && p.m <= 64;
   const bool lazy = fast1 && mem_v2 && p.seg && !getenv("KAIJU_EMU_LAZY_OFF");
   const bool trig1 = fast1 && p.seg && !lazy;
+  Stage1Tables s1tab;
+  build_stage1_tables(ix->ct, ix->st, s1tab);
   if (p.flags & kParamProtein) {
     uint8_t code[256];
     memset(code, 0, sizeof code);
     for (uint32_t a = 0; a < 20; a++) protein_code_entry(ix->ct, a, code);
     for (uint32_t r = 0; r < n; r++) build_fragments_protein(ix->ct, code, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq, r, &err);
   } else if (fast1) {
-    Stage1Tables s1;
-    build_stage1_tables(ix->ct, ix->st, s1);
+    const Stage1Tables &s1 = s1tab;
     uint32_t codes[2 * kS1ListCap];
     alignas(4) uint8_t cnt[kS1CntStride];
-    S1Lane ln{codes, 1, cnt};
+    alignas(4) uint8_t tsbuf[kTsBuf];
+    S1Lane ln{codes, 1, cnt, tsbuf};
     for (uint32_t r = 0; r < n; r++) {
       for (auto &x : codes) x = 0xdeadbeefu;
       memset(cnt, 0xee, sizeof cnt);
+      memset(tsbuf, 0xee, sizeof tsbuf);
       if (trig1) build_fragments_fast<true>(s1, p, b, sq, r, &err, ln);
       else build_fragments_fast<false>(s1, p, b, sq, r, &err, ln);
     }
@@ -222,10 +225,16 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
             bool need = vv == kWinForce;
             const Frag *F = frags.data() + meta[r].frag;
             const uint8_t *pp = pep.data() + meta[r].pep;
-            if (!need && !(vv & kWinMulti)) { const Frag f = F[(vv & ~kWinMulti) - 1u]; need = seg_triggers(cx, pp + f.start, (int)f.len); }
+            auto trig = [&](const Frag &f) {
+              alignas(4) uint8_t row[kS1CntStride], tb[kTsBuf];
+              const bool a = trig_fragment(s1tab, pp, f.start, f.len, tb, row), bb = seg_triggers(cx, pp + f.start, (int)f.len);
+              if (a != bb) { fprintf(stderr, "[emu] trig_fragment disagrees with seg_triggers\n"); abort(); }
+              return a;
+            };
+            if (!need && !(vv & kWinMulti)) need = trig(F[(vv & ~kWinMulti) - 1u]);
             else if (!need) {
               for (uint32_t k = 0; k < (meta[r].nfrag & ~kNfragSegPending) && !need; k++)
-                if (F[k].len >= hits[r].best) need = seg_triggers(cx, pp + F[k].start, (int)F[k].len);
+                if (F[k].len >= hits[r].best) need = trig(F[k]);
             }
             if (need) seglist.push_back(r);
           }
