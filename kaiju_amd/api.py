@@ -62,7 +62,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    path = os.environ.get("KAIJU_GPU_LIB") or _build.LIB      # (KAIJU_GPU_LIB: another build of the library, A/B measurements)
     if not os.path.exists(path):
         _build.build()
     L = C.CDLL(path)

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -503,6 +504,15 @@ static int fail(int code, const std::string &msg) { tl_error = msg; return code;
       return fail(KAIJU_GPU_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+// no exception may cross the C ABI (std::bad_alloc / length_error from a vector sized by a damaged file, ...)
+template <class F>
+static int guarded(F &&f) {
+  try { return f(); }
+  catch (const std::bad_alloc &) { return fail(KAIJU_GPU_ERR_NOMEM, "out of host memory"); }
+  catch (const std::length_error &) { return fail(KAIJU_GPU_ERR_FORMAT, "a size in the file or an argument is not plausible"); }
+  catch (const std::exception &e) { return fail(KAIJU_GPU_ERR_ARG, std::string("unexpected error: ") + e.what()); }
+}
+
 extern "C" int kaiju_gpu_abi_version(void) { return KAIJU_GPU_ABI_VERSION; }
 extern "C" const char *kaiju_gpu_last_error(void) { return tl_error.c_str(); }
 extern "C" const char *kaiju_gpu_strerror(int status) {
@@ -697,6 +707,7 @@ static bool is_image_file(const char *path) {
 }
 
 extern "C" int kaiju_gpu_index_write_image(const char *fmi_path, const char *image_path) {
+  return guarded([&]() -> int {
   if (!fmi_path || !image_path) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   FmiFile f;
   std::string msg;
@@ -706,9 +717,11 @@ extern "C" int kaiju_gpu_index_write_image(const char *fmi_path, const char *ima
   if ((rc = pk.build(f.view(), msg))) return fail(rc, msg);
   if ((rc = pk.write_image(image_path, msg))) return fail(rc, msg);
   return KAIJU_GPU_OK;
+  });
 }
 
 extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_gpu_index **out) {
+  return guarded([&]() -> int {
   if (!fmi_path || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   *out = nullptr;
   int ndev = 0;
@@ -728,6 +741,7 @@ extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_g
   int rc = f.load(fmi_path, msg);
   if (rc) return fail(rc, msg);
   return index_from_view(f.view(), device_id, out);
+  });
 }
 
 extern "C" int kaiju_gpu_index_load_ex(const char *fmi_path, int device_id, int id_mode, kaiju_gpu_index **out) {
@@ -739,12 +753,14 @@ extern "C" int kaiju_gpu_index_load_ex(const char *fmi_path, int device_id, int 
 }
 
 extern "C" int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *hv, int device_id, kaiju_gpu_index **out) {
+  return guarded([&]() -> int {
   if (!hv || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   HostIndexView v;
   v.bwtlen = hv->bwtlen; v.nseq = hv->nseq; v.alen = hv->alen; v.alphabet = hv->alphabet; v.bwt = hv->bwt;
   v.startLcode = hv->startLcode; v.sa = hv->sa; v.ncheck = hv->ncheck; v.chpt_exp = hv->chpt_exp;
   v.nbytes = hv->nbytes; v.pbits = hv->pbits; v.ids = hv->ids;
   return index_from_view(v, device_id, out);
+  });
 }
 
 extern "C" int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info) {
@@ -828,6 +844,7 @@ extern "C" void kaiju_gpu_default_params(kaiju_gpu_params *p, int mode) {
 }
 
 extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, const kaiju_gpu_params *p) {
+  return guarded([&]() -> int {
   if (!out || !ix || !p) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   *out = nullptr;
   if (p->mode != 0 && p->mode != 1) return fail(KAIJU_GPU_ERR_ARG, "mode must be 0 (MEM) or 1 (GREEDY)");
@@ -884,6 +901,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   for (auto &e : c->ev) KJ_HIP(hipEventCreate(&e));
   *out = c.release();
   return KAIJU_GPU_OK;
+  });
 }
 
 extern "C" void kaiju_gpu_destroy(kaiju_gpu_ctx *ctx) { delete ctx; }
@@ -1167,10 +1185,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
 extern "C" int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d_seqs, uint64_t seq_bytes,
                                                const uint64_t *d_off, uint32_t n_reads, int paired,
                                                kaiju_gpu_hit *d_out, void *stream) {
+  return guarded([&]() -> int {
   if (!ctx || (!d_seqs && seq_bytes) || !d_off || (!d_out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   KJ_HIP(hipSetDevice(ctx->ix->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
   return launch_batch(ctx, d_seqs, seq_bytes, d_off, n_reads, paired, ctx->max_read_len, d_out, s);
+  });
 }
 
 // host buffers -> device, kernels queued on the context's stream; the hit records stay in ctx->h_hits
@@ -1199,6 +1219,7 @@ static int classify_host_buffers(kaiju_gpu_ctx *ctx, const char *seqs, const uin
 
 extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off,
                                         uint32_t n_reads, int paired, kaiju_gpu_hit *out) {
+  return guarded([&]() -> int {
   if (!ctx || !off || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   if (n_reads == 0) return KAIJU_GPU_OK;
   const int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
@@ -1207,6 +1228,7 @@ extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, co
   KJ_HIP(hipMemcpyAsync(out, ctx->h_hits.p, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyDeviceToHost, s));
   KJ_HIP(hipStreamSynchronize(s));
   return KAIJU_GPU_OK;
+  });
 }
 
 extern "C" int kaiju_gpu_set_max_read_length(kaiju_gpu_ctx *ctx, uint32_t max_read_len) {
@@ -1234,6 +1256,7 @@ k_lca(DevTaxonomy t, const Hit *__restrict__ hits, uint32_t n, CompactHit *__res
 }
 
 extern "C" int kaiju_gpu_taxonomy_upload(const kaiju_taxonomy *t, int device_id, kaiju_gpu_taxonomy **out) {
+  return guarded([&]() -> int {
   if (!t || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   *out = nullptr;
   int ndev = 0;
@@ -1262,6 +1285,7 @@ extern "C" int kaiju_gpu_taxonomy_upload(const kaiju_taxonomy *t, int device_id,
   g->dev.cap_mask = (uint32_t)(key.size() - 1);
   *out = g.release();
   return KAIJU_GPU_OK;
+  });
 }
 
 extern "C" void kaiju_gpu_taxonomy_free(kaiju_gpu_taxonomy *t) { delete t; }
@@ -1287,6 +1311,7 @@ extern "C" int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_ta
 extern "C" int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
                                                 int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, char *text,
                                                 uint32_t text_stride) {
+  return guarded([&]() -> int {
   if (!ctx || !off || (n_reads && (!out || !vout || !text))) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   if (n_reads == 0) return KAIJU_GPU_OK;
   ctx->verbose = true;
@@ -1318,6 +1343,7 @@ extern "C" int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *
     v.text_len = w;
   }
   return KAIJU_GPU_OK;
+  });
 }
 
 extern "C" const char *kaiju_gpu_index_seq_name(const kaiju_gpu_index *ix, uint32_t iseq) {
@@ -1328,6 +1354,7 @@ extern "C" const char *kaiju_gpu_index_seq_name(const kaiju_gpu_index *ix, uint3
 // classify host buffers and return 16-byte records only (the 184-byte hit records never leave the device)
 extern "C" int kaiju_gpu_classify_batch_compact(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const char *seqs,
                                                 const uint64_t *off, uint32_t n_reads, int paired, kaiju_gpu_compact *out) {
+  return guarded([&]() -> int {
   if (!ctx || !t || !off || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   if (t->device != ctx->ix->device) return fail(KAIJU_GPU_ERR_ARG, "taxonomy lives on another device");
   if (n_reads == 0) return KAIJU_GPU_OK;
@@ -1341,6 +1368,7 @@ extern "C" int kaiju_gpu_classify_batch_compact(kaiju_gpu_ctx *ctx, const kaiju_
   KJ_HIP(hipMemcpyAsync(out, ctx->h_compact.p, (size_t)n_reads * sizeof(kaiju_gpu_compact), hipMemcpyDeviceToHost, s));
   KJ_HIP(hipStreamSynchronize(s));
   return KAIJU_GPU_OK;
+  });
 }
 
 // host buffers in and out (blocking): upload the hit records, k_lca, download the compact records

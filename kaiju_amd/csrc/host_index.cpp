@@ -1,6 +1,7 @@
 // host_index.cpp — see host_index.h
 #include "host_index.h"
 
+#include <sys/stat.h>
 #include <algorithm>
 #include <cctype>
 #include <climits>
@@ -47,9 +48,13 @@ int FmiFile::load(const char *path, std::string &msg) {
   FILE *fp = fopen(path, "rb");
   if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
   Reader rd{fp};
+  // (sizes in the headers are checked against the size of the file before anything is allocated from them)
+  int64_t fsize = 0;
+  { struct stat st; if (fstat(fileno(fp), &st) == 0) fsize = (int64_t)st.st_size; }
+  if (fsize <= 0) fsize = INT64_MAX;           // not a regular file: no bound
   // BWT header, bwt/bwt.c:51-61
   rd.get(len); rd.get(nseq); rd.get(alen);
-  if (!rd.ok || alen <= 1 || alen > 60 || nseq <= 0 || len <= 0) {
+  if (!rd.ok || alen <= 1 || alen > 60 || nseq <= 0 || len <= 0 || len > fsize || (int64_t)nseq * 13 > fsize) {
     fclose(fp); msg = "not a Kaiju .fmi file (bad BWT header)"; return KAIJU_GPU_ERR_FORMAT;
   }
   alphabet.resize((size_t)alen);
@@ -57,7 +62,8 @@ int FmiFile::load(const char *path, std::string &msg) {
   // suffix array header, bwt/suffixArray.c:282-312
   rd.get(salen); rd.get(ncheck); rd.get(chpt_exp); rd.get(nbytes); rd.get(sbits); rd.get(pbits);
   rd.get(mask); rd.get(check); rd.get(sa_nseq);
-  if (!rd.ok || sa_nseq != nseq || nbytes <= 0 || nbytes > 8 || chpt_exp < 0 || chpt_exp > 30 || ncheck < 0) {
+  if (!rd.ok || sa_nseq != nseq || nbytes <= 0 || nbytes > 8 || chpt_exp < 0 || chpt_exp > 30 || ncheck < 0 ||
+      ncheck > fsize / nbytes) {
     fclose(fp); msg = "not a Kaiju .fmi file (bad suffix array header)"; return KAIJU_GPU_ERR_FORMAT;
   }
   ids.resize((size_t)nseq);
@@ -73,7 +79,7 @@ int FmiFile::load(const char *path, std::string &msg) {
   rd.bytes(sa.data(), sa.size());
   // FMI, bwt/fmicommon.h:190-217 + compactfmi.c:165-171
   rd.get(f_alen); rd.get(bwtlen); rd.get(N1); rd.get(N2);
-  if (!rd.ok || f_alen != alen || bwtlen != len || N1 <= 0 || N2 <= 0) {
+  if (!rd.ok || f_alen != alen || bwtlen != len || N1 <= 0 || N2 <= 0 || (int64_t)N1 * alen * 8 > fsize || (int64_t)N2 * alen * 2 > fsize) {
     fclose(fp); msg = "not a Kaiju .fmi file (bad FMI header)"; return KAIJU_GPU_ERR_FORMAT;
   }
   bwt.resize((size_t)bwtlen);

@@ -134,6 +134,104 @@ def make_db(nseq=680001, seed=12345, leaves=None, min_len=30, max_len=3000,
     return SynthDB(codes=codes, offsets=offsets, taxids=taxids, names=names)
 
 
+def make_db_large(nseq, seed=12345, leaves=None, min_len=30, max_len=3000, gamma_shape=2.0, gamma_scale=140.0,
+                  frac_copies=0.35, chunk=1 << 22):
+    """The database of make_db() for sizes where its per-sequence Python loops take too long (refseq-class indexes,
+    >= 2^32 rows): same length / residue / copy-rate statistics, fully vectorised.  Copies are made of ORIGINAL
+    sequences only (no chains), the source lies anywhere before the copy; taxa as in make_db().  Not the same
+    sequences as make_db() for the same seed."""
+    rng = np.random.default_rng(seed)
+    if leaves is None:
+        _, leaves = make_taxonomy()
+    lens = np.clip(rng.gamma(gamma_shape, gamma_scale, size=nseq), min_len, max_len).astype(np.int64)
+    is_copy = rng.random(nseq) < frac_copies
+    is_copy[: max(1, nseq // 100)] = False
+    orig_idx = np.nonzero(~is_copy)[0]
+    copy_idx = np.nonzero(is_copy)[0]
+    # source = a random original in front of the copy
+    n_before = np.searchsorted(orig_idx, copy_idx)                     # originals with a smaller index
+    src = orig_idx[(rng.random(len(copy_idx)) * n_before).astype(np.int64)]
+    lens[copy_idx] = lens[src]
+    bwtlen = int(lens.sum()) + nseq
+    while bwtlen % 65536 >= 65408 or bwtlen % 65536 == 0:              # the reference's rank bug, see make_db()
+        lens[orig_idx[-1]] += 1
+        bwtlen += 1
+    offsets = np.zeros(nseq + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    total = int(offsets[-1])
+    codes = np.empty(total, dtype=np.uint8)
+    cum = np.cumsum(_BG)
+    cum[-1] = 1.0
+    step = 1 << 27
+    for lo in range(0, total, step):
+        hi = min(total, lo + step)
+        codes[lo:hi] = np.searchsorted(cum, rng.random(hi - lo, dtype=np.float32), side="right").astype(np.uint8)
+    np.minimum(codes, 19, out=codes)
+    rates = rng.choice(np.array([0.01, 0.05, 0.15]), size=len(copy_idx))
+    for lo in range(0, len(copy_idx), chunk):                          # copies, a few million sequences at a time
+        ci, sr, rt = copy_idx[lo:lo + chunk], src[lo:lo + chunk], rates[lo:lo + chunk]
+        ln = lens[ci]
+        tot = int(ln.sum())
+        within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+        seg = codes[np.repeat(offsets[sr], ln) + within]
+        mut = rng.random(tot, dtype=np.float32) < np.repeat(rt, ln).astype(np.float32)
+        seg[mut] = rng.integers(0, 20, size=int(mut.sum()), dtype=np.uint8)
+        codes[np.repeat(offsets[ci], ln) + within] = seg
+    taxids = leaves[rng.integers(0, len(leaves), size=nseq)]
+    near = np.zeros(nseq, dtype=bool)
+    near[copy_idx] = rng.random(len(copy_idx)) < 0.7
+    nc = near[copy_idx]
+    base = taxids[src[nc]]
+    taxids[copy_idx[nc]] = base - (base % 10) + rng.integers(0, 10, size=int(nc.sum()))
+    names = _LazyNames(taxids)
+    return SynthDB(codes=codes, offsets=offsets, taxids=taxids, names=names)
+
+
+class _LazyNames:
+    """names[i] of a large database without materialising millions of Python strings"""
+
+    def __init__(self, taxids):
+        self.taxids = taxids
+
+    def __getitem__(self, i):
+        return f"WP{i:09d}.1_{self.taxids[i]}"
+
+    def __len__(self):
+        return len(self.taxids)
+
+
+def write_fasta_large(db: SynthDB, path, chunk=1 << 20):
+    """write_fasta() without a Python loop per sequence: headers `>WPnnnnnnnnn.1_tttttt` of fixed width (taxon ids of
+    make_taxonomy() have six digits)"""
+    aa = np.frombuffer(AA.encode(), dtype=np.uint8)
+    H = 1 + 2 + 9 + 3 + 6 + 1                                          # ">WP" 9 digits ".1_" 6 digits "\n"
+    with open(path, "wb") as f:
+        for lo in range(0, db.nseq, chunk):
+            hi = min(db.nseq, lo + chunk)
+            m = hi - lo
+            ln = np.diff(db.offsets[lo:hi + 1])
+            assert int(db.taxids[lo:hi].max()) < 1000000 and int(db.taxids[lo:hi].min()) >= 100000 and hi <= 10 ** 9
+            rec_len = ln + H + 1
+            rec_off = np.cumsum(rec_len) - rec_len
+            out = np.empty(int(rec_len.sum()), dtype=np.uint8)
+            hdr = np.empty((m, H), dtype=np.uint8)
+            hdr[:, 0:3] = np.frombuffer(b">WP", dtype=np.uint8)
+            idx = np.arange(lo, hi, dtype=np.int64)
+            for d in range(9):
+                hdr[:, 3 + d] = 48 + (idx // 10 ** (8 - d)) % 10
+            hdr[:, 12:15] = np.frombuffer(b".1_", dtype=np.uint8)
+            t = db.taxids[lo:hi].astype(np.int64)
+            for d in range(6):
+                hdr[:, 15 + d] = 48 + (t // 10 ** (5 - d)) % 10
+            hdr[:, 21] = 10
+            out[(rec_off[:, None] + np.arange(H)[None, :]).reshape(-1)] = hdr.reshape(-1)
+            tot = int(ln.sum())
+            within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(ln) - ln, ln)
+            out[np.repeat(rec_off + H, ln) + within] = aa[db.codes[db.offsets[lo]:db.offsets[hi]]]
+            out[rec_off + H + ln] = 10
+            f.write(out.tobytes())
+
+
 def write_fasta(db: SynthDB, path, width=0):
     aa = np.frombuffer(AA.encode(), dtype=np.uint8)
     text = aa[db.codes]

@@ -135,3 +135,26 @@ def test_index_image_roundtrip(golden, tmp_path):
     assert L.kaiju_gpu_index_write_image(golden.fmi.encode(), img2.encode()) == 0
     assert open(img, "rb").read() == open(img2, "rb").read()
     assert L.kaiju_gpu_index_write_image(b"/nonexistent.fmi", img2.encode()) != 0
+
+
+def test_damaged_index_files_return_a_status(golden, tmp_path):
+    """header fields of a .fmi are checked against the file size before anything is allocated from them, and no C++
+    exception crosses the C ABI: a damaged or truncated file gives a negative status (parsing needs no GPU:
+    kaiju_gpu_index_write_image)"""
+    import struct
+    L = api.lib()
+    L.kaiju_gpu_index_write_image.argtypes = [C.c_char_p, C.c_char_p]
+    data = bytearray(open(golden.fmi, "rb").read())
+    img = str(tmp_path / "x.kjimg")
+    assert L.kaiju_gpu_index_write_image(golden.fmi.encode(), img.encode()) == 0
+    cases = {}
+    d = bytearray(data); struct.pack_into("<i", d, 8, 2 ** 31 - 1); cases["nseq"] = d            # int32 nseq
+    d = bytearray(data); struct.pack_into("<q", d, 0, 2 ** 62); cases["len"] = d                  # int64 len
+    cases["truncated"] = data[: len(data) // 3]
+    cases["empty"] = bytearray()
+    for name, d in cases.items():
+        p = str(tmp_path / f"{name}.fmi")
+        open(p, "wb").write(bytes(d))
+        rc = L.kaiju_gpu_index_write_image(p.encode(), img.encode())
+        assert rc < 0, name
+        assert L.kaiju_gpu_strerror(rc)
