@@ -93,7 +93,7 @@ def algorithmic_bytes(oc: dict, nseq: int) -> float:
     lines = oc["kmer_lookups"] + oc["update_si_lines"] + oc["lf_lines"] + oc["sa_samples"] + oc["items_read"] + oc["items_written"]
     small = 16 * (oc["read_meta"] + oc["frag_desc"] + oc["matches_read"] + oc["matches_written"] + 2 * oc["si_spills"])
     term = 8 * math.ceil(math.log2(max(nseq, 2))) * oc["term_searches"]
-    return 128.0 * lines + small + 64.0 * oc["window_fills"] + float(HIT_BYTES) * oc["hits"] + term
+    return 128.0 * lines + small + 64.0 * oc["window_fills"] + float(HIT_BYTES) * oc["hits"] + term + oc.get("record_bytes", 0)
 
 
 def reference_ops(W, fmi, reads_sample, mode, seg, paired, Lm):

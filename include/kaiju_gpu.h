@@ -195,8 +195,9 @@ int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats);
    [5] SA samples read, [6] read descriptors, [7] fragment descriptors, [8] 64-byte peptide windows, [9] terminator
    searches, [10] match records spilled (MEM), [11] hit records written, [12] Greedy multi-letter steps
    (ConsumerThread.cpp:346-395 at one position), [13] queue items read, [14] match records read, [15] queue items
-   written, [16] match records written, [17] wave iterations, [18] lane iterations. */
-#define KAIJU_GPU_N_OP_COUNTS 19
+   written, [16] match records written, [17] wave iterations, [18] lane iterations, [19] bytes of the state / queue / task
+   records the third-generation Greedy kernels read and write. */
+#define KAIJU_GPU_N_OP_COUNTS 20
 int kaiju_gpu_set_count_ops(kaiju_gpu_ctx *ctx, int on);
 int kaiju_gpu_get_op_counts(kaiju_gpu_ctx *ctx, uint64_t *out, uint32_t n_out);
 

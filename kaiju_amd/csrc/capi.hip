@@ -427,6 +427,55 @@ k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Seg
   greedy_lane2<true>(ix, s_ct, p, sq, b, wl, gs);
 }
 
+// third-generation Greedy (kj_core.h: g3_book / g3_search): rounds of a bookkeeping kernel (one lane per read still at
+// work) and a search kernel (persistent lanes over the round's task list)
+__global__ void __launch_bounds__(kBlock)
+k_g3_book(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, G3Arrays g, WorkList wl,
+          const uint32_t *list, const uint32_t *count_ptr, uint32_t count_fixed) {
+  __shared__ ConstTables s_ct;
+  load_tables(s_ct, g_ct);
+  const uint32_t n = count_ptr ? *count_ptr : count_fixed;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    g3_book(ix, s_ct, p, sq, b, g, wl, list ? list[i] : i);
+}
+__global__ void __launch_bounds__(kBlock, 4)
+k_g3_search(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Batch b, G3Arrays g, uint32_t *counter,
+            const uint32_t *n_tasks) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  g3_search(ix, *g_ct, p, b, g, counter, n_tasks, s_win + threadIdx.x * kWinStride);
+}
+// counting instantiations (kaiju_gpu_set_count_ops)
+__global__ void __launch_bounds__(kBlock)
+k_g3_book_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, G3Arrays g, WorkList wl,
+                const uint32_t *list, const uint32_t *count_ptr, uint32_t count_fixed) {
+  __shared__ ConstTables s_ct;
+  load_tables(s_ct, g_ct);
+  const uint32_t n = count_ptr ? *count_ptr : count_fixed;
+  uint32_t oc[kOpcN];
+  for (int x = 0; x < kOpcN; x++) oc[x] = 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    g3_book<true>(ix, s_ct, p, sq, b, g, wl, list ? list[i] : i, oc);
+  opc_flush(g.opc, oc);
+}
+__global__ void __launch_bounds__(kBlock, 2)
+k_g3_search_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Batch b, G3Arrays g, uint32_t *counter,
+                  const uint32_t *n_tasks) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  g3_search<true>(ix, *g_ct, p, b, g, counter, n_tasks, s_win + threadIdx.x * kWinStride);
+}
+// reads still at work after the last round: retry pass
+__global__ void __launch_bounds__(kBlock)
+k_g3_flush(Batch b, WorkList wl, const uint32_t *list, const uint32_t *count_ptr) {
+  const uint32_t n = *count_ptr;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint32_t r = list[i];
+    Hit *h = b.hits + r;
+    h->best = 0; h->n_ids = 0; h->reserved = 0;
+    if (wl.retry_list) { wl.retry_list[atomicAdd(wl.retry_count, 1u)] = r; h->flags = kHitRetry; }
+    else h->flags = kHitInternalOverflow;
+  }
+}
+
 // Index load: the k-mer table one letter deeper.  child[idx * 20 + c - 1] = UpdateSI(parent[idx], c)
 // (bwt.c:160-173) for all 20 letters from the two rank blocks at the ends of the parent's interval;
 // empty intervals stay {0, 0}.  One thread per parent, 160 contiguous bytes of children each.
@@ -797,6 +846,9 @@ struct kaiju_gpu_ctx {
   bool mem_v1 = false;             // KAIJU_GPU_MEM_LANE=v1 (read once, at context creation)
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
+  bool greedy3 = true;             // KAIJU_GPU_GREEDY_LANE=v2 / v1: the earlier generations of the Greedy search
+  uint32_t g3_rounds = 128;        // KAIJU_GPU_G3_ROUNDS: rounds launched per batch (reads still at work then: retry pass)
+  DevBuf g3[9];                    // state, priorities, items, matches, best lists, tasks, two read lists, counters
   DevBuf seglist;
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
@@ -814,6 +866,7 @@ struct kaiju_gpu_ctx {
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 10; i++) if (scratch_main[i].p) (void)hipFree(scratch_main[i].p);
     for (int i = 0; i < 5; i++) if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p);
+    for (int i = 0; i < 9; i++) if (g3[i].p) (void)hipFree(g3[i].p);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -880,7 +933,8 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   else {
     c->greedy2 = ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p->seed_length &&
                  p->seed_length >= 3;
-    if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) if (!strcmp(e, "v1")) c->greedy2 = false;
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; if (strcmp(e, "v3")) c->greedy3 = false; }
+    if (const char *e = getenv("KAIJU_GPU_G3_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->g3_rounds = (uint32_t)v; }
     if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (uint32_t)v; }
     // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
     if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate |= (uint32_t)v << 8; }
@@ -1092,6 +1146,9 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     GreedyArrays ga;
     ga.pool_cap = 192; ga.match_cap = 64;
     const bool use_g2 = c->greedy2 && !c->verbose;
+    // third generation: narrow index with a k-mer table (as the second), fragments of at most kWin residues (the strings of
+    // the fast stage 1), no verbose output
+    const bool use_g3 = use_g2 && c->greedy3 && fast1;
     if (!use_g2) {
       if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
       if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
@@ -1122,7 +1179,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       gr.bestv = static_cast<GBestV *>(c->vb_bestv_retry.p);
     }
     GreedyArrays2 g2{};
-    if (use_g2) {
+    if (use_g2 && !use_g3) {
       if ((rc = ensure(c->scratch_main[5], (lanes_main * (8 * kGSlotsAll) + 4) * sizeof(u128)))) return rc;
       if ((rc = ensure(c->scratch_main[6], lanes_main * (kGSlotsAll - kGSlots) * sizeof(uint32_t)))) return rc;
       if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
@@ -1133,7 +1190,52 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       g2.best = static_cast<GBest2 *>(c->scratch_main[9].p);
       g2.gate = c->greedy_gate;
     }
-    if (n > 0) {
+    if (n > 0 && use_g3) {
+      const uint32_t R = c->g3_rounds;
+      const uint32_t task_cap = 4 * n + 64;
+      if ((rc = ensure(c->g3[0], (size_t)n * sizeof(G3State)))) return rc;
+      if ((rc = ensure(c->g3[1], (size_t)n * kG3Q * sizeof(uint32_t)))) return rc;
+      if ((rc = ensure(c->g3[2], (size_t)n * kG3Q * sizeof(G3Item)))) return rc;
+      if ((rc = ensure(c->g3[3], (size_t)n * kG3M * sizeof(GMatch2)))) return rc;
+      if ((rc = ensure(c->g3[4], (size_t)n * 64 * sizeof(GBest2)))) return rc;
+      if ((rc = ensure(c->g3[5], (size_t)task_cap * sizeof(G3Task)))) return rc;
+      if ((rc = ensure(c->g3[6], (size_t)n * 4 + 16))) return rc;
+      if ((rc = ensure(c->g3[7], (size_t)n * 4 + 16))) return rc;
+      if ((rc = ensure(c->g3[8], (size_t)R * 16 + 16))) return rc;
+      KJ_HIP(hipMemsetAsync(c->g3[0].p, 0, (size_t)n * sizeof(G3State), s));      // phase G3_NEW
+      KJ_HIP(hipMemsetAsync(c->g3[8].p, 0, (size_t)R * 16 + 16, s));
+      uint32_t *C4 = static_cast<uint32_t *>(c->g3[8].p);                           // per round: tasks, reads of the next round, work counter
+      uint32_t *lists[2] = {static_cast<uint32_t *>(c->g3[6].p), static_cast<uint32_t *>(c->g3[7].p)};
+      G3Arrays g;
+      g.st = static_cast<G3State *>(c->g3[0].p); g.prio = static_cast<uint32_t *>(c->g3[1].p);
+      g.items = static_cast<G3Item *>(c->g3[2].p); g.matches = static_cast<GMatch2 *>(c->g3[3].p);
+      g.best = static_cast<GBest2 *>(c->g3[4].p); g.tasks = static_cast<G3Task *>(c->g3[5].p); g.task_cap = task_cap;
+      const uint32_t book_blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + kBlock - 1) / kBlock, (uint64_t)c->n_cu * 32);
+      int occ3 = 4;
+      g.opc = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(cnt) + kOpcOffsetBytes);
+      for (uint32_t k = 0; k < R; k++) {
+        g.task_count = C4 + 4 * k; g.next = lists[(k + 1) & 1]; g.next_count = C4 + 4 * k + 1;
+        const uint32_t *lst = k == 0 ? nullptr : lists[k & 1], *lcnt = k == 0 ? nullptr : C4 + 4 * (k - 1) + 1;
+        if (c->count_ops) {
+          hipLaunchKernelGGL(k_g3_book_count, dim3(book_blocks), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, g, wl_main, lst, lcnt, n);
+          hipLaunchKernelGGL(k_g3_search_count, dim3(c->n_cu * 2), blk, 0, s, ix->dev, ix->d_ct, p, b, g, C4 + 4 * k + 2, C4 + 4 * k);
+        } else {
+          hipLaunchKernelGGL(k_g3_book, dim3(book_blocks), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, g, wl_main, lst, lcnt, n);
+          hipLaunchKernelGGL(k_g3_search, dim3(c->n_cu * occ3), blk, 0, s, ix->dev, ix->d_ct, p, b, g, C4 + 4 * k + 2, C4 + 4 * k);
+        }
+      }
+      hipLaunchKernelGGL(k_g3_flush, dim3(c->n_cu), blk, 0, s, b, wl_main, lists[R & 1], C4 + 4 * (R - 1) + 1);
+      KJ_HIP(hipGetLastError());
+      KJ_HIP(hipEventRecord(c->ev[3], s));
+      hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
+      KJ_HIP(hipGetLastError());
+      if (exact_pass) {
+        xp.g_pool = gr.pool; xp.g_ord = gr.ord; xp.g_matches = gr.matches; xp.g_best = gr.best; xp.g_bestv = gr.bestv;
+        xp.g_pool_cap = gr.pool_cap; xp.g_match_cap = gr.match_cap; xp.blocks_search = c->blocks_retry;
+        xp.vb = vb;
+        KJ_HIP(kj_launch_exact_pass(xp));
+      }
+    } else if (n > 0) {
       if (use_g2 && c->count_ops)
         hipLaunchKernelGGL(k_greedy2_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, p, sq, b, wl_main, g2);
       else if (use_g2)

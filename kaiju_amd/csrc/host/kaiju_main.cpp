@@ -256,9 +256,12 @@ struct BlockReader {
     return size;
   }
   void prescan(unsigned threads) {
-    // opt-in (KAIJU_GPU_PRESCAN=1): on the 8-core build box the streaming walk, which overlaps with parsing, is as fast;
-    // meant for hosts with many cores and files in the page cache
-    if (!mapped || prescanned || !getenv("KAIJU_GPU_PRESCAN")) return;
+    // default on hosts with 16 hardware threads or more (one reader thread walks ~13 M records/s, the ceiling of the whole
+    // pipeline there); on the 8-core build box the streaming walk, which overlaps with parsing, is as fast.
+    // KAIJU_GPU_PRESCAN=0 / 1 switches it off / on everywhere
+    const char *pe = getenv("KAIJU_GPU_PRESCAN");
+    const bool want = pe ? atoi(pe) != 0 : std::thread::hardware_concurrency() >= 16;
+    if (!mapped || prescanned || !want) return;
     if (record_end(pos) == NONE) { rec_start.assign(1, size); prescanned = true; return; }   // (also settles fastq / fasta)
     size_t min_bytes = 32u << 20;
     if (const char *e = getenv("KAIJU_GPU_PRESCAN_MIN")) min_bytes = (size_t)atol(e);     // (tests: several threads on small files)
@@ -609,7 +612,16 @@ int main(int argc, char **argv) {
   if (!parse_only) {
     int tax_rc = 0;
     std::thread tax_loader([&] { if (!xmode) tax_rc = kaiju_taxonomy_load(nodes_fn.c_str(), &tax); });
-    rc = kaiju_gpu_index_load_ex(fmi_fn.c_str(), device, xmode ? KAIJU_GPU_IDS_SEQUENCE : KAIJU_GPU_IDS_TAXON, &index);
+    // a device image next to the index (<file>.kjimg, written by `python -m kaiju_amd.mkimage` or KAIJU_GPU_WRITE_IMAGE=1)
+    // that is not older than it loads without parsing and packing (kaiju_gpu_index_write_image)
+    std::string load_fn = fmi_fn;
+    {
+      struct stat sa, sb;
+      const std::string img = fmi_fn + ".kjimg";
+      if (stat(fmi_fn.c_str(), &sa) == 0 && stat(img.c_str(), &sb) == 0 && sb.st_mtime >= sa.st_mtime && !getenv("KAIJU_GPU_NO_IMAGE")) load_fn = img;
+      else if (getenv("KAIJU_GPU_WRITE_IMAGE") && kaiju_gpu_index_write_image(fmi_fn.c_str(), img.c_str()) == 0) load_fn = img;
+    }
+    rc = kaiju_gpu_index_load_ex(load_fn.c_str(), device, xmode ? KAIJU_GPU_IDS_SEQUENCE : KAIJU_GPU_IDS_TAXON, &index);
     tax_loader.join();
     if (tax_rc != 0) die("Could not open file " + nodes_fn);
     if (rc != 0) die(std::string("Could not load ") + fmi_fn + ": " + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");

@@ -1580,7 +1580,7 @@ KJ_HD unsigned long long *opc_of(const WorkList &wl) {
 // a timed launch.
 enum OpCount : int {
   kOpcKmer, kOpcStep, kOpcStepLines, kOpcLf, kOpcLfLines, kOpcSa, kOpcMeta, kOpcFrag, kOpcFill, kOpcTerm, kOpcSiSpill,
-  kOpcHit, kOpcVmulti, kOpcPopItem, kOpcMload, kOpcPush, kOpcMatchWr, kOpcIters, kOpcLaneIters, kOpcN
+  kOpcHit, kOpcVmulti, kOpcPopItem, kOpcMload, kOpcPush, kOpcMatchWr, kOpcIters, kOpcLaneIters, kOpcRecBytes, kOpcN
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 KJ_HD void opc_flush(unsigned long long *dst, const uint32_t *oc) {
@@ -3427,6 +3427,649 @@ if constexpr (COUNT) oc[kOpcTerm]++;
     atomicAdd(acc + 3, st_slow); atomicAdd(acc + 4, st_book); atomicAdd(acc + 5, (unsigned long long)itc << 32 | st_nheavy);
   }
 #endif
+}
+
+// ----------------------------------------------------------------------------
+// Greedy, third generation: the work of a read alternates between two kernels.
+//
+// profiles/r02_recon: k_greedy2 issues 1440 VALU + 720 SALU instructions per wave iteration at 2 waves per SIMD - 64 lanes in
+// 64 different places of a 13-state algorithm make every iteration pay for (nearly) all of it, queue and score
+// bookkeeping included, and the multi-letter rank step alone costs the kernel half its occupancy.  Here
+//   * g3_search (kernel k_g3_search, persistent lanes, the load-phase structure of mem_lane2) does NOTHING but index
+//     work - seed searches of fragments (maxMatches, bwt.c:261-296), continuations of substitution variants
+//     (maxMatches_withStart, :298-336) and the locate walks (ids_from_SI :799-845) - task by task from a list;
+//   * g3_book (kernel k_g3_book, one lane per read that is still at work) does the best-first bookkeeping of
+//     classify_greedyblosum (ConsumerThread.cpp:424-541) on the results: substitution variants of the matches
+//     (addAllMismatchVariantsAtPosSI :346-395, the 19 substitutes of a position ranked straight from the two rank
+//     blocks at the ends of the match's interval), scores (eval_match_scores :751-797), the queue (getNextFragment
+//     :272-342 with the lazy SEG split) - and writes the next tasks.
+// A substitution variant is searched as soon as it is queued (its search does not depend on anything that happens
+// later), so a round of the two kernels advances a read by a whole level of the best-first tree, not by one item.
+// Per read in device memory: a 64-byte state record, kG3Q queue slots (priority + 64-byte item), the matches of the
+// seed search under way, the list of best matches.  Reads that do not fit (queue, matches, 16-bit keys) go to the
+// retry pass (greedy_lane), as with the second generation.
+// ----------------------------------------------------------------------------
+constexpr int kG3Q = 64;                  // queue slots per read
+constexpr int kG3M = 64;                  // matches of one seed search
+constexpr uint32_t kG3Seed = 0x100u, kG3Locate = 0x200u;   // task codes (below kG3Q: continuation of that queue item)
+enum G3Phase : uint32_t { G3_NEW = 0, G3_POP = 1, G3_WAIT_SEED = 2, G3_DONE = 3 };
+constexpr uint32_t kG3NoMatch = 0xffffffffu;
+constexpr uint32_t kG3SeedOrig = 0x80000000u;     // G3State::seed_slot: the seed search is that of an original fragment
+
+struct G3State {             // 64 bytes per read
+  uint32_t best, nbest, flags, qseq;
+  uint32_t qn, qlive, fo, phase;
+  uint32_t b0lo, b0len;      // the first best match (the others in G3Arrays::best)
+  uint32_t seed_slot;        // whose seed search is under way: a queue slot (SEG piece) or kG3SeedOrig
+  uint32_t seed_nm;          // its result: number of matches, bit 31: more than kG3M
+  uint32_t seed_len, seed_tot;
+  uint64_t seed_pep;         // offset of the fragment in Batch::pep
+};
+static_assert(sizeof(G3State) == 64, "G3State is 64 bytes");
+struct G3Item {              // 64 bytes: a queued SEG piece (num_mm 0, searched when it is popped) or substitution variant
+  uint32_t key, start;       // start: offset of the underlying fragment in the read's peptide area
+  uint32_t len_ml;           // length | residues already matched << 16
+  uint32_t nmm_state;        // substitutions | state << 8 (0: no search yet, 1: search queued, 2: result in m_*)
+  int32_t diff;
+  uint32_t tot_msum;         // sum of the BLOSUM62 diagonal over the sequence | ... over the matched suffix << 16
+  uint32_t si0, si1;         // interval the search resumes from; then: m_lo, m_len of the match it found
+  uint32_t sp0, sp1, sp2, sp3, sa0, sa1;   // substituted positions (16 bit each) / letters (8 bit each)
+  uint32_t m_qiql, m_dp;     // the match found: qi | ql << 16 (kG3NoMatch: none), dsum | psum << 16
+};
+static_assert(sizeof(G3Item) == 64, "G3Item is 64 bytes");
+struct G3Task { uint32_t read, code; uint64_t pepoff; };   // pepoff: the read's peptide area in Batch::pep
+struct G3Arrays {
+  G3State *st;               // [n]
+  uint32_t *prio;            // [n][kG3Q] key << 16 | 0xffff - sequence number, 0 = free slot
+  G3Item *items;             // [n][kG3Q]
+  GMatch2 *matches;          // [n][kG3M]
+  GBest2 *best;              // [n][64]
+  G3Task *tasks;             // tasks of this round
+  uint32_t *task_count;
+  uint32_t task_cap;
+  uint32_t *next;            // reads that take part in the next round
+  uint32_t *next_count;
+  unsigned long long *opc;   // counting instantiations: kOpc* totals (else unused)
+};
+
+// residue `pos` of the fragment of an item with its substitutions applied
+KJ_HD uint32_t g3_residue(const uint8_t *pep, uint32_t start, uint32_t nmm, const uint32_t *sp, const uint32_t *sa, uint32_t pos) {
+  uint32_t c = pep[start + pos];
+  for (uint32_t x = 0; x < nmm && x < (uint32_t)kMaxMismatch; x++) {
+    const uint32_t pz = (sp[x >> 1] >> ((x & 1u) * 16u)) & 0xffffu;
+    if (pz == pos) c = (sa[x >> 2] >> ((x & 3u) * 8u)) & 0xffu;
+  }
+  return c;
+}
+
+// The bookkeeping of read r until it has to wait for a search.  `narrow` indexes only (below 2^32 rows).
+template <bool COUNT = false>
+KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq, const Batch &b,
+                   const G3Arrays &g, const WorkList &wl, uint32_t r, uint32_t *oc = nullptr) {
+  // (COUNT: oc[kOpc*] of the calling lane; records are counted in bytes - kOpcRecBytes -, rank blocks in lines)
+#define G3C(idx, v) do { if (COUNT) oc[idx] += (uint32_t)(v); } while (0)
+  G3State S = g.st[r];
+  G3C(kOpcRecBytes, 2 * sizeof(G3State) + sizeof(ReadMeta));
+  uint32_t *prio = g.prio + (size_t)r * kG3Q;
+  G3Item *items = g.items + (size_t)r * kG3Q;
+  const GMatch2 *M = g.matches + (size_t)r * kG3M;
+  GBest2 *bestl = g.best + (size_t)r * 64;
+  const ReadMeta rm = b.meta[r];
+  const uint32_t nf = rm.nfrag & ~kNfragSegPending;
+  const Frag *F = b.frags + rm.frag;
+  const uint8_t *pep = b.pep + rm.pep;
+  Hit *hit = b.hits + r;
+  bool ovf = false;
+
+  auto add_task = [&](uint32_t code) {
+    const uint32_t k = append_slot(g.task_count);
+    if (k < g.task_cap) { G3Task t; t.read = r; t.code = code; t.pepoff = rm.pep; g.tasks[k] = t; }
+    else ovf = true;                                        // (the list holds four tasks per read of the batch)
+    G3C(kOpcRecBytes, sizeof(G3Task));
+  };
+  // multimap emplace of a variant / SEG piece: the slot (or ~0)
+  auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
+    if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; return ~0u; }
+    uint32_t slot = S.qn;
+    if (S.qlive < S.qn) { slot = 0; while (prio[slot] != 0) slot++; }
+    else if (S.qn >= (uint32_t)kG3Q) { ovf = true; return ~0u; }
+    else S.qn++;
+    prio[slot] = key << 16 | (0xffffu - seq);
+    S.qlive++;
+    G3C(kOpcPush, 1); G3C(kOpcRecBytes, sizeof(G3Item) + 4);
+    return slot;
+  };
+  auto eval_match = [&](uint32_t lo, uint32_t len, uint32_t dsum, int32_t diff) {     // eval_match_scores on one match, :751-797
+    const int sc = (int)dsum + diff;                         // calcScore(seq, qi, ql, diff)
+    const uint32_t score = sc > 0 ? (uint32_t)sc : 0u;
+    if (score < p.min_score) return;
+    if (score > S.best) { S.best = score; S.nbest = 0; }
+    if (score == S.best) {
+      if (S.nbest < p.max_matches_SI && S.nbest < 64) {
+        if (S.nbest == 0) { S.b0lo = lo; S.b0len = len; }
+        else { GBest2 gb; gb.lo = lo; gb.len = len; bestl[S.nbest] = gb; G3C(kOpcRecBytes, sizeof(GBest2)); }
+        S.nbest++;
+      } else S.flags |= kHitSiCap;
+    }
+  };
+  // The fragment `t` has been searched and has nm matches (mat(x): the x-th found): variants behind the matches in the
+  // order `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the list of insert_SI_sorted
+  // (bwt.c:225-252), then the scores.
+  struct Cur { uint32_t start, len, nmm, tot; int32_t diff; uint32_t sp[4], sa[2]; };
+  auto after_search = [&](const Cur &t, uint32_t nm, auto &&mat) {
+    if (nm == 0) return;
+    G3C(kOpcMload, nm); G3C(kOpcRecBytes, nm * sizeof(GMatch2));
+    auto ql_of = [&](uint32_t x) -> int { return (int)(mat(x).qiql >> 16); };
+    auto max_below = [&](int bound) -> int { int v = -1; for (uint32_t x = 0; x < nm; x++) { const int q = ql_of(x); if (q < bound && q > v) v = q; } return v; };
+    auto head_of = [&](int v) -> uint32_t { uint32_t x = 0; while (x < nm && ql_of(x) != v) x++; return x; };
+    auto var_match = [&](const GMatch2 &mm) {
+      const uint32_t m_qi = mm.qiql & 0xffffu, m_ql = mm.qiql >> 16, m_dsum = mm.dp & 0xffffu, m_psum = mm.dp >> 16;
+      const uint32_t mre = m_qi + m_ql - 1u;
+      if (!(m_qi > 0 && mre + 1u >= p.m)) return;                                    // :469
+      // addAllMismatchVariantsAtPosSI(t, qi-1, erase_pos, it), :346-395
+      const uint32_t vlen = (mre < t.len - 1u) ? mre + 1u : t.len;                   // fragment.erase(erase_pos)
+      const uint32_t pz = m_qi - 1u;
+      const uint32_t vorig = ct.idx_to_aa[g3_residue(pep, t.start, t.nmm, t.sp, t.sa, pz)];
+      const int sc = (int)m_psum + t.diff;                                           // calcScore(fragment, f->diff)
+      const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
+      const uint32_t vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];          // unsigned wrap as in :363
+      const int boo = (int)ct.b62[vorig][vorig];
+      if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; return; }
+      const uint32_t vlo = mm.lo, vhi = mm.lo + mm.len;
+      const RankBlock64 *pa = ix.blocks64 + (vlo >> 6), *pb = ix.blocks64 + (vhi >> 6);
+      const uint64_t a0 = pa->plane[0], a1 = pa->plane[1], a2 = pa->plane[2], a3 = pa->plane[3], a4 = pa->plane[4];
+      const uint64_t b0 = pb->plane[0], b1 = pb->plane[1], b2 = pb->plane[2], b3 = pb->plane[3], b4 = pb->plane[4];
+      const uint64_t lowA = (1ull << (vlo & 63u)) - 1ull, lowB = (1ull << (vhi & 63u)) - 1ull;
+      G3C(kOpcVmulti, 1); G3C(kOpcStepLines, (vlo >> 6) != (vhi >> 6) ? 2 : 1);
+      for (uint32_t k = 0; k < 19; k++) {
+        const uint32_t sub = ct.subst[vorig][k];                                     // substitutes in descending score
+        const int bos = (int)ct.b62[vorig][sub];
+        const int32_t after = (int32_t)(vscore + (uint32_t)(int32_t)bos);
+        if (!(after >= (int32_t)S.best && after >= (int32_t)p.min_score)) break;    // :368-369, 390-392
+        const uint32_t cx = ct.aa_to_idx[sub];
+        const uint64_t i0 = (cx & 1u) ? 0ull : ~0ull, i1 = (cx & 2u) ? 0ull : ~0ull, i2 = (cx & 4u) ? 0ull : ~0ull,
+                       i3 = (cx & 8u) ? 0ull : ~0ull, i4 = (cx & 16u) ? 0ull : ~0ull;
+        const uint32_t ra = pa->cnt[cx - 1] + popc64((a0 ^ i0) & (a1 ^ i1) & (a2 ^ i2) & (a3 ^ i3) & (a4 ^ i4) & lowA);
+        const uint32_t rb = pb->cnt[cx - 1] + popc64((b0 ^ i0) & (b1 ^ i1) & (b2 ^ i2) & (b3 ^ i3) & (b4 ^ i4) & lowB);
+        if (ra >= rb) continue;                                                      // UpdateSI fails, :372
+        const uint32_t key = (uint32_t)after;
+        const uint32_t sl = push_slot(key, S.qseq + k);
+        if (sl == ~0u) break;
+        const int bss = (int)ct.b62[sub][sub];
+        G3Item it;
+        it.key = key; it.start = t.start; it.len_ml = vlen | (m_ql + 1u) << 16;
+        it.nmm_state = (t.nmm + 1u) | 1u << 8;
+        it.diff = t.diff + bos - bss;
+        it.tot_msum = ((m_psum - (uint32_t)boo + (uint32_t)bss) & 0xffffu) | (m_dsum + (uint32_t)bss) << 16;
+        it.si0 = ra; it.si1 = rb;
+        it.sp0 = t.sp[0]; it.sp1 = t.sp[1]; it.sp2 = t.sp[2]; it.sp3 = t.sp[3]; it.sa0 = t.sa[0]; it.sa1 = t.sa[1];
+        if (t.nmm < (uint32_t)kMaxMismatch) {
+          const uint32_t hs = (t.nmm & 1u) * 16u, hm = ~(0xffffu << hs), pzz = (pz & 0xffffu) << hs;
+          uint32_t *w = t.nmm < 2 ? &it.sp0 : t.nmm < 4 ? &it.sp1 : t.nmm < 6 ? &it.sp2 : &it.sp3;
+          *w = (*w & hm) | pzz;
+          const uint32_t bs = (t.nmm & 3u) * 8u, bm = ~(0xffu << bs);
+          if (t.nmm < 4u) it.sa0 = (it.sa0 & bm) | cx << bs; else it.sa1 = (it.sa1 & bm) | cx << bs;
+        }
+        it.m_qiql = kG3NoMatch; it.m_dp = 0;
+        items[sl] = it;
+        add_task(sl);                                                                // searched in this round already
+      }
+      S.qseq += 19;
+    };
+    if (p.mismatches > 0 && t.nmm < p.mismatches) {
+      if (nm == 1) var_match(mat(0));
+      else {
+        int v = max_below(0x7fffffff);
+        while (v >= 0 && !ovf) {
+          const uint32_t head = head_of(v);
+          uint32_t cnt = 0;
+          for (uint32_t x = head; x < nm; x++) if (ql_of(x) == v) cnt++;
+          var_match(mat(head));
+          if (cnt >= 2) {                                      // the samelen chain (latest insertion first) ends the walk
+            for (uint32_t x = nm; x-- > head + 1 && !ovf;) if (ql_of(x) == v) var_match(mat(x));
+            break;
+          }
+          v = max_below(v);
+        }
+      }
+    }
+    if (ovf) return;
+    // eval_match_scores(si, t), :751-797: the samelen chains of the classes (descending length, while >= m) in
+    // insertion order, then the class heads in ascending length
+    if (nm == 1) {
+      const GMatch2 mm = mat(0);
+      if ((mm.qiql >> 16) >= p.m) eval_match(mm.lo, mm.len, mm.dp & 0xffffu, t.diff);
+      return;
+    }
+    const int v1 = max_below(0x7fffffff);
+    if (v1 < (int)p.m) return;                                                       // :482
+    int v = v1, vlast = v1;
+    for (;;) {
+      const uint32_t head = head_of(v);
+      for (uint32_t x = head + 1; x < nm; x++) if (ql_of(x) == v) { const GMatch2 mm = mat(x); eval_match(mm.lo, mm.len, mm.dp & 0xffffu, t.diff); }
+      const int nv = max_below(v);
+      if (nv < 0 || nv < (int)p.m) { vlast = v; break; }
+      v = nv;
+    }
+    v = vlast;
+    for (;;) {
+      const GMatch2 mm = mat(head_of(v));
+      eval_match(mm.lo, mm.len, mm.dp & 0xffffu, t.diff);
+      if (v == v1) break;
+      int nv = 0x7fffffff;
+      for (uint32_t x = 0; x < nm; x++) { const int q = ql_of(x); if (q > v && q < nv) nv = q; }
+      v = nv;
+    }
+  };
+
+  if (S.phase == G3_NEW) {
+    S.best = 0; S.nbest = 0; S.flags = 0; S.qseq = 0; S.qn = 0; S.qlive = 0; S.fo = 0; S.b0lo = S.b0len = 0;
+    S.seed_slot = 0; S.seed_nm = 0; S.seed_len = S.seed_tot = 0; S.seed_pep = 0;
+    for (uint32_t q = 0; q < (uint32_t)kG3Q; q++) prio[q] = 0;
+    S.phase = G3_POP;
+  } else if (S.phase == G3_WAIT_SEED) {
+    // the seed search of an original / a SEG piece is done
+    if (S.seed_nm & 0x80000000u) ovf = true;
+    else {
+      Cur t; t.start = (uint32_t)(S.seed_pep - rm.pep); t.len = S.seed_len; t.nmm = 0; t.tot = S.seed_tot; t.diff = 0;
+      t.sp[0] = t.sp[1] = t.sp[2] = t.sp[3] = 0; t.sa[0] = t.sa[1] = 0;
+      after_search(t, S.seed_nm, [&](uint32_t x) -> GMatch2 { return M[x]; });
+    }
+    S.phase = G3_POP;
+  }
+  // getNextFragment(best_match_score), ConsumerThread.cpp:272-342, as long as the results of the popped items are there
+  bool finish = false;
+  while (!ovf && S.phase == G3_POP) {
+    uint32_t dbest = 0, dslot = 0;
+    for (uint32_t q = 0; q < S.qn; q++) { const uint32_t pr = prio[q]; if (pr > dbest) { dbest = pr; dslot = q; } }
+    G3C(kOpcRecBytes, 4 * S.qn);
+    const bool have_o = S.fo < nf, have_d = dbest != 0;
+    const uint32_t dkey = dbest >> 16;
+    Frag on; on.start = on.len = on.key = on.flags = 0;
+    if (have_o) { on = F[S.fo]; G3C(kOpcFrag, 1); }
+    if (!have_o && !have_d) { finish = true; break; }
+    const bool pick_o = have_o && (!have_d || on.key >= dkey);   // an original precedes queued entries of its key
+    if ((pick_o ? on.key : dkey) < S.best) { finish = true; break; }
+    if (pick_o) {
+      if (on.key > 0xffffu || on.len > 0xffffu || on.len > (uint32_t)kWin) { ovf = true; break; }
+      S.fo++;
+      if (p.seg && !(on.flags & kFragChecked)) {
+        // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked pieces are queued, and
+        // the next fragment is popped (:291-334)
+        const uint32_t slot = on.flags >> kFragSlotShift;
+        if (slot) {
+          const SegRec rec = sq.recs[slot - 1];
+          G3C(kOpcRecBytes, sizeof(SegRec));
+          if (rec.overflow) S.flags |= kHitInternalOverflow;
+          Frag f; f.start = on.start; f.len = on.len; f.key = on.key; f.flags = 0;
+          seg_split(ct, p, rec, pep, f, [&](const Frag &q) {
+            const uint32_t sl = push_slot(q.key, S.qseq);
+            if (sl == ~0u) return;
+            S.qseq++;
+            G3Item it;
+            it.key = q.key; it.start = q.start; it.len_ml = q.len; it.nmm_state = 0; it.diff = 0; it.tot_msum = q.key & 0xffffu;
+            it.si0 = it.si1 = 0; it.sp0 = it.sp1 = it.sp2 = it.sp3 = it.sa0 = it.sa1 = 0; it.m_qiql = kG3NoMatch; it.m_dp = 0;
+            items[sl] = it;
+          });
+        }
+        continue;
+      }
+      S.seed_slot = kG3SeedOrig; S.seed_len = on.len; S.seed_tot = on.key; S.seed_pep = rm.pep + on.start; S.seed_nm = 0;
+      add_task(kG3Seed);
+      S.phase = G3_WAIT_SEED;
+      break;
+    }
+    // a queued item
+    const G3Item it = items[dslot];
+    G3C(kOpcPopItem, 1); G3C(kOpcRecBytes, sizeof(G3Item));
+    const uint32_t state = (it.nmm_state >> 8) & 255u, nmm = it.nmm_state & 255u;
+    if (state == 1u) break;                                  // its search runs in this round: wait (phase stays G3_POP)
+    prio[dslot] = 0; S.qlive--;
+    if (nmm == 0) {                                          // a SEG piece: maxMatches like an original
+      if ((it.len_ml & 0xffffu) > (uint32_t)kWin) { ovf = true; break; }
+      S.seed_slot = dslot; S.seed_len = it.len_ml & 0xffffu; S.seed_tot = it.tot_msum & 0xffffu; S.seed_pep = rm.pep + it.start; S.seed_nm = 0;
+      add_task(kG3Seed);
+      S.phase = G3_WAIT_SEED;
+      break;
+    }
+    Cur t; t.start = it.start; t.len = it.len_ml & 0xffffu; t.nmm = nmm; t.tot = it.tot_msum & 0xffffu; t.diff = it.diff;
+    t.sp[0] = it.sp0; t.sp[1] = it.sp1; t.sp[2] = it.sp2; t.sp[3] = it.sp3; t.sa[0] = it.sa0; t.sa[1] = it.sa1;
+    GMatch2 one; one.lo = it.si0; one.len = it.si1; one.qiql = it.m_qiql; one.dp = it.m_dp;
+    after_search(t, it.m_qiql == kG3NoMatch ? 0u : 1u, [&](uint32_t) -> GMatch2 { return one; });
+  }
+  if (ovf) {
+    // the read does not fit the bounds of this generation: retry pass
+    hit->best = 0; hit->n_ids = 0; hit->reserved = 0;
+    if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; hit->flags = kHitRetry; }
+    else hit->flags = kHitInternalOverflow;
+    S.phase = G3_DONE;
+  } else if (finish) {
+    hit->reserved = 0;
+    hit->best = S.nbest ? S.best : 0u;
+    hit->flags = S.flags;
+    hit->n_ids = 0;
+    S.phase = G3_DONE;
+    if (S.nbest) add_task(kG3Locate);
+    if (ovf) { hit->best = 0; hit->flags = kHitInternalOverflow; }
+  }
+  g.st[r] = S;
+  if (S.phase != G3_DONE) { g.next[append_slot(g.next_count)] = r; G3C(kOpcRecBytes, 4); }
+  else G3C(kOpcRecBytes, 16);                              // head of the hit record
+#undef G3C
+}
+
+// The search lane of the third generation: persistent, one task at a time per lane, the load-phase structure of
+// mem_lane2 (two rank blocks, one 16-byte load of something else and - wave-uniform - four 16-byte loads of a record or a
+// peptide window per iteration).  Fragments have at most kWin residues here (g3_book sends longer ones to the retry
+// pass), so a task's window is filled once.
+enum G3Kind : int { S_STEP, S_KMER, S_LF1, S_LF2, S_SA, S_BESTE, S_FETCH, S_TASK, S_WIN, S_IDLE, S_EXIT };
+enum G3Bk : int { SB_NONE, SB_END_MATCH, SB_START_J, SB_SEARCH_DONE, SB_LOC_NEXT, SB_LOC_ROW, SB_LOC_DONE };
+
+template <bool COUNT = false>
+KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p, const Batch &b, const G3Arrays &g,
+                     uint32_t *counter, const uint32_t *n_tasks_ptr, uint8_t *win) {
+  typedef uint32_t P;
+  uint32_t oc[kOpcN];
+  if constexpr (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
+  int kind = S_IDLE;
+  uint32_t r = 0, code = 0;
+  uint64_t pepoff = 0, winsrc = 0;
+  // the fragment being searched
+  uint32_t t_matchlen = 0, t_tot = 0, t_msum = 0, t_nmm = 0;
+  uint32_t sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, sa0 = 0, sa1 = 0;
+  int flen = 0, j = 0, i = 0, last_qi = 0;
+  P lo = 0, hi = 0;
+  uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0, kacc = 0;
+  bool m_ovf = false, kroll = false;
+  uint32_t r_lo = 0, r_len = 0, r_qiql = kG3NoMatch, r_dp = 0;       // the match of a continuation
+  // locate
+  uint32_t cur = 0, nbest = 0, nids = 0, flags = 0, b0lo = 0, b0len = 0;
+  P row = 0, rowend = 0, k = 0;
+  uint64_t id0 = 0, sa_idx = 0;
+  bool fresh = true;
+  Hit *hit = nullptr;
+  const P check = (P)((1u << ix.chpt_exp) - 1);
+  const uint32_t n_items = *n_tasks_ptr < g.task_cap ? *n_tasks_ptr : g.task_cap;
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kmer32) ? ix.kmer_k : 0;
+  const uint32_t nwaves = kj_nwaves();
+  uint32_t wnext = 0, wend = 0, item = 0;
+  const RankBlock64 *const blk0 = ix.blocks64;
+  uint32_t kpow = 1;
+  for (uint32_t q = 1; q < kk; q++) kpow *= 20u;
+  uint64_t dg0 = 0, dg1 = 0;                    // BLOSUM62 diagonal by index-alphabet code, 4 bits each (values 4..11)
+  for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
+  for (int x = 16; x < 32; x++) dg1 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * (x - 16));
+  auto diag = [&](uint32_t cc) -> uint32_t { return (uint32_t)(((cc & 16u) ? dg1 : dg0) >> (4u * (cc & 15u))) & 15u; };
+  auto add_tax = [&](uint64_t tax) {
+    bool dup = false;
+    if (nids >= 1 && tax == id0) dup = true;
+    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+  };
+
+  for (;;) {
+    // ---- (0) hand out tasks to the lanes that finished one (wave-uniform control flow, see mem_lane2) ----
+    {
+      const bool need = kind == S_IDLE;
+      const uint64_t mask = kj_ballot(need);
+      if (mask) {
+        const uint32_t n = popc64(mask);
+        const uint32_t rank = kj_rank_below(mask);
+        const uint32_t avail = wend - wnext;
+        uint32_t newbase = 0, ch = 0;
+        if (n > avail) {
+          const uint32_t left = n_items > wend ? n_items - wend : 0;
+          ch = left / (nwaves * 4u);
+          if (ch > 128u) ch = 128u;
+          if (ch < 8u) ch = 8u;
+          if (ch < n - avail) ch = n - avail;
+          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+          uint32_t got = 0;
+          if (need && rank == 0) got = kj_fetch_chunk(counter, ch);
+          newbase = kj_bcast_uniform(got, leader);
+        }
+        if (need) {
+          item = rank < avail ? wnext + rank : newbase + (rank - avail);
+          kind = item >= n_items ? S_EXIT : S_FETCH;
+        }
+        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
+        else wnext += n;
+      }
+      if (kj_ballot(kind != S_EXIT) == 0) break;
+    }
+
+    // ---- (1) load phase ----
+    const bool is_step = kind == S_STEP, is_lf = kind == S_LF1 || kind == S_LF2;
+    const P posA = is_step ? lo : is_lf ? k : 0;
+    const P posB = is_step ? hi : posA;
+    if constexpr (COUNT) {
+      oc[kOpcLaneIters] += kind != S_EXIT ? 1u : 0u;
+      if (kj_lane() == 0) oc[kOpcIters]++;
+      if (kind == S_KMER) oc[kOpcKmer]++;
+      else if (kind == S_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
+      else if (kind == S_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
+      else if (kind == S_SA) oc[kOpcSa]++;
+      else if (kind == S_WIN) oc[kOpcFill]++;
+      else if (kind == S_FETCH) oc[kOpcRecBytes] += (uint32_t)sizeof(G3Task);
+      else if (kind == S_TASK) oc[kOpcRecBytes] += 64u;
+      else if (kind == S_BESTE) oc[kOpcRecBytes] += (uint32_t)sizeof(GBest2);
+    }
+    const uint32_t cc = (is_step || kind == S_LF2) ? c : 1u;
+    const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
+    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
+    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
+    const uint64_t a4 = pa->plane[4];
+    const uint32_t ca = pa->cnt[cc - 1];
+    const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
+    const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
+    const uint64_t b4 = pb->plane[4];
+    const uint32_t cb = pb->cnt[cc - 1];
+    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
+    if (kind == S_KMER) gaddr = reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
+    else if (kind == S_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    else if (kind == S_FETCH) gaddr = reinterpret_cast<const uint8_t *>(g.tasks + item);
+    else if (kind == S_BESTE) gaddr = reinterpret_cast<const uint8_t *>(g.best + (size_t)r * 64 + cur);
+    const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
+    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
+    if (kj_ballot(kind == S_TASK || kind == S_WIN)) {        // wave-uniform
+      const uint8_t *src = reinterpret_cast<const uint8_t *>(blk0);
+      if (kind == S_WIN) src = b.pep + winsrc;
+      else if (kind == S_TASK) src = (code < (uint32_t)kG3Q) ? reinterpret_cast<const uint8_t *>(g.items + (size_t)r * kG3Q + code)
+                                                              : reinterpret_cast<const uint8_t *>(g.st + r);
+      const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
+      w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
+    }
+
+    // ---- (2) compute ----
+    int bk = SB_NONE;
+    if (is_step || kind == S_LF2) {
+      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
+                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
+      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
+      const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
+      if (is_step) {
+        // UpdateSI(str[i-1]) (bwt.c:160-173)
+        const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
+        const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
+        if (ra >= rb) bk = SB_END_MATCH;
+        else {
+          lo = ra; hi = rb; i--; acc += diag(c);
+          if (i == 0) bk = SB_END_MATCH; else c = win[i - 1];
+        }
+      } else {
+        k = ra; fresh = false;                             // second half of an LF step
+        bk = SB_LOC_ROW;
+      }
+    } else if (kind == S_KMER) {
+      const uint64_t e = ghalf ? gv.y : gv.x;
+      lo = (P)e; hi = (P)e + (P)(e >> 32);
+      if (lo >= hi) { i = j; bk = SB_END_MATCH; }          // seed shorter than kk: never recorded, i > 1
+      else {
+        i = j - (int)kk + 1;
+        if (i == 0) bk = SB_END_MATCH; else { c = win[i - 1]; kind = S_STEP; }
+      }
+    } else if (kind == S_LF1) {
+      const uint32_t sft = k & 63u;
+      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
+          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
+      if (c != 0) kind = S_LF2;
+      else {
+        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+        const uint32_t iseq = (uint32_t)rank_term(ix, k);
+        if constexpr (COUNT) oc[kOpcTerm]++;
+        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+        row++;
+        k = row; fresh = true;
+        bk = SB_LOC_ROW;
+      }
+    } else if (kind == S_SA) {
+      const uint64_t tax = ghalf ? gv.y : gv.x;
+      if (tax != ~0ull) add_tax(tax);
+      row++;
+      k = row; fresh = true;
+      bk = SB_LOC_ROW;
+    } else if (kind == S_BESTE) {
+      const uint64_t e = ghalf ? gv.y : gv.x;
+      row = (P)e; rowend = row + (P)(e >> 32);
+      cur++;
+      k = row; fresh = true;
+      bk = SB_LOC_ROW;
+    } else if (kind == S_FETCH) {
+      r = (uint32_t)gv.x; code = (uint32_t)(gv.x >> 32); pepoff = gv.y;
+      kind = S_TASK;
+    } else if (kind == S_TASK) {
+      if (code < (uint32_t)kG3Q) {
+        // continuation of a substitution variant: maxMatches_withStart, bwt.c:298-336
+        const uint32_t start = (uint32_t)(w0.x >> 32), len_ml = (uint32_t)w0.y, nmm_state = (uint32_t)(w0.y >> 32);
+        flen = (int)(len_ml & 0xffffu); t_matchlen = len_ml >> 16; t_nmm = nmm_state & 255u;
+        const uint32_t tm = (uint32_t)(w1.x >> 32);
+        t_tot = tm & 0xffffu; t_msum = tm >> 16;
+        lo = (P)(uint32_t)w1.y; hi = (P)(uint32_t)(w1.y >> 32);
+        sp0 = (uint32_t)w2.x; sp1 = (uint32_t)(w2.x >> 32); sp2 = (uint32_t)w2.y; sp3 = (uint32_t)(w2.y >> 32);
+        sa0 = (uint32_t)w3.x; sa1 = (uint32_t)(w3.x >> 32);
+        winsrc = pepoff + start;
+        kind = S_WIN;
+      } else if (code == kG3Seed) {
+        // maxMatches(seq, len, seed_length, 0) of an original fragment or SEG piece, bwt.c:261-296
+        flen = (int)(uint32_t)w3.x; t_tot = (uint32_t)(w3.x >> 32); winsrc = w3.y;
+        t_nmm = 0; t_matchlen = 0; t_msum = 0;
+        kind = S_WIN;
+      } else {
+        // locate: the ids of the best matches (ids_from_SI :799-845 for every best SI, no samelen walk)
+        nbest = (uint32_t)(w0.x >> 32); flags = (uint32_t)w0.y;
+        b0lo = (uint32_t)w2.x; b0len = (uint32_t)(w2.x >> 32);
+        hit = b.hits + r;
+        nids = 0; cur = 0;
+        bk = SB_LOC_NEXT;
+      }
+    } else if (kind == S_WIN) {
+      uint32_t *d32 = reinterpret_cast<uint32_t *>(win);
+      d32[0] = (uint32_t)w0.x; d32[1] = (uint32_t)(w0.x >> 32); d32[2] = (uint32_t)w0.y; d32[3] = (uint32_t)(w0.y >> 32);
+      d32[4] = (uint32_t)w1.x; d32[5] = (uint32_t)(w1.x >> 32); d32[6] = (uint32_t)w1.y; d32[7] = (uint32_t)(w1.y >> 32);
+      d32[8] = (uint32_t)w2.x; d32[9] = (uint32_t)(w2.x >> 32); d32[10] = (uint32_t)w2.y; d32[11] = (uint32_t)(w2.y >> 32);
+      d32[12] = (uint32_t)w3.x; d32[13] = (uint32_t)(w3.x >> 32); d32[14] = (uint32_t)w3.y; d32[15] = (uint32_t)(w3.y >> 32);
+      // the substitutions of the variant (the reference edits the fragment string, :380)
+      for (uint32_t x = 0; x < t_nmm && x < (uint32_t)kMaxMismatch; x++) {
+        const uint32_t pw = x < 2 ? sp0 : x < 4 ? sp1 : x < 6 ? sp2 : sp3;
+        const int pz = (int)((pw >> ((x & 1u) * 16u)) & 0xffffu);
+        const uint32_t aw = x < 4 ? sa0 : sa1;
+        if (pz < kWin && pz < flen) win[pz] = (uint8_t)(aw >> ((x & 3u) * 8u));
+      }
+      nm = 0; m_ovf = false; kroll = false; r_qiql = kG3NoMatch; r_lo = r_len = r_dp = 0;
+      j = flen - 1;
+      if (t_nmm == 0) { tail = 0; bk = SB_START_J; }
+      else {
+        i = j - (int)t_matchlen + 1;
+        acc = t_msum;
+        if (i <= 0) bk = SB_END_MATCH; else { c = win[i - 1]; kind = S_STEP; }
+      }
+    }
+
+    // ---- (3) bookkeeping ----
+    while (bk != SB_NONE) {
+      if (bk == SB_END_MATCH) {
+        const int l = j - i + 1;
+        if (t_nmm == 0) {
+          if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {        // bwt.c:276-278
+            if (nm < (uint32_t)kG3M) {
+              GMatch2 mm; mm.lo = lo; mm.len = (uint32_t)(hi - lo); mm.qiql = (uint32_t)i | (uint32_t)l << 16; mm.dp = acc | (t_tot - tail) << 16;
+              g.matches[(size_t)r * kG3M + nm] = mm;
+              if constexpr (COUNT) { oc[kOpcMatchWr]++; oc[kOpcRecBytes] += (uint32_t)sizeof(GMatch2); }
+            } else m_ovf = true;
+            nm++;
+            last_qi = i;
+          }
+          if (i <= 1) bk = SB_SEARCH_DONE;                                  // bwt.c:292
+          else { tail += diag(cj); j--; bk = SB_START_J; }
+        } else {
+          // :443-449: after the last allowed mismatch the match must reach min_fragment_length
+          const int Lreq = (t_nmm == p.mismatches) ? (int)p.m : (int)t_matchlen;
+          if (l >= Lreq) { r_lo = lo; r_len = (uint32_t)(hi - lo); r_qiql = (uint32_t)i | (uint32_t)l << 16; r_dp = acc | t_tot << 16; }
+          bk = SB_SEARCH_DONE;
+        }
+      }
+      if (bk == SB_START_J) {
+        if (j < (int)p.seed_length - 1) bk = SB_SEARCH_DONE;
+        else if (kk && j >= (int)kk - 1) {
+          if (kroll) {
+            const uint32_t cn = win[j - (int)kk + 1];
+            kidx = (kidx - (cj - 1u) * kpow) * 20u + (cn - 1u);
+            kacc = kacc - diag(cj) + diag(cn);
+          } else {
+            kidx = 0; kacc = 0;
+            for (uint32_t q = 0; q < kk; q++) {
+              const uint32_t cq = win[j - (int)q];
+              kidx = kmer_index(kidx, cq);
+              kacc += diag(cq);
+            }
+          }
+          cj = win[j]; acc = kacc; kroll = true;
+          kind = S_KMER; bk = SB_NONE;
+        } else {
+          c = cj = win[j]; kroll = false;
+          lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];                              // InitialSI, bwt.c:146-152
+          acc = diag(c);
+          i = j;
+          if (i == 0) { bk = SB_END_MATCH; continue; }
+          c = win[i - 1]; kind = S_STEP; bk = SB_NONE;
+        }
+      }
+      if (bk == SB_SEARCH_DONE) {
+        if (t_nmm == 0) g.st[r].seed_nm = nm | (m_ovf ? 0x80000000u : 0u);
+        else {
+          G3Item *it = g.items + (size_t)r * kG3Q + code;
+          it->si0 = r_lo; it->si1 = r_len; it->m_qiql = r_qiql; it->m_dp = r_dp;
+          it->nmm_state = t_nmm | 2u << 8;
+        }
+        if constexpr (COUNT) oc[kOpcRecBytes] += t_nmm == 0 ? 4u : 20u;
+        kind = S_IDLE; bk = SB_NONE;
+      }
+      if (bk == SB_LOC_NEXT) {
+        if (cur >= nbest) bk = SB_LOC_DONE;
+        else if (cur == 0) { row = b0lo; rowend = b0lo + b0len; cur = 1; k = row; fresh = true; bk = SB_LOC_ROW; }
+        else { kind = S_BESTE; bk = SB_NONE; }
+      }
+      if (bk == SB_LOC_ROW) {
+        // one row of the locate walk: k is a fresh row (k == row) or the row reached by the LF walk
+        for (;;) {
+          if (row >= rowend) { bk = SB_LOC_NEXT; break; }
+          if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = SB_LOC_DONE; break; }     // :805-807
+          if ((k & check) != 0) { kind = S_LF1; bk = SB_NONE; break; }
+          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+          if (sa_idx < ix.n_sa) { kind = S_SA; bk = SB_NONE; break; }
+          row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
+        }
+        if (bk == SB_LOC_NEXT) continue;
+      }
+      if (bk == SB_LOC_DONE) {
+        hit->n_ids = nids; hit->flags = flags;
+        if constexpr (COUNT) { oc[kOpcHit]++; oc[kOpcRecBytes] += 8u * nids; }
+        kind = S_IDLE; bk = SB_NONE;
+      }
+    }
+  }
+  if constexpr (COUNT) opc_flush(g.opc, oc);
 }
 
 // ----------------------------------------------------------------------------

@@ -263,6 +263,28 @@ def test_fullsize_sample_vs_oracle(gpu_lib, oracle, big, mode, seg):
     assert 0.55 < frac < 0.80          # 70 % of the reads come from the database
 
 
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_fullsize_paired_sample_vs_oracle(gpu_lib, oracle, big, mode):
+    """2 x 150-bp pairs at scale (the shape of BASELINE configs[3]): a batch of 500 k pairs, 10 k of them record by record"""
+    api = gpu_lib
+    from kaiju_amd import synth
+    m1, m2 = synth.make_pairs(big["db"], 500000, seed=778)
+    seqs, off = synth.pack_reads(m1, m2)
+    clf = api.Classifier(big["index"], api.default_params(mode, seg=1))
+    hits = clf.classify(seqs, off, paired=True)
+    assert clf.stats().error_flags == 0
+    assert not (hits["flags"] & 0xC0000000).any()
+    sample = np.sort(np.random.default_rng(12).choice(len(hits), size=10000, replace=False))
+    s2, o2 = synth.pack_reads(m1[sample], m2[sample])
+    ix = oracle.load_fmi(f"{big['W']}/db.fmi")
+    oh = oracle.classify(ix, None, oracle.params(mode, seg=1, use_evalue=0), s2, o2, paired=True)
+    bad = [int(sample[i]) for i in range(len(sample)) if not util.same_hit(oh[i], hits[sample[i]])]
+    assert not bad, bad[:5]
+    # the batch split in two gives the same records
+    h1 = clf.classify(*synth.pack_reads(m1[:250000], m2[:250000]), paired=True)
+    assert (h1 == hits[:250000]).all()
+
+
 def test_fullsize_invariants(gpu_lib, big):
     api = gpu_lib
     clf = api.Classifier(big["index"], api.default_params("mem", seg=1))

@@ -1,0 +1,33 @@
+"""kaiju_build_fmi (kaiju_amd/csrc/mkfmi.cpp) writes byte for byte the file that the reference's kaiju-mkbwt +
+kaiju-mkfmi write (the benchmark index is built with it): the committed golden database (its .fmi was made by the
+reference binaries, tests/golden/make_golden.py) and, where oracle/_ref is present, fresh synthetic databases with
+the sequence-count / length corner cases of SURVEY.md 7 and two checkpoint exponents."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+from kaiju_amd import mkfmi, synth
+
+
+def test_golden_fmi_is_reproduced(golden, tmp_path):
+    out = str(tmp_path / "g.fmi")
+    mkfmi.build_fmi(os.path.join(golden.dir, "db.faa"), out, threads=2, exponent=3)
+    assert filecmp.cmp(out, golden.fmi, shallow=False)
+
+
+@pytest.mark.parametrize("nseq,seed,exponent,threads", [(257, 1, 3, 1), (1000, 2, 3, 4), (1531, 3, 5, 3), (64, 4, 2, 8)])
+def test_same_bytes_as_the_reference_builder(tmp_path, nseq, seed, exponent, threads):
+    if not po.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=nseq, seed=seed, leaves=leaves, max_len=900)
+    faa = str(tmp_path / "db.faa")
+    synth.write_fasta(db, faa)
+    ref = po.ref_build_index(faa, str(tmp_path / "ref"), threads=2, exponent=exponent)
+    ours = str(tmp_path / "ours.fmi")
+    mkfmi.build_fmi(faa, ours, threads=threads, exponent=exponent)
+    assert os.path.getsize(ours) == os.path.getsize(ref)
+    assert filecmp.cmp(ours, ref, shallow=False)
