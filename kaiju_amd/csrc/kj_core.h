@@ -3449,9 +3449,11 @@ if constexpr (COUNT) oc[kOpcTerm]++;
 // seed search under way, the list of best matches.  Reads that do not fit (queue, matches, 16-bit keys) go to the
 // retry pass (greedy_lane), as with the second generation.
 // ----------------------------------------------------------------------------
-constexpr int kG3Q = 64;                  // queue slots per read
+constexpr int kG3Q = 128;                 // queue slots per read
 constexpr int kG3M = 64;                  // matches of one seed search
-constexpr uint32_t kG3Seed = 0x100u, kG3Locate = 0x200u;   // task codes (below kG3Q: continuation of that queue item)
+constexpr uint32_t kG3Seed = 0x100u;      // task code of a seed search (below kG3Q: continuation of that queue item)
+constexpr int kG3TaskBuf = 16;            // tasks a read may ask for in one round (more: asked for again in a later round)
+constexpr uint8_t kG3BufSeed = 0xfe;      // task codes as g3_book notes them in the lane's buffer
 enum G3Phase : uint32_t { G3_NEW = 0, G3_POP = 1, G3_WAIT_SEED = 2, G3_DONE = 3 };
 constexpr uint32_t kG3NoMatch = 0xffffffffu;
 constexpr uint32_t kG3SeedOrig = 0x80000000u;     // G3State::seed_slot: the seed search is that of an original fragment
@@ -3484,13 +3486,18 @@ struct G3Arrays {
   G3Item *items;             // [n][kG3Q]
   GMatch2 *matches;          // [n][kG3M]
   GBest2 *best;              // [n][64]
-  G3Task *tasks;             // tasks of this round
+  G3Task *tasks;             // search tasks of this round (kG3TaskBuf per read of the batch: never full)
   uint32_t *task_count;
   uint32_t task_cap;
   uint32_t *next;            // reads that take part in the next round
   uint32_t *next_count;
+  uint32_t *locate;          // reads whose best matches are to be located (all rounds; one kernel at the end)
+  uint32_t *locate_count;
   unsigned long long *opc;   // counting instantiations: kOpc* totals (else unused)
 };
+// what g3_book leaves to its caller (the kernel appends with one atomic per wavefront, not one per lane and task: 30 M
+// atomic adds on one address per million reads took 0.2 s)
+struct G3Out { uint32_t ntasks; bool again, locate; uint64_t pepoff; };
 
 // residue `pos` of the fragment of an item with its substitutions applied
 KJ_HD uint32_t g3_residue(const uint8_t *pep, uint32_t start, uint32_t nmm, const uint32_t *sp, const uint32_t *sa, uint32_t pos) {
@@ -3504,8 +3511,11 @@ KJ_HD uint32_t g3_residue(const uint8_t *pep, uint32_t start, uint32_t nmm, cons
 
 // The bookkeeping of read r until it has to wait for a search.  `narrow` indexes only (below 2^32 rows).
 template <bool COUNT = false>
-KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq, const Batch &b,
-                   const G3Arrays &g, const WorkList &wl, uint32_t r, uint32_t *oc = nullptr) {
+KJ_HD G3Out g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq, const Batch &b,
+                    const G3Arrays &g, const WorkList &wl, uint32_t r, uint8_t *qls, uint8_t *tb, uint32_t *oc = nullptr) {
+  // (qls: kG3M bytes of the lane - LDS on the device - for the lengths of the matches of a seed search; tb: kG3TaskBuf
+  // bytes for the codes of the tasks the read asks for in this round)
+  G3Out out; out.ntasks = 0; out.again = false; out.locate = false;
   // (COUNT: oc[kOpc*] of the calling lane; records are counted in bytes - kOpcRecBytes -, rank blocks in lines)
 #define G3C(idx, v) do { if (COUNT) oc[idx] += (uint32_t)(v); } while (0)
   G3State S = g.st[r];
@@ -3521,17 +3531,27 @@ KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, c
   Hit *hit = b.hits + r;
   bool ovf = false;
 
-  auto add_task = [&](uint32_t code) {
-    const uint32_t k = append_slot(g.task_count);
-    if (k < g.task_cap) { G3Task t; t.read = r; t.code = code; t.pepoff = rm.pep; g.tasks[k] = t; }
-    else ovf = true;                                        // (the list holds four tasks per read of the batch)
+  // a task of this round; false: the read has asked for kG3TaskBuf already (the search is asked for again in a later round)
+  auto add_task = [&](uint32_t code) -> bool {
+    if (out.ntasks >= (uint32_t)kG3TaskBuf) return false;
+    tb[out.ntasks++] = code == kG3Seed ? kG3BufSeed : (uint8_t)code;
     G3C(kOpcRecBytes, sizeof(G3Task));
+    return true;
   };
   // multimap emplace of a variant / SEG piece: the slot (or ~0)
   auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
     if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; return ~0u; }
     uint32_t slot = S.qn;
-    if (S.qlive < S.qn) { slot = 0; while (prio[slot] != 0) slot++; }
+    if (S.qlive < S.qn) {
+      slot = 0;
+      for (uint32_t q = 0; q < S.qn; q += 4) {               // (four priorities per load)
+        const u128 v = *reinterpret_cast<const u128 *>(prio + q);
+        const uint32_t e[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
+        int hit4 = -1;
+        for (int x = 3; x >= 0; x--) if (e[x] == 0 && q + (uint32_t)x < S.qn) hit4 = x;
+        if (hit4 >= 0) { slot = q + (uint32_t)hit4; break; }
+      }
+    }
     else if (S.qn >= (uint32_t)kG3Q) { ovf = true; return ~0u; }
     else S.qn++;
     prio[slot] = key << 16 | (0xffffu - seq);
@@ -3559,7 +3579,8 @@ KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, c
   auto after_search = [&](const Cur &t, uint32_t nm, auto &&mat) {
     if (nm == 0) return;
     G3C(kOpcMload, nm); G3C(kOpcRecBytes, nm * sizeof(GMatch2));
-    auto ql_of = [&](uint32_t x) -> int { return (int)(mat(x).qiql >> 16); };
+    if (nm > 1) for (uint32_t x = 0; x < nm; x++) qls[x] = (uint8_t)(mat(x).qiql >> 16);   // (lengths <= kWin)
+    auto ql_of = [&](uint32_t x) -> int { return (int)qls[x]; };
     auto max_below = [&](int bound) -> int { int v = -1; for (uint32_t x = 0; x < nm; x++) { const int q = ql_of(x); if (q < bound && q > v) v = q; } return v; };
     auto head_of = [&](int v) -> uint32_t { uint32_t x = 0; while (x < nm && ql_of(x) != v) x++; return x; };
     auto var_match = [&](const GMatch2 &mm) {
@@ -3611,8 +3632,8 @@ KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, c
           if (t.nmm < 4u) it.sa0 = (it.sa0 & bm) | cx << bs; else it.sa1 = (it.sa1 & bm) | cx << bs;
         }
         it.m_qiql = kG3NoMatch; it.m_dp = 0;
-        items[sl] = it;
-        add_task(sl);                                                                // searched in this round already
+        if (!add_task(sl)) it.nmm_state = t.nmm + 1u;                                // searched in this round already (state 1),
+        items[sl] = it;                                                              // or asked for when it is popped (state 0)
       }
       S.qseq += 19;
     };
@@ -3681,7 +3702,11 @@ KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, c
   bool finish = false;
   while (!ovf && S.phase == G3_POP) {
     uint32_t dbest = 0, dslot = 0;
-    for (uint32_t q = 0; q < S.qn; q++) { const uint32_t pr = prio[q]; if (pr > dbest) { dbest = pr; dslot = q; } }
+    for (uint32_t q = 0; q < S.qn; q += 4) {                 // (four priorities per load; slots >= qn hold 0)
+      const u128 v = *reinterpret_cast<const u128 *>(prio + q);
+      const uint32_t e[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
+      for (uint32_t x = 0; x < 4; x++) if (e[x] > dbest) { dbest = e[x]; dslot = q + x; }
+    }
     G3C(kOpcRecBytes, 4 * S.qn);
     const bool have_o = S.fo < nf, have_d = dbest != 0;
     const uint32_t dkey = dbest >> 16;
@@ -3715,8 +3740,8 @@ KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, c
         continue;
       }
       S.seed_slot = kG3SeedOrig; S.seed_len = on.len; S.seed_tot = on.key; S.seed_pep = rm.pep + on.start; S.seed_nm = 0;
-      add_task(kG3Seed);
-      S.phase = G3_WAIT_SEED;
+      if (add_task(kG3Seed)) S.phase = G3_WAIT_SEED;
+      else S.fo--;                                           // no room in this round's list: popped again in the next round
       break;
     }
     // a queued item
@@ -3724,14 +3749,19 @@ KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, c
     G3C(kOpcPopItem, 1); G3C(kOpcRecBytes, sizeof(G3Item));
     const uint32_t state = (it.nmm_state >> 8) & 255u, nmm = it.nmm_state & 255u;
     if (state == 1u) break;                                  // its search runs in this round: wait (phase stays G3_POP)
-    prio[dslot] = 0; S.qlive--;
+    if (nmm != 0 && state == 0u) {                           // its search found no room in the list of its round
+      if (add_task(dslot)) items[dslot].nmm_state = nmm | 1u << 8;
+      break;
+    }
     if (nmm == 0) {                                          // a SEG piece: maxMatches like an original
       if ((it.len_ml & 0xffffu) > (uint32_t)kWin) { ovf = true; break; }
       S.seed_slot = dslot; S.seed_len = it.len_ml & 0xffffu; S.seed_tot = it.tot_msum & 0xffffu; S.seed_pep = rm.pep + it.start; S.seed_nm = 0;
-      add_task(kG3Seed);
+      if (!add_task(kG3Seed)) break;
+      prio[dslot] = 0; S.qlive--;
       S.phase = G3_WAIT_SEED;
       break;
     }
+    prio[dslot] = 0; S.qlive--;
     Cur t; t.start = it.start; t.len = it.len_ml & 0xffffu; t.nmm = nmm; t.tot = it.tot_msum & 0xffffu; t.diff = it.diff;
     t.sp[0] = it.sp0; t.sp[1] = it.sp1; t.sp[2] = it.sp2; t.sp[3] = it.sp3; t.sa[0] = it.sa0; t.sa[1] = it.sa1;
     GMatch2 one; one.lo = it.si0; one.len = it.si1; one.qiql = it.m_qiql; one.dp = it.m_dp;
@@ -3749,21 +3779,32 @@ KJ_HD void g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, c
     hit->flags = S.flags;
     hit->n_ids = 0;
     S.phase = G3_DONE;
-    if (S.nbest) add_task(kG3Locate);
-    if (ovf) { hit->best = 0; hit->flags = kHitInternalOverflow; }
+    out.locate = S.nbest != 0;
   }
   g.st[r] = S;
-  if (S.phase != G3_DONE) { g.next[append_slot(g.next_count)] = r; G3C(kOpcRecBytes, 4); }
-  else G3C(kOpcRecBytes, 16);                              // head of the hit record
+  out.again = S.phase != G3_DONE;
+  out.pepoff = rm.pep;
+  G3C(kOpcRecBytes, out.again ? 4 : 16);                    // the list of the next round / the head of the hit record
 #undef G3C
+  return out;
+}
+// the appends of one lane without wave-level aggregation (host emulation; the kernels do this per wavefront)
+KJ_HD void g3_flush_lane(const G3Arrays &g, uint32_t r, const G3Out &o, const uint8_t *tb) {
+  for (uint32_t k = 0; k < o.ntasks; k++) {
+    const uint32_t at = append_slot(g.task_count);
+    G3Task t; t.read = r; t.code = tb[k] == kG3BufSeed ? kG3Seed : (uint32_t)tb[k]; t.pepoff = o.pepoff;
+    g.tasks[at] = t;
+  }
+  if (o.again) g.next[append_slot(g.next_count)] = r;
+  if (o.locate) g.locate[append_slot(g.locate_count)] = r;
 }
 
 // The search lane of the third generation: persistent, one task at a time per lane, the load-phase structure of
 // mem_lane2 (two rank blocks, one 16-byte load of something else and - wave-uniform - four 16-byte loads of a record or a
 // peptide window per iteration).  Fragments have at most kWin residues here (g3_book sends longer ones to the retry
 // pass), so a task's window is filled once.
-enum G3Kind : int { S_STEP, S_KMER, S_LF1, S_LF2, S_SA, S_BESTE, S_FETCH, S_TASK, S_WIN, S_IDLE, S_EXIT };
-enum G3Bk : int { SB_NONE, SB_END_MATCH, SB_START_J, SB_SEARCH_DONE, SB_LOC_NEXT, SB_LOC_ROW, SB_LOC_DONE };
+enum G3Kind : int { S_STEP, S_KMER, S_FETCH, S_TASK, S_WIN, S_IDLE, S_EXIT };
+enum G3Bk : int { SB_NONE, SB_END_MATCH, SB_START_J, SB_SEARCH_DONE };
 
 template <bool COUNT = false>
 KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p, const Batch &b, const G3Arrays &g,
@@ -3782,13 +3823,6 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
   uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0, kacc = 0;
   bool m_ovf = false, kroll = false;
   uint32_t r_lo = 0, r_len = 0, r_qiql = kG3NoMatch, r_dp = 0;       // the match of a continuation
-  // locate
-  uint32_t cur = 0, nbest = 0, nids = 0, flags = 0, b0lo = 0, b0len = 0;
-  P row = 0, rowend = 0, k = 0;
-  uint64_t id0 = 0, sa_idx = 0;
-  bool fresh = true;
-  Hit *hit = nullptr;
-  const P check = (P)((1u << ix.chpt_exp) - 1);
   const uint32_t n_items = *n_tasks_ptr < g.task_cap ? *n_tasks_ptr : g.task_cap;
   const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kmer32) ? ix.kmer_k : 0;
   const uint32_t nwaves = kj_nwaves();
@@ -3800,12 +3834,6 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
   for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
   for (int x = 16; x < 32; x++) dg1 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * (x - 16));
   auto diag = [&](uint32_t cc) -> uint32_t { return (uint32_t)(((cc & 16u) ? dg1 : dg0) >> (4u * (cc & 15u))) & 15u; };
-  auto add_tax = [&](uint64_t tax) {
-    bool dup = false;
-    if (nids >= 1 && tax == id0) dup = true;
-    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
-  };
 
   for (;;) {
     // ---- (0) hand out tasks to the lanes that finished one (wave-uniform control flow, see mem_lane2) ----
@@ -3839,22 +3867,19 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
     }
 
     // ---- (1) load phase ----
-    const bool is_step = kind == S_STEP, is_lf = kind == S_LF1 || kind == S_LF2;
-    const P posA = is_step ? lo : is_lf ? k : 0;
+    const bool is_step = kind == S_STEP;
+    const P posA = is_step ? lo : 0;
     const P posB = is_step ? hi : posA;
     if constexpr (COUNT) {
       oc[kOpcLaneIters] += kind != S_EXIT ? 1u : 0u;
       if (kj_lane() == 0) oc[kOpcIters]++;
       if (kind == S_KMER) oc[kOpcKmer]++;
       else if (kind == S_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
-      else if (kind == S_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
-      else if (kind == S_SA) oc[kOpcSa]++;
       else if (kind == S_WIN) oc[kOpcFill]++;
       else if (kind == S_FETCH) oc[kOpcRecBytes] += (uint32_t)sizeof(G3Task);
       else if (kind == S_TASK) oc[kOpcRecBytes] += 64u;
-      else if (kind == S_BESTE) oc[kOpcRecBytes] += (uint32_t)sizeof(GBest2);
     }
-    const uint32_t cc = (is_step || kind == S_LF2) ? c : 1u;
+    const uint32_t cc = is_step ? c : 1u;
     const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
     const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
     const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
@@ -3866,9 +3891,7 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
     const uint32_t cb = pb->cnt[cc - 1];
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
     if (kind == S_KMER) gaddr = reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
-    else if (kind == S_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == S_FETCH) gaddr = reinterpret_cast<const uint8_t *>(g.tasks + item);
-    else if (kind == S_BESTE) gaddr = reinterpret_cast<const uint8_t *>(g.best + (size_t)r * 64 + cur);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
     const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
     u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
@@ -3883,23 +3906,18 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
 
     // ---- (2) compute ----
     int bk = SB_NONE;
-    if (is_step || kind == S_LF2) {
+    if (is_step) {
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
       const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
-      if (is_step) {
-        // UpdateSI(str[i-1]) (bwt.c:160-173)
-        const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
-        const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
-        if (ra >= rb) bk = SB_END_MATCH;
-        else {
-          lo = ra; hi = rb; i--; acc += diag(c);
-          if (i == 0) bk = SB_END_MATCH; else c = win[i - 1];
-        }
-      } else {
-        k = ra; fresh = false;                             // second half of an LF step
-        bk = SB_LOC_ROW;
+      // UpdateSI(str[i-1]) (bwt.c:160-173)
+      const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
+      const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
+      if (ra >= rb) bk = SB_END_MATCH;
+      else {
+        lo = ra; hi = rb; i--; acc += diag(c);
+        if (i == 0) bk = SB_END_MATCH; else c = win[i - 1];
       }
     } else if (kind == S_KMER) {
       const uint64_t e = ghalf ? gv.y : gv.x;
@@ -3909,32 +3927,6 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
         i = j - (int)kk + 1;
         if (i == 0) bk = SB_END_MATCH; else { c = win[i - 1]; kind = S_STEP; }
       }
-    } else if (kind == S_LF1) {
-      const uint32_t sft = k & 63u;
-      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
-          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
-      if (c != 0) kind = S_LF2;
-      else {
-        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
-        const uint32_t iseq = (uint32_t)rank_term(ix, k);
-        if constexpr (COUNT) oc[kOpcTerm]++;
-        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
-        row++;
-        k = row; fresh = true;
-        bk = SB_LOC_ROW;
-      }
-    } else if (kind == S_SA) {
-      const uint64_t tax = ghalf ? gv.y : gv.x;
-      if (tax != ~0ull) add_tax(tax);
-      row++;
-      k = row; fresh = true;
-      bk = SB_LOC_ROW;
-    } else if (kind == S_BESTE) {
-      const uint64_t e = ghalf ? gv.y : gv.x;
-      row = (P)e; rowend = row + (P)(e >> 32);
-      cur++;
-      k = row; fresh = true;
-      bk = SB_LOC_ROW;
     } else if (kind == S_FETCH) {
       r = (uint32_t)gv.x; code = (uint32_t)(gv.x >> 32); pepoff = gv.y;
       kind = S_TASK;
@@ -3950,18 +3942,11 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
         sa0 = (uint32_t)w3.x; sa1 = (uint32_t)(w3.x >> 32);
         winsrc = pepoff + start;
         kind = S_WIN;
-      } else if (code == kG3Seed) {
+      } else {
         // maxMatches(seq, len, seed_length, 0) of an original fragment or SEG piece, bwt.c:261-296
         flen = (int)(uint32_t)w3.x; t_tot = (uint32_t)(w3.x >> 32); winsrc = w3.y;
         t_nmm = 0; t_matchlen = 0; t_msum = 0;
         kind = S_WIN;
-      } else {
-        // locate: the ids of the best matches (ids_from_SI :799-845 for every best SI, no samelen walk)
-        nbest = (uint32_t)(w0.x >> 32); flags = (uint32_t)w0.y;
-        b0lo = (uint32_t)w2.x; b0len = (uint32_t)(w2.x >> 32);
-        hit = b.hits + r;
-        nids = 0; cur = 0;
-        bk = SB_LOC_NEXT;
       }
     } else if (kind == S_WIN) {
       uint32_t *d32 = reinterpret_cast<uint32_t *>(win);
@@ -4045,27 +4030,154 @@ KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p,
         if constexpr (COUNT) oc[kOpcRecBytes] += t_nmm == 0 ? 4u : 20u;
         kind = S_IDLE; bk = SB_NONE;
       }
-      if (bk == SB_LOC_NEXT) {
-        if (cur >= nbest) bk = SB_LOC_DONE;
-        else if (cur == 0) { row = b0lo; rowend = b0lo + b0len; cur = 1; k = row; fresh = true; bk = SB_LOC_ROW; }
-        else { kind = S_BESTE; bk = SB_NONE; }
+    }
+  }
+  if constexpr (COUNT) opc_flush(g.opc, oc);
+}
+
+// The locate walks of the third generation, one kernel behind the rounds: for every listed read the ids of its best
+// matches (ids_from_SI ConsumerThread.cpp:799-845 for every best SI in turn, no samelen walk; get_suffix bwt.c:105-121),
+// persistent lanes, one LF step or one SA sample per iteration.
+enum G3LKind : int { L_LF1, L_LF2, L_SA, L_BESTE, L_FETCH, L_STATE, L_IDLE, L_EXIT };
+template <bool COUNT = false>
+KJ_HD void g3_locate(const DevIndex &ix, const Params &p, const Batch &b, const G3Arrays &g, uint32_t *counter) {
+  typedef uint32_t P;
+  uint32_t oc[kOpcN];
+  if constexpr (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
+  int kind = L_IDLE;
+  uint32_t r = 0, c = 1, cur = 0, nbest = 0, nids = 0, flags = 0, b0lo = 0, b0len = 0;
+  P row = 0, rowend = 0, k = 0;
+  uint64_t id0 = 0, sa_idx = 0;
+  bool fresh = true;
+  Hit *hit = nullptr;
+  const P check = (P)((1u << ix.chpt_exp) - 1);
+  const uint32_t n_items = *g.locate_count;
+  const uint32_t nwaves = kj_nwaves();
+  uint32_t wnext = 0, wend = 0, item = 0;
+  const RankBlock64 *const blk0 = ix.blocks64;
+  auto add_tax = [&](uint64_t tax) {
+    bool dup = false;
+    if (nids >= 1 && tax == id0) dup = true;
+    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+  };
+  for (;;) {
+    {
+      const bool need = kind == L_IDLE;
+      const uint64_t mask = kj_ballot(need);
+      if (mask) {
+        const uint32_t n = popc64(mask);
+        const uint32_t rank = kj_rank_below(mask);
+        const uint32_t avail = wend - wnext;
+        uint32_t newbase = 0, ch = 0;
+        if (n > avail) {
+          const uint32_t left = n_items > wend ? n_items - wend : 0;
+          ch = left / (nwaves * 4u);
+          if (ch > 128u) ch = 128u;
+          if (ch < 8u) ch = 8u;
+          if (ch < n - avail) ch = n - avail;
+          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+          uint32_t got = 0;
+          if (need && rank == 0) got = kj_fetch_chunk(counter, ch);
+          newbase = kj_bcast_uniform(got, leader);
+        }
+        if (need) {
+          item = rank < avail ? wnext + rank : newbase + (rank - avail);
+          kind = item >= n_items ? L_EXIT : L_FETCH;
+        }
+        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
+        else wnext += n;
       }
-      if (bk == SB_LOC_ROW) {
-        // one row of the locate walk: k is a fresh row (k == row) or the row reached by the LF walk
+      if (kj_ballot(kind != L_EXIT) == 0) break;
+    }
+    const bool is_lf = kind == L_LF1 || kind == L_LF2;
+    const P posA = is_lf ? k : 0;
+    const uint32_t cc = kind == L_LF2 ? c : 1u;
+    const RankBlock64 *pa = blk0 + (posA >> 6);
+    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
+    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
+    const uint64_t a4 = pa->plane[4];
+    const uint32_t ca = pa->cnt[cc - 1];
+    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
+    if (kind == L_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    else if (kind == L_FETCH) gaddr = reinterpret_cast<const uint8_t *>(g.locate + item);
+    else if (kind == L_BESTE) gaddr = reinterpret_cast<const uint8_t *>(g.best + (size_t)r * 64 + cur);
+    else if (kind == L_STATE) gaddr = reinterpret_cast<const uint8_t *>(g.st + r);
+    const uint32_t goff = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) & 15u);
+    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    u128 g2{0, 0};
+    if (kj_ballot(kind == L_STATE)) g2 = *reinterpret_cast<const u128 *>(kind == L_STATE ? reinterpret_cast<const uint8_t *>(g.st + r) + 32 : reinterpret_cast<const uint8_t *>(blk0));
+    if constexpr (COUNT) {
+      if (kind == L_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
+      else if (kind == L_SA) oc[kOpcSa]++;
+      else if (kind == L_FETCH) oc[kOpcRecBytes] += 4u;
+      else if (kind == L_STATE) oc[kOpcRecBytes] += 32u;
+      else if (kind == L_BESTE) oc[kOpcRecBytes] += (uint32_t)sizeof(GBest2);
+    }
+    int bk = 0;                                              // 1: next best match, 2: next row, 3: done
+    if (kind == L_LF2) {
+      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
+                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
+      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
+      k = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
+      fresh = false;
+      bk = 2;
+    } else if (kind == L_LF1) {
+      const uint32_t sft = k & 63u;
+      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
+          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
+      if (c != 0) kind = L_LF2;
+      else {
+        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+        const uint32_t iseq = (uint32_t)rank_term(ix, k);
+        if constexpr (COUNT) oc[kOpcTerm]++;
+        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+        row++; k = row; fresh = true;
+        bk = 2;
+      }
+    } else if (kind == L_SA) {
+      const uint64_t tax = goff & 8u ? gv.y : gv.x;
+      if (tax != ~0ull) add_tax(tax);
+      row++; k = row; fresh = true;
+      bk = 2;
+    } else if (kind == L_BESTE) {
+      const uint64_t e = goff & 8u ? gv.y : gv.x;
+      row = (P)e; rowend = row + (P)(e >> 32);
+      cur++; k = row; fresh = true;
+      bk = 2;
+    } else if (kind == L_FETCH) {
+      const uint32_t w4[4] = {(uint32_t)gv.x, (uint32_t)(gv.x >> 32), (uint32_t)gv.y, (uint32_t)(gv.y >> 32)};
+      r = w4[goff >> 2];
+      kind = L_STATE;
+    } else if (kind == L_STATE) {
+      nbest = (uint32_t)(gv.x >> 32); flags = (uint32_t)gv.y;
+      b0lo = (uint32_t)g2.x; b0len = (uint32_t)(g2.x >> 32);
+      hit = b.hits + r;
+      nids = 0; cur = 0;
+      bk = 1;
+    }
+    while (bk) {
+      if (bk == 1) {
+        if (cur >= nbest) bk = 3;
+        else if (cur == 0) { row = b0lo; rowend = b0lo + b0len; cur = 1; k = row; fresh = true; bk = 2; }
+        else { kind = L_BESTE; bk = 0; }
+      }
+      if (bk == 2) {
+        // one row of the walk: k is a fresh row (k == row) or the row reached by the LF walk
         for (;;) {
-          if (row >= rowend) { bk = SB_LOC_NEXT; break; }
-          if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = SB_LOC_DONE; break; }     // :805-807
-          if ((k & check) != 0) { kind = S_LF1; bk = SB_NONE; break; }
+          if (row >= rowend) { bk = 1; break; }
+          if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = 3; break; }     // :805-807
+          if ((k & check) != 0) { kind = L_LF1; bk = 0; break; }
           sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-          if (sa_idx < ix.n_sa) { kind = S_SA; bk = SB_NONE; break; }
+          if (sa_idx < ix.n_sa) { kind = L_SA; bk = 0; break; }
           row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
         }
-        if (bk == SB_LOC_NEXT) continue;
+        if (bk == 1) continue;
       }
-      if (bk == SB_LOC_DONE) {
+      if (bk == 3) {
         hit->n_ids = nids; hit->flags = flags;
         if constexpr (COUNT) { oc[kOpcHit]++; oc[kOpcRecBytes] += 8u * nids; }
-        kind = S_IDLE; bk = SB_NONE;
+        kind = L_IDLE; bk = 0;
       }
     }
   }

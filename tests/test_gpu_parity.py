@@ -59,6 +59,47 @@ def test_golden_single(gpu_lib, golden, gidx, oracle, ohandles, mode, seg):
 
 
 @pytest.mark.parametrize("mode,seg", CASES)
+def test_golden_short_reads_fast_path(gpu_lib, golden, gidx, oracle, ohandles, mode, seg, monkeypatch):
+    """a batch of short reads only: k_fragments_fast and, MEM, the lazy SEG flow (the whole golden set holds 1000-nt reads
+    and takes the general stage 1); vs the oracle, the reference's lines and the general path (KAIJU_GPU_STAGE1=old)"""
+    api = gpu_lib
+    idx, seqs, off = golden.short()
+    clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
+    hits = clf.classify(seqs, off)
+    assert clf.stats().error_flags == 0
+    ix, tax = ohandles
+    oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), seqs, off)
+    bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+    assert not bad, (bad[:5], oh[bad[0]], hits[bad[0]])
+    got = finalize_records(api, clf, api.Taxonomy(golden.nodes), hits, off)
+    ref = golden.tsv(f"ref_{mode}_{seg}.tsv")
+    names = [golden.names[i] for i in idx]
+    assert not [(n, g) for n, g in zip(names, got) if g != ref[n]]
+    monkeypatch.setenv("KAIJU_GPU_STAGE1", "old")
+    h2 = api.Classifier(gidx, api.default_params(mode, seg=seg)).classify(seqs, off)
+    assert (h2 == hits).all()
+
+
+def test_greedy_third_generation_on_device(gpu_lib, golden, gidx, oracle, ohandles, monkeypatch):
+    """KAIJU_GPU_GREEDY_LANE=v3: the two-kernel rounds (experimental); short reads and pairs vs the oracle, also with too few
+    rounds (leftovers go to the retry pass)"""
+    api = gpu_lib
+    ix, tax = ohandles
+    _, sseqs, soff = golden.short()
+    monkeypatch.setenv("KAIJU_GPU_GREEDY_LANE", "v3")
+    for rounds in ("128", "9"):
+        monkeypatch.setenv("KAIJU_GPU_G3_ROUNDS", rounds)
+        for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True)):
+            clf = api.Classifier(gidx, api.default_params("greedy", seg=1))
+            hits = clf.classify(seqs, off, paired=pe)
+            st = clf.stats()
+            assert st.error_flags == 0 and (st.n_overflow_retries > 0) == (rounds == "9")
+            oh = oracle.classify(ix, tax, oracle.params("greedy", seg=1, use_evalue=0), seqs, off, paired=pe)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+            assert not bad, (rounds, pe, bad[:5])
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
 def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
     """k_lca: hit records -> 16-byte records on the device; finalize_compact == finalize_hits == reference lines"""
     api = gpu_lib

@@ -75,6 +75,41 @@ def test_lanes_vs_oracle_paired(oracle, emu, golden, handles, mode, seg):
 
 
 @pytest.mark.parametrize("mode,seg", CASES)
+def test_fast_stage1_and_lazy_seg_on_short_reads(oracle, emu, golden, handles, mode, seg, monkeypatch):
+    """batches of short reads take the fast stage 1 (build_fragments_fast) and, MEM, the lazy SEG flow; the same batch
+    through the general stage 1 (KAIJU_EMU_STAGE1_OLD) must give the same records and the same fragment lists"""
+    h, ix, tax = handles
+    idx, seqs, off = golden.short()
+    assert len(idx) > 600
+    oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), seqs, off)
+    gh, _, frags_fast = emu.classify(h, util.gp(mode, seg=seg), seqs, off, want_frags=True)
+    bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+    assert not bad, (bad[:5], oh[bad[0]], gh[bad[0]])
+    monkeypatch.setenv("KAIJU_EMU_STAGE1_OLD", "1")
+    g2, _, frags_old = emu.classify(h, util.gp(mode, seg=seg), seqs, off, want_frags=True)
+    assert (g2 == gh).all()
+    if not (mode == "mem" and seg):            # (lazy SEG leaves the lists of most reads unsplit: compared only where both split eagerly)
+        assert frags_fast == frags_old
+
+
+@pytest.mark.parametrize("seg", [1, 0])
+def test_greedy_third_generation(oracle, emu, golden, handles, seg, monkeypatch):
+    """the two-kernel rounds of the third-generation Greedy search (g3_book / g3_search / g3_locate; experimental on the
+    device, KAIJU_GPU_GREEDY_LANE=v3): single reads and pairs, also with few rounds (leftovers -> retry pass)"""
+    h, ix, tax = handles
+    monkeypatch.setenv("KAIJU_EMU_GREEDY", "v3")
+    _, sseqs, soff = golden.short()
+    for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True)):
+        oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg, use_evalue=0), seqs, off, paired=pe)
+        for rounds in ("128", "9"):
+            monkeypatch.setenv("KAIJU_EMU_G3_ROUNDS", rounds)
+            gh, nretry = emu.classify(h, util.gp("greedy", seg=seg), seqs, off, paired=pe)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+            assert not bad, (seg, pe, rounds, bad[:5])
+            assert (nretry > 0) == (rounds == "9")
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
 def test_retry_pass(oracle, emu, golden, handles, mode, seg, monkeypatch):
     """scratch far too small in the main pass: every overflowing read must come out right
     from the retry pass"""

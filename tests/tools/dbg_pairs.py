@@ -1,5 +1,6 @@
 import sys, os
-sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(R, "tests")); sys.path.insert(0, os.path.join(R, "oracle")); sys.path.insert(0, R)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, util, pyoracle as po
 from kaiju_amd import api
 g = util.Golden(); O = po.Oracle(); oix, otax = O.load_fmi(g.fmi), O.load_nodes(g.nodes)

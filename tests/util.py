@@ -187,6 +187,13 @@ class Golden:
     def tsv(self, name):
         return parse_tsv(os.path.join(GOLD, name))
 
+    def short(self, max_len=191):
+        """(indices, seqs, off) of the golden single reads of at most max_len nucleotides: batches the fast stage 1 serves
+        (kj_core.h: kS1MaxLen), lazy SEG and all - the whole set holds 301- and 1000-nt reads and takes the general path"""
+        idx = [i for i, r in enumerate(self.reads) if len(r) <= max_len]
+        seqs, off = pack([self.reads[i] for i in idx])
+        return idx, seqs, off
+
 
 def oracle_records(hits):
     """oracle hits -> list of (C/U, taxon, best, sorted ids) like parse_tsv values"""
