@@ -2917,6 +2917,10 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             const int sc = (int)m_psum + t_diff;                               // calcScore(fragment, f->diff)
             const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
             vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];             // unsigned wrap as in :363
+            // the substitutes are tried in descending score and the loop ends at the first one below the threshold
+            // (:368-369, 390-392): if the best one is, nothing is ranked and nothing queued
+            const int32_t thr0 = (int32_t)best > (int32_t)p.min_score ? (int32_t)best : (int32_t)p.min_score;
+            if ((int32_t)(vscore + (uint32_t)(int32_t)ct.b62[vorig][ct.subst[vorig][0]]) < thr0) { qseq += 19; bk = GB_VAR_NEXT; continue; }
             kind = G_VMULTI; bk = GB_NONE;
           }
         }
