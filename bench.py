@@ -175,7 +175,7 @@ class Leg:
         self.index, self.dtax, self.dev, self.rank, self.world = index, dtax, dev, rank, world
         self.n, self.L = reads.shape
         self.params = api.default_params(mode, seg=seg)
-        self.nctx = nctx if nctx > 0 else (2 if mode == "mem" else 1)
+        self.nctx = max(1, nctx)
         self.clfs = [api.Classifier(index, self.params) for _ in range(self.nctx)]
         for c in self.clfs:
             c.set_max_read_length(Lm)
@@ -406,9 +406,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("KAIJU_BENCH_READS", 10_000_000)),
                     help="reads per GPU per step")
-    ap.add_argument("--contexts", type=int, default=0,
-                    help="classification contexts that ping-pong the chunks (default: 2 for mem, 1 for greedy)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 5_000_000)))
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="classification contexts that ping-pong the chunks of a step on their HIP streams (default 1: since "
+                         "stage 1 + SEG are 15 %% of a step a second context is worth +1.6 %%, less than one launch per step)")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 10_000_000)),
+                    help="reads (pairs) per launch; default: the whole step in one launch (a persistent kernel ends in a tail "
+                         "in which its lanes run dry: 10 M per launch 189.7, 2 x 5 M 184.1 M reads/s)")
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
     ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"],
                     help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")

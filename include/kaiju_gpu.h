@@ -225,6 +225,9 @@ typedef struct {
 int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
                                      int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, char *text,
                                      uint32_t text_stride);
+/* text_stride that holds column 7 of every read of a batch whose longest read (both mates of a pair together) has
+   max_pair_len letters: callers size `text` with it instead of guessing the library's bound */
+uint32_t kaiju_gpu_verbose_text_stride(uint32_t max_pair_len, int input_is_protein);
 /* name of database sequence iseq as stored in the .fmi ("accession_taxid"), NULL if out of range */
 const char *kaiju_gpu_index_seq_name(const kaiju_gpu_index *index, uint32_t iseq);
 

@@ -102,7 +102,7 @@ void ConsumerThread::doWork() {
       hits.resize(n);
       if (config->verbose) {
         // columns 6 and 7 of -v (ConsumerThread.cpp:527-536, :614-623) come from the library's verbose entry point
-        vstride = (uint32_t)std::min<size_t>(20 * ((config->input_is_protein ? max_pair : max_pair / 3) + 2), 8192) + 1;
+        vstride = kaiju_gpu_verbose_text_stride((uint32_t)max_pair, config->input_is_protein ? 1 : 0);
         vrec.resize(n);
         vtext.resize((size_t)n * vstride);
         rc = kaiju_gpu_classify_batch_verbose(ctx, seqs.data(), off.data(), n, paired ? 1 : 0, hits.data(), vrec.data(),

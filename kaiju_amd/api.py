@@ -268,7 +268,9 @@ class Classifier:
         hits = np.zeros(n, dtype=HIT_DTYPE)
         v = np.zeros(n, dtype=VERBOSE_DTYPE)
         maxpair = int((off[2::2] - off[0:-1:2]).max()) if n else 0
-        stride = min(20 * ((maxpair if self.params.input_is_protein else maxpair // 3) + 2), 8192) + 1
+        lib().kaiju_gpu_verbose_text_stride.restype = C.c_uint32
+        lib().kaiju_gpu_verbose_text_stride.argtypes = [C.c_uint32, C.c_int]
+        stride = int(lib().kaiju_gpu_verbose_text_stride(maxpair, int(self.params.input_is_protein)))
         text = np.zeros(n * stride, dtype=np.uint8)
         _check(lib().kaiju_gpu_classify_batch_verbose(self._h, seqs.ctypes.data, off.ctypes.data, n, 1 if paired else 0,
                                                       hits.ctypes.data, v.ctypes.data, text.ctypes.data, stride))

@@ -1123,7 +1123,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   VerboseOut vb{nullptr, nullptr, nullptr, nullptr, 0};
   if (c->verbose) {
     // columns 6/7: per read kVbAcc sequence numbers and room for 20 matched peptides
-    c->vb_text_cap = (uint32_t)std::min<uint64_t>(20ull * (max_pair / 3 + 2), 8192);
+    c->vb_text_cap = kaiju_gpu_verbose_text_stride((uint32_t)std::min<uint64_t>(max_pair, 0xffffffffull), 0) - 1;   // (max_pair: tripled for protein reads above)
     if ((rc = ensure(c->vb_nacc, (size_t)n * 4 + 16))) return rc;
     if ((rc = ensure(c->vb_acc, (size_t)n * kVbAcc * 4 + 16))) return rc;
     if ((rc = ensure(c->vb_tlen, (size_t)n * 4 + 16))) return rc;
@@ -1500,6 +1500,13 @@ extern "C" int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *
   }
   return KAIJU_GPU_OK;
   });
+}
+
+// room for the text of column 7 of one read: up to 20 matched peptides (max_matches_SI), each at most a fragment long and
+// followed by a comma; 64 KB at most (reads beyond ~9.8 kb with that many long matches are flagged `truncated`)
+extern "C" uint32_t kaiju_gpu_verbose_text_stride(uint32_t max_pair_len, int input_is_protein) {
+  const uint64_t frag = input_is_protein ? (uint64_t)max_pair_len : (uint64_t)max_pair_len / 3;
+  return (uint32_t)std::min<uint64_t>(20ull * (frag + 2), 65536) + 1;
 }
 
 extern "C" const char *kaiju_gpu_index_seq_name(const kaiju_gpu_index *ix, uint32_t iseq) {

@@ -20,7 +20,9 @@
 #include <getopt.h>
 #include <malloc.h>
 #include <sys/mman.h>
+#include <signal.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
@@ -69,8 +71,11 @@ void usage(const char *prog) {
 }
 
 void die(const std::string &msg) {
+  // may be called from a reader / parser / GPU worker thread while others are inside HIP calls: no atexit handlers, no
+  // static destructors (exit() there can hang or crash) - flush what is ours and leave
   fprintf(stderr, "Error: %s\n\n", msg.c_str());
-  exit(EXIT_FAILURE);
+  fflush(nullptr);
+  _exit(EXIT_FAILURE);
 }
 
 std::string now() {
@@ -125,6 +130,15 @@ struct NewlineScan {
   }
 };
 
+// input files mapped for the sample that is being processed (kaiju-multi: unmapped between samples)
+static std::mutex g_map_mutex;
+static std::vector<std::pair<void *, size_t>> g_mappings;
+static void release_mappings() {
+  std::lock_guard<std::mutex> lk(g_map_mutex);
+  for (auto &m : g_mappings) munmap(m.first, m.second);
+  g_mappings.clear();
+}
+
 struct BlockReader {
   std::string path;
   bool ok = false, mapped = false;
@@ -153,6 +167,7 @@ struct BlockReader {
       if (m != MAP_FAILED) {
         madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
         map = static_cast<const char *>(m); map_size = (size_t)st.st_size;
+        { std::lock_guard<std::mutex> lk(g_map_mutex); g_mappings.emplace_back(m, map_size); }
         mapped = true; data = map; size = map_size; eof = true; ok = true;
       }
     }
@@ -164,7 +179,8 @@ struct BlockReader {
   }
   ~BlockReader() {
     if (fp) gzclose(fp);
-    // (a mapping stays until the process ends: blocks still point into it)
+    // (the mapping outlives the reader: blocks in the pipeline still point into it; run_sample() unmaps it when every
+    // block of the sample has been consumed - release_mappings())
   }
   bool more() {                // streamed files: append more text; false at end of file
     if (eof) return false;
@@ -538,6 +554,7 @@ bool protein_has_fragment(const char *s, uint64_t len, const kaiju_gpu_params &p
 }
 
 int main(int argc, char **argv) {
+  signal(SIGPIPE, SIG_IGN);                   // a closed output pipe is a write error, not the end of the process
   // batches come and go by the hundred megabytes: keep that memory in the heap instead of mapping and unmapping (and
   // page-faulting) it for every batch
   mallopt(M_MMAP_THRESHOLD, 1 << 30);
@@ -665,7 +682,10 @@ int main(int argc, char **argv) {
       out = fopen(out_fn.c_str(), "w");
       if (!out) die("Could not open file " + out_fn + " for writing");
     }
-    setvbuf(out, nullptr, _IOFBF, 1 << 22);
+    // (once per stream and before the first write: kaiju-multi comes back here with stdout for every sample)
+    static bool stdout_buffered = false;
+    if (out != stdout || !stdout_buffered) setvbuf(out, nullptr, _IOFBF, 1 << 22);
+    if (out == stdout) stdout_buffered = true;
 
     uint32_t batch_reads = 500000;
     if (const char *e = getenv("KAIJU_GPU_BATCH")) batch_reads = (uint32_t)std::max(1L, atol(e));
@@ -751,7 +771,7 @@ int main(int argc, char **argv) {
             b->vrec.resize(n);
             uint64_t maxpair = 0;
             for (uint32_t q = 0; q < n; q++) maxpair = std::max<uint64_t>(maxpair, b->off[2 * (size_t)q + 2] - b->off[2 * (size_t)q]);
-            b->vstride = (uint32_t)std::min<uint64_t>(20 * ((protein ? maxpair : maxpair / 3) + 2), 8192) + 1;
+            b->vstride = kaiju_gpu_verbose_text_stride((uint32_t)maxpair, protein ? 1 : 0);
             b->vtext.resize((size_t)n * b->vstride);
             r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data(),
                                                  b->vrec.data(), b->vtext.data(), b->vstride);
@@ -889,6 +909,7 @@ int main(int argc, char **argv) {
     for (auto &t : formatters) t.join();
     fflush(out);
     if (out != stdout) fclose(out);
+    release_mappings();
   };
   for (size_t i = 0; i < list1.size(); i++) {
     if (verbose && multi)

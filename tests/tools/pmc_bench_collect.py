@@ -19,8 +19,8 @@ for f in sorted(glob.glob(src + "/pass*/**/p_counter_collection.csv", recursive=
             continue
         acc[k][row["Counter_Name"]].append((float(row["Counter_Value"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6,
                                             int(row["Start_Timestamp"])))
-# bench.py --legs greedy,paired --steps 1 --warmup 0: per leg one timed step (2 launches of 5 M units for the 10 M-read legs,
-# 1 launch of 5 M pairs), the exclusive pass (same launches again) and the counting pass
+# bench.py --legs greedy,paired --steps 1 --warmup 0: per leg the timed steps (one launch of 10 M reads / of 5 M pairs each),
+# the exclusive pass (the same launch again) and the counting pass
 legs = {"mem": ("k_mem", False), "greedy": ("k_greedy2", False), "paired": ("k_mem", True)}
 meas = []
 def big(launches):
@@ -29,25 +29,20 @@ def big(launches):
         return []
     mx = max(d for _, d, _ in launches)
     return [x for x in launches if x[1] > 0.5 * mx]
-km = acc.get("k_mem", {})
-if km:
-    # k_mem launches in time order: headline leg first (single reads), the paired leg last
-    order = sorted(big(km.get("TCC_EA0_RDREQ_sum", [])), key=lambda x: x[2])
-    t_split = None
-    if len(order) >= 3:
-        # the paired launches are the last third (one launch per pass instead of two)
-        t_split = order[-(len(order) // 3)][2]
 for name, (kern, paired) in legs.items():
     c = acc.get(kern)
     if not c:
         continue
     def sel(counter):
         xs = big(c.get(counter, []))
-        if kern == "k_mem" and t_split is not None:
-            # timestamps differ between passes: split by rank instead
-            xs = sorted(xs, key=lambda x: x[2])
-            cut = len(xs) - len(xs) // 3
-            xs = xs[cut:] if paired else xs[:cut]
+        if kern == "k_mem" and xs:
+            # the launches of the paired leg (5 M pairs) take half as long again as those of the headline leg (5 M reads)
+            lo, hi = min(d for _, d, _ in xs), max(d for _, d, _ in xs)
+            if hi > 1.25 * lo:
+                mid = 0.5 * (lo + hi)
+                xs = [x for x in xs if (x[1] > mid) == paired]
+            elif paired:
+                xs = []
         return xs
     rd, rd32 = sel("TCC_EA0_RDREQ_sum"), sel("TCC_EA0_RDREQ_32B_sum")
     wr, wr64 = sel("TCC_EA0_WRREQ_sum"), sel("TCC_EA0_WRREQ_64B_sum")
@@ -55,7 +50,7 @@ for name, (kern, paired) in legs.items():
         continue
     mean = lambda xs: sum(v for v, _, _ in xs) / len(xs)
     r, r32, w, w64 = mean(rd), mean(rd32) if rd32 else 0.0, mean(wr), mean(wr64) if wr64 else 0.0
-    rec = {"mode": "greedy" if name == "greedy" else "mem", "paired": paired, "seg": 1, "nseq": 680001, "reads_per_launch": 5000000,
+    rec = {"mode": "greedy" if name == "greedy" else "mem", "paired": paired, "seg": 1, "nseq": 680001, "reads_per_launch": 5000000 if paired else 10000000,
            "kernel": kern, "launches_averaged": len(rd),
            "hbm_bytes_per_launch": (r - r32) * 128.0 + r32 * 32.0 + w64 * 64.0 + (w - w64) * 32.0,
            "counters_per_launch": {"TCC_EA0_RDREQ_sum": r, "TCC_EA0_RDREQ_32B_sum": r32, "TCC_EA0_WRREQ_sum": w, "TCC_EA0_WRREQ_64B_sum": w64,
