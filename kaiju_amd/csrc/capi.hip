@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -268,6 +269,18 @@ __device__ __forceinline__ void mem_body(const DevIndex &ix, const Params &p, co
 // second-generation lane (kj_core.h:mem_lane2): indexes below 2^32 symbols with a k-mer table
 __global__ void __launch_bounds__(kBlock, 4)
 k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  mem_lane2<false>(ix, p, b, wl, ls);
+}
+// the same kernel under a second name for the second search of the lazy SEG flow (the few reads whose fragments SEG had
+// to cut), so that a kernel trace lists the full-size launches of k_mem by themselves
+__global__ void __launch_bounds__(kBlock, 4)
+k_mem_second(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   LaneScratch ls;
@@ -654,8 +667,22 @@ struct kaiju_gpu_index {
   }
 };
 
-template <class T>
-static int upload(kaiju_gpu_index *ix, const std::vector<T> &v, const T **dst) {
+// KAIJU_GPU_LOAD_TIMES=1: wall time of the phases of an index load / a context creation, on stderr
+struct LoadClock {
+  bool on;
+  double t0, tl;
+  static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+  LoadClock() : on(getenv("KAIJU_GPU_LOAD_TIMES") != nullptr), t0(now()), tl(t0) {}
+  void mark(const char *what) {
+    if (!on) return;
+    const double t = now();
+    fprintf(stderr, "[kaiju_gpu load] %-34s %8.1f ms (at %8.1f ms)\n", what, (t - tl) * 1e3, (t - t0) * 1e3);
+    tl = t;
+  }
+};
+
+template <class T, class A>
+static int upload(kaiju_gpu_index *ix, const std::vector<T, A> &v, const T **dst) {
   void *p = nullptr;
   const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16) + 32;   // slack: 16-byte loads of 8-byte entries
   KJ_HIP(hipMalloc(&p, bytes));
@@ -668,16 +695,39 @@ static int upload(kaiju_gpu_index *ix, const std::vector<T> &v, const T **dst) {
 static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out);
 static thread_local int tl_id_mode = 0;     // kaiju_gpu_index_load_ex: 1 = hits collect sequence numbers
 
-static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_index **out) {
+// The first HIP call of a process starts the runtime (about 0.15 s on an MI355X host); reading and packing an index needs
+// no device, so the check for one runs beside it.  Its verdict still comes first: without a device the load fails with
+// KAIJU_GPU_ERR_NO_DEVICE whatever the file looks like.
+static std::future<int> device_check_async(int device_id) {
+  return std::async(std::launch::async, [device_id]() -> int {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return KAIJU_GPU_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return KAIJU_GPU_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess || hipFree(nullptr) != hipSuccess) return KAIJU_GPU_ERR_HIP;
+    return KAIJU_GPU_OK;
+  });
+}
+static int device_check_result(std::future<int> &f) {
+  const int rc = f.get();
+  if (rc == KAIJU_GPU_ERR_NO_DEVICE) return fail(rc, "hipGetDeviceCount found no device");
+  if (rc == KAIJU_GPU_ERR_ARG) return fail(rc, "device_id out of range");
+  if (rc) return fail(rc, "the HIP runtime did not start on that device");
+  return KAIJU_GPU_OK;
+}
+
+static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_index **out, std::future<int> *dev_started = nullptr) {
   if (!out) return fail(KAIJU_GPU_ERR_ARG, "out is NULL");
   *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(KAIJU_GPU_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
-  if (device_id < 0 || device_id >= ndev) return fail(KAIJU_GPU_ERR_ARG, "device_id out of range");
+  std::future<int> own;
+  if (!dev_started) { own = device_check_async(device_id); dev_started = &own; }
   std::string msg;
   PackedIndex pk;
+  LoadClock lc;
   int rc = pk.build(v, msg);
+  lc.mark("pack (host)");
+  const int drc = device_check_result(*dev_started);
+  lc.mark("wait for the HIP runtime");
+  if (drc) return drc;
   if (rc) return fail(rc, msg);
   return index_from_packed(pk, device_id, out);
 }
@@ -686,6 +736,7 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
 static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out) {
   std::string msg;
   int rc;
+  LoadClock lc;
   if (tl_id_mode == 1) pk.to_sequence_ids();
   std::unique_ptr<kaiju_gpu_index> ix(new kaiju_gpu_index());
   ix->device = device_id;
@@ -695,6 +746,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   std::vector<double> lnfact;
   rc = build_seg_tables(lnfact, ix->st, msg);
   if (rc) return fail(rc, msg);
+  lc.mark("host tables");
   KJ_HIP(hipSetDevice(device_id));
   DevIndex &d = ix->dev;
   if ((rc = upload(ix.get(), pk.blocks, &d.blocks))) return rc;
@@ -727,6 +779,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   for (int a = 0; a < 22; a++) d.C[a] = pk.C[a];
   d.bwtlen = pk.bwtlen; d.n_sa = pk.n_sa; d.sa_skip = pk.sa_skip; d.nseq = pk.nseq; d.chpt_exp = pk.chpt_exp;
   d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k;
+  lc.mark("upload of the packed arrays");
   uint64_t kmer_bytes = 0;
   if (pk.kmer_k) {
     if (!pk.kmer32.empty()) { if ((rc = upload(ix.get(), pk.kmer32, &d.kmer32))) return rc; }
@@ -780,6 +833,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
       kmer_bytes = np * sizeof(ulonglong2) - pk.kmer64.size() * sizeof(ulonglong2);
     }
   }
+  lc.mark("k-mer table (device)");
   kaiju_gpu_index_info &inf = ix->info;
   memset(&inf, 0, sizeof inf);
   inf.bwtlen = (int64_t)pk.bwtlen; inf.nseq = (int32_t)pk.nseq; inf.alen = (int32_t)pk.alen;
@@ -822,23 +876,27 @@ extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_g
   return guarded([&]() -> int {
   if (!fmi_path || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(KAIJU_GPU_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
-  if (device_id < 0 || device_id >= ndev) return fail(KAIJU_GPU_ERR_ARG, "device_id out of range");
+  std::future<int> dev = device_check_async(device_id);
   if (is_image_file(fmi_path)) {
     // a pre-packed image (kaiju_gpu_index_write_image): no parsing, no packing
     PackedIndex pk;
     std::string msg;
+    LoadClock lc;
     const int rc = pk.read_image(fmi_path, msg);
+    lc.mark("read image file");
+    const int drc = device_check_result(dev);
+    lc.mark("wait for the HIP runtime");
+    if (drc) return drc;
     if (rc) return fail(rc, msg);
     return index_from_packed(pk, device_id, out);
   }
   FmiFile f;
   std::string msg;
+  LoadClock lc;
   int rc = f.load(fmi_path, msg);
-  if (rc) return fail(rc, msg);
-  return index_from_view(f.view(), device_id, out);
+  lc.mark("read .fmi file");
+  if (rc) { const int drc = device_check_result(dev); return drc ? drc : fail(rc, msg); }
+  return index_from_view(f.view(), device_id, out, &dev);
   });
 }
 
@@ -1146,9 +1204,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       const bool xo = (p.flags & kParamXOrder) != 0;
       SIEntry *si_main = static_cast<SIEntry *>(c->scratch_main[0].p);
       // the second-generation lane that serves this index (narrow: below 2^32 rows; wide: 64-bit positions)
-      auto launch_v2 = [&](const Params &pp, const WorkList &wl, bool counting) {
+      auto launch_v2 = [&](const Params &pp, const WorkList &wl, bool counting, bool second = false) {
         if (mem_narrow2) {
-          if (counting) hipLaunchKernelGGL(k_mem_count, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+          if (second && !xo) hipLaunchKernelGGL(k_mem_second, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
+          else if (counting) hipLaunchKernelGGL(k_mem_count, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
           else if (xo) hipLaunchKernelGGL(k_mem_x, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
           else hipLaunchKernelGGL(k_mem, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
         } else {
@@ -1179,7 +1238,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         WorkList wl_seg;
         wl_seg.counter = cnt + 23; wl_seg.reads = seglist; wl_seg.n_items_ptr = cnt + 22; wl_seg.n_items = 0;
         wl_seg.retry_list = wl_main.retry_list; wl_seg.retry_count = wl_main.retry_count;
-        launch_v2(p, wl_seg, false);
+        launch_v2(p, wl_seg, false, true);
         KJ_HIP(hipGetLastError());
       }
       hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,

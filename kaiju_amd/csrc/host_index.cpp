@@ -1,18 +1,37 @@
 // host_index.cpp — see host_index.h
 #include "host_index.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <thread>
+#include <time.h>
 
 #include "../../include/kaiju_gpu.h"
 
 namespace kj {
+
+void *big_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (bytes >= (4u << 20)) {
+    if (posix_memalign(&p, 2u << 20, bytes) != 0) throw std::bad_alloc();
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+  } else {
+    p = malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+  }
+  return p;
+}
+void big_free(void *p, size_t) { free(p); }
 
 namespace {
 struct Reader {
@@ -20,12 +39,26 @@ struct Reader {
   bool ok = true;
   template <class T> void get(T &v) { if (ok && fread(&v, sizeof(T), 1, fp) != 1) ok = false; }
   void bytes(void *dst, size_t n) { if (ok && n && fread(dst, 1, n, fp) != n) ok = false; }
+  void big(void *dst, size_t n);      // the same for the big arrays: pieces read by several threads
   void skip(int64_t n) { if (ok && fseeko(fp, (off_t)n, SEEK_CUR) != 0) ok = false; }
 };
 unsigned hw_threads() {
   unsigned n = std::thread::hardware_concurrency();
   return n ? std::min(n, 64u) : 4u;
 }
+// KAIJU_GPU_LOAD_TIMES=1: wall time of the packing phases, on stderr (as capi.hip does for the load as a whole)
+struct PackClock {
+  bool on;
+  double tl;
+  static double now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+  PackClock() : on(getenv("KAIJU_GPU_LOAD_TIMES") != nullptr), tl(now()) {}
+  void mark(const char *what) {
+    if (!on) return;
+    const double t = now();
+    fprintf(stderr, "[kaiju_gpu pack]   %-32s %8.1f ms\n", what, (t - tl) * 1e3);
+    tl = t;
+  }
+};
 template <class F> void parallel_for(uint64_t n, F &&fn) {
   const unsigned nt = (unsigned)std::min<uint64_t>(hw_threads(), n ? n : 1);
   if (nt <= 1) { for (uint64_t i = 0; i < n; i++) fn(i); return; }
@@ -33,6 +66,21 @@ template <class F> void parallel_for(uint64_t n, F &&fn) {
   for (unsigned t = 0; t < nt; t++)
     th.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) fn(i); });
   for (auto &x : th) x.join();
+}
+void Reader::big(void *dst, size_t n) {
+  const size_t piece = 16u << 20;
+  if (!ok || n <= 2 * piece) { bytes(dst, n); return; }
+  const off_t base = ftello(fp);
+  if (base < 0) { bytes(dst, n); return; }     // not seekable
+  const int fd = fileno(fp);
+  uint8_t *d = static_cast<uint8_t *>(dst);
+  std::atomic<bool> good{true};
+  parallel_for((n + piece - 1) / piece, [&](uint64_t c) {
+    size_t b = (size_t)c * piece;
+    const size_t e = std::min(n, b + piece);
+    while (b < e) { const ssize_t r = pread(fd, d + b, e - b, base + (off_t)b); if (r <= 0) { good = false; return; } b += (size_t)r; }
+  });
+  if (!good.load() || fseeko(fp, base + (off_t)n, SEEK_SET) != 0) ok = false;
 }
 }  // namespace
 
@@ -76,14 +124,14 @@ int FmiFile::load(const char *path, std::string &msg) {
   rd.skip((int64_t)nseq * 4);   // seqTermOrder: not used by the search
   rd.skip((int64_t)nseq * 8);   // seqlengths: not used by the search
   sa.resize((size_t)ncheck * (size_t)nbytes);
-  rd.bytes(sa.data(), sa.size());
+  rd.big(sa.data(), sa.size());
   // FMI, bwt/fmicommon.h:190-217 + compactfmi.c:165-171
   rd.get(f_alen); rd.get(bwtlen); rd.get(N1); rd.get(N2);
   if (!rd.ok || f_alen != alen || bwtlen != len || N1 <= 0 || N2 <= 0 || (int64_t)N1 * alen * 8 > fsize || (int64_t)N2 * alen * 2 > fsize) {
     fclose(fp); msg = "not a Kaiju .fmi file (bad FMI header)"; return KAIJU_GPU_ERR_FORMAT;
   }
   bwt.resize((size_t)bwtlen);
-  rd.bytes(bwt.data(), bwt.size());
+  rd.big(bwt.data(), bwt.size());
   rd.skip((int64_t)(N1 - 1) * alen * 8);
   index1_last.resize((size_t)alen);
   rd.bytes(index1_last.data(), (size_t)alen * 8);
@@ -135,32 +183,51 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
   const uint64_t nblk = (bwtlen >> kBlkShift) + 1;
   const uint64_t nsb = (bwtlen >> kSbShift) + 1;
   const uint64_t blk_per_sb = 1ull << (kSbShift - kBlkShift);
-  blocks.assign((size_t)nblk, RankBlock{});
+  PackClock pc;
+  // (the big arrays are sized without being filled: every element is written below, by the thread that owns its superblock)
+  blocks.clear(); blocks.resize((size_t)nblk);
   sb.assign((size_t)nsb * 20, 0);
+  pc.mark("allocate rank blocks");
   // pass 1: letter histogram of every superblock
   std::vector<uint64_t> hist((size_t)nsb * 21, 0);
   const uint8_t *bwt = v.bwt;
   parallel_for(nsb, [&](uint64_t s) {
     const uint64_t b = s << kSbShift, e = std::min<uint64_t>(bwtlen, b + (1ull << kSbShift));
-    uint64_t h[32] = {0};
-    for (uint64_t k = b; k < e; k++) h[lcode[bwt[k]]]++;
-    for (int a = 0; a < 21; a++) hist[(size_t)s * 21 + a] = h[a];
+    // four histograms: consecutive equal letters do not wait for each other's increment
+    uint32_t h[4][256];
+    memset(h, 0, sizeof h);
+    uint64_t k = b;
+    for (; k + 4 <= e; k += 4) { h[0][bwt[k]]++; h[1][bwt[k + 1]]++; h[2][bwt[k + 2]]++; h[3][bwt[k + 3]]++; }
+    for (; k < e; k++) h[0][bwt[k]]++;
+    uint64_t hl[32] = {0};
+    for (int c = 0; c < 256; c++) hl[lcode[c]] += (uint64_t)h[0][c] + h[1][c] + h[2][c] + h[3][c];
+    for (int a = 0; a < 21; a++) hist[(size_t)s * 21 + a] = hl[a];
+    hist[(size_t)s * 21] = hl[0];
+    if (hl[31]) hist[(size_t)s * 21] |= 1ull << 63;          // a byte outside the code table
   });
   uint64_t total[21] = {0};
-  for (uint64_t s = 0; s < nsb; s++) for (int a = 0; a < 21; a++) total[a] += hist[(size_t)s * 21 + a];
+  bool stray = false;
+  for (uint64_t s = 0; s < nsb; s++) {
+    if (hist[(size_t)s * 21] >> 63) { stray = true; hist[(size_t)s * 21] &= ~(1ull << 63); }
+    for (int a = 0; a < 21; a++) total[a] += hist[(size_t)s * 21 + a];
+  }
   {
     uint64_t sum = 0;
     for (int a = 0; a < 21; a++) sum += total[a];
-    if (sum != bwtlen) { msg = "BWT contains byte codes outside the code table"; return KAIJU_GPU_ERR_FORMAT; }
+    if (stray || sum != bwtlen) { msg = "BWT contains byte codes outside the code table"; return KAIJU_GPU_ERR_FORMAT; }
     if (total[0] != nseq) { msg = "number of terminators in the BWT differs from nseq"; return KAIJU_GPU_ERR_FORMAT; }
   }
+  pc.mark("letter histograms");
   // C[] (index1[N1-1], fmicommon.h:160-165; InitialSI bwt.c:146-152 uses bwtlen after the last letter)
   C[0] = 0;
   for (uint32_t a = 1; a < alen; a++) C[a] = C[a - 1] + total[a - 1];
   for (uint32_t a = alen; a < 22; a++) C[a] = bwtlen;
+  // terminators in front of every superblock: where its rows of term_pos go
+  std::vector<uint64_t> term_before((size_t)nsb + 1, 0);
   {
     uint64_t run[21] = {0};
     for (uint64_t s = 0; s < nsb; s++) {
+      term_before[(size_t)s + 1] = term_before[(size_t)s] + hist[(size_t)s * 21];
       for (int a = 1; a < 21; a++) {
         sb[(size_t)s * 20 + (a - 1)] = C[a] + run[a];
         run[a] += hist[(size_t)s * 21 + a];
@@ -175,63 +242,66 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
   if (const char *e = getenv("KAIJU_GPU_FORCE_WIDE")) { wide = true; const int v = atoi(e); if (v >= (int)kSbShift && v <= 31) mb_shift = (uint32_t)v; }
   sb32.clear();
   if (!wide) { sb32.resize(sb.size()); for (size_t q = 0; q < sb.size(); q++) sb32[q] = (uint32_t)sb[q]; }
-  // pass 2: rank blocks
+  blocks64.clear(); mb_base.clear();
+  const uint64_t nb64 = (bwtlen >> 6) + 1;
+  blocks64.resize((size_t)nb64);
+  if (wide) {
+    // counts relative to the start of every 2^mb_shift rows (a multiple of the superblock size)
+    const uint64_t nmb = (bwtlen >> mb_shift) + 1;
+    mb_base.assign((size_t)nmb * 20, 0);
+    for (uint64_t m = 0; m < nmb; m++)
+      for (int a = 0; a < 20; a++) mb_base[(size_t)m * 20 + a] = sb[(size_t)(m << (mb_shift - kSbShift)) * 20 + a];
+  }
+  term_pos.clear();
+  term_pos.resize((size_t)nseq);
+  pc.mark("superblock sums, allocations");
+  // pass 2, one sweep per superblock: the 128-symbol rank blocks (16-bit counts relative to the superblock; first-generation
+  // lanes), the 64-symbol blocks with absolute 32-bit counts (second generation) and the rows of the terminators (rank_term)
   parallel_for(nsb, [&](uint64_t s) {
     uint32_t cnt[32] = {0};
+    uint64_t abs64[32];
+    for (int a = 1; a < 21; a++) {
+      abs64[a] = sb[(size_t)s * 20 + (a - 1)];
+      if (wide) abs64[a] -= mb_base[(size_t)((s << kSbShift) >> mb_shift) * 20 + (a - 1)];
+    }
+    uint64_t *tp = term_pos.data() + term_before[(size_t)s];
     const uint64_t b0 = s * blk_per_sb, b1 = std::min<uint64_t>(nblk, b0 + blk_per_sb);
     for (uint64_t bi = b0; bi < b1; bi++) {
       RankBlock &rb = blocks[(size_t)bi];
       for (int a = 1; a < 21; a++) rb.cnt[a - 1] = (uint16_t)cnt[a];
+      rb.pad[0] = rb.pad[1] = rb.pad[2] = rb.pad[3] = 0;
       const uint64_t k0 = bi << kBlkShift;
-      for (uint32_t t = 0; t < 128; t++) {
-        const uint64_t k = k0 + t;
-        const uint32_t c = k < bwtlen ? lcode[bwt[k]] : 31u;   // padding never matches a letter
-        if (k < bwtlen) cnt[c]++;
-        for (int p = 0; p < 5; p++)
-          if ((c >> p) & 1u) rb.plane[p][t >> 6] |= 1ull << (t & 63);
+      for (uint32_t half = 0; half < 2; half++) {
+        const uint64_t h0 = k0 + 64 * half;
+        const uint64_t b64i = h0 >> 6;
+        uint64_t pl[5] = {0, 0, 0, 0, 0};
+        if (b64i < nb64) {
+          RankBlock64 &r64 = blocks64[(size_t)b64i];
+          for (int a = 1; a < 21; a++) r64.cnt[a - 1] = (uint32_t)(abs64[a] + cnt[a]);
+          r64.pad[0] = r64.pad[1] = 0;
+        }
+        const uint32_t nsym = h0 >= bwtlen ? 0u : (uint32_t)std::min<uint64_t>(64, bwtlen - h0);
+        for (uint32_t t = 0; t < nsym; t++) {
+          const uint32_t c = lcode[bwt[h0 + t]];
+          cnt[c]++;
+          if (c == 0) *tp++ = h0 + t;
+          pl[0] |= (uint64_t)(c & 1u) << t; pl[1] |= (uint64_t)((c >> 1) & 1u) << t; pl[2] |= (uint64_t)((c >> 2) & 1u) << t;
+          pl[3] |= (uint64_t)((c >> 3) & 1u) << t; pl[4] |= (uint64_t)((c >> 4) & 1u) << t;
+        }
+        if (nsym < 64) {                                     // padding (code 31) never matches a letter
+          const uint64_t pad = nsym ? ~0ull << nsym : ~0ull;
+          for (int q = 0; q < 5; q++) pl[q] |= pad;
+        }
+        for (int q = 0; q < 5; q++) rb.plane[q][half] = pl[q];
+        if (b64i < nb64) { RankBlock64 &r64 = blocks64[(size_t)b64i]; for (int q = 0; q < 5; q++) r64.plane[q] = pl[q]; }
       }
     }
   });
-  // 64-symbol blocks with absolute 32-bit counts for the MEM kernel
-  blocks64.clear(); mb_base.clear();
-  {
-    const uint64_t nb64 = (bwtlen >> 6) + 1;
-    blocks64.assign((size_t)nb64, RankBlock64{});
-    if (wide) {
-      // counts relative to the start of every 2^mb_shift rows (a multiple of the superblock size)
-      const uint64_t nmb = (bwtlen >> mb_shift) + 1;
-      mb_base.assign((size_t)nmb * 20, 0);
-      for (uint64_t m = 0; m < nmb; m++)
-        for (int a = 0; a < 20; a++) mb_base[(size_t)m * 20 + a] = sb[(size_t)(m << (mb_shift - kSbShift)) * 20 + a];
-    }
-    parallel_for(nsb, [&](uint64_t s) {
-      uint64_t cnt[32];
-      for (int a = 1; a < 21; a++) {
-        cnt[a] = sb[(size_t)s * 20 + (a - 1)];
-        if (wide) cnt[a] -= mb_base[(size_t)((s << kSbShift) >> mb_shift) * 20 + (a - 1)];
-      }
-      const uint64_t b0 = s << (kSbShift - 6), b1 = std::min<uint64_t>(nb64, b0 + (1ull << (kSbShift - 6)));
-      for (uint64_t bi = b0; bi < b1; bi++) {
-        RankBlock64 &rb = blocks64[(size_t)bi];
-        for (int a = 1; a < 21; a++) rb.cnt[a - 1] = (uint32_t)cnt[a];
-        const uint64_t k0 = bi << 6;
-        for (uint32_t t = 0; t < 64; t++) {
-          const uint64_t k = k0 + t;
-          const uint32_t c = k < bwtlen ? lcode[bwt[k]] : 31u;
-          if (k < bwtlen && c >= 1 && c <= 20) cnt[c]++;
-          for (int pl = 0; pl < 5; pl++) if ((c >> pl) & 1u) rb.plane[pl] |= 1ull << t;
-        }
-      }
-    });
-  }
-  // terminator positions (rows whose BWT letter is 0): rank_term
-  term_pos.clear();
-  term_pos.reserve(nseq);
-  for (uint64_t k = 0; k < bwtlen; k++) if (lcode[bwt[k]] == 0) term_pos.push_back(k);
+  pc.mark("rank blocks + terminator rows");
   // sampled suffix array: only the sequence number is needed (suffixArray.h:37-51)
   sa_skip = (((uint64_t)nseq - 1) >> chpt_exp) + 1;
   n_sa = (uint64_t)v.ncheck;
-  sa_iseq.assign((size_t)n_sa, 0);
+  sa_iseq.clear(); sa_iseq.resize((size_t)n_sa);
   if (v.nbytes < 1 || v.nbytes > 8 || v.pbits < 0 || v.pbits > 62) { msg = "bad suffix array coding"; return KAIJU_GPU_ERR_FORMAT; }
   {
     const uint8_t *sa = v.sa;
@@ -247,6 +317,7 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       }
     });
   }
+  pc.mark("suffix array samples");
   {
     const uint64_t need = bwtlen > 0 ? (((bwtlen - 1) >> chpt_exp) - sa_skip + 1) : 0;
     if (((bwtlen - 1) >> chpt_exp) >= sa_skip && need > n_sa) warnings |= KAIJU_IDX_WARN_SA_SHORT;
@@ -255,26 +326,37 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
   // taxon ids
   seq_taxid.assign(nseq, 0);
   seq_valid.assign(nseq, 0);
+  names.clear();
   names.resize(nseq);
-  for (uint32_t i = 0; i < nseq; i++) {
-    const char *nm = v.ids[i] ? v.ids[i] : "";
-    names[i] = nm;
-    uint64_t id = 0;
-    // bit 0: usable taxon id; bit 1: the name has an accession part in front of the last '_' (verbose column 6)
-    seq_valid[i] = parse_taxid(nm, id) ? (uint8_t)(strrchr(nm, '_') ? 3 : 1) : 0;
-    seq_taxid[i] = id;
-  }
-  sa_taxid.assign((size_t)n_sa + 2, ~0ull);
-  for (uint64_t q = 0; q < n_sa; q++) {
-    const uint32_t is = sa_iseq[(size_t)q];
-    if (is < nseq && seq_valid[is]) sa_taxid[(size_t)q] = seq_taxid[is];
-  }
+  parallel_for(((uint64_t)nseq + 16383) / 16384, [&](uint64_t chunk) {
+    const uint32_t b = (uint32_t)(chunk * 16384), e = (uint32_t)std::min<uint64_t>(nseq, (uint64_t)b + 16384);
+    for (uint32_t i = b; i < e; i++) {
+      const char *nm = v.ids[i] ? v.ids[i] : "";
+      names[i] = nm;
+      uint64_t id = 0;
+      // bit 0: usable taxon id; bit 1: the name has an accession part in front of the last '_' (verbose column 6)
+      seq_valid[i] = parse_taxid(nm, id) ? (uint8_t)(strrchr(nm, '_') ? 3 : 1) : 0;
+      seq_taxid[i] = id;
+    }
+  });
+  sa_taxid.clear();
+  sa_taxid.resize((size_t)n_sa + 2);
+  sa_taxid[(size_t)n_sa] = sa_taxid[(size_t)n_sa + 1] = ~0ull;
+  parallel_for((n_sa + 65535) / 65536, [&](uint64_t chunk) {
+    const uint64_t b = chunk * 65536, e = std::min<uint64_t>(n_sa, b + 65536);
+    for (uint64_t q = b; q < e; q++) {
+      const uint32_t is = sa_iseq[(size_t)q];
+      sa_taxid[(size_t)q] = (is < nseq && seq_valid[is]) ? seq_taxid[is] : ~0ull;
+    }
+  });
+  pc.mark("names, taxon ids");
   {
     // the host builds at most 5 letters; the device grows the table further (capi.hip)
     uint32_t k = 5;
     if (const char *e = getenv("KAIJU_GPU_KMER")) { k = (uint32_t)atoi(e); if (k > 5) k = 5; }
     build_kmer_table(k);
   }
+  pc.mark("k-mer table (host part)");
   return 0;
 }
 
@@ -329,16 +411,42 @@ struct ImgHeader {
   uint8_t trans[128];
   char alphabet[64];
 };
-template <class T> bool put_vec(FILE *fp, const std::vector<T> &v) {
+template <class T, class A> bool put_vec(FILE *fp, const std::vector<T, A> &v) {
   const uint64_t n = v.size();
   return fwrite(&n, 8, 1, fp) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, fp) == n);
 }
-template <class T> bool get_vec(FILE *fp, std::vector<T> &v) {
-  uint64_t n = 0;
-  if (fread(&n, 8, 1, fp) != 1 || n > (1ull << 40)) return false;
-  v.resize((size_t)n);
-  return n == 0 || fread(v.data(), sizeof(T), n, fp) == n;
-}
+// positional reads, big arrays in pieces by several threads (an image is about a GB: one thread copying it out of the
+// page cache takes a quarter of a second)
+struct ImgReader {
+  int fd;
+  uint64_t pos, size;
+  bool raw(void *dst, uint64_t n) {
+    if (n > size - pos) return false;
+    uint8_t *d = static_cast<uint8_t *>(dst);
+    const uint64_t base = pos;
+    pos += n;
+    const uint64_t piece = 16ull << 20;
+    if (n <= 2 * piece) {
+      uint64_t done = 0;
+      while (done < n) { const ssize_t r = pread(fd, d + done, n - done, (off_t)(base + done)); if (r <= 0) return false; done += (uint64_t)r; }
+      return true;
+    }
+    std::atomic<bool> ok{true};
+    parallel_for((n + piece - 1) / piece, [&](uint64_t c) {
+      uint64_t b = c * piece;
+      const uint64_t e = std::min<uint64_t>(n, b + piece);
+      while (b < e) { const ssize_t r = pread(fd, d + b, e - b, (off_t)(base + b)); if (r <= 0) { ok = false; return; } b += (uint64_t)r; }
+    });
+    return ok.load();
+  }
+  template <class T, class A> bool vec(std::vector<T, A> &v) {
+    uint64_t n = 0;
+    if (!raw(&n, 8) || n > (size - pos) / sizeof(T)) return false;
+    v.clear();
+    v.resize((size_t)n);
+    return n == 0 || raw(v.data(), n * sizeof(T));
+  }
+};
 }  // namespace
 
 int PackedIndex::write_image(const char *path, std::string &msg) const {
@@ -368,12 +476,14 @@ int PackedIndex::write_image(const char *path, std::string &msg) const {
 }
 
 int PackedIndex::read_image(const char *path, std::string &msg) {
-  FILE *fp = fopen(path, "rb");
-  if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
+  ImgReader rd{fd, 0, 0};
+  { struct stat st; if (fstat(fd, &st) == 0 && st.st_size > 0) rd.size = (uint64_t)st.st_size; }
   ImgHeader h;
-  bool ok = fread(&h, sizeof h, 1, fp) == 1 && memcmp(h.magic, kImageMagic, 8) == 0 && h.sizes[0] == sizeof(RankBlock) &&
+  bool ok = rd.raw(&h, sizeof h) && memcmp(h.magic, kImageMagic, 8) == 0 && h.sizes[0] == sizeof(RankBlock) &&
             h.sizes[1] == sizeof(RankBlock64) && h.sizes[2] == sizeof(uint2) && h.sizes[3] == sizeof(ulonglong2);
-  if (!ok) { fclose(fp); msg = "not a kaiju GPU index image (or written by another version)"; return KAIJU_GPU_ERR_FORMAT; }
+  if (!ok) { close(fd); msg = "not a kaiju GPU index image (or written by another version)"; return KAIJU_GPU_ERR_FORMAT; }
   memcpy(C, h.C, sizeof C);
   bwtlen = h.bwtlen; n_sa = h.n_sa; sa_skip = h.sa_skip; nseq = h.nseq; chpt_exp = h.chpt_exp; alen = h.alen;
   warnings = h.warnings; kmer_k = h.kmer_k; mb_shift = h.mb_shift_wide & 255u; wide = (h.mb_shift_wide & 256u) != 0;
@@ -382,10 +492,10 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   alphabet = h.alphabet;
   std::vector<uint32_t> nl;
   std::vector<char> nc;
-  ok = get_vec(fp, blocks) && get_vec(fp, blocks64) && get_vec(fp, sa_taxid) && get_vec(fp, sb) && get_vec(fp, sb32) &&
-       get_vec(fp, sa_iseq) && get_vec(fp, seq_taxid) && get_vec(fp, seq_valid) && get_vec(fp, term_pos) &&
-       get_vec(fp, kmer32) && get_vec(fp, kmer64) && get_vec(fp, mb_base) && get_vec(fp, nl) && get_vec(fp, nc);
-  fclose(fp);
+  ok = rd.vec(blocks) && rd.vec(blocks64) && rd.vec(sa_taxid) && rd.vec(sb) && rd.vec(sb32) &&
+       rd.vec(sa_iseq) && rd.vec(seq_taxid) && rd.vec(seq_valid) && rd.vec(term_pos) &&
+       rd.vec(kmer32) && rd.vec(kmer64) && rd.vec(mb_base) && rd.vec(nl) && rd.vec(nc);
+  close(fd);
   uint64_t total = 0;
   for (uint32_t l : nl) total += l;
   // consistency of what the kernels will index
@@ -393,9 +503,14 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
        blocks.size() == (size_t)(bwtlen >> 7) + 1 && (blocks64.empty() || blocks64.size() == (size_t)(bwtlen >> 6) + 1) &&
        sa_iseq.size() >= n_sa && sa_taxid.size() >= n_sa;
   if (!ok) { msg = "truncated or inconsistent index image"; return KAIJU_GPU_ERR_FORMAT; }
+  names.clear();
   names.resize(nl.size());
-  size_t o = 0;
-  for (size_t i = 0; i < nl.size(); i++) { names[i].assign(nc.data() + o, nl[i]); o += nl[i]; }
+  std::vector<uint64_t> no(nl.size() + 1, 0);
+  for (size_t i = 0; i < nl.size(); i++) no[i + 1] = no[i] + nl[i];
+  parallel_for((nl.size() + 16383) / 16384, [&](uint64_t chunk) {
+    const size_t b = (size_t)chunk * 16384, e = std::min(nl.size(), b + 16384);
+    for (size_t i = b; i < e; i++) names[i].assign(nc.data() + no[i], nl[i]);
+  });
   return 0;
 }
 

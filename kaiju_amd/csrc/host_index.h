@@ -14,6 +14,24 @@
 
 namespace kj {
 
+// Allocator of the big arrays (hundreds of MB each): elements are default-initialised - resize() does not fill, so the
+// pages of an array are first touched by the threads that write them, not by one thread zeroing it - and large blocks
+// are 2 MB aligned with transparent huge pages asked for (one page fault per 2 MB instead of per 4 KB).
+void *big_alloc(size_t bytes);
+void big_free(void *p, size_t bytes);
+template <class T> struct BigAlloc {
+  typedef T value_type;
+  BigAlloc() = default;
+  template <class U> BigAlloc(const BigAlloc<U> &) {}
+  T *allocate(size_t n) { return static_cast<T *>(big_alloc(n * sizeof(T))); }
+  void deallocate(T *p, size_t n) { big_free(p, n * sizeof(T)); }
+  template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }                      // default-, not value-initialised
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(static_cast<A &&>(a)...); }
+  template <class U> bool operator==(const BigAlloc<U> &) const { return true; }
+  template <class U> bool operator!=(const BigAlloc<U> &) const { return false; }
+};
+template <class T> using BigVec = std::vector<T, BigAlloc<T>>;
+
 struct HostIndexView {        // borrowed pointers (== kaiju_gpu_host_index)
   int64_t bwtlen = 0;
   int32_t nseq = 0, alen = 0;
@@ -37,11 +55,11 @@ struct FmiFile {
   int32_t sa_nseq = 0;
   std::vector<std::string> ids;
   std::vector<const char *> id_ptrs;
-  std::vector<uint8_t> sa;
+  BigVec<uint8_t> sa;
   int32_t f_alen = 0;
   int64_t bwtlen = 0;
   int32_t N1 = 0, N2 = 0;
-  std::vector<uint8_t> bwt;
+  BigVec<uint8_t> bwt;
   std::vector<int64_t> index1_last;   // index1[N1-1][*] = C[] as stored by the reference
   std::vector<int32_t> startLcode;
   // returns 0 or a negative kaiju_gpu_status; msg receives details
@@ -51,21 +69,21 @@ struct FmiFile {
 
 // the packed index in host memory, ready for upload
 struct PackedIndex {
-  std::vector<RankBlock> blocks;
-  std::vector<RankBlock64> blocks64;   // second-generation lanes: absolute counts (bwtlen < 2^32) or relative to mb_base
+  BigVec<RankBlock> blocks;
+  BigVec<RankBlock64> blocks64;   // second-generation lanes: absolute counts (bwtlen < 2^32) or relative to mb_base
   std::vector<uint64_t> mb_base;       // wide layout: [nmb][20], counts at the start of every 2^mb_shift rows
   uint32_t mb_shift = 0;
   bool wide = false;                   // 64-bit positions (bwtlen >= 2^32, or forced for tests)
-  std::vector<uint64_t> sa_taxid;      // taxon id per sampled SA row (~0: unusable name)
+  BigVec<uint64_t> sa_taxid;      // taxon id per sampled SA row (~0: unusable name)
   std::vector<uint64_t> sb;
   std::vector<uint32_t> sb32;       // copy of sb in 32 bits when bwtlen < 2^32
-  std::vector<uint32_t> sa_iseq;
+  BigVec<uint32_t> sa_iseq;
   std::vector<uint64_t> seq_taxid;
   std::vector<uint8_t> seq_valid;
-  std::vector<uint64_t> term_pos;
+  BigVec<uint64_t> term_pos;
   std::vector<std::string> names;   // sequence names (for the verbose columns)
-  std::vector<uint2> kmer32;        // k-mer table (see DevIndex), one of the two is filled
-  std::vector<ulonglong2> kmer64;
+  BigVec<uint2> kmer32;        // k-mer table (see DevIndex), one of the two is filled
+  BigVec<ulonglong2> kmer64;
   uint32_t kmer_k = 0;
   // builds the k-mer table with k letters (0 = none); needs blocks/sb/C
   void build_kmer_table(uint32_t k);

@@ -13,12 +13,13 @@ src, out = sys.argv[1], sys.argv[2]
 rawname = sys.argv[3] if len(sys.argv) > 3 else src
 acc = collections.defaultdict(lambda: collections.defaultdict(list))      # kernel -> counter -> [(value, dur_ms)]
 for f in sorted(glob.glob(src + "/pass*/**/p_counter_collection.csv", recursive=True)):
-    for row in csv.DictReader(open(f)):
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith("k_")]
+    # the legs run one after the other (headline, greedy, paired): a k_mem launch after the first Greedy search belongs to the paired leg
+    g0 = min([int(r["Start_Timestamp"]) for r in rows if r["Kernel_Name"].startswith("k_greedy2(")] or [1 << 62])
+    for row in rows:
         k = row["Kernel_Name"].split("(")[0]
-        if not k.startswith("k_"):
-            continue
         acc[k][row["Counter_Name"]].append((float(row["Counter_Value"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6,
-                                            int(row["Start_Timestamp"])))
+                                            int(row["Start_Timestamp"]) > g0))
 # bench.py --legs greedy,paired --steps 1 --warmup 0: per leg the timed steps (one launch of 10 M reads / of 5 M pairs each),
 # the exclusive pass (the same launch again) and the counting pass
 legs = {"mem": ("k_mem", False), "greedy": ("k_greedy2", False), "paired": ("k_mem", True)}
@@ -35,14 +36,9 @@ for name, (kern, paired) in legs.items():
         continue
     def sel(counter):
         xs = big(c.get(counter, []))
-        if kern == "k_mem" and xs:
-            # the launches of the paired leg (5 M pairs) take half as long again as those of the headline leg (5 M reads)
-            lo, hi = min(d for _, d, _ in xs), max(d for _, d, _ in xs)
-            if hi > 1.25 * lo:
-                mid = 0.5 * (lo + hi)
-                xs = [x for x in xs if (x[1] > mid) == paired]
-            elif paired:
-                xs = []
+        if kern == "k_mem":
+            xs = [x for x in c.get(counter, []) if x[2] == paired]
+            xs = big(xs)
         return xs
     rd, rd32 = sel("TCC_EA0_RDREQ_sum"), sel("TCC_EA0_RDREQ_32B_sum")
     wr, wr64 = sel("TCC_EA0_WRREQ_sum"), sel("TCC_EA0_WRREQ_64B_sum")
