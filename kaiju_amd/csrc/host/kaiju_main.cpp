@@ -363,18 +363,43 @@ struct BlockReader {
 // ---------------------------------------------------------------------------------------------
 // stage 2: parse blocks into the batch layout (parallel)
 // ---------------------------------------------------------------------------------------------
+// Allocator of the batch buffers (tens of megabytes each, gigabytes in flight): big blocks are 2 MB aligned with transparent
+// huge pages asked for - first touch and release cost per page, and on the virtualised hosts this runs on a 4 KB page
+// costs about as much as a 2 MB one - and elements are default-initialised (resize() before a memcpy writes nothing).
+template <class T> struct HugeAlloc {
+  typedef T value_type;
+  HugeAlloc() = default;
+  template <class U> HugeAlloc(const HugeAlloc<U> &) {}
+  T *allocate(size_t n) {
+    const size_t bytes = n * sizeof(T);
+    void *p = nullptr;
+    if (bytes >= (4u << 20) && !getenv("KAIJU_GPU_NO_HUGEPAGES")) {
+      if (posix_memalign(&p, 2u << 20, bytes) != 0) throw std::bad_alloc();
+      (void)madvise(p, bytes, MADV_HUGEPAGE);
+    } else if (!(p = malloc(bytes ? bytes : 1))) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t) { free(p); }
+  template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(static_cast<A &&>(a)...); }
+  template <class U> bool operator==(const HugeAlloc<U> &) const { return true; }
+  template <class U> bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <class T> using HugeVec = std::vector<T, HugeAlloc<T>>;
+typedef HugeVec<char> CharVec;
+
 struct Batch {
-  std::vector<char> seqs;
-  std::vector<uint64_t> off{0};
-  std::vector<char> names;                 // concatenated
-  std::vector<uint32_t> name_off{0};
+  CharVec seqs;
+  HugeVec<uint64_t> off{0};
+  CharVec names;                           // concatenated
+  HugeVec<uint32_t> name_off{0};
   size_t n() const { return name_off.size() - 1; }
   // results
-  std::vector<kaiju_gpu_hit> hits;         // -v only
-  std::vector<kaiju_gpu_verbose> vrec;     // -v only: columns 6/7
-  std::vector<char> vtext;
+  HugeVec<kaiju_gpu_hit> hits;             // -v only
+  HugeVec<kaiju_gpu_verbose> vrec;         // -v only: columns 6/7
+  CharVec vtext;
   uint32_t vstride = 0;
-  std::vector<kaiju_gpu_compact> compact;
+  HugeVec<kaiju_gpu_compact> compact;
   std::string text;
   void reset() {                           // empty, capacities kept
     seqs.clear(); off.assign(1, 0); names.clear(); name_off.assign(1, 0);
@@ -385,18 +410,26 @@ struct Batch {
 // batches are recycled: their buffers (hundreds of megabytes per batch) are faulted in once, not per batch
 struct BatchPool {
   std::mutex m;
+  std::condition_variable cv;
   std::vector<std::unique_ptr<Batch>> free_list;
+  // Batches alive at once (KAIJU_GPU_MAX_BATCHES): the stages in front of the slowest one would otherwise run ahead by the
+  // whole depth of the pipeline - some forty batches of 100 MB, every page of which is touched once and given back at
+  // exit.  A thread asks for its batch BEFORE it takes the next block of input, so the batches alive are always the
+  // ones with the lowest sequence numbers and the ordered queues behind never wait for one that cannot get a batch.
+  size_t max_alive = 12, alive = 0;
+  BatchPool() { if (const char *e = getenv("KAIJU_GPU_MAX_BATCHES")) max_alive = (size_t)std::max(3L, atol(e)); }
   std::unique_ptr<Batch> get() {
-    {
-      std::lock_guard<std::mutex> lk(m);
-      if (!free_list.empty()) { std::unique_ptr<Batch> b = std::move(free_list.back()); free_list.pop_back(); return b; }
-    }
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return !free_list.empty() || alive < max_alive; });
+    if (!free_list.empty()) { std::unique_ptr<Batch> b = std::move(free_list.back()); free_list.pop_back(); return b; }
+    alive++;
+    lk.unlock();
     return std::unique_ptr<Batch>(new Batch());
   }
   void put(std::unique_ptr<Batch> b) {
     b->reset();
-    std::lock_guard<std::mutex> lk(m);
-    if (free_list.size() < 32) free_list.push_back(std::move(b));
+    { std::lock_guard<std::mutex> lk(m); free_list.push_back(std::move(b)); }
+    cv.notify_one();
   }
 };
 
@@ -425,7 +458,7 @@ inline void wall_mark(const char *what, long long k = -1) {
 // kaijup keeps the whole header line as the read name (kaijup.cpp:249-262 has no suffix cutting)
 bool g_keep_names = false;
 
-inline void append_stripped(std::vector<char> &dst, const char *s, size_t n) {   // strip(), util.cpp:25-32
+inline void append_stripped(CharVec &dst, const char *s, size_t n) {   // strip(), util.cpp:25-32
   const size_t old = dst.size();
   dst.resize(old + n);
   char *d = dst.data() + old;
@@ -461,7 +494,7 @@ struct BlockCursor {
     return true;
   }
   // name (cut at the first of " /\t\r") and stripped sequence of the next record
-  bool next(const char *&name, size_t &name_len, std::vector<char> &seqs) {
+  bool next(const char *&name, size_t &name_len, CharVec &seqs) {
     const char *s; size_t n;
     do { if (!line(s, n)) return false; } while (n == 0);
     s++; n--;                               // erase(0,1)
@@ -637,9 +670,13 @@ int main(int argc, char **argv) {
   kaiju_gpu_taxonomy *dtax = nullptr;
   const int n_ctx = 2;                      // ping-pong: copies of one batch overlap with kernels of the other
   kaiju_gpu_ctx *ctx[n_ctx] = {nullptr, nullptr};
-  int rc = 0;
-  if (!parse_only) {
-    int tax_rc = 0;
+  // The index loads (and nodes.dmp is parsed, and the contexts are created) on a thread of its own while the input is
+  // already being read and parsed: only the GPU stage of the pipeline waits for it.
+  struct Ready { std::mutex m; std::condition_variable cv; bool done = false; } gpu_ready;
+  std::thread loader;
+  if (!parse_only)
+    loader = std::thread([&] {
+    int tax_rc = 0, rc = 0;
     std::thread tax_loader([&] { if (!xmode) tax_rc = kaiju_taxonomy_load(nodes_fn.c_str(), &tax); });
     // a device image next to the index (<file>.kjimg, written by `python -m kaiju_amd.mkimage` or KAIJU_GPU_WRITE_IMAGE=1)
     // that is not older than it loads without parsing and packing (kaiju_gpu_index_write_image)
@@ -667,7 +704,10 @@ int main(int argc, char **argv) {
       if (rc != 0) die(std::string("kaiju_gpu_create: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
     }
     wall_mark("taxonomy uploaded, contexts created");
-  }
+    { std::lock_guard<std::mutex> lk(gpu_ready.m); gpu_ready.done = true; }
+    gpu_ready.cv.notify_all();
+  });
+  auto wait_for_gpu = [&] { std::unique_lock<std::mutex> lk(gpu_ready.m); gpu_ready.cv.wait(lk, [&] { return gpu_ready.done; }); };
 
   // kaiju-multi (kaiju-multi.cpp:221-334): comma separated lists of input / output files, one index load
   const bool multi = prog.find("multi") != std::string::npos;
@@ -709,7 +749,9 @@ int main(int argc, char **argv) {
     if (verbose) fprintf(stderr, "%s Start classification on GPU %d\n", now().c_str(), device);
 
     struct RawPair { std::unique_ptr<RawBlock> a, b; };
-    BatchPool pool;
+    // (one pool for all samples of kaiju-multi, never torn down: giving gigabytes of batch buffers back page by page
+    // when the last sample is done would only delay the end of the process)
+    static BatchPool &pool = *new BatchPool();
     OrderedQueue<RawPair> q_raw(8);
     OrderedQueue<std::unique_ptr<Batch>> q_parsed(6), q_done(6), q_text(8);
 
@@ -719,6 +761,12 @@ int main(int argc, char **argv) {
       if (!r1.ok) die("Could not open file " + in1_fn);
       { StageTimer tm(g_ns_read); r1.prescan(n_workers); }
       wall_mark("input mapped and prescanned");
+      // reads per batch: small enough that a sample fills the pipeline (sixteen batches), large enough that the persistent
+      // lanes of the search kernels get more than a read or two each
+      if (!getenv("KAIJU_GPU_BATCH") && r1.prescanned) {
+        const uint64_t n_rec = r1.rec_start.size() - 1;
+        batch_reads = (uint32_t)std::min<uint64_t>(1000000, std::max<uint64_t>(250000, (n_rec / 16 + 49999) / 50000 * 50000));
+      }
       std::unique_ptr<BlockReader> r2;
       OrderedQueue<std::unique_ptr<RawBlock>> q2(4);
       std::thread reader2;
@@ -763,8 +811,9 @@ int main(int argc, char **argv) {
     for (unsigned w = 0; w < n_workers; w++)
       parsers.emplace_back([&] {
         uint64_t seq; RawPair pr;
-        while (q_raw.take_any(seq, pr)) {
-          std::unique_ptr<Batch> b = pool.get();
+        for (;;) {
+          std::unique_ptr<Batch> b = pool.get();               // (first the batch, then the block: see BatchPool)
+          if (!q_raw.take_any(seq, pr)) { pool.put(std::move(b)); break; }
           { StageTimer tm(g_ns_parse); parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b); }
           if (paired && pr.b->n_records > pr.a->n_records)
             fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
@@ -781,6 +830,7 @@ int main(int argc, char **argv) {
           const uint32_t n = (uint32_t)b->n();
           int r = 0;
           if (parse_only) { q_done.put(seq, std::move(b)); continue; }
+          wait_for_gpu();
           StageTimer tm(g_ns_gpu);
           wall_mark("gpu call begins, batch", (long long)seq);
           if (verbose) {
@@ -949,6 +999,7 @@ int main(int argc, char **argv) {
             (unsigned long long)inexact_batches.load());
     if (!getenv("KAIJU_GPU_ALLOW_INEXACT")) return 3;
   }
+  if (loader.joinable()) loader.join();       // (an input without reads: the verdict on index and nodes.dmp is still due)
   wall_mark("before teardown");
   // Everything is written and closed.  Returning the device memory allocation by allocation and unloading the HIP runtime
   // costs a sizeable fraction of a second that no caller is waiting for, so the process ends here; KAIJU_GPU_CLEAN_EXIT=1 (and
