@@ -397,7 +397,7 @@ struct GreedyArrays2 {
   uint32_t gate;
 };
 constexpr size_t kGreedy2Lds = (size_t)kBlock * (kGWinStride + kGMqStride + kGPrioStride) * 4 + sizeof(ConstTables);
-__global__ void __launch_bounds__(kBlock, 2)
+__global__ void __launch_bounds__(kBlock, kGreedyWavesPerSimd)
 k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   uint32_t *s_prio = s_dyn;                                   // 16-byte aligned rows
@@ -416,6 +416,13 @@ k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue 
   gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
   gs.best = ga.best + lane * 64;
   gs.gate = ga.gate;
+  gs.prof = nullptr;
+#ifdef KJ_PROF
+  __shared__ unsigned long long s_prof[kBlock / 64][2 + 3 * PS_N];
+  for (int x = threadIdx.x & 63; x < 2 + 3 * PS_N; x += 64) s_prof[threadIdx.x >> 6][x] = 0;
+  gs.prof = s_prof[threadIdx.x >> 6];
+  if ((threadIdx.x & 63) == 0) { gs.prof[0] = __builtin_readcyclecounter(); gs.prof[1] = PS_HEAD; }
+#endif
   greedy_lane2(ix, s_ct, p, sq, b, wl, gs);
 }
 __global__ void __launch_bounds__(kBlock, 1)
@@ -437,6 +444,7 @@ k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Seg
   gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
   gs.best = ga.best + lane * 64;
   gs.gate = ga.gate;
+  gs.prof = nullptr;
   greedy_lane2<true>(ix, s_ct, p, sq, b, wl, gs);
 }
 
@@ -946,7 +954,7 @@ struct kaiju_gpu_ctx {
   DevBuf scratch_main[10], scratch_retry[5], h_compact;
   DevBuf redo_bitmap, redo_list, redo_items, redo_index, redo_pool, redo_work, redo_cls;    // the exact pass
   bool greedy2 = false;
-  uint32_t greedy_gate = 3;
+  uint32_t greedy_gate = 3u | 32u << 8;   // heavy iteration every 4th, or as soon as half the wavefront waits for one (measured: r02_gprof)
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
   bool exact_pass = true;          // KAIJU_GPU_EXACT_PASS=0 switches the exact pass off (its reads stay flagged)
   bool count_ops = false;          // kaiju_gpu_set_count_ops: the main pass runs the counting instantiation of its lane
@@ -1043,9 +1051,9 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
                  p->seed_length >= 3;
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; c->greedy3 = !strcmp(e, "v3"); }
     if (const char *e = getenv("KAIJU_GPU_G3_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->g3_rounds = (uint32_t)v; }
-    if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (uint32_t)v; }
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (c->greedy_gate & ~0xffu) | (uint32_t)v; }
     // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
-    if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate |= (uint32_t)v << 8; }
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate = (c->greedy_gate & 0xffu) | (uint32_t)v << 8; }
     if (c->greedy2) {
       KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kGreedy2Lds));
@@ -1091,7 +1099,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if ((rc = ensure(c->frags, n_frag_slots * sizeof(Frag)))) return rc;
   if (n_frag_slots >= 0xffffffffull) return fail(KAIJU_GPU_ERR_UNSUPPORTED, "batch too large: split it (fragment slots exceed 2^32)");
   if ((rc = ensure(c->meta, (size_t)n * sizeof(ReadMeta) + 16))) return rc;
-  if ((rc = ensure(c->counters, 1024))) return rc;     // [0, 256) counters, [512, ..) totals of the counting lanes
+  if ((rc = ensure(c->counters, 4096))) return rc;     // [0, 256) counters, [512, ..) totals of the counting lanes
   if ((rc = ensure(c->retry_list, (size_t)n * 4 + 16))) return rc;
   Batch b;
   b.seqs = static_cast<const uint8_t *>(d_seqs); b.off = d_off; b.n_reads = n; b.paired = paired ? 1 : 0;
@@ -1105,7 +1113,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   SegQueue sq;
   sq.items = static_cast<SegWork *>(c->seg_items.p); sq.recs = static_cast<SegRec *>(c->seg_recs.p);
   sq.count = cnt + 4; sq.cap = (uint32_t)seg_cap;
+#ifdef KJ_PROF
+  KJ_HIP(hipMemsetAsync(cnt, 0, 4096, s));
+#else
   KJ_HIP(hipMemsetAsync(cnt, 0, 1024, s));
+#endif
   if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
@@ -1666,6 +1678,22 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
                       "slow compute %llu, loop head %llu | iterations (sum of last-wave counters) %llu heavy %llu\n",
               acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] >> 32, acc[5] & 0xffffffffull);
   }
+#ifdef KJ_PROF
+  if (ctx->params.mode == 1) {
+    static const char *names[PS_N] = {"HEAD", "AFTER_SEARCH", "VAR_NEXT", "VAR_MATCH", "EVAL_NEXT", "EVAL_MATCH", "POP", "POP_SEG", "FINISH",
+                                      "HANDOUT", "LOAD", "LOAD10", "STEP", "KMER", "LF1", "SA", "VM_RANK", "VM_PUSH", "META", "FRAG",
+                                      "FILL", "MLOAD", "END_MATCH", "START_J", "LOC_ROW", "TAIL"};
+    unsigned long long pv[3 * PS_N];
+    KJ_HIP(hipMemcpy(pv, static_cast<uint8_t *>(ctx->counters.p) + 1024, sizeof pv, hipMemcpyDeviceToHost));
+    unsigned long long tot = 0;
+    for (int x = 0; x < PS_N; x++) tot += pv[3 * x];
+    fprintf(stderr, "[kj prof] section        cycles%%   entries/read  lanes/entry   cycles/entry   (n_reads %u, total wave-cycles %llu)\n", ctx->last_n, tot);
+    for (int x = 0; x < PS_N; x++)
+      fprintf(stderr, "[kj prof] %-13s %7.2f %12.3f %10.1f %12.1f\n", names[x], 100.0 * pv[3 * x] / (double)(tot ? tot : 1),
+              (double)pv[3 * x + 1] / (ctx->last_n ? ctx->last_n : 1), (double)pv[3 * x + 2] / (double)(pv[3 * x + 1] ? pv[3 * x + 1] : 1),
+              (double)pv[3 * x] / (double)(pv[3 * x + 1] ? pv[3 * x + 1] : 1));
+  }
+#endif
   stats->n_reads = ctx->last_n;
   stats->n_overflow_retries = cnt[2];
   stats->n_seg_fragments = cnt[4];

@@ -2704,12 +2704,44 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
 // ----------------------------------------------------------------------------
 #ifdef KJ_G_SMALL                                  // tests: exercise the spill and retry paths
 constexpr int kGMaxM = 1, kGMaxMAll = 2, kGSlots = 1, kGSlotsAll = 3;
+#elif defined(KJ_G_OCC3)                           // experiment: LDS rows small enough for three blocks per CU
+constexpr int kGMaxM = 12, kGMaxMAll = 256;
+constexpr int kGSlots = 20, kGSlotsAll = 128;
 #else
 constexpr int kGMaxM = 24, kGMaxMAll = 256;      // matches of one fragment: lengths in LDS / in LDS + global spill
 constexpr int kGSlots = 44, kGSlotsAll = 128;    // queue slots: priorities in LDS / in LDS + global spill
 #endif
 // LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
+#if defined(KJ_G_OCC3) && !defined(KJ_G_SMALL)
+constexpr int kGWinStride = 17, kGMqStride = 7, kGPrioStride = 20;     // 176 bytes per lane
+constexpr int kGreedyWavesPerSimd = 3;           // (the lane needs 247 VGPRs: at 168 the compiler spills 724 bytes per lane)
+#else
 constexpr int kGWinStride = 17, kGMqStride = 13, kGPrioStride = 44;
+constexpr int kGreedyWavesPerSimd = 2;
+#endif
+
+// -DKJ_PROF (developer build, tests/tools/greedy_prof.sh): where a wavefront of greedy_lane2 spends its cycles.  KJ_P(section)
+// charges the cycles since the previous mark to the PREVIOUS section and notes with how many active lanes the new one is
+// entered; sums per wavefront in LDS, added to the counter block (byte 1024 on) when the wavefront ends.
+enum ProfSec : int { PS_HEAD, PS_AFTER_SEARCH, PS_VAR_NEXT, PS_VAR_MATCH, PS_EVAL_NEXT, PS_EVAL_MATCH, PS_POP, PS_POP_SEG, PS_FINISH,
+                     PS_HANDOUT, PS_LOAD, PS_LOAD10, PS_STEP, PS_KMER, PS_LF1, PS_SA, PS_VM_RANK, PS_VM_PUSH, PS_META, PS_FRAG,
+                     PS_FILL, PS_MLOAD, PS_END_MATCH, PS_START_J, PS_LOC_ROW, PS_TAIL, PS_N };
+#if defined(KJ_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define KJ_P(sec) kj_prof_mark(gs.prof, (sec))
+__device__ __forceinline__ void kj_prof_mark(unsigned long long *pw, int sec) {
+  const unsigned long long now = __builtin_readcyclecounter();
+  const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+  if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) {
+    const unsigned long long prev = pw[1];
+    pw[2 + 3 * prev] += now - pw[0];
+    pw[2 + 3 * sec + 1] += 1ull;
+    pw[2 + 3 * sec + 2] += (unsigned long long)__builtin_popcountll(ex);
+    pw[0] = now; pw[1] = (unsigned long long)sec;
+  }
+}
+#else
+#define KJ_P(sec)
+#endif
 
 struct GMatch2 { uint32_t lo, len, qiql, dp; };          // qi | ql << 16, dsum | psum << 16
 struct GBest2 { uint32_t lo, len; };
@@ -2723,6 +2755,7 @@ struct GreedyScratch2 {
   uint16_t *mq_ext;            // lengths of the matches kGMaxM .. kGMaxMAll-1
   GBest2 *best;                // 64
   uint32_t gate;               // heavy iterations: (iteration & gate) == 0
+  unsigned long long *prof;    // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PS_N)
 };
 
 enum GKind : int { G_STEP, G_KMER, G_LF1, G_LF2, G_SA,                                     // fast
@@ -2861,6 +2894,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
 #define KJ_TICK(acc)
 #endif
   for (;;) {
+    KJ_P(PS_HEAD);
     // wave-uniform: every (gate+1)-th iteration, or as soon as many lanes wait for the slow part
     bool heavy = (itc & (gs.gate & 0xffu)) == 0;
     if (!heavy && (gs.gate >> 8) != 0)
@@ -2873,6 +2907,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       if (kind == G_WAIT) bk = bk_pend;
       while (bk != GB_NONE) {
         if (bk == GB_AFTER_SEARCH) {
+          KJ_P(PS_AFTER_SEARCH);
           if (nm == 0 || m_ovf) bk = GB_POP;               // (overflow: the read is redone in the retry pass)
           else if (p.mismatches > 0 && t_nmm < p.mismatches) {
             // the order in which `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the
@@ -2883,6 +2918,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           } else { ev_pass = -1; bk = GB_EVAL_NEXT; }
         }
         if (bk == GB_VAR_NEXT) {
+          KJ_P(PS_VAR_NEXT);
           bool have = false;
           if (nm == 1) {
             if (vi_phase == 0) { vi_phase = 2; have = true; }
@@ -2906,6 +2942,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           else { ml_for = 0; kind = G_MLOAD; bk = GB_NONE; }
         }
         if (bk == GB_VAR_MATCH) {
+          KJ_P(PS_VAR_MATCH);
           const uint32_t mre = m_qi + m_ql - 1u;
           if (!(m_qi > 0 && mre + 1u >= p.m)) { bk = GB_VAR_NEXT; continue; }          // :469
           else if (!in_win((int)m_qi - 1)) {
@@ -2925,6 +2962,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           }
         }
         if (bk == GB_EVAL_NEXT) {
+          KJ_P(PS_EVAL_NEXT);
           // eval_match_scores(si, t), :751-797: the samelen chains of the classes (descending length,
           // while >= m) in insertion order, then the class heads in ascending length
           if (nm == 1) {
@@ -2960,8 +2998,9 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             }
           }
         }
-        if (bk == GB_EVAL_MATCH) { eval_match(); bk = GB_EVAL_NEXT; continue; }
+        if (bk == GB_EVAL_MATCH) { KJ_P(PS_EVAL_MATCH); eval_match(); bk = GB_EVAL_NEXT; continue; }
         if (bk == GB_POP) {
+          KJ_P(PS_POP);
           // getNextFragment(best_match_score), ConsumerThread.cpp:272-342
           uint32_t dbest = 0, dslot = 0;
           {
@@ -2985,6 +3024,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                 // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked
                 // pieces are queued, and the next fragment is popped (:291-334)
                 const uint32_t slot = oflags >> kFragSlotShift;
+                KJ_P(PS_POP_SEG);
                 if (slot) {
                   const SegRec &rec = sq.recs[slot - 1];
                   if (rec.overflow) flags |= kHitInternalOverflow;
@@ -3014,6 +3054,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           }
         }
         if (bk == GB_FINISH) {
+          KJ_P(PS_FINISH);
           nids = 0;
           hit->reserved = 0;
           if (ovf || m_ovf) {
@@ -3046,6 +3087,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       }
 
       // ---- (H1) hand out reads to the lanes that finished one (see mem_lane2) ----
+      KJ_P(PS_HANDOUT);
       {
         const bool need = kind == G_IDLE;
         const uint64_t mask = kj_ballot(need);
@@ -3078,6 +3120,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     }
 
     // ---- (1) load phase ----
+    KJ_P(PS_LOAD);
     KJ_TICK(st_heavy)
 #if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
     if (heavy) st_nheavy++;
@@ -3122,17 +3165,16 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     else if (kind == G_MLOAD) gaddr = reinterpret_cast<const uint8_t *>(gs.matches + mx);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
     const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
-    // ten 16-byte reads from two lane-chosen places: a window (G_FILL), a queued item (G_POPITEM),
-    // the 20 letter counts of both rank blocks (G_VMULTI)
+    // ten 16-byte reads from two lane-chosen places: a window (G_FILL), a queued item (G_POPITEM)
     u128 xa0{0, 0}, xa1{0, 0}, xa2{0, 0}, xa3{0, 0}, xa4{0, 0}, xb0{0, 0}, xb1{0, 0}, xb2{0, 0}, xb3{0, 0}, xb4{0, 0};
     int fq = 0;
-    if (heavy && kj_ballot(kind == G_FILL || kind == G_POPITEM || is_vm)) {   // wave-uniform
+    if (heavy && kj_ballot(kind == G_FILL || kind == G_POPITEM)) {            // wave-uniform
+      KJ_P(PS_LOAD10);
       fq = fill_top - (kWin - 1);
       if (fq < 0) fq = 0;
       const uint8_t *sa = reinterpret_cast<const uint8_t *>(blk0), *sb = sa;
       if (kind == G_FILL) sa = b.pep + pepoff + t_start + fq;
       else if (kind == G_POPITEM) { sa = reinterpret_cast<const uint8_t *>(gs.pool + 8 * pslot); sb = sa + 80; }
-      else if (is_vm) { sa = reinterpret_cast<const uint8_t *>(&pa->cnt[0]); sb = reinterpret_cast<const uint8_t *>(&pb->cnt[0]); }
       const u128_unaligned *pa16 = reinterpret_cast<const u128_unaligned *>(sa);
       const u128_unaligned *pb16 = reinterpret_cast<const u128_unaligned *>(sb);
       xa0 = pa16[0]; xa1 = pa16[1]; xa2 = pa16[2]; xa3 = pa16[3]; xa4 = pa16[4];
@@ -3143,6 +3185,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     KJ_TICK(st_load)
     int bk = GB_NONE;
     if (is_step || kind == G_LF2) {
+      KJ_P(PS_STEP);
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
@@ -3163,6 +3206,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         bk = GB_LOC_ROW;
       }
     } else if (kind == G_KMER) {
+      KJ_P(PS_KMER);
       const uint64_t e = ghalf ? gv.y : gv.x;
       lo = (P)e; hi = (P)e + (P)(e >> 32);
       if (lo >= hi) { i = j; bk = GB_END_MATCH; }          // seed shorter than kk: never recorded, i > 1
@@ -3173,6 +3217,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
       }
     } else if (kind == G_LF1) {
+      KJ_P(PS_LF1);
       const uint32_t sft = k & 63u;
       c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
           (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
@@ -3187,6 +3232,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         bk = GB_LOC_ROW;
       }
     } else if (kind == G_SA) {
+      KJ_P(PS_SA);
       const uint64_t tax = ghalf ? gv.y : gv.x;
       if (tax != ~0ull) add_tax(tax);
       row++;
@@ -3195,97 +3241,102 @@ if constexpr (COUNT) oc[kOpcTerm]++;
     } else if (heavy) {
       KJ_TICK(st_fast)
       if (is_vm) {
-        // UpdateSI(trans[substitute]) on the interval of the match for all substitutes at once
-        // (ConsumerThread.cpp:366-392): the ranks of the 20 letters at both ends of the interval
+        KJ_P(PS_VM_RANK);
+        // UpdateSI(trans[substitute]) on the interval of the match for all substitutes (ConsumerThread.cpp:366-392).
+        // Only letters that OCCUR in BWT[lo, hi) extend it, and the interval of a match of eleven letters or more is a row
+        // or a few: when both ends lie in the same or in neighbouring rank blocks the letters are read off the two lines
+        // (a symbol at a time, each distinct letter once); an interval that spans more tries all twenty.
         const uint64_t lowA = (1ull << (posA & 63u)) - 1ull, lowB = (1ull << (posB & 63u)) - 1ull;
-        uint64_t A01[4], A23[4], A4[2], B01[4], B23[4], B4[2];
-        A01[0] = ~a01.x & ~a01.y & lowA; A01[1] = a01.x & ~a01.y & lowA; A01[2] = ~a01.x & a01.y & lowA; A01[3] = a01.x & a01.y & lowA;
-        A23[0] = ~a23.x & ~a23.y; A23[1] = a23.x & ~a23.y; A23[2] = ~a23.x & a23.y; A23[3] = a23.x & a23.y;
-        A4[0] = ~a4; A4[1] = a4;
-        B01[0] = ~b01.x & ~b01.y & lowB; B01[1] = b01.x & ~b01.y & lowB; B01[2] = ~b01.x & b01.y & lowB; B01[3] = b01.x & b01.y & lowB;
-        B23[0] = ~b23.x & ~b23.y; B23[1] = b23.x & ~b23.y; B23[2] = ~b23.x & b23.y; B23[3] = b23.x & b23.y;
-        B4[0] = ~b4; B4[1] = b4;
-        uint32_t cntA[20], cntB[20];
-        {
-          const u128 xs[5] = {xa0, xa1, xa2, xa3, xa4}, ys[5] = {xb0, xb1, xb2, xb3, xb4};
-#pragma unroll
-          for (int q = 0; q < 5; q++) {
-            cntA[4 * q] = (uint32_t)xs[q].x; cntA[4 * q + 1] = (uint32_t)(xs[q].x >> 32);
-            cntA[4 * q + 2] = (uint32_t)xs[q].y; cntA[4 * q + 3] = (uint32_t)(xs[q].y >> 32);
-            cntB[4 * q] = (uint32_t)ys[q].x; cntB[4 * q + 1] = (uint32_t)(ys[q].x >> 32);
-            cntB[4 * q + 2] = (uint32_t)ys[q].y; cntB[4 * q + 3] = (uint32_t)(ys[q].y >> 32);
-          }
-        }
+        const uint32_t dblk = (uint32_t)((posB >> 6) - (posA >> 6));
         // the reference stops at the first substitute whose score is too low (:368-369); the
         // substitutes are sorted by score (host_tables.cpp checks), so that is a threshold
         const int32_t thr = (int32_t)best > (int32_t)p.min_score ? (int32_t)best : (int32_t)p.min_score;
-        const uint32_t *brow = reinterpret_cast<const uint32_t *>(ct.b62_idx[vorig]);
-        const uint32_t bw[5] = {brow[0], brow[1], brow[2], brow[3], brow[4]};
         const uint32_t corig = ct.aa_to_idx[vorig];
-        uint32_t ra_[20], rb_[20], succ = 0;
-#pragma unroll
-        for (int cx = 1; cx <= 20; cx++) {
-          ra_[cx - 1] = cntA[cx - 1] + popc64(A01[cx & 3] & A23[(cx >> 2) & 3] & A4[cx >> 4]);
-          rb_[cx - 1] = cntB[cx - 1] + popc64(B01[cx & 3] & B23[(cx >> 2) & 3] & B4[cx >> 4]);
-          const int bos = (int)(int8_t)(bw[(cx - 1) >> 2] >> (8 * ((cx - 1) & 3)));
-          const int32_t after = (int32_t)(vscore + (uint32_t)(int32_t)bos);
-          if (ra_[cx - 1] < rb_[cx - 1] && after >= thr && (uint32_t)cx != corig) succ |= 1u << cx;
-        }
-        if (succ) {
-          const int boo = (int)ct.b62[vorig][vorig];
-          // the variants share everything but the letter: window of the fragment with the new letter
-          const uint32_t pz = m_qi - 1u;
-          const int need_fq = (int)m_qi - 2 - (kWin - 1) > 0 ? (int)m_qi - 2 - (kWin - 1) : 0;
-          const bool win_ok = need_fq == wq;                // the variant resumes at m_qi-2 (if m_qi > 1)
-          const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
-          u128 wv0, wv1, wv2, wv3;
-          wv0.x = w32[0] | (uint64_t)w32[1] << 32; wv0.y = w32[2] | (uint64_t)w32[3] << 32;
-          wv1.x = w32[4] | (uint64_t)w32[5] << 32; wv1.y = w32[6] | (uint64_t)w32[7] << 32;
-          wv2.x = w32[8] | (uint64_t)w32[9] << 32; wv2.y = w32[10] | (uint64_t)w32[11] << 32;
-          wv3.x = w32[12] | (uint64_t)w32[13] << 32; wv3.y = w32[14] | (uint64_t)w32[15] << 32;
-          uint32_t q0 = sp0, q1 = sp1, q2 = sp2, q3 = sp3;
-          if (t_nmm < (uint32_t)kMaxMismatch) {
-            const uint32_t hs = (t_nmm & 1u) * 16u;
-            const uint32_t hm = ~(0xffffu << hs), pzz = (pz & 0xffffu) << hs;
-            switch (t_nmm >> 1) {
-              case 0: q0 = (q0 & hm) | pzz; break;
-              case 1: q1 = (q1 & hm) | pzz; break;
-              case 2: q2 = (q2 & hm) | pzz; break;
-              default: q3 = (q3 & hm) | pzz; break;
-            }
+        auto match_of = [](const u128 &p01, const u128 &p23, uint64_t p4, uint32_t cx) -> uint64_t {
+          const uint64_t ia = (cx & 1u) ? 0ull : ~0ull, ib = (cx & 2u) ? 0ull : ~0ull, ic = (cx & 4u) ? 0ull : ~0ull,
+                         id = (cx & 8u) ? 0ull : ~0ull, ie = (cx & 16u) ? 0ull : ~0ull;
+          return (p01.x ^ ia) & (p01.y ^ ib) & (p23.x ^ ic) & (p23.y ^ id) & (p4 ^ ie);
+        };
+        auto symbol_at = [](const u128 &p01, const u128 &p23, uint64_t p4, uint32_t t) -> uint32_t {
+          return (uint32_t)((p01.x >> t) & 1ull) | (uint32_t)((p01.y >> t) & 1ull) << 1 | (uint32_t)((p23.x >> t) & 1ull) << 2 |
+                 (uint32_t)((p23.y >> t) & 1ull) << 3 | (uint32_t)((p4 >> t) & 1ull) << 4;
+        };
+        uint32_t todo = 0x1ffffeu;                          // letters 1..20
+        if (dblk <= 1u) {
+          todo = 0;
+          uint64_t ma = dblk == 0 ? (lowB & ~lowA) : ~lowA;  // rows of the interval in the first line
+          while (ma) {
+            const uint32_t cx = symbol_at(a01, a23, a4, (uint32_t)__builtin_ctzll(ma));
+            ma &= ~match_of(a01, a23, a4, cx);
+            todo |= 1u << cx;
           }
-          if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; succ = 0; }
-          while (succ) {
-            const uint32_t cx = (uint32_t)__builtin_ctz(succ);
-            succ &= succ - 1u;
-            uint32_t ra = 0, rb = 0;
-#pragma unroll
-            for (int q = 0; q < 20; q++) if (cx == (uint32_t)q + 1u) { ra = ra_[q]; rb = rb_[q]; }
-            const int bos = (int)ct.b62_idx[vorig][cx - 1u], bss = (int)diag(cx);
-            const uint32_t key = (uint32_t)(int32_t)(vscore + (uint32_t)(int32_t)bos);
-            const uint32_t sl = push_slot(key, qseq + ct.subst_rank[vorig][cx - 1u]);
-            if (sl == ~0u) break;
-            uint32_t e0 = sa0, e1 = sa1;
-            if (t_nmm < (uint32_t)kMaxMismatch) {
-              const uint32_t bs = (t_nmm & 3u) * 8u, bm = ~(0xffu << bs);
-              if (t_nmm < 4u) e0 = (e0 & bm) | cx << bs; else e1 = (e1 & bm) | cx << bs;
-            }
-            u128 *dst = gs.pool + 8 * sl;
-            u128 v;
-            v.x = ra | (uint64_t)rb << 32; v.y = key | (uint64_t)t_start << 32; dst[0] = v;
-            v.x = (vlen | (m_ql + 1u) << 16) | (uint64_t)(uint32_t)(t_diff + bos - bss) << 32;
-            v.y = (m_psum - (uint32_t)boo + (uint32_t)bss) | (uint64_t)(m_dsum + (uint32_t)bss) << 32; dst[1] = v;
-            v.x = (t_nmm + 1u) | (uint64_t)q0 << 32; v.y = q1 | (uint64_t)q2 << 32; dst[2] = v;
-            v.x = q3 | (uint64_t)e0 << 32; v.y = e1 | (uint64_t)(win_ok ? (uint32_t)wq + 1u : 0u) << 32; dst[3] = v;
-            if (win_ok) {
-              dst[4] = wv0; dst[5] = wv1; dst[6] = wv2; dst[7] = wv3;
-              reinterpret_cast<uint8_t *>(dst + 4)[(int)pz - wq] = (uint8_t)cx;   // pz is in the window (GB_VAR_MATCH)
-            }
+          uint64_t mb = dblk == 0 ? 0ull : lowB;             // ... and in the second
+          while (mb) {
+            const uint32_t cx = symbol_at(b01, b23, b4, (uint32_t)__builtin_ctzll(mb));
+            mb &= ~match_of(b01, b23, b4, cx);
+            todo |= 1u << cx;
+          }
+          todo &= 0x1ffffeu;                                 // (terminators and the padding behind the last row are no letters)
+        }
+        todo &= ~(1u << corig);
+        uint32_t q0 = sp0, q1 = sp1, q2 = sp2, q3 = sp3;
+        const uint32_t pz = m_qi - 1u;
+        if (t_nmm < (uint32_t)kMaxMismatch) {
+          const uint32_t hs = (t_nmm & 1u) * 16u;
+          const uint32_t hm = ~(0xffffu << hs), pzz = (pz & 0xffffu) << hs;
+          switch (t_nmm >> 1) {
+            case 0: q0 = (q0 & hm) | pzz; break;
+            case 1: q1 = (q1 & hm) | pzz; break;
+            case 2: q2 = (q2 & hm) | pzz; break;
+            default: q3 = (q3 & hm) | pzz; break;
+          }
+        }
+        const int boo = (int)ct.b62[vorig][vorig];
+        // the variants share everything but the letter: window of the fragment with the new letter
+        const int need_fq = (int)m_qi - 2 - (kWin - 1) > 0 ? (int)m_qi - 2 - (kWin - 1) : 0;
+        const bool win_ok = need_fq == wq;                  // the variant resumes at m_qi-2 (if m_qi > 1)
+        while (todo) {
+          const uint32_t cx = (uint32_t)__builtin_ctz(todo);
+          todo &= todo - 1u;
+          const int bos = (int)ct.b62_idx[vorig][cx - 1u];
+          const uint32_t key = (uint32_t)(int32_t)(vscore + (uint32_t)(int32_t)bos);
+          if ((int32_t)key < thr) continue;
+          // the letter's counts in front of the two lines: read now that the letter is known (the lines have just been
+          // fetched, so this is a cache hit - cheaper than holding all forty counts in registers for the few that are used)
+          const uint32_t ra = pa->cnt[cx - 1u] + popc64(match_of(a01, a23, a4, cx) & lowA);
+          const uint32_t rb = pb->cnt[cx - 1u] + popc64(match_of(b01, b23, b4, cx) & lowB);
+          if (ra >= rb) continue;
+          KJ_P(PS_VM_PUSH);
+          if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; break; }
+          const int bss = (int)diag(cx);
+          const uint32_t sl = push_slot(key, qseq + ct.subst_rank[vorig][cx - 1u]);
+          if (sl == ~0u) break;
+          uint32_t e0 = sa0, e1 = sa1;
+          if (t_nmm < (uint32_t)kMaxMismatch) {
+            const uint32_t bs = (t_nmm & 3u) * 8u, bm = ~(0xffu << bs);
+            if (t_nmm < 4u) e0 = (e0 & bm) | cx << bs; else e1 = (e1 & bm) | cx << bs;
+          }
+          u128 *dst = gs.pool + 8 * sl;
+          u128 v;
+          v.x = ra | (uint64_t)rb << 32; v.y = key | (uint64_t)t_start << 32; dst[0] = v;
+          v.x = (vlen | (m_ql + 1u) << 16) | (uint64_t)(uint32_t)(t_diff + bos - bss) << 32;
+          v.y = (m_psum - (uint32_t)boo + (uint32_t)bss) | (uint64_t)(m_dsum + (uint32_t)bss) << 32; dst[1] = v;
+          v.x = (t_nmm + 1u) | (uint64_t)q0 << 32; v.y = q1 | (uint64_t)q2 << 32; dst[2] = v;
+          v.x = q3 | (uint64_t)e0 << 32; v.y = e1 | (uint64_t)(win_ok ? (uint32_t)wq + 1u : 0u) << 32; dst[3] = v;
+          if (win_ok) {
+            const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+            u128 wv;
+            wv.x = w32[0] | (uint64_t)w32[1] << 32; wv.y = w32[2] | (uint64_t)w32[3] << 32; dst[4] = wv;
+            wv.x = w32[4] | (uint64_t)w32[5] << 32; wv.y = w32[6] | (uint64_t)w32[7] << 32; dst[5] = wv;
+            wv.x = w32[8] | (uint64_t)w32[9] << 32; wv.y = w32[10] | (uint64_t)w32[11] << 32; dst[6] = wv;
+            wv.x = w32[12] | (uint64_t)w32[13] << 32; wv.y = w32[14] | (uint64_t)w32[15] << 32; dst[7] = wv;
+            reinterpret_cast<uint8_t *>(dst + 4)[(int)pz - wq] = (uint8_t)cx;   // pz is in the window (GB_VAR_MATCH)
           }
         }
         qseq += 19;
         bk = GB_VAR_NEXT;
       } else if (kind == G_META) {
+        KJ_P(PS_META);
         pepoff = gv.x;
         fbase = (uint32_t)gv.y;
         nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
@@ -3296,9 +3347,11 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         hit = b.hits + r;
         if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
       } else if (kind == G_FRAG) {
+        KJ_P(PS_FRAG);
         on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
         bk = GB_POP;
       } else if (kind == G_FILL || kind == G_POPITEM) {
+        KJ_P(PS_FILL);
         bool fill = kind == G_FILL;
         u128 f0 = xa0, f1 = xa1, f2 = xa2, f3 = xa3;
         int newq = fq;
@@ -3353,6 +3406,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           else bk = GB_VAR_MATCH;
         }
       } else if (kind == G_MLOAD) {
+        KJ_P(PS_MLOAD);
         m_lo = (uint32_t)gv.x; m_len = (uint32_t)(gv.x >> 32);
         m_qi = (uint32_t)gv.y & 0xffffu; m_ql = ((uint32_t)gv.y >> 16) & 0xffffu;
         m_dsum = (uint32_t)(gv.y >> 32) & 0xffffu; m_psum = (uint32_t)(gv.y >> 48) & 0xffffu;
@@ -3362,8 +3416,10 @@ if constexpr (COUNT) oc[kOpcTerm]++;
 
     // ---- (3) fast bookkeeping; everything else waits for the next heavy iteration ----
     if (heavy) { KJ_TICK(st_slow) } else { KJ_TICK(st_fast) }
+    KJ_P(PS_TAIL);
     while (bk != GB_NONE) {
       if (bk == GB_END_MATCH) {
+        KJ_P(PS_END_MATCH);
         const int l = j - i + 1;
         if (t_nmm == 0) {
           if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {        // bwt.c:276-278
@@ -3390,6 +3446,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         }
       }
       if (bk == GB_START_J) {
+        KJ_P(PS_START_J);
         if (j < (int)p.seed_length - 1) bk = GB_AFTER_SEARCH;
         else if (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1))) {
           fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;
@@ -3418,11 +3475,18 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; bk = GB_NONE; }
         }
       }
-      if (bk == GB_LOC_ROW) bk = loc_row();
+      if (bk == GB_LOC_ROW) { KJ_P(PS_LOC_ROW); bk = loc_row(); }
       if (bk > GB_LOC_ROW) { bk_pend = bk; kind = G_WAIT; bk = GB_NONE; }
     }
   }
   if constexpr (COUNT) opc_flush(opc_of(wl), oc);
+#if defined(KJ_PROF) && defined(__HIP_DEVICE_COMPILE__)
+  KJ_P(PS_HEAD);
+  if ((threadIdx.x & 63u) == 0) {
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(wl.counter) + 1024);
+    for (int x = 0; x < 3 * PS_N; x++) atomicAdd(dst + x, gs.prof[2 + x]);
+  }
+#endif
 #if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
   if ((threadIdx.x & 63u) == 0) {
     // experiment only: cycles per section of the lane loop, summed over the wavefronts

@@ -12,14 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import util  # noqa: E402
 
-so = "/tmp/libkaiju_kernel_emu_hist.so"
-srcs = [os.path.join(util.EMU_DIR, "kernel_emu.cpp")] + [os.path.join(util.CSRC, f) for f in
-                                                         ("host_index.cpp", "host_tables.cpp", "taxonomy.cpp")]
-subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-pthread", "-DKJ_HIST",
-                "-o", so] + srcs, check=True)
-util.EMU_SO = so
-util.build_emu = lambda: None
-emu = util.Emu()
+emu = util.Emu("/tmp/libkaiju_kernel_emu_hist.so", defines=("KJ_HIST",))
 emu.lib.emu_hist.restype = C.POINTER(C.c_ulonglong * (8 * 64))
 W = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Raw PMC passes (rocprofv3 --kernel-trace --pmc, one counter group per run) + a kernel-trace summary for one
 # prepared workload, MEM and Greedy; everything is written below <outdir> as CSV (copied to profiles/ by hand).
-# usage: recon_pmc.sh <workdir> <outdir> [nreads] [modes]
+# usage: [PASSES="1 2"] [SKIP_TRACE=1] recon_pmc.sh <workdir> <outdir> [nreads] [modes]
 W=$1; OUT=$2; N=${3:-2000000}; MODES=${4:-"mem greedy"}
 R=$(cd "$(dirname "$0")/../.." && pwd)
 export TMPDIR=/tmp
@@ -10,8 +10,10 @@ OUT=$(cd $OUT && pwd)
 cd /tmp
 [ -f $W/db.fmi ] || python $R/tests/tools/prof_prepare.py $W 680001 $N > $OUT/prepare.log 2>&1
 for MODE in $MODES; do
+  if [ -z "$SKIP_TRACE" ]; then
   python $R/tests/tools/prof_run.py $W $MODE 1 2 $N > $OUT/${MODE}_plain.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${MODE}_trace -o t -- python $R/tests/tools/prof_run.py $W $MODE 1 2 $N > $OUT/${MODE}_trace.log 2>&1
+  fi
   i=0
   for ctrs in \
     "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
@@ -22,6 +24,7 @@ for MODE in $MODES; do
     "FETCH_SIZE" \
     "WRITE_SIZE TCC_WRITE_sum" ; do
     i=$((i+1))
+    if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $i "; then continue; fi
     timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/${MODE}_pmc$i -o p -- python $R/tests/tools/prof_run.py $W $MODE 1 1 $N > $OUT/${MODE}_pmc$i.log 2>&1
     echo "$MODE pass $i rc=$? : $ctrs"
   done
