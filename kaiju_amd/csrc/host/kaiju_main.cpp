@@ -178,6 +178,7 @@ struct BlockReader {
     }
   }
   ~BlockReader() {
+    for (auto &x : scanners) if (x.joinable()) x.join();
     if (fp) gzclose(fp);
     // (the mapping outlives the reader: blocks in the pipeline still point into it; run_sample() unmaps it when every
     // block of the sample has been consumed - release_mappings())
@@ -271,6 +272,17 @@ struct BlockReader {
     }
     return size;
   }
+  // The file is cut into pieces (64 MB, at least one per thread) that a pool of threads walks in file order; next() merges
+  // the pieces one after the other as it needs records, so the first blocks are on their way while the rest of a large
+  // file is still being scanned.
+  struct Piece { size_t guess = 0, limit = 0, stop = 0; std::vector<size_t> starts; bool done = false; };
+  std::vector<Piece> pieces;
+  std::vector<std::thread> scanners;
+  std::mutex pm;
+  std::condition_variable pcv;
+  std::atomic<size_t> next_piece{0};
+  size_t merged = 0, prev_end = 0;
+  bool all_merged = false;
   void prescan(unsigned threads) {
     // default on hosts with 16 hardware threads or more (one reader thread walks ~13 M records/s, the ceiling of the whole
     // pipeline there); on the 8-core build box the streaming walk, which overlaps with parsing, is as fast.
@@ -278,59 +290,85 @@ struct BlockReader {
     const char *pe = getenv("KAIJU_GPU_PRESCAN");
     const bool want = pe ? atoi(pe) != 0 : std::thread::hardware_concurrency() >= 16;
     if (!mapped || prescanned || !want) return;
-    if (record_end(pos) == NONE) { rec_start.assign(1, size); prescanned = true; return; }   // (also settles fastq / fasta)
-    size_t min_bytes = 32u << 20;
-    if (const char *e = getenv("KAIJU_GPU_PRESCAN_MIN")) min_bytes = (size_t)atol(e);     // (tests: several threads on small files)
-    unsigned T = size >= min_bytes ? std::max(1u, threads) : 1u;
-    std::vector<size_t> guess(T + 1, size);
-    guess[0] = pos;
-    for (unsigned t = 1; t < T; t++) guess[t] = guess_start((size_t)((unsigned __int128)size * t / T));
-    for (unsigned t = 1; t < T; t++) if (guess[t] < guess[t - 1]) guess[t] = guess[t - 1];
-    std::vector<std::vector<size_t>> starts(T);
-    std::vector<size_t> stop(T, 0);
-    auto walk = [&](unsigned t) {
-      size_t p = guess[t];
-      const size_t limit = guess[t + 1];
-      while (p < limit) {
-        const size_t h = header_at(p);
-        if (h == NONE || h >= limit) break;
-        starts[t].push_back(p);
-        p = record_end(p);                     // (const for mapped files once the type is known)
-      }
-      stop[t] = p;
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; t++) th.emplace_back(walk, t);
-    walk(0);
-    for (auto &x : th) x.join();
-    bool good = true;
-    for (unsigned t = 0; t + 1 < T && good; t++) {
-      // thread t must have stopped in front of thread t+1's first record with nothing but empty lines in between
-      const size_t h = header_at(stop[t]);
-      const size_t want_h = starts[t + 1].empty() ? header_at(guess[t + 1]) : header_at(starts[t + 1][0]);
-      if (stop[t] > guess[t + 1] || h != want_h) good = false;
-    }
+    prescanned = true;
     rec_start.clear();
+    if (record_end(pos) == NONE) { rec_start.assign(1, size); all_merged = true; return; }   // (also settles fastq / fasta)
+    size_t min_bytes = 32u << 20, piece_bytes = 64u << 20;
+    if (const char *e = getenv("KAIJU_GPU_PRESCAN_MIN")) min_bytes = (size_t)atol(e);     // (tests: several threads on small files)
+    if (const char *e = getenv("KAIJU_GPU_PRESCAN_PIECE")) piece_bytes = (size_t)std::max(1L, atol(e));
+    const unsigned T = size >= min_bytes ? std::max(1u, threads) : 1u;
+    const size_t P = T == 1 ? 1 : std::max<size_t>(T, (size - pos + piece_bytes - 1) / piece_bytes);
+    pieces.resize(P);
+    pieces[0].guess = pos;
+    for (size_t t = 1; t < P; t++) pieces[t].guess = guess_start(pos + (size_t)((unsigned __int128)(size - pos) * t / P));
+    for (size_t t = 1; t < P; t++) if (pieces[t].guess < pieces[t - 1].guess) pieces[t].guess = pieces[t - 1].guess;
+    for (size_t t = 0; t < P; t++) pieces[t].limit = t + 1 < P ? pieces[t + 1].guess : size;
+    prev_end = pos;
+    auto work = [this] {
+      for (;;) {
+        const size_t t = next_piece.fetch_add(1);
+        if (t >= pieces.size()) return;
+        Piece &pc = pieces[t];
+        size_t p = pc.guess;
+        while (p < pc.limit) {
+          const size_t h = header_at(p);
+          if (h == NONE || h >= pc.limit) break;
+          pc.starts.push_back(p);
+          p = record_end(p);                   // (const for mapped files once the type is known)
+        }
+        pc.stop = p;
+        { std::lock_guard<std::mutex> lk(pm); pc.done = true; }
+        pcv.notify_all();
+      }
+    };
+    const unsigned nthreads = (unsigned)std::min<size_t>(T, P);
+    for (unsigned t = 0; t < nthreads; t++) scanners.emplace_back(work);
+  }
+  void join_scanners() { for (auto &x : scanners) x.join(); scanners.clear(); }
+  // appends the record starts of the next piece (waiting for its walk); the guess a piece started from is confirmed when
+  // the walk of the piece before it arrives exactly there with nothing but empty lines in between - otherwise (a quality
+  // line that looks like a header, a file that is not made of four-line records ...) the rest of the file is walked
+  // sequentially from the last confirmed record, so the boundaries are always those of the sequential walk
+  void merge_next_piece() {
+    if (all_merged) return;
+    const size_t t = merged;
+    { std::unique_lock<std::mutex> lk(pm); pcv.wait(lk, [&] { return pieces[t].done; }); }
+    Piece &pc = pieces[t];
+    bool good = true;
+    if (t + 1 < pieces.size()) {
+      const size_t h = header_at(pc.stop), want_h = header_at(pieces[t + 1].guess);
+      if (pc.stop > pieces[t + 1].guess || h != want_h) good = false;
+    }
     if (good) {
       // a record starts where the one before it ended (empty lines in front of a header belong to its record)
-      size_t prev_end = pos;
-      for (unsigned t = 0; t < T; t++) {
-        for (size_t k = 0; k < starts[t].size(); k++) rec_start.push_back(k == 0 ? prev_end : starts[t][k]);
-        if (!starts[t].empty()) prev_end = stop[t];
-      }
-      rec_start.push_back(size);
+      for (size_t k = 0; k < pc.starts.size(); k++) rec_start.push_back(k == 0 ? prev_end : pc.starts[k]);
+      if (!pc.starts.empty()) prev_end = pc.stop;
+      std::vector<size_t>().swap(pc.starts);
+      merged++;
+      if (merged == pieces.size()) { rec_start.push_back(size); all_merged = true; join_scanners(); }
     } else {
-      size_t p = pos;
+      join_scanners();                          // (they only fill their own pieces; let them finish)
+      size_t p = prev_end;
       for (;;) { const size_t e = record_end(p); if (e == NONE) break; rec_start.push_back(p); p = e; }
       rec_start.push_back(size);
+      all_merged = true;
     }
-    prescanned = true;
+  }
+  // records in the file: exact once everything is merged, else extrapolated from the part that is
+  uint64_t estimated_records() {
+    if (!prescanned) return 0;
+    while (!all_merged && rec_start.size() < 2) merge_next_piece();
+    if (all_merged) return rec_start.size() - 1;
+    const size_t bytes = prev_end - pos;
+    return bytes ? (uint64_t)((double)(rec_start.size()) * (double)(size - pos) / (double)bytes) : 0;
   }
 
   // false when the file is exhausted and nothing was produced
   bool next(RawBlock &out, uint32_t want) {
     out.n_records = 0; out.own.clear();
     if (prescanned) {
+      // (the end of a block is the start of the record behind it: one more start than records must be known)
+      while (!all_merged && rec_start.size() <= next_rec + (size_t)want) merge_next_piece();
       const size_t n = rec_start.size() - 1;
       if (next_rec >= n) return false;
       const size_t last = std::min(n, next_rec + want);
@@ -764,7 +802,7 @@ int main(int argc, char **argv) {
       // reads per batch: small enough that a sample fills the pipeline (sixteen batches), large enough that the persistent
       // lanes of the search kernels get more than a read or two each
       if (!getenv("KAIJU_GPU_BATCH") && r1.prescanned) {
-        const uint64_t n_rec = r1.rec_start.size() - 1;
+        const uint64_t n_rec = r1.estimated_records();
         batch_reads = (uint32_t)std::min<uint64_t>(1000000, std::max<uint64_t>(250000, (n_rec / 16 + 49999) / 50000 * 50000));
       }
       std::unique_ptr<BlockReader> r2;

@@ -50,12 +50,14 @@ def ref_records(text: bytes):
     return out
 
 
-def run_cli(tmp_path, f1, f2=None, batch=None, prescan_threads=None):
+def run_cli(tmp_path, f1, f2=None, batch=None, prescan_threads=None, piece=None):
     env = dict(os.environ, KAIJU_GPU_PARSE_ONLY="1")
     if prescan_threads:                       # several boundary-scan threads even on these small files
         env["KAIJU_GPU_PRESCAN"] = "1"
         env["KAIJU_GPU_PRESCAN_MIN"] = "0"
         env["KAIJU_GPU_HOST_THREADS"] = str(prescan_threads)
+        if piece:                             # ... and many more pieces than threads, merged while blocks are handed out
+            env["KAIJU_GPU_PRESCAN_PIECE"] = str(piece)
     if batch:
         env["KAIJU_GPU_BATCH"] = str(batch)
     cmd = [CLI, "-i", str(f1)] + (["-j", str(f2)] if f2 else [])
@@ -119,6 +121,10 @@ def test_fastq_ingest(have_cli, tmp_path, variant):
     for threads in (2, 5, 13):
         got = run_cli(tmp_path, path, batch=97, prescan_threads=threads)
         assert [(g[0], g[1]) for g in got] == want, threads
+    if variant != "gz":
+        for piece in (300, 5000, 70000):
+            got = run_cli(tmp_path, path, batch=97, prescan_threads=4, piece=piece)
+            assert [(g[0], g[1]) for g in got] == want, piece
 
 
 def test_fasta_ingest(have_cli, tmp_path):
@@ -133,6 +139,9 @@ def test_fasta_ingest(have_cli, tmp_path):
     for threads in (3, 8):
         got = run_cli(tmp_path, path, batch=50, prescan_threads=threads)
         assert [(g[0], g[1]) for g in got] == want, threads
+    for piece in (200, 9000):
+        got = run_cli(tmp_path, path, batch=50, prescan_threads=5, piece=piece)
+        assert [(g[0], g[1]) for g in got] == want, piece
     with gzip.open(tmp_path / "r.fa.gz", "wb") as f:
         f.write(text)
     assert [(g[0], g[1]) for g in run_cli(tmp_path, tmp_path / "r.fa.gz", batch=64)] == want
@@ -191,6 +200,9 @@ def test_prescan_false_start_is_caught(have_cli, tmp_path):
     for threads in (2, 7, 16):
         got = run_cli(tmp_path, path, batch=333, prescan_threads=threads)
         assert [(g[0], g[1]) for g in got] == want, threads
+    for piece in (150, 4096):                  # (a wrong guess in the middle: the rest is walked sequentially)
+        got = run_cli(tmp_path, path, batch=333, prescan_threads=6, piece=piece)
+        assert [(g[0], g[1]) for g in got] == want, piece
 
 
 def test_kaijup_names_and_u_line_decision(tmp_path):
