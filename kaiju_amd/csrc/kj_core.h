@@ -2847,7 +2847,22 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     KJ_HISTO(7, qlive);
     if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; return ~0u; }
     uint32_t slot = qn;
-    if (qlive < qn) { slot = 0; while (pr_get(slot) != 0) slot++; }
+    if (qlive < qn) {
+      slot = 0;
+      if constexpr (kGSlots % 4 == 0) {
+        // (four priorities per LDS read; a free slot below qn exists)
+        bool got = false;
+        const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
+        for (uint32_t q = 0; q < nl && !got; q += 4) {
+          const u128 v = *reinterpret_cast<const u128 *>(prio + q);
+          const uint32_t e0 = (uint32_t)v.x, e1 = (uint32_t)(v.x >> 32), e2 = (uint32_t)v.y, e3 = (uint32_t)(v.y >> 32);
+          const uint32_t x = e0 == 0 ? 0u : e1 == 0 ? 1u : e2 == 0 ? 2u : e3 == 0 ? 3u : 4u;
+          if (x < 4u && q + x < nl) { slot = q + x; got = true; }
+        }
+        if (!got) { slot = kGSlots; while (pr_get(slot) != 0) slot++; }
+      } else
+        while (pr_get(slot) != 0) slot++;
+    }
     else if (qn >= (uint32_t)kGSlotsAll) { ovf = true; return ~0u; }
     else qn++;
     pr_set(slot, key << 16 | (0xffffu - seq));
@@ -2924,12 +2939,17 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             if (vi_phase == 0) { vi_phase = 2; have = true; }
           } else if (vi_phase == 0) {
             if (vi_v >= 0) {
-              const uint32_t head = mq_head(vi_v);
-              uint32_t cnt = 0;
-              for (uint32_t x = head; x < nm; x++) if (mq_get(x) == vi_v) cnt++;
+              // one walk over the lengths: head of the class vi_v, its size, the next shorter class
+              uint32_t head = nm, cnt = 0;
+              int below = -1;
+              for (uint32_t x = 0; x < nm; x++) {
+                const int q = mq_get(x);
+                if (q == vi_v) { if (head == nm) head = x; cnt++; }
+                else if (q < vi_v && q > below) below = q;
+              }
               mx = head; vi_head = (int)head; have = true;
               if (cnt >= 2) { vi_phase = 1; vi_x = (int)nm; }
-              else { vi_v = mq_max_below(vi_v); if (vi_v < 0) vi_phase = 2; }
+              else { vi_v = below; if (vi_v < 0) vi_phase = 2; }
             }
           } else if (vi_phase == 1) {
             int x = vi_x - 1;
@@ -2976,24 +2996,29 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             }
             while (bk == GB_EVAL_NEXT) {
               if (ev_pass == 0) {
-                const int head = (int)mq_head(ev_v);
-                int x = (ev_x > head ? ev_x : head) + 1;
-                while (x < (int)nm && mq_get((uint32_t)x) != ev_v) x++;
-                if (x < (int)nm) { ev_x = x; mx = (uint32_t)x; ml_for = 1; kind = G_MLOAD; bk = GB_NONE; }
-                else {
-                  const int nv = mq_max_below(ev_v);
-                  if (nv < 0 || nv < (int)p.m) ev_pass = 1;                    // ev_v is the shortest class >= m
-                  else { ev_v = nv; ev_x = -1; }
+                // one walk over the lengths: the next member of the class ev_v behind its head and behind ev_x, and the
+                // next shorter class
+                int head = -1, nxt = -1, nv = -1;
+                for (uint32_t x = 0; x < nm; x++) {
+                  const int q = mq_get(x);
+                  if (q == ev_v) { if (head < 0) head = (int)x; else if (nxt < 0 && (int)x > ev_x) nxt = (int)x; }
+                  else if (q < ev_v && q > nv) nv = q;
                 }
+                if (nxt >= 0) { ev_x = nxt; mx = (uint32_t)nxt; ml_for = 1; kind = G_MLOAD; bk = GB_NONE; }
+                else if (nv < 0 || nv < (int)p.m) ev_pass = 1;                 // ev_v is the shortest class >= m
+                else { ev_v = nv; ev_x = -1; }
               } else if (ev_done) bk = GB_POP;
               else {
-                mx = mq_head(ev_v); ml_for = 1; kind = G_MLOAD; bk = GB_NONE;
-                if (ev_v == ev_v1) ev_done = true;
-                else {
-                  int nv = 0x7fffffff;
-                  for (uint32_t x = 0; x < nm; x++) { const int q = mq_get(x); if (q > ev_v && q < nv) nv = q; }
-                  ev_v = nv;
+                // the head of the class ev_v and the next longer class, in one walk
+                uint32_t head = nm;
+                int nv = 0x7fffffff;
+                for (uint32_t x = 0; x < nm; x++) {
+                  const int q = mq_get(x);
+                  if (q == ev_v) { if (head == nm) head = x; }
+                  else if (q > ev_v && q < nv) nv = q;
                 }
+                mx = head; ml_for = 1; kind = G_MLOAD; bk = GB_NONE;
+                if (ev_v == ev_v1) ev_done = true; else ev_v = nv;
               }
             }
           }
@@ -3005,7 +3030,18 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           uint32_t dbest = 0, dslot = 0;
           {
             const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
-            for (uint32_t s = 0; s < nl; s++) { const uint32_t pr = prio[s]; if (pr > dbest) { dbest = pr; dslot = s; } }
+            if constexpr (kGSlots % 4 == 0) {
+              // four priorities per LDS read (slots at and above qn hold 0: G_META clears the row)
+              for (uint32_t s = 0; s < nl; s += 4) {
+                const u128 v = *reinterpret_cast<const u128 *>(prio + s);
+                const uint32_t e0 = (uint32_t)v.x, e1 = (uint32_t)(v.x >> 32), e2 = (uint32_t)v.y, e3 = (uint32_t)(v.y >> 32);
+                if (e0 > dbest) { dbest = e0; dslot = s; }
+                if (e1 > dbest) { dbest = e1; dslot = s + 1u; }
+                if (e2 > dbest) { dbest = e2; dslot = s + 2u; }
+                if (e3 > dbest) { dbest = e3; dslot = s + 3u; }
+              }
+            } else
+              for (uint32_t s = 0; s < nl; s++) { const uint32_t pr = prio[s]; if (pr > dbest) { dbest = pr; dslot = s; } }
             for (uint32_t s = kGSlots; s < qn; s++) { const uint32_t pr = gs.prio_ext[s - kGSlots]; if (pr > dbest) { dbest = pr; dslot = s; } }
           }
           const bool have_o = fo < nf, have_d = dbest != 0;
@@ -3341,7 +3377,11 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         fbase = (uint32_t)gv.y;
         nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
         fo = 0; best = 0; nbest = 0; flags = 0; ovf = false; m_ovf = false;
-        for (uint32_t s = 0; s < (uint32_t)kGSlots; s++) prio[s] = 0;
+        if constexpr (kGSlots % 4 == 0) {
+          const u128 z{0, 0};
+          for (uint32_t s = 0; s < (uint32_t)kGSlots; s += 4) *reinterpret_cast<u128 *>(prio + s) = z;
+        } else
+          for (uint32_t s = 0; s < (uint32_t)kGSlots; s++) prio[s] = 0;
         for (uint32_t s = kGSlots; s < qn; s++) gs.prio_ext[s - kGSlots] = 0;
         qn = qlive = qseq = 0;
         hit = b.hits + r;
