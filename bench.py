@@ -292,6 +292,8 @@ class Leg:
         roof = {"bound": "hbm", "kernel": "k_mem" if self.mode == "mem" else "k_greedy2",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                **({"traffic_note": _TRAFFIC_NOTES[(self.mode, bool(self.paired))]}
+                   if _TRAFFIC_NOTES.get((self.mode, bool(self.paired))) else {}),
                 "algorithmic_bytes_per_launch": alg, "units_per_launch": per_launch,
                 "algorithmic_bytes_per_unit": alg / max(per_launch, 1.0),
                 "avg_launch_ms": excl_ms,
@@ -387,10 +389,14 @@ def load_traffic(mode, paired, seg, nseq, per_launch):
             for rec in json.load(f)["measurements"]:
                 if (rec["mode"] == mode and int(rec["seg"]) == int(seg) and rec["nseq"] == nseq and
                         bool(rec.get("paired", False)) == bool(paired) and rec["reads_per_launch"] == int(per_launch)):
+                    _TRAFFIC_NOTES[(mode, bool(paired))] = rec.get("note")
                     return rec["hbm_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         pass
     return None
+
+
+_TRAFFIC_NOTES = {}          # what the matching record of profiles/traffic.json says about when it was collected
 
 
 def free_port():

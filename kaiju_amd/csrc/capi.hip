@@ -3,8 +3,10 @@
 // Kernels:
 //   k_fragments  one lane per read: six-frame translation, fragment list in queue order,
 //                eager SEG split for MEM (stage 1, kj_core.h:build_fragments)
-//   k_mem        persistent lanes, one read at a time per lane: MEM search + locate
-//   k_greedy     persistent lanes: Greedy search (priority queue, substitutions) + locate
+//   k_fragments_fast  the same for mates up to 191 nt; k_trigcheck / k_segflag / k_seg / k_seg_apply*: SEG
+//   k_mem        persistent lanes, one read at a time per lane: MEM search (+ locate for reads with many longest matches)
+//   k_mem_locate one lane per read: the ids of the reads whose one or two longest matches k_mem left in the hit record
+//   k_greedy2    persistent lanes: Greedy search (priority queue, substitutions) + locate
 // Both search kernels are launched twice per batch: the main pass with small per-lane scratch
 // and a retry pass (device-side work list, no host round trip) with worst-case scratch for the
 // few reads whose match buffer / queue overflowed.
@@ -267,7 +269,11 @@ __device__ __forceinline__ void mem_body(const DevIndex &ix, const Params &p, co
   mem_lane<P>(ix, p, b, wl, ls, vb);
 }
 // second-generation lane (kj_core.h:mem_lane2): indexes below 2^32 symbols with a k-mer table
+#ifdef KJ_PROF
+__global__ void __launch_bounds__(kBlock, 3)      // (the section marks need a few registers: no spills at three wavefronts per SIMD)
+#else
 __global__ void __launch_bounds__(kBlock, 4)
+#endif
 k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -275,7 +281,20 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
+#ifdef KJ_PROF
+  __shared__ unsigned long long s_prof[kBlock / 64][2 + 3 * PM_N];
+  for (int x = threadIdx.x & 63; x < 2 + 3 * PM_N; x += 64) s_prof[threadIdx.x >> 6][x] = 0;
+  ls.prof = s_prof[threadIdx.x >> 6];
+  if ((threadIdx.x & 63) == 0) { ls.prof[0] = __builtin_readcyclecounter(); ls.prof[1] = PM_HEAD; }
+#endif
   mem_lane2<false>(ix, p, b, wl, ls);
+}
+// the ids of the reads whose longest matches the lanes above left in their hit records (kParamDeferLocate): one lane per read
+__global__ void __launch_bounds__(256)
+k_mem_locate(DevIndex ix, Params p, Batch b) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= b.n_reads) return;
+  mem_locate_read(ix, p, b.hits + r);
 }
 // the same kernel under a second name for the second search of the lazy SEG flow (the few reads whose fragments SEG had
 // to cut), so that a kernel trace lists the full-size launches of k_mem by themselves
@@ -961,6 +980,7 @@ struct kaiju_gpu_ctx {
   bool mem_v1 = false;             // KAIJU_GPU_MEM_LANE=v1 (read once, at context creation)
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
+  bool defer_locate = true;        // KAIJU_GPU_MEM_LOCATE=inline: the MEM search lanes walk to the ids themselves
   bool greedy3 = false;            // KAIJU_GPU_GREEDY_LANE=v3: the two-kernel rounds of the third generation (experimental: parity-green,
                                    // 1.8x slower than the second generation as measured in round 2)
   uint32_t g3_rounds = 128;        // KAIJU_GPU_G3_ROUNDS: rounds launched per batch (reads still at work then: retry pass)
@@ -1036,6 +1056,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   c->dump_frags = getenv("KAIJU_GPU_DUMP_FRAGS");
   if (const char *e = getenv("KAIJU_GPU_STAGE1")) c->stage1_old = !strcmp(e, "old");
   if (const char *e = getenv("KAIJU_GPU_LAZY_SEG")) c->lazy_seg = atoi(e) != 0;
+  if (const char *e = getenv("KAIJU_GPU_MEM_LOCATE")) c->defer_locate = strcmp(e, "inline") != 0;
   // kaijux: the MEM search of ConsumerThreadx.cpp:135 (maxMatches(.., 1)) finds the same longest matches as
   // greedyExact but lists them in another order, which shows where the id cap cuts and in the peptides of -v
   if (ix->id_mode == KAIJU_GPU_IDS_SEQUENCE && p->mode == 0) c->kp.flags |= kParamXOrder;
@@ -1228,8 +1249,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
           else hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
         }
       };
+      // reads with one or two longest matches are located by k_mem_locate behind the searches (KAIJU_GPU_MEM_LOCATE=inline: by
+      // the search lanes themselves, as in round 1)
+      const bool defer = mem_v2 && mem_narrow2 && !xo && c->defer_locate;
+      Params pd = p;
+      if (defer) pd.flags |= kParamDeferLocate;
       if (mem_v2) {
-        Params pm = p;
+        Params pm = pd;
         if (lazy) pm.flags |= kParamLazySeg;
         launch_v2(pm, wl_main, c->count_ops);
       } else if (ix->dev.sb32)
@@ -1250,12 +1276,16 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         WorkList wl_seg;
         wl_seg.counter = cnt + 23; wl_seg.reads = seglist; wl_seg.n_items_ptr = cnt + 22; wl_seg.n_items = 0;
         wl_seg.retry_list = wl_main.retry_list; wl_seg.retry_count = wl_main.retry_count;
-        launch_v2(p, wl_seg, false, true);
+        launch_v2(pd, wl_seg, false, true);
         KJ_HIP(hipGetLastError());
       }
       hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
+      if (defer) {
+        hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        KJ_HIP(hipGetLastError());
+      }
       if (exact_pass) {
         xp.si = static_cast<SIEntry *>(c->scratch_retry[0].p); xp.si_cap = si_cap_retry; xp.blocks_search = blocks_retry;
         xp.vb = vb;
@@ -1679,6 +1709,19 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
               acc[0], acc[1], acc[2], acc[3], acc[4], acc[5] >> 32, acc[5] & 0xffffffffull);
   }
 #ifdef KJ_PROF
+  if (ctx->params.mode == 0) {
+    static const char *names[PM_N] = {"HEAD", "LOAD", "LOADFILL", "STEP", "KMER", "LF1", "SA", "META", "FRAG", "FILL", "TAIL", "END_MATCH",
+                                      "START_J", "NEXT_FRAG", "LOC_INIT", "LOC_NEXT_SI", "LOC_ROW", "FINISH"};
+    unsigned long long pv[3 * PM_N];
+    KJ_HIP(hipMemcpy(pv, static_cast<uint8_t *>(ctx->counters.p) + 1024, sizeof pv, hipMemcpyDeviceToHost));
+    unsigned long long tot = 0;
+    for (int x = 0; x < PM_N; x++) tot += pv[3 * x];
+    fprintf(stderr, "[kj prof] section        cycles%%   entries/read  lanes/entry   cycles/entry   (k_mem main launch; n_reads %u, total wave-cycles %llu)\n", ctx->last_n, tot);
+    for (int x = 0; x < PM_N; x++)
+      fprintf(stderr, "[kj prof] %-13s %7.2f %12.3f %10.1f %12.1f\n", names[x], 100.0 * pv[3 * x] / (double)(tot ? tot : 1),
+              (double)pv[3 * x + 1] / (ctx->last_n ? ctx->last_n : 1), (double)pv[3 * x + 2] / (double)(pv[3 * x + 1] ? pv[3 * x + 1] : 1),
+              (double)pv[3 * x] / (double)(pv[3 * x + 1] ? pv[3 * x + 1] : 1));
+  }
   if (ctx->params.mode == 1) {
     static const char *names[PS_N] = {"HEAD", "AFTER_SEARCH", "VAR_NEXT", "VAR_MATCH", "EVAL_NEXT", "EVAL_MATCH", "POP", "POP_SEG", "FINISH",
                                       "HANDOUT", "LOAD", "LOAD10", "STEP", "KMER", "LF1", "SA", "VM_RANK", "VM_PUSH", "META", "FRAG",

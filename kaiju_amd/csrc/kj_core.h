@@ -46,6 +46,7 @@ constexpr int kBlkShift = 7;          // rank block = 128 symbols = 128 bytes
 constexpr uint32_t kHitIdCap = 1u, kHitSiCap = 2u;
 constexpr uint32_t kHitInternalOverflow = 0x80000000u;   // scratch too small even in the retry pass
 constexpr uint32_t kHitRetry = 0x40000000u;              // internal: queued for the retry pass
+constexpr uint32_t kHitLocPending = 0x20000000u;         // internal: the ids are still to be located (mem_locate_read); n_ids = matches noted in taxid[]
 constexpr int kWin = 64, kWinStride = 68;                // per-lane peptide window (bytes / LDS stride)
 
 // One rank block: 128 BWT symbols as five bit-planes (2 x 64 bit each) plus the
@@ -105,6 +106,8 @@ struct Params {
   uint32_t flags = 0;        // kParamXOrder | kParamProtein
 };
 // Params::flags
+constexpr uint32_t kParamDeferLocate = 8u;   // MEM, second-generation narrow lane: reads with one or two longest matches leave them in the hit
+                                             // record and k_mem_locate walks to their ids afterwards (mem_locate_read)
 constexpr uint32_t kParamXOrder = 1u;    // kaijux: MEM matches of a fragment are visited in maxMatches' list order (see mem_lane)
 constexpr uint32_t kParamProtein = 2u;   // reads are protein sequences (kaiju -p, kaijup): stage 1 = k_fragments_protein
 constexpr uint32_t kParamLazySeg = 4u;   // MEM: fragments are searched unsplit first; the lanes report the fragments that hold
@@ -1554,10 +1557,38 @@ KJ_HD uint32_t win_get(LaneWin &lw, const uint8_t *fs, int flen, int pos) {
   return lw.w[pos - lw.q];
 }
 
+// -DKJ_PROF (developer build, KAIJU_GPU_LIB=libkaiju_gpu_prof.so tests/tools/prof_run.py): where a wavefront of greedy_lane2 / mem_lane2 spends its cycles.  KJ_P(section)
+// charges the cycles since the previous mark to the PREVIOUS section and notes with how many active lanes the new one is
+// entered; sums per wavefront in LDS, added to the counter block (byte 1024 on) when the wavefront ends.
+enum ProfSec : int { PS_HEAD, PS_AFTER_SEARCH, PS_VAR_NEXT, PS_VAR_MATCH, PS_EVAL_NEXT, PS_EVAL_MATCH, PS_POP, PS_POP_SEG, PS_FINISH,
+                     PS_HANDOUT, PS_LOAD, PS_LOAD10, PS_STEP, PS_KMER, PS_LF1, PS_SA, PS_VM_RANK, PS_VM_PUSH, PS_META, PS_FRAG,
+                     PS_FILL, PS_MLOAD, PS_END_MATCH, PS_START_J, PS_LOC_ROW, PS_TAIL, PS_N };
+enum ProfSecM : int { PM_HEAD, PM_LOAD, PM_LOADFILL, PM_STEP, PM_KMER, PM_LF1, PM_SA, PM_META, PM_FRAG, PM_FILL, PM_TAIL, PM_END_MATCH,
+                      PM_START_J, PM_NEXT_FRAG, PM_LOC_INIT, PM_LOC_NEXT_SI, PM_LOC_ROW, PM_FINISH, PM_N };
+#if defined(KJ_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define KJ_P(sec) kj_prof_mark(gs.prof, (sec))
+#define KJ_PM(sec) kj_prof_mark(ls.prof, (sec))
+__device__ __forceinline__ void kj_prof_mark(unsigned long long *pw, int sec) {
+  const unsigned long long now = __builtin_readcyclecounter();
+  const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+  if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) {
+    const unsigned long long prev = pw[1];
+    pw[2 + 3 * prev] += now - pw[0];
+    pw[2 + 3 * sec + 1] += 1ull;
+    pw[2 + 3 * sec + 2] += (unsigned long long)__builtin_popcountll(ex);
+    pw[0] = now; pw[1] = (unsigned long long)sec;
+  }
+}
+#else
+#define KJ_P(sec)
+#define KJ_PM(sec)
+#endif
+
 struct LaneScratch {
   SIEntry *si;               // this lane's match buffer
   uint32_t si_cap;
   uint8_t *win;              // this lane's peptide window (kWin bytes)
+  unsigned long long *prof = nullptr;   // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PM_N)
 };
 
 struct WorkList {
@@ -1948,6 +1979,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   auto in_win = [&](int pos) -> bool { return pos >= lw.q && pos < lw.q + kWin; };
 
   for (;;) {
+    KJ_PM(PM_HEAD);
     // ---- (0) hand out reads to the lanes that finished one (wave-uniform control flow) ----
     {
       const bool need = kind == K_IDLE;
@@ -1981,6 +2013,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     }
 
     // ---- (1) load phase: no branches between the loads and their first use ----
+    KJ_PM(PM_LOAD);
     KJ_HISTO(5, kind);
     if (kind == K_STEP) KJ_HISTO(4, (uint32_t)(j - i + 1));   // match length before this step
     const bool is_step = kind == K_STEP, is_lf = kind == K_LF1 || kind == K_LF2;
@@ -2024,6 +2057,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
     int fq = 0;
     if (kj_ballot(kind == K_FILL)) {                       // wave-uniform
+      KJ_PM(PM_LOADFILL);
       fq = fill_top - (kWin - 1);
       if (fq < 0) fq = 0;
       const uint8_t *src = kind == K_FILL ? b.pep + fsoff + fq : reinterpret_cast<const uint8_t *>(blk0);
@@ -2034,6 +2068,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     // ---- (2) compute ----
     int bk = BK_NONE;
     if (is_step || kind == K_LF2) {
+      KJ_PM(PM_STEP);
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
@@ -2055,6 +2090,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         bk = BK_LOC_ROW;                                   // re-enters at the checkpoint test
       }
     } else if (kind == K_KMER) {
+      KJ_PM(PM_KMER);
       // InitialSI + (kk-1) UpdateSI in one lookup
       if (WIDE) { lo = (P)gv.x; hi = (P)(gv.x + gv.y); }
       else { const uint64_t e = ghalf ? gv.y : gv.x; lo = (P)e; hi = (P)((uint32_t)e + (uint32_t)(e >> 32)); }
@@ -2066,6 +2102,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
       }
     } else if (kind == K_LF1) {
+      KJ_PM(PM_LF1);
       // first half of an LF step: the BWT letter of row k
       const uint32_t sft = k & 63u;
       c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
@@ -2087,6 +2124,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         bk = BK_LOC_ROW;
       }
     } else if (kind == K_SA) {
+      KJ_PM(PM_SA);
       const uint64_t tax = ghalf ? gv.y : gv.x;
       if (tax != ~0ull) {
         bool dup = false;
@@ -2098,6 +2136,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       k = row; fresh = true;
       bk = BK_LOC_ROW;
     } else if (kind == K_META) {
+      KJ_PM(PM_META);
       pepoff = gv.x;
       fbase = (uint32_t)gv.y;
       nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
@@ -2106,10 +2145,12 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       hit = b.hits + r;
       if (nf == 0) bk = BK_LOC_INIT; else kind = K_FRAG;
     } else if (kind == K_FRAG) {
+      KJ_PM(PM_FRAG);
       dnext.start = (uint32_t)gv.x; dnext.len = (uint32_t)(gv.x >> 32);
       dnext.key = (uint32_t)gv.y; dnext.flags = (uint32_t)(gv.y >> 32);
       bk = BK_NEXT_FRAG;
     } else if (kind == K_FILL) {
+      KJ_PM(PM_FILL);
       lw.q = fq;
       uint32_t *d32 = reinterpret_cast<uint32_t *>(lw.w);   // 4-byte aligned LDS: written as dwords
       d32[0] = (uint32_t)w0.x; d32[1] = (uint32_t)(w0.x >> 32); d32[2] = (uint32_t)w0.y; d32[3] = (uint32_t)(w0.y >> 32);
@@ -2127,8 +2168,10 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     }
 
     // ---- (3) bookkeeping, blocks ordered along the usual flow (see mem_lane) ----
+    KJ_PM(PM_TAIL);
     while (bk != BK_NONE) {
       if (bk == BK_END_MATCH) {
+        KJ_PM(PM_END_MATCH);
         const uint32_t l = (uint32_t)(j - i + 1);
         if (l >= L) {
           if (l > L) { nsi = 0; ovf = false; L = l; multi = false; }   // shorter matches are dropped (bwt.c:366-370, :577-582)
@@ -2145,6 +2188,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         else { j--; bk = BK_START_J; }
       }
       if (bk == BK_START_J) {
+        KJ_PM(PM_START_J);
         // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356)
         if (j < (int)L - 1) bk = BK_NEXT_FRAG;
         else if (kk && j >= (int)kk - 1) {
@@ -2164,6 +2208,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
       }
       if (bk == BK_NEXT_FRAG) {
+        KJ_PM(PM_NEXT_FRAG);
         // getNextFragment(longest): stop when the best remaining key < longest (:550, :279);
         // dnext is the prefetched descriptor of fragment f
         if (f >= nf || (found && dnext.key < L)) bk = BK_LOC_INIT;
@@ -2176,6 +2221,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         }
       }
       if (bk == BK_LOC_INIT) {
+        KJ_PM(PM_LOC_INIT);
         nids = 0; flags = 0;
         hit->best = found ? L : 0u;
         // lazy SEG (kParamLazySeg, wave-uniform): the fragment that holds the longest matches, or the note that there
@@ -2188,9 +2234,21 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           else if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
           else flags = kHitInternalOverflow;
           bk = BK_FINISH;
+        } else if (!WIDE && !XORDER && (p.flags & kParamDeferLocate) && nsi <= 2u) {
+          // the locate walks of 64 different reads share nothing: they run with two or three lanes of a wavefront active
+          // (a third of this kernel's time, profiles/r02_gprof).  The matches are noted in the order in which the walk
+          // below would visit them (matches of one fragment: found for descending j, visited for ascending j) and
+          // k_mem_locate walks them with every lane at work.
+          const bool swap = nsi == 2u && s0frag == s1frag;
+          const uint64_t e0 = (uint64_t)(uint32_t)s0lo | (uint64_t)s0len << 32, e1 = (uint64_t)(uint32_t)s1lo | (uint64_t)s1len << 32;
+          hit->taxid[0] = swap ? e1 : e0;
+          if (nsi == 2u) hit->taxid[1] = swap ? e0 : e1;
+          nids = nsi; flags = kHitLocPending;
+          bk = BK_FINISH;
         } else { gs = ge = 0; cur = XORDER ? 1u : 0u; bk = BK_LOC_NEXT_SI; }
       }
       if (bk == BK_LOC_NEXT_SI) {
+        KJ_PM(PM_LOC_NEXT_SI);
         // matches of one fragment were found for descending j but are visited for ascending j
         // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845).
         // XORDER (kaijux, whose classify_length searches with maxMatches(.., 1), ConsumerThreadx.cpp:135): the list
@@ -2216,6 +2274,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         }
       }
       if (bk == BK_LOC_ROW) {
+        KJ_PM(PM_LOC_ROW);
         // k is either a fresh row (k == row) or the row reached by the LF walk so far
         if (row >= rowend) bk = BK_LOC_NEXT_SI;
         else if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = BK_FINISH; }   // :805-807
@@ -2227,6 +2286,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         }
       }
       if (bk == BK_FINISH) {
+        KJ_PM(PM_FINISH);
         hit->n_ids = nids; hit->flags = flags;
         if constexpr (COUNT) oc[kOpcHit]++;
         kind = K_IDLE; bk = BK_NONE;
@@ -2234,6 +2294,65 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     }
   }
   if constexpr (COUNT) opc_flush(opc_of(wl), oc);
+#if defined(KJ_PROF) && defined(__HIP_DEVICE_COMPILE__)
+  KJ_PM(PM_HEAD);
+  if ((threadIdx.x & 63u) == 0 && ls.prof) {
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(wl.counter) + 1024);
+    for (int x = 0; x < 3 * PM_N; x++) atomicAdd(dst + x, ls.prof[2 + x]);
+  }
+#endif
+}
+
+// The ids of a read whose longest matches mem_lane2 left in its hit record (kHitLocPending): ids_from_SI for every match in
+// turn (ConsumerThread.cpp:799-845; get_suffix bwt.c:105-121, FMindexCurrent compactfmi.c:312-336) - the same steps as
+// BK_LOC_ROW / K_LF1 / K_LF2 / K_SA of the lane, one read per lane, narrow index.
+KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
+  const uint32_t fl0 = hit->flags;
+  if (!(fl0 & kHitLocPending)) return;
+  const uint32_t nsi = hit->n_ids;
+  const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
+  const uint32_t check = (1u << ix.chpt_exp) - 1u;
+  const RankBlock64 *const blk0 = ix.blocks64;
+  uint32_t nids = 0, flags = 0;
+  uint64_t id0 = 0;
+  auto add_tax = [&](uint64_t tax) {
+    bool dup = false;
+    if (nids >= 1 && tax == id0) dup = true;
+    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+  };
+  bool done = false;
+  for (uint32_t s = 0; s < nsi && !done; s++) {
+    const uint32_t lo = (uint32_t)e[s], len = (uint32_t)(e[s] >> 32);
+    const uint32_t rowend = lo + (uint32_t)(int32_t)len;
+    for (uint32_t row = lo; row < rowend; row++) {
+      if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; break; }     // :805-807
+      uint32_t k = row;
+      for (;;) {
+        if ((k & check) == 0) {
+          const uint64_t sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+          if (sa_idx < ix.n_sa) { const uint64_t tax = ix.sa_taxid[sa_idx]; if (tax != ~0ull) add_tax(tax); }
+          break;                                           // (beyond the samples the reference reads out of bounds: the row is skipped)
+        }
+        const RankBlock64 &rb = blk0[k >> 6];
+        const uint32_t sft = k & 63u;
+        const uint32_t c = (uint32_t)((rb.plane[0] >> sft) & 1ull) | (uint32_t)((rb.plane[1] >> sft) & 1ull) << 1 |
+                           (uint32_t)((rb.plane[2] >> sft) & 1ull) << 2 | (uint32_t)((rb.plane[3] >> sft) & 1ull) << 3 |
+                           (uint32_t)((rb.plane[4] >> sft) & 1ull) << 4;
+        if (c == 0) {
+          // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+          const uint32_t iseq = (uint32_t)rank_term(ix, k);
+          if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+          break;
+        }
+        const uint64_t ia = (c & 1u) ? 0ull : ~0ull, ib = (c & 2u) ? 0ull : ~0ull, ic = (c & 4u) ? 0ull : ~0ull,
+                       id = (c & 8u) ? 0ull : ~0ull, ie = (c & 16u) ? 0ull : ~0ull;
+        const uint64_t m = (rb.plane[0] ^ ia) & (rb.plane[1] ^ ib) & (rb.plane[2] ^ ic) & (rb.plane[3] ^ id) & (rb.plane[4] ^ ie);
+        k = rb.cnt[c - 1u] + popc64(m & ((1ull << sft) - 1ull));         // k = C[c] + rank(c, k): the counts are absolute
+      }
+    }
+  }
+  hit->n_ids = nids; hit->flags = flags;
 }
 
 // ----------------------------------------------------------------------------
@@ -2718,29 +2837,6 @@ constexpr int kGreedyWavesPerSimd = 3;           // (the lane needs 247 VGPRs: a
 #else
 constexpr int kGWinStride = 17, kGMqStride = 13, kGPrioStride = 44;
 constexpr int kGreedyWavesPerSimd = 2;
-#endif
-
-// -DKJ_PROF (developer build, tests/tools/greedy_prof.sh): where a wavefront of greedy_lane2 spends its cycles.  KJ_P(section)
-// charges the cycles since the previous mark to the PREVIOUS section and notes with how many active lanes the new one is
-// entered; sums per wavefront in LDS, added to the counter block (byte 1024 on) when the wavefront ends.
-enum ProfSec : int { PS_HEAD, PS_AFTER_SEARCH, PS_VAR_NEXT, PS_VAR_MATCH, PS_EVAL_NEXT, PS_EVAL_MATCH, PS_POP, PS_POP_SEG, PS_FINISH,
-                     PS_HANDOUT, PS_LOAD, PS_LOAD10, PS_STEP, PS_KMER, PS_LF1, PS_SA, PS_VM_RANK, PS_VM_PUSH, PS_META, PS_FRAG,
-                     PS_FILL, PS_MLOAD, PS_END_MATCH, PS_START_J, PS_LOC_ROW, PS_TAIL, PS_N };
-#if defined(KJ_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define KJ_P(sec) kj_prof_mark(gs.prof, (sec))
-__device__ __forceinline__ void kj_prof_mark(unsigned long long *pw, int sec) {
-  const unsigned long long now = __builtin_readcyclecounter();
-  const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
-  if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) {
-    const unsigned long long prev = pw[1];
-    pw[2 + 3 * prev] += now - pw[0];
-    pw[2 + 3 * sec + 1] += 1ull;
-    pw[2 + 3 * sec + 2] += (unsigned long long)__builtin_popcountll(ex);
-    pw[0] = now; pw[1] = (unsigned long long)sec;
-  }
-}
-#else
-#define KJ_P(sec)
 #endif
 
 struct GMatch2 { uint32_t lo, len, qiql, dp; };          // qi | ql << 16, dsum | psum << 16

@@ -212,7 +212,11 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         else { if (xo) mem_lane2<true, true>(d, pp, b, w2, ls); else mem_lane2<true>(d, pp, b, w2, ls); }
       };
       if (mem_v2 && pass == 0) {
-        Params pm = p;
+        // (capi.hip: the ids of reads with one or two longest matches are located by k_mem_locate behind the searches)
+        const bool defer = d.kmer32 && !xo && !getenv("KAIJU_EMU_LOCATE_INLINE");
+        Params pd = p;
+        if (defer) pd.flags |= kParamDeferLocate;
+        Params pm = pd;
         if (lazy) pm.flags |= kParamLazySeg;
         lane_v2(pm, wl);
         if (lazy) {
@@ -264,7 +268,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
           WorkList w2;
           w2.counter = &counter2; w2.n_items = nlist; w2.n_items_ptr = nullptr; w2.reads = seglist.data();
           w2.retry_list = retry.data(); w2.retry_count = &retry_count;
-          if (nlist) lane_v2(p, w2);
+          if (nlist) lane_v2(pd, w2);
           if (getenv("KAIJU_EMU_PRINT_LAZY")) fprintf(stderr, "[emu] lazy SEG: %u of %u reads listed\n", nlist, n);
         }
       }
@@ -341,6 +345,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }
+  // k_mem_locate (capi.hip): behind the main, the second and the retry search
+  if (p.mode == 0) for (uint32_t r = 0; r < n; r++) mem_locate_read(d, p, &hits[r]);
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
   if (p.seg && n > 0) {
     std::vector<uint32_t> redo;
