@@ -2352,6 +2352,7 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
       }
     }
   }
+  for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;   // (the slots that held the matches and got no id)
   hit->n_ids = nids; hit->flags = flags;
 }
 

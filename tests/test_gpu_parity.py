@@ -80,6 +80,25 @@ def test_golden_short_reads_fast_path(gpu_lib, golden, gidx, oracle, ohandles, m
     assert (h2 == hits).all()
 
 
+@pytest.mark.parametrize("seg", [1, 0])
+def test_mem_locate_by_the_search_lanes(gpu_lib, golden, gidx, oracle, ohandles, seg, monkeypatch):
+    """KAIJU_GPU_MEM_LOCATE=inline: the MEM lanes walk to the ids themselves (the flow before k_mem_locate, still the one of
+    reads with more than two longest matches); short reads and pairs vs the oracle and vs the default flow"""
+    api = gpu_lib
+    ix, tax = ohandles
+    _, sseqs, soff = golden.short()
+    for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True)):
+        oh = oracle.classify(ix, tax, oracle.params("mem", seg=seg, use_evalue=0), seqs, off, paired=pe)
+        monkeypatch.delenv("KAIJU_GPU_MEM_LOCATE", raising=False)
+        hd = api.Classifier(gidx, api.default_params("mem", seg=seg)).classify(seqs, off, paired=pe)
+        monkeypatch.setenv("KAIJU_GPU_MEM_LOCATE", "inline")
+        hi = api.Classifier(gidx, api.default_params("mem", seg=seg)).classify(seqs, off, paired=pe)
+        for hits in (hd, hi):
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+            assert not bad, (seg, pe, bad[:5])
+            assert not (hits["flags"] & 0x20000000).any()        # kHitLocPending never leaves the library
+
+
 def test_greedy_third_generation_on_device(gpu_lib, golden, gidx, oracle, ohandles, monkeypatch):
     """KAIJU_GPU_GREEDY_LANE=v3: the two-kernel rounds (experimental); short reads and pairs vs the oracle, also with too few
     rounds (leftovers go to the retry pass)"""

@@ -93,6 +93,25 @@ def test_fast_stage1_and_lazy_seg_on_short_reads(oracle, emu, golden, handles, m
 
 
 @pytest.mark.parametrize("seg", [1, 0])
+def test_mem_locate_in_a_pass_of_its_own(oracle, emu, golden, handles, seg, monkeypatch):
+    """MEM: reads with one or two longest matches leave them in the hit record and mem_locate_read (k_mem_locate on the
+    device) walks to their ids behind the searches; the lanes walking themselves (KAIJU_EMU_LOCATE_INLINE, the flow of
+    KAIJU_GPU_MEM_LOCATE=inline) must give the same records - single reads, pairs, the general set with long reads"""
+    h, ix, tax = handles
+    _, sseqs, soff = golden.short()
+    for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True), (golden.seqs, golden.off, False)):
+        oh = oracle.classify(ix, tax, oracle.params("mem", seg=seg, use_evalue=0), seqs, off, paired=pe)
+        monkeypatch.delenv("KAIJU_EMU_LOCATE_INLINE", raising=False)
+        gd, _ = emu.classify(h, util.gp("mem", seg=seg), seqs, off, paired=pe)
+        monkeypatch.setenv("KAIJU_EMU_LOCATE_INLINE", "1")
+        gi, _ = emu.classify(h, util.gp("mem", seg=seg), seqs, off, paired=pe)
+        assert (gd == gi).all()
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gd[i])]
+        assert not bad, (seg, pe, bad[:5])
+        assert not (gd["flags"] & 0x20000000).any()          # kHitLocPending never leaves the library
+
+
+@pytest.mark.parametrize("seg", [1, 0])
 def test_greedy_third_generation(oracle, emu, golden, handles, seg, monkeypatch):
     """the two-kernel rounds of the third-generation Greedy search (g3_book / g3_search / g3_locate; experimental on the
     device, KAIJU_GPU_GREEDY_LANE=v3): single reads and pairs, also with few rounds (leftovers -> retry pass)"""
