@@ -1919,7 +1919,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // in chunks of consecutive reads (one atomic per chunk, guided chunk size), lanes take reads
 // from the wave's chunk with a ballot/prefix count.
 // ----------------------------------------------------------------------------
-enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT };
+enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT };   // (K_WAIT: -DKJ_MEM_GATE only)
 enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
 
 
@@ -1978,8 +1978,26 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   auto si_frag = [&](uint32_t e) -> uint32_t { return e == 0 ? s0frag : e == 1 ? s1frag : ls.si[e].frag; };
   auto in_win = [&](int pos) -> bool { return pos >= lw.q && pos < lw.q + kWin; };
 
+#ifdef KJ_MEM_ROLL
+  // experiment for round 3: the k-mer index of end position j-1 from that of j (one LDS byte instead of seven);
+  // in round 1 it cost a register too many, the locate state has left the common path since
+  uint32_t roll_cj = 1, roll_pow = 1;
+  bool roll_ok = false;
+  for (uint32_t q = 1; q < kk; q++) roll_pow *= 20u;
+#endif
+#ifdef KJ_MEM_GATE
+  // experiment for round 3: the fragment switches (K_META / K_FRAG / K_FILL: a fifth of the kernel's cycles with
+  // two lanes of 64 active) only in every (KJ_MEM_GATE+1)-th iteration; a lane that needs one waits for it
+  uint32_t gate_it = 0;
+#endif
   for (;;) {
     KJ_PM(PM_HEAD);
+#ifdef KJ_MEM_GATE
+    const bool rare_ok = (gate_it++ & (uint32_t)(KJ_MEM_GATE)) == 0u;
+    const int kind_saved = kind;
+    const bool parked = !rare_ok && (kind == K_META || kind == K_FRAG || kind == K_FILL);
+    if (parked) kind = K_WAIT;
+#endif
     // ---- (0) hand out reads to the lanes that finished one (wave-uniform control flow) ----
     {
       const bool need = kind == K_IDLE;
@@ -2167,6 +2185,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       else bk = BK_START_J;
     }
 
+#ifdef KJ_MEM_GATE
+    if (parked) kind = kind_saved;
+#endif
     // ---- (3) bookkeeping, blocks ordered along the usual flow (see mem_lane) ----
     KJ_PM(PM_TAIL);
     while (bk != BK_NONE) {
@@ -2194,11 +2215,23 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         else if (kk && j >= (int)kk - 1) {
           if (in_win(j) && in_win(j - (int)kk + 1)) {
             // (a rolling update of the index from end position j+1 was tried: it costs a register too many here)
-            kidx = 0;
-            for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
+#ifdef KJ_MEM_ROLL
+            if (roll_ok) kidx = (kidx - (roll_cj - 1u) * roll_pow) * 20u + ((uint32_t)lw.w[j - (int)kk + 1 - lw.q] - 1u);
+            else
+#endif
+            {
+              kidx = 0;
+              for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
+            }
+#ifdef KJ_MEM_ROLL
+            roll_cj = lw.w[j - lw.q]; roll_ok = true;
+#endif
             kind = K_KMER; bk = BK_NONE;
           } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
         } else if (in_win(j)) {
+#ifdef KJ_MEM_ROLL
+          roll_ok = false;
+#endif
           c = lw.w[j - lw.q];
           lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];            // InitialSI, bwt.c:146-152
           i = j;
@@ -2214,6 +2247,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (f >= nf || (found && dnext.key < L)) bk = BK_LOC_INIT;
         else {
           fcur = f; f++;
+#ifdef KJ_MEM_ROLL
+          roll_ok = false;
+#endif
           fsoff = pepoff + dnext.start; flen = (int)dnext.len;
           j = flen - 1;
           fill_top = j; fill_newfrag = true; fill_step = false;

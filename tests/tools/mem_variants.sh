@@ -1,0 +1,29 @@
+#!/bin/bash
+# A/B of compile-time variants of the search lanes.  One library per variant under kaiju_amd/variants/ (git-ignored,
+# travels to the GPU box with the snapshot):
+#   mem_variants.sh build                      here (hipcc cross-compiles; ~35 s per variant)
+#   mem_variants.sh run <outdir> [mode] [n]    on the GPU box: the prepared workload with each library, search times and a
+#                                              checksum of the records (all variants must agree)
+# VARIANTS="base gate1 gate3 roll roll_gate1" (default); others: prof (section profiler), g_occ3
+R=$(cd "$(dirname "$0")/../.." && pwd)
+V=$R/kaiju_amd/variants
+SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-gpu-rdc -Wno-unused-result -w"
+declare -A DEF=( [base]="" [gate1]="-DKJ_MEM_GATE=1" [gate3]="-DKJ_MEM_GATE=3" [roll]="-DKJ_MEM_ROLL" [roll_gate1]="-DKJ_MEM_ROLL -DKJ_MEM_GATE=1" [prof]="-DKJ_PROF" [g_occ3]="-DKJ_G_OCC3" )
+LIST=${VARIANTS:-base gate1 gate3 roll roll_gate1}
+if [ "$1" = build ]; then
+  mkdir -p $V
+  for v in $LIST; do
+    /opt/rocm/bin/hipcc $FLAGS ${DEF[$v]} -o $V/libkaiju_gpu_$v.so $SRC -lpthread && echo "built $v" || echo "$v: build failed"
+  done
+  exit 0
+fi
+OUT=$2; MODE=${3:-mem}; N=${4:-4000000}
+mkdir -p $OUT
+[ -f /tmp/kjw/reads.npy ] || python $R/tests/tools/prof_prepare.py /tmp/kjw 680001 $N > /dev/null 2>&1
+for v in $LIST; do
+  lib=$V/libkaiju_gpu_$v.so
+  [ -f $lib ] || { echo "$v: not built (mem_variants.sh build)"; continue; }
+  KAIJU_GPU_LIB=$lib python $R/tests/tools/prof_run.py /tmp/kjw $MODE 1 3 $N > $OUT/$v.txt 2>&1
+  echo "== $v"; grep -E "search|checksum" $OUT/$v.txt | tail -3
+done

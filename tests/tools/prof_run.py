@@ -23,3 +23,6 @@ for _ in range(reps):
           f"search {st.ms_search:.2f} retry {st.ms_retry:.2f} [{st.n_overflow_retries}] total {st.ms_total:.2f} ms "
           f"-> {len(reads)/st.ms_total*1e3:,.0f} reads/s", flush=True)
 print("hit fraction", float((hits['n_ids'] > 0).mean()))
+# (for A/B runs of kernel variants: the same reads must give the same records)
+print("checksum", int(hits['n_ids'].astype(np.int64).sum()), int(hits['best'].astype(np.int64).sum()),
+      int(hits['taxid'].astype(np.uint64).sum() & np.uint64(0xffffffffffff)))
