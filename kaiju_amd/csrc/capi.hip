@@ -290,12 +290,17 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
   mem_lane2<false>(ix, p, b, wl, ls);
 }
 // the ids of the reads whose longest matches the lanes above left in their hit records (kParamDeferLocate): one lane per read
+#ifdef KJ_LOCATE_PERSIST
+__global__ void __launch_bounds__(256)
+k_mem_locate(DevIndex ix, Params p, Batch b, uint32_t *counter) { mem_locate_lane(ix, p, b, counter); }
+#else
 __global__ void __launch_bounds__(256)
 k_mem_locate(DevIndex ix, Params p, Batch b) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
   if (r >= b.n_reads) return;
   mem_locate_read(ix, p, b.hits + r);
 }
+#endif
 // the same kernel under a second name for the second search of the lazy SEG flow (the few reads whose fragments SEG had
 // to cut), so that a kernel trace lists the full-size launches of k_mem by themselves
 __global__ void __launch_bounds__(kBlock, 4)
@@ -1283,7 +1288,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
       if (defer) {
+#ifdef KJ_LOCATE_PERSIST
+        hipLaunchKernelGGL(k_mem_locate, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, cnt + 24);
+#else
         hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+#endif
         KJ_HIP(hipGetLastError());
       }
       if (exact_pass) {

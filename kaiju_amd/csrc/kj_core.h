@@ -2392,6 +2392,142 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
   hit->n_ids = nids; hit->flags = flags;
 }
 
+#ifdef KJ_LOCATE_PERSIST
+// experiment for round 3: mem_locate_read as persistent lanes with the load-phase structure of the search
+// lanes - a lane pulls read numbers from a work counter, one hit-record fetch, LF step or SA sample per iteration
+enum MLKind : int { ML_LF1, ML_LF2, ML_SA, ML_FETCH, ML_IDLE, ML_EXIT };
+KJ_HD void mem_locate_lane(const DevIndex &ix, const Params &p, const Batch &b, uint32_t *counter) {
+  int kind = ML_IDLE;
+  uint32_t c = 1, cur = 0, nsi = 0, nids = 0, flags = 0, row = 0, rowend = 0, k = 0;
+  uint64_t e0 = 0, e1 = 0, id0 = 0, sa_idx = 0;
+  bool fresh = true;
+  Hit *hit = nullptr;
+  const uint32_t check = (1u << ix.chpt_exp) - 1u;
+  const uint32_t n_items = b.n_reads;
+  const uint32_t nwaves = kj_nwaves();
+  uint32_t wnext = 0, wend = 0, item = 0;
+  const RankBlock64 *const blk0 = ix.blocks64;
+  auto add_tax = [&](uint64_t tax) {
+    bool dup = false;
+    if (nids >= 1 && tax == id0) dup = true;
+    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+  };
+  for (;;) {
+    {
+      const bool need = kind == ML_IDLE;
+      const uint64_t mask = kj_ballot(need);
+      if (mask) {
+        const uint32_t n = popc64(mask);
+        const uint32_t rank = kj_rank_below(mask);
+        const uint32_t avail = wend - wnext;
+        uint32_t newbase = 0, ch = 0;
+        if (n > avail) {
+          const uint32_t left = n_items > wend ? n_items - wend : 0;
+          ch = left / (nwaves * 4u);
+          if (ch > 512u) ch = 512u;
+          if (ch < 64u) ch = 64u;
+          if (ch < n - avail) ch = n - avail;
+          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+          uint32_t got = 0;
+          if (need && rank == 0) got = kj_fetch_chunk(counter, ch);
+          newbase = kj_bcast_uniform(got, leader);
+        }
+        if (need) {
+          item = rank < avail ? wnext + rank : newbase + (rank - avail);
+          kind = item >= n_items ? ML_EXIT : ML_FETCH;
+        }
+        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
+        else wnext += n;
+      }
+      if (kj_ballot(kind != ML_EXIT) == 0) break;
+    }
+    const bool is_lf = kind == ML_LF1 || kind == ML_LF2;
+    const uint32_t posA = is_lf ? k : 0;
+    const uint32_t cc = kind == ML_LF2 ? c : 1u;
+    const RankBlock64 *pa = blk0 + (posA >> 6);
+    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
+    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
+    const uint64_t a4 = pa->plane[4];
+    const uint32_t ca = pa->cnt[cc - 1];
+    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
+    if (kind == ML_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    const uint32_t goff = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) & 15u);
+    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    // the record's header and the two noted matches behind it (records are 184 bytes: 8-byte aligned)
+    uint64_t h0 = 0, h1 = 0, g2x = 0, g2y = 0;
+    if (kj_ballot(kind == ML_FETCH)) {
+      const uint64_t *q = reinterpret_cast<const uint64_t *>(kind == ML_FETCH ? reinterpret_cast<const uint8_t *>(b.hits + item)
+                                                                              : reinterpret_cast<const uint8_t *>(blk0));
+      h0 = q[0]; h1 = q[1]; g2x = q[2]; g2y = q[3];
+    }
+    int bk = 0;                                              // 1: next match, 2: next row, 3: done
+    if (kind == ML_LF2) {
+      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
+                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
+      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
+      k = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
+      fresh = false;
+      bk = 2;
+    } else if (kind == ML_LF1) {
+      const uint32_t sft = k & 63u;
+      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
+          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
+      if (c != 0) kind = ML_LF2;
+      else {
+        const uint32_t iseq = (uint32_t)rank_term(ix, k);
+        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+        row++; k = row; fresh = true;
+        bk = 2;
+      }
+    } else if (kind == ML_SA) {
+      const uint64_t tax = goff & 8u ? gv.y : gv.x;
+      if (tax != ~0ull) add_tax(tax);
+      row++; k = row; fresh = true;
+      bk = 2;
+    } else if (kind == ML_FETCH) {
+      // Hit: best, n_ids | flags, reserved | taxid[0] | taxid[1]
+      const uint32_t fl0 = (uint32_t)h1;
+      if (!(fl0 & kHitLocPending)) kind = ML_IDLE;
+      else {
+        nsi = (uint32_t)(h0 >> 32);
+        e0 = g2x; e1 = g2y;
+        hit = b.hits + item;
+        nids = 0; flags = 0; cur = 0;
+        bk = 1;
+      }
+    }
+    while (bk) {
+      if (bk == 1) {
+        if (cur >= nsi) bk = 3;
+        else {
+          const uint64_t e = cur == 0 ? e0 : e1;
+          row = (uint32_t)e; rowend = row + (uint32_t)(int32_t)(uint32_t)(e >> 32);
+          cur++; k = row; fresh = true;
+          bk = 2;
+        }
+      }
+      if (bk == 2) {
+        for (;;) {
+          if (row >= rowend) { bk = 1; break; }
+          if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = 3; break; }     // :805-807
+          if ((k & check) != 0) { kind = ML_LF1; bk = 0; break; }
+          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+          if (sa_idx < ix.n_sa) { kind = ML_SA; bk = 0; break; }
+          row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
+        }
+        if (bk == 1) continue;
+      }
+      if (bk == 3) {
+        for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;
+        hit->n_ids = nids; hit->flags = flags;
+        kind = ML_IDLE; bk = 0;
+      }
+    }
+  }
+}
+#endif
+
 // ----------------------------------------------------------------------------
 // Greedy lane: classify_greedyblosum (ConsumerThread.cpp:424-541), maxMatches /
 // maxMatches_withStart (bwt.c:261-336), addAllMismatchVariantsAtPosSI (:346-395),

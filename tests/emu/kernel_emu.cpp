@@ -346,7 +346,11 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     }
   }
   // k_mem_locate (capi.hip): behind the main, the second and the retry search
+#ifdef KJ_LOCATE_PERSIST
+  if (p.mode == 0) { uint32_t lc = 0; mem_locate_lane(d, p, b, &lc); }
+#else
   if (p.mode == 0) for (uint32_t r = 0; r < n; r++) mem_locate_read(d, p, &hits[r]);
+#endif
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
   if (p.seg && n > 0) {
     std::vector<uint32_t> redo;
