@@ -1400,16 +1400,30 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         KJ_HIP(kj_launch_exact_pass(xp));
       }
     } else if (n > 0) {
+      Params pg = p;
+#ifdef KJ_G_DEFER_LOCATE
+      if (use_g2 && c->defer_locate) pg.flags |= kParamDeferLocate;       // (experiment: reads with one best match -> k_mem_locate)
+#endif
       if (use_g2 && c->count_ops)
-        hipLaunchKernelGGL(k_greedy2_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, p, sq, b, wl_main, g2);
+        hipLaunchKernelGGL(k_greedy2_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
       else if (use_g2)
-        hipLaunchKernelGGL(k_greedy2, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, p, sq, b, wl_main, g2);
+        hipLaunchKernelGGL(k_greedy2, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
       else
         hipLaunchKernelGGL(k_greedy, dim3(c->blocks_main), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_main, ga, vb);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
+#ifdef KJ_G_DEFER_LOCATE
+      if (pg.flags & kParamDeferLocate) {
+#ifdef KJ_LOCATE_PERSIST
+        hipLaunchKernelGGL(k_mem_locate, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, cnt + 24);
+#else
+        hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+#endif
+        KJ_HIP(hipGetLastError());
+      }
+#endif
       if (exact_pass) {
         xp.g_pool = gr.pool; xp.g_ord = gr.ord; xp.g_matches = gr.matches; xp.g_best = gr.best; xp.g_bestv = gr.bestv;
         xp.g_pool_cap = gr.pool_cap; xp.g_match_cap = gr.match_cap; xp.blocks_search = c->blocks_retry;

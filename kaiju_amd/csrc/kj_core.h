@@ -2349,7 +2349,7 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
   const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
   const uint32_t check = (1u << ix.chpt_exp) - 1u;
   const RankBlock64 *const blk0 = ix.blocks64;
-  uint32_t nids = 0, flags = 0;
+  uint32_t nids = 0, flags = fl0 & ~kHitLocPending;          // (a Greedy read may carry kHitSiCap already)
   uint64_t id0 = 0;
   auto add_tax = [&](uint64_t tax) {
     bool dup = false;
@@ -2493,7 +2493,7 @@ KJ_HD void mem_locate_lane(const DevIndex &ix, const Params &p, const Batch &b, 
         nsi = (uint32_t)(h0 >> 32);
         e0 = g2x; e1 = g2y;
         hit = b.hits + item;
-        nids = 0; flags = 0; cur = 0;
+        nids = 0; flags = fl0 & ~kHitLocPending; cur = 0;
         bk = 1;
       }
     }
@@ -3371,6 +3371,15 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             hit->best = nbest ? best : 0u;
             cur = 0;
             bk = GB_LOC_NEXT_SI;
+#ifdef KJ_G_DEFER_LOCATE
+            // experiment for round 3: a read that ends with ONE best match leaves it in the hit record for
+            // k_mem_locate, as the MEM lanes do (the locate sections of this lane run with one or two lanes active: 7 % of it)
+            if (nbest == 1u && (p.flags & kParamDeferLocate)) {
+              hit->taxid[0] = (uint64_t)b0lo | (uint64_t)b0len << 32;
+              nids = 1; flags |= kHitLocPending;
+              bk = GB_DONE;
+            }
+#endif
           }
         }
         if (bk == GB_LOC_NEXT_SI) {

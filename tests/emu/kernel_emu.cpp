@@ -341,15 +341,26 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         const char *ge = getenv("KAIJU_EMU_GATE");
         GreedyScratch2 g2{reinterpret_cast<uint8_t *>(lds_win), reinterpret_cast<uint16_t *>(lds_mq), lds_prio, pool2.data(),
                           prio_ext.data(), matches2.data(), mq_ext.data(), best2.data(), ge ? (uint32_t)atoi(ge) : 3u};
+#ifdef KJ_G_DEFER_LOCATE
+        Params pg = p;
+        pg.flags |= kParamDeferLocate;
+        greedy_lane2(d, ix->ct, pg, sq, b, wl, g2);
+#else
         greedy_lane2(d, ix->ct, p, sq, b, wl, g2);
+#endif
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }
   // k_mem_locate (capi.hip): behind the main, the second and the retry search
-#ifdef KJ_LOCATE_PERSIST
-  if (p.mode == 0) { uint32_t lc = 0; mem_locate_lane(d, p, b, &lc); }
+#ifdef KJ_G_DEFER_LOCATE
+  const bool locate_pass = true;
 #else
-  if (p.mode == 0) for (uint32_t r = 0; r < n; r++) mem_locate_read(d, p, &hits[r]);
+  const bool locate_pass = p.mode == 0;
+#endif
+#ifdef KJ_LOCATE_PERSIST
+  if (locate_pass) { uint32_t lc = 0; mem_locate_lane(d, p, b, &lc); }
+#else
+  if (locate_pass) for (uint32_t r = 0; r < n; r++) mem_locate_read(d, p, &hits[r]);
 #endif
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
   if (p.seg && n > 0) {
