@@ -434,11 +434,17 @@ k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue 
   gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
   gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
   gs.prio = s_prio + threadIdx.x * kGPrioStride;
+#ifdef KJ_G_OCC3
+  gs.pool = ga.pool; gs.prio_ext = ga.prio_ext; gs.matches = ga.matches; gs.mq_ext = ga.mq_ext; gs.best = ga.best;
+  gs.lane = (uint32_t)lane;
+#else
   gs.pool = ga.pool + lane * (8 * kGSlotsAll);
   gs.prio_ext = ga.prio_ext + lane * (kGSlotsAll - kGSlots);
   gs.matches = ga.matches + lane * kGMaxMAll;
   gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
   gs.best = ga.best + lane * 64;
+  gs.lane = 0;
+#endif
   gs.gate = ga.gate;
   gs.prof = nullptr;
 #ifdef KJ_PROF
@@ -469,6 +475,11 @@ k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Seg
   gs.best = ga.best + lane * 64;
   gs.gate = ga.gate;
   gs.prof = nullptr;
+  gs.lane = 0;
+#ifdef KJ_G_OCC3
+  gs.pool = ga.pool; gs.prio_ext = ga.prio_ext; gs.matches = ga.matches; gs.mq_ext = ga.mq_ext; gs.best = ga.best;
+  gs.lane = (uint32_t)lane;
+#endif
   greedy_lane2<true>(ix, s_ct, p, sq, b, wl, gs);
 }
 

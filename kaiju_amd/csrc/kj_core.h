@@ -3006,7 +3006,11 @@ constexpr int kGSlots = 44, kGSlotsAll = 128;    // queue slots: priorities in L
 // LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
 #if defined(KJ_G_OCC3) && !defined(KJ_G_SMALL)
 constexpr int kGWinStride = 17, kGMqStride = 7, kGPrioStride = 20;     // 176 bytes per lane
+#ifdef KJ_G_OCC3_NOBOUND                           // (developer aid: the register need of the OCC3 code without the bound)
+constexpr int kGreedyWavesPerSimd = 2;
+#else
 constexpr int kGreedyWavesPerSimd = 3;           // (the lane needs 247 VGPRs: at 168 the compiler spills 724 bytes per lane)
+#endif
 #else
 constexpr int kGWinStride = 17, kGMqStride = 13, kGPrioStride = 44;
 constexpr int kGreedyWavesPerSimd = 2;
@@ -3025,6 +3029,7 @@ struct GreedyScratch2 {
   GBest2 *best;                // 64
   uint32_t gate;               // heavy iterations: (iteration & gate) == 0
   unsigned long long *prof;    // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PS_N)
+  uint32_t lane;               // -DKJ_G_OCC3: the device-memory pointers above are the bases of all lanes, this is the lane's number
 };
 
 enum GKind : int { G_STEP, G_KMER, G_LF1, G_LF2, G_SA,                                     // fast
@@ -3035,6 +3040,20 @@ enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_LOC_ROW,                 
                  GB_LOC_NEXT_SI, GB_DONE };
 enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 
+// the lane's scratch in device memory: pointers kept per lane, or (three wavefronts per SIMD) recomputed from the lane number
+#ifdef KJ_G_OCC3
+#define GS_POOL (gs.pool + (size_t)gs.lane * (8 * kGSlotsAll))
+#define GS_PRIO_EXT (gs.prio_ext + (size_t)gs.lane * (kGSlotsAll - kGSlots))
+#define GS_MATCHES (gs.matches + (size_t)gs.lane * kGMaxMAll)
+#define GS_MQ_EXT (gs.mq_ext + (size_t)gs.lane * (kGMaxMAll - kGMaxM))
+#define GS_BEST (gs.best + (size_t)gs.lane * 64)
+#else
+#define GS_POOL gs.pool
+#define GS_PRIO_EXT gs.prio_ext
+#define GS_MATCHES gs.matches
+#define GS_MQ_EXT gs.mq_ext
+#define GS_BEST gs.best
+#endif
 template <bool COUNT = false>
 KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                         const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
@@ -3098,7 +3117,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
 
   auto diag = [&](uint32_t cc) -> uint32_t { return (uint32_t)(((cc & 16u) ? dg1 : dg0) >> (4u * (cc & 15u))) & 15u; };
   auto in_win = [&](int pos) -> bool { return pos >= wq && pos < wq + kWin; };
-  auto mq_get = [&](uint32_t x) -> int { return (int)(x < (uint32_t)kGMaxM ? mq[x] : gs.mq_ext[x - kGMaxM]); };
+  auto mq_get = [&](uint32_t x) -> int { return (int)(x < (uint32_t)kGMaxM ? mq[x] : GS_MQ_EXT[x - kGMaxM]); };
   auto mq_max_below = [&](int bound) -> int {   // largest match length < bound, -1 if none
     int v = -1;
     for (uint32_t x = 0; x < nm; x++) { const int q = mq_get(x); if (q < bound && q > v) v = q; }
@@ -3109,8 +3128,8 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     while (x < nm && mq_get(x) != v) x++;
     return x;
   };
-  auto pr_get = [&](uint32_t s) -> uint32_t { return s < (uint32_t)kGSlots ? prio[s] : gs.prio_ext[s - kGSlots]; };
-  auto pr_set = [&](uint32_t s, uint32_t v) { if (s < (uint32_t)kGSlots) prio[s] = v; else gs.prio_ext[s - kGSlots] = v; };
+  auto pr_get = [&](uint32_t s) -> uint32_t { return s < (uint32_t)kGSlots ? prio[s] : GS_PRIO_EXT[s - kGSlots]; };
+  auto pr_set = [&](uint32_t s, uint32_t v) { if (s < (uint32_t)kGSlots) prio[s] = v; else GS_PRIO_EXT[s - kGSlots] = v; };
   // multimap emplace of a variant / SEG piece: returns the slot (or ~0)
   auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
     KJ_HISTO(7, qlive);
@@ -3148,7 +3167,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     if (score == best) {
       if (nbest < p.max_matches_SI && nbest < 64) {
         if (nbest == 0) { b0lo = m_lo; b0len = m_len; }
-        else { GBest2 gb; gb.lo = m_lo; gb.len = m_len; gs.best[nbest] = gb; }
+        else { GBest2 gb; gb.lo = m_lo; gb.len = m_len; GS_BEST[nbest] = gb; }
         nbest++;
       } else flags |= kHitSiCap;
     }
@@ -3311,7 +3330,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               }
             } else
               for (uint32_t s = 0; s < nl; s++) { const uint32_t pr = prio[s]; if (pr > dbest) { dbest = pr; dslot = s; } }
-            for (uint32_t s = kGSlots; s < qn; s++) { const uint32_t pr = gs.prio_ext[s - kGSlots]; if (pr > dbest) { dbest = pr; dslot = s; } }
+            for (uint32_t s = kGSlots; s < qn; s++) { const uint32_t pr = GS_PRIO_EXT[s - kGSlots]; if (pr > dbest) { dbest = pr; dslot = s; } }
           }
           const bool have_o = fo < nf, have_d = dbest != 0;
           const uint32_t dkey = dbest >> 16;
@@ -3339,7 +3358,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                     const uint32_t sl = push_slot(q.key, qseq);
                     if (sl == ~0u) return;
                     qseq++;
-                    u128 *dst = gs.pool + 8 * sl;
+                    u128 *dst = GS_POOL + 8 * sl;
                     u128 v;
                     v.x = 0; v.y = q.key | (uint64_t)q.start << 32; dst[0] = v;
                     v.x = q.len; v.y = q.key; dst[1] = v;
@@ -3386,7 +3405,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           if (cur >= nbest) bk = GB_DONE;
           else {
             if (cur == 0) { row = b0lo; rowend = b0lo + b0len; }
-            else { const GBest2 gb = gs.best[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
+            else { const GBest2 gb = GS_BEST[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
             cur++;
             k = row; fresh = true;
             bk = loc_row();
@@ -3476,19 +3495,25 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     else if (kind == G_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == G_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == G_FILL && fill_pref && fo < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + fo);
-    else if (kind == G_MLOAD) gaddr = reinterpret_cast<const uint8_t *>(gs.matches + mx);
+    else if (kind == G_MLOAD) gaddr = reinterpret_cast<const uint8_t *>(GS_MATCHES + mx);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
     const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
     // ten 16-byte reads from two lane-chosen places: a window (G_FILL), a queued item (G_POPITEM)
     u128 xa0{0, 0}, xa1{0, 0}, xa2{0, 0}, xa3{0, 0}, xa4{0, 0}, xb0{0, 0}, xb1{0, 0}, xb2{0, 0}, xb3{0, 0}, xb4{0, 0};
     int fq = 0;
+#ifdef KJ_G_OCC3
+    // (three wavefronts per SIMD: these reads wait until the lane consumes them, behind the fast compute, when the rank lines
+    // of this iteration are dead - a second, exposed wait in heavy iterations for forty registers less at the peak)
+    if (false) {
+#else
     if (heavy && kj_ballot(kind == G_FILL || kind == G_POPITEM)) {            // wave-uniform
+#endif
       KJ_P(PS_LOAD10);
       fq = fill_top - (kWin - 1);
       if (fq < 0) fq = 0;
       const uint8_t *sa = reinterpret_cast<const uint8_t *>(blk0), *sb = sa;
       if (kind == G_FILL) sa = b.pep + pepoff + t_start + fq;
-      else if (kind == G_POPITEM) { sa = reinterpret_cast<const uint8_t *>(gs.pool + 8 * pslot); sb = sa + 80; }
+      else if (kind == G_POPITEM) { sa = reinterpret_cast<const uint8_t *>(GS_POOL + 8 * pslot); sb = sa + 80; }
       const u128_unaligned *pa16 = reinterpret_cast<const u128_unaligned *>(sa);
       const u128_unaligned *pb16 = reinterpret_cast<const u128_unaligned *>(sb);
       xa0 = pa16[0]; xa1 = pa16[1]; xa2 = pa16[2]; xa3 = pa16[3]; xa4 = pa16[4];
@@ -3630,7 +3655,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             const uint32_t bs = (t_nmm & 3u) * 8u, bm = ~(0xffu << bs);
             if (t_nmm < 4u) e0 = (e0 & bm) | cx << bs; else e1 = (e1 & bm) | cx << bs;
           }
-          u128 *dst = gs.pool + 8 * sl;
+          u128 *dst = GS_POOL + 8 * sl;
           u128 v;
           v.x = ra | (uint64_t)rb << 32; v.y = key | (uint64_t)t_start << 32; dst[0] = v;
           v.x = (vlen | (m_ql + 1u) << 16) | (uint64_t)(uint32_t)(t_diff + bos - bss) << 32;
@@ -3660,7 +3685,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           for (uint32_t s = 0; s < (uint32_t)kGSlots; s += 4) *reinterpret_cast<u128 *>(prio + s) = z;
         } else
           for (uint32_t s = 0; s < (uint32_t)kGSlots; s++) prio[s] = 0;
-        for (uint32_t s = kGSlots; s < qn; s++) gs.prio_ext[s - kGSlots] = 0;
+        for (uint32_t s = kGSlots; s < qn; s++) GS_PRIO_EXT[s - kGSlots] = 0;
         qn = qlive = qseq = 0;
         hit = b.hits + r;
         if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
@@ -3671,6 +3696,15 @@ if constexpr (COUNT) oc[kOpcTerm]++;
       } else if (kind == G_FILL || kind == G_POPITEM) {
         KJ_P(PS_FILL);
         bool fill = kind == G_FILL;
+#ifdef KJ_G_OCC3
+        fq = fill_top - (kWin - 1);
+        if (fq < 0) fq = 0;
+        {
+          const uint8_t *src = fill ? b.pep + pepoff + t_start + fq : reinterpret_cast<const uint8_t *>(GS_POOL + 8 * pslot);
+          const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
+          xa0 = s16[0]; xa1 = s16[1]; xa2 = s16[2]; xa3 = s16[3];
+        }
+#endif
         u128 f0 = xa0, f1 = xa1, f2 = xa2, f3 = xa3;
         int newq = fq;
         if (!fill) {
@@ -3696,6 +3730,9 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             if (i <= 0) bk = GB_END_MATCH;
             else if (wtag != 0) {                           // the item carries its window
               fill = true; fill_ret = FR_STEP; fill_pref = false;
+#ifdef KJ_G_OCC3
+              { const u128 *w16 = GS_POOL + 8 * pslot + 4; xa4 = w16[0]; xb0 = w16[1]; xb1 = w16[2]; xb2 = w16[3]; }
+#endif
               f0 = xa4; f1 = xb0; f2 = xb1; f3 = xb2; newq = (int)wtag - 1;
             } else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
           }
@@ -3744,8 +3781,8 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             if (nm < (uint32_t)kGMaxMAll) {
               m_lo = lo; m_len = (uint32_t)(hi - lo); m_qi = (uint32_t)i; m_ql = (uint32_t)l; m_dsum = acc; m_psum = t_tot - tail;
               GMatch2 mm; mm.lo = m_lo; mm.len = m_len; mm.qiql = m_qi | m_ql << 16; mm.dp = m_dsum | m_psum << 16;
-              gs.matches[nm] = mm;
-              if (nm < (uint32_t)kGMaxM) mq[nm] = (uint16_t)l; else gs.mq_ext[nm - kGMaxM] = (uint16_t)l;
+              GS_MATCHES[nm] = mm;
+              if (nm < (uint32_t)kGMaxM) mq[nm] = (uint16_t)l; else GS_MQ_EXT[nm - kGMaxM] = (uint16_t)l;
               if constexpr (COUNT) oc[kOpcMatchWr]++;
             } else m_ovf = true;
             nm++;
