@@ -420,17 +420,19 @@ struct GreedyArrays2 {
   u128 *pool; uint32_t *prio_ext; GMatch2 *matches; uint16_t *mq_ext; GBest2 *best;
   uint32_t gate;
 };
-constexpr size_t kGreedy2Lds = (size_t)kBlock * (kGWinStride + kGMqStride + kGPrioStride) * 4 + sizeof(ConstTables);
+constexpr size_t kGreedy2Lds = (size_t)kBlock * (kGWinStride + kGMqStride + kGPrioStride + kGSubStride) * 4 + sizeof(ConstTables);
 __global__ void __launch_bounds__(kBlock, kGreedyWavesPerSimd)
 k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   uint32_t *s_prio = s_dyn;                                   // 16-byte aligned rows
   uint32_t *s_win = s_prio + kBlock * kGPrioStride;
   uint32_t *s_mq = s_win + kBlock * kGWinStride;
-  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_mq + kBlock * kGMqStride);
+  uint32_t *s_sub = s_mq + kBlock * kGMqStride;
+  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_sub + kBlock * kGSubStride);
   load_tables(s_ct, g_ct);
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   GreedyScratch2 gs;
+  gs.sub = s_sub + threadIdx.x * kGSubStride;
   gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
   gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
   gs.prio = s_prio + threadIdx.x * kGPrioStride;
@@ -461,10 +463,12 @@ k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Seg
   uint32_t *s_prio = s_dyn;
   uint32_t *s_win = s_prio + kBlock * kGPrioStride;
   uint32_t *s_mq = s_win + kBlock * kGWinStride;
-  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_mq + kBlock * kGMqStride);
+  uint32_t *s_sub = s_mq + kBlock * kGMqStride;
+  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_sub + kBlock * kGSubStride);
   load_tables(s_ct, g_ct);
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   GreedyScratch2 gs;
+  gs.sub = s_sub + threadIdx.x * kGSubStride;
   gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
   gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
   gs.prio = s_prio + threadIdx.x * kGPrioStride;

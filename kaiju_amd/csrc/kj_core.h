@@ -2997,19 +2997,25 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
 #ifdef KJ_G_SMALL                                  // tests: exercise the spill and retry paths
 constexpr int kGMaxM = 1, kGMaxMAll = 2, kGSlots = 1, kGSlotsAll = 3;
 #elif defined(KJ_G_OCC3)                           // experiment: LDS rows small enough for three blocks per CU
-constexpr int kGMaxM = 12, kGMaxMAll = 256;
-constexpr int kGSlots = 20, kGSlotsAll = 128;
+constexpr int kGMaxM = 8, kGMaxMAll = 256;
+constexpr int kGSlots = 12, kGSlotsAll = 128;
 #else
 constexpr int kGMaxM = 24, kGMaxMAll = 256;      // matches of one fragment: lengths in LDS / in LDS + global spill
 constexpr int kGSlots = 44, kGSlotsAll = 128;    // queue slots: priorities in LDS / in LDS + global spill
 #endif
+#ifdef KJ_G_OCC3
+constexpr int kGSubStride = 17;                  // six words of substitutions + eleven of slow-part state
+#else
+constexpr int kGSubStride = 0;
+#endif
 // LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
 #if defined(KJ_G_OCC3) && !defined(KJ_G_SMALL)
-constexpr int kGWinStride = 17, kGMqStride = 7, kGPrioStride = 20;     // 176 bytes per lane
+constexpr int kGWinStride = 17, kGMqStride = 4, kGPrioStride = 12;     // 132 bytes per lane + 68 (kGSubStride) = 200: three blocks of
+                                                                        // 256 lanes + tables = 159 744 of the CU's 163 840 bytes of LDS
 #ifdef KJ_G_OCC3_NOBOUND                           // (developer aid: the register need of the OCC3 code without the bound)
 constexpr int kGreedyWavesPerSimd = 2;
 #else
-constexpr int kGreedyWavesPerSimd = 3;           // (the lane needs 247 VGPRs: at 168 the compiler spills 724 bytes per lane)
+constexpr int kGreedyWavesPerSimd = 3;           // (the code under KJ_G_OCC3 fits 168 VGPRs without a spill; the default code needs 247)
 #endif
 #else
 constexpr int kGWinStride = 17, kGMqStride = 13, kGPrioStride = 44;
@@ -3030,6 +3036,7 @@ struct GreedyScratch2 {
   uint32_t gate;               // heavy iterations: (iteration & gate) == 0
   unsigned long long *prof;    // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PS_N)
   uint32_t lane;               // -DKJ_G_OCC3: the device-memory pointers above are the bases of all lanes, this is the lane's number
+  uint32_t *sub;               // -DKJ_G_OCC3: LDS, six words: the substitutions of the variant at hand
 };
 
 enum GKind : int { G_STEP, G_KMER, G_LF1, G_LF2, G_SA,                                     // fast
@@ -3064,15 +3071,35 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   // read
   uint32_t r = 0, nf = 0, fo = 0, fbase = 0;
   uint64_t pepoff = 0;
+#ifdef KJ_G_OCC3
+  // (state that only the slow part touches lives in the lane's LDS row: gs.sub[6..14])
+  uint32_t &on_start = gs.sub[6], &on_len = gs.sub[7], &on_key = gs.sub[8], &on_flags = gs.sub[9];
+  uint32_t &b0lo = gs.sub[10], &b0len = gs.sub[11];
+  on_start = on_len = on_key = on_flags = b0lo = b0len = 0;
+  uint32_t best = 0, nbest = 0, flags = 0;
+#else
   uint32_t on_start = 0, on_len = 0, on_key = 0, on_flags = 0;    // original number fo (prefetched)
   uint32_t best = 0, nbest = 0, flags = 0, b0lo = 0, b0len = 0;
+#endif
   bool ovf = false;
   // queue of variants and SEG pieces
+#ifdef KJ_G_OCC3
+  uint32_t &qseq = gs.sub[15], &pslot = gs.sub[16];
+  qseq = pslot = 0;
+  uint32_t qn = 0, qlive = 0;
+#else
   uint32_t qn = 0, qlive = 0, qseq = 0, pslot = 0;
+#endif
   // the fragment being searched
   uint32_t t_start = 0, t_len = 0, t_matchlen = 0, t_tot = 0, t_msum = 0, t_nmm = 0;
   int32_t t_diff = 0;
+#ifdef KJ_G_OCC3
+  // substituted positions (16 bit) / letters (8 bit): six words of the lane's LDS row (touched by the slow part only)
+  uint32_t &sp0 = gs.sub[0], &sp1 = gs.sub[1], &sp2 = gs.sub[2], &sp3 = gs.sub[3], &sa0 = gs.sub[4], &sa1 = gs.sub[5];
+  sp0 = sp1 = sp2 = sp3 = sa0 = sa1 = 0;
+#else
   uint32_t sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, sa0 = 0, sa1 = 0;  // substituted positions (16 bit) / letters (8 bit)
+#endif
   int flen = 0, j = 0, i = 0, last_qi = 0;
   P lo = 0, hi = 0;
   uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0;
@@ -3085,13 +3112,28 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   bool ev_done = false;
   uint32_t mx = 0, ml_for = 0;
   // variant generation
+#ifdef KJ_G_OCC3
+  uint32_t &vorig = gs.sub[12], &vscore = gs.sub[13], &vlen = gs.sub[14];
+  vorig = vscore = vlen = 0;
+#else
   uint32_t vorig = 0, vscore = 0, vlen = 0;
+#endif
   // locate
   uint32_t cur = 0, nids = 0;
   P row = 0, rowend = 0, k = 0;
+#ifdef KJ_G_OCC3
+  uint64_t id0 = 0;
+  uint32_t sa_idx = 0;                           // (an index below 2^32 rows has fewer samples than that)
+#else
   uint64_t id0 = 0, sa_idx = 0;
+#endif
   bool fresh = true;
+#ifdef KJ_G_OCC3
+#define KJ_G_HIT (b.hits + r)                    /* (recomputed: two registers less than a pointer kept per lane) */
+#else
   Hit *hit = nullptr;
+#define KJ_G_HIT hit
+#endif
   int fill_top = 0, fill_ret = FR_START_J;
   bool fill_pref = false;
 
@@ -3114,6 +3156,14 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   uint64_t dg0 = 0, dg1 = 0;
   for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
   for (int x = 16; x < 32; x++) dg1 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * (x - 16));
+#if defined(KJ_G_OCC3) && defined(__HIP_DEVICE_COMPILE__)
+  // (the same in every lane: scalar registers)
+  dg0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dg0) |
+        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dg0 >> 32)) << 32;
+  dg1 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dg1) |
+        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dg1 >> 32)) << 32;
+  kpow = (uint32_t)__builtin_amdgcn_readfirstlane((int)kpow);
+#endif
 
   auto diag = [&](uint32_t cc) -> uint32_t { return (uint32_t)(((cc & 16u) ? dg1 : dg0) >> (4u * (cc & 15u))) & 15u; };
   auto in_win = [&](int pos) -> bool { return pos >= wq && pos < wq + kWin; };
@@ -3178,16 +3228,27 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       if (row >= rowend) return GB_LOC_NEXT_SI;
       if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; return GB_DONE; }     // :805-807
       if ((k & check) != 0) { kind = G_LF1; return GB_NONE; }
+#ifdef KJ_G_OCC3
+      const uint64_t sa64 = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+      sa_idx = (uint32_t)sa64;
+      if (sa64 < ix.n_sa) { kind = G_SA; return GB_NONE; }
+#else
       sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
       if (sa_idx < ix.n_sa) { kind = G_SA; return GB_NONE; }
+#endif
       row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
     }
   };
   auto add_tax = [&](uint64_t tax) {
     bool dup = false;
+#ifdef KJ_G_OCC3
+    for (uint32_t q = 0; q < nids && !dup; q++) if (KJ_G_HIT->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) KJ_G_HIT->taxid[nids++] = tax;
+#else
     if (nids >= 1 && tax == id0) dup = true;
-    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+    for (uint32_t q = 1; q < nids && !dup; q++) if (KJ_G_HIT->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; KJ_G_HIT->taxid[nids++] = tax; }
+#endif
   };
 
 #if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
@@ -3380,21 +3441,21 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         if (bk == GB_FINISH) {
           KJ_P(PS_FINISH);
           nids = 0;
-          hit->reserved = 0;
+          KJ_G_HIT->reserved = 0;
           if (ovf || m_ovf) {
-            hit->best = 0;
+            KJ_G_HIT->best = 0;
             if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
             else flags = kHitInternalOverflow;
             bk = GB_DONE;
           } else {
-            hit->best = nbest ? best : 0u;
+            KJ_G_HIT->best = nbest ? best : 0u;
             cur = 0;
             bk = GB_LOC_NEXT_SI;
 #ifdef KJ_G_DEFER_LOCATE
             // experiment for round 3: a read that ends with ONE best match leaves it in the hit record for
             // k_mem_locate, as the MEM lanes do (the locate sections of this lane run with one or two lanes active: 7 % of it)
             if (nbest == 1u && (p.flags & kParamDeferLocate)) {
-              hit->taxid[0] = (uint64_t)b0lo | (uint64_t)b0len << 32;
+              KJ_G_HIT->taxid[0] = (uint64_t)b0lo | (uint64_t)b0len << 32;
               nids = 1; flags |= kHitLocPending;
               bk = GB_DONE;
             }
@@ -3413,7 +3474,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           }
         }
         if (bk == GB_DONE) {
-          hit->n_ids = nids; hit->flags = flags;
+          KJ_G_HIT->n_ids = nids; KJ_G_HIT->flags = flags;
           if constexpr (COUNT) oc[kOpcHit]++;
           kind = G_IDLE; bk = GB_NONE;
         }
@@ -3687,7 +3748,9 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           for (uint32_t s = 0; s < (uint32_t)kGSlots; s++) prio[s] = 0;
         for (uint32_t s = kGSlots; s < qn; s++) GS_PRIO_EXT[s - kGSlots] = 0;
         qn = qlive = qseq = 0;
+#ifndef KJ_G_OCC3
         hit = b.hits + r;
+#endif
         if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
       } else if (kind == G_FRAG) {
         KJ_P(PS_FRAG);

@@ -341,6 +341,9 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         const char *ge = getenv("KAIJU_EMU_GATE");
         GreedyScratch2 g2{reinterpret_cast<uint8_t *>(lds_win), reinterpret_cast<uint16_t *>(lds_mq), lds_prio, pool2.data(),
                           prio_ext.data(), matches2.data(), mq_ext.data(), best2.data(), ge ? (uint32_t)atoi(ge) : 3u};
+        uint32_t lds_sub[24];
+        for (auto &x : lds_sub) x = 0xdeadbeefu;
+        g2.sub = lds_sub;
 #ifdef KJ_G_DEFER_LOCATE
         Params pg = p;
         pg.flags |= kParamDeferLocate;
