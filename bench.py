@@ -150,18 +150,32 @@ def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample):
     bl = {"value": s / t_cls, "unit": "reads/s" if not paired else "pairs/s", "cores": cores, "kind": "reference",
           "sample": f"{s} of the benchmark {'pairs' if paired else 'reads'}, kaiju -z {cores} -a {mode}{'' if seg else ' -X'}; "
                     f"wall {t_all:.1f}s minus index load {t_load:.1f}s"}
-    df = pd.read_csv(out, sep="\t", header=None, names=["c", "name", "tax"], dtype={"c": str, "name": str, "tax": np.uint64},
-                     usecols=[0, 1, 2])
+    # parity lines: the same reads once more with -v (column 4 = match length / score of the best match,
+    # ConsumerThread.cpp:724-739 + extraoutput), untimed - the baseline above is the reference's plain run
+    outv = f"{W}/cpu_{tag}_out_v.tsv"
+    basev = [x if x != out else outv for x in base] + ["-v"]
+    subprocess.run(basev + inputs(files), check=True, stderr=subprocess.DEVNULL)
+    df = pd.read_csv(outv, sep="\t", header=None, names=["c", "name", "tax", "best"],
+                     dtype={"c": str, "name": str, "tax": np.uint64, "best": np.float64}, usecols=[0, 1, 2, 3])
     idx = df["name"].str.slice(1).astype(np.int64).to_numpy()
     cls = np.zeros(s, dtype=np.uint8)
     tax = np.zeros(s, dtype=np.uint64)
+    best = np.zeros(s, dtype=np.int64)
     seen = np.zeros(s, dtype=np.uint8)
     cls[idx] = (df["c"].to_numpy() == "C").astype(np.uint8)
     tax[idx] = df["tax"].to_numpy()
+    best[idx] = np.nan_to_num(df["best"].to_numpy(), nan=0.0).astype(np.int64)
     seen[idx] = 1
     if not seen.all():
         raise RuntimeError("the reference printed fewer lines than reads")
-    return bl, (cls, tax)
+    # the plain run's lines must say the same as the -v run's first three columns
+    dp = pd.read_csv(out, sep="\t", header=None, names=["c", "name", "tax"], dtype={"c": str, "name": str, "tax": np.uint64},
+                     usecols=[0, 1, 2])
+    ip = dp["name"].str.slice(1).astype(np.int64).to_numpy()
+    if len(ip) != s or not (np.array_equal(cls[ip], (dp["c"].to_numpy() == "C").astype(np.uint8)) and
+                            np.array_equal(tax[ip], dp["tax"].to_numpy())):
+        raise RuntimeError("the reference's -v run disagrees with its plain run")
+    return bl, (cls, tax, best)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -268,6 +282,9 @@ class Leg:
         torch.cuda.synchronize(self.dev)
         self.excl_kern, self.excl_stage = self.kern_ms, self.stage_ms
         self.kern_ms, self.stage_ms = live
+        # the records the TIMED kernels wrote (the pass above runs exactly the launches of a timed step): the parity leg
+        # reads this snapshot, never what the counting pass below leaves in d_compact
+        self.timed_compact = self.d_compact.clone()
         # accounting: the counting instantiation of the lane on the first chunk (untimed)
         c = self.clfs[0]
         c.count_ops(True)
@@ -275,8 +292,11 @@ class Leg:
         torch.cuda.synchronize(self.dev)
         self.op_counts = c.op_counts()
         c.count_ops(False)
-        # the records of chunk 0 were just rewritten by the counting lane: they must equal the timed lanes' (checked
-        # below through the parity leg, which reads d_compact)
+        # the counting lane is another instantiation of the same source: its records must equal the timed lanes'
+        first = (self.bounds[0][1] - self.bounds[0][0]) * COMPACT_BYTES
+        self.count_equals_timed = bool(torch.equal(self.timed_compact[:first], self.d_compact[:first]))
+        if not self.count_equals_timed:
+            raise SystemExit(f"leg {self.name}: the counting instantiation wrote records that differ from the timed kernels'")
         return self
 
     def result(self, world, ref_ops, traffic, nseq):
@@ -317,7 +337,7 @@ class Leg:
 
     def host_records(self, k):
         """finalised (classified, taxon) of the first k reads from the device's compact records"""
-        rec = np.frombuffer(self.d_compact[: k * COMPACT_BYTES].cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
+        rec = np.frombuffer(self.timed_compact[: k * COMPACT_BYTES].cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
         off = offsets(k, self.L, self.Lm, self.paired)
         res = self.clfs[0].finalize_compact(rec, off, paired=self.paired)
         return res["classified"].astype(np.uint8), res["taxon"].astype(np.uint64), rec
@@ -325,7 +345,7 @@ class Leg:
     def close(self):
         for c in self.clfs:
             c.close()
-        del self.d_seqs, self.d_out, self.d_compact, self.d_offs
+        del self.d_seqs, self.d_out, self.d_compact, self.d_offs, self.timed_compact
 
 
 def host_buffers_leg(index, dtax, reads, Lm, seg, dev, calls=4, chunk=2_500_000, nthreads=2):
@@ -544,10 +564,15 @@ def main():
             out["baseline"] = bl
             if ref is not None:
                 k = len(ref[0])
-                cls, tax, _ = leg.host_records(k)
-                bad = np.nonzero((cls != ref[0]) | (tax != ref[1]))[0]
+                cls, tax, rec = leg.host_records(k)
+                best = rec["best"].astype(np.int64)
+                bad = np.nonzero((cls != ref[0]) | (tax != ref[1]) | ((ref[0] != 0) & (best != ref[2])))[0]
                 out["parity"] = {"checked": int(k), "mismatches": int(len(bad)), "first_mismatches": [int(x) for x in bad[:5]],
-                                 "against": "output lines (C/U, taxon) of the unmodified reference binary on the same reads"}
+                                 "records": "timed launch (snapshot of the records written by the same kernels as the timed steps, "
+                                            "taken before the counting pass)",
+                                 "counting_instantiation_equals_timed": bool(leg.count_equals_timed),
+                                 "against": "output lines of the unmodified reference binary (kaiju -v) on the same reads: C/U, "
+                                            "taxon id and, for classified reads, column 4 (match length in MEM, score in Greedy)"}
         except Exception as e:  # noqa: BLE001
             log(rank, f"cpu baseline / parity ({leg.name}) failed:", repr(e))
         return out

@@ -105,3 +105,32 @@ def test_kaijux(gpu_lib, golden, tmp_path):
             subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
             ref = os.path.join(golden.dir, f"refx_{mode}{'_pe' if pe else ''}{'_v' if v else ''}.tsv")
             assert open(out).read() == open(ref).read(), (mode, pe, v)
+
+
+def test_cli_exit_status_of_a_capacity_error(gpu_lib, golden, tmp_path):
+    """a batch in which a device-side capacity bound was exceeded ends the program with status 3 (not with an abort:
+    the index loader thread is joined before that return), status 0 under KAIJU_GPU_ALLOW_INEXACT"""
+    cmd = [build.build_cli(), "-t", golden.nodes, "-f", golden.fmi, "-o", str(tmp_path / "x.tsv"), "-i",
+           os.path.join(golden.dir, "reads.fq"), "-a", "mem"]
+    env = dict(os.environ, KAIJU_GPU_TEST_INEXACT="1")
+    r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 3 and b"capacity bound" in r.stderr
+    r = subprocess.run(cmd, env=dict(env, KAIJU_GPU_ALLOW_INEXACT="1"), stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"Warning" in r.stderr
+    want = [r3[:3] for r3 in first5(os.path.join(golden.dir, "ref_mem_1.tsv"))]
+    assert [tuple(l.rstrip("\n").split("\t")) for l in open(tmp_path / "x.tsv")] == want
+
+
+def test_cli_closed_output_pipe_is_a_failure(gpu_lib, golden, tmp_path):
+    """`kaiju ... | head -1`: the write error ends the program with a non-zero status (the reference dies of SIGPIPE)"""
+    big = str(tmp_path / "big.fq")
+    with open(os.path.join(golden.dir, "reads.fq"), "rb") as f:
+        one = f.read()
+    with open(big, "wb") as f:
+        for _ in range(400):                       # ~ 280 000 reads: more output than a pipe buffer holds
+            f.write(one)
+    cmd = [build.build_cli(), "-t", golden.nodes, "-f", golden.fmi, "-i", big, "-a", "mem"]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    p.stdout.readline()
+    p.stdout.close()
+    assert p.wait(timeout=120) != 0
