@@ -487,104 +487,6 @@ k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Seg
   greedy_lane2<true>(ix, s_ct, p, sq, b, wl, gs);
 }
 
-// third-generation Greedy (kj_core.h: g3_book / g3_search / g3_locate): rounds of a bookkeeping kernel (one lane per read
-// still at work) and a search kernel (persistent lanes over the round's task list), the locate walks once at the end
-constexpr int kG3BookLds = kG3M + 4 + kG3TaskBuf;            // per lane: match lengths, task codes
-template <bool COUNT>
-__device__ __forceinline__ void g3_book_body(const DevIndex &ix, const ConstTables *__restrict__ g_ct, const Params &p,
-                                             const SegQueue &sq, const Batch &b, const G3Arrays &g, const WorkList &wl,
-                                             const uint32_t *list, const uint32_t *count_ptr, uint32_t count_fixed) {
-  __shared__ ConstTables s_ct;
-  __shared__ __attribute__((aligned(4))) uint8_t s_lane[kBlock * kG3BookLds];
-  const uint32_t n = count_ptr ? *count_ptr : count_fixed;
-  if (blockIdx.x * kBlock >= n) return;                      // (rounds behind the last one with work cost a launch, no more)
-  load_tables(s_ct, g_ct);
-  uint8_t *qls = s_lane + threadIdx.x * kG3BookLds, *tb = qls + kG3M + 4;
-  uint32_t oc[kOpcN];
-  if (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
-  // (all lanes of a wavefront take the same number of turns: the appends below are collective)
-  for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-    const uint32_t i = base + threadIdx.x;
-    const bool active = i < n;
-    uint32_t r = 0;
-    G3Out o; o.ntasks = 0; o.again = false; o.locate = false; o.pepoff = 0;
-    if (active) {
-      r = list ? list[i] : i;
-      o = g3_book<COUNT>(ix, s_ct, p, sq, b, g, wl, r, qls, tb, COUNT ? oc : nullptr);
-    }
-    // tasks: one atomic per wavefront
-    uint32_t pre = o.ntasks;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)pre, d, 64); if ((threadIdx.x & 63u) >= (uint32_t)d) pre += v; }
-    const uint32_t total = (uint32_t)__shfl((int)pre, 63, 64);
-    if (total) {
-      uint32_t at = 0;
-      if ((threadIdx.x & 63u) == 63u) at = atomicAdd(g.task_count, total);
-      at = (uint32_t)__shfl((int)at, 63, 64) + pre - o.ntasks;
-      for (uint32_t k = 0; k < o.ntasks; k++) {
-        G3Task t; t.read = r; t.code = tb[k] == kG3BufSeed ? kG3Seed : (uint32_t)tb[k]; t.pepoff = o.pepoff;
-        g.tasks[at + k] = t;
-      }
-    }
-    const uint64_t ma = __ballot(o.again), ml = __ballot(o.locate);
-    if (ma) {
-      uint32_t at = 0;
-      const uint32_t leader = (uint32_t)__builtin_ctzll(ma);
-      if ((threadIdx.x & 63u) == leader) at = atomicAdd(g.next_count, (uint32_t)__popcll(ma));
-      at = (uint32_t)__shfl((int)at, (int)leader, 64);
-      if (o.again) g.next[at + kj_rank_below(ma)] = r;
-    }
-    if (ml) {
-      uint32_t at = 0;
-      const uint32_t leader = (uint32_t)__builtin_ctzll(ml);
-      if ((threadIdx.x & 63u) == leader) at = atomicAdd(g.locate_count, (uint32_t)__popcll(ml));
-      at = (uint32_t)__shfl((int)at, (int)leader, 64);
-      if (o.locate) g.locate[at + kj_rank_below(ml)] = r;
-    }
-  }
-  if (COUNT) opc_flush(g.opc, oc);
-}
-__global__ void __launch_bounds__(kBlock)
-k_g3_book(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, G3Arrays g, WorkList wl,
-          const uint32_t *list, const uint32_t *count_ptr, uint32_t count_fixed) {
-  g3_book_body<false>(ix, g_ct, p, sq, b, g, wl, list, count_ptr, count_fixed);
-}
-__global__ void __launch_bounds__(kBlock, 5)
-k_g3_search(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Batch b, G3Arrays g, uint32_t *counter,
-            const uint32_t *n_tasks) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
-  if (blockIdx.x * (kBlock / 64) * 8 >= *n_tasks) return;    // (fewer tasks than the blocks in front of this one take: nothing to do)
-  g3_search(ix, *g_ct, p, b, g, counter, n_tasks, s_win + threadIdx.x * kWinStride);
-}
-__global__ void __launch_bounds__(kBlock)
-k_g3_locate(DevIndex ix, Params p, Batch b, G3Arrays g, uint32_t *counter) { g3_locate(ix, p, b, g, counter); }
-// counting instantiations (kaiju_gpu_set_count_ops)
-__global__ void __launch_bounds__(kBlock)
-k_g3_book_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, G3Arrays g, WorkList wl,
-                const uint32_t *list, const uint32_t *count_ptr, uint32_t count_fixed) {
-  g3_book_body<true>(ix, g_ct, p, sq, b, g, wl, list, count_ptr, count_fixed);
-}
-__global__ void __launch_bounds__(kBlock, 2)
-k_g3_search_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Batch b, G3Arrays g, uint32_t *counter,
-                  const uint32_t *n_tasks) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
-  g3_search<true>(ix, *g_ct, p, b, g, counter, n_tasks, s_win + threadIdx.x * kWinStride);
-}
-__global__ void __launch_bounds__(kBlock)
-k_g3_locate_count(DevIndex ix, Params p, Batch b, G3Arrays g, uint32_t *counter) { g3_locate<true>(ix, p, b, g, counter); }
-// reads still at work after the last round: retry pass
-__global__ void __launch_bounds__(kBlock)
-k_g3_flush(Batch b, WorkList wl, const uint32_t *list, const uint32_t *count_ptr) {
-  const uint32_t n = *count_ptr;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint32_t r = list[i];
-    Hit *h = b.hits + r;
-    h->best = 0; h->n_ids = 0; h->reserved = 0;
-    if (wl.retry_list) { wl.retry_list[atomicAdd(wl.retry_count, 1u)] = r; h->flags = kHitRetry; }
-    else h->flags = kHitInternalOverflow;
-  }
-}
-
 // Index load: the k-mer table one letter deeper.  child[idx * 20 + c - 1] = UpdateSI(parent[idx], c)
 // (bwt.c:160-173) for all 20 letters from the two rank blocks at the ends of the parent's interval;
 // empty intervals stay {0, 0}.  One thread per parent, 160 contiguous bytes of children each.
@@ -616,6 +518,15 @@ k_kmer_extend(const RankBlock64 *__restrict__ blk, const uint2 *__restrict__ par
 #pragma unroll
     for (int x = 0; x < 10; x++) dst[x] = make_uint4(out[4 * x], out[4 * x + 1], out[4 * x + 2], out[4 * x + 3]);
   }
+}
+
+// Index load, narrow indexes: the k-mer LINES of the table just grown (kj_core.h: DevIndex::kline, kline_build_one): one
+// thread per line - twenty entries gathered with a stride of 20^(k-1) (coalesced over the threads), twenty consecutive ones
+// for the presence bits, the BWT letter of every one-row interval from its rank block.
+__global__ void __launch_bounds__(256)
+k_kline_build(DevIndex ix, uint32_t k, uint64_t n_lines, uint8_t *__restrict__ lines) {
+  for (uint64_t code = (uint64_t)blockIdx.x * 256 + threadIdx.x; code < n_lines; code += (uint64_t)gridDim.x * 256)
+    kline_build_one(ix, k, code, lines + code * kKLineBytes);
 }
 
 // the same for indexes with 64-bit positions: 16-byte entries {lo, len}, counts relative to mb_base
@@ -825,7 +736,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   ix->d_ct = const_cast<ConstTables *>(dct);
   for (int a = 0; a < 22; a++) d.C[a] = pk.C[a];
   d.bwtlen = pk.bwtlen; d.n_sa = pk.n_sa; d.sa_skip = pk.sa_skip; d.nseq = pk.nseq; d.chpt_exp = pk.chpt_exp;
-  d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k;
+  d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k; d.kline = nullptr;
   lc.mark("upload of the packed arrays");
   uint64_t kmer_bytes = 0;
   if (pk.kmer_k) {
@@ -857,6 +768,22 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
       }
       d.kmer32 = cur;
       kmer_bytes = np * sizeof(uint2) - pk.kmer32.size() * sizeof(uint2);
+    }
+    d.kline = nullptr;
+    if (d.kmer32 && d.blocks64 && !d.mb_base && d.kmer_k >= 2) {
+      // the k-mer lines the second-generation lanes read (128 bytes per (k-1)-letter word; k = 7: 8.2 GB)
+      uint64_t nl = 1;
+      for (uint32_t q = 1; q < d.kmer_k; q++) nl *= 20;
+      void *lines = nullptr;
+      if (hipMalloc(&lines, nl * kKLineBytes + 256) == hipSuccess) {
+        ix->allocs.push_back(lines);
+        const uint64_t blocks = std::min<uint64_t>((nl + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(k_kline_build, dim3((unsigned)blocks), dim3(256), 0, 0, d, d.kmer_k, nl, static_cast<uint8_t *>(lines));
+        KJ_HIP(hipGetLastError());
+        KJ_HIP(hipDeviceSynchronize());
+        d.kline = static_cast<const uint8_t *>(lines);
+        kmer_bytes += nl * kKLineBytes;
+      } else (void)hipGetLastError();      // (no room: the lanes of the first generation serve, with the table)
     }
     if (d.kmer64 && d.blocks64 && d.mb_base && want > d.kmer_k) {
       uint64_t np = 1;
@@ -1001,10 +928,6 @@ struct kaiju_gpu_ctx {
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
   bool defer_locate = true;        // KAIJU_GPU_MEM_LOCATE=inline: the MEM search lanes walk to the ids themselves
-  bool greedy3 = false;            // KAIJU_GPU_GREEDY_LANE=v3: the two-kernel rounds of the third generation (experimental: parity-green,
-                                   // 1.8x slower than the second generation as measured in round 2)
-  uint32_t g3_rounds = 128;        // KAIJU_GPU_G3_ROUNDS: rounds launched per batch (reads still at work then: retry pass)
-  DevBuf g3[10];                   // state, priorities, items, matches, best lists, tasks, two read lists, counters, locate list
   DevBuf seglist;
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
@@ -1022,7 +945,6 @@ struct kaiju_gpu_ctx {
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 10; i++) if (scratch_main[i].p) (void)hipFree(scratch_main[i].p);
     for (int i = 0; i < 5; i++) if (scratch_retry[i].p) (void)hipFree(scratch_retry[i].p);
-    for (int i = 0; i < 10; i++) if (g3[i].p) (void)hipFree(g3[i].p);
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1088,10 +1010,9 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   int occ = 0;
   if (p->mode == 0) KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mem, kBlock, 0));
   else {
-    c->greedy2 = ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p->seed_length &&
+    c->greedy2 = ix->dev.blocks64 && ix->dev.kline && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p->seed_length &&
                  p->seed_length >= 3;
-    if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; c->greedy3 = !strcmp(e, "v3"); }
-    if (const char *e = getenv("KAIJU_GPU_G3_ROUNDS")) { int v = atoi(e); if (v >= 1 && v <= 4096) c->g3_rounds = (uint32_t)v; }
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; }
     if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (c->greedy_gate & ~0xffu) | (uint32_t)v; }
     // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
     if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate = (c->greedy_gate & 0xffu) | (uint32_t)v << 8; }
@@ -1164,7 +1085,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
   // which stage 1 / SEG flow: the fast stage 1 serves mates up to kS1MaxLen nucleotides; in MEM mode on the second-generation
   // lanes SEG is then looked at lazily (kj_core.h: kParamLazySeg), everywhere else stage 1 detects the SEG trigger itself
-  const bool mem_narrow2 = ix->dev.blocks64 && ix->dev.kmer32 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
+  const bool mem_narrow2 = ix->dev.blocks64 && ix->dev.kline && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
   const bool mem_wide2 = ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
   const bool mem_v2 = p.mode == 0 && (mem_narrow2 || mem_wide2) && !c->mem_v1 && !c->verbose;
   const bool fast1 = !protein && !c->stage1_old && max_read_len <= kS1MaxLen && p.m >= 1 && p.m <= 64;
@@ -1321,9 +1242,6 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     GreedyArrays ga;
     ga.pool_cap = 192; ga.match_cap = 64;
     const bool use_g2 = c->greedy2 && !c->verbose;
-    // third generation: narrow index with a k-mer table (as the second), fragments of at most kWin residues (the strings of
-    // the fast stage 1), no verbose output
-    const bool use_g3 = use_g2 && c->greedy3 && fast1;
     if (!use_g2) {
       if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
       if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
@@ -1354,7 +1272,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       gr.bestv = static_cast<GBestV *>(c->vb_bestv_retry.p);
     }
     GreedyArrays2 g2{};
-    if (use_g2 && !use_g3) {
+    if (use_g2) {
       if ((rc = ensure(c->scratch_main[5], (lanes_main * (8 * kGSlotsAll) + 4) * sizeof(u128)))) return rc;
       if ((rc = ensure(c->scratch_main[6], lanes_main * (kGSlotsAll - kGSlots) * sizeof(uint32_t)))) return rc;
       if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
@@ -1365,56 +1283,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       g2.best = static_cast<GBest2 *>(c->scratch_main[9].p);
       g2.gate = c->greedy_gate;
     }
-    if (n > 0 && use_g3) {
-      const uint32_t R = c->g3_rounds;
-      const uint32_t task_cap = (uint32_t)std::min<uint64_t>((uint64_t)kG3TaskBuf * n + 64, 0xffffff00ull);   // (what the reads can ask for in a round)
-      if ((rc = ensure(c->g3[0], (size_t)n * sizeof(G3State)))) return rc;
-      if ((rc = ensure(c->g3[1], (size_t)n * kG3Q * sizeof(uint32_t)))) return rc;
-      if ((rc = ensure(c->g3[2], (size_t)n * kG3Q * sizeof(G3Item)))) return rc;
-      if ((rc = ensure(c->g3[3], (size_t)n * kG3M * sizeof(GMatch2)))) return rc;
-      if ((rc = ensure(c->g3[4], (size_t)n * 64 * sizeof(GBest2)))) return rc;
-      if ((rc = ensure(c->g3[5], (size_t)task_cap * sizeof(G3Task)))) return rc;
-      if ((rc = ensure(c->g3[6], (size_t)n * 4 + 16))) return rc;
-      if ((rc = ensure(c->g3[7], (size_t)n * 4 + 16))) return rc;
-      if ((rc = ensure(c->g3[8], (size_t)R * 16 + 32))) return rc;
-      if ((rc = ensure(c->g3[9], (size_t)n * 4 + 16))) return rc;
-      KJ_HIP(hipMemsetAsync(c->g3[0].p, 0, (size_t)n * sizeof(G3State), s));      // phase G3_NEW
-      KJ_HIP(hipMemsetAsync(c->g3[8].p, 0, (size_t)R * 16 + 32, s));
-      uint32_t *C4 = static_cast<uint32_t *>(c->g3[8].p);                           // per round: tasks, reads of the next round, work counter
-      uint32_t *lists[2] = {static_cast<uint32_t *>(c->g3[6].p), static_cast<uint32_t *>(c->g3[7].p)};
-      G3Arrays g;
-      g.st = static_cast<G3State *>(c->g3[0].p); g.prio = static_cast<uint32_t *>(c->g3[1].p);
-      g.items = static_cast<G3Item *>(c->g3[2].p); g.matches = static_cast<GMatch2 *>(c->g3[3].p);
-      g.best = static_cast<GBest2 *>(c->g3[4].p); g.tasks = static_cast<G3Task *>(c->g3[5].p); g.task_cap = task_cap;
-      g.locate = static_cast<uint32_t *>(c->g3[9].p); g.locate_count = C4 + 4 * R;      // (behind the rounds' counters; + 1: its work counter)
-      const uint32_t book_blocks = (uint32_t)std::min<uint64_t>(((uint64_t)n + kBlock - 1) / kBlock, (uint64_t)c->n_cu * 32);
-      int occ3 = 5;
-      g.opc = reinterpret_cast<unsigned long long *>(reinterpret_cast<uint8_t *>(cnt) + kOpcOffsetBytes);
-      for (uint32_t k = 0; k < R; k++) {
-        g.task_count = C4 + 4 * k; g.next = lists[(k + 1) & 1]; g.next_count = C4 + 4 * k + 1;
-        const uint32_t *lst = k == 0 ? nullptr : lists[k & 1], *lcnt = k == 0 ? nullptr : C4 + 4 * (k - 1) + 1;
-        if (c->count_ops) {
-          hipLaunchKernelGGL(k_g3_book_count, dim3(book_blocks), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, g, wl_main, lst, lcnt, n);
-          hipLaunchKernelGGL(k_g3_search_count, dim3(c->n_cu * 2), blk, 0, s, ix->dev, ix->d_ct, p, b, g, C4 + 4 * k + 2, C4 + 4 * k);
-        } else {
-          hipLaunchKernelGGL(k_g3_book, dim3(book_blocks), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, g, wl_main, lst, lcnt, n);
-          hipLaunchKernelGGL(k_g3_search, dim3(c->n_cu * occ3), blk, 0, s, ix->dev, ix->d_ct, p, b, g, C4 + 4 * k + 2, C4 + 4 * k);
-        }
-      }
-      hipLaunchKernelGGL(k_g3_flush, dim3(c->n_cu), blk, 0, s, b, wl_main, lists[R & 1], C4 + 4 * (R - 1) + 1);
-      if (c->count_ops) hipLaunchKernelGGL(k_g3_locate_count, dim3(c->n_cu * 4), blk, 0, s, ix->dev, p, b, g, C4 + 4 * R + 1);
-      else hipLaunchKernelGGL(k_g3_locate, dim3(c->n_cu * 4), blk, 0, s, ix->dev, p, b, g, C4 + 4 * R + 1);
-      KJ_HIP(hipGetLastError());
-      KJ_HIP(hipEventRecord(c->ev[3], s));
-      hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
-      KJ_HIP(hipGetLastError());
-      if (exact_pass) {
-        xp.g_pool = gr.pool; xp.g_ord = gr.ord; xp.g_matches = gr.matches; xp.g_best = gr.best; xp.g_bestv = gr.bestv;
-        xp.g_pool_cap = gr.pool_cap; xp.g_match_cap = gr.match_cap; xp.blocks_search = c->blocks_retry;
-        xp.vb = vb;
-        KJ_HIP(kj_launch_exact_pass(xp));
-      }
-    } else if (n > 0) {
+    if (n > 0) {
       Params pg = p;
 #ifdef KJ_G_DEFER_LOCATE
       if (use_g2 && c->defer_locate) pg.flags |= kParamDeferLocate;       // (experiment: reads with one best match -> k_mem_locate)

@@ -361,7 +361,7 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
 }
 
 void PackedIndex::build_kmer_table(uint32_t k) {
-  kmer32.clear(); kmer64.clear(); kmer_k = 0;
+  kmer32.clear(); kmer64.clear(); kmer_k = 0; kline.clear();
   if (k < 2 || k > 6 || alen != 21) return;
   uint64_t n = 1;
   for (uint32_t q = 0; q < k; q++) n *= 20;
@@ -392,6 +392,19 @@ void PackedIndex::build_kmer_table(uint32_t k) {
     Rec::go(d, *this, small, k, 2, (uint64_t)(c0 - 1) * 20 + (c1 - 1), nlo, nhi);
   });
   kmer_k = k;
+}
+
+// the k-mer lines of the host's table (tests/emu; the device runs the same kline_build_one over the table it has grown)
+void PackedIndex::build_klines() {
+  kline.clear();
+  if (!kmer_k || kmer32.empty() || blocks64.empty()) return;
+  const uint64_t nlines = kmer32.size() / 20;
+  kline.assign((size_t)nlines * kKLineBytes, 0);
+  const DevIndex d = host_view();
+  parallel_for((nlines + 4095) / 4096, [&](uint64_t chunk) {
+    const uint64_t b = chunk * 4096, e = std::min<uint64_t>(nlines, b + 4096);
+    for (uint64_t code = b; code < e; code++) kline_build_one(d, kmer_k, code, kline.data() + (size_t)code * kKLineBytes);
+  });
 }
 
 void PackedIndex::to_sequence_ids() {
@@ -531,6 +544,7 @@ DevIndex PackedIndex::host_view() const {
   d.kmer32 = kmer32.empty() ? nullptr : kmer32.data();
   d.kmer64 = kmer64.empty() ? nullptr : kmer64.data();
   d.kmer_k = kmer_k;
+  d.kline = kline.empty() ? nullptr : kline.data();
   return d;
 }
 

@@ -85,8 +85,11 @@ struct PackedIndex {
   BigVec<uint2> kmer32;        // k-mer table (see DevIndex), one of the two is filled
   BigVec<ulonglong2> kmer64;
   uint32_t kmer_k = 0;
+  BigVec<uint8_t> kline;       // k-mer lines of the host's table (DevIndex::kline; narrow indexes).  For the test emulation only:
+                               // the device builds its own from the table it has grown (capi.hip), an image does not hold them
   // builds the k-mer table with k letters (0 = none); needs blocks/sb/C
   void build_kmer_table(uint32_t k);
+  void build_klines();              // fills kline from kmer32 (call after build_kmer_table / read_image)
   uint64_t C[22] = {0};
   uint64_t bwtlen = 0, n_sa = 0, sa_skip = 0;
   uint32_t nseq = 0, chpt_exp = 0, alen = 0;

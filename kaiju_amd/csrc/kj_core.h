@@ -94,7 +94,63 @@ struct DevIndex {
   const uint2 *kmer32;       // {lo, len} when bwtlen < 2^32
   const ulonglong2 *kmer64;  // {lo, len} otherwise
   uint32_t kmer_k;           // 0 = no table
+  // k-mer LINES (narrow indexes, second-generation lanes): the same table transposed and packed so that ONE 128-byte line
+  // serves TWO consecutive end positions of a search.  Line number = the (k-1)-letter word M = w[j-k+1 .. j-1]; it holds
+  // the suffix interval of M.a for all twenty letters a (a = w[j]: the k-mer that ends at j, 6 bytes each, KLine below) and
+  // one bit per letter b saying whether b.M occurs at all (b = w[j-k]: the k-mer that ends at j-1).  Three of four k-mers
+  // of a read are not in the index: their lookups cost no line of their own any more.
+  const uint8_t *kline;      // [20^(kmer_k-1)] lines of 128 bytes; nullptr = none
 };
+
+// ---- k-mer lines ----------------------------------------------------------------------------------------------------------
+// bytes 0..119: twenty entries {lo: 32 bit, len16: 16 bit} for a = 1..20; bytes 120..123: bit b-1 set = the word b.M has a
+// non-empty interval.  len16: 0 = empty; 1..kKLineMaxLen = the interval's length; kKLineSingle | c = ONE row whose BWT
+// letter is c (0 = terminator): the UpdateSI behind the lookup fails unless the next letter of the read is c - decided
+// without fetching the rank line; kKLineEscape = longer than 16 bits say (the lane starts that search with InitialSI).
+constexpr uint32_t kKLineBytes = 128, kKLinePresent = 120;
+#ifdef KJ_G_SMALL                                  // tests: intervals of more than two rows take the escape path
+constexpr uint32_t kKLineMaxLen = 2u;
+#else
+constexpr uint32_t kKLineMaxLen = 0xffbfu;
+#endif
+constexpr uint32_t kKLineSingle = 0xffc0u, kKLineEscape = 0xffffu;
+// line number of the word M whose letters are handed over from w[j-1] down to w[j-k+1]
+KJ_HD uint32_t kline_code(uint32_t code, uint32_t c) { return code * 20u + (c - 1u); }
+// what the lane keeps per lookup: line number << 6 | offset of the 16 bytes it loads for entry a, in units of 2 bytes
+// (entry a sits at byte 6 (a-1); the load of the last one starts two bytes early so that it stays inside the line)
+KJ_HD uint32_t kline_ref(uint32_t code, uint32_t a) { const uint32_t o = 3u * (a - 1u); return code << 6 | (o > 56u ? 56u : o); }
+KJ_HD uint64_t kline_entry(const u128 &v, uint32_t ref) {          // the 48 bits of the entry from the 16 bytes loaded
+  return ((ref & 63u) == 56u ? (v.x >> 16 | v.y << 48) : v.x) & 0xffffffffffffull;
+}
+// builds line `code` of a table of k-letter words from the word table kmer32 (index: letter matched first = most
+// significant digit) and the BWT letters in blocks64
+KJ_HD void kline_build_one(const DevIndex &ix, uint32_t k, uint64_t code, uint8_t *line) {
+  uint64_t pw = 1;
+  for (uint32_t q = 1; q < k; q++) pw *= 20u;              // 20^(k-1): digit of the letter matched first
+  uint32_t out[32];
+  for (int x = 0; x < 32; x++) out[x] = 0;
+  uint16_t *o16 = reinterpret_cast<uint16_t *>(out);
+  for (uint32_t a = 1; a <= 20u; a++) {
+    const uint2 e = ix.kmer32[code + (uint64_t)(a - 1u) * pw];
+    uint32_t l16 = 0;
+    if (e.y != 0) {
+      if (e.y == 1u) {
+        const RankBlock64 &rb = ix.blocks64[e.x >> 6];
+        const uint32_t s = e.x & 63u;
+        const uint32_t c = (uint32_t)((rb.plane[0] >> s) & 1ull) | (uint32_t)((rb.plane[1] >> s) & 1ull) << 1 |
+                           (uint32_t)((rb.plane[2] >> s) & 1ull) << 2 | (uint32_t)((rb.plane[3] >> s) & 1ull) << 3 |
+                           (uint32_t)((rb.plane[4] >> s) & 1ull) << 4;
+        l16 = kKLineSingle | c;
+      } else l16 = e.y <= kKLineMaxLen ? e.y : kKLineEscape;
+    }
+    o16[3 * (a - 1u)] = (uint16_t)e.x; o16[3 * (a - 1u) + 1] = (uint16_t)(e.x >> 16); o16[3 * (a - 1u) + 2] = (uint16_t)l16;
+  }
+  uint32_t pres = 0;
+  for (uint32_t b = 1; b <= 20u; b++) if (ix.kmer32[code * 20u + (b - 1u)].y != 0) pres |= 1u << (b - 1u);
+  out[kKLinePresent / 4] = pres;
+  uint32_t *dst = reinterpret_cast<uint32_t *>(line);
+  for (int x = 0; x < 32; x++) dst[x] = out[x];
+}
 
 struct Params {
   int32_t mode;              // 0 MEM, 1 GREEDY
@@ -1968,10 +2024,12 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   LaneWin lw{ls.win, 0};
   const P check = (P)((1ull << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
-  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m && (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kmer32)) ? ix.kmer_k : 0;
+  // the narrow lane looks k-mers up in the k-mer LINES (DevIndex::kline), the wide one in the table of 16-byte entries
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m && (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kline)) ? ix.kmer_k : 0;
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0;                 // the wave's chunk of work items (wave-uniform)
   const RankBlock64 *const blk0 = ix.blocks64;
+  bool skipj = false;                           // narrow: the k-mer that ends at the NEXT end position (j - 1) is not in the index
 
   auto si_lo = [&](uint32_t e) -> P { return e == 0 ? s0lo : e == 1 ? s1lo : (P)ls.si[e].lo; };
   auto si_len = [&](uint32_t e) -> uint32_t { return e == 0 ? s0len : e == 1 ? s1len : ls.si[e].len; };
@@ -2058,20 +2116,26 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
     const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
     const uint64_t b4 = pb->plane[4];
-    const uint32_t cb = pb->cnt[cc - 1];
+    // (narrow K_KMER: the second block is not needed - this load fetches the presence bits of the k-mer line instead)
+    const bool kline_step = !WIDE && kind == K_KMER;
+    const uint32_t *cbp = &pb->cnt[cc - 1];
+    if (kline_step) cbp = reinterpret_cast<const uint32_t *>(ix.kline + (size_t)(kidx >> 6) * kKLineBytes + kKLinePresent);
+    const uint32_t cb = *cbp;
     uint64_t mba = 0, mbb = 0;                             // WIDE: counts at the start of the 2^mb_shift rows
     if (WIDE) {
       mba = ix.mb_base[(size_t)((uint64_t)posA >> ix.mb_shift) * 20 + (cc - 1)];
       mbb = ix.mb_base[(size_t)((uint64_t)posB >> ix.mb_shift) * 20 + (cc - 1)];
     }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == K_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
+    if (kind == K_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
     else if (kind == K_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == K_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == K_FILL && fill_newfrag && f < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + f);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
-    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    // 16 bytes: aligned around an 8- or 16-byte item, or (k-mer line) starting at the 2-byte aligned entry
+    const u128 gv = *reinterpret_cast<const u128_unaligned *>(kline_step ? reinterpret_cast<uintptr_t>(gaddr)
+                                                                          : reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
     u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
     int fq = 0;
     if (kj_ballot(kind == K_FILL)) {                       // wave-uniform
@@ -2110,13 +2174,37 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     } else if (kind == K_KMER) {
       KJ_PM(PM_KMER);
       // InitialSI + (kk-1) UpdateSI in one lookup
-      if (WIDE) { lo = (P)gv.x; hi = (P)(gv.x + gv.y); }
-      else { const uint64_t e = ghalf ? gv.y : gv.x; lo = (P)e; hi = (P)((uint32_t)e + (uint32_t)(e >> 32)); }
-      if (lo >= hi) { i = j; bk = BK_END_MATCH; }          // match shorter than kk: never recorded, i > 1
+      uint32_t hint = 32u;                                 // narrow: the BWT letter of a one-row interval (32 = unknown)
+      bool escape = false;
+      if constexpr (WIDE) { lo = (P)gv.x; hi = (P)(gv.x + gv.y); }
+      else {
+        const uint64_t e = kline_entry(gv, kidx);
+        const uint32_t l16 = (uint32_t)(e >> 32);
+        lo = (P)(uint32_t)e;
+        if (l16 >= kKLineSingle) {
+          if (l16 == kKLineEscape) escape = true;
+          else { hi = lo + 1; hint = l16 & 31u; }
+        } else hi = lo + (P)l16;
+        // the k-mer that ends at j - 1 = w[j-kk] in front of the line's word: absent -> that end position is skipped
+        // without a lookup (what the lookup would have led to: an empty interval, a "match" of one letter)
+        skipj = j >= (int)kk && in_win(j - (int)kk) && ((cb >> ((uint32_t)lw.w[j - (int)kk - lw.q] - 1u)) & 1u) == 0u;
+      }
+      if (escape) {
+        // an interval longer than the line's 16 bits can say: this search starts with InitialSI (bwt.c:146-152)
+        c = lw.w[j - lw.q];
+        lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];
+        i = j;                                             // (j >= kk - 1 >= 1)
+        if (in_win(i - 1)) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
+        else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
+      } else if (lo >= hi) { i = j; bk = BK_END_MATCH; }   // match shorter than kk: never recorded, i > 1
       else {
         i = j - (int)kk + 1;
         if (i == 0) bk = BK_END_MATCH;
-        else if (in_win(i - 1)) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
+        else if (in_win(i - 1)) {
+          c = lw.w[i - 1 - lw.q];
+          // one row whose BWT letter is not c: UpdateSI(c) finds nothing (bwt.c:160-173) - the match ends here
+          if (hint != 32u && hint != c) bk = BK_END_MATCH; else kind = K_STEP;
+        }
         else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
       }
     } else if (kind == K_LF1) {
@@ -2212,6 +2300,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         KJ_PM(PM_START_J);
         // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356)
         if (j < (int)L - 1) bk = BK_NEXT_FRAG;
+        else if (!WIDE && skipj) {
+          // the k-mer that ends here is not in the index (the line of end position j + 1 said so): as for an empty table
+          // entry - i = j, nothing recorded, `if (i <= 1) break` (bwt.c:376), --j
+          skipj = false;
+          if (j <= 1) bk = BK_NEXT_FRAG; else j--;
+          continue;
+        }
         else if (kk && j >= (int)kk - 1) {
           if (in_win(j) && in_win(j - (int)kk + 1)) {
             // (a rolling update of the index from end position j+1 was tried: it costs a register too many here)
@@ -2219,9 +2314,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
             if (roll_ok) kidx = (kidx - (roll_cj - 1u) * roll_pow) * 20u + ((uint32_t)lw.w[j - (int)kk + 1 - lw.q] - 1u);
             else
 #endif
-            {
+            if constexpr (WIDE) {
               kidx = 0;
               for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
+            } else {
+              kidx = 0;
+              for (uint32_t q = 1; q < kk; q++) kidx = kline_code(kidx, lw.w[j - (int)q - lw.q]);
+              kidx = kline_ref(kidx, lw.w[j - lw.q]);
             }
 #ifdef KJ_MEM_ROLL
             roll_cj = lw.w[j - lw.q]; roll_ok = true;
@@ -2247,6 +2346,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (f >= nf || (found && dnext.key < L)) bk = BK_LOC_INIT;
         else {
           fcur = f; f++;
+          skipj = false;
 #ifdef KJ_MEM_ROLL
           roll_ok = false;
 #endif
@@ -3143,15 +3243,17 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   int wq = 0;                                   // fragment position of win[0]
   const P check = (P)((1u << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
-  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kmer32) ? ix.kmer_k : 0;
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kline) ? ix.kmer_k : 0;
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0, itc = 0;
   const RankBlock64 *const blk0 = ix.blocks64;
-  // the k-mer index (and diagonal sum) of end position j-1 follows from that of j
+  // k-mer lines (DevIndex::kline): kcode = the line of end position j (the word w[j-kk+1 .. j-1]), kidx = line and entry of
+  // the lookup.  The line (and the diagonal sum of the k-mer) of end position j-1 follows from that of j
   uint32_t kpow = 1;
-  for (uint32_t q = 1; q < kk; q++) kpow *= 20u;
-  uint32_t kacc = 0;
-  bool kroll = false;                           // kidx / kacc / cj describe end position j+1 of this search
+  for (uint32_t q = 2; q < kk; q++) kpow *= 20u;            // 20^(kk-2): digit of w[j-1] in the line number
+  uint32_t kacc = 0, kcode = 0;
+  bool kroll = false;                           // kcode / kacc / cj describe end position j+1 of this search
+  bool skipj = false;                           // the k-mer that ends at the next end position (j - 1) is not in the index
   // BLOSUM62 diagonal by index-alphabet code, 4 bits each (values 4..11)
   uint64_t dg0 = 0, dg1 = 0;
   for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
@@ -3432,7 +3534,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                 }
                 continue;                                   // bk stays GB_POP
               }
-              flen = (int)t_len; nm = 0; kroll = false;
+              flen = (int)t_len; nm = 0; kroll = false; skipj = false;
               j = flen - 1; tail = 0;                       // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
               fill_top = j; fill_ret = FR_START_J; fill_pref = true; kind = G_FILL; bk = GB_NONE;
             }
@@ -3549,16 +3651,21 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
     const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
     const uint64_t b4 = pb->plane[4];
-    const uint32_t cb = pb->cnt[cc - 1];
+    // (G_KMER: the second block is not needed - this load fetches the presence bits of the k-mer line instead)
+    const bool kline_step = kind == G_KMER;
+    const uint32_t *cbp = &pb->cnt[cc - 1];
+    if (kline_step) cbp = reinterpret_cast<const uint32_t *>(ix.kline + (size_t)(kidx >> 6) * kKLineBytes + kKLinePresent);
+    const uint32_t cb = *cbp;
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == G_KMER) gaddr = reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
+    if (kind == G_KMER) gaddr = ix.kline + (size_t)kidx * 2u;
     else if (kind == G_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == G_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == G_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == G_FILL && fill_pref && fo < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + fo);
     else if (kind == G_MLOAD) gaddr = reinterpret_cast<const uint8_t *>(GS_MATCHES + mx);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
-    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    const u128 gv = *reinterpret_cast<const u128_unaligned *>(kline_step ? reinterpret_cast<uintptr_t>(gaddr)
+                                                                          : reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
     // ten 16-byte reads from two lane-chosen places: a window (G_FILL), a queued item (G_POPITEM)
     u128 xa0{0, 0}, xa1{0, 0}, xa2{0, 0}, xa3{0, 0}, xa4{0, 0}, xb0{0, 0}, xb1{0, 0}, xb2{0, 0}, xb3{0, 0}, xb4{0, 0};
     int fq = 0;
@@ -3607,13 +3714,32 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       }
     } else if (kind == G_KMER) {
       KJ_P(PS_KMER);
-      const uint64_t e = ghalf ? gv.y : gv.x;
-      lo = (P)e; hi = (P)e + (P)(e >> 32);
-      if (lo >= hi) { i = j; bk = GB_END_MATCH; }          // seed shorter than kk: never recorded, i > 1
+      const uint64_t e = kline_entry(gv, kidx);
+      const uint32_t l16 = (uint32_t)(e >> 32);
+      uint32_t hint = 32u;                                 // the BWT letter of a one-row interval (32 = unknown)
+      lo = (P)(uint32_t)e;
+      if (l16 >= kKLineSingle && l16 != kKLineEscape) { hi = lo + 1u; hint = l16 & 31u; }
+      else hi = lo + l16;
+      // the k-mer that ends at j - 1 = w[j-kk] in front of the line's word: absent -> that end position is passed without a
+      // lookup (GB_START_J)
+      skipj = j >= (int)kk && in_win(j - (int)kk) && ((cb >> ((uint32_t)win[j - (int)kk - wq] - 1u)) & 1u) == 0u;
+      if (l16 == kKLineEscape) {
+        // an interval longer than the line's 16 bits can say: this search starts with InitialSI (bwt.c:146-152)
+        c = cj;
+        lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];
+        acc = diag(c);
+        i = j;                                             // (j >= kk - 1 >= 1)
+        if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; }
+        else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
+      } else if (lo >= hi) { i = j; bk = GB_END_MATCH; }   // seed shorter than kk: never recorded, i > 1
       else {
         i = j - (int)kk + 1;
         if (i == 0) bk = GB_END_MATCH;
-        else if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; }
+        else if (in_win(i - 1)) {
+          c = win[i - 1 - wq];
+          // one row whose BWT letter is not c: UpdateSI(c) finds nothing (bwt.c:160-173) - the seed is the match
+          if (hint != 32u && hint != c) bk = GB_END_MATCH; else kind = G_STEP;
+        }
         else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
       }
     } else if (kind == G_LF1) {
@@ -3780,7 +3906,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           sp0 = (uint32_t)(xa2.x >> 32); sp1 = (uint32_t)xa2.y; sp2 = (uint32_t)(xa2.y >> 32); sp3 = (uint32_t)xa3.x;
           sa0 = (uint32_t)(xa3.x >> 32); sa1 = (uint32_t)xa3.y;
           const uint32_t wtag = (uint32_t)(xa3.y >> 32);
-          flen = (int)t_len; nm = 0; kroll = false;
+          flen = (int)t_len; nm = 0; kroll = false; skipj = false;
           j = flen - 1;
           if (t_nmm == 0) {
             // a SEG piece: maxMatches like an original
@@ -3870,18 +3996,29 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;
         } else if (kk && j >= (int)kk - 1) {
           if (kroll) {
-            const uint32_t cn = win[j - (int)kk + 1 - wq];
-            kidx = (kidx - (cj - 1u) * kpow) * 20u + (cn - 1u);
+            // from end position j + 1 (letter cj, line kcode = w[j-kk+2 .. j]) to j: w[j] leaves the line's word at its
+            // most significant digit, w[j-kk+1] enters at the least significant one
+            const uint32_t cn = win[j - (int)kk + 1 - wq], c1 = win[j - wq];
+            kcode = (kcode - (c1 - 1u) * kpow) * 20u + (cn - 1u);
             kacc = kacc - diag(cj) + diag(cn);
           } else {
-            kidx = 0; kacc = 0;
-            for (uint32_t q = 0; q < kk; q++) {
+            kcode = 0; kacc = diag(win[j - wq]);
+            for (uint32_t q = 1; q < kk; q++) {
               const uint32_t cq = win[j - (int)q - wq];
-              kidx = kmer_index(kidx, cq);
+              kcode = kline_code(kcode, cq);
               kacc += diag(cq);
             }
           }
           cj = win[j - wq]; acc = kacc; kroll = true;
+          if (skipj) {
+            // the k-mer that ends here is not in the index (the line of end position j + 1 said so): as for an empty entry -
+            // i = j, nothing recorded (GB_END_MATCH: l = 1 < seed_length, i = j >= kk - 1 > 1), on to j - 1
+            skipj = false;
+            if (j <= 1) bk = GB_AFTER_SEARCH;                                 // (`if (i <= 1) break`, bwt.c:292)
+            else { tail += diag(cj); j--; }
+            continue;
+          }
+          kidx = kline_ref(kcode, cj);
           kind = G_KMER; bk = GB_NONE;
         } else {
           c = cj = win[j - wq]; kroll = false;
@@ -3913,761 +4050,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
     atomicAdd(acc + 3, st_slow); atomicAdd(acc + 4, st_book); atomicAdd(acc + 5, (unsigned long long)itc << 32 | st_nheavy);
   }
 #endif
-}
-
-// ----------------------------------------------------------------------------
-// Greedy, third generation: the work of a read alternates between two kernels.
-//
-// profiles/r02_recon: k_greedy2 issues 1440 VALU + 720 SALU instructions per wave iteration at 2 waves per SIMD - 64 lanes in
-// 64 different places of a 13-state algorithm make every iteration pay for (nearly) all of it, queue and score
-// bookkeeping included, and the multi-letter rank step alone costs the kernel half its occupancy.  Here
-//   * g3_search (kernel k_g3_search, persistent lanes, the load-phase structure of mem_lane2) does NOTHING but index
-//     work - seed searches of fragments (maxMatches, bwt.c:261-296), continuations of substitution variants
-//     (maxMatches_withStart, :298-336) and the locate walks (ids_from_SI :799-845) - task by task from a list;
-//   * g3_book (kernel k_g3_book, one lane per read that is still at work) does the best-first bookkeeping of
-//     classify_greedyblosum (ConsumerThread.cpp:424-541) on the results: substitution variants of the matches
-//     (addAllMismatchVariantsAtPosSI :346-395, the 19 substitutes of a position ranked straight from the two rank
-//     blocks at the ends of the match's interval), scores (eval_match_scores :751-797), the queue (getNextFragment
-//     :272-342 with the lazy SEG split) - and writes the next tasks.
-// A substitution variant is searched as soon as it is queued (its search does not depend on anything that happens
-// later), so a round of the two kernels advances a read by a whole level of the best-first tree, not by one item.
-// Per read in device memory: a 64-byte state record, kG3Q queue slots (priority + 64-byte item), the matches of the
-// seed search under way, the list of best matches.  Reads that do not fit (queue, matches, 16-bit keys) go to the
-// retry pass (greedy_lane), as with the second generation.
-// ----------------------------------------------------------------------------
-constexpr int kG3Q = 128;                 // queue slots per read
-constexpr int kG3M = 64;                  // matches of one seed search
-constexpr uint32_t kG3Seed = 0x100u;      // task code of a seed search (below kG3Q: continuation of that queue item)
-constexpr int kG3TaskBuf = 16;            // tasks a read may ask for in one round (more: asked for again in a later round)
-constexpr uint8_t kG3BufSeed = 0xfe;      // task codes as g3_book notes them in the lane's buffer
-enum G3Phase : uint32_t { G3_NEW = 0, G3_POP = 1, G3_WAIT_SEED = 2, G3_DONE = 3 };
-constexpr uint32_t kG3NoMatch = 0xffffffffu;
-constexpr uint32_t kG3SeedOrig = 0x80000000u;     // G3State::seed_slot: the seed search is that of an original fragment
-
-struct G3State {             // 64 bytes per read
-  uint32_t best, nbest, flags, qseq;
-  uint32_t qn, qlive, fo, phase;
-  uint32_t b0lo, b0len;      // the first best match (the others in G3Arrays::best)
-  uint32_t seed_slot;        // whose seed search is under way: a queue slot (SEG piece) or kG3SeedOrig
-  uint32_t seed_nm;          // its result: number of matches, bit 31: more than kG3M
-  uint32_t seed_len, seed_tot;
-  uint64_t seed_pep;         // offset of the fragment in Batch::pep
-};
-static_assert(sizeof(G3State) == 64, "G3State is 64 bytes");
-struct G3Item {              // 64 bytes: a queued SEG piece (num_mm 0, searched when it is popped) or substitution variant
-  uint32_t key, start;       // start: offset of the underlying fragment in the read's peptide area
-  uint32_t len_ml;           // length | residues already matched << 16
-  uint32_t nmm_state;        // substitutions | state << 8 (0: no search yet, 1: search queued, 2: result in m_*)
-  int32_t diff;
-  uint32_t tot_msum;         // sum of the BLOSUM62 diagonal over the sequence | ... over the matched suffix << 16
-  uint32_t si0, si1;         // interval the search resumes from; then: m_lo, m_len of the match it found
-  uint32_t sp0, sp1, sp2, sp3, sa0, sa1;   // substituted positions (16 bit each) / letters (8 bit each)
-  uint32_t m_qiql, m_dp;     // the match found: qi | ql << 16 (kG3NoMatch: none), dsum | psum << 16
-};
-static_assert(sizeof(G3Item) == 64, "G3Item is 64 bytes");
-struct G3Task { uint32_t read, code; uint64_t pepoff; };   // pepoff: the read's peptide area in Batch::pep
-struct G3Arrays {
-  G3State *st;               // [n]
-  uint32_t *prio;            // [n][kG3Q] key << 16 | 0xffff - sequence number, 0 = free slot
-  G3Item *items;             // [n][kG3Q]
-  GMatch2 *matches;          // [n][kG3M]
-  GBest2 *best;              // [n][64]
-  G3Task *tasks;             // search tasks of this round (kG3TaskBuf per read of the batch: never full)
-  uint32_t *task_count;
-  uint32_t task_cap;
-  uint32_t *next;            // reads that take part in the next round
-  uint32_t *next_count;
-  uint32_t *locate;          // reads whose best matches are to be located (all rounds; one kernel at the end)
-  uint32_t *locate_count;
-  unsigned long long *opc;   // counting instantiations: kOpc* totals (else unused)
-};
-// what g3_book leaves to its caller (the kernel appends with one atomic per wavefront, not one per lane and task: 30 M
-// atomic adds on one address per million reads took 0.2 s)
-struct G3Out { uint32_t ntasks; bool again, locate; uint64_t pepoff; };
-
-// residue `pos` of the fragment of an item with its substitutions applied
-KJ_HD uint32_t g3_residue(const uint8_t *pep, uint32_t start, uint32_t nmm, const uint32_t *sp, const uint32_t *sa, uint32_t pos) {
-  uint32_t c = pep[start + pos];
-  for (uint32_t x = 0; x < nmm && x < (uint32_t)kMaxMismatch; x++) {
-    const uint32_t pz = (sp[x >> 1] >> ((x & 1u) * 16u)) & 0xffffu;
-    if (pz == pos) c = (sa[x >> 2] >> ((x & 3u) * 8u)) & 0xffu;
-  }
-  return c;
-}
-
-// The bookkeeping of read r until it has to wait for a search.  `narrow` indexes only (below 2^32 rows).
-template <bool COUNT = false>
-KJ_HD G3Out g3_book(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq, const Batch &b,
-                    const G3Arrays &g, const WorkList &wl, uint32_t r, uint8_t *qls, uint8_t *tb, uint32_t *oc = nullptr) {
-  // (qls: kG3M bytes of the lane - LDS on the device - for the lengths of the matches of a seed search; tb: kG3TaskBuf
-  // bytes for the codes of the tasks the read asks for in this round)
-  G3Out out; out.ntasks = 0; out.again = false; out.locate = false;
-  // (COUNT: oc[kOpc*] of the calling lane; records are counted in bytes - kOpcRecBytes -, rank blocks in lines)
-#define G3C(idx, v) do { if (COUNT) oc[idx] += (uint32_t)(v); } while (0)
-  G3State S = g.st[r];
-  G3C(kOpcRecBytes, 2 * sizeof(G3State) + sizeof(ReadMeta));
-  uint32_t *prio = g.prio + (size_t)r * kG3Q;
-  G3Item *items = g.items + (size_t)r * kG3Q;
-  const GMatch2 *M = g.matches + (size_t)r * kG3M;
-  GBest2 *bestl = g.best + (size_t)r * 64;
-  const ReadMeta rm = b.meta[r];
-  const uint32_t nf = rm.nfrag & ~kNfragSegPending;
-  const Frag *F = b.frags + rm.frag;
-  const uint8_t *pep = b.pep + rm.pep;
-  Hit *hit = b.hits + r;
-  bool ovf = false;
-
-  // a task of this round; false: the read has asked for kG3TaskBuf already (the search is asked for again in a later round)
-  auto add_task = [&](uint32_t code) -> bool {
-    if (out.ntasks >= (uint32_t)kG3TaskBuf) return false;
-    tb[out.ntasks++] = code == kG3Seed ? kG3BufSeed : (uint8_t)code;
-    G3C(kOpcRecBytes, sizeof(G3Task));
-    return true;
-  };
-  // multimap emplace of a variant / SEG piece: the slot (or ~0)
-  auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
-    if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; return ~0u; }
-    uint32_t slot = S.qn;
-    if (S.qlive < S.qn) {
-      slot = 0;
-      for (uint32_t q = 0; q < S.qn; q += 4) {               // (four priorities per load)
-        const u128 v = *reinterpret_cast<const u128 *>(prio + q);
-        const uint32_t e[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
-        int hit4 = -1;
-        for (int x = 3; x >= 0; x--) if (e[x] == 0 && q + (uint32_t)x < S.qn) hit4 = x;
-        if (hit4 >= 0) { slot = q + (uint32_t)hit4; break; }
-      }
-    }
-    else if (S.qn >= (uint32_t)kG3Q) { ovf = true; return ~0u; }
-    else S.qn++;
-    prio[slot] = key << 16 | (0xffffu - seq);
-    S.qlive++;
-    G3C(kOpcPush, 1); G3C(kOpcRecBytes, sizeof(G3Item) + 4);
-    return slot;
-  };
-  auto eval_match = [&](uint32_t lo, uint32_t len, uint32_t dsum, int32_t diff) {     // eval_match_scores on one match, :751-797
-    const int sc = (int)dsum + diff;                         // calcScore(seq, qi, ql, diff)
-    const uint32_t score = sc > 0 ? (uint32_t)sc : 0u;
-    if (score < p.min_score) return;
-    if (score > S.best) { S.best = score; S.nbest = 0; }
-    if (score == S.best) {
-      if (S.nbest < p.max_matches_SI && S.nbest < 64) {
-        if (S.nbest == 0) { S.b0lo = lo; S.b0len = len; }
-        else { GBest2 gb; gb.lo = lo; gb.len = len; bestl[S.nbest] = gb; G3C(kOpcRecBytes, sizeof(GBest2)); }
-        S.nbest++;
-      } else S.flags |= kHitSiCap;
-    }
-  };
-  // The fragment `t` has been searched and has nm matches (mat(x): the x-th found): variants behind the matches in the
-  // order `si_it = si_it->samelen ? si_it->samelen : si_it->next` (:477) visits the list of insert_SI_sorted
-  // (bwt.c:225-252), then the scores.
-  struct Cur { uint32_t start, len, nmm, tot; int32_t diff; uint32_t sp[4], sa[2]; };
-  auto after_search = [&](const Cur &t, uint32_t nm, auto &&mat) {
-    if (nm == 0) return;
-    G3C(kOpcMload, nm); G3C(kOpcRecBytes, nm * sizeof(GMatch2));
-    if (nm > 1) for (uint32_t x = 0; x < nm; x++) qls[x] = (uint8_t)(mat(x).qiql >> 16);   // (lengths <= kWin)
-    auto ql_of = [&](uint32_t x) -> int { return (int)qls[x]; };
-    auto max_below = [&](int bound) -> int { int v = -1; for (uint32_t x = 0; x < nm; x++) { const int q = ql_of(x); if (q < bound && q > v) v = q; } return v; };
-    auto head_of = [&](int v) -> uint32_t { uint32_t x = 0; while (x < nm && ql_of(x) != v) x++; return x; };
-    auto var_match = [&](const GMatch2 &mm) {
-      const uint32_t m_qi = mm.qiql & 0xffffu, m_ql = mm.qiql >> 16, m_dsum = mm.dp & 0xffffu, m_psum = mm.dp >> 16;
-      const uint32_t mre = m_qi + m_ql - 1u;
-      if (!(m_qi > 0 && mre + 1u >= p.m)) return;                                    // :469
-      // addAllMismatchVariantsAtPosSI(t, qi-1, erase_pos, it), :346-395
-      const uint32_t vlen = (mre < t.len - 1u) ? mre + 1u : t.len;                   // fragment.erase(erase_pos)
-      const uint32_t pz = m_qi - 1u;
-      const uint32_t vorig = ct.idx_to_aa[g3_residue(pep, t.start, t.nmm, t.sp, t.sa, pz)];
-      const int sc = (int)m_psum + t.diff;                                           // calcScore(fragment, f->diff)
-      const uint32_t cs = sc > 0 ? (uint32_t)sc : 0u;
-      const uint32_t vscore = cs - (uint32_t)(int32_t)ct.b62[vorig][vorig];          // unsigned wrap as in :363
-      const int boo = (int)ct.b62[vorig][vorig];
-      if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; return; }
-      const uint32_t vlo = mm.lo, vhi = mm.lo + mm.len;
-      const RankBlock64 *pa = ix.blocks64 + (vlo >> 6), *pb = ix.blocks64 + (vhi >> 6);
-      const uint64_t a0 = pa->plane[0], a1 = pa->plane[1], a2 = pa->plane[2], a3 = pa->plane[3], a4 = pa->plane[4];
-      const uint64_t b0 = pb->plane[0], b1 = pb->plane[1], b2 = pb->plane[2], b3 = pb->plane[3], b4 = pb->plane[4];
-      const uint64_t lowA = (1ull << (vlo & 63u)) - 1ull, lowB = (1ull << (vhi & 63u)) - 1ull;
-      G3C(kOpcVmulti, 1); G3C(kOpcStepLines, (vlo >> 6) != (vhi >> 6) ? 2 : 1);
-      for (uint32_t k = 0; k < 19; k++) {
-        const uint32_t sub = ct.subst[vorig][k];                                     // substitutes in descending score
-        const int bos = (int)ct.b62[vorig][sub];
-        const int32_t after = (int32_t)(vscore + (uint32_t)(int32_t)bos);
-        if (!(after >= (int32_t)S.best && after >= (int32_t)p.min_score)) break;    // :368-369, 390-392
-        const uint32_t cx = ct.aa_to_idx[sub];
-        const uint64_t i0 = (cx & 1u) ? 0ull : ~0ull, i1 = (cx & 2u) ? 0ull : ~0ull, i2 = (cx & 4u) ? 0ull : ~0ull,
-                       i3 = (cx & 8u) ? 0ull : ~0ull, i4 = (cx & 16u) ? 0ull : ~0ull;
-        const uint32_t ra = pa->cnt[cx - 1] + popc64((a0 ^ i0) & (a1 ^ i1) & (a2 ^ i2) & (a3 ^ i3) & (a4 ^ i4) & lowA);
-        const uint32_t rb = pb->cnt[cx - 1] + popc64((b0 ^ i0) & (b1 ^ i1) & (b2 ^ i2) & (b3 ^ i3) & (b4 ^ i4) & lowB);
-        if (ra >= rb) continue;                                                      // UpdateSI fails, :372
-        const uint32_t key = (uint32_t)after;
-        const uint32_t sl = push_slot(key, S.qseq + k);
-        if (sl == ~0u) break;
-        const int bss = (int)ct.b62[sub][sub];
-        G3Item it;
-        it.key = key; it.start = t.start; it.len_ml = vlen | (m_ql + 1u) << 16;
-        it.nmm_state = (t.nmm + 1u) | 1u << 8;
-        it.diff = t.diff + bos - bss;
-        it.tot_msum = ((m_psum - (uint32_t)boo + (uint32_t)bss) & 0xffffu) | (m_dsum + (uint32_t)bss) << 16;
-        it.si0 = ra; it.si1 = rb;
-        it.sp0 = t.sp[0]; it.sp1 = t.sp[1]; it.sp2 = t.sp[2]; it.sp3 = t.sp[3]; it.sa0 = t.sa[0]; it.sa1 = t.sa[1];
-        if (t.nmm < (uint32_t)kMaxMismatch) {
-          const uint32_t hs = (t.nmm & 1u) * 16u, hm = ~(0xffffu << hs), pzz = (pz & 0xffffu) << hs;
-          uint32_t *w = t.nmm < 2 ? &it.sp0 : t.nmm < 4 ? &it.sp1 : t.nmm < 6 ? &it.sp2 : &it.sp3;
-          *w = (*w & hm) | pzz;
-          const uint32_t bs = (t.nmm & 3u) * 8u, bm = ~(0xffu << bs);
-          if (t.nmm < 4u) it.sa0 = (it.sa0 & bm) | cx << bs; else it.sa1 = (it.sa1 & bm) | cx << bs;
-        }
-        it.m_qiql = kG3NoMatch; it.m_dp = 0;
-        if (!add_task(sl)) it.nmm_state = t.nmm + 1u;                                // searched in this round already (state 1),
-        items[sl] = it;                                                              // or asked for when it is popped (state 0)
-      }
-      S.qseq += 19;
-    };
-    if (p.mismatches > 0 && t.nmm < p.mismatches) {
-      if (nm == 1) var_match(mat(0));
-      else {
-        int v = max_below(0x7fffffff);
-        while (v >= 0 && !ovf) {
-          const uint32_t head = head_of(v);
-          uint32_t cnt = 0;
-          for (uint32_t x = head; x < nm; x++) if (ql_of(x) == v) cnt++;
-          var_match(mat(head));
-          if (cnt >= 2) {                                      // the samelen chain (latest insertion first) ends the walk
-            for (uint32_t x = nm; x-- > head + 1 && !ovf;) if (ql_of(x) == v) var_match(mat(x));
-            break;
-          }
-          v = max_below(v);
-        }
-      }
-    }
-    if (ovf) return;
-    // eval_match_scores(si, t), :751-797: the samelen chains of the classes (descending length, while >= m) in
-    // insertion order, then the class heads in ascending length
-    if (nm == 1) {
-      const GMatch2 mm = mat(0);
-      if ((mm.qiql >> 16) >= p.m) eval_match(mm.lo, mm.len, mm.dp & 0xffffu, t.diff);
-      return;
-    }
-    const int v1 = max_below(0x7fffffff);
-    if (v1 < (int)p.m) return;                                                       // :482
-    int v = v1, vlast = v1;
-    for (;;) {
-      const uint32_t head = head_of(v);
-      for (uint32_t x = head + 1; x < nm; x++) if (ql_of(x) == v) { const GMatch2 mm = mat(x); eval_match(mm.lo, mm.len, mm.dp & 0xffffu, t.diff); }
-      const int nv = max_below(v);
-      if (nv < 0 || nv < (int)p.m) { vlast = v; break; }
-      v = nv;
-    }
-    v = vlast;
-    for (;;) {
-      const GMatch2 mm = mat(head_of(v));
-      eval_match(mm.lo, mm.len, mm.dp & 0xffffu, t.diff);
-      if (v == v1) break;
-      int nv = 0x7fffffff;
-      for (uint32_t x = 0; x < nm; x++) { const int q = ql_of(x); if (q > v && q < nv) nv = q; }
-      v = nv;
-    }
-  };
-
-  if (S.phase == G3_NEW) {
-    S.best = 0; S.nbest = 0; S.flags = 0; S.qseq = 0; S.qn = 0; S.qlive = 0; S.fo = 0; S.b0lo = S.b0len = 0;
-    S.seed_slot = 0; S.seed_nm = 0; S.seed_len = S.seed_tot = 0; S.seed_pep = 0;
-    for (uint32_t q = 0; q < (uint32_t)kG3Q; q++) prio[q] = 0;
-    S.phase = G3_POP;
-  } else if (S.phase == G3_WAIT_SEED) {
-    // the seed search of an original / a SEG piece is done
-    if (S.seed_nm & 0x80000000u) ovf = true;
-    else {
-      Cur t; t.start = (uint32_t)(S.seed_pep - rm.pep); t.len = S.seed_len; t.nmm = 0; t.tot = S.seed_tot; t.diff = 0;
-      t.sp[0] = t.sp[1] = t.sp[2] = t.sp[3] = 0; t.sa[0] = t.sa[1] = 0;
-      after_search(t, S.seed_nm, [&](uint32_t x) -> GMatch2 { return M[x]; });
-    }
-    S.phase = G3_POP;
-  }
-  // getNextFragment(best_match_score), ConsumerThread.cpp:272-342, as long as the results of the popped items are there
-  bool finish = false;
-  while (!ovf && S.phase == G3_POP) {
-    uint32_t dbest = 0, dslot = 0;
-    for (uint32_t q = 0; q < S.qn; q += 4) {                 // (four priorities per load; slots >= qn hold 0)
-      const u128 v = *reinterpret_cast<const u128 *>(prio + q);
-      const uint32_t e[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
-      for (uint32_t x = 0; x < 4; x++) if (e[x] > dbest) { dbest = e[x]; dslot = q + x; }
-    }
-    G3C(kOpcRecBytes, 4 * S.qn);
-    const bool have_o = S.fo < nf, have_d = dbest != 0;
-    const uint32_t dkey = dbest >> 16;
-    Frag on; on.start = on.len = on.key = on.flags = 0;
-    if (have_o) { on = F[S.fo]; G3C(kOpcFrag, 1); }
-    if (!have_o && !have_d) { finish = true; break; }
-    const bool pick_o = have_o && (!have_d || on.key >= dkey);   // an original precedes queued entries of its key
-    if ((pick_o ? on.key : dkey) < S.best) { finish = true; break; }
-    if (pick_o) {
-      if (on.key > 0xffffu || on.len > 0xffffu || on.len > (uint32_t)kWin) { ovf = true; break; }
-      S.fo++;
-      if (p.seg && !(on.flags & kFragChecked)) {
-        // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked pieces are queued, and
-        // the next fragment is popped (:291-334)
-        const uint32_t slot = on.flags >> kFragSlotShift;
-        if (slot) {
-          const SegRec rec = sq.recs[slot - 1];
-          G3C(kOpcRecBytes, sizeof(SegRec));
-          if (rec.overflow) S.flags |= kHitInternalOverflow;
-          Frag f; f.start = on.start; f.len = on.len; f.key = on.key; f.flags = 0;
-          seg_split(ct, p, rec, pep, f, [&](const Frag &q) {
-            const uint32_t sl = push_slot(q.key, S.qseq);
-            if (sl == ~0u) return;
-            S.qseq++;
-            G3Item it;
-            it.key = q.key; it.start = q.start; it.len_ml = q.len; it.nmm_state = 0; it.diff = 0; it.tot_msum = q.key & 0xffffu;
-            it.si0 = it.si1 = 0; it.sp0 = it.sp1 = it.sp2 = it.sp3 = it.sa0 = it.sa1 = 0; it.m_qiql = kG3NoMatch; it.m_dp = 0;
-            items[sl] = it;
-          });
-        }
-        continue;
-      }
-      S.seed_slot = kG3SeedOrig; S.seed_len = on.len; S.seed_tot = on.key; S.seed_pep = rm.pep + on.start; S.seed_nm = 0;
-      if (add_task(kG3Seed)) S.phase = G3_WAIT_SEED;
-      else S.fo--;                                           // no room in this round's list: popped again in the next round
-      break;
-    }
-    // a queued item
-    const G3Item it = items[dslot];
-    G3C(kOpcPopItem, 1); G3C(kOpcRecBytes, sizeof(G3Item));
-    const uint32_t state = (it.nmm_state >> 8) & 255u, nmm = it.nmm_state & 255u;
-    if (state == 1u) break;                                  // its search runs in this round: wait (phase stays G3_POP)
-    if (nmm != 0 && state == 0u) {                           // its search found no room in the list of its round
-      if (add_task(dslot)) items[dslot].nmm_state = nmm | 1u << 8;
-      break;
-    }
-    if (nmm == 0) {                                          // a SEG piece: maxMatches like an original
-      if ((it.len_ml & 0xffffu) > (uint32_t)kWin) { ovf = true; break; }
-      S.seed_slot = dslot; S.seed_len = it.len_ml & 0xffffu; S.seed_tot = it.tot_msum & 0xffffu; S.seed_pep = rm.pep + it.start; S.seed_nm = 0;
-      if (!add_task(kG3Seed)) break;
-      prio[dslot] = 0; S.qlive--;
-      S.phase = G3_WAIT_SEED;
-      break;
-    }
-    prio[dslot] = 0; S.qlive--;
-    Cur t; t.start = it.start; t.len = it.len_ml & 0xffffu; t.nmm = nmm; t.tot = it.tot_msum & 0xffffu; t.diff = it.diff;
-    t.sp[0] = it.sp0; t.sp[1] = it.sp1; t.sp[2] = it.sp2; t.sp[3] = it.sp3; t.sa[0] = it.sa0; t.sa[1] = it.sa1;
-    GMatch2 one; one.lo = it.si0; one.len = it.si1; one.qiql = it.m_qiql; one.dp = it.m_dp;
-    after_search(t, it.m_qiql == kG3NoMatch ? 0u : 1u, [&](uint32_t) -> GMatch2 { return one; });
-  }
-  if (ovf) {
-    // the read does not fit the bounds of this generation: retry pass
-    hit->best = 0; hit->n_ids = 0; hit->reserved = 0;
-    if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; hit->flags = kHitRetry; }
-    else hit->flags = kHitInternalOverflow;
-    S.phase = G3_DONE;
-  } else if (finish) {
-    hit->reserved = 0;
-    hit->best = S.nbest ? S.best : 0u;
-    hit->flags = S.flags;
-    hit->n_ids = 0;
-    S.phase = G3_DONE;
-    out.locate = S.nbest != 0;
-  }
-  g.st[r] = S;
-  out.again = S.phase != G3_DONE;
-  out.pepoff = rm.pep;
-  G3C(kOpcRecBytes, out.again ? 4 : 16);                    // the list of the next round / the head of the hit record
-#undef G3C
-  return out;
-}
-// the appends of one lane without wave-level aggregation (host emulation; the kernels do this per wavefront)
-KJ_HD void g3_flush_lane(const G3Arrays &g, uint32_t r, const G3Out &o, const uint8_t *tb) {
-  for (uint32_t k = 0; k < o.ntasks; k++) {
-    const uint32_t at = append_slot(g.task_count);
-    G3Task t; t.read = r; t.code = tb[k] == kG3BufSeed ? kG3Seed : (uint32_t)tb[k]; t.pepoff = o.pepoff;
-    g.tasks[at] = t;
-  }
-  if (o.again) g.next[append_slot(g.next_count)] = r;
-  if (o.locate) g.locate[append_slot(g.locate_count)] = r;
-}
-
-// The search lane of the third generation: persistent, one task at a time per lane, the load-phase structure of
-// mem_lane2 (two rank blocks, one 16-byte load of something else and - wave-uniform - four 16-byte loads of a record or a
-// peptide window per iteration).  Fragments have at most kWin residues here (g3_book sends longer ones to the retry
-// pass), so a task's window is filled once.
-enum G3Kind : int { S_STEP, S_KMER, S_FETCH, S_TASK, S_WIN, S_IDLE, S_EXIT };
-enum G3Bk : int { SB_NONE, SB_END_MATCH, SB_START_J, SB_SEARCH_DONE };
-
-template <bool COUNT = false>
-KJ_HD void g3_search(const DevIndex &ix, const ConstTables &ct, const Params &p, const Batch &b, const G3Arrays &g,
-                     uint32_t *counter, const uint32_t *n_tasks_ptr, uint8_t *win) {
-  typedef uint32_t P;
-  uint32_t oc[kOpcN];
-  if constexpr (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
-  int kind = S_IDLE;
-  uint32_t r = 0, code = 0;
-  uint64_t pepoff = 0, winsrc = 0;
-  // the fragment being searched
-  uint32_t t_matchlen = 0, t_tot = 0, t_msum = 0, t_nmm = 0;
-  uint32_t sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, sa0 = 0, sa1 = 0;
-  int flen = 0, j = 0, i = 0, last_qi = 0;
-  P lo = 0, hi = 0;
-  uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0, kacc = 0;
-  bool m_ovf = false, kroll = false;
-  uint32_t r_lo = 0, r_len = 0, r_qiql = kG3NoMatch, r_dp = 0;       // the match of a continuation
-  const uint32_t n_items = *n_tasks_ptr < g.task_cap ? *n_tasks_ptr : g.task_cap;
-  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kmer32) ? ix.kmer_k : 0;
-  const uint32_t nwaves = kj_nwaves();
-  uint32_t wnext = 0, wend = 0, item = 0;
-  const RankBlock64 *const blk0 = ix.blocks64;
-  uint32_t kpow = 1;
-  for (uint32_t q = 1; q < kk; q++) kpow *= 20u;
-  uint64_t dg0 = 0, dg1 = 0;                    // BLOSUM62 diagonal by index-alphabet code, 4 bits each (values 4..11)
-  for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
-  for (int x = 16; x < 32; x++) dg1 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * (x - 16));
-  auto diag = [&](uint32_t cc) -> uint32_t { return (uint32_t)(((cc & 16u) ? dg1 : dg0) >> (4u * (cc & 15u))) & 15u; };
-
-  for (;;) {
-    // ---- (0) hand out tasks to the lanes that finished one (wave-uniform control flow, see mem_lane2) ----
-    {
-      const bool need = kind == S_IDLE;
-      const uint64_t mask = kj_ballot(need);
-      if (mask) {
-        const uint32_t n = popc64(mask);
-        const uint32_t rank = kj_rank_below(mask);
-        const uint32_t avail = wend - wnext;
-        uint32_t newbase = 0, ch = 0;
-        if (n > avail) {
-          const uint32_t left = n_items > wend ? n_items - wend : 0;
-          ch = left / (nwaves * 4u);
-          if (ch > 128u) ch = 128u;
-          if (ch < 8u) ch = 8u;
-          if (ch < n - avail) ch = n - avail;
-          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-          uint32_t got = 0;
-          if (need && rank == 0) got = kj_fetch_chunk(counter, ch);
-          newbase = kj_bcast_uniform(got, leader);
-        }
-        if (need) {
-          item = rank < avail ? wnext + rank : newbase + (rank - avail);
-          kind = item >= n_items ? S_EXIT : S_FETCH;
-        }
-        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
-        else wnext += n;
-      }
-      if (kj_ballot(kind != S_EXIT) == 0) break;
-    }
-
-    // ---- (1) load phase ----
-    const bool is_step = kind == S_STEP;
-    const P posA = is_step ? lo : 0;
-    const P posB = is_step ? hi : posA;
-    if constexpr (COUNT) {
-      oc[kOpcLaneIters] += kind != S_EXIT ? 1u : 0u;
-      if (kj_lane() == 0) oc[kOpcIters]++;
-      if (kind == S_KMER) oc[kOpcKmer]++;
-      else if (kind == S_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
-      else if (kind == S_WIN) oc[kOpcFill]++;
-      else if (kind == S_FETCH) oc[kOpcRecBytes] += (uint32_t)sizeof(G3Task);
-      else if (kind == S_TASK) oc[kOpcRecBytes] += 64u;
-    }
-    const uint32_t cc = is_step ? c : 1u;
-    const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
-    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
-    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
-    const uint64_t a4 = pa->plane[4];
-    const uint32_t ca = pa->cnt[cc - 1];
-    const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
-    const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
-    const uint64_t b4 = pb->plane[4];
-    const uint32_t cb = pb->cnt[cc - 1];
-    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == S_KMER) gaddr = reinterpret_cast<const uint8_t *>(ix.kmer32 + kidx);
-    else if (kind == S_FETCH) gaddr = reinterpret_cast<const uint8_t *>(g.tasks + item);
-    const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
-    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
-    u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
-    if (kj_ballot(kind == S_TASK || kind == S_WIN)) {        // wave-uniform
-      const uint8_t *src = reinterpret_cast<const uint8_t *>(blk0);
-      if (kind == S_WIN) src = b.pep + winsrc;
-      else if (kind == S_TASK) src = (code < (uint32_t)kG3Q) ? reinterpret_cast<const uint8_t *>(g.items + (size_t)r * kG3Q + code)
-                                                              : reinterpret_cast<const uint8_t *>(g.st + r);
-      const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
-      w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
-    }
-
-    // ---- (2) compute ----
-    int bk = SB_NONE;
-    if (is_step) {
-      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
-                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
-      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
-      const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
-      // UpdateSI(str[i-1]) (bwt.c:160-173)
-      const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
-      const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
-      if (ra >= rb) bk = SB_END_MATCH;
-      else {
-        lo = ra; hi = rb; i--; acc += diag(c);
-        if (i == 0) bk = SB_END_MATCH; else c = win[i - 1];
-      }
-    } else if (kind == S_KMER) {
-      const uint64_t e = ghalf ? gv.y : gv.x;
-      lo = (P)e; hi = (P)e + (P)(e >> 32);
-      if (lo >= hi) { i = j; bk = SB_END_MATCH; }          // seed shorter than kk: never recorded, i > 1
-      else {
-        i = j - (int)kk + 1;
-        if (i == 0) bk = SB_END_MATCH; else { c = win[i - 1]; kind = S_STEP; }
-      }
-    } else if (kind == S_FETCH) {
-      r = (uint32_t)gv.x; code = (uint32_t)(gv.x >> 32); pepoff = gv.y;
-      kind = S_TASK;
-    } else if (kind == S_TASK) {
-      if (code < (uint32_t)kG3Q) {
-        // continuation of a substitution variant: maxMatches_withStart, bwt.c:298-336
-        const uint32_t start = (uint32_t)(w0.x >> 32), len_ml = (uint32_t)w0.y, nmm_state = (uint32_t)(w0.y >> 32);
-        flen = (int)(len_ml & 0xffffu); t_matchlen = len_ml >> 16; t_nmm = nmm_state & 255u;
-        const uint32_t tm = (uint32_t)(w1.x >> 32);
-        t_tot = tm & 0xffffu; t_msum = tm >> 16;
-        lo = (P)(uint32_t)w1.y; hi = (P)(uint32_t)(w1.y >> 32);
-        sp0 = (uint32_t)w2.x; sp1 = (uint32_t)(w2.x >> 32); sp2 = (uint32_t)w2.y; sp3 = (uint32_t)(w2.y >> 32);
-        sa0 = (uint32_t)w3.x; sa1 = (uint32_t)(w3.x >> 32);
-        winsrc = pepoff + start;
-        kind = S_WIN;
-      } else {
-        // maxMatches(seq, len, seed_length, 0) of an original fragment or SEG piece, bwt.c:261-296
-        flen = (int)(uint32_t)w3.x; t_tot = (uint32_t)(w3.x >> 32); winsrc = w3.y;
-        t_nmm = 0; t_matchlen = 0; t_msum = 0;
-        kind = S_WIN;
-      }
-    } else if (kind == S_WIN) {
-      uint32_t *d32 = reinterpret_cast<uint32_t *>(win);
-      d32[0] = (uint32_t)w0.x; d32[1] = (uint32_t)(w0.x >> 32); d32[2] = (uint32_t)w0.y; d32[3] = (uint32_t)(w0.y >> 32);
-      d32[4] = (uint32_t)w1.x; d32[5] = (uint32_t)(w1.x >> 32); d32[6] = (uint32_t)w1.y; d32[7] = (uint32_t)(w1.y >> 32);
-      d32[8] = (uint32_t)w2.x; d32[9] = (uint32_t)(w2.x >> 32); d32[10] = (uint32_t)w2.y; d32[11] = (uint32_t)(w2.y >> 32);
-      d32[12] = (uint32_t)w3.x; d32[13] = (uint32_t)(w3.x >> 32); d32[14] = (uint32_t)w3.y; d32[15] = (uint32_t)(w3.y >> 32);
-      // the substitutions of the variant (the reference edits the fragment string, :380)
-      for (uint32_t x = 0; x < t_nmm && x < (uint32_t)kMaxMismatch; x++) {
-        const uint32_t pw = x < 2 ? sp0 : x < 4 ? sp1 : x < 6 ? sp2 : sp3;
-        const int pz = (int)((pw >> ((x & 1u) * 16u)) & 0xffffu);
-        const uint32_t aw = x < 4 ? sa0 : sa1;
-        if (pz < kWin && pz < flen) win[pz] = (uint8_t)(aw >> ((x & 3u) * 8u));
-      }
-      nm = 0; m_ovf = false; kroll = false; r_qiql = kG3NoMatch; r_lo = r_len = r_dp = 0;
-      j = flen - 1;
-      if (t_nmm == 0) { tail = 0; bk = SB_START_J; }
-      else {
-        i = j - (int)t_matchlen + 1;
-        acc = t_msum;
-        if (i <= 0) bk = SB_END_MATCH; else { c = win[i - 1]; kind = S_STEP; }
-      }
-    }
-
-    // ---- (3) bookkeeping ----
-    while (bk != SB_NONE) {
-      if (bk == SB_END_MATCH) {
-        const int l = j - i + 1;
-        if (t_nmm == 0) {
-          if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {        // bwt.c:276-278
-            if (nm < (uint32_t)kG3M) {
-              GMatch2 mm; mm.lo = lo; mm.len = (uint32_t)(hi - lo); mm.qiql = (uint32_t)i | (uint32_t)l << 16; mm.dp = acc | (t_tot - tail) << 16;
-              g.matches[(size_t)r * kG3M + nm] = mm;
-              if constexpr (COUNT) { oc[kOpcMatchWr]++; oc[kOpcRecBytes] += (uint32_t)sizeof(GMatch2); }
-            } else m_ovf = true;
-            nm++;
-            last_qi = i;
-          }
-          if (i <= 1) bk = SB_SEARCH_DONE;                                  // bwt.c:292
-          else { tail += diag(cj); j--; bk = SB_START_J; }
-        } else {
-          // :443-449: after the last allowed mismatch the match must reach min_fragment_length
-          const int Lreq = (t_nmm == p.mismatches) ? (int)p.m : (int)t_matchlen;
-          if (l >= Lreq) { r_lo = lo; r_len = (uint32_t)(hi - lo); r_qiql = (uint32_t)i | (uint32_t)l << 16; r_dp = acc | t_tot << 16; }
-          bk = SB_SEARCH_DONE;
-        }
-      }
-      if (bk == SB_START_J) {
-        if (j < (int)p.seed_length - 1) bk = SB_SEARCH_DONE;
-        else if (kk && j >= (int)kk - 1) {
-          if (kroll) {
-            const uint32_t cn = win[j - (int)kk + 1];
-            kidx = (kidx - (cj - 1u) * kpow) * 20u + (cn - 1u);
-            kacc = kacc - diag(cj) + diag(cn);
-          } else {
-            kidx = 0; kacc = 0;
-            for (uint32_t q = 0; q < kk; q++) {
-              const uint32_t cq = win[j - (int)q];
-              kidx = kmer_index(kidx, cq);
-              kacc += diag(cq);
-            }
-          }
-          cj = win[j]; acc = kacc; kroll = true;
-          kind = S_KMER; bk = SB_NONE;
-        } else {
-          c = cj = win[j]; kroll = false;
-          lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];                              // InitialSI, bwt.c:146-152
-          acc = diag(c);
-          i = j;
-          if (i == 0) { bk = SB_END_MATCH; continue; }
-          c = win[i - 1]; kind = S_STEP; bk = SB_NONE;
-        }
-      }
-      if (bk == SB_SEARCH_DONE) {
-        if (t_nmm == 0) g.st[r].seed_nm = nm | (m_ovf ? 0x80000000u : 0u);
-        else {
-          G3Item *it = g.items + (size_t)r * kG3Q + code;
-          it->si0 = r_lo; it->si1 = r_len; it->m_qiql = r_qiql; it->m_dp = r_dp;
-          it->nmm_state = t_nmm | 2u << 8;
-        }
-        if constexpr (COUNT) oc[kOpcRecBytes] += t_nmm == 0 ? 4u : 20u;
-        kind = S_IDLE; bk = SB_NONE;
-      }
-    }
-  }
-  if constexpr (COUNT) opc_flush(g.opc, oc);
-}
-
-// The locate walks of the third generation, one kernel behind the rounds: for every listed read the ids of its best
-// matches (ids_from_SI ConsumerThread.cpp:799-845 for every best SI in turn, no samelen walk; get_suffix bwt.c:105-121),
-// persistent lanes, one LF step or one SA sample per iteration.
-enum G3LKind : int { L_LF1, L_LF2, L_SA, L_BESTE, L_FETCH, L_STATE, L_IDLE, L_EXIT };
-template <bool COUNT = false>
-KJ_HD void g3_locate(const DevIndex &ix, const Params &p, const Batch &b, const G3Arrays &g, uint32_t *counter) {
-  typedef uint32_t P;
-  uint32_t oc[kOpcN];
-  if constexpr (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
-  int kind = L_IDLE;
-  uint32_t r = 0, c = 1, cur = 0, nbest = 0, nids = 0, flags = 0, b0lo = 0, b0len = 0;
-  P row = 0, rowend = 0, k = 0;
-  uint64_t id0 = 0, sa_idx = 0;
-  bool fresh = true;
-  Hit *hit = nullptr;
-  const P check = (P)((1u << ix.chpt_exp) - 1);
-  const uint32_t n_items = *g.locate_count;
-  const uint32_t nwaves = kj_nwaves();
-  uint32_t wnext = 0, wend = 0, item = 0;
-  const RankBlock64 *const blk0 = ix.blocks64;
-  auto add_tax = [&](uint64_t tax) {
-    bool dup = false;
-    if (nids >= 1 && tax == id0) dup = true;
-    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
-  };
-  for (;;) {
-    {
-      const bool need = kind == L_IDLE;
-      const uint64_t mask = kj_ballot(need);
-      if (mask) {
-        const uint32_t n = popc64(mask);
-        const uint32_t rank = kj_rank_below(mask);
-        const uint32_t avail = wend - wnext;
-        uint32_t newbase = 0, ch = 0;
-        if (n > avail) {
-          const uint32_t left = n_items > wend ? n_items - wend : 0;
-          ch = left / (nwaves * 4u);
-          if (ch > 128u) ch = 128u;
-          if (ch < 8u) ch = 8u;
-          if (ch < n - avail) ch = n - avail;
-          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-          uint32_t got = 0;
-          if (need && rank == 0) got = kj_fetch_chunk(counter, ch);
-          newbase = kj_bcast_uniform(got, leader);
-        }
-        if (need) {
-          item = rank < avail ? wnext + rank : newbase + (rank - avail);
-          kind = item >= n_items ? L_EXIT : L_FETCH;
-        }
-        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
-        else wnext += n;
-      }
-      if (kj_ballot(kind != L_EXIT) == 0) break;
-    }
-    const bool is_lf = kind == L_LF1 || kind == L_LF2;
-    const P posA = is_lf ? k : 0;
-    const uint32_t cc = kind == L_LF2 ? c : 1u;
-    const RankBlock64 *pa = blk0 + (posA >> 6);
-    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
-    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
-    const uint64_t a4 = pa->plane[4];
-    const uint32_t ca = pa->cnt[cc - 1];
-    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == L_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
-    else if (kind == L_FETCH) gaddr = reinterpret_cast<const uint8_t *>(g.locate + item);
-    else if (kind == L_BESTE) gaddr = reinterpret_cast<const uint8_t *>(g.best + (size_t)r * 64 + cur);
-    else if (kind == L_STATE) gaddr = reinterpret_cast<const uint8_t *>(g.st + r);
-    const uint32_t goff = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) & 15u);
-    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
-    u128 g2{0, 0};
-    if (kj_ballot(kind == L_STATE)) g2 = *reinterpret_cast<const u128 *>(kind == L_STATE ? reinterpret_cast<const uint8_t *>(g.st + r) + 32 : reinterpret_cast<const uint8_t *>(blk0));
-    if constexpr (COUNT) {
-      if (kind == L_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
-      else if (kind == L_SA) oc[kOpcSa]++;
-      else if (kind == L_FETCH) oc[kOpcRecBytes] += 4u;
-      else if (kind == L_STATE) oc[kOpcRecBytes] += 32u;
-      else if (kind == L_BESTE) oc[kOpcRecBytes] += (uint32_t)sizeof(GBest2);
-    }
-    int bk = 0;                                              // 1: next best match, 2: next row, 3: done
-    if (kind == L_LF2) {
-      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
-                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
-      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
-      k = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
-      fresh = false;
-      bk = 2;
-    } else if (kind == L_LF1) {
-      const uint32_t sft = k & 63u;
-      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
-          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
-      if (c != 0) kind = L_LF2;
-      else {
-        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
-        const uint32_t iseq = (uint32_t)rank_term(ix, k);
-        if constexpr (COUNT) oc[kOpcTerm]++;
-        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
-        row++; k = row; fresh = true;
-        bk = 2;
-      }
-    } else if (kind == L_SA) {
-      const uint64_t tax = goff & 8u ? gv.y : gv.x;
-      if (tax != ~0ull) add_tax(tax);
-      row++; k = row; fresh = true;
-      bk = 2;
-    } else if (kind == L_BESTE) {
-      const uint64_t e = goff & 8u ? gv.y : gv.x;
-      row = (P)e; rowend = row + (P)(e >> 32);
-      cur++; k = row; fresh = true;
-      bk = 2;
-    } else if (kind == L_FETCH) {
-      const uint32_t w4[4] = {(uint32_t)gv.x, (uint32_t)(gv.x >> 32), (uint32_t)gv.y, (uint32_t)(gv.y >> 32)};
-      r = w4[goff >> 2];
-      kind = L_STATE;
-    } else if (kind == L_STATE) {
-      nbest = (uint32_t)(gv.x >> 32); flags = (uint32_t)gv.y;
-      b0lo = (uint32_t)g2.x; b0len = (uint32_t)(g2.x >> 32);
-      hit = b.hits + r;
-      nids = 0; cur = 0;
-      bk = 1;
-    }
-    while (bk) {
-      if (bk == 1) {
-        if (cur >= nbest) bk = 3;
-        else if (cur == 0) { row = b0lo; rowend = b0lo + b0len; cur = 1; k = row; fresh = true; bk = 2; }
-        else { kind = L_BESTE; bk = 0; }
-      }
-      if (bk == 2) {
-        // one row of the walk: k is a fresh row (k == row) or the row reached by the LF walk
-        for (;;) {
-          if (row >= rowend) { bk = 1; break; }
-          if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = 3; break; }     // :805-807
-          if ((k & check) != 0) { kind = L_LF1; bk = 0; break; }
-          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-          if (sa_idx < ix.n_sa) { kind = L_SA; bk = 0; break; }
-          row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
-        }
-        if (bk == 1) continue;
-      }
-      if (bk == 3) {
-        hit->n_ids = nids; hit->flags = flags;
-        if constexpr (COUNT) { oc[kOpcHit]++; oc[kOpcRecBytes] += 8u * nids; }
-        kind = L_IDLE; bk = 0;
-      }
-    }
-  }
-  if constexpr (COUNT) opc_flush(g.opc, oc);
 }
 
 // ----------------------------------------------------------------------------

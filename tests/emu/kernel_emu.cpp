@@ -34,6 +34,7 @@ void *emu_index_load(const char *path, char *err, int errlen) {
   std::string msg;
   int rc = ix->file.load(path, msg);
   if (rc == 0) rc = ix->packed.build(ix->file.view(), msg);
+  if (rc == 0) ix->packed.build_klines();          // (the device builds its k-mer lines in capi.hip: k_kline_build)
   if (rc == 0) rc = build_const_tables(ix->packed.trans, ix->ct, msg);
   if (rc == 0) rc = build_seg_tables(ix->lnfact, ix->st, msg);
   if (rc != 0) { snprintf(err, (size_t)errlen, "%s", msg.c_str()); delete ix; return nullptr; }
@@ -282,53 +283,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1" or default (v2 where possible)
       std::vector<GBestV> bestvv(64);
       gs.bestv = g_vb.n_acc ? bestvv.data() : nullptr;
-      const char *gen = getenv("KAIJU_EMU_GREEDY");      // "v3": the third generation (KAIJU_GPU_GREEDY_LANE=v3 on the device)
-      if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc && fast1 && gen && !strcmp(gen, "v3")) {
-        // third generation (capi.hip: rounds of k_g3_book / k_g3_search)
-        std::vector<G3State> st(n);
-        memset(st.data(), 0, sizeof(G3State) * n);
-        std::vector<uint32_t> prio((size_t)n * kG3Q, 0xdeadbeefu);
-        std::vector<G3Item> items((size_t)n * kG3Q);
-        std::vector<GMatch2> matches3((size_t)n * kG3M);
-        std::vector<GBest2> best3((size_t)n * 64);
-        const uint32_t task_cap = kG3TaskBuf * n + 64;
-        std::vector<uint32_t> loc_list(n);
-        uint32_t loc_count = 0;
-        std::vector<G3Task> tasks(task_cap);
-        std::vector<uint32_t> listA(n), listB(n);
-        for (uint32_t r = 0; r < n; r++) listA[r] = r;
-        uint32_t n_active = n, rounds = 0;
-        uint32_t *cur_list = listA.data(), *next_list = listB.data();
-        const char *re = getenv("KAIJU_EMU_G3_ROUNDS");
-        const uint32_t max_rounds = re ? (uint32_t)atoi(re) : 128u;
-        while (n_active && rounds < max_rounds) {
-          uint32_t task_count = 0, next_count = 0, work = 0;
-          G3Arrays g{st.data(), prio.data(), items.data(), matches3.data(), best3.data(), tasks.data(), &task_count, task_cap,
-                     next_list, &next_count, loc_list.data(), &loc_count, nullptr};
-          uint8_t qls[kG3M + 4], tb[kG3TaskBuf];
-          for (uint32_t a = 0; a < n_active; a++) {
-            const G3Out o = g3_book(d, ix->ct, p, sq, b, g, wl, cur_list[a], qls, tb);
-            g3_flush_lane(g, cur_list[a], o, tb);
-          }
-          g3_search(d, ix->ct, p, b, g, &work, &task_count, win);
-          std::swap(cur_list, next_list);
-          n_active = next_count;
-          rounds++;
-        }
-        // reads still at work after the last round: retry pass (k_g3_flush)
-        for (uint32_t a = 0; a < n_active; a++) {
-          const uint32_t r = cur_list[a];
-          hits[r].best = 0; hits[r].n_ids = 0; hits[r].reserved = 0; hits[r].flags = kHitRetry;
-          retry[retry_count++] = r;
-        }
-        {
-          uint32_t work = 0, dummy = 0;
-          G3Arrays g{st.data(), prio.data(), items.data(), matches3.data(), best3.data(), tasks.data(), &dummy, task_cap,
-                     nullptr, &dummy, loc_list.data(), &loc_count, nullptr};
-          g3_locate(d, p, b, g, &work);
-        }
-        if (getenv("KAIJU_EMU_PRINT_LAZY")) fprintf(stderr, "[emu] greedy3: %u rounds, %u reads left for the retry pass\n", rounds, n_active);
-      } else if (d.blocks64 && d.kmer32 && !v && pass == 0 && !g_vb.n_acc) {
+      if (d.blocks64 && d.kline && !v && pass == 0 && !g_vb.n_acc) {
         alignas(16) uint32_t lds_win[kGWinStride], lds_mq[kGMqStride], lds_prio[kGPrioStride];
         for (auto &x : lds_win) x = 0xdeadbeefu;
         for (auto &x : lds_mq) x = 0xdeadbeefu;

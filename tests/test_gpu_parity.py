@@ -99,26 +99,6 @@ def test_mem_locate_by_the_search_lanes(gpu_lib, golden, gidx, oracle, ohandles,
             assert not (hits["flags"] & 0x20000000).any()        # kHitLocPending never leaves the library
 
 
-def test_greedy_third_generation_on_device(gpu_lib, golden, gidx, oracle, ohandles, monkeypatch):
-    """KAIJU_GPU_GREEDY_LANE=v3: the two-kernel rounds (experimental); short reads and pairs vs the oracle, also with too few
-    rounds (leftovers go to the retry pass)"""
-    api = gpu_lib
-    ix, tax = ohandles
-    _, sseqs, soff = golden.short()
-    monkeypatch.setenv("KAIJU_GPU_GREEDY_LANE", "v3")
-    for rounds in ("128", "9"):
-        monkeypatch.setenv("KAIJU_GPU_G3_ROUNDS", rounds)
-        for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True)):
-            clf = api.Classifier(gidx, api.default_params("greedy", seg=1))
-            hits = clf.classify(seqs, off, paired=pe)
-            st = clf.stats()
-            assert st.error_flags == 0 and (st.n_overflow_retries > 0) == (rounds == "9")
-            oh = oracle.classify(ix, tax, oracle.params("greedy", seg=1, use_evalue=0), seqs, off, paired=pe)
-            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
-            assert not bad, (rounds, pe, bad[:5])
-
-
-@pytest.mark.parametrize("mode,seg", CASES)
 def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
     """k_lca: hit records -> 16-byte records on the device; finalize_compact == finalize_hits == reference lines"""
     api = gpu_lib

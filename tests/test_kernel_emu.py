@@ -111,23 +111,6 @@ def test_mem_locate_in_a_pass_of_its_own(oracle, emu, golden, handles, seg, monk
         assert not (gd["flags"] & 0x20000000).any()          # kHitLocPending never leaves the library
 
 
-@pytest.mark.parametrize("seg", [1, 0])
-def test_greedy_third_generation(oracle, emu, golden, handles, seg, monkeypatch):
-    """the two-kernel rounds of the third-generation Greedy search (g3_book / g3_search / g3_locate; experimental on the
-    device, KAIJU_GPU_GREEDY_LANE=v3): single reads and pairs, also with few rounds (leftovers -> retry pass)"""
-    h, ix, tax = handles
-    monkeypatch.setenv("KAIJU_EMU_GREEDY", "v3")
-    _, sseqs, soff = golden.short()
-    for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True)):
-        oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg, use_evalue=0), seqs, off, paired=pe)
-        for rounds in ("128", "9"):
-            monkeypatch.setenv("KAIJU_EMU_G3_ROUNDS", rounds)
-            gh, nretry = emu.classify(h, util.gp("greedy", seg=seg), seqs, off, paired=pe)
-            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
-            assert not bad, (seg, pe, rounds, bad[:5])
-            assert (nretry > 0) == (rounds == "9")
-
-
 @pytest.mark.parametrize("mode,seg", CASES)
 def test_retry_pass(oracle, emu, golden, handles, mode, seg, monkeypatch):
     """scratch far too small in the main pass: every overflowing read must come out right

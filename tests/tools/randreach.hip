@@ -28,7 +28,21 @@ __global__ void __launch_bounds__(256) k_reach(const uint4 *__restrict__ tab, ui
     if (MODE == 14 && (i & 1)) b += far_line0;
     const uint4 *p = tab + b * 8;
     if (MODE == 1) { const uint4 v = p[s & 7]; acc ^= v.x ^ v.w; }
-    else { const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3 + (s & 3) + ((s >> 2) & 1)]; acc ^= v0.x ^ v1.y ^ v2.z ^ v3.w; }
+    else if (MODE == 2) {            // two 16-byte loads of one lane in the same 64-byte half (k-mer line: entry + presence bits)
+      const uint4 v0 = p[(s & 4) + 0], v1 = p[(s & 4) + 1 + (s & 1)]; acc ^= v0.x ^ v1.y;
+    } else if (MODE == 3) {          // two loads of one lane in the two halves of the line
+      const uint4 v0 = p[s & 3], v1 = p[4 + ((s >> 2) & 3)]; acc ^= v0.x ^ v1.y;
+    } else if (MODE == 41 || MODE == 42) {
+      // quad-cooperative: the four lanes of a quad fetch ONE line together (the line of the quad's lane 0: one DPP broadcast),
+      // 41: the four chunks of one 64-byte half; 42: three chunks of the first half + one chunk of the rest (rank block: five
+      // planes + one count).  Lines per wave instruction: 16
+      const uint64_t b0 = (uint64_t)__shfl((unsigned long long)b, (int)(threadIdx.x & 60u), 64);
+      const uint64_t s0 = (uint64_t)__shfl((unsigned long long)s, (int)(threadIdx.x & 60u), 64);
+      const uint4 *q = tab + b0 * 8;
+      const uint32_t l4 = threadIdx.x & 3u;
+      const uint32_t ch = MODE == 41 ? (uint32_t)(s0 & 4) + l4 : (l4 < 3u ? l4 : 2u + (uint32_t)(s0 % 6u));
+      const uint4 v = q[ch]; acc ^= v.x ^ v.w;
+    } else { const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3 + (s & 3) + ((s >> 2) & 1)]; acc ^= v0.x ^ v1.y ^ v2.z ^ v3.w; }
   }
   if (acc == 0x12345678u) out[0] = acc;
 }
@@ -53,13 +67,17 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, 0);
       if (mode == 1) k_reach<1><<<blocks, 256>>>(tab, nlines, far0, iters, out);
+      else if (mode == 2) k_reach<2><<<blocks, 256>>>(tab, nlines, far0, iters, out);
+      else if (mode == 3) k_reach<3><<<blocks, 256>>>(tab, nlines, far0, iters, out);
+      else if (mode == 41) k_reach<41><<<blocks, 256>>>(tab, nlines, far0, iters, out);
+      else if (mode == 42) k_reach<42><<<blocks, 256>>>(tab, nlines, far0, iters, out);
       else if (mode == 14) k_reach<14><<<blocks, 256>>>(tab, nlines, far0, iters, out);
       else k_reach<4><<<blocks, 256>>>(tab, nlines, far0, iters, out);
       hipEventRecord(e1, 0); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (ms < best) best = ms;
     }
-    const double q = (double)blocks * 256 * iters;
+    const double q = (double)blocks * 256 * iters / ((mode == 41 || mode == 42) ? 4.0 : 1.0);    // (quad modes: a line per quad and load)
     printf("alloc %zu GiB mode %d window %8.2f GiB lanes %d loads/lane %d: %8.3f ms  %6.2f G lines/s  %7.1f GB/s at 128 B/line\n",
            alloc >> 30, mode, (double)win / (double)(1ull << 30), blocks * 256, iters, best, q / best * 1e-6, q * 128 / best * 1e-6);
     fflush(stdout);
