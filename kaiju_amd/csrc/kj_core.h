@@ -2299,14 +2299,14 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (bk == BK_START_J) {
         KJ_PM(PM_START_J);
         // for (j = len-1; j >= L-1; --j), L = max(m, longest) and growing (bwt.c:356)
-        if (j < (int)L - 1) bk = BK_NEXT_FRAG;
-        else if (!WIDE && skipj) {
+        if (!WIDE && skipj && j >= (int)L - 1) {
           // the k-mer that ends here is not in the index (the line of end position j + 1 said so): as for an empty table
-          // entry - i = j, nothing recorded, `if (i <= 1) break` (bwt.c:376), --j
-          skipj = false;
+          // entry - i = j, nothing recorded, `if (i <= 1) break` (bwt.c:376), --j - and on to j - 1 in the same pass
           if (j <= 1) bk = BK_NEXT_FRAG; else j--;
-          continue;
         }
+        skipj = false;
+        if (bk == BK_NEXT_FRAG) {}
+        else if (j < (int)L - 1) bk = BK_NEXT_FRAG;
         else if (kk && j >= (int)kk - 1) {
           if (in_win(j) && in_win(j - (int)kk + 1)) {
             // (a rolling update of the index from end position j+1 was tried: it costs a register too many here)
@@ -3991,9 +3991,24 @@ if constexpr (COUNT) oc[kOpcTerm]++;
       }
       if (bk == GB_START_J) {
         KJ_P(PS_START_J);
-        if (j < (int)p.seed_length - 1) bk = GB_AFTER_SEARCH;
+        if (skipj && j >= (int)p.seed_length - 1 && in_win(j) && in_win(j - (int)kk + 1)) {
+          // the k-mer that ends here is not in the index (the line of end position j + 1 said so): as for an empty entry - i = j,
+          // nothing recorded (GB_END_MATCH: l = 1 < seed_length), `if (i <= 1) break` (bwt.c:292), on to j - 1 in the same pass;
+          // the line number and the diagonal sum roll over this end position too (kroll holds: the lookup at j + 1 set it)
+          skipj = false;
+          if (j <= 1) bk = GB_AFTER_SEARCH;
+          else {
+            const uint32_t cn = win[j - (int)kk + 1 - wq], c1 = win[j - wq];
+            kcode = (kcode - (c1 - 1u) * kpow) * 20u + (cn - 1u);
+            kacc = kacc - diag(cj) + diag(cn);
+            cj = c1;
+            tail += diag(c1); j--;
+          }
+        }
+        if (bk != GB_START_J) {}
+        else if (j < (int)p.seed_length - 1) { skipj = false; bk = GB_AFTER_SEARCH; }
         else if (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1))) {
-          fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;
+          fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;     // (skipj, if set, waits)
         } else if (kk && j >= (int)kk - 1) {
           if (kroll) {
             // from end position j + 1 (letter cj, line kcode = w[j-kk+2 .. j]) to j: w[j] leaves the line's word at its
@@ -4010,14 +4025,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             }
           }
           cj = win[j - wq]; acc = kacc; kroll = true;
-          if (skipj) {
-            // the k-mer that ends here is not in the index (the line of end position j + 1 said so): as for an empty entry -
-            // i = j, nothing recorded (GB_END_MATCH: l = 1 < seed_length, i = j >= kk - 1 > 1), on to j - 1
-            skipj = false;
-            if (j <= 1) bk = GB_AFTER_SEARCH;                                 // (`if (i <= 1) break`, bwt.c:292)
-            else { tail += diag(cj); j--; }
-            continue;
-          }
           kidx = kline_ref(kcode, cj);
           kind = G_KMER; bk = GB_NONE;
         } else {

@@ -99,6 +99,7 @@ def test_mem_locate_by_the_search_lanes(gpu_lib, golden, gidx, oracle, ohandles,
             assert not (hits["flags"] & 0x20000000).any()        # kHitLocPending never leaves the library
 
 
+@pytest.mark.parametrize("mode,seg", CASES)
 def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
     """k_lca: hit records -> 16-byte records on the device; finalize_compact == finalize_hits == reference lines"""
     api = gpu_lib
