@@ -290,17 +290,12 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
   mem_lane2<false>(ix, p, b, wl, ls);
 }
 // the ids of the reads whose longest matches the lanes above left in their hit records (kParamDeferLocate): one lane per read
-#ifdef KJ_LOCATE_PERSIST
-__global__ void __launch_bounds__(256)
-k_mem_locate(DevIndex ix, Params p, Batch b, uint32_t *counter) { mem_locate_lane(ix, p, b, counter); }
-#else
 __global__ void __launch_bounds__(256)
 k_mem_locate(DevIndex ix, Params p, Batch b) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
   if (r >= b.n_reads) return;
   mem_locate_read(ix, p, b.hits + r);
 }
-#endif
 // the same kernel under a second name for the second search of the lazy SEG flow (the few reads whose fragments SEG had
 // to cut), so that a kernel trace lists the full-size launches of k_mem by themselves
 __global__ void __launch_bounds__(kBlock, 4)
@@ -436,17 +431,8 @@ k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue 
   gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
   gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
   gs.prio = s_prio + threadIdx.x * kGPrioStride;
-#ifdef KJ_G_OCC3
   gs.pool = ga.pool; gs.prio_ext = ga.prio_ext; gs.matches = ga.matches; gs.mq_ext = ga.mq_ext; gs.best = ga.best;
   gs.lane = (uint32_t)lane;
-#else
-  gs.pool = ga.pool + lane * (8 * kGSlotsAll);
-  gs.prio_ext = ga.prio_ext + lane * (kGSlotsAll - kGSlots);
-  gs.matches = ga.matches + lane * kGMaxMAll;
-  gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
-  gs.best = ga.best + lane * 64;
-  gs.lane = 0;
-#endif
   gs.gate = ga.gate;
   gs.prof = nullptr;
 #ifdef KJ_PROF
@@ -480,10 +466,8 @@ k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Seg
   gs.gate = ga.gate;
   gs.prof = nullptr;
   gs.lane = 0;
-#ifdef KJ_G_OCC3
   gs.pool = ga.pool; gs.prio_ext = ga.prio_ext; gs.matches = ga.matches; gs.mq_ext = ga.mq_ext; gs.best = ga.best;
   gs.lane = (uint32_t)lane;
-#endif
   greedy_lane2<true>(ix, s_ct, p, sq, b, wl, gs);
 }
 
@@ -1224,11 +1208,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
       if (defer) {
-#ifdef KJ_LOCATE_PERSIST
-        hipLaunchKernelGGL(k_mem_locate, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, cnt + 24);
-#else
         hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
-#endif
         KJ_HIP(hipGetLastError());
       }
       if (exact_pass) {
@@ -1285,9 +1265,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     }
     if (n > 0) {
       Params pg = p;
-#ifdef KJ_G_DEFER_LOCATE
       if (use_g2 && c->defer_locate) pg.flags |= kParamDeferLocate;       // (experiment: reads with one best match -> k_mem_locate)
-#endif
       if (use_g2 && c->count_ops)
         hipLaunchKernelGGL(k_greedy2_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
       else if (use_g2)
@@ -1298,16 +1276,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       KJ_HIP(hipEventRecord(c->ev[3], s));
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
-#ifdef KJ_G_DEFER_LOCATE
       if (pg.flags & kParamDeferLocate) {
-#ifdef KJ_LOCATE_PERSIST
-        hipLaunchKernelGGL(k_mem_locate, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, cnt + 24);
-#else
         hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
-#endif
         KJ_HIP(hipGetLastError());
       }
-#endif
       if (exact_pass) {
         xp.g_pool = gr.pool; xp.g_ord = gr.ord; xp.g_matches = gr.matches; xp.g_best = gr.best; xp.g_bestv = gr.bestv;
         xp.g_pool_cap = gr.pool_cap; xp.g_match_cap = gr.match_cap; xp.blocks_search = c->blocks_retry;

@@ -1975,7 +1975,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // in chunks of consecutive reads (one atomic per chunk, guided chunk size), lanes take reads
 // from the wave's chunk with a ballot/prefix count.
 // ----------------------------------------------------------------------------
-enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT };   // (K_WAIT: -DKJ_MEM_GATE only)
+enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT };
 enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
 
 
@@ -2036,26 +2036,17 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   auto si_frag = [&](uint32_t e) -> uint32_t { return e == 0 ? s0frag : e == 1 ? s1frag : ls.si[e].frag; };
   auto in_win = [&](int pos) -> bool { return pos >= lw.q && pos < lw.q + kWin; };
 
-#ifdef KJ_MEM_ROLL
-  // experiment for round 3: the k-mer index of end position j-1 from that of j (one LDS byte instead of seven);
-  // in round 1 it cost a register too many, the locate state has left the common path since
-  uint32_t roll_cj = 1, roll_pow = 1;
-  bool roll_ok = false;
-  for (uint32_t q = 1; q < kk; q++) roll_pow *= 20u;
-#endif
-#ifdef KJ_MEM_GATE
-  // experiment for round 3: the fragment switches (K_META / K_FRAG / K_FILL: a fifth of the kernel's cycles with
-  // two lanes of 64 active) only in every (KJ_MEM_GATE+1)-th iteration; a lane that needs one waits for it
+  // the fragment switches (K_META / K_FRAG / K_FILL: a fifth of the kernel's cycles with two lanes of 64 active when they run
+  // in every iteration, profiles/r02_gprof) only run in every second iteration; a lane that needs one waits for it (K_WAIT).
+  // Measured (profiles/r03_variants): every 2nd -4.2 %, every 4th -4.0 % of the kernel
+  constexpr uint32_t kMemRareGate = 1u;
   uint32_t gate_it = 0;
-#endif
   for (;;) {
     KJ_PM(PM_HEAD);
-#ifdef KJ_MEM_GATE
-    const bool rare_ok = (gate_it++ & (uint32_t)(KJ_MEM_GATE)) == 0u;
+    const bool rare_ok = (gate_it++ & kMemRareGate) == 0u;
     const int kind_saved = kind;
     const bool parked = !rare_ok && (kind == K_META || kind == K_FRAG || kind == K_FILL);
     if (parked) kind = K_WAIT;
-#endif
     // ---- (0) hand out reads to the lanes that finished one (wave-uniform control flow) ----
     {
       const bool need = kind == K_IDLE;
@@ -2273,9 +2264,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       else bk = BK_START_J;
     }
 
-#ifdef KJ_MEM_GATE
     if (parked) kind = kind_saved;
-#endif
     // ---- (3) bookkeeping, blocks ordered along the usual flow (see mem_lane) ----
     KJ_PM(PM_TAIL);
     while (bk != BK_NONE) {
@@ -2310,10 +2299,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         else if (kk && j >= (int)kk - 1) {
           if (in_win(j) && in_win(j - (int)kk + 1)) {
             // (a rolling update of the index from end position j+1 was tried: it costs a register too many here)
-#ifdef KJ_MEM_ROLL
-            if (roll_ok) kidx = (kidx - (roll_cj - 1u) * roll_pow) * 20u + ((uint32_t)lw.w[j - (int)kk + 1 - lw.q] - 1u);
-            else
-#endif
             if constexpr (WIDE) {
               kidx = 0;
               for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
@@ -2322,15 +2307,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
               for (uint32_t q = 1; q < kk; q++) kidx = kline_code(kidx, lw.w[j - (int)q - lw.q]);
               kidx = kline_ref(kidx, lw.w[j - lw.q]);
             }
-#ifdef KJ_MEM_ROLL
-            roll_cj = lw.w[j - lw.q]; roll_ok = true;
-#endif
             kind = K_KMER; bk = BK_NONE;
           } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
         } else if (in_win(j)) {
-#ifdef KJ_MEM_ROLL
-          roll_ok = false;
-#endif
           c = lw.w[j - lw.q];
           lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];            // InitialSI, bwt.c:146-152
           i = j;
@@ -2347,9 +2326,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         else {
           fcur = f; f++;
           skipj = false;
-#ifdef KJ_MEM_ROLL
-          roll_ok = false;
-#endif
           fsoff = pepoff + dnext.start; flen = (int)dnext.len;
           j = flen - 1;
           fill_top = j; fill_newfrag = true; fill_step = false;
@@ -2492,141 +2468,6 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
   hit->n_ids = nids; hit->flags = flags;
 }
 
-#ifdef KJ_LOCATE_PERSIST
-// experiment for round 3: mem_locate_read as persistent lanes with the load-phase structure of the search
-// lanes - a lane pulls read numbers from a work counter, one hit-record fetch, LF step or SA sample per iteration
-enum MLKind : int { ML_LF1, ML_LF2, ML_SA, ML_FETCH, ML_IDLE, ML_EXIT };
-KJ_HD void mem_locate_lane(const DevIndex &ix, const Params &p, const Batch &b, uint32_t *counter) {
-  int kind = ML_IDLE;
-  uint32_t c = 1, cur = 0, nsi = 0, nids = 0, flags = 0, row = 0, rowend = 0, k = 0;
-  uint64_t e0 = 0, e1 = 0, id0 = 0, sa_idx = 0;
-  bool fresh = true;
-  Hit *hit = nullptr;
-  const uint32_t check = (1u << ix.chpt_exp) - 1u;
-  const uint32_t n_items = b.n_reads;
-  const uint32_t nwaves = kj_nwaves();
-  uint32_t wnext = 0, wend = 0, item = 0;
-  const RankBlock64 *const blk0 = ix.blocks64;
-  auto add_tax = [&](uint64_t tax) {
-    bool dup = false;
-    if (nids >= 1 && tax == id0) dup = true;
-    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
-  };
-  for (;;) {
-    {
-      const bool need = kind == ML_IDLE;
-      const uint64_t mask = kj_ballot(need);
-      if (mask) {
-        const uint32_t n = popc64(mask);
-        const uint32_t rank = kj_rank_below(mask);
-        const uint32_t avail = wend - wnext;
-        uint32_t newbase = 0, ch = 0;
-        if (n > avail) {
-          const uint32_t left = n_items > wend ? n_items - wend : 0;
-          ch = left / (nwaves * 4u);
-          if (ch > 512u) ch = 512u;
-          if (ch < 64u) ch = 64u;
-          if (ch < n - avail) ch = n - avail;
-          const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-          uint32_t got = 0;
-          if (need && rank == 0) got = kj_fetch_chunk(counter, ch);
-          newbase = kj_bcast_uniform(got, leader);
-        }
-        if (need) {
-          item = rank < avail ? wnext + rank : newbase + (rank - avail);
-          kind = item >= n_items ? ML_EXIT : ML_FETCH;
-        }
-        if (n > avail) { wnext = newbase + (n - avail); wend = newbase + ch; }
-        else wnext += n;
-      }
-      if (kj_ballot(kind != ML_EXIT) == 0) break;
-    }
-    const bool is_lf = kind == ML_LF1 || kind == ML_LF2;
-    const uint32_t posA = is_lf ? k : 0;
-    const uint32_t cc = kind == ML_LF2 ? c : 1u;
-    const RankBlock64 *pa = blk0 + (posA >> 6);
-    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
-    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
-    const uint64_t a4 = pa->plane[4];
-    const uint32_t ca = pa->cnt[cc - 1];
-    const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == ML_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
-    const uint32_t goff = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) & 15u);
-    const u128 gv = *reinterpret_cast<const u128 *>(reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
-    // the record's header and the two noted matches behind it (records are 184 bytes: 8-byte aligned)
-    uint64_t h0 = 0, h1 = 0, g2x = 0, g2y = 0;
-    if (kj_ballot(kind == ML_FETCH)) {
-      const uint64_t *q = reinterpret_cast<const uint64_t *>(kind == ML_FETCH ? reinterpret_cast<const uint8_t *>(b.hits + item)
-                                                                              : reinterpret_cast<const uint8_t *>(blk0));
-      h0 = q[0]; h1 = q[1]; g2x = q[2]; g2y = q[3];
-    }
-    int bk = 0;                                              // 1: next match, 2: next row, 3: done
-    if (kind == ML_LF2) {
-      const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
-                     id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
-      const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
-      k = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
-      fresh = false;
-      bk = 2;
-    } else if (kind == ML_LF1) {
-      const uint32_t sft = k & 63u;
-      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
-          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
-      if (c != 0) kind = ML_LF2;
-      else {
-        const uint32_t iseq = (uint32_t)rank_term(ix, k);
-        if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
-        row++; k = row; fresh = true;
-        bk = 2;
-      }
-    } else if (kind == ML_SA) {
-      const uint64_t tax = goff & 8u ? gv.y : gv.x;
-      if (tax != ~0ull) add_tax(tax);
-      row++; k = row; fresh = true;
-      bk = 2;
-    } else if (kind == ML_FETCH) {
-      // Hit: best, n_ids | flags, reserved | taxid[0] | taxid[1]
-      const uint32_t fl0 = (uint32_t)h1;
-      if (!(fl0 & kHitLocPending)) kind = ML_IDLE;
-      else {
-        nsi = (uint32_t)(h0 >> 32);
-        e0 = g2x; e1 = g2y;
-        hit = b.hits + item;
-        nids = 0; flags = fl0 & ~kHitLocPending; cur = 0;
-        bk = 1;
-      }
-    }
-    while (bk) {
-      if (bk == 1) {
-        if (cur >= nsi) bk = 3;
-        else {
-          const uint64_t e = cur == 0 ? e0 : e1;
-          row = (uint32_t)e; rowend = row + (uint32_t)(int32_t)(uint32_t)(e >> 32);
-          cur++; k = row; fresh = true;
-          bk = 2;
-        }
-      }
-      if (bk == 2) {
-        for (;;) {
-          if (row >= rowend) { bk = 1; break; }
-          if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = 3; break; }     // :805-807
-          if ((k & check) != 0) { kind = ML_LF1; bk = 0; break; }
-          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-          if (sa_idx < ix.n_sa) { kind = ML_SA; bk = 0; break; }
-          row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
-        }
-        if (bk == 1) continue;
-      }
-      if (bk == 3) {
-        for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;
-        hit->n_ids = nids; hit->flags = flags;
-        kind = ML_IDLE; bk = 0;
-      }
-    }
-  }
-}
-#endif
 
 // ----------------------------------------------------------------------------
 // Greedy lane: classify_greedyblosum (ConsumerThread.cpp:424-541), maxMatches /
@@ -3096,27 +2937,16 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
 // ----------------------------------------------------------------------------
 #ifdef KJ_G_SMALL                                  // tests: exercise the spill and retry paths
 constexpr int kGMaxM = 1, kGMaxMAll = 2, kGSlots = 1, kGSlotsAll = 3;
-#elif defined(KJ_G_OCC3)                           // experiment: LDS rows small enough for three blocks per CU
+#else                           // experiment: LDS rows small enough for three blocks per CU
 constexpr int kGMaxM = 8, kGMaxMAll = 256;
 constexpr int kGSlots = 12, kGSlotsAll = 128;
-#else
-constexpr int kGMaxM = 24, kGMaxMAll = 256;      // matches of one fragment: lengths in LDS / in LDS + global spill
-constexpr int kGSlots = 44, kGSlotsAll = 128;    // queue slots: priorities in LDS / in LDS + global spill
 #endif
-#ifdef KJ_G_OCC3
 constexpr int kGSubStride = 17;                  // six words of substitutions + eleven of slow-part state
-#else
-constexpr int kGSubStride = 0;
-#endif
 // LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
-#if defined(KJ_G_OCC3) && !defined(KJ_G_SMALL)
+#ifndef KJ_G_SMALL
 constexpr int kGWinStride = 17, kGMqStride = 4, kGPrioStride = 12;     // 132 bytes per lane + 68 (kGSubStride) = 200: three blocks of
                                                                         // 256 lanes + tables = 159 744 of the CU's 163 840 bytes of LDS
-#ifdef KJ_G_OCC3_NOBOUND                           // (developer aid: the register need of the OCC3 code without the bound)
-constexpr int kGreedyWavesPerSimd = 2;
-#else
-constexpr int kGreedyWavesPerSimd = 3;           // (the code under KJ_G_OCC3 fits 168 VGPRs without a spill; the default code needs 247)
-#endif
+constexpr int kGreedyWavesPerSimd = 3;           // (168 VGPRs without a spill; with the slow-part state in registers instead of LDS: 247, two wavefronts)
 #else
 constexpr int kGWinStride = 17, kGMqStride = 13, kGPrioStride = 44;
 constexpr int kGreedyWavesPerSimd = 2;
@@ -3135,8 +2965,8 @@ struct GreedyScratch2 {
   GBest2 *best;                // 64
   uint32_t gate;               // heavy iterations: (iteration & gate) == 0
   unsigned long long *prof;    // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PS_N)
-  uint32_t lane;               // -DKJ_G_OCC3: the device-memory pointers above are the bases of all lanes, this is the lane's number
-  uint32_t *sub;               // -DKJ_G_OCC3: LDS, six words: the substitutions of the variant at hand
+  uint32_t lane;               // the device-memory pointers above are the bases of all lanes, this is the lane's number
+  uint32_t *sub;               // LDS, kGSubStride words: the substitutions of the variant at hand + slow-part state
 };
 
 enum GKind : int { G_STEP, G_KMER, G_LF1, G_LF2, G_SA,                                     // fast
@@ -3148,19 +2978,11 @@ enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_LOC_ROW,                 
 enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 
 // the lane's scratch in device memory: pointers kept per lane, or (three wavefronts per SIMD) recomputed from the lane number
-#ifdef KJ_G_OCC3
 #define GS_POOL (gs.pool + (size_t)gs.lane * (8 * kGSlotsAll))
 #define GS_PRIO_EXT (gs.prio_ext + (size_t)gs.lane * (kGSlotsAll - kGSlots))
 #define GS_MATCHES (gs.matches + (size_t)gs.lane * kGMaxMAll)
 #define GS_MQ_EXT (gs.mq_ext + (size_t)gs.lane * (kGMaxMAll - kGMaxM))
 #define GS_BEST (gs.best + (size_t)gs.lane * 64)
-#else
-#define GS_POOL gs.pool
-#define GS_PRIO_EXT gs.prio_ext
-#define GS_MATCHES gs.matches
-#define GS_MQ_EXT gs.mq_ext
-#define GS_BEST gs.best
-#endif
 template <bool COUNT = false>
 KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                         const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
@@ -3171,35 +2993,22 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   // read
   uint32_t r = 0, nf = 0, fo = 0, fbase = 0;
   uint64_t pepoff = 0;
-#ifdef KJ_G_OCC3
   // (state that only the slow part touches lives in the lane's LDS row: gs.sub[6..14])
   uint32_t &on_start = gs.sub[6], &on_len = gs.sub[7], &on_key = gs.sub[8], &on_flags = gs.sub[9];
   uint32_t &b0lo = gs.sub[10], &b0len = gs.sub[11];
   on_start = on_len = on_key = on_flags = b0lo = b0len = 0;
   uint32_t best = 0, nbest = 0, flags = 0;
-#else
-  uint32_t on_start = 0, on_len = 0, on_key = 0, on_flags = 0;    // original number fo (prefetched)
-  uint32_t best = 0, nbest = 0, flags = 0, b0lo = 0, b0len = 0;
-#endif
   bool ovf = false;
   // queue of variants and SEG pieces
-#ifdef KJ_G_OCC3
   uint32_t &qseq = gs.sub[15], &pslot = gs.sub[16];
   qseq = pslot = 0;
   uint32_t qn = 0, qlive = 0;
-#else
-  uint32_t qn = 0, qlive = 0, qseq = 0, pslot = 0;
-#endif
   // the fragment being searched
   uint32_t t_start = 0, t_len = 0, t_matchlen = 0, t_tot = 0, t_msum = 0, t_nmm = 0;
   int32_t t_diff = 0;
-#ifdef KJ_G_OCC3
   // substituted positions (16 bit) / letters (8 bit): six words of the lane's LDS row (touched by the slow part only)
   uint32_t &sp0 = gs.sub[0], &sp1 = gs.sub[1], &sp2 = gs.sub[2], &sp3 = gs.sub[3], &sa0 = gs.sub[4], &sa1 = gs.sub[5];
   sp0 = sp1 = sp2 = sp3 = sa0 = sa1 = 0;
-#else
-  uint32_t sp0 = 0, sp1 = 0, sp2 = 0, sp3 = 0, sa0 = 0, sa1 = 0;  // substituted positions (16 bit) / letters (8 bit)
-#endif
   int flen = 0, j = 0, i = 0, last_qi = 0;
   P lo = 0, hi = 0;
   uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0;
@@ -3212,28 +3021,15 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   bool ev_done = false;
   uint32_t mx = 0, ml_for = 0;
   // variant generation
-#ifdef KJ_G_OCC3
   uint32_t &vorig = gs.sub[12], &vscore = gs.sub[13], &vlen = gs.sub[14];
   vorig = vscore = vlen = 0;
-#else
-  uint32_t vorig = 0, vscore = 0, vlen = 0;
-#endif
   // locate
   uint32_t cur = 0, nids = 0;
   P row = 0, rowend = 0, k = 0;
-#ifdef KJ_G_OCC3
   uint64_t id0 = 0;
   uint32_t sa_idx = 0;                           // (an index below 2^32 rows has fewer samples than that)
-#else
-  uint64_t id0 = 0, sa_idx = 0;
-#endif
   bool fresh = true;
-#ifdef KJ_G_OCC3
 #define KJ_G_HIT (b.hits + r)                    /* (recomputed: two registers less than a pointer kept per lane) */
-#else
-  Hit *hit = nullptr;
-#define KJ_G_HIT hit
-#endif
   int fill_top = 0, fill_ret = FR_START_J;
   bool fill_pref = false;
 
@@ -3251,14 +3047,14 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   // the lookup.  The line (and the diagonal sum of the k-mer) of end position j-1 follows from that of j
   uint32_t kpow = 1;
   for (uint32_t q = 2; q < kk; q++) kpow *= 20u;            // 20^(kk-2): digit of w[j-1] in the line number
-  uint32_t kacc = 0, kcode = 0;
-  bool kroll = false;                           // kcode / kacc / cj describe end position j+1 of this search
+  uint32_t kacc = 0;                            // (the line number lives in kidx >> 6)
+  bool kroll = false;                           // kidx >> 6 / kacc / cj describe end position j+1 of this search
   bool skipj = false;                           // the k-mer that ends at the next end position (j - 1) is not in the index
   // BLOSUM62 diagonal by index-alphabet code, 4 bits each (values 4..11)
   uint64_t dg0 = 0, dg1 = 0;
   for (int x = 0; x < 16; x++) dg0 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * x);
   for (int x = 16; x < 32; x++) dg1 |= (uint64_t)((uint32_t)ct.diag_idx[x] & 15u) << (4 * (x - 16));
-#if defined(KJ_G_OCC3) && defined(__HIP_DEVICE_COMPILE__)
+#ifdef __HIP_DEVICE_COMPILE__
   // (the same in every lane: scalar registers)
   dg0 = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)dg0) |
         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dg0 >> 32)) << 32;
@@ -3330,27 +3126,16 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       if (row >= rowend) return GB_LOC_NEXT_SI;
       if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; return GB_DONE; }     // :805-807
       if ((k & check) != 0) { kind = G_LF1; return GB_NONE; }
-#ifdef KJ_G_OCC3
       const uint64_t sa64 = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
       sa_idx = (uint32_t)sa64;
       if (sa64 < ix.n_sa) { kind = G_SA; return GB_NONE; }
-#else
-      sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-      if (sa_idx < ix.n_sa) { kind = G_SA; return GB_NONE; }
-#endif
       row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
     }
   };
   auto add_tax = [&](uint64_t tax) {
     bool dup = false;
-#ifdef KJ_G_OCC3
     for (uint32_t q = 0; q < nids && !dup; q++) if (KJ_G_HIT->taxid[q] == tax) dup = true;
     if (!dup && nids < (uint32_t)kMaxIds) KJ_G_HIT->taxid[nids++] = tax;
-#else
-    if (nids >= 1 && tax == id0) dup = true;
-    for (uint32_t q = 1; q < nids && !dup; q++) if (KJ_G_HIT->taxid[q] == tax) dup = true;
-    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; KJ_G_HIT->taxid[nids++] = tax; }
-#endif
   };
 
 #if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
@@ -3553,7 +3338,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             KJ_G_HIT->best = nbest ? best : 0u;
             cur = 0;
             bk = GB_LOC_NEXT_SI;
-#ifdef KJ_G_DEFER_LOCATE
             // experiment for round 3: a read that ends with ONE best match leaves it in the hit record for
             // k_mem_locate, as the MEM lanes do (the locate sections of this lane run with one or two lanes active: 7 % of it)
             if (nbest == 1u && (p.flags & kParamDeferLocate)) {
@@ -3561,7 +3345,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               nids = 1; flags |= kHitLocPending;
               bk = GB_DONE;
             }
-#endif
           }
         }
         if (bk == GB_LOC_NEXT_SI) {
@@ -3669,13 +3452,9 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     // ten 16-byte reads from two lane-chosen places: a window (G_FILL), a queued item (G_POPITEM)
     u128 xa0{0, 0}, xa1{0, 0}, xa2{0, 0}, xa3{0, 0}, xa4{0, 0}, xb0{0, 0}, xb1{0, 0}, xb2{0, 0}, xb3{0, 0}, xb4{0, 0};
     int fq = 0;
-#ifdef KJ_G_OCC3
     // (three wavefronts per SIMD: these reads wait until the lane consumes them, behind the fast compute, when the rank lines
     // of this iteration are dead - a second, exposed wait in heavy iterations for forty registers less at the peak)
     if (false) {
-#else
-    if (heavy && kj_ballot(kind == G_FILL || kind == G_POPITEM)) {            // wave-uniform
-#endif
       KJ_P(PS_LOAD10);
       fq = fill_top - (kWin - 1);
       if (fq < 0) fq = 0;
@@ -3874,9 +3653,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           for (uint32_t s = 0; s < (uint32_t)kGSlots; s++) prio[s] = 0;
         for (uint32_t s = kGSlots; s < qn; s++) GS_PRIO_EXT[s - kGSlots] = 0;
         qn = qlive = qseq = 0;
-#ifndef KJ_G_OCC3
-        hit = b.hits + r;
-#endif
         if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
       } else if (kind == G_FRAG) {
         KJ_P(PS_FRAG);
@@ -3885,7 +3661,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
       } else if (kind == G_FILL || kind == G_POPITEM) {
         KJ_P(PS_FILL);
         bool fill = kind == G_FILL;
-#ifdef KJ_G_OCC3
         fq = fill_top - (kWin - 1);
         if (fq < 0) fq = 0;
         {
@@ -3893,7 +3668,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
           xa0 = s16[0]; xa1 = s16[1]; xa2 = s16[2]; xa3 = s16[3];
         }
-#endif
         u128 f0 = xa0, f1 = xa1, f2 = xa2, f3 = xa3;
         int newq = fq;
         if (!fill) {
@@ -3919,9 +3693,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             if (i <= 0) bk = GB_END_MATCH;
             else if (wtag != 0) {                           // the item carries its window
               fill = true; fill_ret = FR_STEP; fill_pref = false;
-#ifdef KJ_G_OCC3
               { const u128 *w16 = GS_POOL + 8 * pslot + 4; xa4 = w16[0]; xb0 = w16[1]; xb1 = w16[2]; xb2 = w16[3]; }
-#endif
               f0 = xa4; f1 = xb0; f2 = xb1; f3 = xb2; newq = (int)wtag - 1;
             } else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
           }
@@ -3999,7 +3771,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           if (j <= 1) bk = GB_AFTER_SEARCH;
           else {
             const uint32_t cn = win[j - (int)kk + 1 - wq], c1 = win[j - wq];
-            kcode = (kcode - (c1 - 1u) * kpow) * 20u + (cn - 1u);
+            kidx = (((kidx >> 6) - (c1 - 1u) * kpow) * 20u + (cn - 1u)) << 6;
             kacc = kacc - diag(cj) + diag(cn);
             cj = c1;
             tail += diag(c1); j--;
@@ -4010,11 +3782,12 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         else if (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1))) {
           fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;     // (skipj, if set, waits)
         } else if (kk && j >= (int)kk - 1) {
+          uint32_t kcode;
           if (kroll) {
-            // from end position j + 1 (letter cj, line kcode = w[j-kk+2 .. j]) to j: w[j] leaves the line's word at its
+            // from end position j + 1 (letter cj, line kidx >> 6 = w[j-kk+2 .. j]) to j: w[j] leaves the line's word at its
             // most significant digit, w[j-kk+1] enters at the least significant one
             const uint32_t cn = win[j - (int)kk + 1 - wq], c1 = win[j - wq];
-            kcode = (kcode - (c1 - 1u) * kpow) * 20u + (cn - 1u);
+            kcode = ((kidx >> 6) - (c1 - 1u) * kpow) * 20u + (cn - 1u);
             kacc = kacc - diag(cj) + diag(cn);
           } else {
             kcode = 0; kacc = diag(win[j - wq]);

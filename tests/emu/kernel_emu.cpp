@@ -299,27 +299,15 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         uint32_t lds_sub[24];
         for (auto &x : lds_sub) x = 0xdeadbeefu;
         g2.sub = lds_sub;
-#ifdef KJ_G_DEFER_LOCATE
         Params pg = p;
         pg.flags |= kParamDeferLocate;
         greedy_lane2(d, ix->ct, pg, sq, b, wl, g2);
-#else
-        greedy_lane2(d, ix->ct, p, sq, b, wl, g2);
-#endif
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }
   // k_mem_locate (capi.hip): behind the main, the second and the retry search
-#ifdef KJ_G_DEFER_LOCATE
   const bool locate_pass = true;
-#else
-  const bool locate_pass = p.mode == 0;
-#endif
-#ifdef KJ_LOCATE_PERSIST
-  if (locate_pass) { uint32_t lc = 0; mem_locate_lane(d, p, b, &lc); }
-#else
   if (locate_pass) for (uint32_t r = 0; r < n; r++) mem_locate_read(d, p, &hits[r]);
-#endif
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
   if (p.seg && n > 0) {
     std::vector<uint32_t> redo;

@@ -4,14 +4,14 @@
 #   mem_variants.sh build                      here (hipcc cross-compiles; ~35 s per variant)
 #   mem_variants.sh run <outdir> [mode] [n]    on the GPU box: the prepared workload with each library, search times and a
 #                                              checksum of the records (all variants must agree)
-# VARIANTS="base gate1 gate3 roll roll_gate1 locp all3" (default; locp: k_mem_locate as persistent lanes); others: gdefer, gdefer_locp (Greedy: reads with one best
-# match located by k_mem_locate; run with mode greedy), prof (section profiler), g_occ3
+# VARIANTS="cur prof" (default: the current source, the section profiler); add entries to DEF for new experiments.  Round 3
+# measured gate1 / gate3 / roll / locp / gdefer / g_occ3 this way (profiles/r03_variants/): the winners are the default code now
 R=$(cd "$(dirname "$0")/../.." && pwd)
 V=$R/kaiju_amd/variants
 SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-gpu-rdc -Wno-unused-result -w"
-declare -A DEF=( [base]="" [gate1]="-DKJ_MEM_GATE=1" [gate3]="-DKJ_MEM_GATE=3" [roll]="-DKJ_MEM_ROLL" [roll_gate1]="-DKJ_MEM_ROLL -DKJ_MEM_GATE=1" [locp]="-DKJ_LOCATE_PERSIST" [all3]="-DKJ_LOCATE_PERSIST -DKJ_MEM_ROLL -DKJ_MEM_GATE=1" [gdefer]="-DKJ_G_DEFER_LOCATE" [gdefer_locp]="-DKJ_G_DEFER_LOCATE -DKJ_LOCATE_PERSIST" [prof]="-DKJ_PROF" [g_occ3]="-DKJ_G_OCC3" )
-LIST=${VARIANTS:-base gate1 gate3 roll roll_gate1 locp all3}
+declare -A DEF=( [cur]="" [prof]="-DKJ_PROF" [stats]="-DKJ_STATS" )
+LIST=${VARIANTS:-cur prof}
 if [ "$1" = build ]; then
   mkdir -p $V
   for v in $LIST; do
