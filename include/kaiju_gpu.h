@@ -155,6 +155,10 @@ int kaiju_gpu_index_load_ex(const char *fmi_or_image_path, int device_id, int id
    written to a file; kaiju_gpu_index_load() recognises such a file by its magic and uploads it without
    parsing or packing anything.  Needs no GPU. */
 int kaiju_gpu_index_write_image(const char *fmi_path, const char *image_path);
+/* Size in bytes of the .fmi an image was made from (its header remembers it), so that a caller can tell an image of ANOTHER
+   index that merely has a newer time stamp (cp -p, rsync -t, restored backups) from a usable one.  Returns 0 or a negative
+   status (not an image of this version: KAIJU_GPU_ERR_FORMAT). */
+int kaiju_gpu_index_image_source_bytes(const char *image_path, uint64_t *fmi_bytes);
 
 int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info);
 void kaiju_gpu_index_free(kaiju_gpu_index *ix);

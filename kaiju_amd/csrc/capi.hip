@@ -14,6 +14,7 @@
 // There is no CPU fallback: without a HIP device every entry point that needs one fails with
 // KAIJU_GPU_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -294,7 +295,13 @@ __global__ void __launch_bounds__(256)
 k_mem_locate(DevIndex ix, Params p, Batch b) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
   if (r >= b.n_reads) return;
-  mem_locate_read(ix, p, b.hits + r);
+  mem_locate_read<false>(ix, p, b.hits + r);
+}
+__global__ void __launch_bounds__(256)
+k_mem_locate_wide(DevIndex ix, Params p, Batch b) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= b.n_reads) return;
+  mem_locate_read<true>(ix, p, b.hits + r);
 }
 // the same kernel under a second name for the second search of the lazy SEG flow (the few reads whose fragments SEG had
 // to cut), so that a kernel trace lists the full-size launches of k_mem by themselves
@@ -317,6 +324,8 @@ k_mem_wide2(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
+  __shared__ __attribute__((aligned(16))) uint8_t s_coop[(kBlock / 64) * kCoopBytesPerWave];
+  ls.coop = s_coop + (threadIdx.x >> 6) * kCoopBytesPerWave;
   mem_lane2<true>(ix, p, b, wl, ls);
 }
 // counting instantiations (kaiju_gpu_set_count_ops): the same lanes adding up their memory steps (kj_core.h: OpCount);
@@ -340,6 +349,8 @@ k_mem_wide2_count(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, 
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
+  __shared__ __attribute__((aligned(16))) uint8_t s_coop[(kBlock / 64) * kCoopBytesPerWave];
+  ls.coop = s_coop + (threadIdx.x >> 6) * kCoopBytesPerWave;
   if (p.flags & kParamXOrder) mem_lane2<true, true, true>(ix, p, b, wl, ls);
   else mem_lane2<true, false, true>(ix, p, b, wl, ls);
 }
@@ -363,6 +374,8 @@ k_mem_wide2_x(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
+  __shared__ __attribute__((aligned(16))) uint8_t s_coop[(kBlock / 64) * kCoopBytesPerWave];
+  ls.coop = s_coop + (threadIdx.x >> 6) * kCoopBytesPerWave;
   mem_lane2<true, true>(ix, p, b, wl, ls);
 }
 // first-generation lane with 32-bit positions (kept for A/B measurements: KAIJU_GPU_MEM_LANE=v1)
@@ -691,15 +704,13 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   lc.mark("host tables");
   KJ_HIP(hipSetDevice(device_id));
   DevIndex &d = ix->dev;
-  if ((rc = upload(ix.get(), pk.blocks, &d.blocks))) return rc;
-  if ((rc = upload(ix.get(), pk.sb, &d.sb))) return rc;
-  d.sb32 = nullptr;
-  if (!pk.sb32.empty() && (rc = upload(ix.get(), pk.sb32, &d.sb32))) return rc;
-  d.blocks64 = nullptr;
-  if (!pk.blocks64.empty() && (rc = upload(ix.get(), pk.blocks64, &d.blocks64))) return rc;
+  // what goes to HBM per index row: rank blocks 2 B, SA sample (e = 3) 0.5 B of sequence numbers and, on a
+  // narrow index, 1 B of taxon ids
+  if ((rc = upload(ix.get(), pk.blocks64, &d.blocks64))) return rc;
   d.mb_base = nullptr; d.mb_shift = pk.mb_shift;
   if (!pk.mb_base.empty() && (rc = upload(ix.get(), pk.mb_base, &d.mb_base))) return rc;
-  if ((rc = upload(ix.get(), pk.sa_taxid, &d.sa_taxid))) return rc;
+  d.sa_taxid = nullptr;
+  if (!pk.sa_taxid.empty() && (rc = upload(ix.get(), pk.sa_taxid, &d.sa_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.sa_iseq, &d.sa_iseq))) return rc;
   if ((rc = upload(ix.get(), pk.seq_taxid, &d.seq_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.seq_valid, &d.seq_valid))) return rc;
@@ -825,8 +836,18 @@ extern "C" int kaiju_gpu_index_write_image(const char *fmi_path, const char *ima
   if (rc) return fail(rc, msg);
   PackedIndex pk;
   if ((rc = pk.build(f.view(), msg))) return fail(rc, msg);
+  { struct stat st; if (stat(fmi_path, &st) == 0) pk.src_fmi_bytes = (uint64_t)st.st_size; }
   if ((rc = pk.write_image(image_path, msg))) return fail(rc, msg);
   return KAIJU_GPU_OK;
+  });
+}
+
+extern "C" int kaiju_gpu_index_image_source_bytes(const char *image_path, uint64_t *fmi_bytes) {
+  return guarded([&]() -> int {
+  if (!image_path || !fmi_bytes) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  std::string msg;
+  const int rc = PackedIndex::image_source_bytes(image_path, *fmi_bytes, msg);
+  return rc ? fail(rc, msg) : KAIJU_GPU_OK;
   });
 }
 
@@ -1176,14 +1197,14 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       };
       // reads with one or two longest matches are located by k_mem_locate behind the searches (KAIJU_GPU_MEM_LOCATE=inline: by
       // the search lanes themselves, as in round 1)
-      const bool defer = mem_v2 && mem_narrow2 && !xo && c->defer_locate;
+      const bool defer = mem_v2 && !xo && c->defer_locate;
       Params pd = p;
       if (defer) pd.flags |= kParamDeferLocate;
       if (mem_v2) {
         Params pm = pd;
         if (lazy) pm.flags |= kParamLazySeg;
         launch_v2(pm, wl_main, c->count_ops);
-      } else if (ix->dev.sb32)
+      } else if (!ix->dev.mb_base)
         hipLaunchKernelGGL(k_mem_v1, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main, si_main, si_cap, vb);
       else
         hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main, si_main, si_cap, vb);
@@ -1208,7 +1229,8 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
       if (defer) {
-        hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        if (mem_narrow2) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        else hipLaunchKernelGGL(k_mem_locate_wide, grid_reads, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
       }
       if (exact_pass) {

@@ -730,7 +730,10 @@ int main(int argc, char **argv) {
     {
       struct stat sa, sb;
       const std::string img = fmi_fn + ".kjimg";
-      if (stat(fmi_fn.c_str(), &sa) == 0 && stat(img.c_str(), &sb) == 0 && sb.st_mtime >= sa.st_mtime && !getenv("KAIJU_GPU_NO_IMAGE")) load_fn = img;
+      // (usable: not older than the index AND made from a .fmi of this very size - time stamps alone survive cp -p / rsync -t)
+      uint64_t src_bytes = 0;
+      if (stat(fmi_fn.c_str(), &sa) == 0 && stat(img.c_str(), &sb) == 0 && sb.st_mtime >= sa.st_mtime && !getenv("KAIJU_GPU_NO_IMAGE") &&
+          kaiju_gpu_index_image_source_bytes(img.c_str(), &src_bytes) == 0 && src_bytes == (uint64_t)sa.st_size) load_fn = img;
       else if (getenv("KAIJU_GPU_WRITE_IMAGE") && kaiju_gpu_index_write_image(fmi_fn.c_str(), img.c_str()) == 0) load_fn = img;
     }
     rc = kaiju_gpu_index_load_ex(load_fn.c_str(), device, xmode ? KAIJU_GPU_IDS_SEQUENCE : KAIJU_GPU_IDS_TAXON, &index);

@@ -180,13 +180,9 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     if (s < 0 || e > 256 || s > e) { msg = "bad startLcode table"; return KAIJU_GPU_ERR_FORMAT; }
     for (int k = s; k < e; k++) lcode[k] = (uint8_t)a;
   }
-  const uint64_t nblk = (bwtlen >> kBlkShift) + 1;
-  const uint64_t nsb = (bwtlen >> kSbShift) + 1;
-  const uint64_t blk_per_sb = 1ull << (kSbShift - kBlkShift);
+  const uint64_t nsb = (bwtlen >> kSbShift) + 1;            // the host packs in pieces ("superblocks") of 2^kSbShift symbols
   PackClock pc;
-  // (the big arrays are sized without being filled: every element is written below, by the thread that owns its superblock)
-  blocks.clear(); blocks.resize((size_t)nblk);
-  sb.assign((size_t)nsb * 20, 0);
+  std::vector<uint64_t> sb((size_t)nsb * 20, 0);            // C[c] + occurrences of c before every piece (not uploaded)
   pc.mark("allocate rank blocks");
   // pass 1: letter histogram of every superblock
   std::vector<uint64_t> hist((size_t)nsb * 21, 0);
@@ -234,14 +230,11 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       }
     }
   }
-  sb32.clear();
   // KAIJU_GPU_FORCE_WIDE=<shift>: treat the index as one with 64-bit positions (tests of that path on small
   // indexes; the value is the log2 of the rows per count base, 16..31)
   wide = bwtlen >= 0xffffffffull;
   mb_shift = 31;
   if (const char *e = getenv("KAIJU_GPU_FORCE_WIDE")) { wide = true; const int v = atoi(e); if (v >= (int)kSbShift && v <= 31) mb_shift = (uint32_t)v; }
-  sb32.clear();
-  if (!wide) { sb32.resize(sb.size()); for (size_t q = 0; q < sb.size(); q++) sb32[q] = (uint32_t)sb[q]; }
   blocks64.clear(); mb_base.clear();
   const uint64_t nb64 = (bwtlen >> 6) + 1;
   blocks64.resize((size_t)nb64);
@@ -255,8 +248,8 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
   term_pos.clear();
   term_pos.resize((size_t)nseq);
   pc.mark("superblock sums, allocations");
-  // pass 2, one sweep per superblock: the 128-symbol rank blocks (16-bit counts relative to the superblock; first-generation
-  // lanes), the 64-symbol blocks with absolute 32-bit counts (second generation) and the rows of the terminators (rank_term)
+  // pass 2, one sweep per piece: the rank blocks (64 symbols, 32-bit counts: absolute, or relative to mb_base) and the rows of
+  // the terminators (rank_term).  (every element of the big arrays is written here, by the thread that owns its piece)
   parallel_for(nsb, [&](uint64_t s) {
     uint32_t cnt[32] = {0};
     uint64_t abs64[32];
@@ -265,36 +258,26 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       if (wide) abs64[a] -= mb_base[(size_t)((s << kSbShift) >> mb_shift) * 20 + (a - 1)];
     }
     uint64_t *tp = term_pos.data() + term_before[(size_t)s];
-    const uint64_t b0 = s * blk_per_sb, b1 = std::min<uint64_t>(nblk, b0 + blk_per_sb);
+    const uint64_t b0 = s << (kSbShift - 6), b1 = std::min<uint64_t>(nb64, b0 + (1ull << (kSbShift - 6)));
     for (uint64_t bi = b0; bi < b1; bi++) {
-      RankBlock &rb = blocks[(size_t)bi];
-      for (int a = 1; a < 21; a++) rb.cnt[a - 1] = (uint16_t)cnt[a];
-      rb.pad[0] = rb.pad[1] = rb.pad[2] = rb.pad[3] = 0;
-      const uint64_t k0 = bi << kBlkShift;
-      for (uint32_t half = 0; half < 2; half++) {
-        const uint64_t h0 = k0 + 64 * half;
-        const uint64_t b64i = h0 >> 6;
-        uint64_t pl[5] = {0, 0, 0, 0, 0};
-        if (b64i < nb64) {
-          RankBlock64 &r64 = blocks64[(size_t)b64i];
-          for (int a = 1; a < 21; a++) r64.cnt[a - 1] = (uint32_t)(abs64[a] + cnt[a]);
-          r64.pad[0] = r64.pad[1] = 0;
-        }
-        const uint32_t nsym = h0 >= bwtlen ? 0u : (uint32_t)std::min<uint64_t>(64, bwtlen - h0);
-        for (uint32_t t = 0; t < nsym; t++) {
-          const uint32_t c = lcode[bwt[h0 + t]];
-          cnt[c]++;
-          if (c == 0) *tp++ = h0 + t;
-          pl[0] |= (uint64_t)(c & 1u) << t; pl[1] |= (uint64_t)((c >> 1) & 1u) << t; pl[2] |= (uint64_t)((c >> 2) & 1u) << t;
-          pl[3] |= (uint64_t)((c >> 3) & 1u) << t; pl[4] |= (uint64_t)((c >> 4) & 1u) << t;
-        }
-        if (nsym < 64) {                                     // padding (code 31) never matches a letter
-          const uint64_t pad = nsym ? ~0ull << nsym : ~0ull;
-          for (int q = 0; q < 5; q++) pl[q] |= pad;
-        }
-        for (int q = 0; q < 5; q++) rb.plane[q][half] = pl[q];
-        if (b64i < nb64) { RankBlock64 &r64 = blocks64[(size_t)b64i]; for (int q = 0; q < 5; q++) r64.plane[q] = pl[q]; }
+      RankBlock64 &r64 = blocks64[(size_t)bi];
+      for (int a = 1; a < 21; a++) r64.cnt[a - 1] = (uint32_t)(abs64[a] + cnt[a]);
+      r64.pad[0] = r64.pad[1] = 0;
+      const uint64_t h0 = bi << 6;
+      uint64_t pl[5] = {0, 0, 0, 0, 0};
+      const uint32_t nsym = h0 >= bwtlen ? 0u : (uint32_t)std::min<uint64_t>(64, bwtlen - h0);
+      for (uint32_t t = 0; t < nsym; t++) {
+        const uint32_t c = lcode[bwt[h0 + t]];
+        cnt[c]++;
+        if (c == 0) *tp++ = h0 + t;
+        pl[0] |= (uint64_t)(c & 1u) << t; pl[1] |= (uint64_t)((c >> 1) & 1u) << t; pl[2] |= (uint64_t)((c >> 2) & 1u) << t;
+        pl[3] |= (uint64_t)((c >> 3) & 1u) << t; pl[4] |= (uint64_t)((c >> 4) & 1u) << t;
       }
+      if (nsym < 64) {                                       // padding (code 31) never matches a letter
+        const uint64_t pad = nsym ? ~0ull << nsym : ~0ull;
+        for (int q = 0; q < 5; q++) pl[q] |= pad;
+      }
+      for (int q = 0; q < 5; q++) r64.plane[q] = pl[q];
     }
   });
   pc.mark("rank blocks + terminator rows");
@@ -339,16 +322,20 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       seq_taxid[i] = id;
     }
   });
+  // the taxon id of every sampled row (second-generation lanes: the locate ends with ONE load).  Not for the wide layout:
+  // 8 bytes per sample is a byte per row at e = 3 - its lanes read the sequence number and then seq_taxid
   sa_taxid.clear();
-  sa_taxid.resize((size_t)n_sa + 2);
-  sa_taxid[(size_t)n_sa] = sa_taxid[(size_t)n_sa + 1] = ~0ull;
-  parallel_for((n_sa + 65535) / 65536, [&](uint64_t chunk) {
-    const uint64_t b = chunk * 65536, e = std::min<uint64_t>(n_sa, b + 65536);
-    for (uint64_t q = b; q < e; q++) {
-      const uint32_t is = sa_iseq[(size_t)q];
-      sa_taxid[(size_t)q] = (is < nseq && seq_valid[is]) ? seq_taxid[is] : ~0ull;
-    }
-  });
+  if (!wide) {
+    sa_taxid.resize((size_t)n_sa + 2);
+    sa_taxid[(size_t)n_sa] = sa_taxid[(size_t)n_sa + 1] = ~0ull;
+    parallel_for((n_sa + 65535) / 65536, [&](uint64_t chunk) {
+      const uint64_t b = chunk * 65536, e = std::min<uint64_t>(n_sa, b + 65536);
+      for (uint64_t q = b; q < e; q++) {
+        const uint32_t is = sa_iseq[(size_t)q];
+        sa_taxid[(size_t)q] = (is < nseq && seq_valid[is]) ? seq_taxid[is] : ~0ull;
+      }
+    });
+  }
   pc.mark("names, taxon ids");
   {
     // the host builds at most 5 letters; the device grows the table further (capi.hip)
@@ -409,15 +396,16 @@ void PackedIndex::build_klines() {
 
 void PackedIndex::to_sequence_ids() {
   for (uint32_t i = 0; i < nseq; i++) { seq_taxid[i] = i; seq_valid[i] = 3; }
-  for (uint64_t q = 0; q < n_sa; q++) sa_taxid[(size_t)q] = sa_iseq[(size_t)q] < nseq ? (uint64_t)sa_iseq[(size_t)q] : ~0ull;
+  if (!sa_taxid.empty()) for (uint64_t q = 0; q < n_sa; q++) sa_taxid[(size_t)q] = sa_iseq[(size_t)q] < nseq ? (uint64_t)sa_iseq[(size_t)q] : ~0ull;
 }
 
 // ---- device image file: header, then every array as (u64 element count, raw elements) ----
 namespace {
-const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '3'};
+const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '4'};
 struct ImgHeader {
   char magic[8];
-  uint64_t sizes[8];          // sizeof RankBlock, RankBlock64, uint2, ulonglong2 (layout guard) + spare
+  uint64_t sizes[8];          // [0] size in bytes of the .fmi the image was made from, [1..3] sizeof RankBlock64, uint2, ulonglong2
+                              // (layout guard), the rest spare
   uint64_t C[22];
   uint64_t bwtlen, n_sa, sa_skip;
   uint32_t nseq, chpt_exp, alen, warnings, kmer_k, mb_shift_wide;   // mb_shift | wide << 8
@@ -468,14 +456,14 @@ int PackedIndex::write_image(const char *path, std::string &msg) const {
   ImgHeader h;
   memset(&h, 0, sizeof h);
   memcpy(h.magic, kImageMagic, 8);
-  h.sizes[0] = sizeof(RankBlock); h.sizes[1] = sizeof(RankBlock64); h.sizes[2] = sizeof(uint2); h.sizes[3] = sizeof(ulonglong2);
+  h.sizes[0] = src_fmi_bytes; h.sizes[1] = sizeof(RankBlock64); h.sizes[2] = sizeof(uint2); h.sizes[3] = sizeof(ulonglong2);
   memcpy(h.C, C, sizeof C);
   h.bwtlen = bwtlen; h.n_sa = n_sa; h.sa_skip = sa_skip; h.nseq = nseq; h.chpt_exp = chpt_exp; h.alen = alen;
   h.warnings = warnings; h.kmer_k = kmer_k; h.mb_shift_wide = mb_shift | (wide ? 256u : 0u);
   memcpy(h.trans, trans, 128);
   snprintf(h.alphabet, sizeof h.alphabet, "%s", alphabet.c_str());
   bool ok = fwrite(&h, sizeof h, 1, fp) == 1;
-  ok = ok && put_vec(fp, blocks) && put_vec(fp, blocks64) && put_vec(fp, sa_taxid) && put_vec(fp, sb) && put_vec(fp, sb32) &&
+  ok = ok && put_vec(fp, blocks64) && put_vec(fp, sa_taxid) &&
        put_vec(fp, sa_iseq) && put_vec(fp, seq_taxid) && put_vec(fp, seq_valid) && put_vec(fp, term_pos) &&
        put_vec(fp, kmer32) && put_vec(fp, kmer64) && put_vec(fp, mb_base);
   // names: lengths then the characters
@@ -494,10 +482,11 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   ImgReader rd{fd, 0, 0};
   { struct stat st; if (fstat(fd, &st) == 0 && st.st_size > 0) rd.size = (uint64_t)st.st_size; }
   ImgHeader h;
-  bool ok = rd.raw(&h, sizeof h) && memcmp(h.magic, kImageMagic, 8) == 0 && h.sizes[0] == sizeof(RankBlock) &&
+  bool ok = rd.raw(&h, sizeof h) && memcmp(h.magic, kImageMagic, 8) == 0 &&
             h.sizes[1] == sizeof(RankBlock64) && h.sizes[2] == sizeof(uint2) && h.sizes[3] == sizeof(ulonglong2);
   if (!ok) { close(fd); msg = "not a kaiju GPU index image (or written by another version)"; return KAIJU_GPU_ERR_FORMAT; }
   memcpy(C, h.C, sizeof C);
+  src_fmi_bytes = h.sizes[0];
   bwtlen = h.bwtlen; n_sa = h.n_sa; sa_skip = h.sa_skip; nseq = h.nseq; chpt_exp = h.chpt_exp; alen = h.alen;
   warnings = h.warnings; kmer_k = h.kmer_k; mb_shift = h.mb_shift_wide & 255u; wide = (h.mb_shift_wide & 256u) != 0;
   memcpy(trans, h.trans, 128);
@@ -505,7 +494,7 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   alphabet = h.alphabet;
   std::vector<uint32_t> nl;
   std::vector<char> nc;
-  ok = rd.vec(blocks) && rd.vec(blocks64) && rd.vec(sa_taxid) && rd.vec(sb) && rd.vec(sb32) &&
+  ok = rd.vec(blocks64) && rd.vec(sa_taxid) &&
        rd.vec(sa_iseq) && rd.vec(seq_taxid) && rd.vec(seq_valid) && rd.vec(term_pos) &&
        rd.vec(kmer32) && rd.vec(kmer64) && rd.vec(mb_base) && rd.vec(nl) && rd.vec(nc);
   close(fd);
@@ -513,8 +502,8 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   for (uint32_t l : nl) total += l;
   // consistency of what the kernels will index
   ok = ok && total == nc.size() && nl.size() == nseq && seq_taxid.size() == nseq && seq_valid.size() == nseq &&
-       blocks.size() == (size_t)(bwtlen >> 7) + 1 && (blocks64.empty() || blocks64.size() == (size_t)(bwtlen >> 6) + 1) &&
-       sa_iseq.size() >= n_sa && sa_taxid.size() >= n_sa;
+       blocks64.size() == (size_t)(bwtlen >> 6) + 1 && sa_iseq.size() >= n_sa && (wide ? sa_taxid.empty() : sa_taxid.size() >= n_sa) &&
+       (!wide || mb_base.size() == (size_t)((bwtlen >> mb_shift) + 1) * 20);
   if (!ok) { msg = "truncated or inconsistent index image"; return KAIJU_GPU_ERR_FORMAT; }
   names.clear();
   names.resize(nl.size());
@@ -527,16 +516,26 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   return 0;
 }
 
+int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::string &msg) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
+  ImgHeader h;
+  const bool ok = fread(&h, sizeof h, 1, fp) == 1 && memcmp(h.magic, kImageMagic, 8) == 0;
+  fclose(fp);
+  if (!ok) { msg = "not a kaiju GPU index image (or written by another version)"; return KAIJU_GPU_ERR_FORMAT; }
+  bytes = h.sizes[0];
+  return 0;
+}
+
 uint64_t PackedIndex::bytes() const {
-  return blocks.size() * sizeof(RankBlock) + sb.size() * 8 + sa_iseq.size() * 4 + seq_taxid.size() * 8 +
-         seq_valid.size() + term_pos.size() * 8 + kmer32.size() * 8 + kmer64.size() * 16 + sb32.size() * 4 +
-         blocks64.size() * sizeof(RankBlock64) + sa_taxid.size() * 8;
+  return sa_iseq.size() * 4 + seq_taxid.size() * 8 + seq_valid.size() + term_pos.size() * 8 + kmer32.size() * 8 + kmer64.size() * 16 +
+         mb_base.size() * 8 + blocks64.size() * sizeof(RankBlock64) + sa_taxid.size() * 8;
 }
 
 DevIndex PackedIndex::host_view() const {
   DevIndex d;
-  d.blocks64 = blocks64.empty() ? nullptr : blocks64.data(); d.sa_taxid = sa_taxid.data();
-  d.blocks = blocks.data(); d.sb = sb.data(); d.sb32 = sb32.empty() ? nullptr : sb32.data(); d.sa_iseq = sa_iseq.data();
+  d.blocks64 = blocks64.empty() ? nullptr : blocks64.data(); d.sa_taxid = sa_taxid.empty() ? nullptr : sa_taxid.data();
+  d.sa_iseq = sa_iseq.data();
   d.seq_taxid = seq_taxid.data(); d.seq_valid = seq_valid.data(); d.term_pos = term_pos.data();
   for (int a = 0; a < 22; a++) d.C[a] = C[a];
   d.bwtlen = bwtlen; d.n_sa = n_sa; d.sa_skip = sa_skip; d.nseq = nseq; d.chpt_exp = chpt_exp;

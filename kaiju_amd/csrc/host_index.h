@@ -69,14 +69,12 @@ struct FmiFile {
 
 // the packed index in host memory, ready for upload
 struct PackedIndex {
-  BigVec<RankBlock> blocks;
   BigVec<RankBlock64> blocks64;   // second-generation lanes: absolute counts (bwtlen < 2^32) or relative to mb_base
   std::vector<uint64_t> mb_base;       // wide layout: [nmb][20], counts at the start of every 2^mb_shift rows
   uint32_t mb_shift = 0;
   bool wide = false;                   // 64-bit positions (bwtlen >= 2^32, or forced for tests)
   BigVec<uint64_t> sa_taxid;      // taxon id per sampled SA row (~0: unusable name)
-  std::vector<uint64_t> sb;
-  std::vector<uint32_t> sb32;       // copy of sb in 32 bits when bwtlen < 2^32
+  uint64_t src_fmi_bytes = 0;        // size of the .fmi this was packed from (0: not from a file); kept in an image's header
   BigVec<uint32_t> sa_iseq;
   std::vector<uint64_t> seq_taxid;
   std::vector<uint8_t> seq_valid;
@@ -107,6 +105,7 @@ struct PackedIndex {
   // the packed arrays as one file ("device image": written once, loaded instead of parsing and packing the .fmi)
   int write_image(const char *path, std::string &msg) const;
   int read_image(const char *path, std::string &msg);
+  static int image_source_bytes(const char *path, uint64_t &bytes, std::string &msg);   // header field of an image file
 };
 
 // name -> taxon id with the rule of ids_from_SI (ConsumerThread.cpp:809-833)

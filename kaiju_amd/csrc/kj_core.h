@@ -41,27 +41,20 @@ typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 // constants shared with the host
 // ----------------------------------------------------------------------------
 constexpr int kMaxIds = 21;
-constexpr int kSbShift = 16;          // superblock = 65536 symbols
-constexpr int kBlkShift = 7;          // rank block = 128 symbols = 128 bytes
+constexpr int kSbShift = 16;          // host packing works in pieces of 65536 symbols; the wide layout's count bases are multiples
 constexpr uint32_t kHitIdCap = 1u, kHitSiCap = 2u;
 constexpr uint32_t kHitInternalOverflow = 0x80000000u;   // scratch too small even in the retry pass
 constexpr uint32_t kHitRetry = 0x40000000u;              // internal: queued for the retry pass
 constexpr uint32_t kHitLocPending = 0x20000000u;         // internal: the ids are still to be located (mem_locate_read); n_ids = matches noted in taxid[]
 constexpr int kWin = 64, kWinStride = 68;                // per-lane peptide window (bytes / LDS stride)
+constexpr int kLocWideShift = 40;                        // kHitLocPending on a wide index: a match is row | length << 40 ...
+constexpr uint32_t kLocWideMaxLen = 1u << 24;            // ... for lengths below this (others are located by the search lane)
 
-// One rank block: 128 BWT symbols as five bit-planes (2 x 64 bit each) plus the
-// number of occurrences of letters 1..20 between the superblock start and the
-// block start (16 bit is enough: < 65536).  128 bytes, 128-byte aligned.
-struct alignas(128) RankBlock {
-  uint64_t plane[5][2];
-  uint16_t cnt[20];
-  uint16_t pad[4];
-};
-static_assert(sizeof(RankBlock) == 128, "RankBlock must be one 128-byte line");
-
-// Layout used by the MEM kernel for indexes below 2^32 symbols: 64 symbols per 128-byte line,
-// five 64-bit planes + ABSOLUTE 32-bit counts (C[c] folded in) of letters 1..20 before the block.
-// One rank query = 4 load instructions (16+16+8 bytes of planes, 4 bytes of count), no superblock.
+// THE rank structure (all lanes, all index sizes since round 3): 64 symbols per 128-byte line, five 64-bit planes + 32-bit
+// counts (C[c] folded in) of letters 1..20 before the block - absolute for indexes below 2^32 rows, relative to a base every
+// 2^mb_shift rows (DevIndex::mb_base) for larger ones.  One rank query = one line: 16+16+8 bytes of planes, 4 bytes of count.
+// (Round 1-2 also kept a 128-symbol layout with 16-bit counts and superblocks for the first-generation lanes: 0.94 B/row that
+// a refseq-class index has no room for.)
 struct alignas(128) RankBlock64 {
   uint64_t plane[5];
   uint32_t cnt[20];
@@ -74,9 +67,6 @@ struct DevIndex {
   const uint64_t *mb_base;   // "wide" layout (any bwtlen): [nmb][20] counts (C[c] folded in) at the start of every
   uint32_t mb_shift;         //   2^mb_shift rows; nullptr / 0 when the counts in blocks64 are absolute
   const uint64_t *sa_taxid;  // taxon id of every sampled SA row (~0 = unusable name), for the MEM kernel
-  const RankBlock *blocks;   // [(bwtlen >> 7) + 1]
-  const uint64_t *sb;        // [nsb][20]: C[c] + occurrences of c before the superblock
-  const uint32_t *sb32;      // the same in 32 bits when bwtlen < 2^32 (else nullptr)
   const uint32_t *sa_iseq;   // sequence number of every sampled SA row (rows >= nseq)
   const uint64_t *seq_taxid; // taxon id per sequence (rule of ConsumerThread.cpp:809-833)
   const uint8_t *seq_valid;  // 0 where strtoul gave ULONG_MAX
@@ -295,31 +285,76 @@ KJ_HD uint32_t kj_bcast_uniform(uint32_t v, uint32_t) { return v; }
 // P = uint32_t for indexes below 2^32 symbols (half the address/count arithmetic), else uint64_t.
 template <class P>
 KJ_HD P rank_p(const DevIndex &ix, uint32_t c, P k) {
-  const RankBlock *b = ix.blocks + (k >> kBlkShift);
-  const uint32_t r = (uint32_t)k & 127u;
-  uint64_t m0 = ~0ull, m1 = ~0ull;
+  const RankBlock64 &b = ix.blocks64[(uint64_t)k >> 6];
+  uint64_t m = (1ull << ((uint32_t)k & 63u)) - 1ull;
 #pragma unroll
-  for (int p = 0; p < 5; p++) {
-    const uint64_t inv = ((c >> p) & 1u) ? 0ull : ~0ull;
-    m0 &= b->plane[p][0] ^ inv;
-    m1 &= b->plane[p][1] ^ inv;
-  }
-  const uint64_t lm0 = r >= 64 ? ~0ull : ((1ull << r) - 1);
-  const uint64_t lm1 = r > 64 ? ((1ull << (r - 64)) - 1) : 0ull;
-  const uint32_t in_blk = b->cnt[c - 1] + popc64(m0 & lm0) + popc64(m1 & lm1);
-  if (sizeof(P) == 4) return (P)(ix.sb32[(uint32_t)(k >> kSbShift) * 20u + (c - 1)] + in_blk);
-  return (P)(ix.sb[(uint64_t)(k >> kSbShift) * 20 + (c - 1)] + in_blk);
+  for (int p = 0; p < 5; p++) m &= ((c >> p) & 1u) ? b.plane[p] : ~b.plane[p];
+  const uint64_t base = ix.mb_base ? ix.mb_base[(size_t)((uint64_t)k >> ix.mb_shift) * 20 + (c - 1)] : 0ull;
+  return (P)(base + b.cnt[c - 1] + popc64(m));
 }
 KJ_HD uint64_t rank_c(const DevIndex &ix, uint32_t c, uint64_t k) { return rank_p<uint64_t>(ix, c, k); }
 
 KJ_HD uint32_t symbol_at(const DevIndex &ix, uint64_t k) {
-  const RankBlock *b = ix.blocks + (k >> kBlkShift);
-  const uint32_t w = ((uint32_t)k >> 6) & 1u, s = (uint32_t)k & 63u;
+  const RankBlock64 &b = ix.blocks64[k >> 6];
+  const uint32_t s = (uint32_t)k & 63u;
   uint32_t c = 0;
 #pragma unroll
-  for (int p = 0; p < 5; p++) c |= (uint32_t)((b->plane[p][w] >> s) & 1ull) << p;
+  for (int p = 0; p < 5; p++) c |= (uint32_t)((b.plane[p] >> s) & 1ull) << p;
   return c;
 }
+
+// ---- quad-cooperative fetch of rank blocks (wide lanes; DESIGN.md 3.3, profiles/r03_randreach_*.txt) --------------------------
+// On a footprint beyond a few GiB a lane that pulls its rank block with four loads of its own (16 + 16 + 8 + 4 bytes) gets a
+// third of the line rate of one that issues ONE load per line (19 against 38-46 G lines/s): what costs is the number of
+// far-reaching requests in flight, not the bytes.  Here the four lanes of a quad fetch the block of each of them in turn -
+// lane 0..2 the three 16-byte pieces that hold the five bit planes, lane 3 the piece with the count of the letter asked for -
+// straight into LDS (global_load_lds: destination = wave-uniform base + lane * 16, i.e. 64 contiguous bytes per query), one
+// wave instruction = sixteen lines with four lanes each.  Two blocks (the two ends of an interval) per lane and iteration:
+// eight instructions, as before, but a quarter of the distinct requests; the lane then reads its 2 x 52 bytes back from LDS.
+constexpr int kCoopRound = 1040;                   // LDS bytes per round (64 lanes x 16 + 16 of skew against bank conflicts)
+constexpr int kCoopBytesPerWave = 8 * kCoopRound;  // two blocks x four rounds
+struct RankLines { u128 a01, a23; uint64_t a4; uint32_t ca; u128 b01, b23; uint64_t b4; uint32_t cb; };
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int T> KJ_HD uint32_t kj_quad_bcast(uint32_t v) {         // value of lane T of the quad, in all four lanes
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, T * 0x55, 0xf, 0xf, false);
+}
+template <int T> KJ_HD void coop_round(const RankBlock64 *blk0, uint64_t blkA, uint64_t blkB, uint32_t cnt_off, uint8_t *lds_wave) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((address_space(1))) const void glb_void;
+  const uint64_t bA = (uint64_t)kj_quad_bcast<T>((uint32_t)blkA) | (uint64_t)kj_quad_bcast<T>((uint32_t)(blkA >> 32)) << 32;
+  const uint64_t bB = (uint64_t)kj_quad_bcast<T>((uint32_t)blkB) | (uint64_t)kj_quad_bcast<T>((uint32_t)(blkB >> 32)) << 32;
+  const uint32_t co = kj_quad_bcast<T>(cnt_off);
+  const uint32_t l4 = threadIdx.x & 3u;
+  const uint32_t off = l4 < 3u ? l4 * 16u : co;
+  const uint8_t *ga = reinterpret_cast<const uint8_t *>(blk0 + bA) + off, *gb = reinterpret_cast<const uint8_t *>(blk0 + bB) + off;
+  __builtin_amdgcn_global_load_lds((glb_void *)ga, (lds_void *)(lds_wave + T * kCoopRound), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((glb_void *)gb, (lds_void *)(lds_wave + (4 + T) * kCoopRound), 16, 0, 0);
+}
+// blkA / blkB: block numbers of the lane's two queries, cc: its letter (1..20); lds_wave: the wavefront's kCoopBytesPerWave bytes
+KJ_HD void coop_fetch2(const RankBlock64 *blk0, uint64_t blkA, uint64_t blkB, uint32_t cc, uint8_t *lds_wave, RankLines &r) {
+  const uint32_t cnt_at = 40u + 4u * (cc - 1u);                     // byte offset of the count in the block
+  const uint32_t cnt_off = cnt_at > 112u ? 112u : cnt_at;          // the 16 bytes fetched for it stay inside the line
+  coop_round<0>(blk0, blkA, blkB, cnt_off, lds_wave);
+  coop_round<1>(blk0, blkA, blkB, cnt_off, lds_wave);
+  coop_round<2>(blk0, blkA, blkB, cnt_off, lds_wave);
+  coop_round<3>(blk0, blkA, blkB, cnt_off, lds_wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint8_t *ma = lds_wave + (lane & 3u) * kCoopRound + (lane >> 2) * 64u, *mb = ma + 4 * kCoopRound;
+  r.a01 = *reinterpret_cast<const u128 *>(ma); r.a23 = *reinterpret_cast<const u128 *>(ma + 16);
+  r.a4 = *reinterpret_cast<const uint64_t *>(ma + 32);
+  r.ca = *reinterpret_cast<const uint32_t *>(ma + 48 + (cnt_at - cnt_off));
+  r.b01 = *reinterpret_cast<const u128 *>(mb); r.b23 = *reinterpret_cast<const u128 *>(mb + 16);
+  r.b4 = *reinterpret_cast<const uint64_t *>(mb + 32);
+  r.cb = *reinterpret_cast<const uint32_t *>(mb + 48 + (cnt_at - cnt_off));
+}
+#else
+KJ_HD void coop_fetch2(const RankBlock64 *blk0, uint64_t blkA, uint64_t blkB, uint32_t cc, uint8_t *, RankLines &r) {
+  const RankBlock64 *pa = blk0 + blkA, *pb = blk0 + blkB;            // (host emulation: one lane, plain reads)
+  r.a01.x = pa->plane[0]; r.a01.y = pa->plane[1]; r.a23.x = pa->plane[2]; r.a23.y = pa->plane[3]; r.a4 = pa->plane[4]; r.ca = pa->cnt[cc - 1];
+  r.b01.x = pb->plane[0]; r.b01.y = pb->plane[1]; r.b23.x = pb->plane[2]; r.b23.y = pb->plane[3]; r.b4 = pb->plane[4]; r.cb = pb->cnt[cc - 1];
+}
+#endif
 
 // number of terminators in bwt[0, k)  (FMindexCurrent for letter 0; C[0] == 0)
 KJ_HD uint64_t rank_term(const DevIndex &ix, uint64_t k) {
@@ -1645,6 +1680,7 @@ struct LaneScratch {
   uint32_t si_cap;
   uint8_t *win;              // this lane's peptide window (kWin bytes)
   unsigned long long *prof = nullptr;   // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PM_N)
+  uint8_t *coop = nullptr;   // wide lanes: the wavefront's kCoopBytesPerWave bytes of LDS (coop_fetch2; 16-byte aligned, wave-uniform)
 };
 
 struct WorkList {
@@ -2099,19 +2135,29 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       else if (kind == K_FILL) { oc[kOpcFill]++; if (fill_newfrag && f < nf) oc[kOpcFrag]++; }
     }
     const uint32_t cc = (is_step || kind == K_LF2) ? c : 1u;
-    const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
-    const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
-    const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
-    const uint64_t a4 = pa->plane[4];
-    const uint32_t ca = pa->cnt[cc - 1];
-    const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
-    const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
-    const uint64_t b4 = pb->plane[4];
-    // (narrow K_KMER: the second block is not needed - this load fetches the presence bits of the k-mer line instead)
     const bool kline_step = !WIDE && kind == K_KMER;
-    const uint32_t *cbp = &pb->cnt[cc - 1];
-    if (kline_step) cbp = reinterpret_cast<const uint32_t *>(ix.kline + (size_t)(kidx >> 6) * kKLineBytes + kKLinePresent);
-    const uint32_t cb = *cbp;
+    u128 a01, a23, b01, b23;
+    uint64_t a4, b4;
+    uint32_t ca, cb;
+    if constexpr (WIDE) {
+      // the two rank blocks through LDS, fetched by the quad together (coop_fetch2)
+      RankLines rl;
+      coop_fetch2(blk0, (uint64_t)posA >> 6, (uint64_t)posB >> 6, cc, ls.coop, rl);
+      a01 = rl.a01; a23 = rl.a23; a4 = rl.a4; ca = rl.ca; b01 = rl.b01; b23 = rl.b23; b4 = rl.b4; cb = rl.cb;
+    } else {
+      const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
+      a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
+      a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
+      a4 = pa->plane[4];
+      ca = pa->cnt[cc - 1];
+      b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
+      b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
+      b4 = pb->plane[4];
+      // (K_KMER: the second block is not needed - this load fetches the presence bits of the k-mer line instead)
+      const uint32_t *cbp = &pb->cnt[cc - 1];
+      if (kline_step) cbp = reinterpret_cast<const uint32_t *>(ix.kline + (size_t)(kidx >> 6) * kKLineBytes + kKLinePresent);
+      cb = *cbp;
+    }
     uint64_t mba = 0, mbb = 0;                             // WIDE: counts at the start of the 2^mb_shift rows
     if (WIDE) {
       mba = ix.mb_base[(size_t)((uint64_t)posA >> ix.mb_shift) * 20 + (cc - 1)];
@@ -2119,7 +2165,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
     if (kind == K_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
-    else if (kind == K_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    else if (kind == K_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == K_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == K_FILL && fill_newfrag && f < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + f);
@@ -2222,7 +2268,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       }
     } else if (kind == K_SA) {
       KJ_PM(PM_SA);
-      const uint64_t tax = ghalf ? gv.y : gv.x;
+      uint64_t tax;
+      if constexpr (WIDE) {
+        // the wide layout keeps the sequence number of a sampled row (4 bytes), not its taxon id (8): one more, dependent, read
+        const uint32_t q = (uint32_t)sa_idx & 3u;
+        const uint32_t iseq = q == 0 ? (uint32_t)gv.x : q == 1 ? (uint32_t)(gv.x >> 32) : q == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
+        tax = (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
+      } else tax = ghalf ? gv.y : gv.x;
       if (tax != ~0ull) {
         bool dup = false;
         if (nids >= 1 && tax == id0) dup = true;
@@ -2346,13 +2398,16 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           else if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
           else flags = kHitInternalOverflow;
           bk = BK_FINISH;
-        } else if (!WIDE && !XORDER && (p.flags & kParamDeferLocate) && nsi <= 2u) {
+        } else if (!XORDER && (p.flags & kParamDeferLocate) && nsi <= 2u &&
+                   (!WIDE || (s0len < kLocWideMaxLen && (nsi < 2u || s1len < kLocWideMaxLen)))) {
           // the locate walks of 64 different reads share nothing: they run with two or three lanes of a wavefront active
           // (a third of this kernel's time, profiles/r02_gprof).  The matches are noted in the order in which the walk
           // below would visit them (matches of one fragment: found for descending j, visited for ascending j) and
           // k_mem_locate walks them with every lane at work.
           const bool swap = nsi == 2u && s0frag == s1frag;
-          const uint64_t e0 = (uint64_t)(uint32_t)s0lo | (uint64_t)s0len << 32, e1 = (uint64_t)(uint32_t)s1lo | (uint64_t)s1len << 32;
+          // (narrow: row | length << 32; wide: row | length << 40, lengths below 2^24)
+          const uint64_t e0 = WIDE ? ((uint64_t)s0lo | (uint64_t)s0len << kLocWideShift) : ((uint64_t)(uint32_t)s0lo | (uint64_t)s0len << 32);
+          const uint64_t e1 = WIDE ? ((uint64_t)s1lo | (uint64_t)s1len << kLocWideShift) : ((uint64_t)(uint32_t)s1lo | (uint64_t)s1len << 32);
           hit->taxid[0] = swap ? e1 : e0;
           if (nsi == 2u) hit->taxid[1] = swap ? e0 : e1;
           nids = nsi; flags = kHitLocPending;
@@ -2418,12 +2473,14 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 // The ids of a read whose longest matches mem_lane2 left in its hit record (kHitLocPending): ids_from_SI for every match in
 // turn (ConsumerThread.cpp:799-845; get_suffix bwt.c:105-121, FMindexCurrent compactfmi.c:312-336) - the same steps as
 // BK_LOC_ROW / K_LF1 / K_LF2 / K_SA of the lane, one read per lane, narrow index.
+template <bool WIDE>
 KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
+  typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   const uint32_t fl0 = hit->flags;
   if (!(fl0 & kHitLocPending)) return;
   const uint32_t nsi = hit->n_ids;
   const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
-  const uint32_t check = (1u << ix.chpt_exp) - 1u;
+  const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
   uint32_t nids = 0, flags = fl0 & ~kHitLocPending;          // (a Greedy read may carry kHitSiCap already)
   uint64_t id0 = 0;
@@ -2435,19 +2492,25 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
   };
   bool done = false;
   for (uint32_t s = 0; s < nsi && !done; s++) {
-    const uint32_t lo = (uint32_t)e[s], len = (uint32_t)(e[s] >> 32);
-    const uint32_t rowend = lo + (uint32_t)(int32_t)len;
-    for (uint32_t row = lo; row < rowend; row++) {
+    const P lo = WIDE ? (P)(e[s] & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)e[s];
+    const uint32_t len = WIDE ? (uint32_t)(e[s] >> kLocWideShift) : (uint32_t)(e[s] >> 32);
+    const P rowend = lo + (P)(int32_t)len;
+    for (P row = lo; row < rowend; row++) {
       if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; break; }     // :805-807
-      uint32_t k = row;
+      P k = row;
       for (;;) {
         if ((k & check) == 0) {
           const uint64_t sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-          if (sa_idx < ix.n_sa) { const uint64_t tax = ix.sa_taxid[sa_idx]; if (tax != ~0ull) add_tax(tax); }
+          if (sa_idx < ix.n_sa) {
+            uint64_t tax;
+            if constexpr (WIDE) { const uint32_t iseq = ix.sa_iseq[sa_idx]; tax = (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull; }
+            else tax = ix.sa_taxid[sa_idx];
+            if (tax != ~0ull) add_tax(tax);
+          }
           break;                                           // (beyond the samples the reference reads out of bounds: the row is skipped)
         }
         const RankBlock64 &rb = blk0[k >> 6];
-        const uint32_t sft = k & 63u;
+        const uint32_t sft = (uint32_t)k & 63u;
         const uint32_t c = (uint32_t)((rb.plane[0] >> sft) & 1ull) | (uint32_t)((rb.plane[1] >> sft) & 1ull) << 1 |
                            (uint32_t)((rb.plane[2] >> sft) & 1ull) << 2 | (uint32_t)((rb.plane[3] >> sft) & 1ull) << 3 |
                            (uint32_t)((rb.plane[4] >> sft) & 1ull) << 4;
@@ -2460,7 +2523,10 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
         const uint64_t ia = (c & 1u) ? 0ull : ~0ull, ib = (c & 2u) ? 0ull : ~0ull, ic = (c & 4u) ? 0ull : ~0ull,
                        id = (c & 8u) ? 0ull : ~0ull, ie = (c & 16u) ? 0ull : ~0ull;
         const uint64_t m = (rb.plane[0] ^ ia) & (rb.plane[1] ^ ib) & (rb.plane[2] ^ ic) & (rb.plane[3] ^ id) & (rb.plane[4] ^ ie);
-        k = rb.cnt[c - 1u] + popc64(m & ((1ull << sft) - 1ull));         // k = C[c] + rank(c, k): the counts are absolute
+        // k = C[c] + rank(c, k): the counts are absolute, or (wide) relative to the base of the row's 2^mb_shift rows
+        uint64_t base = 0;
+        if constexpr (WIDE) base = ix.mb_base[(size_t)((uint64_t)k >> ix.mb_shift) * 20 + (c - 1u)];
+        k = (P)(base + rb.cnt[c - 1u] + popc64(m & ((1ull << sft) - 1ull)));
       }
     }
   }

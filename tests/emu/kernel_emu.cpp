@@ -5,6 +5,7 @@
 // index, fragment construction, SEG, MEM and Greedy state machines) against the oracle on a
 // machine without a GPU.  This library is built and loaded by tests only; the product
 // library (libkaiju_gpu.so) contains no CPU path and fails loudly without a HIP device.
+#include <sys/stat.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -214,7 +215,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       };
       if (mem_v2 && pass == 0) {
         // (capi.hip: the ids of reads with one or two longest matches are located by k_mem_locate behind the searches)
-        const bool defer = d.kmer32 && !xo && !getenv("KAIJU_EMU_LOCATE_INLINE");
+        const bool defer = !xo && !getenv("KAIJU_EMU_LOCATE_INLINE");
         Params pd = p;
         if (defer) pd.flags |= kParamDeferLocate;
         Params pm = pd;
@@ -273,7 +274,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
           if (getenv("KAIJU_EMU_PRINT_LAZY")) fprintf(stderr, "[emu] lazy SEG: %u of %u reads listed\n", nlist, n);
         }
       }
-      else if (d.sb32 && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls, g_vb);
+      else if (!d.mb_base && !(v && !strcmp(v, "wide")) && pass == 0) mem_lane<uint32_t>(d, p, b, wl, ls, g_vb);
       else mem_lane<uint64_t>(d, p, b, wl, ls, g_vb);
     } else {
       GreedyScratch gs;
@@ -307,7 +308,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   }
   // k_mem_locate (capi.hip): behind the main, the second and the retry search
   const bool locate_pass = true;
-  if (locate_pass) for (uint32_t r = 0; r < n; r++) mem_locate_read(d, p, &hits[r]);
+  if (locate_pass) for (uint32_t r = 0; r < n; r++) { if (d.mb_base) mem_locate_read<true>(d, p, &hits[r]); else mem_locate_read<false>(d, p, &hits[r]); }
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
   if (p.seg && n > 0) {
     std::vector<uint32_t> redo;
@@ -379,11 +380,13 @@ extern "C" int emu_image_roundtrip(const char *fmi, const char *image) {
   if (f.load(fmi, msg)) return -1;
   PackedIndex a, b;
   if (a.build(f.view(), msg)) return -2;
+  { struct stat st; if (stat(fmi, &st) == 0) a.src_fmi_bytes = (uint64_t)st.st_size; }     // (as kaiju_gpu_index_write_image does)
   if (a.write_image(image, msg)) return -3;
   if (b.read_image(image, msg)) return -4;
+  if (a.src_fmi_bytes != b.src_fmi_bytes) return 4;
   auto same = [](const auto &x, const auto &y) { return x.size() == y.size() && (x.empty() || !memcmp(x.data(), y.data(), x.size() * sizeof(x[0]))); };
-  if (!same(a.blocks, b.blocks) || !same(a.blocks64, b.blocks64) || !same(a.sa_taxid, b.sa_taxid) || !same(a.sb, b.sb) ||
-      !same(a.sb32, b.sb32) || !same(a.sa_iseq, b.sa_iseq) || !same(a.seq_taxid, b.seq_taxid) || !same(a.seq_valid, b.seq_valid) ||
+  if (!same(a.blocks64, b.blocks64) || !same(a.sa_taxid, b.sa_taxid) ||
+      !same(a.sa_iseq, b.sa_iseq) || !same(a.seq_taxid, b.seq_taxid) || !same(a.seq_valid, b.seq_valid) ||
       !same(a.term_pos, b.term_pos) || !same(a.kmer32, b.kmer32) || !same(a.kmer64, b.kmer64) || !same(a.mb_base, b.mb_base)) return 1;
   if (a.names != b.names || a.alphabet != b.alphabet || memcmp(a.C, b.C, sizeof a.C) || memcmp(a.trans, b.trans, 128)) return 2;
   if (a.bwtlen != b.bwtlen || a.n_sa != b.n_sa || a.sa_skip != b.sa_skip || a.nseq != b.nseq || a.chpt_exp != b.chpt_exp ||
