@@ -161,6 +161,23 @@ int kaiju_gpu_index_write_image(const char *fmi_path, const char *image_path);
 int kaiju_gpu_index_image_source_bytes(const char *image_path, uint64_t *fmi_bytes);
 
 int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info);
+
+/* What the index occupies in HBM, array by array (bytes).  Per index row: rank blocks 2 B; suffix-array sample at exponent e:
+   4 / 2^e B of sequence numbers and - indexes below 2^32 rows only - 8 / 2^e B of taxon ids; the k-mer table and its lines
+   do not grow with the index (20^k entries).  A refseq-class index (58 G rows, e = 3) is 2.5 B per row = 145 GB + tables. */
+typedef struct kaiju_gpu_index_footprint {
+  uint64_t rank_blocks;   /* RankBlock64 lines: five bit planes + twenty counts per 64 rows                                */
+  uint64_t count_bases;   /* wide layout: the 64-bit counts at the start of every 2^31 rows                               */
+  uint64_t sa_seq;        /* sequence number of every sampled suffix-array row                                            */
+  uint64_t sa_taxid;      /* taxon id of every sampled row (narrow indexes)                                               */
+  uint64_t seq_tables;    /* per database sequence: taxon id, validity, row of its terminator                             */
+  uint64_t kmer_table;    /* suffix interval of every k-letter word                                                       */
+  uint64_t kmer_lines;    /* the same as 128-byte lines for two end positions each (narrow indexes)                       */
+  uint64_t other;         /* constant tables                                                                              */
+  uint64_t total;
+  uint32_t kmer_k, wide;  /* k of the table; 1 = 64-bit positions                                                         */
+} kaiju_gpu_index_footprint;
+int kaiju_gpu_index_get_footprint(const kaiju_gpu_index *ix, kaiju_gpu_index_footprint *out);
 void kaiju_gpu_index_free(kaiju_gpu_index *ix);
 
 /* ---- classification -------------------------------------------------- */

@@ -35,6 +35,14 @@ class IndexInfo(C.Structure):
                 ("alphabet", C.c_char * 64)]
 
 
+class IndexFootprint(C.Structure):        # kaiju_gpu_index_footprint
+    _fields_ = [(k, C.c_uint64) for k in ("rank_blocks", "count_bases", "sa_seq", "sa_taxid", "seq_tables", "kmer_table",
+                                          "kmer_lines", "other", "total")] + [("kmer_k", C.c_uint32), ("wide", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
 class Stats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_seg_fragments", C.c_uint64), ("n_overflow_retries", C.c_uint64),
                 ("error_flags", C.c_uint64),
@@ -71,6 +79,8 @@ def lib():
     L.kaiju_gpu_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.kaiju_gpu_index_get_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
     L.kaiju_gpu_index_free.argtypes = [C.c_void_p]
+    if hasattr(L, "kaiju_gpu_index_get_footprint"):        # (an older build loaded through KAIJU_GPU_LIB for an A/B run has none)
+        L.kaiju_gpu_index_get_footprint.argtypes = [C.c_void_p, C.POINTER(IndexFootprint)]
     L.kaiju_gpu_default_params.argtypes = [C.POINTER(Params), C.c_int]
     L.kaiju_gpu_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(Params)]
     L.kaiju_gpu_destroy.argtypes = [C.c_void_p]
@@ -136,6 +146,9 @@ class Index:
         _check(L.kaiju_gpu_index_load_ex(fmi_path.encode(), device, id_mode, C.byref(self._h)))
         self.info = IndexInfo()
         _check(lib().kaiju_gpu_index_get_info(self._h, C.byref(self.info)))
+        self.footprint = IndexFootprint()
+        if hasattr(lib(), "kaiju_gpu_index_get_footprint"):
+            _check(lib().kaiju_gpu_index_get_footprint(self._h, C.byref(self.footprint)))
         self.device = device
 
     @property

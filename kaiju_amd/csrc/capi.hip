@@ -614,6 +614,7 @@ struct kaiju_gpu_index {
   double *d_lnfact = nullptr;
   std::vector<void *> allocs;
   kaiju_gpu_index_info info{};
+  kaiju_gpu_index_footprint fp{};
   std::vector<std::string> names;
   int id_mode = 0;                // KAIJU_GPU_IDS_TAXON / KAIJU_GPU_IDS_SEQUENCE
   ~kaiju_gpu_index() {
@@ -809,6 +810,28 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   inf.chpt_exp = (int32_t)pk.chpt_exp;
   inf.db_length = (double)((int64_t)pk.bwtlen - (int64_t)pk.nseq);   // Config.cpp:20
   inf.device_bytes = pk.bytes() + kmer_bytes;
+  {
+    kaiju_gpu_index_footprint &f = ix->fp;
+    f.rank_blocks = pk.blocks64.size() * sizeof(RankBlock64);
+    f.count_bases = pk.mb_base.size() * 8;
+    f.sa_seq = pk.sa_iseq.size() * 4;
+    f.sa_taxid = pk.sa_taxid.size() * 8;
+    f.seq_tables = pk.seq_taxid.size() * 8 + pk.seq_valid.size() + pk.term_pos.size() * 8;
+    uint64_t nw = 1;
+    for (uint32_t q = 0; q < d.kmer_k; q++) nw *= 20;
+    f.kmer_table = d.kmer_k ? nw * (d.kmer64 ? sizeof(ulonglong2) : sizeof(uint2)) : 0;
+    f.kmer_lines = d.kline ? nw / 20 * kKLineBytes : 0;
+    f.other = sizeof(ConstTables) + sizeof(Stage1Tables) + lnfact.size() * 8;
+    f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other;
+    f.kmer_k = d.kmer_k; f.wide = d.mb_base ? 1u : 0u;
+    inf.device_bytes = f.total;
+    if (getenv("KAIJU_GPU_LOAD_TIMES"))
+      fprintf(stderr, "[kaiju_gpu load] HBM: rank blocks %.2f GB, count bases %.3f GB, SA sample %.2f (sequence numbers) + %.2f (taxon ids) GB, "
+                      "sequence tables %.2f GB, k = %u table %.2f GB + lines %.2f GB; %.2f B per index row without the k-mer tables\n",
+              f.rank_blocks * 1e-9, f.count_bases * 1e-9, f.sa_seq * 1e-9, f.sa_taxid * 1e-9, f.seq_tables * 1e-9, f.kmer_k,
+              f.kmer_table * 1e-9, f.kmer_lines * 1e-9,
+              (double)(f.total - f.kmer_table - f.kmer_lines) / (double)(pk.bwtlen ? pk.bwtlen : 1));
+  }
   inf.warnings = pk.warnings;
   snprintf(inf.alphabet, sizeof inf.alphabet, "%s", pk.alphabet.c_str());
   ix->names.swap(pk.names);
@@ -901,6 +924,11 @@ extern "C" int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *hv, int dev
 extern "C" int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info) {
   if (!ix || !info) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   *info = ix->info;
+  return KAIJU_GPU_OK;
+}
+extern "C" int kaiju_gpu_index_get_footprint(const kaiju_gpu_index *ix, kaiju_gpu_index_footprint *out) {
+  if (!ix || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  *out = ix->fp;
   return KAIJU_GPU_OK;
 }
 extern "C" void kaiju_gpu_index_free(kaiju_gpu_index *ix) { delete ix; }

@@ -99,18 +99,25 @@ def bench(W, out=None):
     reads = np.load(f"{W}/reads.npy")
     pairs = np.load(f"{W}/pairs.npy")
     result = {"index": {"bwtlen": int(index.info.bwtlen), "rows_over_2_32": index.info.bwtlen / 2 ** 32, "nseq": nseq,
-                        "fmi_bytes": os.path.getsize(f"{W}/db.fmi"), "hbm_bytes": int(index.info.device_bytes)}}
+                        "fmi_bytes": os.path.getsize(f"{W}/db.fmi"), "hbm_bytes": int(index.info.device_bytes),
+                        "footprint": index.footprint.as_dict() if hasattr(index, "footprint") else None}}
+    legs = os.environ.get("WIDE_LEGS", "mem,greedy,paired").split(",")
     for name, mode, rd, pe in (("mem", "mem", reads, False), ("greedy", "greedy", reads, False), ("paired", "mem", pairs, True)):
+        if name not in legs:
+            continue
         leg = B.Leg(name, mode, pe, rd, 150, index, dtax, dev, 0, 1, 1, 1_500_000, 0)
         leg.run(2, 1)
         ref_ops = None
         bl = par = None
         try:
+            if os.environ.get("WIDE_NO_REF"):
+                raise RuntimeError("reference leg switched off (WIDE_NO_REF)")
             blr, ref = B.run_reference(W, f"{W}/db.fmi", f"{W}/nodes.dmp", rd, 150, pe, mode, 1, 200000)
             bl = blr
             if ref is not None:
-                cls, tax, _ = leg.host_records(len(ref[0]))
-                badidx = np.nonzero((cls != ref[0]) | (tax != ref[1]))[0]
+                cls, tax, rec = leg.host_records(len(ref[0]))
+                best = rec["best"].astype(np.int64)
+                badidx = np.nonzero((cls != ref[0]) | (tax != ref[1]) | ((ref[0] != 0) & (best != ref[2])))[0]
                 par = {"checked": int(len(ref[0])), "mismatches": int(len(badidx))}
         except Exception as e:  # noqa: BLE001
             print("[wide] reference leg failed:", repr(e), flush=True)
