@@ -427,10 +427,12 @@ k_greedy_retry(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQ
 struct GreedyArrays2 {
   u128 *pool; uint32_t *prio_ext; GMatch2 *matches; uint16_t *mq_ext; GBest2 *best;
   uint32_t gate;
+  GBest2W *bestw;                // wide indexes: best is nullptr then
 };
 constexpr size_t kGreedy2Lds = (size_t)kBlock * (kGWinStride + kGMqStride + kGPrioStride + kGSubStride) * 4 + sizeof(ConstTables);
-__global__ void __launch_bounds__(kBlock, kGreedyWavesPerSimd)
-k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+template <bool COUNT, bool WIDE>
+__device__ __forceinline__ void greedy2_body(const DevIndex &ix, const ConstTables *__restrict__ g_ct, const Params &p, const SegQueue &sq,
+                                             const Batch &b, const WorkList &wl, const GreedyArrays2 &ga) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   uint32_t *s_prio = s_dyn;                                   // 16-byte aligned rows
   uint32_t *s_win = s_prio + kBlock * kGPrioStride;
@@ -444,44 +446,37 @@ k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue 
   gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
   gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
   gs.prio = s_prio + threadIdx.x * kGPrioStride;
-  gs.pool = ga.pool; gs.prio_ext = ga.prio_ext; gs.matches = ga.matches; gs.mq_ext = ga.mq_ext; gs.best = ga.best;
+  // (the device-memory scratch as bases of all lanes: the lane computes its own pieces from its number)
+  gs.pool = ga.pool; gs.prio_ext = ga.prio_ext; gs.matches = ga.matches; gs.mq_ext = ga.mq_ext; gs.best = ga.best; gs.bestw = ga.bestw;
   gs.lane = (uint32_t)lane;
   gs.gate = ga.gate;
   gs.prof = nullptr;
 #ifdef KJ_PROF
   __shared__ unsigned long long s_prof[kBlock / 64][2 + 3 * PS_N];
-  for (int x = threadIdx.x & 63; x < 2 + 3 * PS_N; x += 64) s_prof[threadIdx.x >> 6][x] = 0;
-  gs.prof = s_prof[threadIdx.x >> 6];
-  if ((threadIdx.x & 63) == 0) { gs.prof[0] = __builtin_readcyclecounter(); gs.prof[1] = PS_HEAD; }
+  if constexpr (!COUNT) {
+    for (int x = threadIdx.x & 63; x < 2 + 3 * PS_N; x += 64) s_prof[threadIdx.x >> 6][x] = 0;
+    gs.prof = s_prof[threadIdx.x >> 6];
+    if ((threadIdx.x & 63) == 0) { gs.prof[0] = __builtin_readcyclecounter(); gs.prof[1] = PS_HEAD; }
+  }
 #endif
-  greedy_lane2(ix, s_ct, p, sq, b, wl, gs);
+  greedy_lane2<COUNT, WIDE>(ix, s_ct, p, sq, b, wl, gs);
+}
+__global__ void __launch_bounds__(kBlock, kGreedyWavesPerSimd)
+k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+  greedy2_body<false, false>(ix, g_ct, p, sq, b, wl, ga);
 }
 __global__ void __launch_bounds__(kBlock, 1)
 k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  uint32_t *s_prio = s_dyn;
-  uint32_t *s_win = s_prio + kBlock * kGPrioStride;
-  uint32_t *s_mq = s_win + kBlock * kGWinStride;
-  uint32_t *s_sub = s_mq + kBlock * kGMqStride;
-  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_sub + kBlock * kGSubStride);
-  load_tables(s_ct, g_ct);
-  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  GreedyScratch2 gs;
-  gs.sub = s_sub + threadIdx.x * kGSubStride;
-  gs.win = reinterpret_cast<uint8_t *>(s_win + threadIdx.x * kGWinStride);
-  gs.mq = reinterpret_cast<uint16_t *>(s_mq + threadIdx.x * kGMqStride);
-  gs.prio = s_prio + threadIdx.x * kGPrioStride;
-  gs.pool = ga.pool + lane * (8 * kGSlotsAll);
-  gs.prio_ext = ga.prio_ext + lane * (kGSlotsAll - kGSlots);
-  gs.matches = ga.matches + lane * kGMaxMAll;
-  gs.mq_ext = ga.mq_ext + lane * (kGMaxMAll - kGMaxM);
-  gs.best = ga.best + lane * 64;
-  gs.gate = ga.gate;
-  gs.prof = nullptr;
-  gs.lane = 0;
-  gs.pool = ga.pool; gs.prio_ext = ga.prio_ext; gs.matches = ga.matches; gs.mq_ext = ga.mq_ext; gs.best = ga.best;
-  gs.lane = (uint32_t)lane;
-  greedy_lane2<true>(ix, s_ct, p, sq, b, wl, gs);
+  greedy2_body<true, false>(ix, g_ct, p, sq, b, wl, ga);
+}
+// the same lane with 64-bit positions: indexes of 2^32 rows and more (the k-mer table instead of the lines)
+__global__ void __launch_bounds__(kBlock, 2)
+k_greedy2_wide(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+  greedy2_body<false, true>(ix, g_ct, p, sq, b, wl, ga);
+}
+__global__ void __launch_bounds__(kBlock, 1)
+k_greedy2_wide_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+  greedy2_body<true, true>(ix, g_ct, p, sq, b, wl, ga);
 }
 
 // Index load: the k-mer table one letter deeper.  child[idx * 20 + c - 1] = UpdateSI(parent[idx], c)
@@ -1043,8 +1038,9 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   int occ = 0;
   if (p->mode == 0) KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mem, kBlock, 0));
   else {
-    c->greedy2 = ix->dev.blocks64 && ix->dev.kline && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p->seed_length &&
-                 p->seed_length >= 3;
+    const bool g_wide = ix->dev.mb_base != nullptr;
+    c->greedy2 = ix->dev.blocks64 && (g_wide ? ix->dev.kmer64 != nullptr : ix->dev.kline != nullptr) && ix->dev.kmer_k >= 2 &&
+                 ix->dev.kmer_k <= p->seed_length && p->seed_length >= 3;
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; }
     if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (c->greedy_gate & ~0xffu) | (uint32_t)v; }
     // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
@@ -1054,7 +1050,12 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
                                  (int)kGreedy2Lds));
       KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2_count), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kGreedy2Lds));
-      KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy2, kBlock, kGreedy2Lds));
+      KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2_wide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kGreedy2Lds));
+      KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2_wide_count), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kGreedy2Lds));
+      if (g_wide) KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy2_wide, kBlock, kGreedy2Lds));
+      else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy2, kBlock, kGreedy2Lds));
     } else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy, kBlock, 0));
   }
   if (occ < 1) occ = 1;
@@ -1307,16 +1308,23 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       if ((rc = ensure(c->scratch_main[6], lanes_main * (kGSlotsAll - kGSlots) * sizeof(uint32_t)))) return rc;
       if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
       if ((rc = ensure(c->scratch_main[8], lanes_main * (kGMaxMAll - kGMaxM) * sizeof(uint16_t)))) return rc;
-      if ((rc = ensure(c->scratch_main[9], lanes_main * 64 * sizeof(GBest2)))) return rc;
+      const bool g_wide = ix->dev.mb_base != nullptr;
+      if ((rc = ensure(c->scratch_main[9], lanes_main * 64 * (g_wide ? sizeof(GBest2W) : sizeof(GBest2))))) return rc;
       g2.pool = static_cast<u128 *>(c->scratch_main[5].p); g2.prio_ext = static_cast<uint32_t *>(c->scratch_main[6].p);
       g2.matches = static_cast<GMatch2 *>(c->scratch_main[7].p); g2.mq_ext = static_cast<uint16_t *>(c->scratch_main[8].p);
-      g2.best = static_cast<GBest2 *>(c->scratch_main[9].p);
+      g2.best = g_wide ? nullptr : static_cast<GBest2 *>(c->scratch_main[9].p);
+      g2.bestw = g_wide ? static_cast<GBest2W *>(c->scratch_main[9].p) : nullptr;
       g2.gate = c->greedy_gate;
     }
     if (n > 0) {
       Params pg = p;
       if (use_g2 && c->defer_locate) pg.flags |= kParamDeferLocate;       // (experiment: reads with one best match -> k_mem_locate)
-      if (use_g2 && c->count_ops)
+      const bool g_wide = ix->dev.mb_base != nullptr;
+      if (use_g2 && c->count_ops && g_wide)
+        hipLaunchKernelGGL(k_greedy2_wide_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
+      else if (use_g2 && g_wide)
+        hipLaunchKernelGGL(k_greedy2_wide, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
+      else if (use_g2 && c->count_ops)
         hipLaunchKernelGGL(k_greedy2_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
       else if (use_g2)
         hipLaunchKernelGGL(k_greedy2, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
@@ -1327,7 +1335,8 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
       if (pg.flags & kParamDeferLocate) {
-        hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        else hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
       }
       if (exact_pass) {

@@ -3019,7 +3019,10 @@ constexpr int kGreedyWavesPerSimd = 2;
 #endif
 
 struct GMatch2 { uint32_t lo, len, qiql, dp; };          // qi | ql << 16, dsum | psum << 16
+                                                         // (wide: lo 40 bits | qi 12 | ql 12, then len 32 | dsum 16 | psum 16)
 struct GBest2 { uint32_t lo, len; };
+struct GBest2W { uint64_t lo; uint32_t len, pad; };      // wide indexes
+constexpr uint32_t kGWideMaxFrag = 4095u;                // wide: fragment positions are kept in 12 bits (longer: retry pass)
 struct GreedyScratch2 {
   uint8_t *win;                // LDS: peptide window, kWin bytes, 4-byte aligned
   uint16_t *mq;                // LDS: lengths of the first kGMaxM matches
@@ -3029,6 +3032,7 @@ struct GreedyScratch2 {
   GMatch2 *matches;            // kGMaxMAll
   uint16_t *mq_ext;            // lengths of the matches kGMaxM .. kGMaxMAll-1
   GBest2 *best;                // 64
+  GBest2W *bestw;              // 64, wide indexes (one of the two is used)
   uint32_t gate;               // heavy iterations: (iteration & gate) == 0
   unsigned long long *prof;    // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PS_N)
   uint32_t lane;               // the device-memory pointers above are the bases of all lanes, this is the lane's number
@@ -3049,10 +3053,13 @@ enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 #define GS_MATCHES (gs.matches + (size_t)gs.lane * kGMaxMAll)
 #define GS_MQ_EXT (gs.mq_ext + (size_t)gs.lane * (kGMaxMAll - kGMaxM))
 #define GS_BEST (gs.best + (size_t)gs.lane * 64)
-template <bool COUNT = false>
+#define GS_BESTW (gs.bestw + (size_t)gs.lane * 64)
+// WIDE: indexes of 2^32 rows and more - 64-bit positions, block counts relative to DevIndex::mb_base, the k-mer TABLE of
+// 16-byte entries instead of the k-mer lines, sequence numbers instead of taxon ids at the sampled rows
+template <bool COUNT = false, bool WIDE = false>
 KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                         const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
-  typedef uint32_t P;
+  typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   uint32_t oc[kOpcN];
   if constexpr (COUNT) for (int x = 0; x < kOpcN; x++) oc[x] = 0;
   int kind = G_IDLE, bk_pend = GB_NONE;
@@ -3080,7 +3087,8 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0;
   bool m_ovf = false;
   // the match at hand
-  uint32_t m_lo = 0, m_len = 0, m_qi = 0, m_ql = 0, m_dsum = 0, m_psum = 0;
+  P m_lo = 0;
+  uint32_t m_len = 0, m_qi = 0, m_ql = 0, m_dsum = 0, m_psum = 0;
   // walk over the matches for the substitution variants / for the scores
   int vi_v = -1, vi_x = 0, vi_phase = 2, vi_head = 0;
   int ev_pass = 0, ev_v = 0, ev_x = -1, ev_v1 = 0;
@@ -3093,7 +3101,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   uint32_t cur = 0, nids = 0;
   P row = 0, rowend = 0, k = 0;
   uint64_t id0 = 0;
-  uint32_t sa_idx = 0;                           // (an index below 2^32 rows has fewer samples than that)
+  P sa_idx = 0;                                  // (an index below 2^32 rows has fewer samples than that)
   bool fresh = true;
 #define KJ_G_HIT (b.hits + r)                    /* (recomputed: two registers less than a pointer kept per lane) */
   int fill_top = 0, fill_ret = FR_START_J;
@@ -3105,14 +3113,16 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   int wq = 0;                                   // fragment position of win[0]
   const P check = (P)((1u << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
-  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 && ix.kline) ? ix.kmer_k : 0;
+  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 &&
+                       (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kline)) ? ix.kmer_k : 0;
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0, itc = 0;
   const RankBlock64 *const blk0 = ix.blocks64;
   // k-mer lines (DevIndex::kline): kcode = the line of end position j (the word w[j-kk+1 .. j-1]), kidx = line and entry of
   // the lookup.  The line (and the diagonal sum of the k-mer) of end position j-1 follows from that of j
   uint32_t kpow = 1;
-  for (uint32_t q = 2; q < kk; q++) kpow *= 20u;            // 20^(kk-2): digit of w[j-1] in the line number
+  for (uint32_t q = WIDE ? 1 : 2; q < kk; q++) kpow *= 20u; // 20^(kk-2): digit of w[j-1] in the line number (wide: 20^(kk-1), digit
+                                                            // of w[j] in the table index)
   uint32_t kacc = 0;                            // (the line number lives in kidx >> 6)
   bool kroll = false;                           // kidx >> 6 / kacc / cj describe end position j+1 of this search
   bool skipj = false;                           // the k-mer that ends at the next end position (j - 1) is not in the index
@@ -3180,8 +3190,9 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     if (score > best) { best = score; nbest = 0; }
     if (score == best) {
       if (nbest < p.max_matches_SI && nbest < 64) {
-        if (nbest == 0) { b0lo = m_lo; b0len = m_len; }
-        else { GBest2 gb; gb.lo = m_lo; gb.len = m_len; GS_BEST[nbest] = gb; }
+        if constexpr (WIDE) { GBest2W gb; gb.lo = m_lo; gb.len = m_len; gb.pad = 0; GS_BESTW[nbest] = gb; }
+        else if (nbest == 0) { b0lo = (uint32_t)m_lo; b0len = m_len; }
+        else { GBest2 gb; gb.lo = (uint32_t)m_lo; gb.len = m_len; GS_BEST[nbest] = gb; }
         nbest++;
       } else flags |= kHitSiCap;
     }
@@ -3193,7 +3204,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; return GB_DONE; }     // :805-807
       if ((k & check) != 0) { kind = G_LF1; return GB_NONE; }
       const uint64_t sa64 = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-      sa_idx = (uint32_t)sa64;
+      sa_idx = (P)sa64;
       if (sa64 < ix.n_sa) { kind = G_SA; return GB_NONE; }
       row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
     }
@@ -3356,7 +3367,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             else {
               t_start = on_start; t_len = on_len; t_diff = 0; t_matchlen = 0; t_tot = on_key; t_msum = 0; t_nmm = 0;
               const uint32_t oflags = on_flags;
-              if (on_key > 0xffffu || on_len > 0xffffu) ovf = true;
+              if (on_key > 0xffffu || on_len > (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && on_start >= (1u << 24))) ovf = true;
               fo++;
               if (p.seg && !(oflags & kFragChecked)) {
                 // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked
@@ -3368,15 +3379,23 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                   if (rec.overflow) flags |= kHitInternalOverflow;
                   Frag f; f.start = t_start; f.len = t_len; f.key = on_key; f.flags = 0;
                   seg_split(ct, p, rec, b.pep + pepoff, f, [&](const Frag &q) {
-                    if (q.len > 0xffffu) { ovf = true; return; }
+                    if (q.len > (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && q.start >= (1u << 24))) { ovf = true; return; }
                     const uint32_t sl = push_slot(q.key, qseq);
                     if (sl == ~0u) return;
                     qseq++;
                     u128 *dst = GS_POOL + 8 * sl;
                     u128 v;
+                    if constexpr (WIDE) {
+                      // (wide items: interval ends 64 bit each; start of the fragment and key move to words 2 and 3)
+                      v.x = v.y = 0; dst[0] = v;
+                      v.x = q.len; v.y = q.key; dst[1] = v;
+                      v.x = (uint64_t)q.start << 8; v.y = 0; dst[2] = v;
+                      v.x = 0; v.y = (uint64_t)(q.key << 16) << 32; dst[3] = v;
+                    } else {
                     v.x = 0; v.y = q.key | (uint64_t)q.start << 32; dst[0] = v;
                     v.x = q.len; v.y = q.key; dst[1] = v;
                     v.x = v.y = 0; dst[2] = v; dst[3] = v;   // no substitutions, no window
+                    }
                   });
                 }
                 if (fo < nf) {
@@ -3407,16 +3426,26 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             // experiment for round 3: a read that ends with ONE best match leaves it in the hit record for
             // k_mem_locate, as the MEM lanes do (the locate sections of this lane run with one or two lanes active: 7 % of it)
             if (nbest == 1u && (p.flags & kParamDeferLocate)) {
-              KJ_G_HIT->taxid[0] = (uint64_t)b0lo | (uint64_t)b0len << 32;
-              nids = 1; flags |= kHitLocPending;
-              bk = GB_DONE;
+              if constexpr (WIDE) {
+                const GBest2W gb = GS_BESTW[0];
+                if (gb.len < kLocWideMaxLen) {
+                  KJ_G_HIT->taxid[0] = gb.lo | (uint64_t)gb.len << kLocWideShift;
+                  nids = 1; flags |= kHitLocPending;
+                  bk = GB_DONE;
+                }
+              } else {
+                KJ_G_HIT->taxid[0] = (uint64_t)b0lo | (uint64_t)b0len << 32;
+                nids = 1; flags |= kHitLocPending;
+                bk = GB_DONE;
+              }
             }
           }
         }
         if (bk == GB_LOC_NEXT_SI) {
           if (cur >= nbest) bk = GB_DONE;
           else {
-            if (cur == 0) { row = b0lo; rowend = b0lo + b0len; }
+            if constexpr (WIDE) { const GBest2W gb = GS_BESTW[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
+            else if (cur == 0) { row = b0lo; rowend = b0lo + b0len; }
             else { const GBest2 gb = GS_BEST[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
             cur++;
             k = row; fresh = true;
@@ -3500,14 +3529,19 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     const u128 b01 = *reinterpret_cast<const u128 *>(&pb->plane[0]);
     const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
     const uint64_t b4 = pb->plane[4];
-    // (G_KMER: the second block is not needed - this load fetches the presence bits of the k-mer line instead)
-    const bool kline_step = kind == G_KMER;
+    // (narrow G_KMER: the second block is not needed - this load fetches the presence bits of the k-mer line instead)
+    const bool kline_step = !WIDE && kind == G_KMER;
     const uint32_t *cbp = &pb->cnt[cc - 1];
     if (kline_step) cbp = reinterpret_cast<const uint32_t *>(ix.kline + (size_t)(kidx >> 6) * kKLineBytes + kKLinePresent);
     const uint32_t cb = *cbp;
+    uint64_t mba = 0, mbb = 0;                             // WIDE: counts at the start of the 2^mb_shift rows
+    if constexpr (WIDE) {
+      mba = ix.mb_base[(size_t)((uint64_t)posA >> ix.mb_shift) * 20 + (cc - 1)];
+      mbb = ix.mb_base[(size_t)((uint64_t)posB >> ix.mb_shift) * 20 + (cc - 1)];
+    }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == G_KMER) gaddr = ix.kline + (size_t)kidx * 2u;
-    else if (kind == G_SA) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    if (kind == G_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
+    else if (kind == G_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == G_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == G_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == G_FILL && fill_pref && fo < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + fo);
@@ -3541,11 +3575,11 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
-      const P ra = ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull));
+      const P ra = (P)(mba + ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull)));
       if (is_step) {
         // UpdateSI(str[i-1]) (bwt.c:160-173)
         const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
-        const P rb = cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull));
+        const P rb = (P)(mbb + cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull)));
         if (ra >= rb) bk = GB_END_MATCH;
         else {
           lo = ra; hi = rb; i--; acc += diag(c);
@@ -3559,6 +3593,17 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       }
     } else if (kind == G_KMER) {
       KJ_P(PS_KMER);
+      if constexpr (WIDE) {
+        // the k-mer table of 16-byte entries {lo, len}
+        lo = (P)gv.x; hi = (P)(gv.x + gv.y);
+        if (lo >= hi) { i = j; bk = GB_END_MATCH; }        // seed shorter than kk: never recorded, i > 1
+        else {
+          i = j - (int)kk + 1;
+          if (i == 0) bk = GB_END_MATCH;
+          else if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; }
+          else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
+        }
+      } else {
       const uint64_t e = kline_entry(gv, kidx);
       const uint32_t l16 = (uint32_t)(e >> 32);
       uint32_t hint = 32u;                                 // the BWT letter of a one-row interval (32 = unknown)
@@ -3587,6 +3632,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         }
         else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
       }
+      }
     } else if (kind == G_LF1) {
       KJ_P(PS_LF1);
       const uint32_t sft = k & 63u;
@@ -3604,7 +3650,13 @@ if constexpr (COUNT) oc[kOpcTerm]++;
       }
     } else if (kind == G_SA) {
       KJ_P(PS_SA);
-      const uint64_t tax = ghalf ? gv.y : gv.x;
+      uint64_t tax;
+      if constexpr (WIDE) {
+        // the wide layout keeps the sequence number of a sampled row (4 bytes), not its taxon id: one more, dependent, read
+        const uint32_t q4 = (uint32_t)sa_idx & 3u;
+        const uint32_t iseq = q4 == 0 ? (uint32_t)gv.x : q4 == 1 ? (uint32_t)(gv.x >> 32) : q4 == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
+        tax = (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
+      } else tax = ghalf ? gv.y : gv.x;
       if (tax != ~0ull) add_tax(tax);
       row++;
       k = row; fresh = true;
@@ -3674,8 +3726,12 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           if ((int32_t)key < thr) continue;
           // the letter's counts in front of the two lines: read now that the letter is known (the lines have just been
           // fetched, so this is a cache hit - cheaper than holding all forty counts in registers for the few that are used)
-          const uint32_t ra = pa->cnt[cx - 1u] + popc64(match_of(a01, a23, a4, cx) & lowA);
-          const uint32_t rb = pb->cnt[cx - 1u] + popc64(match_of(b01, b23, b4, cx) & lowB);
+          P ra = (P)(pa->cnt[cx - 1u] + popc64(match_of(a01, a23, a4, cx) & lowA));
+          P rb = (P)(pb->cnt[cx - 1u] + popc64(match_of(b01, b23, b4, cx) & lowB));
+          if constexpr (WIDE) {
+            ra += (P)ix.mb_base[(size_t)((uint64_t)posA >> ix.mb_shift) * 20 + (cx - 1u)];
+            rb += (P)ix.mb_base[(size_t)((uint64_t)posB >> ix.mb_shift) * 20 + (cx - 1u)];
+          }
           if (ra >= rb) continue;
           KJ_P(PS_VM_PUSH);
           if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; break; }
@@ -3689,11 +3745,15 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           }
           u128 *dst = GS_POOL + 8 * sl;
           u128 v;
-          v.x = ra | (uint64_t)rb << 32; v.y = key | (uint64_t)t_start << 32; dst[0] = v;
+          if constexpr (WIDE) { v.x = ra; v.y = rb; }
+          else { v.x = ra | (uint64_t)rb << 32; v.y = key | (uint64_t)t_start << 32; }
+          dst[0] = v;
           v.x = (vlen | (m_ql + 1u) << 16) | (uint64_t)(uint32_t)(t_diff + bos - bss) << 32;
           v.y = (m_psum - (uint32_t)boo + (uint32_t)bss) | (uint64_t)(m_dsum + (uint32_t)bss) << 32; dst[1] = v;
-          v.x = (t_nmm + 1u) | (uint64_t)q0 << 32; v.y = q1 | (uint64_t)q2 << 32; dst[2] = v;
-          v.x = q3 | (uint64_t)e0 << 32; v.y = e1 | (uint64_t)(win_ok ? (uint32_t)wq + 1u : 0u) << 32; dst[3] = v;
+          // (wide: the fragment's start rides in word 2 next to the number of substitutions, the key in word 3 next to the tag)
+          v.x = ((t_nmm + 1u) | (WIDE ? t_start << 8 : 0u)) | (uint64_t)q0 << 32; v.y = q1 | (uint64_t)q2 << 32; dst[2] = v;
+          v.x = q3 | (uint64_t)e0 << 32;
+          v.y = e1 | (uint64_t)((win_ok ? (uint32_t)wq + 1u : 0u) | (WIDE ? key << 16 : 0u)) << 32; dst[3] = v;
           if (win_ok) {
             const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
             u128 wv;
@@ -3737,15 +3797,15 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         u128 f0 = xa0, f1 = xa1, f2 = xa2, f3 = xa3;
         int newq = fq;
         if (!fill) {
-          lo = (P)xa0.x; hi = (P)(xa0.x >> 32);
-          t_start = (uint32_t)(xa0.y >> 32);
+          if constexpr (WIDE) { lo = (P)xa0.x; hi = (P)xa0.y; t_start = ((uint32_t)xa2.x >> 8) & 0xffffffu; }
+          else { lo = (P)xa0.x; hi = (P)(xa0.x >> 32); t_start = (uint32_t)(xa0.y >> 32); }
           t_len = (uint32_t)xa1.x & 0xffffu; t_matchlen = ((uint32_t)xa1.x >> 16) & 0xffffu;
           t_diff = (int32_t)(uint32_t)(xa1.x >> 32);
           t_tot = (uint32_t)xa1.y; t_msum = (uint32_t)(xa1.y >> 32);
-          t_nmm = (uint32_t)xa2.x;
+          t_nmm = WIDE ? ((uint32_t)xa2.x & 0xffu) : (uint32_t)xa2.x;
           sp0 = (uint32_t)(xa2.x >> 32); sp1 = (uint32_t)xa2.y; sp2 = (uint32_t)(xa2.y >> 32); sp3 = (uint32_t)xa3.x;
           sa0 = (uint32_t)(xa3.x >> 32); sa1 = (uint32_t)xa3.y;
-          const uint32_t wtag = (uint32_t)(xa3.y >> 32);
+          const uint32_t wtag = WIDE ? ((uint32_t)(xa3.y >> 32) & 0xffffu) : (uint32_t)(xa3.y >> 32);
           flen = (int)t_len; nm = 0; kroll = false; skipj = false;
           j = flen - 1;
           if (t_nmm == 0) {
@@ -3789,9 +3849,14 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         }
       } else if (kind == G_MLOAD) {
         KJ_P(PS_MLOAD);
-        m_lo = (uint32_t)gv.x; m_len = (uint32_t)(gv.x >> 32);
-        m_qi = (uint32_t)gv.y & 0xffffu; m_ql = ((uint32_t)gv.y >> 16) & 0xffffu;
-        m_dsum = (uint32_t)(gv.y >> 32) & 0xffffu; m_psum = (uint32_t)(gv.y >> 48) & 0xffffu;
+        if constexpr (WIDE) {
+          m_lo = (P)(gv.x & ((1ull << 40) - 1ull)); m_qi = (uint32_t)(gv.x >> 40) & 0xfffu; m_ql = (uint32_t)(gv.x >> 52) & 0xfffu;
+          m_len = (uint32_t)gv.y; m_dsum = (uint32_t)(gv.y >> 32) & 0xffffu; m_psum = (uint32_t)(gv.y >> 48) & 0xffffu;
+        } else {
+          m_lo = (uint32_t)gv.x; m_len = (uint32_t)(gv.x >> 32);
+          m_qi = (uint32_t)gv.y & 0xffffu; m_ql = ((uint32_t)gv.y >> 16) & 0xffffu;
+          m_dsum = (uint32_t)(gv.y >> 32) & 0xffffu; m_psum = (uint32_t)(gv.y >> 48) & 0xffffu;
+        }
         bk = ml_for == 0 ? GB_VAR_MATCH : GB_EVAL_MATCH;
       }
     }
@@ -3805,10 +3870,17 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         const int l = j - i + 1;
         if (t_nmm == 0) {
           if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {        // bwt.c:276-278
-            if (nm < (uint32_t)kGMaxMAll) {
+            if (nm < (uint32_t)kGMaxMAll && (!WIDE || (uint64_t)(hi - lo) <= 0xffffffffull)) {
               m_lo = lo; m_len = (uint32_t)(hi - lo); m_qi = (uint32_t)i; m_ql = (uint32_t)l; m_dsum = acc; m_psum = t_tot - tail;
-              GMatch2 mm; mm.lo = m_lo; mm.len = m_len; mm.qiql = m_qi | m_ql << 16; mm.dp = m_dsum | m_psum << 16;
+              if constexpr (WIDE) {
+                u128 mm;
+                mm.x = (uint64_t)m_lo | (uint64_t)m_qi << 40 | (uint64_t)m_ql << 52;
+                mm.y = m_len | (uint64_t)m_dsum << 32 | (uint64_t)m_psum << 48;
+                reinterpret_cast<u128 *>(GS_MATCHES)[nm] = mm;
+              } else {
+              GMatch2 mm; mm.lo = (uint32_t)m_lo; mm.len = m_len; mm.qiql = m_qi | m_ql << 16; mm.dp = m_dsum | m_psum << 16;
               GS_MATCHES[nm] = mm;
+              }
               if (nm < (uint32_t)kGMaxM) mq[nm] = (uint16_t)l; else GS_MQ_EXT[nm - kGMaxM] = (uint16_t)l;
               if constexpr (COUNT) oc[kOpcMatchWr]++;
             } else m_ovf = true;
@@ -3821,6 +3893,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           // :443-449: after the last allowed mismatch the match must reach min_fragment_length
           const int Lreq = (t_nmm == p.mismatches) ? (int)p.m : (int)t_matchlen;
           if (l >= Lreq) {
+            if (WIDE && (uint64_t)(hi - lo) > 0xffffffffull) m_ovf = true;
             m_lo = lo; m_len = (uint32_t)(hi - lo); m_qi = (uint32_t)i; m_ql = (uint32_t)l; m_dsum = acc; m_psum = t_tot;
             nm = 1;
           }
@@ -3847,6 +3920,22 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         else if (j < (int)p.seed_length - 1) { skipj = false; bk = GB_AFTER_SEARCH; }
         else if (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1))) {
           fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;     // (skipj, if set, waits)
+        } else if (WIDE && kk && j >= (int)kk - 1) {
+          // wide: index of the word w[j-kk+1 .. j] in the k-mer table (w[j] = most significant digit), rolled from that of j + 1
+          if (kroll) {
+            const uint32_t cn = win[j - (int)kk + 1 - wq];
+            kidx = (kidx - (cj - 1u) * kpow) * 20u + (cn - 1u);
+            kacc = kacc - diag(cj) + diag(cn);
+          } else {
+            kidx = 0; kacc = 0;
+            for (uint32_t q = 0; q < kk; q++) {
+              const uint32_t cq = win[j - (int)q - wq];
+              kidx = kmer_index(kidx, cq);
+              kacc += diag(cq);
+            }
+          }
+          cj = win[j - wq]; acc = kacc; kroll = true;
+          kind = G_KMER; bk = GB_NONE;
         } else if (kk && j >= (int)kk - 1) {
           uint32_t kcode;
           if (kroll) {

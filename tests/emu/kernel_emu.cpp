@@ -284,7 +284,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1" or default (v2 where possible)
       std::vector<GBestV> bestvv(64);
       gs.bestv = g_vb.n_acc ? bestvv.data() : nullptr;
-      if (d.blocks64 && d.kline && !v && pass == 0 && !g_vb.n_acc) {
+      if (d.blocks64 && (d.kline || (d.mb_base && d.kmer64)) && !v && pass == 0 && !g_vb.n_acc) {
         alignas(16) uint32_t lds_win[kGWinStride], lds_mq[kGMqStride], lds_prio[kGPrioStride];
         for (auto &x : lds_win) x = 0xdeadbeefu;
         for (auto &x : lds_mq) x = 0xdeadbeefu;
@@ -294,15 +294,17 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         std::vector<GMatch2> matches2(kGMaxMAll);
         std::vector<uint16_t> mq_ext(kGMaxMAll - kGMaxM, 0xdead);
         std::vector<GBest2> best2(64);
+        std::vector<GBest2W> best2w(64);
         const char *ge = getenv("KAIJU_EMU_GATE");
         GreedyScratch2 g2{reinterpret_cast<uint8_t *>(lds_win), reinterpret_cast<uint16_t *>(lds_mq), lds_prio, pool2.data(),
-                          prio_ext.data(), matches2.data(), mq_ext.data(), best2.data(), ge ? (uint32_t)atoi(ge) : 3u};
+                          prio_ext.data(), matches2.data(), mq_ext.data(), best2.data(), best2w.data(), ge ? (uint32_t)atoi(ge) : 3u};
         uint32_t lds_sub[24];
         for (auto &x : lds_sub) x = 0xdeadbeefu;
         g2.sub = lds_sub;
         Params pg = p;
         pg.flags |= kParamDeferLocate;
-        greedy_lane2(d, ix->ct, pg, sq, b, wl, g2);
+        if (d.mb_base) greedy_lane2<false, true>(d, ix->ct, pg, sq, b, wl, g2);
+        else greedy_lane2(d, ix->ct, pg, sq, b, wl, g2);
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }

@@ -301,6 +301,30 @@ def test_wide_mem_lane(oracle, emu, golden, handles, shift, monkeypatch):
             assert not bad, (shift, seg, pe, bad[:5])
 
 
+@pytest.mark.parametrize("shift", ["16", "19"])
+def test_wide_greedy_lane(oracle, emu, golden, handles, shift, monkeypatch):
+    """second-generation Greedy lane with 64-bit positions (greedy_lane2<COUNT, WIDE = true>), forced on the golden index:
+    the k-mer table of 16-byte entries, block counts relative to a base every 2^shift rows, sequence numbers at the sampled rows,
+    queue items and match records in their wide packing; single reads, pairs, long reads, parameter variants"""
+    monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
+    h = emu.load(golden.fmi)
+    _, ix, tax = handles
+    reads = util.long_reads(n=30)
+    lseqs, loff = util.pack(reads)
+    for seg in (1, 0):
+        for seqs, off, pe in ((golden.seqs, golden.off, False), (golden.pseqs, golden.poff, True), (lseqs, loff, False)):
+            oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg, use_evalue=0), seqs, off, paired=pe)
+            gh, nretry = emu.classify(h, util.gp("greedy", seg=seg), seqs, off, paired=pe)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+            assert not bad, (shift, seg, pe, bad[:5])
+    for kw in (dict(mismatches=0), dict(mismatches=5, min_score=50), dict(m=15)):
+        okw = {("min_fragment_length" if k == "m" else k): v for k, v in kw.items()}
+        oh = oracle.classify(ix, tax, oracle.params("greedy", seg=1, use_evalue=0, **okw), golden.seqs, golden.off)
+        gh, _ = emu.classify(h, util.gp("greedy", seg=1, use_evalue=0, **kw), golden.seqs, golden.off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (shift, kw, bad[:5])
+
+
 def test_randomised_databases_and_parameters():
     """a few rounds of tests/tools/fuzz_emu.py: random databases with repeats and low-complexity stretches, reads
     with Ns / lower case / odd lengths / pairs, random parameters (the long hunts run from the command line)"""
