@@ -287,6 +287,13 @@ int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p, double db_
    (bwt/mkbwt.c:922-1099, bwt/mkfmi.c:21-97); the reference binary reads the result.
    threads <= 0: all hardware threads.  Host only. */
 int kaiju_build_fmi(const char *faa_path, const char *out_fmi_path, int threads, int chpt_exp);
+/* The .fmi of the database in which every sequence of the FASTA occurs `copies` times in a row, without sorting it again (equal
+   suffixes order by file position, so every row of the file's own index becomes `copies` rows); byte for byte what
+   kaiju_build_fmi writes for the FASTA with the repeats spelled out.  Test / benchmark infrastructure: an index of 2^32 rows
+   and more (the layout with 64-bit positions) from a small FASTA in seconds.  copy_taxids (may be NULL): copy t of sequence
+   number i, named X_<id>, is named X_<copy_taxids[(i + t) % n_copy_taxids]>. */
+int kaiju_build_fmi_replicated(const char *faa_path, const char *out_fmi_path, int threads, int chpt_exp, uint64_t copies,
+                               const uint64_t *copy_taxids, uint32_t n_copy_taxids);
 const char *kaiju_build_fmi_error(void);
 
 #ifdef __cplusplus

@@ -109,8 +109,16 @@ struct SufLess {
   }
 };
 
+// copies > 1: the index of the database in which every sequence of the FASTA file occurs `copies` times in a row (copy t of
+// sequence i is sequence i * copies + t of that database) - WITHOUT sorting it again: equal suffixes of different sequences
+// compare by file order, so row r of the index of the file becomes the rows r * copies .. r * copies + copies - 1.  The output
+// is byte for byte what this builder (and the reference's) writes for the FASTA with the repeats spelled out
+// (tests/test_mkfmi_pin.py); a 2^32-row index for the tests of the wide path takes half a minute this way instead of the
+// seven minutes of sorting 4.3 G suffixes.  copy_taxids (optional): copy t of a sequence named X_<id> is named
+// X_<copy_taxids[(i + t) % n]>, so that the copies do not all carry one taxon.
 template <class I>
-int build(const char *faa, const char *out, int threads, int chpt_exp) {
+int build(const char *faa, const char *out, int threads, int chpt_exp, uint64_t copies = 1, const uint64_t *copy_taxids = nullptr,
+          uint32_t n_copy_taxids = 0) {
   // alphabet of kaiju-makedb:373 with the terminator in front (mkbwt.c:read_alphabet)
   const char alphabet[] = "*ACDEFGHIKLMNPQRSTVWY";
   const int alen = 21;
@@ -186,31 +194,41 @@ int build(const char *faa, const char *out, int threads, int chpt_exp) {
   }
 
   // ---- BWT -----------------------------------------------------------------------------------
-  std::vector<uint8_t> bwt(tlen);
-  for (uint64_t i = 0; i < nseq; i++) bwt[i] = seqs[i].len ? T[seqs[i].start + seqs[i].len - 1] : 0;
-  parallel_chunks(nt, nsuf, [&](uint64_t b, uint64_t e, unsigned) {
-    for (uint64_t k = b; k < e; k++) { const uint64_t p = SA[k]; bwt[nseq + k] = is_start[p] ? 0 : T[p - 1]; }
-  });
+  const uint64_t N = copies < 1 ? 1 : copies;
+  const uint64_t otlen = tlen * N, onseq = nseq * N;          // what the output describes
+  if (onseq >= 0x7fffffffull) { g_err = "too many sequences for the .fmi header (int32)"; return KAIJU_GPU_ERR_ARG; }
+  std::vector<uint8_t> bwt(otlen);
+  {
+    auto base_bwt = [&](uint64_t r) -> uint8_t {
+      if (r < nseq) return seqs[r].len ? T[seqs[r].start + seqs[r].len - 1] : 0;
+      const uint64_t p = SA[r - nseq];
+      return is_start[p] ? 0 : T[p - 1];
+    };
+    parallel_chunks(nt, tlen, [&](uint64_t b, uint64_t e, unsigned) {
+      for (uint64_t r = b; r < e; r++) { const uint8_t c = base_bwt(r); for (uint64_t t = 0; t < N; t++) bwt[r * N + t] = c; }
+    });
+  }
 
   // ---- suffix array samples (init_suffixArray suffixArray.c:140-180) -------------------------
   long maxlen = 0;
   for (auto &s : seqs) if ((long)s.len > maxlen) maxlen = (long)s.len;
-  const int sbits = bits_needed((long)nseq), pbits = bits_needed(maxlen);
+  const int sbits = bits_needed((long)onseq), pbits = bits_needed(maxlen);
   const int nbytes = (7 + sbits + pbits) / 8;
-  const int64_t ncheck = (int64_t)(tlen >> chpt_exp) - (int64_t)(nseq >> chpt_exp);   // the header value
+  const int64_t ncheck = (int64_t)(otlen >> chpt_exp) - (int64_t)(onseq >> chpt_exp);   // the header value
   const int64_t mask = (1 << pbits) - 1, check = (1 << chpt_exp) - 1;
   std::vector<uint8_t> sa((size_t)std::max<int64_t>(ncheck, 0) * nbytes, 0);
   {
     const uint64_t step = 1ull << chpt_exp;
-    const uint64_t first = ((nseq + step - 1) >> chpt_exp) << chpt_exp;   // first sampled row >= nseq
-    const uint64_t nsamp = first < tlen ? ((tlen - 1 - first) >> chpt_exp) + 1 : 0;
+    const uint64_t first = ((onseq + step - 1) >> chpt_exp) << chpt_exp;   // first sampled row >= nseq
+    const uint64_t nsamp = first < otlen ? ((otlen - 1 - first) >> chpt_exp) + 1 : 0;
     parallel_chunks(nt, nsamp, [&](uint64_t b, uint64_t e, unsigned) {
       for (uint64_t q = b; q < e; q++) {
         if ((int64_t)q >= ncheck) break;            // mkfmi only carries ncheck entries over
         const uint64_t k = first + (q << chpt_exp);
-        const uint64_t p = SA[k - nseq];
+        const uint64_t r = k / N, t = k % N;         // row of the file's own index, copy
+        const uint64_t p = SA[r - nseq];
         const uint64_t i = seq_index(p);
-        long val = (long)rank_of[i];
+        long val = (long)((uint64_t)rank_of[i] * N + t);
         val = (val << pbits) + (long)(p - seqs[i].start);
         uint8_t *c = sa.data() + q * nbytes;
         for (int n = nbytes; n-- > 0;) { c[n] = (uint8_t)val; val >>= 8; }
@@ -219,7 +237,7 @@ int build(const char *faa, const char *out, int threads, int chpt_exp) {
   }
 
   // ---- FMI (fmicommon.h:77-171, compactfmi.c:108-150,399-457) ---------------------------------
-  const int64_t bwtlen = (int64_t)tlen;
+  const int64_t bwtlen = (int64_t)otlen;
   int N1 = (int)(((bwtlen - 1) >> 16) + 2);
   if (((int64_t)N1 << 16) == bwtlen) N1 -= 1;
   int N2 = (int)(((bwtlen - 1) >> 8) + 2);
@@ -300,22 +318,33 @@ int build(const char *faa, const char *out, int threads, int chpt_exp) {
   setvbuf(fp, nullptr, _IOFBF, 1 << 22);
   auto W = [&](const void *p, size_t n) { return n == 0 || fwrite(p, 1, n, fp) == n; };
   bool ok = true;
-  const int32_t nseq32 = (int32_t)nseq, alen32 = alen;
+  const int32_t nseq32 = (int32_t)onseq, alen32 = alen;
   ok &= W(&bwtlen, 8); ok &= W(&nseq32, 4); ok &= W(&alen32, 4); ok &= W(alphabet, alen);
   ok &= W(&bwtlen, 8); ok &= W(&ncheck, 8);
   const int32_t e32 = chpt_exp, nb32 = nbytes, sb32 = sbits, pb32 = pbits;
   ok &= W(&e32, 4); ok &= W(&nb32, 4); ok &= W(&sb32, 4); ok &= W(&pb32, 4);
   ok &= W(&mask, 8); ok &= W(&check, 8); ok &= W(&nseq32, 4);
   for (uint64_t r = 0; r < nseq; r++) {
-    const std::string &id = seqs[read_of_rank[r]].id;
-    const uint8_t l = (uint8_t)std::min<size_t>(255, id.size());
-    ok &= W(&l, 1); ok &= W(id.data(), l);
+    const uint64_t fi = read_of_rank[r];
+    const std::string &id0 = seqs[fi].id;
+    for (uint64_t t = 0; t < N; t++) {
+      std::string idt;
+      const std::string *id = &id0;
+      if (N > 1 && n_copy_taxids) {
+        const size_t us = id0.rfind('_');
+        idt = (us == std::string::npos ? id0 : id0.substr(0, us)) + "_" + std::to_string(copy_taxids[(fi + t) % n_copy_taxids]);
+        id = &idt;
+      }
+      const uint8_t l = (uint8_t)std::min<size_t>(255, id->size());
+      ok &= W(&l, 1); ok &= W(id->data(), l);
+    }
   }
   {
-    std::vector<int32_t> sto(nseq);
-    std::vector<int64_t> sl(nseq);
-    for (uint64_t r = 0; r < nseq; r++) { sto[r] = (int32_t)read_of_rank[r]; sl[r] = (int64_t)seqs[read_of_rank[r]].len; }
-    ok &= W(sto.data(), nseq * 4); ok &= W(sl.data(), nseq * 8);
+    std::vector<int32_t> sto(onseq);
+    std::vector<int64_t> sl(onseq);
+    for (uint64_t r = 0; r < nseq; r++)
+      for (uint64_t t = 0; t < N; t++) { sto[r * N + t] = (int32_t)(read_of_rank[r] * N + t); sl[r * N + t] = (int64_t)seqs[read_of_rank[r]].len; }
+    ok &= W(sto.data(), onseq * 4); ok &= W(sl.data(), onseq * 8);
   }
   ok &= W(sa.data(), sa.size());
   const int32_t n1 = N1, n2 = N2;
@@ -342,6 +371,14 @@ extern "C" int kaiju_build_fmi(const char *faa_path, const char *out_fmi_path, i
   fclose(fp);
   if ((uint64_t)sz < 0xf0000000ull) return build<uint32_t>(faa_path, out_fmi_path, threads, chpt_exp);
   return build<uint64_t>(faa_path, out_fmi_path, threads, chpt_exp);
+}
+
+extern "C" int kaiju_build_fmi_replicated(const char *faa_path, const char *out_fmi_path, int threads, int chpt_exp, uint64_t copies,
+                                          const uint64_t *copy_taxids, uint32_t n_copy_taxids) {
+  if (!faa_path || !out_fmi_path || chpt_exp < 0 || chpt_exp > 20 || copies < 1 || (n_copy_taxids && !copy_taxids)) return KAIJU_GPU_ERR_ARG;
+  if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  // (the FILE is sorted, so 32-bit suffix positions do as long as it has fewer than 4 G symbols)
+  return build<uint32_t>(faa_path, out_fmi_path, threads, chpt_exp, copies, copy_taxids, n_copy_taxids);
 }
 
 extern "C" const char *kaiju_build_fmi_error(void) { return g_err.c_str(); }

@@ -31,3 +31,31 @@ def test_same_bytes_as_the_reference_builder(tmp_path, nseq, seed, exponent, thr
     mkfmi.build_fmi(faa, ours, threads=threads, exponent=exponent)
     assert os.path.getsize(ours) == os.path.getsize(ref)
     assert filecmp.cmp(ours, ref, shallow=False)
+
+
+@pytest.mark.parametrize("copies,exponent,with_taxids", [(3, 3, False), (7, 2, True), (2, 5, False)])
+def test_replicated_database_without_a_second_sort(golden, tmp_path, copies, exponent, with_taxids):
+    """kaiju_build_fmi_replicated(file, copies) == kaiju_build_fmi(file with every record repeated `copies` times): the
+    shortcut that makes a 2^32-row index for the wide-path tests in seconds writes the very bytes the sorter would"""
+    src = os.path.join(golden.dir, "db.faa")
+    recs = []
+    with open(src) as f:
+        for line in f:
+            if line.startswith(">"):
+                recs.append([line.strip()[1:].split()[0], []])
+            else:
+                recs[-1][1].append(line.strip())
+    taxids = [11, 222, 3333, 44444, 5] if with_taxids else None
+    rep = str(tmp_path / "rep.faa")
+    with open(rep, "w") as f:
+        for i, (name, seq) in enumerate(recs):
+            for t in range(copies):
+                nm = name
+                if taxids:
+                    nm = (name[: name.rfind("_")] if "_" in name else name) + "_" + str(taxids[(i + t) % len(taxids)])
+                f.write(f">{nm}\n{''.join(seq)}\n")
+    a, b = str(tmp_path / "sorted.fmi"), str(tmp_path / "replicated.fmi")
+    mkfmi.build_fmi(rep, a, threads=3, exponent=exponent)
+    mkfmi.build_fmi_replicated(src, b, copies, threads=3, exponent=exponent, copy_taxids=taxids)
+    assert os.path.getsize(a) == os.path.getsize(b)
+    assert filecmp.cmp(a, b, shallow=False)
