@@ -309,7 +309,8 @@ class Leg:
         oc = self.op_counts
         alg = algorithmic_bytes(oc, nseq) * (per_launch / first)          # counted on chunk 0, scaled to the mean launch
         achieved = alg / (excl_ms * 1e-3) / 1e9 if excl_ms > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_mem" if self.mode == "mem" else "k_greedy2",
+        wide_ix = self.index.info.bwtlen >= 2 ** 32
+        roof = {"bound": "hbm", "kernel": ("k_mem_wide2" if wide_ix else "k_mem") if self.mode == "mem" else ("k_greedy2_wide" if wide_ix else "k_greedy2"),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 **({"traffic_note": _TRAFFIC_NOTES[(self.mode, bool(self.paired))]}
@@ -482,18 +483,42 @@ def main():
     # ---------------- workload (untimed) ----------------
     t0 = time.time()
     lines, leaves = synth.make_taxonomy()
-    db = synth.make_db(nseq=args.nseq, seed=12345, leaves=leaves)
+    # (--nseq 15500001: 4.33 G residues, an index of 2^32 rows and more - the layout with 64-bit positions, BASELINE configs[3]
+    #  class; the database generator without per-sequence Python loops serves from a few million sequences on, and sorting the
+    #  suffixes of such a database takes about seven minutes of the host's cores before the first step is timed)
+    big_db = args.nseq > 2_000_000
+    db = (synth.make_db_large if big_db else synth.make_db)(nseq=args.nseq, seed=12345, leaves=leaves)
     fmi, nodes = f"{W}/db_{args.nseq}.fmi", f"{W}/nodes.dmp"
     if rank == 0:
         synth.write_nodes_dmp(nodes, lines)
         if not os.path.exists(fmi):
-            synth.write_fasta(db, f"{W}/db_{args.nseq}.faa")
+            (synth.write_fasta_large if big_db else synth.write_fasta)(db, f"{W}/db_{args.nseq}.faa")
             mkfmi.build_fmi(f"{W}/db_{args.nseq}.faa", fmi + ".tmp", threads=0, exponent=3)
             os.replace(fmi + ".tmp", fmi)
+            if big_db:
+                os.remove(f"{W}/db_{args.nseq}.faa")
         log(rank, f"database {db.nseq} seqs / {db.total_aa} aa, index {os.path.getsize(fmi)/1e6:.0f} MB file "
                   f"({time.time()-t0:.1f}s)")
     kdist.barrier()
-    index = api.Index(fmi, device=local_rank)
+    # N ranks, one host: the .fmi is parsed and packed ONCE (rank 0 writes the device image next to it, no GPU needed), the
+    # ranks upload that image - and only a few at a time, so that the host never holds more than `conc` copies of the packed
+    # arrays (a refseq-class image is 150 GB; eight at once would not fit the host that eight parsed .fmi would not fit either)
+    load_path = fmi
+    if world > 1:
+        img = fmi + ".kjimg"
+        if rank == 0 and not (os.path.exists(img) and os.path.getmtime(img) >= os.path.getmtime(fmi)):
+            rc = api.lib().kaiju_gpu_index_write_image(fmi.encode(), (img + ".tmp").encode())
+            if rc != 0:
+                raise SystemExit(f"kaiju_gpu_index_write_image failed ({rc})")
+            os.replace(img + ".tmp", img)
+        kdist.barrier()
+        load_path = img
+    conc = max(1, int(os.environ.get("KAIJU_BENCH_LOAD_CONCURRENCY", "4")))
+    index = None
+    for g in range(0, world, conc):
+        if g <= rank < g + conc:
+            index = api.Index(load_path, device=local_rank)
+        kdist.barrier()
     dtax = api.DeviceTaxonomy(api.Taxonomy(nodes), local_rank)
     n = args.reads
     Lm = 150
@@ -589,12 +614,16 @@ def main():
         "value": hr["value"], "unit": hr["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": hr["ms_per_step"], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"viruses-like synthetic index ({db.nseq} proteins, {db.total_aa} aa, .fmi "
+        "config": {"workload": f"{'refseq_ref-class (2^32 rows and more: 64-bit positions)' if index.info.bwtlen >= 2 ** 32 else 'viruses-like'} "
+                               f"synthetic index ({db.nseq} proteins, {db.total_aa} aa, .fmi "
                                f"{os.path.getsize(fmi)/1e6:.0f} MB, e=3); {n} synthetic {'2x' if args.paired else ''}{Lm}-bp reads{' (pairs)' if args.paired else ''} per GPU per step "
                                f"(70% back-translated DB windows, 30% random); kaiju -a {args.mode} -m 11"
                                f"{'' if seg else ' -X'} (SEG {'on' if seg else 'off'})",
                    "reads_per_gpu_per_step": n, "chunk": head.chunk, "contexts_in_flight": head.nctx, "index_replicated": True,
+                   "index_hbm_bytes": index.footprint.as_dict(),
                    "ranks": world, "per_rank_units_per_s": per_rank,
+                   "process_group": ({"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size()}
+                                     if torch.distributed.is_initialized() else None),
                    "gather": (f"one async RCCL gather of 16-B records (device LCA of the 184-B hit records) per chunk to rank 0; "
                               f"{head.gathered_timed / max(args.steps, 1):.0f} B into rank 0 per step"
                               if world > 1 else "none (1 GPU); device LCA to 16-B records still runs"),

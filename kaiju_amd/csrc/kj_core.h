@@ -2026,8 +2026,14 @@ KJ_HD uint32_t kj_fetch_chunk(uint32_t *counter, uint32_t n) { const uint32_t v 
 #if defined(KJ_HIST) && !defined(__HIP_DEVICE_COMPILE__)
 extern unsigned long long kj_hist[8][64];
 #define KJ_HISTO(h, v) kj_hist[h][(v) < 63 ? (v) : 63]++
+// (MEM lane: how many letters a match still grows after its interval has shrunk to one row - what a text comparison could replace)
+static int kj_single_at = 0;
+#define KJ_HIST_SINGLE(is1, len) { if ((is1) && !kj_single_at) kj_single_at = (len); }
+#define KJ_HIST_SINGLE_END(l) { if (kj_single_at) { KJ_HISTO(3, (int)(l) - kj_single_at); KJ_HISTO(2, kj_single_at); } kj_single_at = 0; }
 #else
 #define KJ_HISTO(h, v)
+#define KJ_HIST_SINGLE(is1, len)
+#define KJ_HIST_SINGLE_END(l)
 #endif
 template <bool WIDE, bool XORDER = false, bool COUNT = false>
 KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
@@ -2199,6 +2205,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (ra >= rb) bk = BK_END_MATCH;
         else {
           lo = ra; hi = rb; i--;
+          KJ_HIST_SINGLE(hi - lo == 1, j - i + 1);
           if (i == 0) bk = BK_END_MATCH;
           else if (in_win(i - 1)) c = lw.w[i - 1 - lw.q];
           else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
@@ -2236,6 +2243,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       } else if (lo >= hi) { i = j; bk = BK_END_MATCH; }   // match shorter than kk: never recorded, i > 1
       else {
         i = j - (int)kk + 1;
+        KJ_HIST_SINGLE(hi - lo == 1, (int)kk);
         if (i == 0) bk = BK_END_MATCH;
         else if (in_win(i - 1)) {
           c = lw.w[i - 1 - lw.q];
@@ -2323,6 +2331,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (bk == BK_END_MATCH) {
         KJ_PM(PM_END_MATCH);
         const uint32_t l = (uint32_t)(j - i + 1);
+        KJ_HIST_SINGLE_END(l);
         if (l >= L) {
           if (l > L) { nsi = 0; ovf = false; L = l; multi = false; }   // shorter matches are dropped (bwt.c:366-370, :577-582)
           const uint32_t ilen = (uint32_t)(int32_t)(hi - lo);

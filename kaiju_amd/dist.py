@@ -24,7 +24,10 @@ def env_world():
 def init(backend: str):
     import torch.distributed as dist
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    # KAIJU_DIST_FORCE_INIT=1: a process group of ONE rank, so that barrier / all-reduce / gather of a single-GPU run go
+    # through the backend (RCCL) as they do at N > 1 - the readiness check for boxes with one GPU (tests/test_gpu_dist1.py)
+    force = os.environ.get("KAIJU_DIST_FORCE_INIT") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -55,7 +58,7 @@ class HitGatherer:
     def gather(self, chunk):
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             if self.keep:
                 self.results.append([chunk])
             return

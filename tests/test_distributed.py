@@ -80,3 +80,17 @@ def test_two_rank_gather_matches_single_process(tmp_path, emu, golden):
     ref, _ = emu.classify(h, util.gp("mem", seg=1), golden.seqs, golden.off)
     assert len(got) == len(ref)
     assert (got == ref).all()
+
+
+def test_bench_refuses_a_launcher_that_disagrees_with_gpus(tmp_path):
+    """bench.py --gpus N: a launcher that started another number of ranks is an error, and without a launcher the script only
+    starts N ranks itself when N GPUs are visible (none here) - no silent fall-back to fewer GPUs"""
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and b"WORLD_SIZE=1" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0 and b"GPU(s) visible" in r.stderr
