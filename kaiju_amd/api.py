@@ -37,7 +37,7 @@ class IndexInfo(C.Structure):
 
 class IndexFootprint(C.Structure):        # kaiju_gpu_index_footprint
     _fields_ = [(k, C.c_uint64) for k in ("rank_blocks", "count_bases", "sa_seq", "sa_taxid", "seq_tables", "kmer_table",
-                                          "kmer_lines", "other", "total")] + [("kmer_k", C.c_uint32), ("wide", C.c_uint32)]
+                                          "kmer_lines", "text", "sa_full", "other", "total")] + [("kmer_k", C.c_uint32), ("wide", C.c_uint32)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -521,6 +521,34 @@ k_kline_build(DevIndex ix, uint32_t k, uint64_t n_lines, uint8_t *__restrict__ l
     kline_build_one(ix, k, code, lines + code * kKLineBytes);
 }
 
+// Index load, narrow indexes with room to spare: the database text and the full suffix array for the text verification of the
+// MEM lane (kj_core.h: DevIndex::sa_full / text).  k_suffix_walk: (sequence, offset) of the suffix of every row by the
+// reference's own walk (suffix_of_row = get_suffix, bwt.c:105-121); k_seq_lens: a sequence's length = the offset of its
+// terminator suffix (rows 0 .. nseq-1); k_text_build: row r's suffix lies at g = off[sequence] + 1 + offset, and the letter
+// in front of it is the row's BWT letter.
+__global__ void __launch_bounds__(256)
+k_suffix_walk(DevIndex ix, const uint32_t *__restrict__ smp_pos, uint32_t *__restrict__ row_seq, uint32_t *__restrict__ row_pos, uint32_t *bad) {
+  for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < ix.bwtlen; r += (uint64_t)gridDim.x * 256) {
+    uint32_t sq = 0, ps = 0;
+    if (!suffix_of_row(ix, smp_pos, r, sq, ps) || sq >= ix.nseq) { atomicOr(bad, 1u); sq = 0; ps = 0; }
+    row_seq[r] = sq; row_pos[r] = ps;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_seq_lens(uint32_t nseq, const uint32_t *__restrict__ row_seq, const uint32_t *__restrict__ row_pos, uint32_t *__restrict__ len) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r < nseq) len[row_seq[r]] = row_pos[r];
+}
+__global__ void __launch_bounds__(256)
+k_text_build(DevIndex ix, const uint32_t *__restrict__ row_seq, const uint32_t *__restrict__ row_pos, const uint32_t *__restrict__ off,
+             uint32_t *__restrict__ sa_full, uint8_t *__restrict__ text) {
+  for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < ix.bwtlen; r += (uint64_t)gridDim.x * 256) {
+    const uint32_t g = off[row_seq[r]] + 1u + row_pos[r];
+    sa_full[r] = g;
+    text[g - 1u] = (uint8_t)symbol_at(ix, r);
+  }
+}
+
 // the same for indexes with 64-bit positions: 16-byte entries {lo, len}, counts relative to mb_base
 __global__ void __launch_bounds__(256)
 k_kmer_extend_wide(const RankBlock64 *__restrict__ blk, const uint64_t *__restrict__ mb_base, uint32_t mb_shift,
@@ -799,6 +827,55 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     }
   }
   lc.mark("k-mer table (device)");
+  // ---- text verification: the database text + the full suffix array (5 bytes per row; narrow indexes with room for it) ----
+  d.sa_full = nullptr; d.text = nullptr;
+  uint64_t text_bytes = 0;
+  {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const uint64_t need_peak = pk.bwtlen * 13 + ((uint64_t)pk.nseq << 3) + (64u << 20);       // two temporaries + the two arrays
+    const bool want = !getenv("KAIJU_GPU_NO_TEXT") && !d.mb_base && d.blocks64 && !pk.sa_pos.empty() && !(pk.warnings & KAIJU_IDX_WARN_SA_SHORT) &&
+                      pk.bwtlen + pk.nseq + 4 * (uint64_t)kTextPad < 0xffffffffull && need_peak < free_b / 2;
+    if (want) {
+      const uint32_t *d_smp = nullptr;
+      if ((rc = upload(ix.get(), pk.sa_pos, &d_smp))) return rc;
+      void *smp_alloc = ix->allocs.back();
+      uint32_t *row_seq = nullptr, *row_pos = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bad = nullptr, *sa_full = nullptr;
+      uint8_t *text = nullptr;
+      bool ok = hipMalloc((void **)&row_seq, pk.bwtlen * 4) == hipSuccess && hipMalloc((void **)&row_pos, pk.bwtlen * 4) == hipSuccess &&
+                hipMalloc((void **)&d_len, (size_t)pk.nseq * 4 + 16) == hipSuccess && hipMalloc((void **)&d_off, (size_t)pk.nseq * 4 + 16) == hipSuccess &&
+                hipMalloc((void **)&d_bad, 16) == hipSuccess;
+      if (ok) {
+        (void)hipMemset(d_bad, 0, 16);
+        (void)hipMemset(d_len, 0, (size_t)pk.nseq * 4);
+        const unsigned blocks = (unsigned)std::min<uint64_t>((pk.bwtlen + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(k_suffix_walk, dim3(blocks), dim3(256), 0, 0, d, d_smp, row_seq, row_pos, d_bad);
+        hipLaunchKernelGGL(k_seq_lens, dim3((pk.nseq + 255) / 256), dim3(256), 0, 0, pk.nseq, row_seq, row_pos, d_len);
+        std::vector<uint32_t> len(pk.nseq), off(pk.nseq);
+        uint32_t bad = 0;
+        ok = hipMemcpy(len.data(), d_len, (size_t)pk.nseq * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+        uint64_t at = kTextPad;
+        for (uint32_t q = 0; ok && q < pk.nseq; q++) { off[q] = (uint32_t)at; at += (uint64_t)len[q] + 1; if (at + kTextPad >= 0xffffffffull) ok = false; }
+        text_bytes = at + 2 * kTextPad;
+        ok = ok && hipMemcpy(d_off, off.data(), (size_t)pk.nseq * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMalloc((void **)&sa_full, pk.bwtlen * 4 + 64) == hipSuccess && hipMalloc((void **)&text, text_bytes) == hipSuccess;
+        if (ok) {
+          (void)hipMemset(text, 0, text_bytes);
+          hipLaunchKernelGGL(k_text_build, dim3(blocks), dim3(256), 0, 0, d, row_seq, row_pos, d_off, sa_full, text);
+          ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+        }
+      }
+      (void)hipGetLastError();
+      for (void *q : {(void *)row_seq, (void *)row_pos, (void *)d_len, (void *)d_off, (void *)d_bad}) if (q) (void)hipFree(q);
+      // (the sample offsets were only needed here)
+      (void)hipFree(smp_alloc);
+      ix->allocs.pop_back();
+      if (ok) { ix->allocs.push_back(sa_full); ix->allocs.push_back(text); d.sa_full = sa_full; d.text = text; }
+      else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; }
+    }
+  }
+  lc.mark("text + full suffix array (device)");
   kaiju_gpu_index_info &inf = ix->info;
   memset(&inf, 0, sizeof inf);
   inf.bwtlen = (int64_t)pk.bwtlen; inf.nseq = (int32_t)pk.nseq; inf.alen = (int32_t)pk.alen;
@@ -817,14 +894,17 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     f.kmer_table = d.kmer_k ? nw * (d.kmer64 ? sizeof(ulonglong2) : sizeof(uint2)) : 0;
     f.kmer_lines = d.kline ? nw / 20 * kKLineBytes : 0;
     f.other = sizeof(ConstTables) + sizeof(Stage1Tables) + lnfact.size() * 8;
-    f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other;
+    f.text = d.text ? text_bytes : 0;
+    f.sa_full = d.sa_full ? pk.bwtlen * 4 : 0;
+    f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other + f.text + f.sa_full;
     f.kmer_k = d.kmer_k; f.wide = d.mb_base ? 1u : 0u;
     inf.device_bytes = f.total;
     if (getenv("KAIJU_GPU_LOAD_TIMES"))
       fprintf(stderr, "[kaiju_gpu load] HBM: rank blocks %.2f GB, count bases %.3f GB, SA sample %.2f (sequence numbers) + %.2f (taxon ids) GB, "
-                      "sequence tables %.2f GB, k = %u table %.2f GB + lines %.2f GB; %.2f B per index row without the k-mer tables\n",
+                      "sequence tables %.2f GB, k = %u table %.2f GB + lines %.2f GB, text %.2f GB + full suffix array %.2f GB; %.2f B per index row "
+                      "without the k-mer tables\n",
               f.rank_blocks * 1e-9, f.count_bases * 1e-9, f.sa_seq * 1e-9, f.sa_taxid * 1e-9, f.seq_tables * 1e-9, f.kmer_k,
-              f.kmer_table * 1e-9, f.kmer_lines * 1e-9,
+              f.kmer_table * 1e-9, f.kmer_lines * 1e-9, f.text * 1e-9, f.sa_full * 1e-9,
               (double)(f.total - f.kmer_table - f.kmer_lines) / (double)(pk.bwtlen ? pk.bwtlen : 1));
   }
   inf.warnings = pk.warnings;

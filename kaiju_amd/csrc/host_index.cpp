@@ -290,6 +290,11 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     const uint8_t *sa = v.sa;
     const int nb = v.nbytes, pb = v.pbits;
     uint32_t *dst = sa_iseq.data();
+    // the offsets too (text verification, narrow indexes): they fit 32 bits when pbits <= 32
+    sa_pos.clear();
+    if (!wide && pb <= 32) sa_pos.resize((size_t)n_sa);
+    uint32_t *dpos = sa_pos.empty() ? nullptr : sa_pos.data();
+    const uint64_t pmask = pb >= 64 ? ~0ull : ((1ull << pb) - 1ull);
     parallel_for((n_sa + 65535) / 65536, [&](uint64_t chunk) {
       const uint64_t b = chunk * 65536, e = std::min<uint64_t>(n_sa, b + 65536);
       for (uint64_t i = b; i < e; i++) {
@@ -297,6 +302,7 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
         uint64_t val = 0;
         for (int q = 0; q < nb; q++) val = (val << 8) + c[q];
         dst[i] = (uint32_t)(val >> pb);
+        if (dpos) dpos[i] = (uint32_t)(val & pmask);
       }
     });
   }
@@ -401,7 +407,7 @@ void PackedIndex::to_sequence_ids() {
 
 // ---- device image file: header, then every array as (u64 element count, raw elements) ----
 namespace {
-const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '4'};
+const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '5'};
 struct ImgHeader {
   char magic[8];
   uint64_t sizes[8];          // [0] size in bytes of the .fmi the image was made from, [1..3] sizeof RankBlock64, uint2, ulonglong2
@@ -464,7 +470,7 @@ int PackedIndex::write_image(const char *path, std::string &msg) const {
   snprintf(h.alphabet, sizeof h.alphabet, "%s", alphabet.c_str());
   bool ok = fwrite(&h, sizeof h, 1, fp) == 1;
   ok = ok && put_vec(fp, blocks64) && put_vec(fp, sa_taxid) &&
-       put_vec(fp, sa_iseq) && put_vec(fp, seq_taxid) && put_vec(fp, seq_valid) && put_vec(fp, term_pos) &&
+       put_vec(fp, sa_iseq) && put_vec(fp, sa_pos) && put_vec(fp, seq_taxid) && put_vec(fp, seq_valid) && put_vec(fp, term_pos) &&
        put_vec(fp, kmer32) && put_vec(fp, kmer64) && put_vec(fp, mb_base);
   // names: lengths then the characters
   std::vector<uint32_t> nl(names.size());
@@ -495,7 +501,7 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   std::vector<uint32_t> nl;
   std::vector<char> nc;
   ok = rd.vec(blocks64) && rd.vec(sa_taxid) &&
-       rd.vec(sa_iseq) && rd.vec(seq_taxid) && rd.vec(seq_valid) && rd.vec(term_pos) &&
+       rd.vec(sa_iseq) && rd.vec(sa_pos) && rd.vec(seq_taxid) && rd.vec(seq_valid) && rd.vec(term_pos) &&
        rd.vec(kmer32) && rd.vec(kmer64) && rd.vec(mb_base) && rd.vec(nl) && rd.vec(nc);
   close(fd);
   uint64_t total = 0;
@@ -503,7 +509,7 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   // consistency of what the kernels will index
   ok = ok && total == nc.size() && nl.size() == nseq && seq_taxid.size() == nseq && seq_valid.size() == nseq &&
        blocks64.size() == (size_t)(bwtlen >> 6) + 1 && sa_iseq.size() >= n_sa && (wide ? sa_taxid.empty() : sa_taxid.size() >= n_sa) &&
-       (!wide || mb_base.size() == (size_t)((bwtlen >> mb_shift) + 1) * 20);
+       (!wide || mb_base.size() == (size_t)((bwtlen >> mb_shift) + 1) * 20) && (sa_pos.empty() || sa_pos.size() == sa_iseq.size());
   if (!ok) { msg = "truncated or inconsistent index image"; return KAIJU_GPU_ERR_FORMAT; }
   names.clear();
   names.resize(nl.size());
@@ -514,6 +520,40 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
     for (size_t i = b; i < e; i++) names[i].assign(nc.data() + no[i], nl[i]);
   });
   return 0;
+}
+
+// The text and the full suffix array of a narrow index, on the host (test emulation; capi.hip runs the same steps as
+// kernels: k_suffix_walk, k_text_build): every row's (sequence, offset) by get_suffix, the sequences' lengths from the rows
+// of their terminator suffixes, sequence s (in the numbering of the samples) at text[off[s]] = 0, text[off[s] + 1 ..] = residues.
+void PackedIndex::build_text() {
+  sa_full.clear(); text.clear();
+  if (wide || sa_pos.empty() || blocks64.empty() || (warnings & KAIJU_IDX_WARN_SA_SHORT) || bwtlen + nseq + 2 * kTextPad >= 0xffffffffull) return;
+  const DevIndex d = host_view();
+  BigVec<uint32_t> rs((size_t)bwtlen), rp((size_t)bwtlen);
+  std::atomic<bool> ok{true};
+  parallel_for((bwtlen + 65535) / 65536, [&](uint64_t chunk) {
+    const uint64_t b = chunk * 65536, e = std::min<uint64_t>(bwtlen, b + 65536);
+    for (uint64_t r = b; r < e; r++) if (!suffix_of_row(d, sa_pos.data(), r, rs[(size_t)r], rp[(size_t)r])) ok = false;
+  });
+  if (!ok.load()) return;
+  std::vector<uint64_t> off((size_t)nseq + 1, 0);
+  {
+    std::vector<uint32_t> len(nseq, 0);
+    for (uint32_t r = 0; r < nseq; r++) { if (rs[r] >= nseq) return; len[rs[r]] = rp[r]; }
+    off[0] = kTextPad;
+    for (uint32_t q = 0; q < nseq; q++) off[(size_t)q + 1] = off[q] + len[q] + 1;
+  }
+  if (off[nseq] + kTextPad >= 0xffffffffull) return;
+  text.assign((size_t)(off[nseq] + 2 * kTextPad), 0);
+  sa_full.resize((size_t)bwtlen);
+  parallel_for((bwtlen + 65535) / 65536, [&](uint64_t chunk) {
+    const uint64_t b = chunk * 65536, e = std::min<uint64_t>(bwtlen, b + 65536);
+    for (uint64_t r = b; r < e; r++) {
+      const uint64_t g = off[rs[(size_t)r]] + 1 + rp[(size_t)r];
+      sa_full[(size_t)r] = (uint32_t)g;
+      text[(size_t)(g - 1)] = (uint8_t)symbol_at(d, r);
+    }
+  });
 }
 
 int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::string &msg) {
@@ -544,6 +584,8 @@ DevIndex PackedIndex::host_view() const {
   d.kmer64 = kmer64.empty() ? nullptr : kmer64.data();
   d.kmer_k = kmer_k;
   d.kline = kline.empty() ? nullptr : kline.data();
+  d.sa_full = sa_full.empty() ? nullptr : sa_full.data();
+  d.text = text.empty() ? nullptr : text.data();
   return d;
 }
 

@@ -76,6 +76,12 @@ struct PackedIndex {
   BigVec<uint64_t> sa_taxid;      // taxon id per sampled SA row (~0: unusable name)
   uint64_t src_fmi_bytes = 0;        // size of the .fmi this was packed from (0: not from a file); kept in an image's header
   BigVec<uint32_t> sa_iseq;
+  BigVec<uint32_t> sa_pos;        // offset (within its sequence) of every sampled row: what the text builder needs besides sa_iseq
+                                  // (narrow indexes; empty where an offset does not fit 32 bits)
+  // text verification (DevIndex::sa_full / text), built on the HOST for the test emulation only - the device builds its own
+  BigVec<uint32_t> sa_full;
+  BigVec<uint8_t> text;
+  void build_text();                // fills sa_full / text (call after build / read_image); leaves them empty if not applicable
   std::vector<uint64_t> seq_taxid;
   std::vector<uint8_t> seq_valid;
   BigVec<uint64_t> term_pos;

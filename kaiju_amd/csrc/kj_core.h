@@ -90,7 +90,20 @@ struct DevIndex {
   // one bit per letter b saying whether b.M occurs at all (b = w[j-k]: the k-mer that ends at j-1).  Three of four k-mers
   // of a read are not in the index: their lookups cost no line of their own any more.
   const uint8_t *kline;      // [20^(kmer_k-1)] lines of 128 bytes; nullptr = none
+  // TEXT VERIFICATION (narrow indexes that leave room): the database itself - text[] in index-alphabet codes,
+  // every sequence behind a 0 byte - and the position in it of the suffix of EVERY row (the full suffix array, 4 bytes a row).
+  // Once a backward search has narrowed to one row and still has letters to go, its match grows exactly as far as the read
+  // agrees with the text in front of that row's suffix (UpdateSI on a one-row interval succeeds iff the BWT letter of the row
+  // = the letter in front of the suffix equals the next letter of the read): one suffix-array load and one 64-byte text load
+  // replace - in the benchmark workload - twenty dependent rank steps per such match, 36 of 76 steps per read.
+  const uint32_t *sa_full;   // [bwtlen] position in text[] of the suffix of row r; nullptr = no text verification
+  const uint8_t *text;       // 64 zero bytes, then per sequence (in the order of the sampled sequence numbers) 0 + its residues
 };
+constexpr uint32_t kTextPad = 64;            // zero bytes in front of the first sequence (a text window never starts below 0)
+constexpr int kTextMinLeft = 3;              // letters left in front of the match for the text comparison to be worth its two loads
+constexpr int kTextTrigLen = 9;              // ... and the match at least this long: intervals shrink to one row at six to eight letters
+                                             // (190 M to 4 G rows) and four of five such matches end right there - the ones that
+                                             // have grown two letters past that point go on for twenty more on average
 
 // ---- k-mer lines ----------------------------------------------------------------------------------------------------------
 // bytes 0..119: twenty entries {lo: 32 bit, len16: 16 bit} for a = 1..20; bytes 120..123: bit b-1 set = the word b.M has a
@@ -364,6 +377,30 @@ KJ_HD uint64_t rank_term(const DevIndex &ix, uint64_t k) {
     if (ix.term_pos[mid] < k) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+// get_suffix (bwt.c:105-121) for row r: sequence number (in the order of the samples: rank among the sorted sequences) and
+// offset of the suffix of row r.  smp_pos: the offset part of every sampled row (the sequence part is sa_iseq).  Rows below
+// nseq (the suffixes that consist of a terminator only - no search ever asks for them, the text builder does) take their first
+// LF step unconditionally.  Returns false where the reference would read beyond its sample array.
+KJ_HD bool suffix_of_row(const DevIndex &ix, const uint32_t *smp_pos, uint64_t r, uint32_t &iseq, uint32_t &pos) {
+  const uint64_t check = (1ull << ix.chpt_exp) - 1ull;
+  uint64_t k = r;
+  uint32_t steps = 0;
+  bool first = r < ix.nseq;
+  for (;;) {
+    if (!first && (k & check) == 0) {
+      const uint64_t q = (k >> ix.chpt_exp) - ix.sa_skip;
+      if (q >= ix.n_sa) return false;
+      iseq = ix.sa_iseq[q]; pos = smp_pos[q] + steps;
+      return true;
+    }
+    first = false;
+    const uint32_t c = symbol_at(ix, k);
+    steps++;
+    if (c == 0) { iseq = (uint32_t)rank_term(ix, k); pos = steps - 1u; return true; }
+    k = rank_c(ix, c, k);
+  }
 }
 
 // k-mer table lookup: letters w[0] (matched first, i.e. the rightmost residue) .. w[k-1]
@@ -2011,7 +2048,8 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // in chunks of consecutive reads (one atomic per chunk, guided chunk size), lanes take reads
 // from the wave's chunk with a ballot/prefix count.
 // ----------------------------------------------------------------------------
-enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT };
+enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT,
+                     K_SAPOS, K_TEXT };   // text verification (narrow): suffix-array entry of the row, then the text in front of it
 enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
 
 
@@ -2087,7 +2125,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     KJ_PM(PM_HEAD);
     const bool rare_ok = (gate_it++ & kMemRareGate) == 0u;
     const int kind_saved = kind;
-    const bool parked = !rare_ok && (kind == K_META || kind == K_FRAG || kind == K_FILL);
+    const bool parked = !rare_ok && (kind == K_META || kind == K_FRAG || kind == K_FILL || kind == K_TEXT);
     if (parked) kind = K_WAIT;
     // ---- (0) hand out reads to the lanes that finished one (wave-uniform control flow) ----
     {
@@ -2135,7 +2173,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (kind == K_KMER) oc[kOpcKmer]++;
       else if (kind == K_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
       else if (kind == K_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
-      else if (kind == K_SA) oc[kOpcSa]++;
+      else if (kind == K_SA || kind == K_SAPOS) oc[kOpcSa]++;                 // (a suffix-array line either way)
+      else if (kind == K_TEXT) oc[kOpcFill]++;                                 // (64 bytes of text: priced like a window)
       else if (kind == K_META) oc[kOpcMeta]++;
       else if (kind == K_FRAG) oc[kOpcFrag]++;
       else if (kind == K_FILL) { oc[kOpcFill]++; if (fill_newfrag && f < nf) oc[kOpcFrag]++; }
@@ -2172,6 +2211,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
     if (kind == K_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
     else if (kind == K_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
+    else if (!WIDE && kind == K_SAPOS) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_full + lo);
     else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == K_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == K_FILL && fill_newfrag && f < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + f);
@@ -2181,11 +2221,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
                                                                           : reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
     u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
     int fq = 0;
-    if (kj_ballot(kind == K_FILL)) {                       // wave-uniform
+    if (kj_ballot(kind == K_FILL || kind == K_TEXT)) {     // wave-uniform
       KJ_PM(PM_LOADFILL);
       fq = fill_top - (kWin - 1);
       if (fq < 0) fq = 0;
-      const uint8_t *src = kind == K_FILL ? b.pep + fsoff + fq : reinterpret_cast<const uint8_t *>(blk0);
+      // (K_TEXT: the 64 bytes of the database that lie where fragment positions 0..63 would if the match went on)
+      const uint8_t *src = kind == K_FILL ? b.pep + fsoff + fq : (!WIDE && kind == K_TEXT) ? ix.text + (kidx - (uint32_t)i)
+                                                                                           : reinterpret_cast<const uint8_t *>(blk0);
       const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
       w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
     }
@@ -2207,6 +2249,10 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           lo = ra; hi = rb; i--;
           KJ_HIST_SINGLE(hi - lo == 1, j - i + 1);
           if (i == 0) bk = BK_END_MATCH;
+          else if (!WIDE && ix.text && hi - lo == 1 && j - i + 1 >= kTextTrigLen && i >= kTextMinLeft && lw.q == 0 && i <= kWin) {
+            // one row left and letters to go: the rest of this match is read off the database text (K_SAPOS, K_TEXT)
+            kind = K_SAPOS;
+          }
           else if (in_win(i - 1)) c = lw.w[i - 1 - lw.q];
           else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
         }
@@ -2292,6 +2338,27 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       row++;
       k = row; fresh = true;
       bk = BK_LOC_ROW;
+    } else if (!WIDE && kind == K_SAPOS) {
+      // position in the text of the suffix of row lo = of fragment position i
+      const uint32_t q = (uint32_t)lo & 3u;
+      kidx = q == 0 ? (uint32_t)gv.x : q == 1 ? (uint32_t)(gv.x >> 32) : q == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
+      kind = K_TEXT;
+    } else if (!WIDE && kind == K_TEXT) {
+      // UpdateSI on a one-row interval succeeds iff the letter in front of the suffix is the next letter of the read
+      // (bwt.c:160-173 with hi - lo = 1): the match ends in front of the highest position x < i whose letter differs from the
+      // text's (a terminator, 0, differs from every letter), or at the start of the fragment
+      const uint32_t *w32 = reinterpret_cast<const uint32_t *>(lw.w);
+      const uint64_t t8[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
+      int x = -1;
+#pragma unroll
+      for (int wi = 0; wi < 8; wi++) {
+        const int nb = i - 8 * wi;                          // bytes of this word below position i
+        const uint64_t mask = nb >= 8 ? ~0ull : nb <= 0 ? 0ull : ((1ull << (8 * nb)) - 1ull);
+        const uint64_t d = (t8[wi] ^ ((uint64_t)w32[2 * wi] | (uint64_t)w32[2 * wi + 1] << 32)) & mask;
+        if (d) x = 8 * wi + ((63 - (int)__builtin_clzll(d)) >> 3);
+      }
+      i = x + 1;
+      bk = BK_END_MATCH;                                    // (lo, hi still name the one row the search had reached: same sequence)
     } else if (kind == K_META) {
       KJ_PM(PM_META);
       pepoff = gv.x;

@@ -36,6 +36,7 @@ void *emu_index_load(const char *path, char *err, int errlen) {
   int rc = ix->file.load(path, msg);
   if (rc == 0) rc = ix->packed.build(ix->file.view(), msg);
   if (rc == 0) ix->packed.build_klines();          // (the device builds its k-mer lines in capi.hip: k_kline_build)
+  if (rc == 0 && !getenv("KAIJU_EMU_NO_TEXT")) ix->packed.build_text();   // (... and its text / full suffix array: k_suffix_walk, k_text_build)
   if (rc == 0) rc = build_const_tables(ix->packed.trans, ix->ct, msg);
   if (rc == 0) rc = build_seg_tables(ix->lnfact, ix->st, msg);
   if (rc != 0) { snprintf(err, (size_t)errlen, "%s", msg.c_str()); delete ix; return nullptr; }
@@ -388,7 +389,7 @@ extern "C" int emu_image_roundtrip(const char *fmi, const char *image) {
   if (a.src_fmi_bytes != b.src_fmi_bytes) return 4;
   auto same = [](const auto &x, const auto &y) { return x.size() == y.size() && (x.empty() || !memcmp(x.data(), y.data(), x.size() * sizeof(x[0]))); };
   if (!same(a.blocks64, b.blocks64) || !same(a.sa_taxid, b.sa_taxid) ||
-      !same(a.sa_iseq, b.sa_iseq) || !same(a.seq_taxid, b.seq_taxid) || !same(a.seq_valid, b.seq_valid) ||
+      !same(a.sa_iseq, b.sa_iseq) || !same(a.sa_pos, b.sa_pos) || !same(a.seq_taxid, b.seq_taxid) || !same(a.seq_valid, b.seq_valid) ||
       !same(a.term_pos, b.term_pos) || !same(a.kmer32, b.kmer32) || !same(a.kmer64, b.kmer64) || !same(a.mb_base, b.mb_base)) return 1;
   if (a.names != b.names || a.alphabet != b.alphabet || memcmp(a.C, b.C, sizeof a.C) || memcmp(a.trans, b.trans, 128)) return 2;
   if (a.bwtlen != b.bwtlen || a.n_sa != b.n_sa || a.sa_skip != b.sa_skip || a.nseq != b.nseq || a.chpt_exp != b.chpt_exp ||
