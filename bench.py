@@ -655,6 +655,13 @@ def main():
         result["parity"] = parity
         result["parity_checked_reads"] = sum(p["checked"] for p in parity.values())
         result["mismatches"] = sum(p["mismatches"] for p in parity.values())
+    # (RCCL leaves a line about its library path in the C library's stdout buffer: out with it BEFORE the result, so that the
+    #  JSON line is the last thing this process prints)
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
     print(json.dumps(result), flush=True)
 
 

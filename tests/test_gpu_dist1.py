@@ -23,7 +23,9 @@ def test_single_rank_through_rccl(gpu_lib, tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--reads", "200000",
                         "--nseq", "20001", "--legs", "", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
-    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    out_lines = r.stdout.decode().strip().splitlines()
+    assert out_lines[-1].startswith("{"), out_lines[-3:]           # the JSON line is the LAST line of stdout (RCCL's own chatter first)
+    line = json.loads(out_lines[-1])
     assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["value"] > 0
     pg = line["config"]["process_group"]
     assert pg == {"backend": "nccl", "world_size": 1}, pg
