@@ -174,7 +174,7 @@ typedef struct kaiju_gpu_index_footprint {
   uint64_t kmer_table;    /* suffix interval of every k-letter word                                                       */
   uint64_t kmer_lines;    /* the same as 128-byte lines for two end positions each (narrow indexes)                       */
   uint64_t text;          /* the database text (narrow indexes with room: text verification of long matches)             */
-  uint64_t sa_full;       /* ... and the position in it of every row's suffix, 4 bytes per row                            */
+  uint64_t sa_full;       /* ... and position + sequence of every row's suffix, 2 x 4 bytes per row                      */
   uint64_t other;         /* constant tables                                                                              */
   uint64_t total;
   uint32_t kmer_k, wide;  /* k of the table; 1 = 64-bit positions                                                         */

@@ -828,7 +828,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   }
   lc.mark("k-mer table (device)");
   // ---- text verification: the database text + the full suffix array (5 bytes per row; narrow indexes with room for it) ----
-  d.sa_full = nullptr; d.text = nullptr;
+  d.sa_full = nullptr; d.text = nullptr; d.row_seq = nullptr;
   uint64_t text_bytes = 0;
   {
     size_t free_b = 0, total_b = 0;
@@ -867,11 +867,15 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         }
       }
       (void)hipGetLastError();
-      for (void *q : {(void *)row_seq, (void *)row_pos, (void *)d_len, (void *)d_off, (void *)d_bad}) if (q) (void)hipFree(q);
+      for (void *q : {(void *)row_pos, (void *)d_len, (void *)d_off, (void *)d_bad}) if (q) (void)hipFree(q);
+      if (!ok && row_seq) { (void)hipFree(row_seq); row_seq = nullptr; }     // (kept otherwise: DevIndex::row_seq)
       // (the sample offsets were only needed here)
       (void)hipFree(smp_alloc);
       ix->allocs.pop_back();
-      if (ok) { ix->allocs.push_back(sa_full); ix->allocs.push_back(text); d.sa_full = sa_full; d.text = text; }
+      if (ok) {
+        ix->allocs.push_back(sa_full); ix->allocs.push_back(text); ix->allocs.push_back(row_seq);
+        d.sa_full = sa_full; d.text = text; d.row_seq = row_seq;
+      }
       else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; }
     }
   }
@@ -895,7 +899,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     f.kmer_lines = d.kline ? nw / 20 * kKLineBytes : 0;
     f.other = sizeof(ConstTables) + sizeof(Stage1Tables) + lnfact.size() * 8;
     f.text = d.text ? text_bytes : 0;
-    f.sa_full = d.sa_full ? pk.bwtlen * 4 : 0;
+    f.sa_full = d.sa_full ? pk.bwtlen * 8 : 0;                 // (+ the sequence of every row, DevIndex::row_seq)
     f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other + f.text + f.sa_full;
     f.kmer_k = d.kmer_k; f.wide = d.mb_base ? 1u : 0u;
     inf.device_bytes = f.total;

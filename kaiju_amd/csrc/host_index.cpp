@@ -526,7 +526,7 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
 // kernels: k_suffix_walk, k_text_build): every row's (sequence, offset) by get_suffix, the sequences' lengths from the rows
 // of their terminator suffixes, sequence s (in the numbering of the samples) at text[off[s]] = 0, text[off[s] + 1 ..] = residues.
 void PackedIndex::build_text() {
-  sa_full.clear(); text.clear();
+  sa_full.clear(); text.clear(); row_seq.clear();
   if (wide || sa_pos.empty() || blocks64.empty() || (warnings & KAIJU_IDX_WARN_SA_SHORT) || bwtlen + nseq + 2 * kTextPad >= 0xffffffffull) return;
   const DevIndex d = host_view();
   BigVec<uint32_t> rs((size_t)bwtlen), rp((size_t)bwtlen);
@@ -554,6 +554,7 @@ void PackedIndex::build_text() {
       text[(size_t)(g - 1)] = (uint8_t)symbol_at(d, r);
     }
   });
+  row_seq.swap(rs);
 }
 
 int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::string &msg) {
@@ -586,6 +587,7 @@ DevIndex PackedIndex::host_view() const {
   d.kline = kline.empty() ? nullptr : kline.data();
   d.sa_full = sa_full.empty() ? nullptr : sa_full.data();
   d.text = text.empty() ? nullptr : text.data();
+  d.row_seq = row_seq.empty() ? nullptr : row_seq.data();
   return d;
 }
 

@@ -98,6 +98,8 @@ struct DevIndex {
   // replace - in the benchmark workload - twenty dependent rank steps per such match, 36 of 76 steps per read.
   const uint32_t *sa_full;   // [bwtlen] position in text[] of the suffix of row r; nullptr = no text verification
   const uint8_t *text;       // 64 zero bytes, then per sequence (in the order of the sampled sequence numbers) 0 + its residues
+  const uint32_t *row_seq;   // [bwtlen] the sequence the suffix of row r lies in, as get_suffix finds it by walking to a sampled row
+                             // (built along with sa_full): k_mem_locate reads an id with two loads instead of walking; nullptr = walk
 };
 constexpr uint32_t kTextPad = 64;            // zero bytes in front of the first sequence (a text window never starts below 0)
 constexpr int kTextMinLeft = 3;              // letters left in front of the match for the text comparison to be worth its two loads
@@ -2573,6 +2575,14 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
     const P rowend = lo + (P)(int32_t)len;
     for (P row = lo; row < rowend; row++) {
       if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; break; }     // :805-807
+      if constexpr (!WIDE) {
+        if (ix.row_seq) {
+          // the walk below, precomputed for every row at index load (k_suffix_walk)
+          const uint32_t iseq = ix.row_seq[row];
+          if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+          continue;
+        }
+      }
       P k = row;
       for (;;) {
         if ((k & check) == 0) {
