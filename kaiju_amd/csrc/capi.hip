@@ -1389,7 +1389,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     GreedyArrays2 g2{};
     if (use_g2) {
       if ((rc = ensure(c->scratch_main[5], (lanes_main * (8 * kGSlotsAll) + 4) * sizeof(u128)))) return rc;
-      if ((rc = ensure(c->scratch_main[6], lanes_main * (kGSlotsAll - kGSlots) * sizeof(uint32_t)))) return rc;
+      if ((rc = ensure(c->scratch_main[6], (lanes_main * (kGSlotsAll - kGSlots) + 16) * sizeof(uint32_t)))) return rc;   // (+ slack: read 16 bytes at a time)
       if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
       if ((rc = ensure(c->scratch_main[8], lanes_main * (kGMaxMAll - kGMaxM) * sizeof(uint16_t)))) return rc;
       const bool g_wide = ix->dev.mb_base != nullptr;

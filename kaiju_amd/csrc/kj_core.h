@@ -3153,9 +3153,12 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   uint32_t r = 0, nf = 0, fo = 0, fbase = 0;
   uint64_t pepoff = 0;
   // (state that only the slow part touches lives in the lane's LDS row: gs.sub[6..14])
-  uint32_t &on_start = gs.sub[6], &on_len = gs.sub[7], &on_key = gs.sub[8], &on_flags = gs.sub[9];
+  // (length and key of the prefetched original share a word, 16 bits each, saturating: a fragment that reaches 65535 in
+  // either goes to the retry pass; the word this frees holds the largest priority in the queue's overflow area)
+  uint32_t &on_start = gs.sub[6], &on_kl = gs.sub[7], &ext_max = gs.sub[8], &on_flags = gs.sub[9];
+  auto on_pack = [](uint32_t len, uint32_t key) -> uint32_t { return (len > 0xffffu ? 0xffffu : len) | (key > 0xffffu ? 0xffffu : key) << 16; };
   uint32_t &b0lo = gs.sub[10], &b0len = gs.sub[11];
-  on_start = on_len = on_key = on_flags = b0lo = b0len = 0;
+  on_start = on_kl = ext_max = on_flags = b0lo = b0len = 0;
   uint32_t best = 0, nbest = 0, flags = 0;
   bool ovf = false;
   // queue of variants and SEG pieces
@@ -3238,33 +3241,42 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     while (x < nm && mq_get(x) != v) x++;
     return x;
   };
-  auto pr_get = [&](uint32_t s) -> uint32_t { return s < (uint32_t)kGSlots ? prio[s] : GS_PRIO_EXT[s - kGSlots]; };
-  auto pr_set = [&](uint32_t s, uint32_t v) { if (s < (uint32_t)kGSlots) prio[s] = v; else GS_PRIO_EXT[s - kGSlots] = v; };
   // multimap emplace of a variant / SEG piece: returns the slot (or ~0)
+  // The queue's priorities: slots 0 .. kGSlots-1 in LDS (freed slots are used again; qlive = the live ones among them), further
+  // entries in the overflow area in device memory, APPEND-ONLY within a read (qn = slots handed out so far); ext_max = the
+  // largest priority there, so that a pop only reads the overflow area when the best entry lies in it (live entries at a
+  // push: 12 and more in 45 % of the cases - with a scan of the overflow area in every pop and every push, a fifth of this
+  // lane's cycles went there, profiles/r03_l7).
   auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
-    KJ_HISTO(7, qlive);
+    KJ_HISTO(7, qlive + (qn > (uint32_t)kGSlots ? qn - (uint32_t)kGSlots : 0u));
     if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; return ~0u; }
-    uint32_t slot = qn;
-    if (qlive < qn) {
+    const uint32_t pr = key << 16 | (0xffffu - seq);
+    const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
+    uint32_t slot;
+    if (qlive < nl) {
+      // a free slot among the LDS slots handed out so far
       slot = 0;
       if constexpr (kGSlots % 4 == 0) {
-        // (four priorities per LDS read; a free slot below qn exists)
         bool got = false;
-        const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
         for (uint32_t q = 0; q < nl && !got; q += 4) {
           const u128 v = *reinterpret_cast<const u128 *>(prio + q);
           const uint32_t e0 = (uint32_t)v.x, e1 = (uint32_t)(v.x >> 32), e2 = (uint32_t)v.y, e3 = (uint32_t)(v.y >> 32);
           const uint32_t x = e0 == 0 ? 0u : e1 == 0 ? 1u : e2 == 0 ? 2u : e3 == 0 ? 3u : 4u;
           if (x < 4u && q + x < nl) { slot = q + x; got = true; }
         }
-        if (!got) { slot = kGSlots; while (pr_get(slot) != 0) slot++; }
       } else
-        while (pr_get(slot) != 0) slot++;
-    }
+        while (prio[slot] != 0) slot++;
+      qlive++;
+    } else if (qn < (uint32_t)kGSlots) { slot = qn++; qlive++; }
     else if (qn >= (uint32_t)kGSlotsAll) { ovf = true; return ~0u; }
-    else qn++;
-    pr_set(slot, key << 16 | (0xffffu - seq));
-    qlive++;
+    else {
+      slot = qn++;
+      GS_PRIO_EXT[slot - kGSlots] = pr;
+      if (pr > ext_max) ext_max = pr;
+      if constexpr (COUNT) oc[kOpcPush]++;
+      return slot;
+    }
+    prio[slot] = pr;
     if constexpr (COUNT) oc[kOpcPush]++;
     return slot;
   };
@@ -3426,7 +3438,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         if (bk == GB_POP) {
           KJ_P(PS_POP);
           // getNextFragment(best_match_score), ConsumerThread.cpp:272-342
-          uint32_t dbest = 0, dslot = 0;
+          uint32_t dbest = 0, dslot = 0, ext_second = 0;
           {
             const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
             if constexpr (kGSlots % 4 == 0) {
@@ -3441,19 +3453,46 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               }
             } else
               for (uint32_t s = 0; s < nl; s++) { const uint32_t pr = prio[s]; if (pr > dbest) { dbest = pr; dslot = s; } }
-            for (uint32_t s = kGSlots; s < qn; s++) { const uint32_t pr = GS_PRIO_EXT[s - kGSlots]; if (pr > dbest) { dbest = pr; dslot = s; } }
+            if (ext_max > dbest) {
+              // the best entry lies in the overflow area: find it, and the runner-up there (the next ext_max).  Entries
+              // behind qn are stale; the loads of a pass are independent (sixteen priorities in flight at a time)
+              const uint32_t next = qn - (uint32_t)kGSlots;
+              uint32_t e1 = 0, s1 = 0, e2 = 0;
+              for (uint32_t base = 0; base < next; base += 16) {
+                const u128 *src = reinterpret_cast<const u128 *>(GS_PRIO_EXT + base);
+                u128 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = (base + 4u * q < next) ? src[q] : u128{0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                  const uint32_t w[4] = {(uint32_t)v[q].x, (uint32_t)(v[q].x >> 32), (uint32_t)v[q].y, (uint32_t)(v[q].y >> 32)};
+#pragma unroll
+                  for (int z = 0; z < 4; z++) {
+                    const uint32_t idx = base + 4u * q + z;
+                    const uint32_t pr = idx < next ? w[z] : 0u;
+                    if (pr > e1) { e2 = e1; e1 = pr; s1 = idx; } else if (pr > e2) e2 = pr;
+                  }
+                }
+              }
+              dbest = e1; dslot = (uint32_t)kGSlots + s1; ext_second = e2;
+            }
           }
           const bool have_o = fo < nf, have_d = dbest != 0;
           const uint32_t dkey = dbest >> 16;
           if ((!have_o && !have_d) || ovf || m_ovf) bk = GB_FINISH;
           else {
+            const uint32_t on_key = on_kl >> 16, on_len = on_kl & 0xffffu;
             const bool pick_o = have_o && (!have_d || on_key >= dkey);
             if ((pick_o ? on_key : dkey) < best) bk = GB_FINISH;
-            else if (!pick_o) { pr_set(dslot, 0); qlive--; pslot = dslot; kind = G_POPITEM; bk = GB_NONE; }
+            else if (!pick_o) {
+              if (dslot < (uint32_t)kGSlots) { prio[dslot] = 0; qlive--; }
+              else { GS_PRIO_EXT[dslot - kGSlots] = 0; ext_max = ext_second; }
+              pslot = dslot; kind = G_POPITEM; bk = GB_NONE;
+            }
             else {
               t_start = on_start; t_len = on_len; t_diff = 0; t_matchlen = 0; t_tot = on_key; t_msum = 0; t_nmm = 0;
               const uint32_t oflags = on_flags;
-              if (on_key > 0xffffu || on_len > (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && on_start >= (1u << 24))) ovf = true;
+              if (on_key >= 0xffffu || on_len >= (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && on_start >= (1u << 24))) ovf = true;
               fo++;
               if (p.seg && !(oflags & kFragChecked)) {
                 // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked
@@ -3486,7 +3525,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                 }
                 if (fo < nf) {
                   const Frag nx = b.frags[fbase + fo];
-                  on_start = nx.start; on_len = nx.len; on_key = nx.key; on_flags = nx.flags;
+                  on_start = nx.start; on_kl = on_pack(nx.len, nx.key); on_flags = nx.flags;
                 }
                 continue;                                   // bk stays GB_POP
               }
@@ -3863,12 +3902,11 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           for (uint32_t s = 0; s < (uint32_t)kGSlots; s += 4) *reinterpret_cast<u128 *>(prio + s) = z;
         } else
           for (uint32_t s = 0; s < (uint32_t)kGSlots; s++) prio[s] = 0;
-        for (uint32_t s = kGSlots; s < qn; s++) GS_PRIO_EXT[s - kGSlots] = 0;
-        qn = qlive = qseq = 0;
+        qn = qlive = qseq = 0; ext_max = 0;                  // (the overflow area is append-only within a read: nothing to clear)
         if (nf == 0) bk = GB_FINISH; else kind = G_FRAG;
       } else if (kind == G_FRAG) {
         KJ_P(PS_FRAG);
-        on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
+        on_start = (uint32_t)gv.x; on_kl = on_pack((uint32_t)(gv.x >> 32), (uint32_t)gv.y); on_flags = (uint32_t)(gv.y >> 32);
         bk = GB_POP;
       } else if (kind == G_FILL || kind == G_POPITEM) {
         KJ_P(PS_FILL);
@@ -3926,7 +3964,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
               if (pz >= wq && pz < wq + kWin && pz < (int)t_len) win[pz - wq] = (uint8_t)(aw >> ((x & 3u) * 8u));
             }
             if (fill_pref && fo < nf) {
-              on_start = (uint32_t)gv.x; on_len = (uint32_t)(gv.x >> 32); on_key = (uint32_t)gv.y; on_flags = (uint32_t)(gv.y >> 32);
+              on_start = (uint32_t)gv.x; on_kl = on_pack((uint32_t)(gv.x >> 32), (uint32_t)gv.y); on_flags = (uint32_t)(gv.y >> 32);
             }
           }
           if (fill_ret == FR_STEP) { c = win[i - 1 - wq]; kind = G_STEP; }

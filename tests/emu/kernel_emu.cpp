@@ -291,7 +291,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         for (auto &x : lds_mq) x = 0xdeadbeefu;
         for (auto &x : lds_prio) x = 0xdeadbeefu;
         std::vector<u128> pool2(8 * kGSlotsAll + 4);
-        std::vector<uint32_t> prio_ext(kGSlotsAll - kGSlots, 0xdeadbeefu);
+        std::vector<uint32_t> prio_ext(kGSlotsAll - kGSlots + 16, 0xdeadbeefu);     // (+ slack: read 16 bytes at a time)
         std::vector<GMatch2> matches2(kGMaxMAll);
         std::vector<uint16_t> mq_ext(kGMaxMAll - kGMaxM, 0xdead);
         std::vector<GBest2> best2(64);
