@@ -172,9 +172,7 @@ k_segflag(Params p, SegTables st, Batch b, SegQueue sq, const uint32_t *seglist,
       F[k].flags = fl;
     }
     b.meta[r].nfrag = nf | pending;
-    uint4 *h = reinterpret_cast<uint4 *>(b.hits + r);      // 184 bytes, 8-byte aligned
-    uint64_t *h8 = reinterpret_cast<uint64_t *>(b.hits + r);
-    (void)h;
+    uint64_t *h8 = reinterpret_cast<uint64_t *>(b.hits + r);   // 184 bytes, 8-byte aligned
     for (int x = 0; x < (int)(sizeof(Hit) / 8); x++) h8[x] = 0;
   }
 }

@@ -434,6 +434,11 @@ template <class T> struct HugeAlloc {
 template <class T> using HugeVec = std::vector<T, HugeAlloc<T>>;
 typedef HugeVec<char> CharVec;
 
+// bytes of column-7 text per call of the verbose entry point (KAIJU_GPU_VERBOSE_BUDGET: tests make it small)
+static uint64_t verbose_text_budget() {
+  static const uint64_t v = [] { const char *e = getenv("KAIJU_GPU_VERBOSE_BUDGET"); const long long x = e ? atoll(e) : 0; return x > 0 ? (uint64_t)x : 1ull << 30; }();
+  return v;
+}
 struct Batch {
   CharVec seqs;
   HugeVec<uint64_t> off{0};
@@ -443,13 +448,20 @@ struct Batch {
   // results
   HugeVec<kaiju_gpu_hit> hits;             // -v only
   HugeVec<kaiju_gpu_verbose> vrec;         // -v only: columns 6/7
-  CharVec vtext;
-  uint32_t vstride = 0;
+  // -v only: the matched peptides (column 7).  The library wants one stride for all reads of a call - room for the longest
+  // of them, up to 64 KB - so a batch is classified in pieces of at most verbose_text_budget() bytes of text: one 10-kb read in a
+  // batch of a million no longer asks for 64 GB
+  struct VPiece { uint32_t lo = 0, n = 0, stride = 0; CharVec text; };
+  std::vector<VPiece> vpieces;
+  const char *vtext_of(size_t r) const {
+    for (const VPiece &p : vpieces) if (r >= p.lo && r < (size_t)p.lo + p.n) return p.text.data() + (r - p.lo) * (size_t)p.stride;
+    return nullptr;
+  }
   HugeVec<kaiju_gpu_compact> compact;
   std::string text;
   void reset() {                           // empty, capacities kept
     seqs.clear(); off.assign(1, 0); names.clear(); name_off.assign(1, 0);
-    hits.clear(); vrec.clear(); vtext.clear(); vstride = 0; compact.clear(); text.clear();
+    hits.clear(); vrec.clear(); vpieces.clear(); compact.clear(); text.clear();
   }
 };
 
@@ -885,12 +897,32 @@ int main(int argc, char **argv) {
           if (verbose) {
             b->hits.resize(n);
             b->vrec.resize(n);
-            uint64_t maxpair = 0;
-            for (uint32_t q = 0; q < n; q++) maxpair = std::max<uint64_t>(maxpair, b->off[2 * (size_t)q + 2] - b->off[2 * (size_t)q]);
-            b->vstride = kaiju_gpu_verbose_text_stride((uint32_t)maxpair, protein ? 1 : 0);
-            b->vtext.resize((size_t)n * b->vstride);
-            r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data(),
-                                                 b->vrec.data(), b->vtext.data(), b->vstride);
+            std::vector<uint64_t> poff;
+            for (uint32_t lo = 0; lo < n && r == 0;) {
+              // the longest piece from read lo on whose text fits the budget (at least one read)
+              uint64_t maxpair = 0;
+              uint32_t hi = lo, stride = 0;
+              while (hi < n) {
+                const uint64_t mp = std::max<uint64_t>(maxpair, b->off[2 * (size_t)hi + 2] - b->off[2 * (size_t)hi]);
+                const uint32_t st = kaiju_gpu_verbose_text_stride((uint32_t)mp, protein ? 1 : 0);
+                if (hi > lo && (uint64_t)(hi - lo + 1) * st > verbose_text_budget()) break;
+                maxpair = mp; stride = st; hi++;
+              }
+              b->vpieces.emplace_back();
+              Batch::VPiece &pc = b->vpieces.back();
+              pc.lo = lo; pc.n = hi - lo; pc.stride = stride;
+              pc.text.resize((size_t)pc.n * stride);
+              const uint64_t base = b->off[2 * (size_t)lo];
+              const uint64_t *po = b->off.data() + 2 * (size_t)lo;
+              if (base != 0) {                   // (the entry point wants off[0] == 0)
+                poff.resize(2 * (size_t)pc.n + 1);
+                for (size_t q = 0; q < poff.size(); q++) poff[q] = po[q] - base;
+                po = poff.data();
+              }
+              r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data() + base, po, pc.n, paired ? 1 : 0, b->hits.data() + lo,
+                                                   b->vrec.data() + lo, pc.text.data(), stride);
+              lo = hi;
+            }
           } else if (xmode) {
             b->hits.resize(n);
             r = kaiju_gpu_classify_batch(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data());
@@ -966,7 +998,7 @@ int main(int argc, char **argv) {
               for (uint32_t q = 0; q < k; q++) { const char *sn = kaiju_gpu_index_seq_name(index, (uint32_t)ids[q]); if (sn) text += sn; text += ','; }
               text += '\t';
               if (verbose) {
-                text.append(b->vtext.data() + (size_t)r * b->vstride, b->vrec[r].text_len);
+                text.append(b->vtext_of(r), b->vrec[r].text_len);
                 if (b->vrec[r].truncated) { fprintf(stderr, "Warning: matched peptides of read %.*s truncated\n", (int)nl, nm); inexact_reads++; }
               }
               text += '\n';
@@ -1005,7 +1037,7 @@ int main(int argc, char **argv) {
                 std::sort(acc, acc + na);
                 for (uint32_t q = 0; q < na; q++) if (q == 0 || acc[q] != acc[q - 1]) { text += acc[q]; text += ','; }
                 text += '\t';
-                text.append(b->vtext.data() + (size_t)r * b->vstride, v.text_len);
+                text.append(b->vtext_of(r), v.text_len);
                 if (v.truncated) { fprintf(stderr, "Warning: matched peptides of read %.*s truncated\n", (int)nl, nm); inexact_reads++; }
               }
               text += '\n';

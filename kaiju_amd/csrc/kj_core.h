@@ -260,6 +260,9 @@ struct Batch {
 // peptide area of read r: <= 2*(len1+len2) + 12 bytes of strings after 8 bytes of front padding (build_fragments), or six
 // strings of whole 16-byte units per mate, <= 2*(len1+len2) + 192 bytes (build_fragments_fast)
 constexpr uint64_t kPepPerRead = 208;
+// (the fast stage 1 writes six strings of whole 16-byte units per mate: 96 * (len / 48 + 1) bytes, at most 2 * len + 192 per
+//  read with two mates; pep_base() rounds the start down by up to 15 bytes - ADVICE r02: tie the constant to that layout)
+static_assert(kPepPerRead >= 2 * 96 + 15 + 1, "kPepPerRead must cover the unit padding of build_fragments_fast plus the rounding of pep_base");
 KJ_HD uint64_t pep_base(const uint64_t *off, uint32_t r) { return ((2 * off[2 * (uint64_t)r] + 15) & ~15ull) + kPepPerRead * r + 16; }
 // fragment slots of read r: a read has at most (2*(len1+len2)+12)/(m+1) disjoint fragments;
 // twice that is reserved so that SEG pieces can sit next to their parents

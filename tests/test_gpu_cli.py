@@ -134,3 +134,15 @@ def test_cli_closed_output_pipe_is_a_failure(gpu_lib, golden, tmp_path):
     p.stdout.readline()
     p.stdout.close()
     assert p.wait(timeout=120) != 0
+
+
+def test_cli_verbose_batches_in_pieces(gpu_lib, golden, tmp_path, monkeypatch):
+    """-v: the text of column 7 is collected in pieces of a bounded size (one long read must not size the buffers of a whole
+    batch); with a budget of a few reads per piece the lines are still the reference's, all seven columns"""
+    monkeypatch.setenv("KAIJU_GPU_VERBOSE_BUDGET", "5000")
+    for mode in ("mem", "greedy"):
+        out = run_cli(tmp_path, golden, ["-i", os.path.join(golden.dir, "reads.fq"), "-a", mode], f"pieces_{mode}.tsv")
+        assert first5(out) == first5(os.path.join(golden.dir, f"ref_{mode}_1.tsv"))
+    out = run_cli(tmp_path, golden, ["-i", os.path.join(golden.dir, "pairs_1.fq"), "-j", os.path.join(golden.dir, "pairs_2.fq"), "-a", "greedy"],
+                  "pieces_pe.tsv")
+    assert first5(out) == first5(os.path.join(golden.dir, "ref_greedy_1_pe.tsv"))
