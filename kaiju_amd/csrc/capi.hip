@@ -1758,6 +1758,13 @@ extern "C" int kaiju_gpu_get_stats(kaiju_gpu_ctx *ctx, kaiju_gpu_stats *stats) {
   }
 #endif
   stats->n_reads = ctx->last_n;
+  if (getenv("KAIJU_GPU_OVF_STATS") && ctx->params.mode == 1) {
+    uint32_t why[8] = {0};
+    KJ_HIP(hipMemcpy(why, static_cast<uint32_t *>(ctx->counters.p) + 40, sizeof why, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[kaiju_gpu] Greedy reads sent to the retry pass, by reason: key/sequence bits %u, queue full %u, original too long %u, "
+                    "SEG piece too long %u, variant too long %u, matches per fragment %u, wide interval %u\n",
+            why[0], why[1], why[2], why[3], why[4], why[5], why[6]);
+  }
   stats->n_overflow_retries = cnt[2];
   stats->n_seg_fragments = cnt[4];
   // bit 0 (a SegRec overflowed in the MEM split of the main pass) is settled by the exact pass, which reports its own

@@ -2054,7 +2054,8 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // from the wave's chunk with a ballot/prefix count.
 // ----------------------------------------------------------------------------
 enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT,
-                     K_SAPOS, K_TEXT };   // text verification (narrow): suffix-array entry of the row, then the text in front of it
+                     K_SAPOS, K_TEXT,     // text verification (narrow): suffix-array entry of the row, then the text in front of it
+                     K_BK = 16 };         // K_BK + b: bookkeeping block b of MemBk is due (no memory access)
 enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
 
 
@@ -2364,6 +2365,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       }
       i = x + 1;
       bk = BK_END_MATCH;                                    // (lo, hi still name the one row the search had reached: same sequence)
+    } else if (kind >= K_BK) {
+      bk = kind - K_BK;                                      // a bookkeeping block left over from the last iteration
     } else if (kind == K_META) {
       KJ_PM(PM_META);
       pepoff = gv.x;
@@ -2399,7 +2402,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     if (parked) kind = kind_saved;
     // ---- (3) bookkeeping, blocks ordered along the usual flow (see mem_lane) ----
     KJ_PM(PM_TAIL);
-    while (bk != BK_NONE) {
+    // ONE pass over the blocks, which stand in the order of the usual flow (a `while` around them made every variable of the
+    // lane a loop-carried value: the compiler copied some thirty registers at the head of that loop and again at every join -
+    // half of the kernel's VALU instructions were v_mov).  The one transition against that order - the walk over the rows of
+    // three and more longest matches: LOC_ROW -> LOC_NEXT_SI - waits for the next iteration (kind = K_BK + block).
+    {
       if (bk == BK_END_MATCH) {
         KJ_PM(PM_END_MATCH);
         const uint32_t l = (uint32_t)(j - i + 1);
@@ -2540,6 +2547,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         kind = K_IDLE; bk = BK_NONE;
       }
     }
+    if (bk != BK_NONE) kind = K_BK + bk;
   }
   if constexpr (COUNT) opc_flush(opc_of(wl), oc);
 #if defined(KJ_PROF) && defined(__HIP_DEVICE_COMPILE__)
@@ -3145,6 +3153,15 @@ enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 #define GS_BESTW (gs.bestw + (size_t)gs.lane * 64)
 // WIDE: indexes of 2^32 rows and more - 64-bit positions, block counts relative to DevIndex::mb_base, the k-mer TABLE of
 // 16-byte entries instead of the k-mer lines, sequence numbers instead of taxon ids at the sampled rows
+// why a read left the lane for the retry pass: counters in the batch's counter block (words 40..47; kaiju_gpu_get_stats prints
+// them under KAIJU_GPU_OVF_STATS=1).  0 key / sequence number beyond 16 bits, 1 more than kGSlotsAll live queue entries, 2 an
+// original beyond the lane's length fields, 3 a SEG piece beyond them, 4 a variant beyond them, 5 more than kGMaxMAll matches in a
+// fragment, 6 (wide) an interval of 2^32 rows and more
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KJ_OVF(wl, why) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>((wl).counter) & ~(uintptr_t)255) + 40 + (why), 1u)
+#else
+#define KJ_OVF(wl, why) ((void)0)
+#endif
 template <bool COUNT = false, bool WIDE = false>
 KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                         const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
@@ -3252,7 +3269,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   // lane's cycles went there, profiles/r03_l7).
   auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
     KJ_HISTO(7, qlive + (qn > (uint32_t)kGSlots ? qn - (uint32_t)kGSlots : 0u));
-    if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; return ~0u; }
+    if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; KJ_OVF(wl, 0); return ~0u; }
     const uint32_t pr = key << 16 | (0xffffu - seq);
     const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
     uint32_t slot;
@@ -3278,7 +3295,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         // is used again; none free = more than kGSlotsAll live entries: retry pass
         slot = kGSlots;
         while (slot < (uint32_t)kGSlotsAll && GS_PRIO_EXT[slot - kGSlots] != 0) slot++;
-        if (slot >= (uint32_t)kGSlotsAll) { ovf = true; return ~0u; }
+        if (slot >= (uint32_t)kGSlotsAll) { ovf = true; KJ_OVF(wl, 1); return ~0u; }
       }
       GS_PRIO_EXT[slot - kGSlots] = pr;
       if (pr > ext_max) ext_max = pr;
@@ -3501,7 +3518,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             else {
               t_start = on_start; t_len = on_len; t_diff = 0; t_matchlen = 0; t_tot = on_key; t_msum = 0; t_nmm = 0;
               const uint32_t oflags = on_flags;
-              if (on_key >= 0xffffu || on_len >= (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && on_start >= (1u << 24))) ovf = true;
+              if (on_key >= 0xffffu || on_len >= (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && on_start >= (1u << 24))) { ovf = true; KJ_OVF(wl, 2); }
               fo++;
               if (p.seg && !(oflags & kFragChecked)) {
                 // SEG found regions in this fragment (SEG pass): the parent is dropped, its unmasked
@@ -3513,7 +3530,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                   if (rec.overflow) flags |= kHitInternalOverflow;
                   Frag f; f.start = t_start; f.len = t_len; f.key = on_key; f.flags = 0;
                   seg_split(ct, p, rec, b.pep + pepoff, f, [&](const Frag &q) {
-                    if (q.len > (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && q.start >= (1u << 24))) { ovf = true; return; }
+                    if (q.len > (WIDE ? kGWideMaxFrag : 0xffffu) || (WIDE && q.start >= (1u << 24))) { ovf = true; KJ_OVF(wl, 3); return; }
                     const uint32_t sl = push_slot(q.key, qseq);
                     if (sl == ~0u) return;
                     qseq++;
@@ -3868,7 +3885,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           }
           if (ra >= rb) continue;
           KJ_P(PS_VM_PUSH);
-          if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; break; }
+          if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; KJ_OVF(wl, 4); break; }
           const int bss = (int)diag(cx);
           const uint32_t sl = push_slot(key, qseq + ct.subst_rank[vorig][cx - 1u]);
           if (sl == ~0u) break;
@@ -4016,7 +4033,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
               }
               if (nm < (uint32_t)kGMaxM) mq[nm] = (uint16_t)l; else GS_MQ_EXT[nm - kGMaxM] = (uint16_t)l;
               if constexpr (COUNT) oc[kOpcMatchWr]++;
-            } else m_ovf = true;
+            } else { if (!m_ovf) KJ_OVF(wl, 5); m_ovf = true; }
             nm++;
             last_qi = i;
           }
@@ -4026,7 +4043,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           // :443-449: after the last allowed mismatch the match must reach min_fragment_length
           const int Lreq = (t_nmm == p.mismatches) ? (int)p.m : (int)t_matchlen;
           if (l >= Lreq) {
-            if (WIDE && (uint64_t)(hi - lo) > 0xffffffffull) m_ovf = true;
+            if (WIDE && (uint64_t)(hi - lo) > 0xffffffffull) { m_ovf = true; KJ_OVF(wl, 6); }
             m_lo = lo; m_len = (uint32_t)(hi - lo); m_qi = (uint32_t)i; m_ql = (uint32_t)l; m_dsum = acc; m_psum = t_tot;
             nm = 1;
           }
