@@ -3153,11 +3153,11 @@ enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 #define GS_BESTW (gs.bestw + (size_t)gs.lane * 64)
 // WIDE: indexes of 2^32 rows and more - 64-bit positions, block counts relative to DevIndex::mb_base, the k-mer TABLE of
 // 16-byte entries instead of the k-mer lines, sequence numbers instead of taxon ids at the sampled rows
-// why a read left the lane for the retry pass: counters in the batch's counter block (words 40..47; kaiju_gpu_get_stats prints
-// them under KAIJU_GPU_OVF_STATS=1).  0 key / sequence number beyond 16 bits, 1 more than kGSlotsAll live queue entries, 2 an
+// why a read left the lane for the retry pass (-DKJ_OVF_STATS builds): counters in the batch's counter block (words 40..47;
+// kaiju_gpu_get_stats prints them under KAIJU_GPU_OVF_STATS=1).  0 key / sequence number beyond 16 bits, 1 more than kGSlotsAll live queue entries, 2 an
 // original beyond the lane's length fields, 3 a SEG piece beyond them, 4 a variant beyond them, 5 more than kGMaxMAll matches in a
 // fragment, 6 (wide) an interval of 2^32 rows and more
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(KJ_OVF_STATS)         // (a diagnostic build: tests/tools/mem_variants.sh, variant ovf)
 #define KJ_OVF(wl, why) atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uintptr_t>((wl).counter) & ~(uintptr_t)255) + 40 + (why), 1u)
 #else
 #define KJ_OVF(wl, why) ((void)0)
