@@ -2070,12 +2070,16 @@ KJ_HD uint32_t kj_fetch_chunk(uint32_t *counter, uint32_t n) { const uint32_t v 
 #if defined(KJ_HIST) && !defined(__HIP_DEVICE_COMPILE__)
 extern unsigned long long kj_hist[8][64];
 #define KJ_HISTO(h, v) kj_hist[h][(v) < 63 ? (v) : 63]++
+#ifndef KJ_HIST_QSHIFT
+#define KJ_HIST_QSHIFT 0
+#endif
 // (MEM lane: how many letters a match still grows after its interval has shrunk to one row - what a text comparison could replace)
 static int kj_single_at = 0;
 #define KJ_HIST_SINGLE(is1, len) { if ((is1) && !kj_single_at) kj_single_at = (len); }
 #define KJ_HIST_SINGLE_END(l) { if (kj_single_at) { KJ_HISTO(3, (int)(l) - kj_single_at); KJ_HISTO(2, kj_single_at); } kj_single_at = 0; }
 #else
 #define KJ_HISTO(h, v)
+#define KJ_HIST_QSHIFT 0
 #define KJ_HIST_SINGLE(is1, len)
 #define KJ_HIST_SINGLE_END(l)
 #endif
@@ -3100,9 +3104,17 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
 // ----------------------------------------------------------------------------
 #ifdef KJ_G_SMALL                                  // tests: exercise the spill and retry paths
 constexpr int kGMaxM = 1, kGMaxMAll = 2, kGSlots = 1, kGSlotsAll = 3;
-#else                           // experiment: LDS rows small enough for three blocks per CU
+#elif defined(KJ_BIGQ)                             // (workload statistics on the host: how many queue slots do the reads want?)
+constexpr int kGMaxM = 8, kGMaxMAll = 1024;
+constexpr int kGSlots = 12, kGSlotsAll = 8192;
+#else
 constexpr int kGMaxM = 8, kGMaxMAll = 256;
-constexpr int kGSlots = 12, kGSlotsAll = 128;
+// queue slots: 12 priorities in LDS, 512 slots in all (64 KB of items per lane in device memory).  With 128, reads of the
+// benchmark's viruses-size index never ran out, but on a 1 G-row index one push in ten found all slots handed out (the
+// overflow area is append-only within a read: a dead slot then has to be searched for) and 2 reads in 10 000 had more than
+// 128 LIVE entries - the retry pass they went to took five times as long as the whole batch (profiles/r03_l10).  The most
+// slots a read of that workload asked for: 496.
+constexpr int kGSlots = 12, kGSlotsAll = 512;
 #endif
 constexpr int kGSubStride = 17;                  // six words of substitutions + eleven of slow-part state
 // LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
@@ -3268,7 +3280,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   // push: 12 and more in 45 % of the cases - with a scan of the overflow area in every pop and every push, a fifth of this
   // lane's cycles went there, profiles/r03_l7).
   auto push_slot = [&](uint32_t key, uint32_t seq) -> uint32_t {
-    KJ_HISTO(7, qlive + (qn > (uint32_t)kGSlots ? qn - (uint32_t)kGSlots : 0u));
+    KJ_HISTO(7, (qlive + (qn > (uint32_t)kGSlots ? qn - (uint32_t)kGSlots : 0u)) >> KJ_HIST_QSHIFT);   // (slots handed out: live entries + popped overflow slots)
     if (key > 0xffffu || seq >= 0xfffeu) { ovf = true; KJ_OVF(wl, 0); return ~0u; }
     const uint32_t pr = key << 16 | (0xffffu - seq);
     const uint32_t nl = qn < (uint32_t)kGSlots ? qn : (uint32_t)kGSlots;
