@@ -150,6 +150,10 @@ int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *view, int device_id, k
    sequence numbers (kaiju_gpu_index_seq_name() gives the names), first-seen order, capped like taxon ids. */
 enum { KAIJU_GPU_IDS_TAXON = 0, KAIJU_GPU_IDS_SEQUENCE = 1 };
 int kaiju_gpu_index_load_ex(const char *fmi_or_image_path, int device_id, int id_mode, kaiju_gpu_index **out);
+/* The same index on several GPUs of the node (north star: "index replicated per GPU"): parsed and packed once, uploaded to
+   devices[0 .. n_devices-1] in turn; out[k] is the replica on devices[k] (free each with kaiju_gpu_index_free). */
+int kaiju_gpu_index_load_devices(const char *fmi_or_image_path, const int *devices, int n_devices, int id_mode,
+                                 kaiju_gpu_index **out);
 
 /* Device image of an index: the arrays of the HBM layout, packed once on the host and
    written to a file; kaiju_gpu_index_load() recognises such a file by its magic and uploads it without

@@ -669,7 +669,7 @@ static int upload(kaiju_gpu_index *ix, const std::vector<T, A> &v, const T **dst
   return 0;
 }
 
-static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out);
+static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out, bool keep_packed = false);
 static thread_local int tl_id_mode = 0;     // kaiju_gpu_index_load_ex: 1 = hits collect sequence numbers
 
 // The first HIP call of a process starts the runtime (about 0.15 s on an MI355X host); reading and packing an index needs
@@ -710,7 +710,7 @@ static int index_from_view(const HostIndexView &v, int device_id, kaiju_gpu_inde
 }
 
 // upload of the packed arrays (from a freshly packed .fmi or from an image file)
-static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out) {
+static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **out, bool keep_packed) {
   std::string msg;
   int rc;
   LoadClock lc;
@@ -911,7 +911,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   }
   inf.warnings = pk.warnings;
   snprintf(inf.alphabet, sizeof inf.alphabet, "%s", pk.alphabet.c_str());
-  ix->names.swap(pk.names);
+  if (keep_packed) ix->names = pk.names; else ix->names.swap(pk.names);    // (keep_packed: further GPUs get the same arrays)
   KJ_HIP(hipDeviceSynchronize());
   *out = ix.release();
   return KAIJU_GPU_OK;
@@ -985,6 +985,34 @@ extern "C" int kaiju_gpu_index_load_ex(const char *fmi_path, int device_id, int 
   const int rc = kaiju_gpu_index_load(fmi_path, device_id, out);
   tl_id_mode = 0;
   return rc;
+}
+
+// One index, several GPUs of a node: the file is parsed and packed (or its image read) ONCE, the packed arrays go to every
+// device in turn; each device grows its own k-mer table, lines and text arrays.  out[k] belongs to devices[k].
+extern "C" int kaiju_gpu_index_load_devices(const char *fmi_path, const int *devices, int n_devices, int id_mode, kaiju_gpu_index **out) {
+  return guarded([&]() -> int {
+  if (!fmi_path || !devices || !out || n_devices < 1) return fail(KAIJU_GPU_ERR_ARG, "bad argument");
+  if (id_mode != KAIJU_GPU_IDS_TAXON && id_mode != KAIJU_GPU_IDS_SEQUENCE) return fail(KAIJU_GPU_ERR_ARG, "id_mode");
+  for (int k = 0; k < n_devices; k++) out[k] = nullptr;
+  std::future<int> dev = device_check_async(devices[0]);
+  PackedIndex pk;
+  std::string msg;
+  int rc;
+  if (is_image_file(fmi_path)) rc = pk.read_image(fmi_path, msg);
+  else {
+    FmiFile f;
+    rc = f.load(fmi_path, msg);
+    if (rc == 0) rc = pk.build(f.view(), msg);
+  }
+  const int drc = device_check_result(dev);
+  if (drc) return drc;
+  if (rc) return fail(rc, msg);
+  tl_id_mode = id_mode;
+  for (int k = 0; k < n_devices && rc == 0; k++) rc = index_from_packed(pk, devices[k], &out[k], k + 1 < n_devices);
+  tl_id_mode = 0;
+  if (rc) for (int k = 0; k < n_devices; k++) { delete out[k]; out[k] = nullptr; }
+  return rc;
+  });
 }
 
 extern "C" int kaiju_gpu_index_from_host(const kaiju_gpu_host_index *hv, int device_id, kaiju_gpu_index **out) {

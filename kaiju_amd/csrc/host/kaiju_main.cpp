@@ -718,16 +718,25 @@ int main(int argc, char **argv) {
   // developer/test switch: run the ingest stages only and print "name<TAB>mate1<TAB>mate2" per read
   const bool parse_only = getenv("KAIJU_GPU_PARSE_ONLY") != nullptr;
   if (verbose) fprintf(stderr, "%s Reading database\n", now().c_str());
-  int device = 0;
-  if (const char *e = getenv("KAIJU_GPU_DEVICE")) device = atoi(e);
+  // Which GPUs: KAIJU_GPU_DEVICE=<n> (one, default 0) or KAIJU_GPU_DEVICES=<n,n,...|all>: the index is replicated on each of
+  // them (parsed and packed once), input block b goes to context b mod (2 x GPUs) - SURVEY 8e's "block b to GPU b mod N" -
+  // and the formatter stage puts the lines back in input order.
+  std::vector<int> devices;
+  if (const char *e = getenv("KAIJU_GPU_DEVICES")) {
+    if (!strcmp(e, "all")) { const int nd = kaiju_gpu_device_count(); for (int d = 0; d < nd; d++) devices.push_back(d); }
+    else for (const char *q = e; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+  }
+  if (devices.empty()) devices.push_back(getenv("KAIJU_GPU_DEVICE") ? atoi(getenv("KAIJU_GPU_DEVICE")) : 0);
+  const int n_dev = (int)devices.size();
   // nodes.dmp is parsed while the index loads
   kaiju_taxonomy *tax = nullptr;
-  kaiju_gpu_index *index = nullptr;
+  std::vector<kaiju_gpu_index *> indexes((size_t)n_dev, nullptr);
+  kaiju_gpu_index *index = nullptr;           // the first replica: sequence names, info
   kaiju_gpu_index_info info;
   memset(&info, 0, sizeof info);
-  kaiju_gpu_taxonomy *dtax = nullptr;
-  const int n_ctx = 2;                      // ping-pong: copies of one batch overlap with kernels of the other
-  kaiju_gpu_ctx *ctx[n_ctx] = {nullptr, nullptr};
+  std::vector<kaiju_gpu_taxonomy *> dtaxes((size_t)n_dev, nullptr);
+  const int n_ctx = 2 * n_dev;              // per GPU two: copies of one batch overlap with kernels of the other
+  std::vector<kaiju_gpu_ctx *> ctx((size_t)n_ctx, nullptr);
   // The index loads (and nodes.dmp is parsed, and the contexts are created) on a thread of its own while the input is
   // already being read and parsed: only the GPU stage of the pipeline waits for it.
   struct Ready { std::mutex m; std::condition_variable cv; bool done = false; } gpu_ready;
@@ -748,7 +757,8 @@ int main(int argc, char **argv) {
           kaiju_gpu_index_image_source_bytes(img.c_str(), &src_bytes) == 0 && src_bytes == (uint64_t)sa.st_size) load_fn = img;
       else if (getenv("KAIJU_GPU_WRITE_IMAGE") && kaiju_gpu_index_write_image(fmi_fn.c_str(), img.c_str()) == 0) load_fn = img;
     }
-    rc = kaiju_gpu_index_load_ex(load_fn.c_str(), device, xmode ? KAIJU_GPU_IDS_SEQUENCE : KAIJU_GPU_IDS_TAXON, &index);
+    rc = kaiju_gpu_index_load_devices(load_fn.c_str(), devices.data(), n_dev, xmode ? KAIJU_GPU_IDS_SEQUENCE : KAIJU_GPU_IDS_TAXON, indexes.data());
+    index = indexes[0];
     wall_mark("index on the device");
     tax_loader.join();
     wall_mark("nodes.dmp parsed");
@@ -756,12 +766,13 @@ int main(int argc, char **argv) {
     if (rc != 0) die(std::string("Could not load ") + fmi_fn + ": " + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
     kaiju_gpu_index_get_info(index, &info);
     if (info.warnings && verbose) fprintf(stderr, " Warning: the index triggers a latent bug of the reference (flags %u)\n", info.warnings);
-    if (!verbose && !xmode) {
-      rc = kaiju_gpu_taxonomy_upload(tax, device, &dtax);
-      if (rc != 0) die(std::string("kaiju_gpu_taxonomy_upload: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
-    }
-    for (int k = 0; k < n_ctx; k++) {
-      rc = kaiju_gpu_create(&ctx[k], index, &params);
+    if (!verbose && !xmode)
+      for (int d = 0; d < n_dev; d++) {
+        rc = kaiju_gpu_taxonomy_upload(tax, devices[(size_t)d], &dtaxes[(size_t)d]);
+        if (rc != 0) die(std::string("kaiju_gpu_taxonomy_upload: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
+      }
+    for (int k = 0; k < n_ctx; k++) {          // contexts 2d and 2d + 1 live on GPU d
+      rc = kaiju_gpu_create(&ctx[(size_t)k], indexes[(size_t)(k / 2)], &params);
       if (rc != 0) die(std::string("kaiju_gpu_create: ") + kaiju_gpu_strerror(rc) + " (" + kaiju_gpu_last_error() + ")");
     }
     wall_mark("taxonomy uploaded, contexts created");
@@ -928,7 +939,7 @@ int main(int argc, char **argv) {
             r = kaiju_gpu_classify_batch(ctx[k], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->hits.data());
           } else {
             b->compact.resize(n);
-            r = kaiju_gpu_classify_batch_compact(ctx[k], dtax, b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
+            r = kaiju_gpu_classify_batch_compact(ctx[k], dtaxes[(size_t)(k / 2)], b->seqs.data(), b->off.data(), n, paired ? 1 : 0, b->compact.data());
           }
           if (r != 0) die(std::string("classification failed: ") + kaiju_gpu_strerror(r) + " (" + kaiju_gpu_last_error() + ")");
           // reads for which a capacity bound of the kernels was exceeded (KAIJU_HIT_INEXACT, kaiju_gpu_stats.error_flags)
@@ -1095,9 +1106,9 @@ int main(int argc, char **argv) {
     fflush(nullptr);
     _exit(EXIT_SUCCESS);
   }
-  for (int k = 0; k < n_ctx; k++) if (ctx[k]) kaiju_gpu_destroy(ctx[k]);
-  if (dtax) kaiju_gpu_taxonomy_free(dtax);
-  if (index) kaiju_gpu_index_free(index);
+  for (int k = 0; k < n_ctx; k++) if (ctx[(size_t)k]) kaiju_gpu_destroy(ctx[(size_t)k]);
+  for (kaiju_gpu_taxonomy *t : dtaxes) if (t) kaiju_gpu_taxonomy_free(t);
+  for (kaiju_gpu_index *ix : indexes) if (ix) kaiju_gpu_index_free(ix);
   if (tax) kaiju_taxonomy_free(tax);
   wall_mark("teardown done");
   return EXIT_SUCCESS;

@@ -146,3 +146,19 @@ def test_cli_verbose_batches_in_pieces(gpu_lib, golden, tmp_path, monkeypatch):
     out = run_cli(tmp_path, golden, ["-i", os.path.join(golden.dir, "pairs_1.fq"), "-j", os.path.join(golden.dir, "pairs_2.fq"), "-a", "greedy"],
                   "pieces_pe.tsv")
     assert first5(out) == first5(os.path.join(golden.dir, "ref_greedy_1_pe.tsv"))
+
+
+def test_cli_blocks_over_several_gpus(gpu_lib, golden, tmp_path, monkeypatch):
+    """KAIJU_GPU_DEVICES: the index is replicated (parsed and packed once, kaiju_gpu_index_load_devices), input block b goes to
+    context b mod (2 x GPUs), the lines come out in input order.  On a box with one GPU the list names it twice - two replicas,
+    four contexts: the plumbing of an 8-GPU node - and small blocks make sure every context gets work."""
+    monkeypatch.setenv("KAIJU_GPU_DEVICES", "0,0")
+    monkeypatch.setenv("KAIJU_GPU_BATCH", "50")
+    for mode in ("mem", "greedy"):
+        out = run_cli(tmp_path, golden, ["-i", os.path.join(golden.dir, "reads.fq"), "-a", mode], f"multi_{mode}.tsv")
+        assert first5(out) == first5(os.path.join(golden.dir, f"ref_{mode}_1.tsv"))
+    out = str(tmp_path / "multi_nv.tsv")
+    subprocess.run([build.build_cli(), "-t", golden.nodes, "-f", golden.fmi, "-o", out, "-i", os.path.join(golden.dir, "reads.fq"), "-a", "greedy"],
+                   check=True)
+    got = [tuple(l.rstrip("\n").split("\t")) for l in open(out)]
+    assert got == [r[:3] for r in first5(os.path.join(golden.dir, "ref_greedy_1.tsv"))]
