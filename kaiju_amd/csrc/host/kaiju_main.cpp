@@ -818,7 +818,7 @@ int main(int argc, char **argv) {
     if (const char *e = getenv("KAIJU_GPU_BATCH")) batch_reads = (uint32_t)std::max(1L, atol(e));
     unsigned n_workers = std::max(2u, std::min(16u, std::thread::hardware_concurrency() / 2));
     if (const char *e = getenv("KAIJU_GPU_HOST_THREADS")) n_workers = (unsigned)std::max(1, atoi(e));
-    if (verbose) fprintf(stderr, "%s Start classification on GPU %d\n", now().c_str(), device);
+    if (verbose) fprintf(stderr, "%s Start classification on GPU %d%s\n", now().c_str(), devices[0], n_dev > 1 ? " and further ones (KAIJU_GPU_DEVICES)" : "");
 
     struct RawPair { std::unique_ptr<RawBlock> a, b; };
     // (one pool for all samples of kaiju-multi, never torn down: giving gigabytes of batch buffers back page by page
