@@ -3117,6 +3117,10 @@ constexpr int kGMaxM = 8, kGMaxMAll = 256;
 constexpr int kGSlots = 12, kGSlotsAll = 512;
 #endif
 constexpr int kGSubStride = 17;                  // six words of substitutions + eleven of slow-part state
+#ifndef KJ_G_EXT_PASS
+#define KJ_G_EXT_PASS 4
+#endif
+constexpr int kGExtPass = KJ_G_EXT_PASS;         // 16-byte loads in flight per pass over the queue's overflow area (4 priorities each)
 // LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
 #ifndef KJ_G_SMALL
 constexpr int kGWinStride = 17, kGMqStride = 4, kGPrioStride = 12;     // 132 bytes per lane + 68 (kGSubStride) = 200: three blocks of
@@ -3493,16 +3497,16 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               for (uint32_t s = 0; s < nl; s++) { const uint32_t pr = prio[s]; if (pr > dbest) { dbest = pr; dslot = s; } }
             if (ext_max > dbest) {
               // the best entry lies in the overflow area: find it, and the runner-up there (the next ext_max).  Entries
-              // behind qn are stale; the loads of a pass are independent (sixteen priorities in flight at a time)
+              // behind qn are stale; the loads of a pass are independent (4 * kGExtPass priorities in flight at a time)
               const uint32_t next = qn - (uint32_t)kGSlots;
               uint32_t e1 = 0, s1 = 0, e2 = 0;
-              for (uint32_t base = 0; base < next; base += 16) {
+              for (uint32_t base = 0; base < next; base += 4 * kGExtPass) {
                 const u128 *src = reinterpret_cast<const u128 *>(GS_PRIO_EXT + base);
-                u128 v[4];
+                u128 v[kGExtPass];
 #pragma unroll
-                for (int q = 0; q < 4; q++) v[q] = (base + 4u * q < next) ? src[q] : u128{0, 0};
+                for (int q = 0; q < kGExtPass; q++) v[q] = (base + 4u * q < next) ? src[q] : u128{0, 0};
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kGExtPass; q++) {
                   const uint32_t w[4] = {(uint32_t)v[q].x, (uint32_t)(v[q].x >> 32), (uint32_t)v[q].y, (uint32_t)(v[q].y >> 32)};
 #pragma unroll
                   for (int z = 0; z < 4; z++) {
