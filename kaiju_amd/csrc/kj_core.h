@@ -2476,11 +2476,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           kind = K_FILL; bk = BK_NONE;
         }
       }
-#ifdef KJ_MEM_BGATE
-      // experiment: the end of a read (LOC_INIT, FINISH: one or two lanes of 64, 0.7 times per wave iteration) only in every
-      // (KJ_MEM_BGATE+1)-th iteration, the one in front of an iteration that admits K_META
-      if (bk == BK_LOC_INIT && (gate_it & (uint32_t)(KJ_MEM_BGATE)) != 0u) { kind = K_BK + BK_LOC_INIT; bk = BK_NONE; }
-#endif
       if (bk == BK_LOC_INIT) {
         KJ_PM(PM_LOC_INIT);
         nids = 0; flags = 0;
