@@ -1058,7 +1058,8 @@ struct kaiju_gpu_ctx {
   DevBuf scratch_main[10], scratch_retry[5], h_compact;
   DevBuf redo_bitmap, redo_list, redo_items, redo_index, redo_pool, redo_work, redo_cls;    // the exact pass
   bool greedy2 = false;
-  uint32_t greedy_gate = 3u | 32u << 8;   // heavy iteration every 4th, or as soon as half the wavefront waits for one (measured: r02_gprof)
+  uint32_t greedy_gate = 1u | 32u << 8;   // heavy iteration every 2nd, or as soon as half the wavefront waits for one (measured: r02_gprof; round 3,
+                                           // with the span rule and the probes thinning the fast iterations: every 2nd beats every 4th, profiles/r03_l14)
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
   bool exact_pass = true;          // KAIJU_GPU_EXACT_PASS=0 switches the exact pass off (its reads stay flagged)
   bool count_ops = false;          // kaiju_gpu_set_count_ops: the main pass runs the counting instantiation of its lane

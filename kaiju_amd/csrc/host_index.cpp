@@ -346,7 +346,7 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
   {
     // the host builds at most 5 letters; the device grows the table further (capi.hip)
     uint32_t k = 5;
-    if (const char *e = getenv("KAIJU_GPU_KMER")) { k = (uint32_t)atoi(e); if (k > 5) k = 5; }
+    if (const char *e = getenv("KAIJU_GPU_KMER")) { k = (uint32_t)atoi(e); if (k > 6) k = 6; }   // (6: tests/tools, 0.9 GB of host memory)
     build_kmer_table(k);
   }
   pc.mark("k-mer table (host part)");

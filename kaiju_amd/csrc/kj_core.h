@@ -107,6 +107,45 @@ constexpr int kTextTrigLen = 9;              // ... and the match at least this 
                                              // (190 M to 4 G rows) and four of five such matches end right there - the ones that
                                              // have grown two letters past that point go on for twenty more on average
 
+// ---- the span rule ---------------------------------------------------------------------------------------------------------
+// maxMatches / greedyExact search every end position j of a fragment anew (bwt.c:265, :356).  Let an earlier search of the
+// fragment, from end position j' > j, have ended at i' (w[i'..j'] occurs, w[i'-1..j'] does not) and let the k-mer
+// w[j-k+1..j] of the search at hand lie inside that match (j-k+1 >= i') with ONE row in the index.  That row is the k-mer's
+// copy inside the (then also unique) occurrence of w[i'..j'], so the UpdateSI chain of this search walks that occurrence: it
+// succeeds down to i' and fails at i'-1, where the text holds a letter that is not w[i'-1].  The search ends at i' - known
+// without a step - and is never recorded: greedyExact wants l >= L with L >= j'-i'+1 > j-i'+1 (bwt.c:364-371), maxMatches
+// wants i < cur->qi with cur->qi <= i' once the search from j' was recorded, and l >= L otherwise failed there already
+// (bwt.c:274-276).  The lanes keep i' in `i` (set to the fragment's length when a fragment starts) and go straight to the
+// end-of-match bookkeeping, which evaluates those very conditions.  Benchmark reads, Greedy: UpdateSI steps per read
+// 119 -> see DESIGN.md 3.4.
+#ifdef KJ_NO_SPAN_RULE
+constexpr bool kSpanRule = false;
+#else
+constexpr bool kSpanRule = true;
+#endif
+constexpr bool kSpanRuleStep = kSpanRule;          // Greedy: also for intervals that shrink to one row behind the k-mer lookup
+// ---- probes (MEM lane, narrow) ---------------------------------------------------------------------------------------------
+// greedyExact records a match only if it is at least L long (L = min_fragment_length, then the longest so far, bwt.c:364).
+// A match of L letters that ends at j' in [j-L+k, j] contains the k-mer that ends at e = j-L+k (letters j-L+1 .. e): if that
+// k-mer is not in the index - or is one row inside the last match (the span rule above: every search that reaches it ends
+// where that match ended) - none of the L-k+1 end positions e..j can be recorded, and the searches from them have no other
+// effect (`if (i<=1) break`, bwt.c:376, only ends a loop that ends anyway: an unrecorded match is shorter than L <= j+1).
+// One lookup passes them all; a k-mer that is there sends the lane to the usual search from j.
+#ifdef KJ_NO_PROBE
+constexpr bool kMemProbe = false;
+#else
+constexpr bool kMemProbe = true;
+#endif
+// Greedy lane (narrow): maxMatches records a match only if it starts in front of the last recorded one (i < cur->qi,
+// bwt.c:276).  Once a match [q, J] is recorded, a recordable match that ends at j' >= q+k-2 contains the letters q-1 .. q+k-2:
+// ONE lookup of that k-mer right behind the recording; absent (it holds the letter the match failed on) = the end positions
+// q+k-2 .. J-1 are passed at once (they cannot break the loop either: their matches start at q > 1 or behind it).
+#ifdef KJ_NO_PROBE
+constexpr bool kGreedyProbe = false;
+#else
+constexpr bool kGreedyProbe = true;
+#endif
+
 // ---- k-mer lines ----------------------------------------------------------------------------------------------------------
 // bytes 0..119: twenty entries {lo: 32 bit, len16: 16 bit} for a = 1..20; bytes 120..123: bit b-1 set = the word b.M has a
 // non-empty interval.  len16: 0 = empty; 1..kKLineMaxLen = the interval's length; kKLineSingle | c = ONE row whose BWT
@@ -2055,6 +2094,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // ----------------------------------------------------------------------------
 enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT,
                      K_SAPOS, K_TEXT,     // text verification (narrow): suffix-array entry of the row, then the text in front of it
+                     K_PROBE,             // narrow: a k-mer lookup that decides L-k+1 end positions at once (kMemProbe)
                      K_BK = 16 };         // K_BK + b: bookkeeping block b of MemBk is due (no memory access)
 enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
 
@@ -2174,13 +2214,14 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     KJ_HISTO(5, kind);
     if (kind == K_STEP) KJ_HISTO(4, (uint32_t)(j - i + 1));   // match length before this step
     const bool is_step = kind == K_STEP, is_lf = kind == K_LF1 || kind == K_LF2;
+    const bool is_kmer = kind == K_KMER || (!WIDE && kind == K_PROBE);
     const P posA = is_step ? lo : is_lf ? k : 0;
     const P posB = is_step ? hi : posA;
     if constexpr (COUNT) {
       // one rank block line per LF step (K_LF1 and K_LF2 read the same block), one or two per UpdateSI
       oc[kOpcLaneIters] += (kind != K_EXIT) ? 1u : 0u;
       if (kj_lane() == 0) oc[kOpcIters]++;
-      if (kind == K_KMER) oc[kOpcKmer]++;
+      if (is_kmer) oc[kOpcKmer]++;
       else if (kind == K_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
       else if (kind == K_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
       else if (kind == K_SA || kind == K_SAPOS) oc[kOpcSa]++;                 // (a suffix-array line either way)
@@ -2190,7 +2231,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       else if (kind == K_FILL) { oc[kOpcFill]++; if (fill_newfrag && f < nf) oc[kOpcFrag]++; }
     }
     const uint32_t cc = (is_step || kind == K_LF2) ? c : 1u;
-    const bool kline_step = !WIDE && kind == K_KMER;
+    const bool kline_step = !WIDE && is_kmer;
     u128 a01, a23, b01, b23;
     uint64_t a4, b4;
     uint32_t ca, cb;
@@ -2219,7 +2260,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       mbb = ix.mb_base[(size_t)((uint64_t)posB >> ix.mb_shift) * 20 + (cc - 1)];
     }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == K_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
+    if (is_kmer) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
     else if (kind == K_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (!WIDE && kind == K_SAPOS) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_full + lo);
     else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
@@ -2244,6 +2285,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 
     // ---- (2) compute ----
     int bk = BK_NONE;
+    bool noprobe = false;                                 // the search from j comes next whatever its k-mers say (a probe found its k-mer)
     if (is_step || kind == K_LF2) {
       KJ_PM(PM_STEP);
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
@@ -2271,7 +2313,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         k = ra; fresh = false;
         bk = BK_LOC_ROW;                                   // re-enters at the checkpoint test
       }
-    } else if (kind == K_KMER) {
+    } else if (is_kmer) {
       KJ_PM(PM_KMER);
       // InitialSI + (kk-1) UpdateSI in one lookup
       uint32_t hint = 32u;                                 // narrow: the BWT letter of a one-row interval (32 = unknown)
@@ -2289,7 +2331,17 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         // without a lookup (what the lookup would have led to: an empty interval, a "match" of one letter)
         skipj = j >= (int)kk && in_win(j - (int)kk) && ((cb >> ((uint32_t)lw.w[j - (int)kk - lw.q] - 1u)) & 1u) == 0u;
       }
-      if (escape) {
+      if (!WIDE && kind == K_PROBE) {
+        // the k-mer that ends at e = j - (L - kk) (kMemProbe)
+        const int e = j - (int)(L - kk);
+        if (!escape && (lo >= hi || (kSpanRule && hi - lo == 1 && e - (int)kk + 1 >= i))) {
+          // ... and the one that ends at e - 1, absent, passes end position e - 1 too
+          const bool prev_absent = e >= (int)kk && in_win(e - (int)kk) && ((cb >> ((uint32_t)lw.w[e - (int)kk - lw.q] - 1u)) & 1u) == 0u;
+          j = e - 1 - (prev_absent ? 1 : 0);
+        } else noprobe = true;
+        skipj = false;
+        bk = BK_START_J;
+      } else if (escape) {
         // an interval longer than the line's 16 bits can say: this search starts with InitialSI (bwt.c:146-152)
         c = lw.w[j - lw.q];
         lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];
@@ -2297,6 +2349,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (in_win(i - 1)) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
         else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
       } else if (lo >= hi) { i = j; bk = BK_END_MATCH; }   // match shorter than kk: never recorded, i > 1
+      else if (kSpanRule && hi - lo == 1 && j - (int)kk + 1 >= i) bk = BK_END_MATCH;   // inside the last match (see kSpanRule): i stays
       else {
         i = j - (int)kk + 1;
         KJ_HIST_SINGLE(hi - lo == 1, (int)kk);
@@ -2441,17 +2494,20 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (bk == BK_NEXT_FRAG) {}
         else if (j < (int)L - 1) bk = BK_NEXT_FRAG;
         else if (kk && j >= (int)kk - 1) {
-          if (in_win(j) && in_win(j - (int)kk + 1)) {
+          // narrow: the lookup is a probe (kMemProbe) unless one has just sent the lane here; e = the end position of its k-mer
+          const bool probe = !WIDE && kMemProbe && !noprobe && L > kk && L <= (uint32_t)kWin;
+          const int e = probe ? j - (int)(L - kk) : j;
+          if (in_win(j) && in_win(e - (int)kk + 1)) {
             // (a rolling update of the index from end position j+1 was tried: it costs a register too many here)
             if constexpr (WIDE) {
               kidx = 0;
               for (uint32_t q = 0; q < kk; q++) kidx = kmer_index(kidx, lw.w[j - (int)q - lw.q]);
             } else {
               kidx = 0;
-              for (uint32_t q = 1; q < kk; q++) kidx = kline_code(kidx, lw.w[j - (int)q - lw.q]);
-              kidx = kline_ref(kidx, lw.w[j - lw.q]);
+              for (uint32_t q = 1; q < kk; q++) kidx = kline_code(kidx, lw.w[e - (int)q - lw.q]);
+              kidx = kline_ref(kidx, lw.w[e - lw.q]);
             }
-            kind = K_KMER; bk = BK_NONE;
+            kind = probe ? K_PROBE : K_KMER; bk = BK_NONE;
           } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
         } else if (in_win(j)) {
           c = lw.w[j - lw.q];
@@ -2472,6 +2528,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           skipj = false;
           fsoff = pepoff + dnext.start; flen = (int)dnext.len;
           j = flen - 1;
+          i = flen;                                        // (span rule: no earlier search in this fragment)
           fill_top = j; fill_newfrag = true; fill_step = false;
           kind = K_FILL; bk = BK_NONE;
         }
@@ -3152,7 +3209,7 @@ struct GreedyScratch2 {
   uint32_t *sub;               // LDS, kGSubStride words: the substitutions of the variant at hand + slow-part state
 };
 
-enum GKind : int { G_STEP, G_KMER, G_LF1, G_LF2, G_SA,                                     // fast
+enum GKind : int { G_STEP, G_KMER, G_PROBE, G_LF1, G_LF2, G_SA,                            // fast (G_PROBE: a k-mer lookup, kGreedyProbe)
                    G_VMULTI, G_META, G_FRAG, G_FILL, G_POPITEM, G_MLOAD, G_WAIT, G_IDLE,   // heavy iterations only
                    G_EXIT };
 enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_LOC_ROW,                            // fast
@@ -3573,6 +3630,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               }
               flen = (int)t_len; nm = 0; kroll = false; skipj = false;
               j = flen - 1; tail = 0;                       // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
+              i = flen;                                     // (span rule: no earlier search in this fragment)
               fill_top = j; fill_ret = FR_START_J; fill_pref = true; kind = G_FILL; bk = GB_NONE;
             }
           }
@@ -3668,13 +3726,14 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
 #endif
     KJ_HISTO(6, kind);
     const bool is_step = kind == G_STEP, is_vm = kind == G_VMULTI, is_lf = kind == G_LF1 || kind == G_LF2;
+    const bool is_kmer = kind == G_KMER || (!WIDE && kind == G_PROBE);
     const P vlo = m_lo, vhi = m_lo + m_len;
     const P posA = is_step ? lo : is_vm ? vlo : is_lf ? k : 0;
     const P posB = is_step ? hi : is_vm ? vhi : posA;
     if constexpr (COUNT) {
       oc[kOpcLaneIters] += (kind != G_EXIT && kind != G_WAIT) ? 1u : 0u;
       if (kj_lane() == 0) oc[kOpcIters]++;
-      if (kind == G_KMER) oc[kOpcKmer]++;
+      if (is_kmer) oc[kOpcKmer]++;
       else if (kind == G_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
       else if (kind == G_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
       else if (kind == G_SA) oc[kOpcSa]++;
@@ -3697,7 +3756,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     const u128 b23 = *reinterpret_cast<const u128 *>(&pb->plane[2]);
     const uint64_t b4 = pb->plane[4];
     // (narrow G_KMER: the second block is not needed - this load fetches the presence bits of the k-mer line instead)
-    const bool kline_step = !WIDE && kind == G_KMER;
+    const bool kline_step = !WIDE && is_kmer;
     const uint32_t *cbp = &pb->cnt[cc - 1];
     if (kline_step) cbp = reinterpret_cast<const uint32_t *>(ix.kline + (size_t)(kidx >> 6) * kKLineBytes + kKLinePresent);
     const uint32_t cb = *cbp;
@@ -3707,7 +3766,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       mbb = ix.mb_base[(size_t)((uint64_t)posB >> ix.mb_shift) * 20 + (cc - 1)];
     }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
-    if (kind == G_KMER) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
+    if (is_kmer) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
     else if (kind == G_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == G_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == G_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
@@ -3751,6 +3810,11 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         else {
           lo = ra; hi = rb; i--; acc += diag(c);
           if (i == 0) bk = GB_END_MATCH;
+          else if (kSpanRuleStep && t_nmm == 0 && nm != 0 && hi - lo == 1 && i >= last_qi) {
+            // the span rule for an interval that shrinks to one row behind the k-mer lookup: the recorded match that reaches
+            // furthest (last_qi, from a larger end position) contains it, the search ends where that one ended or, unrecorded, beyond
+            i = last_qi; bk = GB_END_MATCH;
+          }
           else if (in_win(i - 1)) c = win[i - 1 - wq];
           else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
         }
@@ -3758,12 +3822,13 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         k = ra; fresh = false;                             // second half of an LF step
         bk = GB_LOC_ROW;
       }
-    } else if (kind == G_KMER) {
+    } else if (is_kmer) {
       KJ_P(PS_KMER);
       if constexpr (WIDE) {
         // the k-mer table of 16-byte entries {lo, len}
         lo = (P)gv.x; hi = (P)(gv.x + gv.y);
         if (lo >= hi) { i = j; bk = GB_END_MATCH; }        // seed shorter than kk: never recorded, i > 1
+        else if (kSpanRule && gv.y == 1ull && j - (int)kk + 1 >= i) bk = GB_END_MATCH;   // inside the last match (kSpanRule): i stays
         else {
           i = j - (int)kk + 1;
           if (i == 0) bk = GB_END_MATCH;
@@ -3780,6 +3845,13 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       // the k-mer that ends at j - 1 = w[j-kk] in front of the line's word: absent -> that end position is passed without a
       // lookup (GB_START_J)
       skipj = j >= (int)kk && in_win(j - (int)kk) && ((cb >> ((uint32_t)win[j - (int)kk - wq] - 1u)) & 1u) == 0u;
+      if (kind == G_PROBE) {
+        // the k-mer q-1 .. q+kk-2 behind the recording of [q, J] (kGreedyProbe): absent = on to end position q+kk-3; acc holds the
+        // diagonal sum of the letters passed
+        if (l16 == 0u) { tail += acc; j = (int)last_qi + (int)kk - 3; }
+        skipj = false; kroll = false;
+        bk = GB_START_J;
+      } else
       if (l16 == kKLineEscape) {
         // an interval longer than the line's 16 bits can say: this search starts with InitialSI (bwt.c:146-152)
         c = cj;
@@ -3789,6 +3861,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; }
         else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
       } else if (lo >= hi) { i = j; bk = GB_END_MATCH; }   // seed shorter than kk: never recorded, i > 1
+      else if (kSpanRule && hi - lo == 1 && j - (int)kk + 1 >= i) bk = GB_END_MATCH;   // inside the last match (kSpanRule): i stays
       else {
         i = j - (int)kk + 1;
         if (i == 0) bk = GB_END_MATCH;
@@ -3977,6 +4050,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           if (t_nmm == 0) {
             // a SEG piece: maxMatches like an original
             tail = 0;
+            i = flen;
             fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL;
           } else {
             // maxMatches_withStart, bwt.c:298-336
@@ -4030,12 +4104,15 @@ if constexpr (COUNT) oc[kOpcTerm]++;
     // ---- (3) fast bookkeeping; everything else waits for the next heavy iteration ----
     if (heavy) { KJ_TICK(st_slow) } else { KJ_TICK(st_fast) }
     KJ_P(PS_TAIL);
+    bool probe_now = false;
     while (bk != GB_NONE) {
       if (bk == GB_END_MATCH) {
         KJ_P(PS_END_MATCH);
         const int l = j - i + 1;
         if (t_nmm == 0) {
+          bool recorded = false;
           if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {        // bwt.c:276-278
+            recorded = true;
             if (nm < (uint32_t)kGMaxMAll && (!WIDE || (uint64_t)(hi - lo) <= 0xffffffffull)) {
               m_lo = lo; m_len = (uint32_t)(hi - lo); m_qi = (uint32_t)i; m_ql = (uint32_t)l; m_dsum = acc; m_psum = t_tot - tail;
               if constexpr (WIDE) {
@@ -4054,7 +4131,11 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             last_qi = i;
           }
           if (i <= 1) bk = GB_AFTER_SEARCH;                                 // bwt.c:292
-          else { tail += diag(cj); j--; bk = GB_START_J; }
+          else {
+            tail += diag(cj); j--; bk = GB_START_J;
+            // kGreedyProbe: the k-mer i-1 .. i+kk-2 is looked up before the search from j (GB_START_J builds the lookup)
+            probe_now = !WIDE && kGreedyProbe && recorded && kk && l > (int)kk && in_win(i - 1) && in_win(i + (int)kk - 2);
+          }
         } else {
           // :443-449: after the last allowed mismatch the match must reach min_fragment_length
           const int Lreq = (t_nmm == p.mismatches) ? (int)p.m : (int)t_matchlen;
@@ -4068,6 +4149,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
       }
       if (bk == GB_START_J) {
         KJ_P(PS_START_J);
+        if (probe_now) skipj = false;                      // (the probe's answer may move j: what the last line said about j is dropped)
         if (skipj && j >= (int)p.seed_length - 1 && in_win(j) && in_win(j - (int)kk + 1)) {
           // the k-mer that ends here is not in the index (the line of end position j + 1 said so): as for an empty entry - i = j,
           // nothing recorded (GB_END_MATCH: l = 1 < seed_length), `if (i <= 1) break` (bwt.c:292), on to j - 1 in the same pass;
@@ -4084,7 +4166,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         }
         if (bk != GB_START_J) {}
         else if (j < (int)p.seed_length - 1) { skipj = false; bk = GB_AFTER_SEARCH; }
-        else if (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1))) {
+        else if (!probe_now && (!in_win(j) || (kk && j >= (int)kk - 1 && !in_win(j - (int)kk + 1)))) {
           fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL; bk = GB_NONE;     // (skipj, if set, waits)
         } else if (WIDE && kk && j >= (int)kk - 1) {
           // wide: index of the word w[j-kk+1 .. j] in the k-mer table (w[j] = most significant digit), rolled from that of j + 1
@@ -4104,23 +4186,34 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           kind = G_KMER; bk = GB_NONE;
         } else if (kk && j >= (int)kk - 1) {
           uint32_t kcode;
-          if (kroll) {
+          const int ej = probe_now ? i + (int)kk - 2 : j;   // end position of the k-mer looked up
+          if (kroll && !probe_now) {
             // from end position j + 1 (letter cj, line kidx >> 6 = w[j-kk+2 .. j]) to j: w[j] leaves the line's word at its
             // most significant digit, w[j-kk+1] enters at the least significant one
             const uint32_t cn = win[j - (int)kk + 1 - wq], c1 = win[j - wq];
             kcode = ((kidx >> 6) - (c1 - 1u) * kpow) * 20u + (cn - 1u);
             kacc = kacc - diag(cj) + diag(cn);
           } else {
-            kcode = 0; kacc = diag(win[j - wq]);
+            kcode = 0; kacc = diag(win[ej - wq]);
             for (uint32_t q = 1; q < kk; q++) {
-              const uint32_t cq = win[j - (int)q - wq];
+              const uint32_t cq = win[ej - (int)q - wq];
               kcode = kline_code(kcode, cq);
               kacc += diag(cq);
             }
           }
+          if (probe_now) {
+            // what the end positions ej .. j add to `tail` if they are passed = the recorded match's diagonal sum (acc) less its
+            // last letter (cj) and its first kk-2 (the k-mer's less its two outer letters); acc is free until the next search
+            const uint32_t ce = win[ej - wq];
+            acc = acc - diag(cj) - (kacc - diag(ce) - diag(win[i - 1 - wq]));
+            kroll = false;
+            kidx = kline_ref(kcode, ce);
+            kind = G_PROBE; bk = GB_NONE;
+          } else {
           cj = win[j - wq]; acc = kacc; kroll = true;
           kidx = kline_ref(kcode, cj);
           kind = G_KMER; bk = GB_NONE;
+          }
         } else {
           c = cj = win[j - wq]; kroll = false;
           lo = (P)ix.C[c]; hi = (P)ix.C[c + 1];                              // InitialSI, bwt.c:146-152

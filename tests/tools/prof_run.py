@@ -22,6 +22,13 @@ for _ in range(reps):
     print(f"{mode} seg={seg} n={len(reads)}: translate {st.ms_translate:.2f} seg {st.ms_seg:.2f} [{st.n_seg_fragments}] "
           f"search {st.ms_search:.2f} retry {st.ms_retry:.2f} [{st.n_overflow_retries}] total {st.ms_total:.2f} ms "
           f"-> {len(reads)/st.ms_total*1e3:,.0f} reads/s", flush=True)
+if os.environ.get("PROF_RUN_COUNTS"):
+    # one more pass with the counting instantiation of the search kernel: memory steps per read
+    clf.count_ops(True)
+    clf.classify(seqs, off)
+    oc = clf.op_counts()
+    clf.count_ops(False)
+    print("ops per read", {k: round(v / len(reads), 2) for k, v in oc.items() if v})
 print("hit fraction", float((hits['n_ids'] > 0).mean()))
 # (for A/B runs of kernel variants: the same reads must give the same records)
 print("checksum", int(hits['n_ids'].astype(np.int64).sum()), int(hits['best'].astype(np.int64).sum()),

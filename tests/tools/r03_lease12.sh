@@ -1,11 +1,18 @@
 #!/bin/bash
+# lease 12: the span rule (kj_core.h kSpanRule) - norule / cur (k-mer lookups) / step (+ intervals that shrink to one row later)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_l12; mkdir -p $O
 export TMPDIR=/tmp
-python tests/tools/prof_prepare.py /tmp/kjw 680001 4000000 > $O/prepare.log 2>&1
-run() { name=$1; lib=$2; mode=$3; shift 3
-  env "$@" KAIJU_GPU_LIB=$PWD/$lib python tests/tools/prof_run.py /tmp/kjw $mode 1 3 4000000 > $O/$name.txt 2>&1
-  echo "== $name"; grep -E "search|checksum" $O/$name.txt | tail -2; }
-run greedy_pass4 kaiju_amd/libkaiju_gpu.so greedy X=1
-run greedy_pass8 kaiju_amd/variants/libkaiju_gpu_ext8.so greedy X=1
-( timeout 900 python -m pytest tests/test_gpu_cli.py -m gpu -x -q ) > $O/gpu_cli_tests.log 2>&1; echo "cli tests rc=$?"; tail -2 $O/gpu_cli_tests.log
+[ -f /tmp/kjw/reads.npy ] || python tests/tools/prof_prepare.py /tmp/kjw 680001 4000000 > $O/prepare.log 2>&1
+for mode in mem greedy; do
+  for v in norule cur step; do
+    [ $mode = mem ] && [ $v = step ] && continue
+    PROF_RUN_COUNTS=1 KAIJU_GPU_LIB=$PWD/kaiju_amd/variants/libkaiju_gpu_$v.so timeout 600 python tests/tools/prof_run.py /tmp/kjw $mode 1 3 4000000 > $O/${mode}_$v.txt 2>&1
+    echo "== $mode $v"; grep -E "search|checksum|ops per" $O/${mode}_$v.txt | tail -3
+  done
+done
+for gw in "1 32" "3 16" "3 48"; do
+  set -- $gw
+  KAIJU_GPU_GREEDY_GATE=$1 KAIJU_GPU_GREEDY_WAITERS=$2 KAIJU_GPU_LIB=$PWD/kaiju_amd/variants/libkaiju_gpu_step.so timeout 600 python tests/tools/prof_run.py /tmp/kjw greedy 1 2 4000000 > $O/sweep_step_$1_$2.txt 2>&1
+  echo "== sweep step gate $1 waiters $2: $(grep search $O/sweep_step_$1_$2.txt | tail -1)"
+done
