@@ -2160,6 +2160,20 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   uint32_t wnext = 0, wend = 0;                 // the wave's chunk of work items (wave-uniform)
   const RankBlock64 *const blk0 = ix.blocks64;
   bool skipj = false;                           // narrow: the k-mer that ends at the NEXT end position (j - 1) is not in the index
+  // wide: a probe is a whole search from e = j - (L - pw) (k-mer lookup, then steps): if it dies with fewer than pw letters the
+  // word j-L+1 .. e is not in the index and the end positions e .. j are passed (kMemProbe).  pw = the shortest word that a
+  // fifth of the index's rows could hold at most (rows / 20^pw <= 0.2: eight letters at 4.3 G rows, nine at 66 G); pj = the end
+  // position the probe stands in for (-1: the search at hand is no probe; -2: nor may the next one be)
+  int pj = -1;
+  uint32_t pw = kk;
+  if constexpr (WIDE) {
+    uint64_t words = 1;
+    for (uint32_t q = 0; q < kk; q++) words *= 20u;
+    while (pw < 14u && ix.bwtlen > words / 5u) { words *= 20u; pw++; }
+#ifdef KJ_PROBE_W_ADD
+    pw += KJ_PROBE_W_ADD;                       // (tests on small indexes: probes of several steps)
+#endif
+  }
 
   auto si_lo = [&](uint32_t e) -> P { return e == 0 ? s0lo : e == 1 ? s1lo : (P)ls.si[e].lo; };
   auto si_len = [&](uint32_t e) -> uint32_t { return e == 0 ? s0len : e == 1 ? s1len : ls.si[e].len; };
@@ -2301,6 +2315,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           lo = ra; hi = rb; i--;
           KJ_HIST_SINGLE(hi - lo == 1, j - i + 1);
           if (i == 0) bk = BK_END_MATCH;
+          else if (WIDE && pj >= 0 && j - i + 1 >= (int)pw) bk = BK_END_MATCH;   // a probe whose word is in the index: no need to go on
           else if (!WIDE && ix.text && hi - lo == 1 && j - i + 1 >= kTextTrigLen && i >= kTextMinLeft && lw.q == 0 && i <= kWin) {
             // one row left and letters to go: the rest of this match is read off the database text (K_SAPOS, K_TEXT)
             kind = K_SAPOS;
@@ -2353,7 +2368,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       else {
         i = j - (int)kk + 1;
         KJ_HIST_SINGLE(hi - lo == 1, (int)kk);
-        if (i == 0) bk = BK_END_MATCH;
+        if (i == 0 || (WIDE && pj >= 0 && kk >= pw)) bk = BK_END_MATCH;   // (a probe of kk letters ends with the lookup)
         else if (in_win(i - 1)) {
           c = lw.w[i - 1 - lw.q];
           // one row whose BWT letter is not c: UpdateSI(c) finds nothing (bwt.c:160-173) - the match ends here
@@ -2468,6 +2483,20 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         KJ_PM(PM_END_MATCH);
         const uint32_t l = (uint32_t)(j - i + 1);
         KJ_HIST_SINGLE_END(l);
+        bool probed = false;
+        if constexpr (WIDE) {
+          if (pj >= 0) {
+            // the search from e was a probe: fewer than pw letters = no match of L letters ends at e .. pj (each would contain the
+            // word j-L+1 .. e); otherwise the search from pj comes next, unprobed (and `i`, the end of a search from a SMALLER end
+            // position, is no bound for the span rule there)
+            probed = true;
+            if (l < pw) { j--; pj = -1; }
+            else { j = pj; pj = -2; i = flen; }             // (-2: until the lookup of that search is on its way - a window refill may come first)
+            bk = BK_START_J;
+          }
+        }
+        if (probed) {}
+        else
         if (l >= L) {
           if (l > L) { nsi = 0; ovf = false; L = l; multi = false; }   // shorter matches are dropped (bwt.c:366-370, :577-582)
           const uint32_t ilen = (uint32_t)(int32_t)(hi - lo);
@@ -2479,7 +2508,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           nsi++;
           found = true;
         }
-        if (i <= 1) bk = BK_NEXT_FRAG;                     // bwt.c:376
+        if (probed) {}
+        else if (i <= 1) bk = BK_NEXT_FRAG;                // bwt.c:376
         else { j--; bk = BK_START_J; }
       }
       if (bk == BK_START_J) {
@@ -2492,8 +2522,12 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         }
         skipj = false;
         if (bk == BK_NEXT_FRAG) {}
-        else if (j < (int)L - 1) bk = BK_NEXT_FRAG;
+        else if (j < (int)L - 1 && !(WIDE && pj >= 0)) bk = BK_NEXT_FRAG;   // (a probe's end position lies below L - 1)
         else if (kk && j >= (int)kk - 1) {
+          if constexpr (WIDE) {
+            // wide: the search from e = j - (L - pw) stands in for the end positions e .. j (see pj above)
+            if (kMemProbe && pj == -1 && L > pw) { pj = j; j -= (int)(L - pw); }
+          }
           // narrow: the lookup is a probe (kMemProbe) unless one has just sent the lane here; e = the end position of its k-mer
           const bool probe = !WIDE && kMemProbe && !noprobe && L > kk && L <= (uint32_t)kWin;
           const int e = probe ? j - (int)(L - kk) : j;
@@ -2508,6 +2542,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
               kidx = kline_ref(kidx, lw.w[e - lw.q]);
             }
             kind = probe ? K_PROBE : K_KMER; bk = BK_NONE;
+            if (WIDE && pj == -2) pj = -1;
           } else { fill_top = j; fill_newfrag = false; fill_step = false; kind = K_FILL; bk = BK_NONE; }
         } else if (in_win(j)) {
           c = lw.w[j - lw.q];
@@ -2529,6 +2564,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           fsoff = pepoff + dnext.start; flen = (int)dnext.len;
           j = flen - 1;
           i = flen;                                        // (span rule: no earlier search in this fragment)
+          pj = -1;
           fill_top = j; fill_newfrag = true; fill_step = false;
           kind = K_FILL; bk = BK_NONE;
         }

@@ -1,6 +1,7 @@
 """Randomised parity hunt on the CPU: random small databases (with repeats and low-complexity stretches), reads with
 Ns / lower case / odd lengths / pairs, random parameters; host emulation of the kernel logic vs the oracle.
    fuzz_emu.py [rounds] [seed] [first round]
+FUZZ_DEFINES="KJ_PROBE_W_ADD=2" KAIJU_GPU_FORCE_WIDE=16: the wide lanes with probes of several steps
 FUZZ_VARIANT=kaiju (default) | kaijux (ids = database sequences, MEM lists matches as maxMatches(.., 1) does) |
              protein (kaiju -p: protein reads) | kaijup (both)"""
 import os
@@ -110,8 +111,14 @@ def main(rounds=None, seed=None, first=None, variant=None):
     rounds = rounds if rounds is not None else (int(sys.argv[1]) if len(sys.argv) > 1 else 20)
     seed = seed if seed is not None else (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     # FUZZ_SMALL=1: the emulation built with tiny bounds of the second-generation Greedy lane (spill / retry paths)
-    emu = (util.Emu(so=os.path.join(util.EMU_DIR, "libkaiju_kernel_emu_small.so"), defines=("KJ_G_SMALL",))
-           if os.environ.get("FUZZ_SMALL") else util.Emu())
+    # FUZZ_DEFINES="A B=2": extra -D flags (own library); with KAIJU_GPU_FORCE_WIDE=16 in the environment the wide lanes run
+    extra = tuple(os.environ.get("FUZZ_DEFINES", "").split())
+    if os.environ.get("FUZZ_SMALL"):
+        emu = util.Emu(so=os.path.join(util.EMU_DIR, "libkaiju_kernel_emu_small.so"), defines=("KJ_G_SMALL",) + extra)
+    elif extra:
+        emu = util.Emu(so=os.path.join(util.EMU_DIR, "libkaiju_kernel_emu_" + "_".join(d.replace("=", "") for d in extra) + ".so"), defines=extra)
+    else:
+        emu = util.Emu()
     orc = po.Oracle()
     total = 0
     first = first if first is not None else (int(sys.argv[3]) if len(sys.argv) > 3 else 0)
