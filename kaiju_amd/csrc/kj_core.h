@@ -2183,7 +2183,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   // the fragment switches (K_META / K_FRAG / K_FILL: a fifth of the kernel's cycles with two lanes of 64 active when they run
   // in every iteration, profiles/r02_gprof) only run in every second iteration; a lane that needs one waits for it (K_WAIT).
   // Measured (profiles/r03_variants): every 2nd -4.2 %, every 4th -4.0 % of the kernel
+#ifdef KJ_MEM_GATE
+  constexpr uint32_t kMemRareGate = KJ_MEM_GATE;         // (tests/tools/mem_variants.sh)
+#else
   constexpr uint32_t kMemRareGate = 1u;
+#endif
   uint32_t gate_it = 0;
   for (;;) {
     KJ_PM(PM_HEAD);
@@ -2351,7 +2355,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         const int e = j - (int)(L - kk);
         if (!escape && (lo >= hi || (kSpanRule && hi - lo == 1 && e - (int)kk + 1 >= i))) {
           // ... and the one that ends at e - 1, absent, passes end position e - 1 too
+#ifdef KJ_NO_PREV_ABSENT
+          const bool prev_absent = false;
+#else
           const bool prev_absent = e >= (int)kk && in_win(e - (int)kk) && ((cb >> ((uint32_t)lw.w[e - (int)kk - lw.q] - 1u)) & 1u) == 0u;
+#endif
           j = e - 1 - (prev_absent ? 1 : 0);
         } else noprobe = true;
         skipj = false;

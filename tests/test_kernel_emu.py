@@ -667,3 +667,29 @@ def test_protein_evalue_gate_and_lca(emu, golden, handles, seg):
         got = ("C", int(r["taxon"]), int(r["best"]), tuple(sorted(int(x) for x in g["taxid"][:g["n_ids"]]))) if r["classified"] \
             else ("U", 0, None, ())
         assert got == ref[nm], (nm, got, ref[nm])
+
+
+def test_skip_rules_and_probes(oracle, golden, handles, monkeypatch):
+    """kj_core.h kSpanRule / kMemProbe / kGreedyProbe pass end positions whose searches cannot be recorded.  Three builds of the
+    lanes - as shipped, with the rules compiled out, and with the wide lane's probes two letters longer than the index size
+    asks for (probes of several UpdateSI steps on a small index) - give the oracle's records, narrow and forced wide."""
+    _, ix, tax = handles
+    reads = util.long_reads(n=30)
+    lseqs, loff = util.pack(reads)
+    builds = [("plain", ()), ("norules", ("KJ_NO_SPAN_RULE", "KJ_NO_PROBE")), ("longprobe", ("KJ_PROBE_W_ADD=2",))]
+    for tag, defs in builds:
+        e = util.Emu(so=os.path.join(util.EMU_DIR, f"libkaiju_kernel_emu_{tag}.so"), defines=defs) if defs else util.Emu()
+        for wide in (None, "17"):
+            if wide:
+                monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", wide)
+            else:
+                monkeypatch.delenv("KAIJU_GPU_FORCE_WIDE", raising=False)
+            h = e.load(golden.fmi)
+            for mode, kw, okw in (("mem", dict(), dict()), ("mem", dict(m=20), dict(min_fragment_length=20)),
+                                  ("greedy", dict(), dict(use_evalue=0)), ("greedy", dict(seed_length=9), dict(use_evalue=0, seed_length=9))):
+                for seqs, off, pe in ((golden.seqs, golden.off, False), (golden.pseqs, golden.poff, True), (lseqs, loff, False)):
+                    oh = oracle.classify(ix, tax, oracle.params(mode, seg=1, **okw), seqs, off, paired=pe)
+                    gh, _ = e.classify(h, util.gp(mode, seg=1, **({"use_evalue": 0} if mode == "greedy" else {}), **kw), seqs, off, paired=pe)
+                    bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+                    assert not bad, (tag, wide, mode, kw, pe, bad[:5])
+            e.lib.emu_index_free(h)
