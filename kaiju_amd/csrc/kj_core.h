@@ -116,8 +116,7 @@ constexpr int kTextTrigLen = 9;              // ... and the match at least this 
 // without a step - and is never recorded: greedyExact wants l >= L with L >= j'-i'+1 > j-i'+1 (bwt.c:364-371), maxMatches
 // wants i < cur->qi with cur->qi <= i' once the search from j' was recorded, and l >= L otherwise failed there already
 // (bwt.c:274-276).  The lanes keep i' in `i` (set to the fragment's length when a fragment starts) and go straight to the
-// end-of-match bookkeeping, which evaluates those very conditions.  Benchmark reads, Greedy: UpdateSI steps per read
-// 119 -> see DESIGN.md 3.4.
+// end-of-match bookkeeping, which evaluates those very conditions.  Measured: DESIGN.md 3.3 / 3.4.
 #ifdef KJ_NO_SPAN_RULE
 constexpr bool kSpanRule = false;
 #else
@@ -139,7 +138,8 @@ constexpr bool kMemProbe = true;
 // Greedy lane (narrow): maxMatches records a match only if it starts in front of the last recorded one (i < cur->qi,
 // bwt.c:276).  Once a match [q, J] is recorded, a recordable match that ends at j' >= q+k-2 contains the letters q-1 .. q+k-2:
 // ONE lookup of that k-mer right behind the recording; absent (it holds the letter the match failed on) = the end positions
-// q+k-2 .. J-1 are passed at once (they cannot break the loop either: their matches start at q > 1 or behind it).
+// q+k-2 .. J-1 are passed at once (they cannot break the loop either: a search from a smaller end position reaches at least as
+// far as the one from J, so without that k-mer their matches start at q itself, and q > 1 or the loop had ended at J).
 #ifdef KJ_NO_PROBE
 constexpr bool kGreedyProbe = false;
 #else
@@ -2183,11 +2183,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   // the fragment switches (K_META / K_FRAG / K_FILL: a fifth of the kernel's cycles with two lanes of 64 active when they run
   // in every iteration, profiles/r02_gprof) only run in every second iteration; a lane that needs one waits for it (K_WAIT).
   // Measured (profiles/r03_variants): every 2nd -4.2 %, every 4th -4.0 % of the kernel
-#ifdef KJ_MEM_GATE
-  constexpr uint32_t kMemRareGate = KJ_MEM_GATE;         // (tests/tools/mem_variants.sh)
-#else
-  constexpr uint32_t kMemRareGate = 1u;
-#endif
+  constexpr uint32_t kMemRareGate = 1u;                 // (behind the probes: 0 -> +2.5 %, 3 -> +3.5 %, profiles/r03_l17)
   uint32_t gate_it = 0;
   for (;;) {
     KJ_PM(PM_HEAD);
@@ -2355,11 +2351,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         const int e = j - (int)(L - kk);
         if (!escape && (lo >= hi || (kSpanRule && hi - lo == 1 && e - (int)kk + 1 >= i))) {
           // ... and the one that ends at e - 1, absent, passes end position e - 1 too
-#ifdef KJ_NO_PREV_ABSENT
-          const bool prev_absent = false;
-#else
           const bool prev_absent = e >= (int)kk && in_win(e - (int)kk) && ((cb >> ((uint32_t)lw.w[e - (int)kk - lw.q] - 1u)) & 1u) == 0u;
-#endif
           j = e - 1 - (prev_absent ? 1 : 0);
         } else noprobe = true;
         skipj = false;

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03_l17; mkdir -p $O
 export TMPDIR=/tmp
 [ -f /tmp/kjw/reads.npy ] || python tests/tools/prof_prepare.py /tmp/kjw 680001 4000000 > $O/prepare.log 2>&1
-for v in cur nopa gate0 gate3; do
+for v in cur nopa gate0 gate3; do   # (nopa / gate0 / gate3: -DKJ_NO_PREV_ABSENT, -DKJ_MEM_GATE=0|3 - switches that were removed with the result)
   KAIJU_GPU_LIB=$PWD/kaiju_amd/variants/libkaiju_gpu_$v.so timeout 600 python tests/tools/prof_run.py /tmp/kjw mem 1 4 4000000 > $O/mem_$v.txt 2>&1
   echo "== mem $v"; grep -E "search|checksum" $O/mem_$v.txt | tail -3
 done
