@@ -434,11 +434,12 @@ def main():
     ap.add_argument("--reads", type=int, default=int(os.environ.get("KAIJU_BENCH_READS", 10_000_000)),
                     help="reads per GPU per step")
     ap.add_argument("--contexts", type=int, default=1,
-                    help="classification contexts that ping-pong the chunks of a step on their HIP streams (default 1: since "
-                         "stage 1 + SEG are 15 %% of a step a second context is worth +1.6 %%, less than one launch per step)")
+                    help="classification contexts that ping-pong the chunks of a step on their HIP streams (default 1: the persistent "
+                         "search kernels leave no room for the other context's kernels - measured in rounds 2 and 3: +1.6 %% and "
+                         "nothing, less than what a second launch per step costs; DESIGN.md 6b)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 10_000_000)),
                     help="reads (pairs) per launch; default: the whole step in one launch (a persistent kernel ends in a tail "
-                         "in which its lanes run dry: 10 M per launch 189.7, 2 x 5 M 184.1 M reads/s)")
+                         "in which its lanes run dry: round 2 measured 10 M per launch 189.7, 2 x 5 M 184.1 M reads/s)")
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
     ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"],
                     help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")
