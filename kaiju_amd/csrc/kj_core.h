@@ -2108,7 +2108,7 @@ KJ_HD uint32_t kj_fetch_chunk(uint32_t *counter, uint32_t n) { const uint32_t v 
 #endif
 
 #if defined(KJ_HIST) && !defined(__HIP_DEVICE_COMPILE__)
-extern unsigned long long kj_hist[8][64];
+extern unsigned long long kj_hist[16][64];
 #define KJ_HISTO(h, v) kj_hist[h][(v) < 63 ? (v) : 63]++
 #ifndef KJ_HIST_QSHIFT
 #define KJ_HIST_QSHIFT 0
@@ -3834,6 +3834,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     int bk = GB_NONE;
     if (is_step || kind == G_LF2) {
       KJ_P(PS_STEP);
+      if (is_step) KJ_HISTO(12, t_nmm == 0 ? 0 : (uint64_t)(hi - lo) == 1 ? 1 : 2);                              // (UpdateSI steps: originals / variants on one row / on more)
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
@@ -3941,6 +3942,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
       KJ_TICK(st_fast)
       if (is_vm) {
         KJ_P(PS_VM_RANK);
+        KJ_HISTO(8, m_len == 1 ? 0 : m_len <= 4 ? 1 : 2); KJ_HISTO(9, t_nmm);   // (rows of the interval the substitutes are tried on)
         // UpdateSI(trans[substitute]) on the interval of the match for all substitutes (ConsumerThread.cpp:366-392).
         // Only letters that OCCUR in BWT[lo, hi) extend it, and the interval of a match of eleven letters or more is a row
         // or a few: when both ends lie in the same or in neighbouring rank blocks the letters are read off the two lines
@@ -4083,6 +4085,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           const uint32_t wtag = WIDE ? ((uint32_t)(xa3.y >> 32) & 0xffffu) : (uint32_t)(xa3.y >> 32);
           flen = (int)t_len; nm = 0; kroll = false; skipj = false;
           j = flen - 1;
+          if (t_nmm != 0) { KJ_HISTO(10, (uint64_t)(hi - lo) == 1 ? 0 : (uint64_t)(hi - lo) <= 4 ? 1 : 2); KJ_HISTO(11, t_nmm); }   // (popped variants)
           if (t_nmm == 0) {
             // a SEG piece: maxMatches like an original
             tail = 0;

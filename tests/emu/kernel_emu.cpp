@@ -409,6 +409,6 @@ extern "C" uint64_t emu_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n) 
 }
 
 #ifdef KJ_HIST
-namespace kj { unsigned long long kj_hist[8][64]; }
+namespace kj { unsigned long long kj_hist[16][64]; }
 extern "C" const unsigned long long *emu_hist() { return &kj::kj_hist[0][0]; }
 #endif
