@@ -2166,6 +2166,14 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   // position the probe stands in for (-1: the search at hand is no probe; -2: nor may the next one be)
   int pj = -1;
   uint32_t pw = kk;
+  // narrow: a k-mer lookup as a probe pays while fewer than nine k-mers of ten exist (a probe that finds its k-mer costs an
+  // iteration on top of the search it could not spare): rows <= 2 * 20^k, i.e. any narrow index at k = 7 below 2.56 G rows
+  bool nprobe = kMemProbe && !WIDE;
+  if constexpr (!WIDE) {
+    uint64_t words = 2;
+    for (uint32_t q = 0; q < kk; q++) words *= 20u;
+    nprobe = nprobe && ix.bwtlen <= words;
+  }
   if constexpr (WIDE) {
     uint64_t words = 1;
     for (uint32_t q = 0; q < kk; q++) words *= 20u;
@@ -2529,7 +2537,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
             if (kMemProbe && pj == -1 && L > pw) { pj = j; j -= (int)(L - pw); }
           }
           // narrow: the lookup is a probe (kMemProbe) unless one has just sent the lane here; e = the end position of its k-mer
-          const bool probe = !WIDE && kMemProbe && !noprobe && L > kk && L <= (uint32_t)kWin;
+          const bool probe = nprobe && !noprobe && L > kk && L <= (uint32_t)kWin;
           const int e = probe ? j - (int)(L - kk) : j;
           if (in_win(j) && in_win(e - (int)kk + 1)) {
             // (a rolling update of the index from end position j+1 was tried: it costs a register too many here)
