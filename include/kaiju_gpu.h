@@ -164,6 +164,13 @@ int kaiju_gpu_index_write_image(const char *fmi_path, const char *image_path);
    status (not an image of this version: KAIJU_GPU_ERR_FORMAT). */
 int kaiju_gpu_index_image_source_bytes(const char *image_path, uint64_t *fmi_bytes);
 
+/* Host only: header fields of an image and the number of bytes a load streams from it to the device.  A load of an image
+   reads its small arrays (taxon ids, names, count bases) into host memory and moves the arrays that grow with the index - rank
+   blocks, sampled suffix-array entries, terminator rows, the k-mer table - from the file to HBM in page-locked pieces
+   (KAIJU_GPU_STREAM_PIECE_MB, default 256), two in flight: no host copy of the index exists at any time (the reference maps
+   the whole .fmi into every process, readIndexes bwt/bwt.c:78-88).  info->device_bytes = bytes of the packed arrays. */
+int kaiju_gpu_index_image_info(const char *image_path, kaiju_gpu_index_info *info, uint64_t *streamed_bytes);
+
 int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info);
 
 /* What the index occupies in HBM, array by array (bytes).  Per index row: rank blocks 2 B; suffix-array sample at exponent e:

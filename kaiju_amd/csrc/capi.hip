@@ -14,9 +14,13 @@
 // There is no CPU fallback: without a HIP device every entry point that needs one fails with
 // KAIJU_GPU_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <future>
@@ -24,6 +28,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kaiju_gpu.h"
@@ -644,6 +649,7 @@ struct kaiju_gpu_index {
   }
 };
 
+static double LoadClockNow() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
 // KAIJU_GPU_LOAD_TIMES=1: wall time of the phases of an index load / a context creation, on stderr
 struct LoadClock {
   bool on;
@@ -665,6 +671,87 @@ static int upload(kaiju_gpu_index *ix, const std::vector<T, A> &v, const T **dst
   KJ_HIP(hipMalloc(&p, bytes));
   ix->allocs.push_back(p);
   if (!v.empty()) KJ_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = static_cast<const T *>(p);
+  return 0;
+}
+
+// An array that was left in its image file (PackedIndex::lazy): file -> page-locked pieces -> HBM, two pieces in flight (the
+// readers fill one while the other is on its way to the device), never a host copy of the whole array - a refseq-class image
+// is 150 GB and eight ranks of a node load it side by side (the reference maps the whole .fmi into every process:
+// readIndexes bwt/bwt.c:78-88).  KAIJU_GPU_STREAM_PIECE_MB sets the piece size (default 256; tests use 1).
+struct ImageStreamer {
+  int fd = -1;
+  size_t piece = 0;
+  void *buf[2] = {nullptr, nullptr};
+  hipStream_t stream = nullptr;
+  hipEvent_t done[2] = {nullptr, nullptr};
+  uint64_t bytes_streamed = 0;
+  double t_read = 0, t_total = 0;
+  ~ImageStreamer() {
+    if (fd >= 0) close(fd);
+    for (int k = 0; k < 2; k++) { if (buf[k]) (void)hipHostFree(buf[k]); if (done[k]) (void)hipEventDestroy(done[k]); }
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  int open_file(const std::string &path) {
+    if (fd >= 0) return 0;
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return fail(KAIJU_GPU_ERR_IO, "cannot open " + path);
+    size_t mb = 256;
+    if (const char *e = getenv("KAIJU_GPU_STREAM_PIECE_MB")) { const long v = atol(e); if (v >= 1 && v <= 4096) mb = (size_t)v; }
+    piece = mb << 20;
+    for (int k = 0; k < 2; k++) {
+      KJ_HIP(hipHostMalloc(&buf[k], piece, hipHostMallocDefault));
+      KJ_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+    }
+    KJ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    return 0;
+  }
+  // bytes [off, off + n) of the file to device memory at dst
+  int run(uint64_t off, uint64_t n, void *dst) {
+    const double t0 = LoadClockNow();
+    const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    bool used[2] = {false, false};
+    uint64_t at = 0;
+    for (int k = 0; at < n; k ^= 1) {
+      const size_t len = (size_t)std::min<uint64_t>(piece, n - at);
+      if (used[k]) KJ_HIP(hipEventSynchronize(done[k]));               // the copy out of this buffer has finished
+      const double tr = LoadClockNow();
+      std::atomic<bool> ok{true};
+      const size_t sub = std::max<size_t>((len + nthreads - 1) / nthreads, 1u << 20);
+      std::vector<std::thread> th;
+      for (size_t b = 0; b < len; b += sub) {
+        const size_t e = std::min(len, b + sub);
+        th.emplace_back([&, b, e]() {
+          size_t q = b;
+          uint8_t *d = static_cast<uint8_t *>(buf[k]);
+          while (q < e) { const ssize_t r = pread(fd, d + q, e - q, (off_t)(off + at + q)); if (r <= 0) { ok = false; return; } q += (size_t)r; }
+        });
+      }
+      for (auto &x : th) x.join();
+      t_read += LoadClockNow() - tr;
+      if (!ok.load()) return fail(KAIJU_GPU_ERR_IO, "short read from the index image");
+      KJ_HIP(hipMemcpyAsync(static_cast<uint8_t *>(dst) + at, buf[k], len, hipMemcpyHostToDevice, stream));
+      KJ_HIP(hipEventRecord(done[k], stream));
+      used[k] = true;
+      at += len;
+    }
+    KJ_HIP(hipStreamSynchronize(stream));
+    bytes_streamed += n;
+    t_total += LoadClockNow() - t0;
+    return 0;
+  }
+};
+
+// a host vector, or - when it is empty and the image reader left the array in its file - the file's bytes
+template <class T, class A>
+static int upload_arr(kaiju_gpu_index *ix, ImageStreamer &is, const std::string &path, const std::vector<T, A> &v, const LazyArr &l, const T **dst) {
+  if (!v.empty() || l.n == 0) return upload(ix, v, dst);
+  int rc = is.open_file(path);
+  if (rc) return rc;
+  void *p = nullptr;
+  KJ_HIP(hipMalloc(&p, l.n * sizeof(T) + 32));
+  ix->allocs.push_back(p);
+  if ((rc = is.run(l.off, l.n * sizeof(T), p))) return rc;
   *dst = static_cast<const T *>(p);
   return 0;
 }
@@ -728,15 +815,17 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   DevIndex &d = ix->dev;
   // what goes to HBM per index row: rank blocks 2 B, SA sample (e = 3) 0.5 B of sequence numbers and, on a
   // narrow index, 1 B of taxon ids
-  if ((rc = upload(ix.get(), pk.blocks64, &d.blocks64))) return rc;
+  ImageStreamer is;
+  const std::string &ipath = pk.lazy.path;
+  if ((rc = upload_arr(ix.get(), is, ipath, pk.blocks64, pk.lazy.blocks64, &d.blocks64))) return rc;
   d.mb_base = nullptr; d.mb_shift = pk.mb_shift;
   if (!pk.mb_base.empty() && (rc = upload(ix.get(), pk.mb_base, &d.mb_base))) return rc;
   d.sa_taxid = nullptr;
   if (!pk.sa_taxid.empty() && (rc = upload(ix.get(), pk.sa_taxid, &d.sa_taxid))) return rc;
-  if ((rc = upload(ix.get(), pk.sa_iseq, &d.sa_iseq))) return rc;
+  if ((rc = upload_arr(ix.get(), is, ipath, pk.sa_iseq, pk.lazy.sa_iseq, &d.sa_iseq))) return rc;
   if ((rc = upload(ix.get(), pk.seq_taxid, &d.seq_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.seq_valid, &d.seq_valid))) return rc;
-  if ((rc = upload(ix.get(), pk.term_pos, &d.term_pos))) return rc;
+  if ((rc = upload_arr(ix.get(), is, ipath, pk.term_pos, pk.lazy.term_pos, &d.term_pos))) return rc;
   const double *dl = nullptr;
   if ((rc = upload(ix.get(), lnfact, &dl))) return rc;
   ix->st.lnfact = dl;
@@ -754,11 +843,16 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   for (int a = 0; a < 22; a++) d.C[a] = pk.C[a];
   d.bwtlen = pk.bwtlen; d.n_sa = pk.n_sa; d.sa_skip = pk.sa_skip; d.nseq = pk.nseq; d.chpt_exp = pk.chpt_exp;
   d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k; d.kline = nullptr;
-  lc.mark("upload of the packed arrays");
+  const uint64_t n_kmer32 = PackedIndex::count(pk.kmer32, pk.lazy.kmer32), n_kmer64 = PackedIndex::count(pk.kmer64, pk.lazy.kmer64);
   uint64_t kmer_bytes = 0;
   if (pk.kmer_k) {
-    if (!pk.kmer32.empty()) { if ((rc = upload(ix.get(), pk.kmer32, &d.kmer32))) return rc; }
-    else if ((rc = upload(ix.get(), pk.kmer64, &d.kmer64))) return rc;
+    if (n_kmer32) { if ((rc = upload_arr(ix.get(), is, ipath, pk.kmer32, pk.lazy.kmer32, &d.kmer32))) return rc; }
+    else if ((rc = upload_arr(ix.get(), is, ipath, pk.kmer64, pk.lazy.kmer64, &d.kmer64))) return rc;
+    lc.mark("upload of the packed arrays");
+    if (is.bytes_streamed && lc.on)
+      fprintf(stderr, "[kaiju_gpu load]   streamed from the image file: %.2f GB in %.2f s (%.1f GB/s; %.2f s of it reading pieces into "
+                      "page-locked memory, pieces of %zu MB)\n", is.bytes_streamed * 1e-9, is.t_total, is.bytes_streamed * 1e-9 / std::max(is.t_total, 1e-9),
+              is.t_read, is.piece >> 20);
     // Deeper tables are grown on the device, one letter at a time.  Depth: KAIJU_GPU_KMER, or the
     // largest k <= 7 whose table (20^k entries of 8 bytes) has at most 8 entries per index row -
     // 10 GB for a viruses-size index, which is what 288 GB of HBM are for.
@@ -784,7 +878,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         np *= 20; d.kmer_k++;
       }
       d.kmer32 = cur;
-      kmer_bytes = np * sizeof(uint2) - pk.kmer32.size() * sizeof(uint2);
+      kmer_bytes = np * sizeof(uint2) - n_kmer32 * sizeof(uint2);
     }
     d.kline = nullptr;
     if (d.kmer32 && d.blocks64 && !d.mb_base && d.kmer_k >= 2) {
@@ -821,7 +915,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         np *= 20; d.kmer_k++;
       }
       d.kmer64 = cur;
-      kmer_bytes = np * sizeof(ulonglong2) - pk.kmer64.size() * sizeof(ulonglong2);
+      kmer_bytes = np * sizeof(ulonglong2) - n_kmer64 * sizeof(ulonglong2);
     }
   }
   lc.mark("k-mer table (device)");
@@ -832,11 +926,11 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t need_peak = pk.bwtlen * 13 + ((uint64_t)pk.nseq << 3) + (64u << 20);       // two temporaries + the two arrays
-    const bool want = !getenv("KAIJU_GPU_NO_TEXT") && !d.mb_base && d.blocks64 && !pk.sa_pos.empty() && !(pk.warnings & KAIJU_IDX_WARN_SA_SHORT) &&
+    const bool want = !getenv("KAIJU_GPU_NO_TEXT") && !d.mb_base && d.blocks64 && PackedIndex::count(pk.sa_pos, pk.lazy.sa_pos) && !(pk.warnings & KAIJU_IDX_WARN_SA_SHORT) &&
                       pk.bwtlen + pk.nseq + 4 * (uint64_t)kTextPad < 0xffffffffull && need_peak < free_b / 2;
     if (want) {
       const uint32_t *d_smp = nullptr;
-      if ((rc = upload(ix.get(), pk.sa_pos, &d_smp))) return rc;
+      if ((rc = upload_arr(ix.get(), is, ipath, pk.sa_pos, pk.lazy.sa_pos, &d_smp))) return rc;
       void *smp_alloc = ix->allocs.back();
       uint32_t *row_seq = nullptr, *row_pos = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bad = nullptr, *sa_full = nullptr;
       uint8_t *text = nullptr;
@@ -886,11 +980,11 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   inf.device_bytes = pk.bytes() + kmer_bytes;
   {
     kaiju_gpu_index_footprint &f = ix->fp;
-    f.rank_blocks = pk.blocks64.size() * sizeof(RankBlock64);
+    f.rank_blocks = PackedIndex::count(pk.blocks64, pk.lazy.blocks64) * sizeof(RankBlock64);
     f.count_bases = pk.mb_base.size() * 8;
-    f.sa_seq = pk.sa_iseq.size() * 4;
+    f.sa_seq = PackedIndex::count(pk.sa_iseq, pk.lazy.sa_iseq) * 4;
     f.sa_taxid = pk.sa_taxid.size() * 8;
-    f.seq_tables = pk.seq_taxid.size() * 8 + pk.seq_valid.size() + pk.term_pos.size() * 8;
+    f.seq_tables = pk.seq_taxid.size() * 8 + pk.seq_valid.size() + PackedIndex::count(pk.term_pos, pk.lazy.term_pos) * 8;
     uint64_t nw = 1;
     for (uint32_t q = 0; q < d.kmer_k; q++) nw *= 20;
     f.kmer_table = d.kmer_k ? nw * (d.kmer64 ? sizeof(ulonglong2) : sizeof(uint2)) : 0;
@@ -932,12 +1026,16 @@ extern "C" int kaiju_gpu_index_write_image(const char *fmi_path, const char *ima
   if (!fmi_path || !image_path) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   FmiFile f;
   std::string msg;
+  LoadClock lc;
   int rc = f.load(fmi_path, msg);
+  lc.mark("read .fmi file");
   if (rc) return fail(rc, msg);
   PackedIndex pk;
   if ((rc = pk.build(f.view(), msg))) return fail(rc, msg);
+  lc.mark("pack (host)");
   { struct stat st; if (stat(fmi_path, &st) == 0) pk.src_fmi_bytes = (uint64_t)st.st_size; }
   if ((rc = pk.write_image(image_path, msg))) return fail(rc, msg);
+  lc.mark("write image file");
   return KAIJU_GPU_OK;
   });
 }
@@ -951,6 +1049,31 @@ extern "C" int kaiju_gpu_index_image_source_bytes(const char *image_path, uint64
   });
 }
 
+// Host only: what an image file holds, read the way the loader reads it (header and the small arrays; the arrays that grow with
+// the index are only located) - a caller can check an image and see how many bytes a load streams to the device without a GPU.
+extern "C" int kaiju_gpu_index_image_info(const char *image_path, kaiju_gpu_index_info *info, uint64_t *streamed_bytes) {
+  return guarded([&]() -> int {
+  if (!image_path || !info) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (!is_image_file(image_path)) return fail(KAIJU_GPU_ERR_FORMAT, "not a kaiju GPU index image");
+  PackedIndex pk;
+  std::string msg;
+  const int rc = pk.read_image(image_path, msg, true);
+  if (rc) return fail(rc, msg);
+  memset(info, 0, sizeof *info);
+  info->bwtlen = (int64_t)pk.bwtlen; info->nseq = (int32_t)pk.nseq; info->alen = (int32_t)pk.alen; info->chpt_exp = (int32_t)pk.chpt_exp;
+  info->db_length = (double)((int64_t)pk.bwtlen - (int64_t)pk.nseq);
+  info->device_bytes = pk.bytes();
+  info->warnings = pk.warnings;
+  snprintf(info->alphabet, sizeof info->alphabet, "%s", pk.alphabet.c_str());
+  if (streamed_bytes) {
+    const ImageLazy &l = pk.lazy;
+    *streamed_bytes = l.blocks64.n * sizeof(RankBlock64) + l.sa_iseq.n * 4 + l.sa_pos.n * 4 + l.term_pos.n * 8 + l.kmer32.n * sizeof(uint2) +
+                      l.kmer64.n * sizeof(ulonglong2);
+  }
+  return KAIJU_GPU_OK;
+  });
+}
+
 extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_gpu_index **out) {
   return guarded([&]() -> int {
   if (!fmi_path || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
@@ -961,8 +1084,11 @@ extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_g
     PackedIndex pk;
     std::string msg;
     LoadClock lc;
-    const int rc = pk.read_image(fmi_path, msg);
-    lc.mark("read image file");
+    // the arrays that grow with the index are streamed from the file to the device (kaijux ids rewrite the sampled ids on the
+    // host: that mode reads everything; KAIJU_GPU_IMAGE_HOST_COPY=1 does so too, for comparison)
+    const bool lazy = tl_id_mode == 0 && !getenv("KAIJU_GPU_IMAGE_HOST_COPY");
+    const int rc = pk.read_image(fmi_path, msg, lazy);
+    lc.mark(lazy ? "read image file (small arrays)" : "read image file");
     const int drc = device_check_result(dev);
     lc.mark("wait for the HIP runtime");
     if (drc) return drc;
@@ -998,7 +1124,7 @@ extern "C" int kaiju_gpu_index_load_devices(const char *fmi_path, const int *dev
   PackedIndex pk;
   std::string msg;
   int rc;
-  if (is_image_file(fmi_path)) rc = pk.read_image(fmi_path, msg);
+  if (is_image_file(fmi_path)) rc = pk.read_image(fmi_path, msg, id_mode == 0 && !getenv("KAIJU_GPU_IMAGE_HOST_COPY"));
   else {
     FmiFile f;
     rc = f.load(fmi_path, msg);

@@ -420,7 +420,22 @@ struct ImgHeader {
 };
 template <class T, class A> bool put_vec(FILE *fp, const std::vector<T, A> &v) {
   const uint64_t n = v.size();
-  return fwrite(&n, 8, 1, fp) == 1 && (n == 0 || fwrite(v.data(), sizeof(T), n, fp) == n);
+  if (fwrite(&n, 8, 1, fp) != 1) return false;
+  const uint64_t bytes = n * sizeof(T), piece = 64ull << 20;
+  if (bytes <= 2 * piece) return n == 0 || fwrite(v.data(), sizeof(T), n, fp) == n;
+  // a big array: pieces written side by side (one thread copying tens of GB into the page cache takes a minute)
+  if (fflush(fp) != 0) return false;
+  const off_t base = ftello(fp);
+  if (base < 0) return fwrite(v.data(), sizeof(T), n, fp) == n;
+  const int fd = fileno(fp);
+  const uint8_t *s = reinterpret_cast<const uint8_t *>(v.data());
+  std::atomic<bool> ok{true};
+  parallel_for((bytes + piece - 1) / piece, [&](uint64_t c) {
+    uint64_t b = c * piece;
+    const uint64_t e = std::min<uint64_t>(bytes, b + piece);
+    while (b < e) { const ssize_t r = pwrite(fd, s + b, (size_t)(e - b), base + (off_t)b); if (r <= 0) { ok = false; return; } b += (uint64_t)r; }
+  });
+  return ok.load() && fseeko(fp, base + (off_t)bytes, SEEK_SET) == 0;
 }
 // positional reads, big arrays in pieces by several threads (an image is about a GB: one thread copying it out of the
 // page cache takes a quarter of a second)
@@ -453,6 +468,16 @@ struct ImgReader {
     v.resize((size_t)n);
     return n == 0 || raw(v.data(), n * sizeof(T));
   }
+  // the same array left where it is: count and offset noted, the elements skipped
+  template <class T, class A> bool vec_lazy(std::vector<T, A> &v, LazyArr &l, bool lazy) {
+    if (!lazy) { l = LazyArr{}; return vec(v); }
+    uint64_t n = 0;
+    if (!raw(&n, 8) || n > (size - pos) / sizeof(T)) return false;
+    v.clear();
+    l.n = n; l.off = pos;
+    pos += n * sizeof(T);
+    return true;
+  }
 };
 }  // namespace
 
@@ -482,7 +507,7 @@ int PackedIndex::write_image(const char *path, std::string &msg) const {
   return 0;
 }
 
-int PackedIndex::read_image(const char *path, std::string &msg) {
+int PackedIndex::read_image(const char *path, std::string &msg, bool lazy_big) {
   const int fd = open(path, O_RDONLY);
   if (fd < 0) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
   ImgReader rd{fd, 0, 0};
@@ -500,16 +525,21 @@ int PackedIndex::read_image(const char *path, std::string &msg) {
   alphabet = h.alphabet;
   std::vector<uint32_t> nl;
   std::vector<char> nc;
-  ok = rd.vec(blocks64) && rd.vec(sa_taxid) &&
-       rd.vec(sa_iseq) && rd.vec(sa_pos) && rd.vec(seq_taxid) && rd.vec(seq_valid) && rd.vec(term_pos) &&
-       rd.vec(kmer32) && rd.vec(kmer64) && rd.vec(mb_base) && rd.vec(nl) && rd.vec(nc);
+  lazy = ImageLazy{};
+  if (lazy_big) lazy.path = path;
+  ok = rd.vec_lazy(blocks64, lazy.blocks64, lazy_big) && rd.vec(sa_taxid) &&
+       rd.vec_lazy(sa_iseq, lazy.sa_iseq, lazy_big) && rd.vec_lazy(sa_pos, lazy.sa_pos, lazy_big) && rd.vec(seq_taxid) && rd.vec(seq_valid) &&
+       rd.vec_lazy(term_pos, lazy.term_pos, lazy_big) &&
+       rd.vec_lazy(kmer32, lazy.kmer32, lazy_big) && rd.vec_lazy(kmer64, lazy.kmer64, lazy_big) && rd.vec(mb_base) && rd.vec(nl) && rd.vec(nc);
   close(fd);
   uint64_t total = 0;
   for (uint32_t l : nl) total += l;
   // consistency of what the kernels will index
   ok = ok && total == nc.size() && nl.size() == nseq && seq_taxid.size() == nseq && seq_valid.size() == nseq &&
-       blocks64.size() == (size_t)(bwtlen >> 6) + 1 && sa_iseq.size() >= n_sa && (wide ? sa_taxid.empty() : sa_taxid.size() >= n_sa) &&
-       (!wide || mb_base.size() == (size_t)((bwtlen >> mb_shift) + 1) * 20) && (sa_pos.empty() || sa_pos.size() == sa_iseq.size());
+       count(blocks64, lazy.blocks64) == (bwtlen >> 6) + 1 && count(sa_iseq, lazy.sa_iseq) >= n_sa && (wide ? sa_taxid.empty() : sa_taxid.size() >= n_sa) &&
+       (!wide || mb_base.size() == (size_t)((bwtlen >> mb_shift) + 1) * 20) &&
+       (count(sa_pos, lazy.sa_pos) == 0 || count(sa_pos, lazy.sa_pos) == count(sa_iseq, lazy.sa_iseq)) && count(term_pos, lazy.term_pos) == nseq &&
+       ((count(kmer32, lazy.kmer32) == 0) != (count(kmer64, lazy.kmer64) == 0) || kmer_k == 0);
   if (!ok) { msg = "truncated or inconsistent index image"; return KAIJU_GPU_ERR_FORMAT; }
   names.clear();
   names.resize(nl.size());
@@ -569,8 +599,9 @@ int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::stri
 }
 
 uint64_t PackedIndex::bytes() const {
-  return sa_iseq.size() * 4 + seq_taxid.size() * 8 + seq_valid.size() + term_pos.size() * 8 + kmer32.size() * 8 + kmer64.size() * 16 +
-         mb_base.size() * 8 + blocks64.size() * sizeof(RankBlock64) + sa_taxid.size() * 8;
+  return count(sa_iseq, lazy.sa_iseq) * 4 + seq_taxid.size() * 8 + seq_valid.size() + count(term_pos, lazy.term_pos) * 8 +
+         count(kmer32, lazy.kmer32) * 8 + count(kmer64, lazy.kmer64) * 16 +
+         mb_base.size() * 8 + count(blocks64, lazy.blocks64) * sizeof(RankBlock64) + sa_taxid.size() * 8;
 }
 
 DevIndex PackedIndex::host_view() const {

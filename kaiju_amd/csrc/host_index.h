@@ -67,8 +67,18 @@ struct FmiFile {
   HostIndexView view() const;
 };
 
+// an array of an image file that was NOT read into host memory: element count and where its elements start in the file
+// (capi.hip streams such arrays from the file to the device in pieces through page-locked buffers)
+struct LazyArr { uint64_t off = 0, n = 0; };
+struct ImageLazy {
+  std::string path;            // empty: nothing is lazy
+  LazyArr blocks64, sa_iseq, sa_pos, term_pos, kmer32, kmer64;
+};
+
 // the packed index in host memory, ready for upload
 struct PackedIndex {
+  ImageLazy lazy;                   // read_image(.., lazy_big = true): the arrays that grow with the index stay in the file
+  template <class V> static uint64_t count(const V &v, const LazyArr &l) { return v.empty() ? l.n : (uint64_t)v.size(); }
   BigVec<RankBlock64> blocks64;   // second-generation lanes: absolute counts (bwtlen < 2^32) or relative to mb_base
   std::vector<uint64_t> mb_base;       // wide layout: [nmb][20], counts at the start of every 2^mb_shift rows
   uint32_t mb_shift = 0;
@@ -110,7 +120,9 @@ struct PackedIndex {
   void to_sequence_ids();
   // the packed arrays as one file ("device image": written once, loaded instead of parsing and packing the .fmi)
   int write_image(const char *path, std::string &msg) const;
-  int read_image(const char *path, std::string &msg);
+  // lazy_big: rank blocks, sampled sequence numbers / offsets, terminator rows and the k-mer table are not read - `lazy` says
+  // where they are (a refseq-class image is 150 GB: eight ranks of a node cannot each hold a host copy of it)
+  int read_image(const char *path, std::string &msg, bool lazy_big = false);
   static int image_source_bytes(const char *path, uint64_t &bytes, std::string &msg);   // header field of an image file
 };
 

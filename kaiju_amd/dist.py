@@ -80,6 +80,18 @@ class HitGatherer:
             self._retire(self.pending.pop(0))
 
 
+def gather_to_root(t, world: int, rank: int):
+    """one tensor of every rank on rank 0 (a list in rank order; None elsewhere) - the parity samples of an N-rank bench
+    line, not the data path"""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return [t]
+    bufs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, gather_list=bufs, dst=0)
+    return bufs
+
+
 def max_over_ranks(value: float, device=None) -> float:
     import torch
     import torch.distributed as dist

@@ -40,6 +40,8 @@ void *emu_index_load(const char *path, char *err, int errlen) {
   if (rc == 0) rc = build_const_tables(ix->packed.trans, ix->ct, msg);
   if (rc == 0) rc = build_seg_tables(ix->lnfact, ix->st, msg);
   if (rc != 0) { snprintf(err, (size_t)errlen, "%s", msg.c_str()); delete ix; return nullptr; }
+  // (tests/tools/big_rows_emu.py: an index of 2^33 rows and more next to the oracle's copy in 62 GB of host memory)
+  if (getenv("KAIJU_EMU_DROP_FILE")) { BigVec<uint8_t>().swap(ix->file.bwt); BigVec<uint8_t>().swap(ix->file.sa); }
   return ix;
 }
 // kaijux semantics: ids are sequence numbers

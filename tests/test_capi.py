@@ -158,3 +158,27 @@ def test_damaged_index_files_return_a_status(golden, tmp_path):
         rc = L.kaiju_gpu_index_write_image(p.encode(), img.encode())
         assert rc < 0, name
         assert L.kaiju_gpu_strerror(rc)
+
+
+def test_image_info_locates_the_streamed_arrays(golden, tmp_path):
+    """kaiju_gpu_index_image_info (host only) reads an image the way the loader does - header and small arrays into memory, the
+    arrays that grow with the index only located for the streamed upload - and says how many bytes a load streams"""
+    L = api.lib()
+    L.kaiju_gpu_index_write_image.argtypes = [C.c_char_p, C.c_char_p]
+    L.kaiju_gpu_index_image_info.argtypes = [C.c_char_p, C.POINTER(api.IndexInfo), C.POINTER(C.c_uint64)]
+    img = str(tmp_path / "db.kjimg")
+    assert L.kaiju_gpu_index_write_image(golden.fmi.encode(), img.encode()) == 0
+    info, streamed = api.IndexInfo(), C.c_uint64(0)
+    assert L.kaiju_gpu_index_image_info(img.encode(), C.byref(info), C.byref(streamed)) == 0
+    import struct
+    bwtlen, nseq = struct.unpack_from("<qi", open(golden.fmi, "rb").read(12))
+    assert (info.bwtlen, info.nseq, info.alen, info.chpt_exp) == (bwtlen, nseq, 21, 3)
+    # rank blocks (128 B per 64 rows) + sampled sequence numbers and offsets + terminator rows + the host's k = 5 table
+    n_sa = ((bwtlen - 1) >> 3) - (((nseq - 1) >> 3) + 1) + 1
+    want = ((bwtlen >> 6) + 1) * 128 + nseq * 8 + 20 ** 5 * 8
+    assert want + 8 * (n_sa - 1) <= streamed.value <= want + 8 * (n_sa + 1)
+    assert streamed.value < os.path.getsize(img) and streamed.value <= info.device_bytes
+    # a truncated image and a .fmi are refused
+    open(str(tmp_path / "cut.kjimg"), "wb").write(open(img, "rb").read()[: os.path.getsize(img) // 2])
+    assert L.kaiju_gpu_index_image_info(str(tmp_path / "cut.kjimg").encode(), C.byref(info), None) < 0
+    assert L.kaiju_gpu_index_image_info(golden.fmi.encode(), C.byref(info), None) < 0

@@ -94,3 +94,59 @@ def test_bench_refuses_a_launcher_that_disagrees_with_gpus(tmp_path):
     assert r.returncode != 0 and b"WORLD_SIZE=1" in r.stderr
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode != 0 and b"GPU(s) visible" in r.stderr
+
+
+def _parity_worker(rank, world, port, tmpdir):
+    """the per-rank parity plumbing of an N-rank bench line: every rank's sample of reads and of records goes to rank 0"""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    kdist.init("gloo")
+    k, L = 50, 150
+    reads = np.full((k, L), 65 + rank, dtype=np.uint8)
+    recs = np.arange(k * 16, dtype=np.uint8) + rank
+    a = kdist.gather_to_root(torch.from_numpy(reads.reshape(-1)), world, rank)
+    b = kdist.gather_to_root(torch.from_numpy(recs), world, rank)
+    if rank == 0:
+        assert len(a) == world and len(b) == world
+        for r in range(world):
+            assert (a[r].numpy().reshape(k, L) == 65 + r).all()
+            assert (b[r].numpy() == (np.arange(k * 16, dtype=np.uint8) + r)).all()
+        open(os.path.join(tmpdir, "ok"), "w").write("1")
+    else:
+        assert a is None and b is None
+    kdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_parity_samples_of_every_rank_reach_rank_0(tmp_path):
+    mp.spawn(_parity_worker, args=(2, free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(str(tmp_path / "ok"))
+
+
+def test_bench_parity_comparison_and_strong_scaling_blocks():
+    """bench.py's comparison with the reference's lines (C/U, taxon, column 4 for classified reads) and the read blocks of a
+    strong-scaling job: the ranks' contiguous shares of ONE workload are the same reads whatever the number of ranks"""
+    sys.path.insert(0, util.ROOT)
+    import bench
+    from kaiju_amd import synth
+    ref = (np.array([1, 0, 1, 1], dtype=np.uint8), np.array([7, 0, 9, 9], dtype=np.uint64), np.array([11, 0, 30, 30], dtype=np.int64))
+    cls, tax, best = ref[0].copy(), ref[1].copy(), ref[2].copy()
+    assert bench.compare_with_reference(cls, tax, best, ref)["mismatches"] == 0
+    best[1] = 99                                    # column 4 of an unclassified read is not compared
+    assert bench.compare_with_reference(cls, tax, best, ref)["mismatches"] == 0
+    best[2] = 31
+    tax[3] = 8
+    out = bench.compare_with_reference(cls, tax, best, ref)
+    assert out["mismatches"] == 2 and out["first_mismatches"] == [2, 3] and out["checked"] == 4
+    _, leaves = synth.make_taxonomy(3, 2, 2)
+    db = synth.make_db(nseq=301, seed=5, leaves=leaves)
+    old = bench.READ_BLOCK
+    bench.READ_BLOCK = 64
+    try:
+        for paired in (False, True):
+            whole = bench.reads_of_range(db, 0, 300, paired, 777000)
+            assert whole.shape == (300, 300 if paired else 150)
+            for world in (2, 3, 4):
+                parts = [bench.reads_of_range(db, *kdist.shard_bounds(300, r, world), paired, 777000) for r in range(world)]
+                assert (np.concatenate(parts, axis=0) == whole).all()
+    finally:
+        bench.READ_BLOCK = old

@@ -59,3 +59,27 @@ def test_replicated_database_without_a_second_sort(golden, tmp_path, copies, exp
     mkfmi.build_fmi_replicated(src, b, copies, threads=3, exponent=exponent, copy_taxids=taxids)
     assert os.path.getsize(a) == os.path.getsize(b)
     assert filecmp.cmp(a, b, shallow=False)
+
+
+def test_the_64_bit_instantiation_writes_the_same_bytes(golden, tmp_path, monkeypatch):
+    """databases of 4 G symbols and more are sorted with 64-bit suffix positions (refseq-class indexes of bench.py): the same
+    template, forced onto the golden database and a many-piece FASTA (the reader cuts the file at record starts and parses the
+    pieces side by side)"""
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=4001, seed=9, leaves=leaves, max_len=900)
+    faa = str(tmp_path / "db.faa")
+    synth.write_fasta(db, faa)
+    a, b, c = str(tmp_path / "a.fmi"), str(tmp_path / "b.fmi"), str(tmp_path / "c.fmi")
+    mkfmi.build_fmi(faa, a, threads=1, exponent=3)
+    mkfmi.build_fmi(faa, c, threads=16, exponent=3)
+    monkeypatch.setenv("KAIJU_MKFMI_FORCE64", "1")
+    mkfmi.build_fmi(faa, b, threads=5, exponent=3)
+    assert filecmp.cmp(a, b, shallow=False) and filecmp.cmp(a, c, shallow=False)
+    g = str(tmp_path / "g.fmi")
+    mkfmi.build_fmi(os.path.join(golden.dir, "db.faa"), g, threads=3, exponent=3)
+    assert filecmp.cmp(g, golden.fmi, shallow=False)
+    r32, r64 = str(tmp_path / "r32.fmi"), str(tmp_path / "r64.fmi")
+    mkfmi.build_fmi_replicated(faa, r64, 3, threads=4, exponent=3)
+    monkeypatch.delenv("KAIJU_MKFMI_FORCE64")
+    mkfmi.build_fmi_replicated(faa, r32, 3, threads=4, exponent=3)
+    assert filecmp.cmp(r32, r64, shallow=False)
