@@ -533,6 +533,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --reads is the size of ONE workload per step, split over the ranks in contiguous blocks "
                          "(BASELINE configs[4]: 400 M reads sharded over 8 GPUs); default: weak scaling, --reads per GPU")
+    ap.add_argument("--no-ref-ops", action="store_true",
+                    help="skip the op counts of the reference's algorithm (roofline.work_rate): the instrumented oracle reads the "
+                         ".fmi once more, a minute for a refseq-class index")
     ap.add_argument("--prepare-only", action="store_true", help="build the database, the .fmi (and the image with --image) and exit; no GPU needed")
     ap.add_argument("--parity-sample", type=int, default=200_000,
                     help="N > 1: reads (pairs) of EVERY rank whose gathered records rank 0 compares with the reference binary")
@@ -708,7 +711,8 @@ def main():
         if args.no_cpu_baseline or world != 1:
             return out
         try:
-            out["ref_ops"] = reference_ops(W, fmi, rd[:oracle_sample], leg.mode, seg, leg.paired, Lm)
+            if not args.no_ref_ops:
+                out["ref_ops"] = reference_ops(W, fmi, rd[:oracle_sample], leg.mode, seg, leg.paired, Lm)
         except Exception as e:  # noqa: BLE001 - the accounting legs must never kill the measurement
             log(rank, f"reference op counts ({leg.name}) failed:", repr(e))
         try:

@@ -699,6 +699,7 @@ struct ImageStreamer {
     size_t mb = 256;
     if (const char *e = getenv("KAIJU_GPU_STREAM_PIECE_MB")) { const long v = atol(e); if (v >= 1 && v <= 4096) mb = (size_t)v; }
     piece = mb << 20;
+    if (const char *e = getenv("KAIJU_GPU_STREAM_PIECE_KB")) { const long v = atol(e); if (v >= 4 && v <= (4096L << 10)) piece = (size_t)v << 10; }   // (tests)
     for (int k = 0; k < 2; k++) {
       KJ_HIP(hipHostMalloc(&buf[k], piece, hipHostMallocDefault));
       KJ_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
@@ -717,7 +718,7 @@ struct ImageStreamer {
       if (used[k]) KJ_HIP(hipEventSynchronize(done[k]));               // the copy out of this buffer has finished
       const double tr = LoadClockNow();
       std::atomic<bool> ok{true};
-      const size_t sub = std::max<size_t>((len + nthreads - 1) / nthreads, 1u << 20);
+      const size_t sub = std::max<size_t>((len + nthreads - 1) / nthreads, std::min<size_t>(1u << 20, std::max<size_t>(piece / 4, 4096)));
       std::vector<std::thread> th;
       for (size_t b = 0; b < len; b += sub) {
         const size_t e = std::min(len, b + sub);

@@ -144,12 +144,26 @@ def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
     api = gpu_lib
     img = str(tmp_path / "db.kjimg")
     api.write_index_image(golden.fmi, img)
-    idx2 = api.Index(img)
-    assert idx2.info.bwtlen == gidx.info.bwtlen and idx2.info.nseq == gidx.info.nseq
-    for mode in ("mem", "greedy"):
-        a = api.Classifier(gidx, api.default_params(mode, seg=1)).classify(golden.seqs, golden.off)
-        b = api.Classifier(idx2, api.default_params(mode, seg=1)).classify(golden.seqs, golden.off)
-        assert (a == b).all()
+    # the arrays that grow with the index are streamed from the file to the device in page-locked pieces: default piece size
+    # (one piece here), pieces of 16 KB (dozens per array, several reader threads per piece), and the host-copy path
+    for env in ({}, {"KAIJU_GPU_STREAM_PIECE_KB": "16"}, {"KAIJU_GPU_IMAGE_HOST_COPY": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            idx2 = api.Index(img)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert idx2.info.bwtlen == gidx.info.bwtlen and idx2.info.nseq == gidx.info.nseq
+        assert idx2.footprint.as_dict() == gidx.footprint.as_dict()
+        for mode in ("mem", "greedy"):
+            a = api.Classifier(gidx, api.default_params(mode, seg=1)).classify(golden.seqs, golden.off)
+            b = api.Classifier(idx2, api.default_params(mode, seg=1)).classify(golden.seqs, golden.off)
+            assert (a == b).all(), env
+        idx2.close()
     # a damaged image is refused
     data = open(img, "rb").read()
     bad = str(tmp_path / "bad.kjimg")

@@ -1,0 +1,62 @@
+#!/bin/bash
+# One GPU lease = one call of this script on the GPU box:   gpurun -- bash tests/tools/lease.sh <name> <task> [<task> ...]
+# Everything a task writes goes to gpurun_out/<name>/ (merged back; what is worth judging is copied to profiles/ by hand).
+# Tasks (each under its own timeout; a failing task does not stop the following ones):
+#   suite            pytest -m gpu (full GPU suite)                                   -> gpu_tests.log
+#   smoke            __graft_entry__.smoke()                                          -> smoke.log
+#   bench            python bench.py (default line: headline + legs + CPU baseline)   -> bench_n1.json / .err
+#   bench:<args>     python bench.py <args> ("," stands for a blank)                  -> bench_<n>.json / .err
+#   stats            rocprofv3 --kernel-trace --stats of the headline leg             -> kernel_stats.csv
+#   stats_greedy     ... of --mode greedy                                             -> kernel_stats_greedy.csv
+#   pmc              PMC passes of the search kernels (tests/tools/pmc_bench.sh) + profiles/traffic.json
+#   refseq_ref       BASELINE configs[3] at its named scale (100 M proteins, 28 G rows; real sort): bench.py --image --paired
+#   refseq           BASELINE configs[4] class (200 M proteins, 56 G rows): one MEM leg on one GPU
+#   py:<script>      python <script> ("," stands for a blank)                         -> py_<n>.log
+#   sh:<script>      bash <script>                                                    -> sh_<n>.log
+cd "$GRAFT_REPO_ROOT" || exit 1
+NAME=$1; shift
+O=gpurun_out/$NAME; mkdir -p "$O"
+export TMPDIR=/tmp
+n=0
+for task in "$@"; do
+  n=$((n + 1))
+  t0=$(date +%s)
+  case "$task" in
+    suite)
+      ( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $O/gpu_tests.log 2>&1; echo "[lease] suite rc=$?"; tail -4 $O/gpu_tests.log ;;
+    smoke)
+      timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "[lease] smoke rc=$?"; tail -3 $O/smoke.log ;;
+    bench)
+      timeout 1500 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "[lease] bench rc=$?"; tail -6 $O/bench_n1.err ;;
+    bench:*)
+      args=$(echo "${task#bench:}" | tr ',' ' ')
+      timeout 2400 python bench.py $args > $O/bench_$n.json 2> $O/bench_$n.err; echo "[lease] bench $args rc=$?"; tail -6 $O/bench_$n.err ;;
+    stats)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --legs "" --steps 5 > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_under_rocprof.err )
+      cp $O/stats/s_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null; rm -rf $O/stats; echo "[lease] stats"; head -8 $O/kernel_stats.csv ;;
+    stats_greedy)
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_g -o s -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --mode greedy --legs "" --steps 3 > $GRAFT_REPO_ROOT/$O/bench_greedy_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_greedy_under_rocprof.err )
+      cp $O/stats_g/s_kernel_stats.csv $O/kernel_stats_greedy.csv 2>/dev/null; rm -rf $O/stats_g; echo "[lease] stats_greedy"; head -6 $O/kernel_stats_greedy.csv ;;
+    pmc)
+      bash tests/tools/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log
+      python tests/tools/pmc_bench_collect.py $O/pmc profiles/traffic.json $O/pmc_raw > $O/pmc_collect.log 2>&1; cp profiles/traffic.json profiles/traffic_all_kernels.json $O/ 2>/dev/null; tail -3 $O/pmc_collect.log ;;
+    refseq_ref|refseq)
+      # the database, its .fmi and the device image live in /dev/shm (the box has 3 TB of memory, / only 79 GB)
+      W=/dev/shm/kaiju_big_$task; mkdir -p $W
+      if [ "$task" = refseq_ref ]; then NSEQ=100000001; ARGS="--paired --reads 5000000 --steps 10 --legs greedy --leg-steps 2 --cpu-sample 200000 --cpu-sample-legs 100000"
+      else NSEQ=200000001; ARGS="--reads 10000000 --steps 3 --legs paired --leg-steps 1 --cpu-sample 200000 --cpu-sample-legs 100000"; fi
+      ( time KAIJU_GPU_LOAD_TIMES=1 timeout ${LEASE_BIG_TIMEOUT:-1700} python bench.py --work $W --nseq $NSEQ --image --warmup 1 --no-ref-ops $ARGS ) > $O/bench_$task.json 2> $O/bench_$task.err
+      echo "[lease] $task rc=$?"; grep -v "^\[kaiju_gpu pack\]" $O/bench_$task.err | tail -40; ls -la $W > $O/files_$task.txt; df -h /dev/shm >> $O/files_$task.txt; free -g >> $O/files_$task.txt
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$task -o s -- python $GRAFT_REPO_ROOT/bench.py --work $W --nseq $NSEQ --image --no-cpu-baseline --legs "" --steps 3 --warmup 1 $(echo $ARGS | sed 's/--steps [0-9]*//; s/--legs [a-z]*//') > $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.err )
+      cp $O/stats_$task/s_kernel_stats.csv $O/kernel_stats_$task.csv 2>/dev/null; rm -rf $O/stats_$task; head -6 $O/kernel_stats_$task.csv
+      rm -rf $W ;;
+    py:*)
+      args=$(echo "${task#py:}" | tr ',' ' ')
+      timeout 2400 python $args > $O/py_$n.log 2>&1; echo "[lease] python $args rc=$?"; tail -15 $O/py_$n.log ;;
+    sh:*)
+      timeout 2400 bash ${task#sh:} $O > $O/sh_$n.log 2>&1; echo "[lease] ${task#sh:} rc=$?"; tail -15 $O/sh_$n.log ;;
+    *) echo "[lease] unknown task $task" ;;
+  esac
+  echo "[lease] $task took $(( $(date +%s) - t0 )) s"
+done
+du -sh $O
