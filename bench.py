@@ -211,7 +211,8 @@ def big_database(W, nseq, rank):
     the FASTA and the code / offset / taxon arrays under W; every rank maps them (reads are drawn from the database)"""
     base = f"{W}/db_{nseq}"
     if rank == 0 and not (os.path.exists(base + ".taxids") and os.path.exists(base + ".codes")):
-        exe = f"{W}/gen_db"
+        import tempfile
+        exe = os.path.join(tempfile.gettempdir(), f"kaiju_gen_db_{os.getpid()}")       # (not under W: /dev/shm may be mounted noexec)
         subprocess.run(["gcc", "-O2", "-fopenmp", "-o", exe, os.path.join(ROOT, "tests", "tools", "gen_db.c"), "-lm"], check=True)
         subprocess.run([exe, str(nseq), "20260926", base + ".faa", base + ".codes", base + ".offsets", base + ".taxids.tmp"], check=True)
         os.replace(base + ".taxids.tmp", base + ".taxids")

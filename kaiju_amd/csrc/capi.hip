@@ -921,7 +921,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   }
   lc.mark("k-mer table (device)");
   // ---- text verification: the database text + the full suffix array (5 bytes per row; narrow indexes with room for it) ----
-  d.sa_full = nullptr; d.text = nullptr; d.row_seq = nullptr;
+  d.sa_full = nullptr; d.text = nullptr; d.row_seq = nullptr; d.seq_off = nullptr;
   uint64_t text_bytes = 0;
   {
     size_t free_b = 0, total_b = 0;
@@ -960,14 +960,15 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         }
       }
       (void)hipGetLastError();
-      for (void *q : {(void *)row_pos, (void *)d_len, (void *)d_off, (void *)d_bad}) if (q) (void)hipFree(q);
+      for (void *q : {(void *)row_pos, (void *)d_len, (void *)d_bad}) if (q) (void)hipFree(q);
       if (!ok && row_seq) { (void)hipFree(row_seq); row_seq = nullptr; }     // (kept otherwise: DevIndex::row_seq)
+      if (!ok && d_off) { (void)hipFree(d_off); d_off = nullptr; }           // (kept otherwise: DevIndex::seq_off)
       // (the sample offsets were only needed here)
       (void)hipFree(smp_alloc);
       ix->allocs.pop_back();
       if (ok) {
-        ix->allocs.push_back(sa_full); ix->allocs.push_back(text); ix->allocs.push_back(row_seq);
-        d.sa_full = sa_full; d.text = text; d.row_seq = row_seq;
+        ix->allocs.push_back(sa_full); ix->allocs.push_back(text); ix->allocs.push_back(row_seq); ix->allocs.push_back(d_off);
+        d.sa_full = sa_full; d.text = text; d.row_seq = row_seq; d.seq_off = d_off;
       }
       else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; }
     }
