@@ -920,13 +920,17 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     }
   }
   lc.mark("k-mer table (device)");
-  // ---- text verification: the database text + the full suffix array (5 bytes per row; narrow indexes with room for it) ----
-  d.sa_full = nullptr; d.text = nullptr; d.row_seq = nullptr; d.seq_off = nullptr;
+  // ---- text verification: the database text (1 B per row), the full suffix array and the sequence of every row (4 B per row
+  //      each: 9 bytes per row in all, + 4 B per sequence for the text offsets; narrow indexes with room for it).  Room = twice
+  //      the peak of the build (two temporaries of 4 B per row next to the arrays) plus what the classification contexts of
+  //      two streams allocate later (scratch of the search lanes, peptides, fragment lists: up to ~4 GB for 10 M-read batches) -
+  //      an index that does not leave that much goes without the text arrays rather than failing in kaiju_gpu_create ----
+  d.sa_full = nullptr; d.text = nullptr; d.row_seq = nullptr;
   uint64_t text_bytes = 0;
   {
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const uint64_t need_peak = pk.bwtlen * 13 + ((uint64_t)pk.nseq << 3) + (64u << 20);       // two temporaries + the two arrays
+    const uint64_t need_peak = pk.bwtlen * 13 + ((uint64_t)pk.nseq << 3) + (64u << 20) + (4ull << 30);   // 9 B per row kept + one temporary of 4 B per row + contexts
     const bool want = !getenv("KAIJU_GPU_NO_TEXT") && !d.mb_base && d.blocks64 && PackedIndex::count(pk.sa_pos, pk.lazy.sa_pos) && !(pk.warnings & KAIJU_IDX_WARN_SA_SHORT) &&
                       pk.bwtlen + pk.nseq + 4 * (uint64_t)kTextPad < 0xffffffffull && need_peak < free_b / 2;
     if (want) {
@@ -960,15 +964,14 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         }
       }
       (void)hipGetLastError();
-      for (void *q : {(void *)row_pos, (void *)d_len, (void *)d_bad}) if (q) (void)hipFree(q);
+      for (void *q : {(void *)row_pos, (void *)d_len, (void *)d_off, (void *)d_bad}) if (q) (void)hipFree(q);
       if (!ok && row_seq) { (void)hipFree(row_seq); row_seq = nullptr; }     // (kept otherwise: DevIndex::row_seq)
-      if (!ok && d_off) { (void)hipFree(d_off); d_off = nullptr; }           // (kept otherwise: DevIndex::seq_off)
       // (the sample offsets were only needed here)
       (void)hipFree(smp_alloc);
       ix->allocs.pop_back();
       if (ok) {
-        ix->allocs.push_back(sa_full); ix->allocs.push_back(text); ix->allocs.push_back(row_seq); ix->allocs.push_back(d_off);
-        d.sa_full = sa_full; d.text = text; d.row_seq = row_seq; d.seq_off = d_off;
+        ix->allocs.push_back(sa_full); ix->allocs.push_back(text); ix->allocs.push_back(row_seq);
+        d.sa_full = sa_full; d.text = text; d.row_seq = row_seq;
       }
       else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; }
     }
@@ -1026,14 +1029,15 @@ static bool is_image_file(const char *path) {
 extern "C" int kaiju_gpu_index_write_image(const char *fmi_path, const char *image_path) {
   return guarded([&]() -> int {
   if (!fmi_path || !image_path) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
-  FmiFile f;
+  std::unique_ptr<FmiFile> f(new FmiFile());
   std::string msg;
   LoadClock lc;
-  int rc = f.load(fmi_path, msg);
+  int rc = f->load(fmi_path, msg);
   lc.mark("read .fmi file");
   if (rc) return fail(rc, msg);
   PackedIndex pk;
-  if ((rc = pk.build(f.view(), msg))) return fail(rc, msg);
+  if ((rc = pk.build(f->view(), msg))) return fail(rc, msg);
+  f.reset();                        // (a refseq-class .fmi is 60 GB in memory: gone before the image, as large again, is written)
   lc.mark("pack (host)");
   { struct stat st; if (stat(fmi_path, &st) == 0) pk.src_fmi_bytes = (uint64_t)st.st_size; }
   if ((rc = pk.write_image(image_path, msg))) return fail(rc, msg);

@@ -724,7 +724,23 @@ int main(int argc, char **argv) {
   std::vector<int> devices;
   if (const char *e = getenv("KAIJU_GPU_DEVICES")) {
     if (!strcmp(e, "all")) { const int nd = kaiju_gpu_device_count(); for (int d = 0; d < nd; d++) devices.push_back(d); }
-    else for (const char *q = e; *q;) { devices.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+    else {
+      // a comma separated list of device numbers: every entry a number of an existing device, none twice (a replica of the
+      // index per entry: "0,,1" or "a,b" must not quietly become GPU 0 more than once); KAIJU_GPU_DEVICES_ALLOW_REPEAT=1
+      // lets tests put several replicas on one GPU
+      const int nd = parse_only ? 1 << 20 : kaiju_gpu_device_count();
+      for (const char *q = e; ; ) {
+        char *end = nullptr;
+        const long v = strtol(q, &end, 10);
+        if (end == q || (*end && *end != ',')) die(std::string("KAIJU_GPU_DEVICES: not a list of device numbers: ") + e);
+        if (v < 0 || v >= nd) die(std::string("KAIJU_GPU_DEVICES: no such device: ") + std::to_string(v));
+        if (!getenv("KAIJU_GPU_DEVICES_ALLOW_REPEAT"))
+          for (int d : devices) if (d == (int)v) die(std::string("KAIJU_GPU_DEVICES: device listed twice: ") + std::to_string(v));
+        devices.push_back((int)v);
+        if (!*end) break;
+        q = end + 1;
+      }
+    }
   }
   if (devices.empty()) devices.push_back(getenv("KAIJU_GPU_DEVICE") ? atoi(getenv("KAIJU_GPU_DEVICE")) : 0);
   const int n_dev = (int)devices.size();
@@ -905,10 +921,12 @@ int main(int argc, char **argv) {
           wait_for_gpu();
           StageTimer tm(g_ns_gpu);
           wall_mark("gpu call begins, batch", (long long)seq);
+          uint64_t piece_error_flags = 0;
           if (verbose) {
             b->hits.resize(n);
             b->vrec.resize(n);
             std::vector<uint64_t> poff;
+            piece_error_flags = 0;
             for (uint32_t lo = 0; lo < n && r == 0;) {
               // the longest piece from read lo on whose text fits the budget (at least one read)
               uint64_t maxpair = 0;
@@ -932,6 +950,8 @@ int main(int argc, char **argv) {
               }
               r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data() + base, po, pc.n, paired ? 1 : 0, b->hits.data() + lo,
                                                    b->vrec.data() + lo, pc.text.data(), stride);
+              // (the device counters are zeroed per launch: the flags of every piece count, not only the last one's)
+              { kaiju_gpu_stats ps; if (r == 0 && kaiju_gpu_get_stats(ctx[k], &ps) == 0) piece_error_flags |= ps.error_flags; }
               lo = hi;
             }
           } else if (xmode) {
@@ -945,7 +965,7 @@ int main(int argc, char **argv) {
           // reads for which a capacity bound of the kernels was exceeded (KAIJU_HIT_INEXACT, kaiju_gpu_stats.error_flags)
           {
             kaiju_gpu_stats st;
-            if (kaiju_gpu_get_stats(ctx[k], &st) == 0 && st.error_flags) inexact_batches++;
+            if ((kaiju_gpu_get_stats(ctx[k], &st) == 0 && st.error_flags) || piece_error_flags) inexact_batches++;
             uint64_t ni = 0;
             if (!b->hits.empty()) { for (uint32_t q = 0; q < n; q++) ni += (b->hits[q].flags & KAIJU_HIT_INEXACT) ? 1 : 0; }
             else for (uint32_t q = 0; q < n; q++) ni += (b->compact[q].info & KAIJU_HIT_INEXACT) ? 1 : 0;
@@ -1089,7 +1109,9 @@ int main(int argc, char **argv) {
             g_ns_format.load() * 1e-9, g_ns_write.load() * 1e-9);
   if (loader.joinable()) loader.join();       // (an input without reads: the verdict on index and nodes.dmp is still due;
                                               //  joined BEFORE any return: leaving main with a joinable thread is std::terminate)
-  if (getenv("KAIJU_GPU_TEST_INEXACT")) inexact_reads++;     // (tests: the exit path below without a read that overflows anything)
+#ifdef KAIJU_CLI_TEST_HOOKS
+  if (getenv("KAIJU_GPU_TEST_INEXACT")) inexact_reads++;     // (test build only: the exit path below without a read that overflows anything)
+#endif
   if (inexact_batches.load() || inexact_reads.load()) {
     // the reference has no such bounds: say so instead of printing lines that may differ from its output silently
     fprintf(stderr, "%s: a capacity bound of the GPU kernels was exceeded (%llu reads flagged; %llu batches in which the exact pass for "

@@ -556,7 +556,7 @@ int PackedIndex::read_image(const char *path, std::string &msg, bool lazy_big) {
 // kernels: k_suffix_walk, k_text_build): every row's (sequence, offset) by get_suffix, the sequences' lengths from the rows
 // of their terminator suffixes, sequence s (in the numbering of the samples) at text[off[s]] = 0, text[off[s] + 1 ..] = residues.
 void PackedIndex::build_text() {
-  sa_full.clear(); text.clear(); row_seq.clear(); seq_off.clear();
+  sa_full.clear(); text.clear(); row_seq.clear();
   if (wide || sa_pos.empty() || blocks64.empty() || (warnings & KAIJU_IDX_WARN_SA_SHORT) || bwtlen + nseq + 2 * kTextPad >= 0xffffffffull) return;
   const DevIndex d = host_view();
   BigVec<uint32_t> rs((size_t)bwtlen), rp((size_t)bwtlen);
@@ -585,8 +585,6 @@ void PackedIndex::build_text() {
     }
   });
   row_seq.swap(rs);
-  seq_off.resize(nseq);
-  for (uint32_t q = 0; q < nseq; q++) seq_off[q] = (uint32_t)off[q];
 }
 
 int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::string &msg) {
@@ -621,7 +619,6 @@ DevIndex PackedIndex::host_view() const {
   d.sa_full = sa_full.empty() ? nullptr : sa_full.data();
   d.text = text.empty() ? nullptr : text.data();
   d.row_seq = row_seq.empty() ? nullptr : row_seq.data();
-  d.seq_off = seq_off.empty() ? nullptr : seq_off.data();
   return d;
 }
 

@@ -89,7 +89,7 @@ struct PackedIndex {
   BigVec<uint32_t> sa_pos;        // offset (within its sequence) of every sampled row: what the text builder needs besides sa_iseq
                                   // (narrow indexes; empty where an offset does not fit 32 bits)
   // text verification (DevIndex::sa_full / text), built on the HOST for the test emulation only - the device builds its own
-  BigVec<uint32_t> sa_full, row_seq, seq_off;
+  BigVec<uint32_t> sa_full, row_seq;
   BigVec<uint8_t> text;
   void build_text();                // fills sa_full / text (call after build / read_image); leaves them empty if not applicable
   std::vector<uint64_t> seq_taxid;

@@ -100,18 +100,7 @@ struct DevIndex {
   const uint8_t *text;       // 64 zero bytes, then per sequence (in the order of the sampled sequence numbers) 0 + its residues
   const uint32_t *row_seq;   // [bwtlen] the sequence the suffix of row r lies in, as get_suffix finds it by walking to a sampled row
                              // (built along with sa_full): k_mem_locate reads an id with two loads instead of walking; nullptr = walk
-  const uint32_t *seq_off;   // [nseq] position in text[] of the 0 byte in front of sequence q (ascending): the sequence of a text
-                             // position (Greedy matches that were grown along the text carry a position, not a row)
 };
-// the sequence whose residues hold text position g (off[q] < g <= off[q] + its length): the last q with seq_off[q] < g
-KJ_HD uint32_t seq_of_textpos(const DevIndex &ix, uint32_t g) {
-  uint32_t lo = 0, hi = ix.nseq;                 // first q with seq_off[q] >= g
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (ix.seq_off[mid] < g) lo = mid + 1; else hi = mid;
-  }
-  return lo - 1u;                                // (g lies behind the 0 byte of sequence 0: lo >= 1)
-}
 constexpr uint32_t kTextPad = 64;            // zero bytes in front of the first sequence (a text window never starts below 0)
 constexpr int kTextMinLeft = 3;              // letters left in front of the match for the text comparison to be worth its two loads
 constexpr int kTextTrigLen = 9;              // ... and the match at least this long: intervals shrink to one row at six to eight letters

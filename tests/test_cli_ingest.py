@@ -238,3 +238,18 @@ def test_kaijup_names_and_u_line_decision(tmp_path):
     r = subprocess.run([CLI, "-p", "-t", "-", "-f", "-", "-i", os.path.join(util.GOLD, "prot.fa"), "-j", os.path.join(util.GOLD, "prot.fa")],
                        env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1"), capture_output=True)
     assert r.returncode != 0 and b"Protein input only supports one input file" in r.stderr
+
+
+def test_device_list_is_validated(tmp_path):
+    """KAIJU_GPU_DEVICES: every entry a device number, none twice - "a,b" or "0,,1" must not quietly become GPU 0 more than once
+    (checked before anything is loaded; with KAIJU_GPU_PARSE_ONLY no GPU is asked how many devices exist)"""
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(b"@r0\nACGTACGTACGTACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIIII\n")
+    base = [CLI, "-t", "/dev/null", "-f", "/dev/null", "-i", str(fq)]
+    for bad, msg in (("a,b", b"not a list"), ("0,,1", b"not a list"), ("0,1,", b"not a list"), ("0,1,0", b"listed twice"), ("-1", b"no such device")):
+        r = subprocess.run(base, env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1", KAIJU_GPU_DEVICES=bad), capture_output=True)
+        assert r.returncode != 0 and msg in r.stderr, (bad, r.stderr)
+    r = subprocess.run(base, env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1", KAIJU_GPU_DEVICES="0,3,1"), capture_output=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base, env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1", KAIJU_GPU_DEVICES="0,0", KAIJU_GPU_DEVICES_ALLOW_REPEAT="1"), capture_output=True)
+    assert r.returncode == 0, r.stderr

@@ -110,9 +110,17 @@ def test_kaijux(gpu_lib, golden, tmp_path):
 def test_cli_exit_status_of_a_capacity_error(gpu_lib, golden, tmp_path):
     """a batch in which a device-side capacity bound was exceeded ends the program with status 3 (not with an abort:
     the index loader thread is joined before that return), status 0 under KAIJU_GPU_ALLOW_INEXACT"""
-    cmd = [build.build_cli(), "-t", golden.nodes, "-f", golden.fmi, "-o", str(tmp_path / "x.tsv"), "-i",
+    # (the switch that fakes an inexact read exists in a test build of the program only: -DKAIJU_CLI_TEST_HOOKS)
+    build.build_cli()
+    exe = str(tmp_path / "kaiju_testhooks")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DKAIJU_CLI_TEST_HOOKS", "-o", exe, build.CLI_SRC, "-L" + build.HERE, "-lkaiju_gpu", "-lz",
+                    "-lpthread", "-Wl,-rpath," + build.HERE], check=True)
+    cmd = [exe, "-t", golden.nodes, "-f", golden.fmi, "-o", str(tmp_path / "x.tsv"), "-i",
            os.path.join(golden.dir, "reads.fq"), "-a", "mem"]
     env = dict(os.environ, KAIJU_GPU_TEST_INEXACT="1")
+    # the shipped program ignores the switch
+    r = subprocess.run([build.CLI] + cmd[1:], env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0
     r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
     assert r.returncode == 3 and b"capacity bound" in r.stderr
     r = subprocess.run(cmd, env=dict(env, KAIJU_GPU_ALLOW_INEXACT="1"), stderr=subprocess.PIPE)
@@ -153,6 +161,10 @@ def test_cli_blocks_over_several_gpus(gpu_lib, golden, tmp_path, monkeypatch):
     context b mod (2 x GPUs), the lines come out in input order.  On a box with one GPU the list names it twice - two replicas,
     four contexts: the plumbing of an 8-GPU node - and small blocks make sure every context gets work."""
     monkeypatch.setenv("KAIJU_GPU_DEVICES", "0,0")
+    r = subprocess.run([build.build_cli(), "-t", golden.nodes, "-f", golden.fmi, "-o", str(tmp_path / "no.tsv"), "-i",
+                        os.path.join(golden.dir, "reads.fq")], stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"listed twice" in r.stderr            # (a device named twice is refused unless a test asks for it)
+    monkeypatch.setenv("KAIJU_GPU_DEVICES_ALLOW_REPEAT", "1")
     monkeypatch.setenv("KAIJU_GPU_BATCH", "50")
     for mode in ("mem", "greedy"):
         out = run_cli(tmp_path, golden, ["-i", os.path.join(golden.dir, "reads.fq"), "-a", mode], f"multi_{mode}.tsv")

@@ -9,8 +9,7 @@
 #   stats            rocprofv3 --kernel-trace --stats of the headline leg             -> kernel_stats.csv
 #   stats_greedy     ... of --mode greedy                                             -> kernel_stats_greedy.csv
 #   pmc              PMC passes of the search kernels (tests/tools/pmc_bench.sh) + profiles/traffic.json
-#   refseq_ref       BASELINE configs[3] at its named scale (100 M proteins, 28 G rows; real sort): bench.py --image --paired
-#   refseq           BASELINE configs[4] class (200 M proteins, 56 G rows): one MEM leg on one GPU
+#   refseq_ref       BASELINE configs[3] at its named scale (28 G rows: 14.3 M proteins x 7): bench.py --image --paired
 #   py:<script>      python <script> ("," stands for a blank)                         -> py_<n>.log
 #   sh:<script>      bash <script>                                                    -> sh_<n>.log
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -40,15 +39,30 @@ for task in "$@"; do
     pmc)
       bash tests/tools/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log
       python tests/tools/pmc_bench_collect.py $O/pmc profiles/traffic.json $O/pmc_raw > $O/pmc_collect.log 2>&1; cp profiles/traffic.json profiles/traffic_all_kernels.json $O/ 2>/dev/null; tail -3 $O/pmc_collect.log ;;
-    refseq_ref|refseq)
-      # the database, its .fmi and the device image live in /dev/shm (the box has 3 TB of memory, / only 79 GB)
+    refseq_ref)
+      # BASELINE configs[3]: refseq_ref class, 28 G rows.  The box's cgroup allows 300 GiB of memory INCLUDING /dev/shm (the host
+      # has 3 TB, / only 79 GB): a real sort of 28 G suffixes (224 GB of 64-bit positions) does not fit, so the index is the one of
+      # a 4.0 G-row database (14.3 M proteins, sorted for real) with every protein seven times (kaiju_build_fmi_replicated);
+      # a refseq-class index of 58 G rows (configs[4]: .fmi 122 GB + image 150 GB) cannot be staged on this box at all.
+      # A watchdog ends the task before the cgroup would (a box driven out of memory is a strike).
       W=/dev/shm/kaiju_big_$task; mkdir -p $W
-      if [ "$task" = refseq_ref ]; then NSEQ=100000001; ARGS="--paired --reads 5000000 --steps 10 --legs greedy --leg-steps 2 --cpu-sample 200000 --cpu-sample-legs 100000"
-      else NSEQ=200000001; ARGS="--reads 10000000 --steps 3 --legs paired --leg-steps 1 --cpu-sample 200000 --cpu-sample-legs 100000"; fi
-      ( time KAIJU_GPU_LOAD_TIMES=1 timeout ${LEASE_BIG_TIMEOUT:-1700} python bench.py --work $W --nseq $NSEQ --image --warmup 1 --no-ref-ops $ARGS ) > $O/bench_$task.json 2> $O/bench_$task.err
+      NSEQ=14300001; ARGS="--copies 7 --paired --reads 5000000 --steps 10 --legs greedy --leg-steps 2 --cpu-sample 200000 --cpu-sample-legs 100000"
+      # the bench runs in a process group of its own, so that the watchdog can end exactly that group
+      setsid bash -c "KAIJU_GPU_LOAD_TIMES=1 exec timeout ${LEASE_BIG_TIMEOUT:-1700} python bench.py --work $W --nseq $NSEQ --image --warmup 1 --no-ref-ops $ARGS > $O/bench_$task.json 2> $O/bench_$task.err" &
+      BP=$!
+      ( while sleep 2; do
+          kill -0 $BP 2>/dev/null || break
+          cur=$(cat /sys/fs/cgroup/memory.current 2>/dev/null || echo 0)
+          echo "$(date +%s) $cur" >> $O/memory_$task.txt
+          if [ "$cur" -gt 285000000000 ]; then echo "[lease] memory watchdog: $cur bytes - ending the task" >> $O/bench_$task.err; kill -KILL -- -$BP; rm -rf $W; break; fi
+        done ) &
+      WD=$!
+      wait $BP
       echo "[lease] $task rc=$?"; grep -v "^\[kaiju_gpu pack\]" $O/bench_$task.err | tail -40; ls -la $W > $O/files_$task.txt; df -h /dev/shm >> $O/files_$task.txt; free -g >> $O/files_$task.txt
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$task -o s -- python $GRAFT_REPO_ROOT/bench.py --work $W --nseq $NSEQ --image --no-cpu-baseline --legs "" --steps 3 --warmup 1 $(echo $ARGS | sed 's/--steps [0-9]*//; s/--legs [a-z]*//') > $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.err )
       cp $O/stats_$task/s_kernel_stats.csv $O/kernel_stats_$task.csv 2>/dev/null; rm -rf $O/stats_$task; head -6 $O/kernel_stats_$task.csv
+      kill $WD 2>/dev/null
+      sort -k2 -n $O/memory_$task.txt | tail -1 > $O/memory_peak_$task.txt; rm -f $O/memory_$task.txt
       rm -rf $W ;;
     py:*)
       args=$(echo "${task#py:}" | tr ',' ' ')

@@ -10,7 +10,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 V=$R/kaiju_amd/variants
 SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-gpu-rdc -Wno-unused-result -w"
-declare -A DEF=( [cur]="" [prof]="-DKJ_PROF" [stats]="-DKJ_STATS" [ovf]="-DKJ_OVF_STATS" [norule]="-DKJ_NO_SPAN_RULE -DKJ_NO_PROBE" [noprobe]="-DKJ_NO_PROBE" )
+declare -A DEF=( [cur]="" [prof]="-DKJ_PROF" [stats]="-DKJ_STATS" [ovf]="-DKJ_OVF_STATS" [norule]="-DKJ_NO_SPAN_RULE -DKJ_NO_PROBE" [noprobe]="-DKJ_NO_PROBE" [notext]="-DKJ_G_NO_TEXT" )
 LIST=${VARIANTS:-cur prof}
 if [ "$1" = build ]; then
   mkdir -p $V
@@ -25,6 +25,8 @@ mkdir -p $OUT
 for v in $LIST; do
   lib=$V/libkaiju_gpu_$v.so
   [ -f $lib ] || { echo "$v: not built (mem_variants.sh build)"; continue; }
-  KAIJU_GPU_LIB=$lib python $R/tests/tools/prof_run.py /tmp/kjw $MODE 1 3 $N > $OUT/$v.txt 2>&1
+  # (the section profiler's build has no counting instantiation worth running: its counting pass is skipped)
+  case $v in *prof*) CNT= ;; *) CNT=$PROF_RUN_COUNTS ;; esac
+  PROF_RUN_COUNTS=$CNT KAIJU_GPU_LIB=$lib python $R/tests/tools/prof_run.py /tmp/kjw $MODE 1 3 $N > $OUT/$v.txt 2>&1
   echo "== $v"; grep -E "search|checksum" $OUT/$v.txt | tail -3
 done
