@@ -115,7 +115,7 @@ def reference_ops(W, fmi, reads_sample, mode, seg, paired, Lm):
             "sample": k, "oracle_reads_per_s": k / max(t, 1e-9)}
 
 
-def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample):
+def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample, tag_suffix=""):
     """the unmodified reference on `sample` of the reads: (baseline dict, per-read (classified, taxon) arrays)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
@@ -124,7 +124,7 @@ def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample):
     import pandas as pd
     cores = os.cpu_count() or 1
     s = min(sample, len(reads))
-    tag = f"{mode}{'_pe' if paired else ''}"
+    tag = f"{mode}{'_pe' if paired else ''}{tag_suffix}"
     files = [f"{W}/cpu_{tag}_1.fq"] + ([f"{W}/cpu_{tag}_2.fq"] if paired else [])
     one = [f"{W}/cpu_{tag}_one_1.fq"] + ([f"{W}/cpu_{tag}_one_2.fq"] if paired else [])
     for k, (fn, fo) in enumerate(zip(files, one)):
@@ -518,8 +518,12 @@ def main():
                     help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")
     ap.add_argument("--no-seg", action="store_true")
     ap.add_argument("--paired", action="store_true", help="headline leg on 2 x 150-bp pairs instead of single reads")
-    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host"),
-                    help="further legs in the same line: greedy, paired, host (comma separated; '' = none)")
+    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host,hard"),
+                    help="further legs in the same line: greedy, paired, host, hard (comma separated; '' = none).  hard: MEM and Greedy on "
+                         "a database that is NOT i.i.d. (synth.make_db_hard: families of 50-500 near-identical proteins, low-complexity "
+                         "inserts; reads with Ns) - retries, inexact reads and the rate next to the i.i.d. legs")
+    ap.add_argument("--hard-nseq", type=int, default=200_001)
+    ap.add_argument("--hard-reads", type=int, default=2_000_000)
     ap.add_argument("--leg-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
@@ -694,6 +698,30 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(rank, "host_buffers leg failed:", repr(e))
 
+    # ---------------- the hostile leg: a database that is not i.i.d. (its own index next to the benchmark's) ----------------
+    hard = None
+    if "hard" in legs_wanted and world == 1 and not big_db and copies == 1:
+        try:
+            t1 = time.time()
+            hdb = synth.make_db_hard(nseq=args.hard_nseq, seed=4321, leaves=leaves)
+            hfmi = f"{W}/db_hard_{args.hard_nseq}.fmi"
+            if not os.path.exists(hfmi):
+                synth.write_fasta(hdb, f"{W}/db_hard_{args.hard_nseq}.faa")
+                mkfmi.build_fmi(f"{W}/db_hard_{args.hard_nseq}.faa", hfmi + ".tmp", threads=0, exponent=3)
+                os.replace(hfmi + ".tmp", hfmi)
+            hindex = api.Index(hfmi, device=local_rank)
+            hreads = synth.sprinkle_n(synth.make_reads(hdb, args.hard_reads, seed=779))
+            log(rank, f"hard database {hdb.nseq} seqs / {hdb.total_aa} aa, index {hindex.footprint.total/1e9:.2f} GB in HBM ({time.time()-t1:.1f}s)")
+            hard = {"db": hdb, "fmi": hfmi, "reads": hreads, "index": hindex, "legs": {}}
+            for nm, mode in (("hard", "mem"), ("hard_greedy", "greedy")):
+                leg = Leg(nm, mode, False, hreads, Lm, hindex, dtax, dev, rank, world, seg, args.chunk, args.contexts)
+                leg.run(args.leg_steps, 1)
+                log(rank, f"leg {nm}: {leg.n * args.leg_steps / leg.elapsed / 1e6:.1f} M reads/s, {leg.retries / max(args.leg_steps, 1):.0f} reads per step in the retry pass")
+                hard["legs"][nm] = leg
+        except Exception as e:  # noqa: BLE001
+            log(rank, "hard leg failed:", repr(e))
+            hard = None
+
     # N > 1: a sample of EVERY rank's reads and of the records its timed kernels wrote goes to rank 0, which checks each against
     # the reference binary (an N-GPU line must not state a rate with nothing looking at the gathered records)
     rank_samples = None
@@ -707,7 +735,7 @@ def main():
         return
 
     # ---------------- accounting legs on the host: reference baseline + parity, reference op counts ----------------
-    def cpu_leg(leg, rd, sample, oracle_sample):
+    def cpu_leg(leg, rd, sample, oracle_sample, fmi=fmi, tag_suffix=""):
         out = {"ref_ops": None, "baseline": None, "parity": None}
         if args.no_cpu_baseline or world != 1:
             return out
@@ -717,7 +745,7 @@ def main():
         except Exception as e:  # noqa: BLE001 - the accounting legs must never kill the measurement
             log(rank, f"reference op counts ({leg.name}) failed:", repr(e))
         try:
-            bl, ref = run_reference(W, fmi, nodes, rd, Lm, leg.paired, leg.mode, seg, sample)
+            bl, ref = run_reference(W, fmi, nodes, rd, Lm, leg.paired, leg.mode, seg, sample, tag_suffix)
             out["baseline"] = bl
             if ref is not None:
                 k = len(ref[0])
@@ -737,6 +765,9 @@ def main():
         if nm in extra:
             acc[nm] = cpu_leg(extra[nm], keep[nm][1], args.cpu_sample_legs, 10000)
 
+    if hard is not None:
+        for nm, leg in hard["legs"].items():
+            acc[nm] = cpu_leg(leg, hard["reads"], min(args.cpu_sample_legs, 200_000), 5000, fmi=hard["fmi"], tag_suffix="_hard")
     per_rank_parity = None
     if rank_samples is not None:
         rds, recs, k = rank_samples
@@ -796,6 +827,21 @@ def main():
                                                extra[nm].bounds[0][1] - extra[nm].bounds[0][0]), db.nseq)
             lr["workload"] = ("the same index and reads, kaiju -a greedy -e 3 (BASELINE configs[2])" if nm == "greedy" else
                               f"the same index, {extra[nm].n} synthetic 2x{Lm}-bp pairs per GPU per step, kaiju -a mem (shape of BASELINE configs[3])")
+            if acc[nm]["baseline"] is not None:
+                lr["cpu_baseline"] = acc[nm]["baseline"]
+            if acc[nm]["parity"] is not None:
+                parity[nm] = acc[nm]["parity"]
+            result[nm] = lr
+    if hard is not None:
+        for nm, leg in hard["legs"].items():
+            lr = leg.result(world, acc[nm]["ref_ops"], None, hard["db"].nseq)
+            rec = np.frombuffer(leg.timed_compact.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
+            lr["workload"] = (f"NOT i.i.d.: {hard['db'].nseq} proteins / {hard['db'].total_aa} aa in families of 50-500 near-identical members "
+                              f"(0.5-3 % substitutions), low-complexity inserts in 5 % of them; {leg.n} 150-bp reads per step, 5 % of them with "
+                              f"1-4 Ns; kaiju -a {leg.mode}")
+            lr["inexact_reads_per_step"] = int((rec["info"] >> 31).sum())
+            lr["id_cap_reads_per_step"] = int(((rec["info"] >> 8) & 1).sum())
+            lr["fraction_reads_with_hit"] = round(float(((rec["info"] & 0xff) > 0).mean()), 4)
             if acc[nm]["baseline"] is not None:
                 lr["cpu_baseline"] = acc[nm]["baseline"]
             if acc[nm]["parity"] is not None:

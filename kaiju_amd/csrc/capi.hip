@@ -239,6 +239,7 @@ k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   __shared__ __attribute__((aligned(16))) uint8_t s_frag[kSegStage];
   __shared__ int32_t s_work[4 * kSegMaxRegions];
   __shared__ uint8_t s_cls[kSegStage];
+  __shared__ ulonglong2 s_pre[kSegPacked + 1];               // prefix letter counts of the fragment (s_Trim's windows: seg_trim)
   if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
   if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
   __syncthreads();
@@ -246,7 +247,7 @@ k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   const CoopWave coop;
   const uint32_t n = min(*sq.count, sq.cap);
   for (uint32_t s = blockIdx.x; s < n; s += gridDim.x)       // trip count is uniform over the block
-    seg_compute(cx, coop, b, p, sq, s, s_frag, kSegStage, s_work, s_cls, [] { __syncthreads(); });
+    seg_compute(cx, coop, b, p, sq, s, s_frag, kSegStage, s_work, s_cls, [] { __syncthreads(); }, s_pre);
 }
 
 // MEM: apply the SEG records to the fragment lists

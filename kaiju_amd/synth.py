@@ -187,6 +187,72 @@ def make_db_large(nseq, seed=12345, leaves=None, min_len=30, max_len=3000, gamma
     return SynthDB(codes=codes, offsets=offsets, taxids=taxids, names=names)
 
 
+def make_db_hard(nseq=200001, seed=4321, leaves=None, fam_lo=50, fam_hi=500, frac_lowcomplexity=0.05,
+                 min_len=30, max_len=1500, gamma_shape=2.0, gamma_scale=140.0):
+    """A database that is NOT i.i.d. (bench.py's `hard` leg): protein FAMILIES of fam_lo .. fam_hi near-identical members (0.5 - 3 %
+    substitutions against the family's founder, so that exact matches have intervals of dozens to hundreds of rows and the
+    members' taxa differ), and low-complexity inserts (runs of one to three letters, 10 - 40 residues) in frac_lowcomplexity of
+    the sequences - what the skip rules, the queue / match-list capacities and the SEG region bound of the kernels were NOT
+    tuned on.  Same return type as make_db()."""
+    rng = np.random.default_rng(seed)
+    if leaves is None:
+        _, leaves = make_taxonomy()
+    sizes = []
+    while sum(sizes) < nseq:
+        sizes.append(int(rng.integers(fam_lo, fam_hi + 1)))
+    sizes[-1] -= sum(sizes) - nseq
+    if sizes[-1] <= 0:
+        sizes.pop()
+        sizes[-1] += nseq - sum(sizes)
+    seqs, taxids = [], []
+    for fam, size in enumerate(sizes):
+        L = int(np.clip(rng.gamma(gamma_shape, gamma_scale), min_len, max_len))
+        founder = rng.choice(20, size=L, p=_BG).astype(np.uint8)
+        members = np.tile(founder, (size, 1))
+        rates = rng.choice(np.array([0.005, 0.01, 0.03]), size=size)
+        mut = rng.random((size, L)) < rates[:, None]
+        mut[0] = False
+        members[mut] = rng.integers(0, 20, size=int(mut.sum()), dtype=np.uint8)
+        genus = leaves[rng.integers(0, len(leaves))]
+        tx = genus - (genus % 10) + rng.integers(0, 10, size=size)          # a family mostly stays in one genus ...
+        far = rng.random(size) < 0.1
+        tx[far] = leaves[rng.integers(0, len(leaves), size=int(far.sum()))]  # ... with a tenth of its members elsewhere
+        lc = rng.random(size) < frac_lowcomplexity
+        for m in range(size):
+            row = members[m]
+            if lc[m]:
+                k = int(rng.integers(1, 4))
+                unit = rng.integers(0, 20, size=k, dtype=np.uint8)
+                ins = np.tile(unit, int(rng.integers(10, 41)) // k + 1)[: int(rng.integers(10, 41))]
+                at = int(rng.integers(0, L + 1))
+                row = np.concatenate([row[:at], ins, row[at:]])
+            seqs.append(row)
+        taxids.append(tx)
+    lens = np.array([len(x) for x in seqs], dtype=np.int64)
+    # steer clear of the reference's two latent index bugs as make_db() does (nseq % 8 != 0 is the caller's choice of nseq)
+    bwtlen = int(lens.sum()) + nseq
+    while bwtlen % 65536 >= 65408 or bwtlen % 65536 == 0:
+        seqs[-1] = np.concatenate([seqs[-1], rng.integers(0, 20, size=1, dtype=np.uint8)])
+        lens[-1] += 1
+        bwtlen += 1
+    offsets = np.zeros(nseq + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    taxids = np.concatenate(taxids).astype(np.int64)
+    return SynthDB(codes=np.concatenate(seqs), offsets=offsets, taxids=taxids, names=[f"WP{n:09d}.1_{t}" for n, t in enumerate(taxids)])
+
+
+def sprinkle_n(reads: np.ndarray, seed=99, frac_reads=0.05, max_n=4):
+    """reads with ambiguous bases: frac_reads of the rows get 1 .. max_n letters replaced by 'N' (in place; returns reads)"""
+    rng = np.random.default_rng(seed)
+    n, L = reads.shape
+    sel = np.nonzero(rng.random(n) < frac_reads)[0]
+    cnt = rng.integers(1, max_n + 1, size=len(sel))
+    for k in range(max_n):
+        rows = sel[cnt > k]
+        reads[rows, rng.integers(0, L, size=len(rows))] = ord("N")
+    return reads
+
+
 class _LazyNames:
     """names[i] of a large database without materialising millions of Python strings"""
 

@@ -503,6 +503,10 @@ static void init_lnfact(void) {
   }
   lnfact_ready = 1;
 }
+/* the table as this restatement derives it (tests/test_seg_tables_pin.py compares it with the reference's printed table) */
+int ko_lnfact_n(void) { return LNFACT_N; }
+double ko_lnfact(int n) { init_lnfact(); return (n >= 0 && n < LNFACT_N) ? lnfact_tab[n] : -1.0; }
+
 /* s_lnfact, blast_seg.c:1850-1855 */
 static double s_lnfact(int n) {
   if (n < LNFACT_N) return lnfact_tab[n];
