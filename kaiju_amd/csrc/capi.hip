@@ -301,11 +301,22 @@ k_mem_locate(DevIndex ix, Params p, Batch b) {
   if (r >= b.n_reads) return;
   mem_locate_read<false>(ix, p, b.hits + r);
 }
+// Indexes without the row -> sequence table (wide ones; narrow ones that had no room for the text arrays): a TEAM of kLocTeam
+// lanes per read walks the rows of a match side by side (mem_locate_read_team)
+constexpr int kLocTeam = 8;
 __global__ void __launch_bounds__(256)
 k_mem_locate_wide(DevIndex ix, Params p, Batch b) {
-  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t r = (blockIdx.x * 256 + threadIdx.x) / kLocTeam;
   if (r >= b.n_reads) return;
-  mem_locate_read<true>(ix, p, b.hits + r);
+  TeamWave<kLocTeam> team;
+  mem_locate_read_team<true, kLocTeam>(ix, p, b.hits + r, team);
+}
+__global__ void __launch_bounds__(256)
+k_mem_locate_team(DevIndex ix, Params p, Batch b) {
+  const uint32_t r = (blockIdx.x * 256 + threadIdx.x) / kLocTeam;
+  if (r >= b.n_reads) return;
+  TeamWave<kLocTeam> team;
+  mem_locate_read_team<false, kLocTeam>(ix, p, b.hits + r, team);
 }
 // the same kernel under a second name for the second search of the lazy SEG flow (the few reads whose fragments SEG had
 // to cut), so that a kernel trace lists the full-size launches of k_mem by themselves
@@ -1361,6 +1372,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
+  const dim3 grid_team((unsigned)(((uint64_t)n * kLocTeam + 255) / 256));          // k_mem_locate_wide / _team: kLocTeam lanes per read
   // which stage 1 / SEG flow: the fast stage 1 serves mates up to kS1MaxLen nucleotides; in MEM mode on the second-generation
   // lanes SEG is then looked at lazily (kj_core.h: kParamLazySeg), everywhere else stage 1 detects the SEG trigger itself
   const bool mem_narrow2 = ix->dev.blocks64 && ix->dev.kline && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
@@ -1502,8 +1514,9 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
       if (defer) {
-        if (mem_narrow2) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
-        else hipLaunchKernelGGL(k_mem_locate_wide, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        if (mem_narrow2 && ix->dev.row_seq) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        else if (mem_narrow2) hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
+        else hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
       }
       if (exact_pass) {
@@ -1579,8 +1592,9 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
       if (pg.flags & kParamDeferLocate) {
-        if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_reads, dim3(256), 0, s, ix->dev, p, b);
-        else hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
+        else if (ix->dev.row_seq) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        else hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
       }
       if (exact_pass) {

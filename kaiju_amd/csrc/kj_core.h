@@ -2764,6 +2764,101 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
 }
 
 
+// The same for a TEAM of T lanes per read (T a power of two, the lanes of a team next to each other in the wavefront): the rows
+// of a match are walked T at a time, one row per lane, and the team's first lane then takes their ids in row order - the
+// order, the duplicates and the 21-id cut of the sequential loop (:799-845).  On an index without the row -> sequence table
+// (wide indexes; narrow ones that had no room for it) a row costs a walk of up to 2^e dependent LF steps, and a read whose
+// matches hold seven rows costs seven walks one after the other: 18.5 ms per 5 M pairs on a 28 G-row index with every protein
+// seven times (profiles/r04_refseq_ref), a third of the step.  Team: how a lane learns what its team mates found -
+//   TeamWave<T> (device): shuffles;  TeamSerial<T> (host emulation): the T walks run one after the other into an array.
+template <int T>
+struct TeamSerial {
+  uint64_t vals[T];
+  template <class F> KJ_HD void compute(F &&f) { for (int tl = 0; tl < T; tl++) vals[tl] = f(tl); }
+  KJ_HD uint64_t get(int q) const { return vals[q]; }
+  KJ_HD bool leader() const { return true; }
+  KJ_HD bool from_leader(bool v) const { return v; }
+};
+#if defined(__HIPCC__)
+template <int T>
+struct TeamWave {
+  uint64_t mine;
+  template <class F> __device__ __forceinline__ void compute(F &&f) { mine = f((int)(threadIdx.x & (T - 1))); }
+  __device__ __forceinline__ uint64_t get(int q) const {
+    const int src = (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)) + q;
+    return (uint64_t)(uint32_t)__shfl((int)(uint32_t)mine, src, 64) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(mine >> 32), src, 64) << 32;
+  }
+  __device__ __forceinline__ bool leader() const { return (threadIdx.x & (T - 1)) == 0; }
+  __device__ __forceinline__ bool from_leader(bool v) const { return __shfl((int)v, (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)), 64) != 0; }
+};
+#endif
+template <bool WIDE, int T, class Team>
+KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, Team &team) {
+  typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
+  const uint32_t fl0 = hit->flags;                            // (every lane of the team reads the same record: team-uniform)
+  if (!(fl0 & kHitLocPending)) return;
+  const uint32_t nsi = hit->n_ids;
+  const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
+  const P check = (P)((1ull << ix.chpt_exp) - 1ull);
+  const RankBlock64 *const blk0 = ix.blocks64;
+  uint32_t nids = 0, flags = fl0 & ~kHitLocPending;           // (the leader's; a Greedy read may carry kHitSiCap already)
+  uint64_t id0 = 0;
+  auto add_tax = [&](uint64_t tax) {
+    bool dup = false;
+    if (nids >= 1 && tax == id0) dup = true;
+    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+  };
+  // the id of one row: ~0 = none (a name without a usable id, or a row beyond the samples, where the reference reads out of bounds)
+  auto walk = [&](P k) -> uint64_t {
+    for (;;) {
+      if ((k & check) == 0) {
+        const uint64_t sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+        if (sa_idx >= ix.n_sa) return ~0ull;
+        if constexpr (WIDE) { const uint32_t iseq = ix.sa_iseq[sa_idx]; return (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull; }
+        else return ix.sa_taxid[sa_idx];
+      }
+      const RankBlock64 &rb = blk0[k >> 6];
+      const uint32_t sft = (uint32_t)k & 63u;
+      const uint32_t c = (uint32_t)((rb.plane[0] >> sft) & 1ull) | (uint32_t)((rb.plane[1] >> sft) & 1ull) << 1 |
+                         (uint32_t)((rb.plane[2] >> sft) & 1ull) << 2 | (uint32_t)((rb.plane[3] >> sft) & 1ull) << 3 |
+                         (uint32_t)((rb.plane[4] >> sft) & 1ull) << 4;
+      if (c == 0) {
+        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+        const uint32_t iseq = (uint32_t)rank_term(ix, k);
+        return (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
+      }
+      const uint64_t ia = (c & 1u) ? 0ull : ~0ull, ib = (c & 2u) ? 0ull : ~0ull, ic = (c & 4u) ? 0ull : ~0ull,
+                     id = (c & 8u) ? 0ull : ~0ull, ie = (c & 16u) ? 0ull : ~0ull;
+      const uint64_t m = (rb.plane[0] ^ ia) & (rb.plane[1] ^ ib) & (rb.plane[2] ^ ic) & (rb.plane[3] ^ id) & (rb.plane[4] ^ ie);
+      uint64_t base = 0;
+      if constexpr (WIDE) base = ix.mb_base[(size_t)((uint64_t)k >> ix.mb_shift) * 20 + (c - 1u)];
+      k = (P)(base + rb.cnt[c - 1u] + popc64(m & ((1ull << sft) - 1ull)));
+    }
+  };
+  bool done = false;                                          // team-uniform
+  for (uint32_t s = 0; s < nsi && !done; s++) {
+    const P lo = WIDE ? (P)(e[s] & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)e[s];
+    const uint32_t len = WIDE ? (uint32_t)(e[s] >> kLocWideShift) : (uint32_t)(e[s] >> 32);
+    const P rowend = lo + (P)(int32_t)len;
+    for (P row0 = lo; row0 < rowend && !done; row0 += (P)T) {
+      team.compute([&](int tl) -> uint64_t { const P row = row0 + (P)tl; return row < rowend ? walk(row) : ~0ull; });
+#pragma unroll
+      for (int q = 0; q < T; q++) {
+        const uint64_t tax = team.get(q);
+        if (team.leader() && !done && row0 + (P)q < rowend) {
+          if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; }     // :805-807, tested in front of every row
+          else if (tax != ~0ull) add_tax(tax);
+        }
+      }
+      done = team.from_leader(done);
+    }
+  }
+  if (!team.leader()) return;
+  for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;   // (the slots that held the matches and got no id)
+  hit->n_ids = nids; hit->flags = flags;
+}
+
 // ----------------------------------------------------------------------------
 // Greedy lane: classify_greedyblosum (ConsumerThread.cpp:424-541), maxMatches /
 // maxMatches_withStart (bwt.c:261-336), addAllMismatchVariantsAtPosSI (:346-395),

@@ -320,7 +320,14 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   }
   // k_mem_locate (capi.hip): behind the main, the second and the retry search
   const bool locate_pass = true;
-  if (locate_pass) for (uint32_t r = 0; r < n; r++) { if (d.mb_base) mem_locate_read<true>(d, p, &hits[r]); else mem_locate_read<false>(d, p, &hits[r]); }
+  // (indexes without the row -> sequence table are located by teams of lanes on the device: k_mem_locate_wide / _team; here a
+  //  team of four whose walks run one after the other, KAIJU_EMU_LOCATE_SERIAL=1: the one-lane function)
+  if (locate_pass) for (uint32_t r = 0; r < n; r++) {
+    const bool serial = getenv("KAIJU_EMU_LOCATE_SERIAL") != nullptr;
+    if (d.mb_base) { if (serial) mem_locate_read<true>(d, p, &hits[r]); else { TeamSerial<4> tm; mem_locate_read_team<true, 4>(d, p, &hits[r], tm); } }
+    else if (d.row_seq || serial) mem_locate_read<false>(d, p, &hits[r]);
+    else { TeamSerial<4> tm; mem_locate_read_team<false, 4>(d, p, &hits[r], tm); }
+  }
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
   if (p.seg && n > 0) {
     std::vector<uint32_t> redo;
