@@ -295,11 +295,21 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
   mem_lane2<false>(ix, p, b, wl, ls);
 }
 // the ids of the reads whose longest matches the lanes above left in their hit records (kParamDeferLocate): one lane per read
+// (narrow index with the row -> sequence table: an id is two loads.  Reads whose matches hold more than kLocDeferRows rows are
+//  listed - one atomic per wavefront - and located by teams, k_mem_locate_list)
+constexpr uint32_t kLocDeferRows = 8;
 __global__ void __launch_bounds__(256)
-k_mem_locate(DevIndex ix, Params p, Batch b) {
+k_mem_locate(DevIndex ix, Params p, Batch b, uint32_t *list, uint32_t *count) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= b.n_reads) return;
-  mem_locate_read<false>(ix, p, b.hits + r);
+  const bool defer = r < b.n_reads && !mem_locate_read<false>(ix, p, b.hits + r, list ? kLocDeferRows : 0u);
+  const uint64_t m = __ballot(defer);
+  if (m) {
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (defer) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+  }
 }
 // Indexes without the row -> sequence table (wide ones; narrow ones that had no room for the text arrays): a TEAM of kLocTeam
 // lanes per read walks the rows of a match side by side (mem_locate_read_team)
@@ -310,6 +320,14 @@ k_mem_locate_wide(DevIndex ix, Params p, Batch b) {
   if (r >= b.n_reads) return;
   TeamWave<kLocTeam> team;
   mem_locate_read_team<true, kLocTeam>(ix, p, b.hits + r, team);
+}
+__global__ void __launch_bounds__(256)
+k_mem_locate_list(DevIndex ix, Params p, Batch b, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count) {
+  const uint32_t n = *count, nteams = gridDim.x * (256 / kLocTeam);
+  for (uint32_t t = (blockIdx.x * 256 + threadIdx.x) / kLocTeam; t < n; t += nteams) {    // (team-uniform trip count)
+    TeamWave<kLocTeam> team;
+    mem_locate_read_team<false, kLocTeam>(ix, p, b.hits + list[t], team);
+  }
 }
 __global__ void __launch_bounds__(256)
 k_mem_locate_team(DevIndex ix, Params p, Batch b) {
@@ -542,12 +560,22 @@ k_kline_build(DevIndex ix, uint32_t k, uint64_t n_lines, uint8_t *__restrict__ l
 // terminator suffix (rows 0 .. nseq-1); k_text_build: row r's suffix lies at g = off[sequence] + 1 + offset, and the letter
 // in front of it is the row's BWT letter.
 __global__ void __launch_bounds__(256)
-k_suffix_walk(DevIndex ix, const uint32_t *__restrict__ smp_pos, uint32_t *__restrict__ row_seq, uint32_t *__restrict__ row_pos, uint32_t *bad) {
+k_suffix_walk(DevIndex ix, const uint32_t *__restrict__ smp_pos, uint32_t *__restrict__ row_seq, uint32_t *__restrict__ row_pos, uint32_t *bad,
+              uint32_t *__restrict__ beyond_rows) {
+  // bad[0]: a row could not be resolved; bad[1]: number of rows whose walk passed the missing sample of an index with the
+  // reference's short sample array (beyond_rows[0 .. kBeyondRowsMax): those rows - k_rows_beyond unsets their sequence)
   for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < ix.bwtlen; r += (uint64_t)gridDim.x * 256) {
     uint32_t sq = 0, ps = 0;
-    if (!suffix_of_row(ix, smp_pos, r, sq, ps) || sq >= ix.nseq) { atomicOr(bad, 1u); sq = 0; ps = 0; }
+    bool by = false;
+    if (!suffix_of_row(ix, smp_pos, r, sq, ps, &by) || sq >= ix.nseq) { atomicOr(bad, 1u); sq = 0; ps = 0; }
+    if (by) { const uint32_t at = atomicAdd(bad + 1, 1u); if (at < kBeyondRowsMax) beyond_rows[at] = (uint32_t)r; }
     row_seq[r] = sq; row_pos[r] = ps;
   }
+}
+__global__ void __launch_bounds__(256)
+k_rows_beyond(const uint32_t *__restrict__ beyond_rows, uint32_t n, uint32_t *__restrict__ row_seq) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x < n) row_seq[beyond_rows[x]] = 0xffffffffu;          // a locate of that row finds no sequence (the reference reads out of bounds there)
 }
 __global__ void __launch_bounds__(256)
 k_seq_lens(uint32_t nseq, const uint32_t *__restrict__ row_seq, const uint32_t *__restrict__ row_pos, uint32_t *__restrict__ len) {
@@ -943,27 +971,27 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t need_peak = pk.bwtlen * 13 + ((uint64_t)pk.nseq << 3) + (64u << 20) + (4ull << 30);   // 9 B per row kept + one temporary of 4 B per row + contexts
-    const bool want = !getenv("KAIJU_GPU_NO_TEXT") && !d.mb_base && d.blocks64 && PackedIndex::count(pk.sa_pos, pk.lazy.sa_pos) && !(pk.warnings & KAIJU_IDX_WARN_SA_SHORT) &&
+    const bool want = !getenv("KAIJU_GPU_NO_TEXT") && !d.mb_base && d.blocks64 && PackedIndex::count(pk.sa_pos, pk.lazy.sa_pos) &&
                       pk.bwtlen + pk.nseq + 4 * (uint64_t)kTextPad < 0xffffffffull && need_peak < free_b / 2;
     if (want) {
       const uint32_t *d_smp = nullptr;
       if ((rc = upload_arr(ix.get(), is, ipath, pk.sa_pos, pk.lazy.sa_pos, &d_smp))) return rc;
       void *smp_alloc = ix->allocs.back();
-      uint32_t *row_seq = nullptr, *row_pos = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bad = nullptr, *sa_full = nullptr;
+      uint32_t *row_seq = nullptr, *row_pos = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bad = nullptr, *sa_full = nullptr, *d_beyond = nullptr;
       uint8_t *text = nullptr;
       bool ok = hipMalloc((void **)&row_seq, pk.bwtlen * 4) == hipSuccess && hipMalloc((void **)&row_pos, pk.bwtlen * 4) == hipSuccess &&
                 hipMalloc((void **)&d_len, (size_t)pk.nseq * 4 + 16) == hipSuccess && hipMalloc((void **)&d_off, (size_t)pk.nseq * 4 + 16) == hipSuccess &&
-                hipMalloc((void **)&d_bad, 16) == hipSuccess;
+                hipMalloc((void **)&d_bad, 16) == hipSuccess && hipMalloc((void **)&d_beyond, (size_t)kBeyondRowsMax * 4) == hipSuccess;
       if (ok) {
         (void)hipMemset(d_bad, 0, 16);
         (void)hipMemset(d_len, 0, (size_t)pk.nseq * 4);
         const unsigned blocks = (unsigned)std::min<uint64_t>((pk.bwtlen + 255) / 256, 1u << 20);
-        hipLaunchKernelGGL(k_suffix_walk, dim3(blocks), dim3(256), 0, 0, d, d_smp, row_seq, row_pos, d_bad);
+        hipLaunchKernelGGL(k_suffix_walk, dim3(blocks), dim3(256), 0, 0, d, d_smp, row_seq, row_pos, d_bad, d_beyond);
         hipLaunchKernelGGL(k_seq_lens, dim3((pk.nseq + 255) / 256), dim3(256), 0, 0, pk.nseq, row_seq, row_pos, d_len);
         std::vector<uint32_t> len(pk.nseq), off(pk.nseq);
-        uint32_t bad = 0;
+        uint32_t bad[2] = {0, 0};                           // [1]: rows behind the missing sample of a KAIJU_IDX_WARN_SA_SHORT index
         ok = hipMemcpy(len.data(), d_len, (size_t)pk.nseq * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost) == hipSuccess && bad == 0;
+             hipMemcpy(bad, d_bad, 8, hipMemcpyDeviceToHost) == hipSuccess && bad[0] == 0 && bad[1] <= kBeyondRowsMax;
         uint64_t at = kTextPad;
         for (uint32_t q = 0; ok && q < pk.nseq; q++) { off[q] = (uint32_t)at; at += (uint64_t)len[q] + 1; if (at + kTextPad >= 0xffffffffull) ok = false; }
         text_bytes = at + 2 * kTextPad;
@@ -972,11 +1000,12 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         if (ok) {
           (void)hipMemset(text, 0, text_bytes);
           hipLaunchKernelGGL(k_text_build, dim3(blocks), dim3(256), 0, 0, d, row_seq, row_pos, d_off, sa_full, text);
+          if (bad[1]) hipLaunchKernelGGL(k_rows_beyond, dim3((bad[1] + 255) / 256), dim3(256), 0, 0, d_beyond, bad[1], row_seq);
           ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
         }
       }
       (void)hipGetLastError();
-      for (void *q : {(void *)row_pos, (void *)d_len, (void *)d_off, (void *)d_bad}) if (q) (void)hipFree(q);
+      for (void *q : {(void *)row_pos, (void *)d_len, (void *)d_off, (void *)d_bad, (void *)d_beyond}) if (q) (void)hipFree(q);
       if (!ok && row_seq) { (void)hipFree(row_seq); row_seq = nullptr; }     // (kept otherwise: DevIndex::row_seq)
       // (the sample offsets were only needed here)
       (void)hipFree(smp_alloc);
@@ -1211,7 +1240,7 @@ struct kaiju_gpu_ctx {
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
   bool defer_locate = true;        // KAIJU_GPU_MEM_LOCATE=inline: the MEM search lanes walk to the ids themselves
-  DevBuf seglist;
+  DevBuf seglist, loc_list;
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
   DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
@@ -1222,7 +1251,7 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist,
+    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist, &loc_list,
                      &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry,
                      &redo_bitmap, &redo_list, &redo_items, &redo_index, &redo_pool, &redo_work, &redo_cls};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
@@ -1352,6 +1381,8 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if ((rc = ensure(c->meta, (size_t)n * sizeof(ReadMeta) + 16))) return rc;
   if ((rc = ensure(c->counters, 4096))) return rc;     // [0, 256) counters, [512, ..) totals of the counting lanes
   if ((rc = ensure(c->retry_list, (size_t)n * 4 + 16))) return rc;
+  if ((rc = ensure(c->loc_list, (size_t)n * 4 + 16))) return rc;        // reads whose matches hold many rows: located by teams
+  uint32_t *loc_list = static_cast<uint32_t *>(c->loc_list.p);
   Batch b;
   b.seqs = static_cast<const uint8_t *>(d_seqs); b.off = d_off; b.n_reads = n; b.paired = paired ? 1 : 0;
   b.pep = static_cast<uint8_t *>(c->pep.p); b.frags = static_cast<Frag *>(c->frags.p);
@@ -1514,7 +1545,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
       if (defer) {
-        if (mem_narrow2 && ix->dev.row_seq) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        if (mem_narrow2 && ix->dev.row_seq) {
+          hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+          hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 16), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+        }
         else if (mem_narrow2) hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
         else hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
@@ -1593,7 +1627,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       KJ_HIP(hipGetLastError());
       if (pg.flags & kParamDeferLocate) {
         if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
-        else if (ix->dev.row_seq) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        else if (ix->dev.row_seq) {
+          hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+          hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 16), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+        }
         else hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
       }

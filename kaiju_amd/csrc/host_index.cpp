@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <time.h>
@@ -557,15 +558,23 @@ int PackedIndex::read_image(const char *path, std::string &msg, bool lazy_big) {
 // of their terminator suffixes, sequence s (in the numbering of the samples) at text[off[s]] = 0, text[off[s] + 1 ..] = residues.
 void PackedIndex::build_text() {
   sa_full.clear(); text.clear(); row_seq.clear();
-  if (wide || sa_pos.empty() || blocks64.empty() || (warnings & KAIJU_IDX_WARN_SA_SHORT) || bwtlen + nseq + 2 * kTextPad >= 0xffffffffull) return;
+  if (wide || sa_pos.empty() || blocks64.empty() || bwtlen + nseq + 2 * kTextPad >= 0xffffffffull) return;
   const DevIndex d = host_view();
   BigVec<uint32_t> rs((size_t)bwtlen), rp((size_t)bwtlen);
   std::atomic<bool> ok{true};
+  // (an index with the reference's short sample array, KAIJU_IDX_WARN_SA_SHORT: the handful of rows whose walk runs into the
+  //  missing sample are resolved through the next one; a locate of such a row stays undefined, i.e. skipped - see below)
+  std::mutex bm;
+  std::vector<uint64_t> beyond_rows;
   parallel_for((bwtlen + 65535) / 65536, [&](uint64_t chunk) {
     const uint64_t b = chunk * 65536, e = std::min<uint64_t>(bwtlen, b + 65536);
-    for (uint64_t r = b; r < e; r++) if (!suffix_of_row(d, sa_pos.data(), r, rs[(size_t)r], rp[(size_t)r])) ok = false;
+    for (uint64_t r = b; r < e; r++) {
+      bool by = false;
+      if (!suffix_of_row(d, sa_pos.data(), r, rs[(size_t)r], rp[(size_t)r], &by)) ok = false;
+      if (by) { std::lock_guard<std::mutex> lk(bm); beyond_rows.push_back(r); }
+    }
   });
-  if (!ok.load()) return;
+  if (!ok.load() || beyond_rows.size() > kBeyondRowsMax) return;
   std::vector<uint64_t> off((size_t)nseq + 1, 0);
   {
     std::vector<uint32_t> len(nseq, 0);
@@ -585,6 +594,7 @@ void PackedIndex::build_text() {
     }
   });
   row_seq.swap(rs);
+  for (uint64_t r : beyond_rows) row_seq[(size_t)r] = 0xffffffffu;        // located rows: no sequence (the reference reads out of bounds)
 }
 
 int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::string &msg) {

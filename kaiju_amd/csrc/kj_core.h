@@ -101,6 +101,7 @@ struct DevIndex {
   const uint32_t *row_seq;   // [bwtlen] the sequence the suffix of row r lies in, as get_suffix finds it by walking to a sampled row
                              // (built along with sa_full): k_mem_locate reads an id with two loads instead of walking; nullptr = walk
 };
+constexpr uint32_t kBeyondRowsMax = 4096;    // rows whose walk passes the missing sample of a KAIJU_IDX_WARN_SA_SHORT index (a few)
 constexpr uint32_t kTextPad = 64;            // zero bytes in front of the first sequence (a text window never starts below 0)
 constexpr int kTextMinLeft = 3;              // letters left in front of the match for the text comparison to be worth its two loads
 constexpr int kTextTrigLen = 9;              // ... and the match at least this long: intervals shrink to one row at six to eight letters
@@ -427,7 +428,10 @@ KJ_HD uint64_t rank_term(const DevIndex &ix, uint64_t k) {
 // offset of the suffix of row r.  smp_pos: the offset part of every sampled row (the sequence part is sa_iseq).  Rows below
 // nseq (the suffixes that consist of a terminator only - no search ever asks for them, the text builder does) take their first
 // LF step unconditionally.  Returns false where the reference would read beyond its sample array.
-KJ_HD bool suffix_of_row(const DevIndex &ix, const uint32_t *smp_pos, uint64_t r, uint32_t &iseq, uint32_t &pos) {
+// `beyond` (optional): an index whose header counts one sample too few (KAIJU_IDX_WARN_SA_SHORT: the reference reads out of
+// bounds at that row, its answer there is undefined) - the walk passes the missing sample as if the row were not sampled,
+// goes on to the next one and says so; without `beyond` such a row makes the function fail as before.
+KJ_HD bool suffix_of_row(const DevIndex &ix, const uint32_t *smp_pos, uint64_t r, uint32_t &iseq, uint32_t &pos, bool *beyond = nullptr) {
   const uint64_t check = (1ull << ix.chpt_exp) - 1ull;
   uint64_t k = r;
   uint32_t steps = 0;
@@ -435,9 +439,12 @@ KJ_HD bool suffix_of_row(const DevIndex &ix, const uint32_t *smp_pos, uint64_t r
   for (;;) {
     if (!first && (k & check) == 0) {
       const uint64_t q = (k >> ix.chpt_exp) - ix.sa_skip;
-      if (q >= ix.n_sa) return false;
-      iseq = ix.sa_iseq[q]; pos = smp_pos[q] + steps;
-      return true;
+      if (q < ix.n_sa) {
+        iseq = ix.sa_iseq[q]; pos = smp_pos[q] + steps;
+        return true;
+      }
+      if (!beyond) return false;
+      *beyond = true;
     }
     first = false;
     const uint32_t c = symbol_at(ix, k);
@@ -2694,13 +2701,20 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 // The ids of a read whose longest matches mem_lane2 left in its hit record (kHitLocPending): ids_from_SI for every match in
 // turn (ConsumerThread.cpp:799-845; get_suffix bwt.c:105-121, FMindexCurrent compactfmi.c:312-336) - the same steps as
 // BK_LOC_ROW / K_LF1 / K_LF2 / K_SA of the lane, one read per lane, narrow index.
+// defer_rows (0 = never): a read whose matches hold more rows than that is left as it is and false is returned - the caller
+// hands it to a team of lanes (mem_locate_read_team): families of near-identical proteins give intervals of hundreds of rows
+// of which the reference visits every one unless twenty-one taxa turn up (bench.py's `hard` leg)
 template <bool WIDE>
-KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
+KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32_t defer_rows = 0) {
   typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   const uint32_t fl0 = hit->flags;
-  if (!(fl0 & kHitLocPending)) return;
+  if (!(fl0 & kHitLocPending)) return true;
   const uint32_t nsi = hit->n_ids;
   const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
+  if (defer_rows) {
+    const uint64_t rows = (WIDE ? (e[0] >> kLocWideShift) : (e[0] >> 32)) + (nsi > 1u ? (WIDE ? (e[1] >> kLocWideShift) : (e[1] >> 32)) : 0ull);
+    if (rows > defer_rows) return false;
+  }
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
   uint32_t nids = 0, flags = fl0 & ~kHitLocPending;          // (a Greedy read may carry kHitSiCap already)
@@ -2761,6 +2775,7 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
   }
   for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;   // (the slots that held the matches and got no id)
   hit->n_ids = nids; hit->flags = flags;
+  return true;
 }
 
 
@@ -2811,6 +2826,12 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
   };
   // the id of one row: ~0 = none (a name without a usable id, or a row beyond the samples, where the reference reads out of bounds)
   auto walk = [&](P k) -> uint64_t {
+    if constexpr (!WIDE) {
+      if (ix.row_seq) {                                       // the walk below, precomputed for every row at index load (k_suffix_walk)
+        const uint32_t iseq = ix.row_seq[k];
+        return (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
+      }
+    }
     for (;;) {
       if ((k & check) == 0) {
         const uint64_t sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
@@ -3327,9 +3348,6 @@ KJ_HD void greedy_lane(const DevIndex &ix, const ConstTables &ct, const Params &
 // ----------------------------------------------------------------------------
 #ifdef KJ_G_SMALL                                  // tests: exercise the spill and retry paths
 constexpr int kGMaxM = 1, kGMaxMAll = 2, kGSlots = 1, kGSlotsAll = 3;
-#elif defined(KJ_BIGQ)                             // (workload statistics on the host: how many queue slots do the reads want?)
-constexpr int kGMaxM = 8, kGMaxMAll = 1024;
-constexpr int kGSlots = 12, kGSlotsAll = 8192;
 #else
 constexpr int kGMaxM = 8, kGMaxMAll = 256;
 // queue slots: 12 priorities in LDS, 512 slots in all (64 KB of items per lane in device memory).  With 128, reads of the
@@ -3340,10 +3358,8 @@ constexpr int kGMaxM = 8, kGMaxMAll = 256;
 constexpr int kGSlots = 12, kGSlotsAll = 512;
 #endif
 constexpr int kGSubStride = 17;                  // six words of substitutions + eleven of slow-part state
-#ifndef KJ_G_EXT_PASS
-#define KJ_G_EXT_PASS 4
-#endif
-constexpr int kGExtPass = KJ_G_EXT_PASS;         // 16-byte loads in flight per pass over the queue's overflow area (4 priorities each)
+constexpr int kGExtPass = 4;                     // 16-byte loads in flight per pass over the queue's overflow area (4 priorities each;
+                                                 // 8: slower)
 // LDS rows (dwords): strides chosen odd (byte / dword accesses) or 4 x odd (16-byte accesses)
 #ifndef KJ_G_SMALL
 constexpr int kGWinStride = 17, kGMqStride = 4, kGPrioStride = 12;     // 132 bytes per lane + 68 (kGSubStride) = 200: three blocks of

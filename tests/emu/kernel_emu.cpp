@@ -52,6 +52,13 @@ void *emu_index_load_x(const char *path, char *err, int errlen) {
 }
 void emu_index_free(void *h) { delete (EmuIndex *)h; }
 uint32_t emu_index_warnings(void *h) { return ((EmuIndex *)h)->packed.warnings; }
+// 1: the text arrays of text verification were built (sa_full / text / row_seq); number of rows whose row_seq says "no sequence"
+int emu_has_text(void *h) { return ((EmuIndex *)h)->packed.sa_full.empty() ? 0 : 1; }
+uint64_t emu_rows_without_sequence(void *h) {
+  uint64_t n = 0;
+  for (uint32_t v : ((EmuIndex *)h)->packed.row_seq) n += v == 0xffffffffu;
+  return n;
+}
 // the product's ln(n!) table (host_tables.cpp: build_seg_tables), entry n; -1 beyond it; emu_lnfact_n(): its length
 uint32_t emu_lnfact_n(void *h) { return (uint32_t)((EmuIndex *)h)->lnfact.size(); }
 double emu_lnfact(void *h, uint32_t n) { EmuIndex *ix = (EmuIndex *)h; return n < ix->lnfact.size() ? ix->lnfact[n] : -1.0; }
@@ -325,7 +332,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   if (locate_pass) for (uint32_t r = 0; r < n; r++) {
     const bool serial = getenv("KAIJU_EMU_LOCATE_SERIAL") != nullptr;
     if (d.mb_base) { if (serial) mem_locate_read<true>(d, p, &hits[r]); else { TeamSerial<4> tm; mem_locate_read_team<true, 4>(d, p, &hits[r], tm); } }
-    else if (d.row_seq || serial) mem_locate_read<false>(d, p, &hits[r]);
+    else if (serial) mem_locate_read<false>(d, p, &hits[r]);
+    else if (d.row_seq && mem_locate_read<false>(d, p, &hits[r], 8)) {}          // (k_mem_locate: short row lists itself, the others listed)
     else { TeamSerial<4> tm; mem_locate_read_team<false, 4>(d, p, &hits[r], tm); }
   }
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass

@@ -481,3 +481,26 @@ def test_device_resident_entry_points(gpu_lib, golden, gidx, mode):
     assert (got == want).all()
     for p in (d_seqs, d_off, d_hits, d_rec):
         hip.free(p)
+
+
+def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, monkeypatch):
+    """an index with the reference's short suffix-array sample (nseq % 8 == 0, KAIJU_IDX_WARN_SA_SHORT) gets its text arrays
+    too (the rows behind the missing sample are resolved through the next one): same records as without them"""
+    from kaiju_amd import mkfmi, synth
+    api = gpu_lib
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=1600, seed=11, leaves=leaves, max_len=700)
+    faa, fmi = str(tmp_path / "db.faa"), str(tmp_path / "db.fmi")
+    synth.write_fasta(db, faa)
+    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+    seqs, off = synth.pack_reads(synth.make_reads(db, 20000, seed=5))
+    with_text = api.Index(fmi)
+    assert with_text.info.warnings & 1 and with_text.footprint.text > 0 and with_text.footprint.sa_full > 0
+    monkeypatch.setenv("KAIJU_GPU_NO_TEXT", "1")
+    without = api.Index(fmi)
+    assert without.footprint.text == 0
+    for mode in ("mem", "greedy"):
+        a = api.Classifier(with_text, api.default_params(mode, seg=1)).classify(seqs, off)
+        b = api.Classifier(without, api.default_params(mode, seg=1)).classify(seqs, off)
+        assert (a == b).all(), mode
+        assert (a["n_ids"] > 0).mean() > 0.4

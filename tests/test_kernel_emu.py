@@ -693,3 +693,38 @@ def test_skip_rules_and_probes(oracle, golden, handles, monkeypatch):
                     bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
                     assert not bad, (tag, wide, mode, kw, pe, bad[:5])
             e.lib.emu_index_free(h)
+
+
+def test_text_arrays_on_an_index_with_the_short_sample_array(tmp_path, monkeypatch):
+    """One real database in eight (nseq % 2^e == 0) has the reference's short suffix-array sample (KAIJU_IDX_WARN_SA_SHORT).
+    Round 3 built no text arrays for such an index - text verification and the two-load locate silently gone.  Now the few
+    rows whose walk runs into the missing sample are resolved through the next one; a locate of such a row stays "no
+    sequence" (the reference reads out of bounds there).  The lanes with the text arrays must classify exactly like the lanes
+    without them (which walk and step as before)."""
+    import ctypes as C
+    from kaiju_amd import mkfmi, synth
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=1600, seed=11, leaves=leaves, max_len=700)          # 1600 % 8 == 0
+    faa, fmi = str(tmp_path / "db.faa"), str(tmp_path / "db.fmi")
+    synth.write_fasta(db, faa)
+    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+    seqs, off = synth.pack_reads(synth.make_reads(db, 3000, seed=5))
+    m1, m2 = synth.make_pairs(db, 800, seed=6)
+    pseqs, poff = synth.pack_reads(m1, m2)
+    emu = util.Emu()
+    emu.lib.emu_rows_without_sequence.restype = C.c_uint64
+    emu.lib.emu_rows_without_sequence.argtypes = [C.c_void_p]
+    emu.lib.emu_has_text.argtypes = [C.c_void_p]
+    h = emu.load(fmi)
+    assert emu.lib.emu_index_warnings(h) & 1                                       # KAIJU_IDX_WARN_SA_SHORT
+    assert emu.lib.emu_has_text(h) == 1
+    assert 1 <= emu.lib.emu_rows_without_sequence(h) <= 4096
+    monkeypatch.setenv("KAIJU_EMU_NO_TEXT", "1")
+    h0 = emu.load(fmi)
+    assert emu.lib.emu_has_text(h0) == 0
+    for mode in ("mem", "greedy"):
+        for s, o, pe in ((seqs, off, False), (pseqs, poff, True)):
+            a, _ = emu.classify(h, util.gp(mode), s, o, paired=pe)
+            b, _ = emu.classify(h0, util.gp(mode), s, o, paired=pe)
+            assert (a == b).all(), (mode, pe)
+            assert (a["n_ids"] > 0).mean() > 0.4
