@@ -239,7 +239,6 @@ k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   __shared__ __attribute__((aligned(16))) uint8_t s_frag[kSegStage];
   __shared__ int32_t s_work[4 * kSegMaxRegions];
   __shared__ uint8_t s_cls[kSegStage];
-  __shared__ ulonglong2 s_pre[kSegPacked + 1];               // prefix letter counts of the fragment (s_Trim's windows: seg_trim)
   if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
   if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
   __syncthreads();
@@ -247,7 +246,7 @@ k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   const CoopWave coop;
   const uint32_t n = min(*sq.count, sq.cap);
   for (uint32_t s = blockIdx.x; s < n; s += gridDim.x)       // trip count is uniform over the block
-    seg_compute(cx, coop, b, p, sq, s, s_frag, kSegStage, s_work, s_cls, [] { __syncthreads(); }, s_pre);
+    seg_compute(cx, coop, b, p, sq, s, s_frag, kSegStage, s_work, s_cls, [] { __syncthreads(); });
 }
 
 // MEM: apply the SEG records to the fragment lists
@@ -1057,6 +1056,16 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   return KAIJU_GPU_OK;
 }
 
+// An image of 2 GB and more is streamed to the device (no host copy); a smaller one is read into host memory and uploaded
+// from there - allocating the page-locked pieces costs more than streaming saves (viruses-size image, 0.5 GB: 256 against 79 ms,
+// profiles/r04_cli).  KAIJU_GPU_IMAGE_HOST_COPY=1: never stream; a piece size in the environment (tests): always.
+static bool image_wants_streaming(const char *path) {
+  if (getenv("KAIJU_GPU_IMAGE_HOST_COPY")) return false;
+  if (getenv("KAIJU_GPU_STREAM_PIECE_KB") || getenv("KAIJU_GPU_STREAM_PIECE_MB")) return true;
+  struct stat st;
+  return stat(path, &st) == 0 && (uint64_t)st.st_size >= (2ull << 30);
+}
+
 // does the file start with the magic of an index image?
 static bool is_image_file(const char *path) {
   char m[8] = {0};
@@ -1133,7 +1142,7 @@ extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_g
     LoadClock lc;
     // the arrays that grow with the index are streamed from the file to the device (kaijux ids rewrite the sampled ids on the
     // host: that mode reads everything; KAIJU_GPU_IMAGE_HOST_COPY=1 does so too, for comparison)
-    const bool lazy = tl_id_mode == 0 && !getenv("KAIJU_GPU_IMAGE_HOST_COPY");
+    const bool lazy = tl_id_mode == 0 && image_wants_streaming(fmi_path);
     const int rc = pk.read_image(fmi_path, msg, lazy);
     lc.mark(lazy ? "read image file (small arrays)" : "read image file");
     const int drc = device_check_result(dev);
@@ -1171,7 +1180,7 @@ extern "C" int kaiju_gpu_index_load_devices(const char *fmi_path, const int *dev
   PackedIndex pk;
   std::string msg;
   int rc;
-  if (is_image_file(fmi_path)) rc = pk.read_image(fmi_path, msg, id_mode == 0 && !getenv("KAIJU_GPU_IMAGE_HOST_COPY"));
+  if (is_image_file(fmi_path)) rc = pk.read_image(fmi_path, msg, id_mode == 0 && image_wants_streaming(fmi_path));
   else {
     FmiFile f;
     rc = f.load(fmi_path, msg);

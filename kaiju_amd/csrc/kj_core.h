@@ -568,15 +568,8 @@ KJ_HD int zero_fields6(uint64_t x) {
 
 // ln P0 of the sub-window s[i .. i+l) (s_GetProb blast_seg.c:1944-1967 with s_LnAss :1890-1933 and
 // s_LnPerm :1864-1879 on the descending state vector), l <= kSegPacked
-// pre (optional): pre[k] = the packed counts of s[0 .. k) - then the counts of a window are a difference of two entries (no
-// field borrows from its neighbour: every count of the longer prefix is at least that of the shorter), instead of a walk
-// over its letters: s_Trim looks at O(len^2) windows of a raw segment, each of O(len) letters
-KJ_HD double seg_window_prob_packed(const SegCtx &cx, const uint8_t *s, int l, int i, const ulonglong2 *pre = nullptr) {
+KJ_HD double seg_window_prob_packed(const SegCtx &cx, const uint8_t *s, int l, int i) {
   uint64_t c0 = 0, c1 = 0;             // 6-bit counts, letters 0..9 and 10..19
-  if (pre) {
-    const ulonglong2 hi = pre[i + l], lo = pre[i];
-    c0 = hi.x - lo.x; c1 = hi.y - lo.y;
-  } else
   for (int k = 0; k < l; k++) {
     const uint32_t a = KJ_SL(s, i + k);
     if (a < 10) c0 += 1ull << (6 * a); else c1 += 1ull << (6 * (a - 10));
@@ -640,8 +633,7 @@ KJ_HD double seg_window_prob_generic(const SegCtx &cx, const uint8_t *s, int l, 
 // keeping a window only if its probability is strictly smaller than the best so far; with the
 // visiting order t = d(d+1)/2 + i (d = len - l) that is the lexicographic minimum of (prob, t).
 template <class Coop>
-KJ_HD void seg_trim(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len, int &lend_out, int &rend_out,
-                    const ulonglong2 *pre = nullptr) {
+KJ_HD void seg_trim(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len, int &lend_out, int &rend_out) {
   int minlen = 1;
   if (len - kSegMaxTrim > minlen) minlen = len - kSegMaxTrim;
   const int D = len - minlen;                     // number of window lengths
@@ -652,7 +644,7 @@ KJ_HD void seg_trim(const SegCtx &cx, const Coop &coop, const uint8_t *s, int le
   for (int t = coop.lane(); t < W; t += coop.width()) {
     while (base + d + 1 <= t) { base += d + 1; d++; }
     const int i = t - base, l = len - d;
-    const double prob = l <= kSegPacked ? seg_window_prob_packed(cx, s, l, i, pre) : seg_window_prob_generic(cx, s, l, i);
+    const double prob = l <= kSegPacked ? seg_window_prob_packed(cx, s, l, i) : seg_window_prob_generic(cx, s, l, i);
     if (prob < best) { best = prob; best_t = t; }
   }
   coop.reduce_min(best, best_t);
@@ -679,20 +671,6 @@ KJ_HD void seg_classes(const SegCtx &cx, const Coop &coop, const uint8_t *s, int
   }
 }
 
-// pre[k] = packed 6-bit counts of the letters of s[0 .. k), k = 0 .. len (len <= kSegPacked: no count outgrows its field),
-// spread over the lanes of the team
-template <class Coop>
-KJ_HD void seg_prefix_counts(const Coop &coop, const uint8_t *s, int len, ulonglong2 *pre) {
-  for (int t = coop.lane(); t <= len; t += coop.width()) {
-    uint64_t c0 = 0, c1 = 0;
-    for (int k = 0; k < t; k++) {
-      const uint32_t a = KJ_SL(s, k);
-      if (a < 10) c0 += 1ull << (6 * a); else c1 += 1ull << (6 * (a - 10));
-    }
-    pre[t].x = c0; pre[t].y = c1;
-  }
-}
-
 // One level of s_SegSeq (blast_seg.c:2027-2113) on s[0..len).  At the top level
 // (`TOP`) a trigger window lying left of its trimmed segment starts a second scan of
 // the left remainder, of which only the LAST segment survives (:2093-2097: the head of
@@ -702,7 +680,7 @@ KJ_HD void seg_prefix_counts(const Coop &coop, const uint8_t *s, int len, ulongl
 // string, cls[0] being the window that starts at s[0].
 template <bool TOP, class Coop>
 KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len, int offset,
-                   int32_t *beg, int32_t *end, int n, int cap, bool &overflow, const uint8_t *cls, const ulonglong2 *pre = nullptr) {
+                   int32_t *beg, int32_t *end, int n, int cap, bool &overflow, const uint8_t *cls) {
   if (len < kSegWindow) return n;
   const int first = kSegDown, last = len - kSegUp;
   int lowlim = first;
@@ -740,7 +718,7 @@ KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len
     }
     const int rawleft = loi - kSegDown, rawright = hii + kSegUp - 1;
     int tl, tr;
-    seg_trim(cx, coop, s + rawleft, rawright - rawleft + 1, tl, tr, pre ? pre + rawleft : nullptr);
+    seg_trim(cx, coop, s + rawleft, rawright - rawleft + 1, tl, tr);
     const int leftend = rawleft + tl, rightend = rawleft + tr;
     if constexpr (TOP) {
       if (i + kSegUp - 1 < leftend) {
@@ -749,7 +727,7 @@ KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len
         int32_t tb[1], te[1];
         bool ov = false;
         const int k = seg_scan<false>(cx, coop, s + rawleft, leftend - rawleft, offset + rawleft, tb, te, 0, 1, ov,
-                                      cls ? cls + rawleft : nullptr, pre ? pre + rawleft : nullptr);
+                                      cls ? cls + rawleft : nullptr);
         if (k > 0) {
           if (n < cap) { beg[n] = tb[0]; end[n] = te[0]; n++; } else overflow = true;
         }
@@ -774,17 +752,14 @@ KJ_HD int seg_scan(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len
 template <class Coop, class Sync>
 KJ_HD int seg_regions(const SegCtx &cx, const Coop &coop, const uint8_t *s, int len,
                       int32_t *left, int32_t *right, bool &overflow, int32_t *work, uint8_t *cls, Sync &&team_sync,
-                      int cap = kSegMaxRegions, ulonglong2 *pre = nullptr) {
-  // (cap: capacity of the two scan lists in `work` and of left/right; the exact pass of long fragments passes more;
-  //  pre: kSegPacked + 1 entries shared by the team for the prefix counts of fragments up to kSegPacked residues)
+                      int cap = kSegMaxRegions) {
+  // (cap: capacity of the two scan lists in `work` and of left/right; the exact pass of long fragments passes more)
   int32_t *b = work, *e = work + cap;
-  if (len > kSegPacked) pre = nullptr;
-  if (len >= kSegWindow) {
-    if (cls) seg_classes(cx, coop, s, len, cls);
-    if (pre) seg_prefix_counts(coop, s, len, pre);
-    if (cls || pre) team_sync();
+  if (cls && len >= kSegWindow) {
+    seg_classes(cx, coop, s, len, cls);
+    team_sync();
   }
-  const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, cap, overflow, cls, pre);
+  const int n = seg_scan<true>(cx, coop, s, len, 0, b, e, 0, cap, overflow, cls);
   if (n == 0) return 0;
   // the reference's list is in reverse creation order; s_MergeSegs (:2122-2152, hilenmin 0)
   // walks it from the head and merges a node with its successor while they overlap
@@ -1081,8 +1056,7 @@ KJ_HD bool seg_triggers(const SegCtx &cx, const S &s, int len) {
 // fragment so that the scan does not go to device memory for every residue.
 template <class Coop, class Sync>
 KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const Params &p, const SegQueue &sq,
-                       uint32_t slot, uint8_t *stage, uint32_t stage_cap, int32_t *work, uint8_t *cls, Sync &&team_sync,
-                       ulonglong2 *pre = nullptr) {
+                       uint32_t slot, uint8_t *stage, uint32_t stage_cap, int32_t *work, uint8_t *cls, Sync &&team_sync) {
   const SegWork wk = sq.items[slot];
   const ReadMeta rm = b.meta[wk.read];
   const Frag f = b.frags[rm.frag + wk.frag];
@@ -1098,8 +1072,7 @@ KJ_HD void seg_compute(const SegCtx &cx, const Coop &coop, const Batch &b, const
   int32_t *left = work + 2 * kSegMaxRegions, *right = work + 3 * kSegMaxRegions;
   bool ov = false;
   // (cls holds stage_cap bytes; the previous fragment's classes are no longer read: the syncs above)
-  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov, work, (stage && f.len <= stage_cap) ? cls : nullptr, team_sync,
-                            kSegMaxRegions, (stage && f.len <= stage_cap) ? pre : nullptr);
+  const int n = seg_regions(cx, coop, src, (int)f.len, left, right, ov, work, (stage && f.len <= stage_cap) ? cls : nullptr, team_sync);
   if (coop.lane() != 0) return;
   SegRec rec;
   rec.overflow = (ov || n > kSegRecRegions || f.len > 65535u) ? 1 : 0;

@@ -82,9 +82,7 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   int32_t work[2 * kSegMaxRegions];
   std::vector<uint8_t> cls((size_t)len + 1);
   const bool use_cls = !getenv("KAIJU_EMU_SEG_NOCLS");
-  std::vector<ulonglong2> pre(kSegPacked + 1);                  // prefix letter counts (k_seg's LDS array); KAIJU_EMU_SEG_NOPRE: without
-  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov, work, use_cls ? cls.data() : nullptr, [] {}, kSegMaxRegions,
-                      getenv("KAIJU_EMU_SEG_NOPRE") ? nullptr : pre.data());
+  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov, work, use_cls ? cls.data() : nullptr, [] {});
   return ov ? -1 : n;
 }
 
@@ -171,9 +169,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     int32_t segwork[4 * kSegMaxRegions];
     std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
     std::vector<uint8_t> segcls(64);
-    std::vector<ulonglong2> segpre(kSegPacked + 1);
     for (uint32_t s = 0; s < seg_count && s < seg_cap; s++)
-      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {}, segpre.data());
+      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
     if (p.mode == 0) for (uint32_t r = 0; r < n; r++) seg_apply_mem(ix->ct, p, b, sq, r, &err);
   }
   if (frag_dump) {
@@ -279,9 +276,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
           }
           int32_t segwork[4 * kSegMaxRegions];
           std::vector<uint8_t> segstage(64), segcls(64);
-          std::vector<ulonglong2> segpre2(kSegPacked + 1);
           for (uint32_t s2 = 0; s2 < seg_count && s2 < seg_cap; s2++)
-            seg_compute(cx, CoopSerial{}, b, p, sq, s2, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {}, segpre2.data());
+            seg_compute(cx, CoopSerial{}, b, p, sq, s2, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
           for (uint32_t r : seglist) seg_apply_mem(ix->ct, p, b, sq, r, &err);
           uint32_t counter2 = 0, nlist = (uint32_t)seglist.size();
           WorkList w2;

@@ -146,7 +146,7 @@ def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
     api.write_index_image(golden.fmi, img)
     # the arrays that grow with the index are streamed from the file to the device in page-locked pieces: default piece size
     # (one piece here), pieces of 16 KB (dozens per array, several reader threads per piece), and the host-copy path
-    for env in ({}, {"KAIJU_GPU_STREAM_PIECE_KB": "16"}, {"KAIJU_GPU_IMAGE_HOST_COPY": "1"}):
+    for env in ({"KAIJU_GPU_STREAM_PIECE_MB": "256"}, {"KAIJU_GPU_STREAM_PIECE_KB": "16"}, {"KAIJU_GPU_IMAGE_HOST_COPY": "1"}, {}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
@@ -502,5 +502,17 @@ def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, 
     for mode in ("mem", "greedy"):
         a = api.Classifier(with_text, api.default_params(mode, seg=1)).classify(seqs, off)
         b = api.Classifier(without, api.default_params(mode, seg=1)).classify(seqs, off)
-        assert (a == b).all(), mode
+        _same_but_for_the_rows_behind_the_missing_sample(a, b, mode)
         assert (a["n_ids"] > 0).mean() > 0.4
+
+
+def _same_but_for_the_rows_behind_the_missing_sample(a, b, what):
+    """a: records with the text arrays, b: without.  The same best lengths / scores everywhere; the ids may differ for the
+    handful of reads whose match ends on a row whose get_suffix walk runs into the MISSING sample: the reference reads out of
+    bounds there (undefined), the walking locate skips the row, and a match that was grown along the text is located through
+    the row it had reached when the text took over - another row of the same sequence, which has its sample."""
+    assert (a["best"] == b["best"]).all(), what
+    bad = np.nonzero(a != b)[0]
+    assert len(bad) <= max(3, len(a) // 2000), (what, len(bad))
+    for i in bad:
+        assert b[i]["n_ids"] < a[i]["n_ids"], (what, int(i))
