@@ -2674,20 +2674,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 // The ids of a read whose longest matches mem_lane2 left in its hit record (kHitLocPending): ids_from_SI for every match in
 // turn (ConsumerThread.cpp:799-845; get_suffix bwt.c:105-121, FMindexCurrent compactfmi.c:312-336) - the same steps as
 // BK_LOC_ROW / K_LF1 / K_LF2 / K_SA of the lane, one read per lane, narrow index.
-// defer_rows (0 = never): a read whose matches hold more rows than that is left as it is and false is returned - the caller
-// hands it to a team of lanes (mem_locate_read_team): families of near-identical proteins give intervals of hundreds of rows
-// of which the reference visits every one unless twenty-one taxa turn up (bench.py's `hard` leg)
 template <bool WIDE>
-KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32_t defer_rows = 0) {
+KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
   typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   const uint32_t fl0 = hit->flags;
-  if (!(fl0 & kHitLocPending)) return true;
+  if (!(fl0 & kHitLocPending)) return;
   const uint32_t nsi = hit->n_ids;
   const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
-  if (defer_rows) {
-    const uint64_t rows = (WIDE ? (e[0] >> kLocWideShift) : (e[0] >> 32)) + (nsi > 1u ? (WIDE ? (e[1] >> kLocWideShift) : (e[1] >> 32)) : 0ull);
-    if (rows > defer_rows) return false;
-  }
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
   uint32_t nids = 0, flags = fl0 & ~kHitLocPending;          // (a Greedy read may carry kHitSiCap already)
@@ -2748,7 +2741,6 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   }
   for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;   // (the slots that held the matches and got no id)
   hit->n_ids = nids; hit->flags = flags;
-  return true;
 }
 
 
