@@ -124,6 +124,20 @@ constexpr bool kSpanRule = false;
 constexpr bool kSpanRule = true;
 #endif
 constexpr bool kSpanRuleStep = kSpanRule;          // Greedy: also for intervals that shrink to one row behind the k-mer lookup
+// ---- the span rule for intervals of ANY size (round 4) ------------------------------------------------------------------------
+// The rule above asks for a k-mer with ONE row.  What it uses is that every occurrence of the k-mer lies inside an occurrence
+// of the earlier match M = w[i'..j'] - and that holds whenever the k-mer K (inside M) has AS MANY rows as M: every occurrence
+// of M holds one of K at a fixed offset, so |occ(K)| >= |occ(M)|, and with equality that map is onto.  Then every occurrence
+// of K is preceded by w[j-k], ..., w[i'] and none by w[i'-1] (UpdateSI of that letter on M's interval found nothing): the
+// search from j ends at i', as a one-row one would.  Databases are redundant - strains, paralogues, the benchmark's mutated
+// copies, a refseq-class index in which every protein occurs seven times: a true match there NEVER has one row, and without
+// this the searches from the forty end positions inside a 50-letter match each walk the whole of it again.  `last_sz` = the
+// size of the interval in which the last search ended (MEM: of `i`; Greedy also: of the last recorded match, `last_qi`).
+#ifdef KJ_NO_SPAN_EQ
+constexpr bool kSpanEq = false;
+#else
+constexpr bool kSpanEq = true;
+#endif
 // ---- probes (MEM lane, narrow) ---------------------------------------------------------------------------------------------
 // greedyExact records a match only if it is at least L long (L = min_fragment_length, then the longest so far, bwt.c:364).
 // A match of L letters that ends at j' in [j-L+k, j] contains the k-mer that ends at e = j-L+k (letters j-L+1 .. e): if that
@@ -2147,6 +2161,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   int flen = 0, j = 0, i = 0;
   P lo = 0, hi = 0;
   uint32_t c = 1, L = p.m, nsi = 0, kidx = 0;
+  P last_sz = 1;                              // rows of the interval the last search ended in (kSpanEq; 1: the one-row rule)
   bool found = false, ovf = false, multi = false;
   int fill_top = 0;
   bool fill_newfrag = false, fill_step = false;
@@ -2364,7 +2379,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (!WIDE && kind == K_PROBE) {
         // the k-mer that ends at e = j - (L - kk) (kMemProbe)
         const int e = j - (int)(L - kk);
-        if (!escape && (lo >= hi || (kSpanRule && hi - lo == 1 && e - (int)kk + 1 >= i))) {
+        if (!escape && (lo >= hi || (kSpanRule && hi - lo == (kSpanEq ? last_sz : (P)1) && e - (int)kk + 1 >= i))) {
           // ... and the one that ends at e - 1, absent, passes end position e - 1 too
           const bool prev_absent = e >= (int)kk && in_win(e - (int)kk) && ((cb >> ((uint32_t)lw.w[e - (int)kk - lw.q] - 1u)) & 1u) == 0u;
           j = e - 1 - (prev_absent ? 1 : 0);
@@ -2379,7 +2394,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         if (in_win(i - 1)) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
         else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
       } else if (lo >= hi) { i = j; bk = BK_END_MATCH; }   // match shorter than kk: never recorded, i > 1
-      else if (kSpanRule && hi - lo == 1 && j - (int)kk + 1 >= i) bk = BK_END_MATCH;   // inside the last match (see kSpanRule): i stays
+      else if (kSpanRule && hi - lo == (kSpanEq ? last_sz : (P)1) && j - (int)kk + 1 >= i) bk = BK_END_MATCH;   // inside the last match (see kSpanRule, kSpanEq): i stays
       else {
         i = j - (int)kk + 1;
         KJ_HIST_SINGLE(hi - lo == 1, (int)kk);
@@ -2498,6 +2513,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         KJ_PM(PM_END_MATCH);
         const uint32_t l = (uint32_t)(j - i + 1);
         KJ_HIST_SINGLE_END(l);
+        if constexpr (kSpanEq) last_sz = hi > lo ? (P)(hi - lo) : (P)1;   // (an absent k-mer ends its search at i = j: no k-mer lies inside that)
         bool probed = false;
         if constexpr (WIDE) {
           if (pj >= 0) {
@@ -3413,6 +3429,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   sp0 = sp1 = sp2 = sp3 = sa0 = sa1 = 0;
   int flen = 0, j = 0, i = 0, last_qi = 0;
   P lo = 0, hi = 0;
+  P sz_i = 1, sz_q = 1;                       // kSpanEq: rows of the interval the last search ended in / of the last recorded match
   uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0;
   bool m_ovf = false;
   // the match at hand
@@ -3958,7 +3975,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         else {
           lo = ra; hi = rb; i--; acc += diag(c);
           if (i == 0) bk = GB_END_MATCH;
-          else if (kSpanRuleStep && t_nmm == 0 && nm != 0 && hi - lo == 1 && i >= last_qi) {
+          else if (kSpanRuleStep && t_nmm == 0 && nm != 0 && hi - lo == (kSpanEq ? sz_q : (P)1) && i >= last_qi) {
             // the span rule for an interval that shrinks to one row behind the k-mer lookup: the recorded match that reaches
             // furthest (last_qi, from a larger end position) contains it, the search ends where that one ended or, unrecorded, beyond
             i = last_qi; bk = GB_END_MATCH;
@@ -3976,7 +3993,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         // the k-mer table of 16-byte entries {lo, len}
         lo = (P)gv.x; hi = (P)(gv.x + gv.y);
         if (lo >= hi) { i = j; bk = GB_END_MATCH; }        // seed shorter than kk: never recorded, i > 1
-        else if (kSpanRule && gv.y == 1ull && j - (int)kk + 1 >= i) bk = GB_END_MATCH;   // inside the last match (kSpanRule): i stays
+        else if (kSpanRule && gv.y == (kSpanEq ? (uint64_t)sz_i : 1ull) && j - (int)kk + 1 >= i) bk = GB_END_MATCH;   // inside the last match (kSpanRule, kSpanEq): i stays
         else {
           i = j - (int)kk + 1;
           if (i == 0) bk = GB_END_MATCH;
@@ -4009,7 +4026,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; }
         else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
       } else if (lo >= hi) { i = j; bk = GB_END_MATCH; }   // seed shorter than kk: never recorded, i > 1
-      else if (kSpanRule && hi - lo == 1 && j - (int)kk + 1 >= i) bk = GB_END_MATCH;   // inside the last match (kSpanRule): i stays
+      else if (kSpanRule && hi - lo == (kSpanEq ? sz_i : (P)1) && j - (int)kk + 1 >= i) bk = GB_END_MATCH;   // inside the last match (kSpanRule, kSpanEq): i stays
       else {
         i = j - (int)kk + 1;
         if (i == 0) bk = GB_END_MATCH;
@@ -4260,6 +4277,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
         KJ_P(PS_END_MATCH);
         const int l = j - i + 1;
         if (t_nmm == 0) {
+          if constexpr (kSpanEq) sz_i = hi > lo ? (P)(hi - lo) : (P)1;
           bool recorded = false;
           if (l >= (int)p.seed_length && (nm == 0 || i < last_qi)) {        // bwt.c:276-278
             recorded = true;
@@ -4279,6 +4297,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             } else { if (!m_ovf) KJ_OVF(wl, 5); m_ovf = true; }
             nm++;
             last_qi = i;
+            if constexpr (kSpanEq) sz_q = (P)(hi - lo);
           }
           if (i <= 1) bk = GB_AFTER_SEARCH;                                 // bwt.c:292
           else {
