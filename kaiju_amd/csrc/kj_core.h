@@ -3430,15 +3430,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   int flen = 0, j = 0, i = 0, last_qi = 0;
   P lo = 0, hi = 0;
   P sz_i = 1, sz_q = 1;                       // kSpanEq: rows of the interval the last search ended in / of the last recorded match
-  // WIDE probe (kGreedyProbe; the narrow lane's is a k-mer line lookup, G_PROBE): behind a recorded match [q, J] a recordable
-  // match that ends at j' in [e, J-1], e = q + pw - 2, starts in front of q (bwt.c:276), i.e. holds the pw letters q-1 .. e.  The
-  // search from e stands in for those end positions: if it ends without reaching q-1 the word is not in the index and the
-  // searches from e .. J-1 are passed (none can be recorded, and an unrecorded search has no other effect); if it reaches q-1 it
-  // stops there and the search from J-1 comes next as usual.  pw = the shortest word a fifth of the index's rows could hold at
-  // most (mem_lane2): nine letters at 28 G rows.  pj = the end position to go back to (-1: no probe under way); pinfo = what
-  // `tail` grows by in either case (low half: the letters e .. J, high half: the letter J alone).
-  int pj = -1;
-  uint32_t pinfo = 0, pw = 0;
   uint32_t c = 1, cj = 1, acc = 0, tail = 0, nm = 0, kidx = 0;
   bool m_ovf = false;
   // the match at hand
@@ -3473,15 +3464,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0, itc = 0;
   const RankBlock64 *const blk0 = ix.blocks64;
-  if constexpr (WIDE) {
-    pw = kk;
-    uint64_t words = 1;
-    for (uint32_t q = 0; q < kk; q++) words *= 20u;
-    while (pw < 14u && ix.bwtlen > words / 5u) { words *= 20u; pw++; }
-#ifdef KJ_PROBE_W_ADD
-    pw += KJ_PROBE_W_ADD;                       // (tests on small indexes: probes of several steps)
-#endif
-  }
   // k-mer lines (DevIndex::kline): kcode = the line of end position j (the word w[j-kk+1 .. j-1]), kidx = line and entry of
   // the lookup.  The line (and the diagonal sum of the k-mer) of end position j-1 follows from that of j
   uint32_t kpow = 1;
@@ -3813,7 +3795,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               flen = (int)t_len; nm = 0; kroll = false; skipj = false;
               j = flen - 1; tail = 0;                       // maxMatches(seq, len, seed_length, 0), bwt.c:261-296
               i = flen;                                     // (span rule: no earlier search in this fragment)
-              pj = -1;
               fill_top = j; fill_ret = FR_START_J; fill_pref = true; kind = G_FILL; bk = GB_NONE;
             }
           }
@@ -3993,7 +3974,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         if (ra >= rb) bk = GB_END_MATCH;
         else {
           lo = ra; hi = rb; i--; acc += diag(c);
-          if (i == 0 || (WIDE && pj >= 0 && i < last_qi)) bk = GB_END_MATCH;     // (a probe that has reached q-1: its word is in the index)
+          if (i == 0) bk = GB_END_MATCH;
           else if (kSpanRuleStep && t_nmm == 0 && nm != 0 && hi - lo == (kSpanEq ? sz_q : (P)1) && i >= last_qi) {
             // the span rule for an interval that shrinks to one row behind the k-mer lookup: the recorded match that reaches
             // furthest (last_qi, from a larger end position) contains it, the search ends where that one ended or, unrecorded, beyond
@@ -4015,7 +3996,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         else if (kSpanRule && gv.y == (kSpanEq ? (uint64_t)sz_i : 1ull) && j - (int)kk + 1 >= i) bk = GB_END_MATCH;   // inside the last match (kSpanRule, kSpanEq): i stays
         else {
           i = j - (int)kk + 1;
-          if (i == 0 || (pj >= 0 && i < last_qi)) bk = GB_END_MATCH;
+          if (i == 0) bk = GB_END_MATCH;
           else if (in_win(i - 1)) { c = win[i - 1 - wq]; kind = G_STEP; }
           else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
         }
@@ -4237,7 +4218,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             // a SEG piece: maxMatches like an original
             tail = 0;
             i = flen;
-            pj = -1;
             fill_top = j; fill_ret = FR_START_J; fill_pref = false; kind = G_FILL;
           } else {
             // maxMatches_withStart, bwt.c:298-336
@@ -4296,22 +4276,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
       if (bk == GB_END_MATCH) {
         KJ_P(PS_END_MATCH);
         const int l = j - i + 1;
-        if (WIDE && t_nmm == 0 && pj >= 0) {
-          // the search from e = last_qi + pw - 2 was a probe
-          if (i < last_qi) {
-            // its word is in the index: the search from J - 1 comes next, as if nothing had happened (the span rule's last search is
-            // the recorded match again)
-            tail += pinfo >> 16; j = pj; i = last_qi;
-            if constexpr (kSpanEq) sz_i = sz_q;
-          } else {
-            // it is not: no match that ends at e .. J-1 starts in front of last_qi - on to end position e - 1 (this search, from
-            // e, is the span rule's last search)
-            if constexpr (kSpanEq) sz_i = hi > lo ? (P)(hi - lo) : (P)1;
-            tail += pinfo & 0xffffu; j = last_qi + (int)pw - 3;
-          }
-          pj = -1; kroll = false;
-          bk = GB_START_J;
-        } else
         if (t_nmm == 0) {
           if constexpr (kSpanEq) sz_i = hi > lo ? (P)(hi - lo) : (P)1;
           bool recorded = false;
@@ -4336,16 +4300,6 @@ if constexpr (COUNT) oc[kOpcTerm]++;
             if constexpr (kSpanEq) sz_q = (P)(hi - lo);
           }
           if (i <= 1) bk = GB_AFTER_SEARCH;                                 // bwt.c:292
-          else if (WIDE && kGreedyProbe && recorded && kk && l > (int)pw + 1 && i + (int)pw - 2 >= (int)p.seed_length - 1 &&
-                   in_win(i - 1) && in_win(j)) {                            // (e is an end position of the loop, bwt.c:265)
-            // the probe behind this recording (see pj): the search from e = i + pw - 2 first
-            const int e = i + (int)pw - 2;
-            uint32_t s2 = 0;
-            for (int x = i; x < e; x++) s2 += diag(win[x - wq]);            // the match's letters in front of e
-            pinfo = ((acc - s2) & 0xffffu) | diag(cj) << 16;
-            pj = j - 1; j = e; kroll = false;
-            bk = GB_START_J;
-          }
           else {
             tail += diag(cj); j--; bk = GB_START_J;
             // kGreedyProbe: the k-mer i-1 .. i+kk-2 is looked up before the search from j (GB_START_J builds the lookup)
