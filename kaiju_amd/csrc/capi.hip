@@ -294,13 +294,29 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
   mem_lane2<false>(ix, p, b, wl, ls);
 }
 // the ids of the reads whose longest matches the lanes above left in their hit records (kParamDeferLocate): one lane per read
+// (narrow index with the row -> sequence table: an id is two loads, and the rows of a match are neighbours in that table -
+//  teams of lanes were SLOWER here even for matches of hundreds of rows, bench.py's hard leg: 12.2 -> 14.6 ms per 2 M reads.
+//  What such matches cost was the look-up of every row's taxon among the ids collected so far: reads whose matches hold more
+//  than kLocDeferRows rows are listed - one atomic per wavefront - and located by k_mem_locate_list, the instantiation that
+//  keeps the collected ids in registers)
+constexpr uint32_t kLocDeferRows = 8;
 __global__ void __launch_bounds__(256)
-k_mem_locate(DevIndex ix, Params p, Batch b) {
-  // (narrow index with the row -> sequence table: an id is two loads, and the rows of a match are neighbours in that table -
-  //  teams of lanes were SLOWER here even for matches of hundreds of rows, bench.py's hard leg: 12.2 -> 14.6 ms per 2 M reads)
+k_mem_locate(DevIndex ix, Params p, Batch b, uint32_t *list, uint32_t *count) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= b.n_reads) return;
-  mem_locate_read<false>(ix, p, b.hits + r);
+  const bool defer = r < b.n_reads && !mem_locate_read<false>(ix, p, b.hits + r, list ? kLocDeferRows : 0u);
+  const uint64_t m = __ballot(defer);
+  if (m) {
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (defer) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_mem_locate_list(DevIndex ix, Params p, Batch b, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count) {
+  const uint32_t n = *count;
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) mem_locate_read<false, true>(ix, p, b.hits + list[t]);
 }
 // Indexes without the row -> sequence table (wide ones; narrow ones that had no room for the text arrays): a TEAM of kLocTeam
 // lanes per read walks the rows of a match side by side (mem_locate_read_team)
@@ -1233,7 +1249,7 @@ struct kaiju_gpu_ctx {
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
   bool defer_locate = true;        // KAIJU_GPU_MEM_LOCATE=inline: the MEM search lanes walk to the ids themselves
-  DevBuf seglist;
+  DevBuf seglist, loc_list;
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
   DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
@@ -1244,7 +1260,7 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist,
+    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist, &loc_list,
                      &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry,
                      &redo_bitmap, &redo_list, &redo_items, &redo_index, &redo_pool, &redo_work, &redo_cls};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
@@ -1374,6 +1390,8 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if ((rc = ensure(c->meta, (size_t)n * sizeof(ReadMeta) + 16))) return rc;
   if ((rc = ensure(c->counters, 4096))) return rc;     // [0, 256) counters, [512, ..) totals of the counting lanes
   if ((rc = ensure(c->retry_list, (size_t)n * 4 + 16))) return rc;
+  if ((rc = ensure(c->loc_list, (size_t)n * 4 + 16))) return rc;        // reads whose matches hold many rows (k_mem_locate_list)
+  uint32_t *loc_list = static_cast<uint32_t *>(c->loc_list.p);
   Batch b;
   b.seqs = static_cast<const uint8_t *>(d_seqs); b.off = d_off; b.n_reads = n; b.paired = paired ? 1 : 0;
   b.pep = static_cast<uint8_t *>(c->pep.p); b.frags = static_cast<Frag *>(c->frags.p);
@@ -1536,7 +1554,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
       if (defer) {
-        if (mem_narrow2 && ix->dev.row_seq) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        if (mem_narrow2 && ix->dev.row_seq) {
+          hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+          hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+        }
         else if (mem_narrow2) hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
         else hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
@@ -1615,7 +1636,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       KJ_HIP(hipGetLastError());
       if (pg.flags & kParamDeferLocate) {
         if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
-        else if (ix->dev.row_seq) hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b);
+        else if (ix->dev.row_seq) {
+          hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+          hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+        }
         else hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
       }

@@ -2690,22 +2690,46 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 // The ids of a read whose longest matches mem_lane2 left in its hit record (kHitLocPending): ids_from_SI for every match in
 // turn (ConsumerThread.cpp:799-845; get_suffix bwt.c:105-121, FMindexCurrent compactfmi.c:312-336) - the same steps as
 // BK_LOC_ROW / K_LF1 / K_LF2 / K_SA of the lane, one read per lane, narrow index.
-template <bool WIDE>
-KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
+// MANYROWS: the instantiation for reads whose matches hold many rows (a protein family: hundreds of rows of a dozen taxa).  The
+// ids collected so far then also sit in registers (fully unrolled, no dynamic indexing) - looking every row's taxon up in the
+// record in device memory, five dependent loads a row, was most of the post-search time on a database that is not i.i.d.
+// (bench.py's hard leg).  42 registers: the common case (one row, one id) keeps the lean instantiation and hands reads with
+// more than defer_rows rows on (returns false, the record untouched; defer_rows 0 = never).
+template <bool WIDE, bool MANYROWS = false>
+KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32_t defer_rows = 0) {
   typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   const uint32_t fl0 = hit->flags;
-  if (!(fl0 & kHitLocPending)) return;
+  if (!(fl0 & kHitLocPending)) return true;
   const uint32_t nsi = hit->n_ids;
   const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
+  if (defer_rows) {
+    const uint64_t rows = (WIDE ? (e[0] >> kLocWideShift) : (e[0] >> 32)) + (nsi > 1u ? (WIDE ? (e[1] >> kLocWideShift) : (e[1] >> 32)) : 0ull);
+    if (rows > defer_rows) return false;
+  }
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
   uint32_t nids = 0, flags = fl0 & ~kHitLocPending;          // (a Greedy read may carry kHitSiCap already)
   uint64_t id0 = 0;
+  uint64_t idr[MANYROWS ? kMaxIds : 1];
+  if constexpr (MANYROWS) {
+#pragma unroll
+    for (int q = 0; q < kMaxIds; q++) idr[q] = 0;
+  }
   auto add_tax = [&](uint64_t tax) {
     bool dup = false;
-    if (nids >= 1 && tax == id0) dup = true;
-    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+    if constexpr (MANYROWS) {
+#pragma unroll
+      for (int q = 0; q < kMaxIds; q++) dup = dup || (q < (int)nids && idr[q] == tax);
+      if (!dup && nids < (uint32_t)kMaxIds) {
+#pragma unroll
+        for (int q = 0; q < kMaxIds; q++) if (q == (int)nids) idr[q] = tax;
+        hit->taxid[nids++] = tax;
+      }
+    } else {
+      if (nids >= 1 && tax == id0) dup = true;
+      for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+      if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
+    }
   };
   bool done = false;
   for (uint32_t s = 0; s < nsi && !done; s++) {
@@ -2757,6 +2781,7 @@ KJ_HD void mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit) {
   }
   for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;   // (the slots that held the matches and got no id)
   hit->n_ids = nids; hit->flags = flags;
+  return true;
 }
 
 

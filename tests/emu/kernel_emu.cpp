@@ -328,7 +328,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   if (locate_pass) for (uint32_t r = 0; r < n; r++) {
     const bool serial = getenv("KAIJU_EMU_LOCATE_SERIAL") != nullptr;
     if (d.mb_base) { if (serial) mem_locate_read<true>(d, p, &hits[r]); else { TeamSerial<4> tm; mem_locate_read_team<true, 4>(d, p, &hits[r], tm); } }
-    else if (d.row_seq || serial) mem_locate_read<false>(d, p, &hits[r]);
+    else if (serial) mem_locate_read<false>(d, p, &hits[r]);
+    else if (d.row_seq) { if (!mem_locate_read<false>(d, p, &hits[r], 8)) mem_locate_read<false, true>(d, p, &hits[r]); }   // (k_mem_locate, k_mem_locate_list)
     else { TeamSerial<4> tm; mem_locate_read_team<false, 4>(d, p, &hits[r], tm); }
   }
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
