@@ -702,8 +702,8 @@ def test_text_arrays_on_an_index_with_the_short_sample_array(tmp_path, monkeypat
     sequence" (the reference reads out of bounds there).  The lanes with the text arrays must classify exactly like the lanes
     without them (which walk and step as before)."""
     import ctypes as C
-    if os.environ.get("KAIJU_GPU_FORCE_WIDE"):
-        pytest.skip("the text arrays are a narrow-index feature")
+    if os.environ.get("KAIJU_GPU_FORCE_WIDE") or os.environ.get("KAIJU_EMU_NO_TEXT"):
+        pytest.skip("the text arrays are a narrow-index feature (and switched off by KAIJU_EMU_NO_TEXT)")
     from kaiju_amd import mkfmi, synth
     _, leaves = synth.make_taxonomy(3, 3, 3)
     db = synth.make_db(nseq=1600, seed=11, leaves=leaves, max_len=700)          # 1600 % 8 == 0
