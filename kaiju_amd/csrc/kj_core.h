@@ -2823,20 +2823,12 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
   uint32_t nids = 0, flags = fl0 & ~kHitLocPending;           // (the leader's; a Greedy read may carry kHitSiCap already)
-  // (the ids collected so far also sit in registers, as in mem_locate_read<.., MANYROWS>: while the leader looked them up in the
-  //  record in device memory its seven team mates waited - seven ids a read on the refseq_ref-class index)
-  uint64_t idr[kMaxIds];
-#pragma unroll
-  for (int q = 0; q < kMaxIds; q++) idr[q] = 0;
+  uint64_t id0 = 0;
   auto add_tax = [&](uint64_t tax) {
     bool dup = false;
-#pragma unroll
-    for (int q = 0; q < kMaxIds; q++) dup = dup || (q < (int)nids && idr[q] == tax);
-    if (!dup && nids < (uint32_t)kMaxIds) {
-#pragma unroll
-      for (int q = 0; q < kMaxIds; q++) if (q == (int)nids) idr[q] = tax;
-      hit->taxid[nids++] = tax;
-    }
+    if (nids >= 1 && tax == id0) dup = true;
+    for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
+    if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
   };
   // the id of one row: ~0 = none (a name without a usable id, or a row beyond the samples, where the reference reads out of bounds)
   auto walk = [&](P k) -> uint64_t {
