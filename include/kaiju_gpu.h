@@ -184,8 +184,9 @@ typedef struct kaiju_gpu_index_footprint {
   uint64_t seq_tables;    /* per database sequence: taxon id, validity, row of its terminator                             */
   uint64_t kmer_table;    /* suffix interval of every k-letter word                                                       */
   uint64_t kmer_lines;    /* the same as 128-byte lines for two end positions each (narrow indexes)                       */
-  uint64_t text;          /* the database text (narrow indexes with room: text verification of long matches)             */
-  uint64_t sa_full;       /* ... and position + sequence of every row's suffix, 2 x 4 bytes per row                      */
+  uint64_t text;          /* the database text (indexes that leave room for it: text verification of long matches)       */
+  uint64_t sa_full;       /* ... and position + sequence of every row's suffix, 2 x 4 bytes per row (narrow indexes), or  */
+                          /* the 40-bit text position of every 2^s-th row (wide indexes: s = 0 .. 3 by the room left)     */
   uint64_t other;         /* constant tables                                                                              */
   uint64_t total;
   uint32_t kmer_k, wide;  /* k of the table; 1 = 64-bit positions                                                         */

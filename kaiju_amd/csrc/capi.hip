@@ -591,6 +591,51 @@ k_text_build(DevIndex ix, const uint32_t *__restrict__ row_seq, const uint32_t *
   }
 }
 
+// Index load, indexes with 64-bit positions that leave room: the database text and the text position of every 2^tv_shift-th
+// row (DevIndex::sa_tpos5), by walking every sequence from its terminator row (seq_walk_len / seq_walk_fill, kj_core.h).  A lane
+// that has finished a sequence takes the next one (sequences are 30 .. 30 000 letters long: a wave of 64 whole walks would wait
+// for its longest), one LF step per loop iteration.
+__global__ void __launch_bounds__(256)
+k_seq_walk_len(DevIndex ix, uint32_t *next, uint32_t *__restrict__ t_seq, uint32_t *__restrict__ len, uint32_t *bad) {
+  uint64_t k = 0, n = 0;
+  uint32_t t = 0;
+  bool active = false;
+  for (;;) {
+    if (!active) {
+      t = atomicAdd(next, 1u);
+      if (t >= ix.nseq) break;
+      k = t; n = 0; active = true;
+    }
+    const uint32_t c = symbol_at(ix, k);
+    if (c == 0 || n >= 0xfffffff0ull) {
+      const uint32_t q = c == 0 ? (uint32_t)rank_term(ix, k) : 0xffffffffu;
+      if (q >= ix.nseq) { atomicOr(bad, 1u); t_seq[t] = 0; }
+      else { t_seq[t] = q; len[q] = (uint32_t)n; }
+      active = false;
+    } else { k = rank_c(ix, c, k); n++; }
+  }
+}
+__global__ void __launch_bounds__(256)
+k_seq_walk_fill(DevIndex ix, uint32_t *next, const uint32_t *__restrict__ t_seq, const uint32_t *__restrict__ len, const uint64_t *__restrict__ off,
+                uint8_t *__restrict__ text, uint8_t *__restrict__ tpos5, uint32_t tv_shift) {
+  const uint64_t tvm = (1ull << tv_shift) - 1ull;
+  uint64_t k = 0, g = 0, left = 0;
+  bool active = false;
+  for (;;) {
+    if (!active) {
+      const uint32_t t = atomicAdd(next, 1u);
+      if (t >= ix.nseq) break;
+      const uint32_t q = t_seq[t];
+      k = t; g = off[(size_t)q + 1]; left = (uint64_t)len[q] + 1; active = true;
+    }
+    if ((k & tvm) == 0) put_tpos5(tpos5, k >> tv_shift, g);
+    const uint32_t c = symbol_at(ix, k);
+    text[g - 1] = (uint8_t)c;
+    if (c == 0 || --left == 0) active = false;
+    else { k = rank_c(ix, c, k); g--; }
+  }
+}
+
 // the same for indexes with 64-bit positions: 16-byte entries {lo, len}, counts relative to mb_base
 __global__ void __launch_bounds__(256)
 k_kmer_extend_wide(const RankBlock64 *__restrict__ blk, const uint64_t *__restrict__ mb_base, uint32_t mb_shift,
@@ -1016,6 +1061,63 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
       else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; }
     }
   }
+  // ---- the same for an index with 64-bit positions: the text (1 B per row) and the text position of every 2^tv_shift-th row
+  //      (5 B each), the densest sample that - with the temporaries of the build and 8 GB for the classification contexts -
+  //      fits in 60 % of the free HBM: every row at 4 G rows (26 GB).  Indexes of 2^34 rows and more only on request
+  //      (KAIJU_GPU_TV_SHIFT=s forces a sample; every second row at refseq_ref's 28 G rows would be 98 GB next to the index's
+  //      92 GB, nothing fits at refseq_nr's 58 G): measured on 4.35 G rows only (profiles/r04_wide_text) ----
+  d.sa_tpos5 = nullptr; d.tv_shift = 0;
+  uint64_t tpos_bytes = 0;
+  if (d.mb_base && d.blocks64 && d.term_pos && !getenv("KAIJU_GPU_NO_TEXT") && pk.bwtlen + 4 * (uint64_t)kTextPad < kTposNone) {
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const uint64_t tb_est = pk.bwtlen + 3 * (uint64_t)kTextPad, tmp = (uint64_t)pk.nseq * 16 + 64;
+    int tv = -1;
+    if (const char *e = getenv("KAIJU_GPU_TV_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 8) tv = v; }
+    else if (pk.bwtlen < (1ull << 34))
+      for (int v = 0; v <= 3 && tv < 0; v++)
+        if ((double)(tb_est + ((pk.bwtlen >> v) + 1) * 5 + tmp + (8ull << 30)) <= 0.6 * (double)free_b) tv = v;
+    if (tv >= 0) {
+      uint32_t *t_seq = nullptr, *d_len = nullptr, *d_cnt = nullptr;
+      uint64_t *d_off = nullptr;
+      uint8_t *text = nullptr, *tpos = nullptr;
+      tpos_bytes = ((pk.bwtlen >> tv) + 1) * 5 + 16;
+      bool ok = hipMalloc((void **)&t_seq, (size_t)pk.nseq * 4 + 16) == hipSuccess && hipMalloc((void **)&d_len, (size_t)pk.nseq * 4 + 16) == hipSuccess &&
+                hipMalloc((void **)&d_off, ((size_t)pk.nseq + 1) * 8) == hipSuccess && hipMalloc((void **)&d_cnt, 16) == hipSuccess;
+      if (ok) {
+        (void)hipMemset(d_cnt, 0, 16);
+        (void)hipMemset(d_len, 0, (size_t)pk.nseq * 4);
+        int n_cu = 256;
+        { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
+        const unsigned blocks = (unsigned)std::min<uint64_t>(((uint64_t)pk.nseq + 255) / 256, (uint64_t)n_cu * 8);
+        hipLaunchKernelGGL(k_seq_walk_len, dim3(blocks), dim3(256), 0, 0, d, d_cnt, t_seq, d_len, d_cnt + 1);
+        std::vector<uint32_t> len(pk.nseq);
+        std::vector<uint64_t> off((size_t)pk.nseq + 1);
+        uint32_t cnt[2] = {0, 0};
+        ok = hipMemcpy(len.data(), d_len, (size_t)pk.nseq * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(cnt, d_cnt, 8, hipMemcpyDeviceToHost) == hipSuccess && cnt[1] == 0;
+        off[0] = kTextPad;
+        for (uint32_t q = 0; q < pk.nseq; q++) off[(size_t)q + 1] = off[q] + len[q] + 1;
+        text_bytes = off[pk.nseq] + 2 * kTextPad;
+        // (every row lies on exactly one walk: the lengths add up to the rows of the index, or the index is damaged)
+        ok = ok && off[pk.nseq] - kTextPad == pk.bwtlen && text_bytes < kTposNone &&
+             hipMemcpy(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMalloc((void **)&text, text_bytes) == hipSuccess && hipMalloc((void **)&tpos, tpos_bytes) == hipSuccess;
+        if (ok) {
+          (void)hipMemset(text, 0, text_bytes);
+          (void)hipMemset(tpos, 0xff, tpos_bytes);
+          (void)hipMemset(d_cnt, 0, 16);
+          hipLaunchKernelGGL(k_seq_walk_fill, dim3(blocks), dim3(256), 0, 0, d, d_cnt, t_seq, d_len, d_off, text, tpos, (uint32_t)tv);
+          ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+        }
+      }
+      (void)hipGetLastError();
+      for (void *q : {(void *)t_seq, (void *)d_len, (void *)d_off, (void *)d_cnt}) if (q) (void)hipFree(q);
+      if (ok) { ix->allocs.push_back(text); ix->allocs.push_back(tpos); d.text = text; d.sa_tpos5 = tpos; d.tv_shift = (uint32_t)tv; }
+      else { if (text) (void)hipFree(text); if (tpos) (void)hipFree(tpos); text_bytes = 0; tpos_bytes = 0; }
+    }
+    lc.mark("text + text positions (device, 64-bit rows)");
+  } else
   lc.mark("text + full suffix array (device)");
   kaiju_gpu_index_info &inf = ix->info;
   memset(&inf, 0, sizeof inf);
@@ -1036,7 +1138,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     f.kmer_lines = d.kline ? nw / 20 * kKLineBytes : 0;
     f.other = sizeof(ConstTables) + sizeof(Stage1Tables) + lnfact.size() * 8;
     f.text = d.text ? text_bytes : 0;
-    f.sa_full = d.sa_full ? pk.bwtlen * 8 : 0;                 // (+ the sequence of every row, DevIndex::row_seq)
+    f.sa_full = d.sa_full ? pk.bwtlen * 8 : d.sa_tpos5 ? tpos_bytes : 0;   // (+ the sequence of every row, DevIndex::row_seq; wide: the text positions)
     f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other + f.text + f.sa_full;
     f.kmer_k = d.kmer_k; f.wide = d.mb_base ? 1u : 0u;
     inf.device_bytes = f.total;

@@ -556,8 +556,41 @@ int PackedIndex::read_image(const char *path, std::string &msg, bool lazy_big) {
 // The text and the full suffix array of a narrow index, on the host (test emulation; capi.hip runs the same steps as
 // kernels: k_suffix_walk, k_text_build): every row's (sequence, offset) by get_suffix, the sequences' lengths from the rows
 // of their terminator suffixes, sequence s (in the numbering of the samples) at text[off[s]] = 0, text[off[s] + 1 ..] = residues.
+void PackedIndex::build_text_wide(uint32_t shift) {
+  sa_full.clear(); text.clear(); row_seq.clear(); sa_tpos5.clear();
+  tv_shift = shift;
+  if (!wide || blocks64.empty() || term_pos.empty() || shift > 8) return;
+  const DevIndex d = host_view();
+  std::vector<uint32_t> t_seq(nseq), len(nseq, 0);
+  std::atomic<bool> ok{true};
+  parallel_for(((uint64_t)nseq + 255) / 256, [&](uint64_t chunk) {
+    const uint64_t b = chunk * 256, e = std::min<uint64_t>(nseq, b + 256);
+    for (uint64_t t = b; t < e; t++) {
+      uint32_t q = 0;
+      const uint64_t n = seq_walk_len(d, t, q);
+      if (q >= nseq || n >= 0xffffffffull) { ok = false; q = 0; }
+      t_seq[(size_t)t] = q;
+      len[q] = (uint32_t)n;                    // (every sequence is the end of exactly one walk)
+    }
+  });
+  if (!ok.load()) return;
+  std::vector<uint64_t> off((size_t)nseq + 1, 0);
+  off[0] = kTextPad;
+  for (uint32_t q = 0; q < nseq; q++) off[(size_t)q + 1] = off[q] + len[q] + 1;
+  if (off[nseq] + 2 * kTextPad >= kTposNone) return;
+  text.assign((size_t)(off[nseq] + 2 * kTextPad), 0);
+  sa_tpos5.assign((size_t)(((bwtlen >> shift) + 1) * 5 + 16), 0xff);
+  parallel_for(((uint64_t)nseq + 255) / 256, [&](uint64_t chunk) {
+    const uint64_t b = chunk * 256, e = std::min<uint64_t>(nseq, b + 256);
+    for (uint64_t t = b; t < e; t++) {
+      const uint32_t q = t_seq[(size_t)t];
+      seq_walk_fill(d, t, off[(size_t)q + 1], len[q], text.data(), sa_tpos5.data(), shift);
+    }
+  });
+}
+
 void PackedIndex::build_text() {
-  sa_full.clear(); text.clear(); row_seq.clear();
+  sa_full.clear(); text.clear(); row_seq.clear(); sa_tpos5.clear();
   if (wide || sa_pos.empty() || blocks64.empty() || bwtlen + nseq + 2 * kTextPad >= 0xffffffffull) return;
   const DevIndex d = host_view();
   BigVec<uint32_t> rs((size_t)bwtlen), rp((size_t)bwtlen);
@@ -629,6 +662,7 @@ DevIndex PackedIndex::host_view() const {
   d.sa_full = sa_full.empty() ? nullptr : sa_full.data();
   d.text = text.empty() ? nullptr : text.data();
   d.row_seq = row_seq.empty() ? nullptr : row_seq.data();
+  d.sa_tpos5 = sa_tpos5.empty() ? nullptr : sa_tpos5.data(); d.tv_shift = tv_shift;
   return d;
 }
 

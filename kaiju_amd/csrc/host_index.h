@@ -91,6 +91,9 @@ struct PackedIndex {
   // text verification (DevIndex::sa_full / text), built on the HOST for the test emulation only - the device builds its own
   BigVec<uint32_t> sa_full, row_seq;
   BigVec<uint8_t> text;
+  BigVec<uint8_t> sa_tpos5;       // wide layout: DevIndex::sa_tpos5 (text position of every 2^tv_shift-th row)
+  uint32_t tv_shift = 0;
+  void build_text_wide(uint32_t shift);   // fills text / sa_tpos5 of a wide index (seq_walk_len / seq_walk_fill, kj_core.h)
   void build_text();                // fills sa_full / text (call after build / read_image); leaves them empty if not applicable
   std::vector<uint64_t> seq_taxid;
   std::vector<uint8_t> seq_valid;

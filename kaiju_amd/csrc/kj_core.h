@@ -100,9 +100,20 @@ struct DevIndex {
   const uint8_t *text;       // 64 zero bytes, then per sequence (in the order of the sampled sequence numbers) 0 + its residues
   const uint32_t *row_seq;   // [bwtlen] the sequence the suffix of row r lies in, as get_suffix finds it by walking to a sampled row
                              // (built along with sa_full): k_mem_locate reads an id with two loads instead of walking; nullptr = walk
+  // the same for indexes with 64-bit positions (mb_base set) that leave room: text[] as above and the position in it of the
+  // suffix of every 2^tv_shift-th row, 40 bits each (tv_shift = 0 where HBM allows, e.g. 6 B per row at 4 G rows; 1 at
+  // refseq_ref's 28 G rows: 3.5 B per row).  A one-row search steps on until its row is one of those (tv_shift = 1: one more
+  // step on average), then compares with the text as the narrow lane does.
+  const uint8_t *sa_tpos5;   // [(bwtlen >> tv_shift) + 1] entries of 5 bytes (little endian), 16 bytes of padding behind; nullptr = none
+  uint32_t tv_shift;
 };
+constexpr uint64_t kTposNone = (1ull << 40) - 1ull;
 constexpr uint32_t kBeyondRowsMax = 4096;    // rows whose walk passes the missing sample of a KAIJU_IDX_WARN_SA_SHORT index (a few)
 constexpr uint32_t kTextPad = 64;            // zero bytes in front of the first sequence (a text window never starts below 0)
+#ifndef KJ_TEXT_CMP
+#define KJ_TEXT_CMP 48
+#endif
+constexpr int kTextCmp = KJ_TEXT_CMP;        // letters one K_TEXT round compares (a multiple of 4, at most kWin = the 64 bytes loaded)
 constexpr int kTextMinLeft = 3;              // letters left in front of the match for the text comparison to be worth its two loads
 constexpr int kTextTrigLen = 9;              // ... and the match at least this long: intervals shrink to one row at six to eight letters
                                              // (190 M to 4 G rows) and four of five such matches end right there - the ones that
@@ -342,7 +353,10 @@ KJ_HD uint32_t kj_rank_below(uint64_t mask) {
 KJ_HD uint32_t kj_bcast_uniform(uint32_t v, uint32_t src_lane) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)src_lane));
 }
+// bytes s .. s+3 (s = 0..3) of the eight bytes lo, hi (v_alignbyte_b32)
+KJ_HD uint32_t kj_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbyte(hi, lo, s); }
 #else
+KJ_HD uint32_t kj_alignbyte(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (s & 3u))); }
 KJ_HD uint64_t kj_ballot(bool p) { return p ? 1ull : 0ull; }
 KJ_HD uint32_t kj_lane() { return 0; }
 KJ_HD uint32_t kj_bcast(uint32_t v, uint32_t) { return v; }
@@ -465,6 +479,39 @@ KJ_HD bool suffix_of_row(const DevIndex &ix, const uint32_t *smp_pos, uint64_t r
     steps++;
     if (c == 0) { iseq = (uint32_t)rank_term(ix, k); pos = steps - 1u; return true; }
     k = rank_c(ix, c, k);
+  }
+}
+
+// Text arrays of an index with 64-bit positions, built by walking every SEQUENCE once from its terminator suffix (rows
+// 0 .. nseq-1) to its first letter: one LF step per index row and no sample offsets (suffix_of_row costs 2^chpt_exp - 1
+// steps per row on average and wants the offset of every sampled row, which the wide layout does not keep).
+//   seq_walk_len:  length of the sequence that ends at terminator row t, and its number (the rank of the terminator that the
+//                  walk ends at, as in suffix_of_row)
+//   seq_walk_fill: g_end = text position of that terminator (off[iseq + 1] in the layout of DevIndex::text); every row on
+//                  the way writes its BWT letter in front of its suffix and - if it is a 2^tv_shift-th row - its position
+KJ_HD uint64_t seq_walk_len(const DevIndex &ix, uint64_t t, uint32_t &iseq) {
+  uint64_t k = t, n = 0;
+  for (;;) {
+    const uint32_t c = symbol_at(ix, k);
+    if (c == 0) { iseq = (uint32_t)rank_term(ix, k); return n; }
+    k = rank_c(ix, c, k);
+    if (++n > ix.bwtlen) { iseq = 0xffffffffu; return n; }      // (a damaged index: no walk is longer than the text)
+  }
+}
+KJ_HD void put_tpos5(uint8_t *a, uint64_t idx, uint64_t g) {
+  uint8_t *e = a + idx * 5u;
+  e[0] = (uint8_t)g; e[1] = (uint8_t)(g >> 8); e[2] = (uint8_t)(g >> 16); e[3] = (uint8_t)(g >> 24); e[4] = (uint8_t)(g >> 32);
+}
+KJ_HD void seq_walk_fill(const DevIndex &ix, uint64_t t, uint64_t g_end, uint64_t n, uint8_t *text, uint8_t *tpos5, uint32_t tv_shift) {
+  const uint64_t tvm = (1ull << tv_shift) - 1ull;
+  uint64_t k = t, g = g_end;
+  for (uint64_t step = 0; step <= n; step++) {
+    if ((k & tvm) == 0) put_tpos5(tpos5, k >> tv_shift, g);
+    const uint32_t c = symbol_at(ix, k);
+    text[g - 1] = (uint8_t)c;
+    if (c == 0) return;
+    k = rank_c(ix, c, k);
+    g--;
   }
 }
 
@@ -2114,7 +2161,7 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // from the wave's chunk with a ballot/prefix count.
 // ----------------------------------------------------------------------------
 enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT,
-                     K_SAPOS, K_TEXT,     // text verification (narrow): suffix-array entry of the row, then the text in front of it
+                     K_SAPOS, K_TEXT,     // text verification: suffix-array entry of the row, then the text in front of it
                      K_PROBE,             // narrow: a k-mer lookup that decides L-k+1 end positions at once (kMemProbe)
                      K_BK = 16 };         // K_BK + b: bookkeeping block b of MemBk is due (no memory access)
 enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
@@ -2306,14 +2353,16 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
     if (is_kmer) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
     else if (kind == K_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
-    else if (!WIDE && kind == K_SAPOS) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_full + lo);
+    else if (kind == K_SAPOS) gaddr = WIDE ? ix.sa_tpos5 + (size_t)((uint64_t)lo >> ix.tv_shift) * 5u : reinterpret_cast<const uint8_t *>(ix.sa_full + lo);
     else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == K_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == K_FILL && fill_newfrag && f < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + f);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
     // 16 bytes: aligned around an 8- or 16-byte item, or (k-mer line) starting at the 2-byte aligned entry
-    const u128 gv = *reinterpret_cast<const u128_unaligned *>(kline_step ? reinterpret_cast<uintptr_t>(gaddr)
-                                                                          : reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
+    // (... or, wide, at the 5-byte entry of a text position)
+    const bool g_asis = kline_step || (WIDE && kind == K_SAPOS);
+    const u128 gv = *reinterpret_cast<const u128_unaligned *>(g_asis ? reinterpret_cast<uintptr_t>(gaddr)
+                                                                     : reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
     u128 w0{0, 0}, w1{0, 0}, w2{0, 0}, w3{0, 0};
     int fq = 0;
     if (kj_ballot(kind == K_FILL || kind == K_TEXT)) {     // wave-uniform
@@ -2321,8 +2370,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       fq = fill_top - (kWin - 1);
       if (fq < 0) fq = 0;
       // (K_TEXT: the 64 bytes of the database that lie where fragment positions 0..63 would if the match went on)
-      const uint8_t *src = kind == K_FILL ? b.pep + fsoff + fq : (!WIDE && kind == K_TEXT) ? ix.text + (kidx - (uint32_t)i)
-                                                                                           : reinterpret_cast<const uint8_t *>(blk0);
+      // (K_TEXT: the kTextCmp bytes of the database in front of the suffix, i.e. where fragment positions i-kTextCmp .. i-1 would lie)
+      const uint8_t *src = kind == K_FILL ? b.pep + fsoff + fq : kind != K_TEXT ? reinterpret_cast<const uint8_t *>(blk0)
+                           : WIDE ? ix.text + (size_t)((uint64_t)k - (uint64_t)kTextCmp) : ix.text + (kidx - (uint32_t)kTextCmp);
       const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
       w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
     }
@@ -2346,8 +2396,10 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           KJ_HIST_SINGLE(hi - lo == 1, j - i + 1);
           if (i == 0) bk = BK_END_MATCH;
           else if (WIDE && pj >= 0 && j - i + 1 >= (int)pw) bk = BK_END_MATCH;   // a probe whose word is in the index: no need to go on
-          else if (!WIDE && ix.text && hi - lo == 1 && j - i + 1 >= kTextTrigLen && i >= kTextMinLeft && lw.q == 0 && i <= kWin) {
-            // one row left and letters to go: the rest of this match is read off the database text (K_SAPOS, K_TEXT)
+          else if ((WIDE ? ix.sa_tpos5 != nullptr && ((uint64_t)lo & ((1ull << ix.tv_shift) - 1ull)) == 0 : ix.text != nullptr) &&
+                   hi - lo == 1 && j - i + 1 >= kTextTrigLen && i >= kTextMinLeft && lw.q == 0 && i <= kWin) {
+            // one row left and letters to go: the rest of this match is read off the database text (K_SAPOS, K_TEXT).
+            // (wide: only rows whose text position is kept - the search steps on until it stands on one)
             kind = K_SAPOS;
           }
           else if (in_win(i - 1)) c = lw.w[i - 1 - lw.q];
@@ -2446,27 +2498,52 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       row++;
       k = row; fresh = true;
       bk = BK_LOC_ROW;
-    } else if (!WIDE && kind == K_SAPOS) {
+    } else if (kind == K_SAPOS) {
       // position in the text of the suffix of row lo = of fragment position i
-      const uint32_t q = (uint32_t)lo & 3u;
-      kidx = q == 0 ? (uint32_t)gv.x : q == 1 ? (uint32_t)(gv.x >> 32) : q == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
-      kind = K_TEXT;
-    } else if (!WIDE && kind == K_TEXT) {
+      if constexpr (WIDE) {
+        k = (P)(gv.x & kTposNone);                            // (k: free until the locate)
+        if ((uint64_t)k == kTposNone) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }   // no position known for this row: the search steps on
+        else kind = K_TEXT;
+      } else {
+        const uint32_t q = (uint32_t)lo & 3u;
+        kidx = q == 0 ? (uint32_t)gv.x : q == 1 ? (uint32_t)(gv.x >> 32) : q == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
+        kind = K_TEXT;
+      }
+    } else if (kind == K_TEXT) {
       // UpdateSI on a one-row interval succeeds iff the letter in front of the suffix is the next letter of the read
       // (bwt.c:160-173 with hi - lo = 1): the match ends in front of the highest position x < i whose letter differs from the
-      // text's (a terminator, 0, differs from every letter), or at the start of the fragment
+      // text's (a terminator, 0, differs from every letter), or at the start of the fragment.  kTextCmp letters per round: text
+      // dword q holds what fragment positions i-kTextCmp+4q .. +3 are compared with; the window's bytes are brought into that
+      // alignment with one byte-align per dword.  Whatever stands below position 0 (the window words are clamped to the
+      // window) may differ or not: a difference there means "down to the start of the fragment" as well
       const uint32_t *w32 = reinterpret_cast<const uint32_t *>(lw.w);
-      const uint64_t t8[8] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
-      int x = -1;
+      const uint32_t t32[16] = {(uint32_t)w0.x, (uint32_t)(w0.x >> 32), (uint32_t)w0.y, (uint32_t)(w0.y >> 32),
+                                (uint32_t)w1.x, (uint32_t)(w1.x >> 32), (uint32_t)w1.y, (uint32_t)(w1.y >> 32),
+                                (uint32_t)w2.x, (uint32_t)(w2.x >> 32), (uint32_t)w2.y, (uint32_t)(w2.y >> 32),
+                                (uint32_t)w3.x, (uint32_t)(w3.x >> 32), (uint32_t)w3.y, (uint32_t)(w3.y >> 32)};
+      const int d0 = (i >> 2) - (kTextCmp >> 2);            // window dword of position i - 32 (rounded down)
+      const uint32_t sh = (uint32_t)i & 3u;
+      uint32_t lo32 = w32[d0 < 0 ? 0 : d0];
+      int best = -0x10000;
 #pragma unroll
-      for (int wi = 0; wi < 8; wi++) {
-        const int nb = i - 8 * wi;                          // bytes of this word below position i
-        const uint64_t mask = nb >= 8 ? ~0ull : nb <= 0 ? 0ull : ((1ull << (8 * nb)) - 1ull);
-        const uint64_t d = (t8[wi] ^ ((uint64_t)w32[2 * wi] | (uint64_t)w32[2 * wi + 1] << 32)) & mask;
-        if (d) x = 8 * wi + ((63 - (int)__builtin_clzll(d)) >> 3);
+      for (int q = 0; q < (kTextCmp >> 2); q++) {
+        const int dq = d0 + q + 1;
+        const uint32_t hi32 = w32[dq < 0 ? 0 : dq > (kWin >> 2) - 1 ? (kWin >> 2) - 1 : dq];
+        const uint32_t d = t32[q] ^ kj_alignbyte(hi32, lo32, sh);
+        // highest differing byte of this dword: 4q + 3 - clz / 8 (no difference: far below every other candidate)
+        const int cand = d ? 4 * q + 3 - (int)((uint32_t)__builtin_clz(d) >> 3) : -0x10000;
+        best = cand > best ? cand : best;
+        lo32 = hi32;
       }
-      i = x + 1;
-      bk = BK_END_MATCH;                                    // (lo, hi still name the one row the search had reached: same sequence)
+      if (best >= 0 || i <= kTextCmp) {
+        const int x = best >= 0 ? i - kTextCmp + best : -1;
+        i = x < 0 ? 0 : x + 1;
+        bk = BK_END_MATCH;                                  // (lo, hi still name the one row the search had reached: same sequence)
+      } else {
+        // all of them agree and there are more: one more round (fragments this long are rare: i <= kWin at the first one)
+        i -= kTextCmp;
+        if constexpr (WIDE) k -= (P)kTextCmp; else kidx -= (uint32_t)kTextCmp;
+      }
     } else if (kind >= K_BK) {
       bk = kind - K_BK;                                      // a bookkeeping block left over from the last iteration
     } else if (kind == K_META) {

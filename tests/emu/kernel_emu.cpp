@@ -36,7 +36,12 @@ void *emu_index_load(const char *path, char *err, int errlen) {
   int rc = ix->file.load(path, msg);
   if (rc == 0) rc = ix->packed.build(ix->file.view(), msg);
   if (rc == 0) ix->packed.build_klines();          // (the device builds its k-mer lines in capi.hip: k_kline_build)
-  if (rc == 0 && !getenv("KAIJU_EMU_NO_TEXT")) ix->packed.build_text();   // (... and its text / full suffix array: k_suffix_walk, k_text_build)
+  if (rc == 0 && !getenv("KAIJU_EMU_NO_TEXT")) {
+    // (... and its text arrays: k_suffix_walk, k_text_build; wide: k_seq_walk_len, k_seq_walk_fill - text positions of every
+    //  2^KAIJU_EMU_TV_SHIFT-th row, default every second one so that searches both wait for such a row and stand on one)
+    if (ix->packed.wide) ix->packed.build_text_wide(getenv("KAIJU_EMU_TV_SHIFT") ? (uint32_t)atoi(getenv("KAIJU_EMU_TV_SHIFT")) : 1u);
+    else ix->packed.build_text();
+  }
   if (rc == 0) rc = build_const_tables(ix->packed.trans, ix->ct, msg);
   if (rc == 0) rc = build_seg_tables(ix->lnfact, ix->st, msg);
   if (rc != 0) { snprintf(err, (size_t)errlen, "%s", msg.c_str()); delete ix; return nullptr; }
@@ -53,7 +58,7 @@ void *emu_index_load_x(const char *path, char *err, int errlen) {
 void emu_index_free(void *h) { delete (EmuIndex *)h; }
 uint32_t emu_index_warnings(void *h) { return ((EmuIndex *)h)->packed.warnings; }
 // 1: the text arrays of text verification were built (sa_full / text / row_seq); number of rows whose row_seq says "no sequence"
-int emu_has_text(void *h) { return ((EmuIndex *)h)->packed.sa_full.empty() ? 0 : 1; }
+int emu_has_text(void *h) { return ((EmuIndex *)h)->packed.sa_full.empty() && ((EmuIndex *)h)->packed.sa_tpos5.empty() ? 0 : 1; }
 uint64_t emu_rows_without_sequence(void *h) {
   uint64_t n = 0;
   for (uint32_t v : ((EmuIndex *)h)->packed.row_seq) n += v == 0xffffffffu;

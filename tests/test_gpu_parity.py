@@ -139,6 +139,41 @@ def test_wide_index_path(gpu_lib, golden, oracle, ohandles, shift, monkeypatch):
             assert not bad, (shift, mode, pe, bad[:5])
 
 
+@pytest.mark.gpu
+def test_text_positions_of_an_index_with_64_bit_rows(gpu_lib, oracle, tmp_path, monkeypatch):
+    """Wide layout with the database text and the text position of every 2^tv_shift-th row (k_seq_walk_len / k_seq_walk_fill at
+    index load, K_SAPOS / K_TEXT in k_mem_wide2): every sample density - and no text at all - gives the oracle's records"""
+    api = gpu_lib
+    from kaiju_amd import mkfmi, synth
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=6000, seed=21, leaves=leaves, max_len=900)
+    faa, fmi = str(tmp_path / "db.faa"), str(tmp_path / "db.fmi")
+    synth.write_fasta(db, faa)
+    mkfmi.build_fmi(faa, fmi, threads=4, exponent=3)
+    seqs, off = synth.pack_reads(synth.make_reads(db, 30000, seed=9))
+    m1, m2 = synth.make_pairs(db, 5000, seed=10)
+    pseqs, poff = synth.pack_reads(m1, m2)
+    ix = oracle.load_fmi(fmi)
+    want = {pe: oracle.classify(ix, None, oracle.params("mem", seg=1), s, o, paired=pe) for s, o, pe in ((seqs, off, False), (pseqs, poff, True))}
+    monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", "18")
+    for tv in ("none", "auto", "0", "1", "3"):
+        monkeypatch.delenv("KAIJU_GPU_NO_TEXT", raising=False)
+        monkeypatch.delenv("KAIJU_GPU_TV_SHIFT", raising=False)
+        if tv == "none":
+            monkeypatch.setenv("KAIJU_GPU_NO_TEXT", "1")
+        elif tv != "auto":
+            monkeypatch.setenv("KAIJU_GPU_TV_SHIFT", tv)
+        idx = api.Index(fmi)
+        fp = idx.footprint
+        assert fp.wide == 1 and (fp.text > 0) == (tv != "none") and (fp.sa_full > 0) == (tv != "none")
+        clf = api.Classifier(idx, api.default_params("mem", seg=1))
+        for s, o, pe in ((seqs, off, False), (pseqs, poff, True)):
+            hits = clf.classify(s, o, paired=pe)
+            assert clf.stats().error_flags == 0
+            bad = [i for i in range(len(hits)) if not util.same_hit(want[pe][i], hits[i])]
+            assert not bad, (tv, pe, bad[:5])
+
+
 def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
     """an index loaded from its device image classifies exactly like the one packed from the .fmi"""
     api = gpu_lib

@@ -734,3 +734,37 @@ def test_text_arrays_on_an_index_with_the_short_sample_array(tmp_path, monkeypat
             bad = np.nonzero(a != b)[0]
             assert len(bad) <= 3 and all(b[i]["n_ids"] < a[i]["n_ids"] for i in bad), (mode, pe, bad[:5])
             assert (a["n_ids"] > 0).mean() > 0.4
+
+
+def test_text_positions_of_an_index_with_64_bit_rows(oracle, tmp_path, monkeypatch):
+    """Wide layout: the database text and the text position of every 2^tv_shift-th row (DevIndex::sa_tpos5, built by walking
+    every sequence once: seq_walk_len / seq_walk_fill).  A one-row search steps on until it stands on such a row and then
+    compares with the text.  Every sample density gives the oracle's records - and the records of the lanes without the text."""
+    import ctypes as C
+    from kaiju_amd import mkfmi, synth
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=2500, seed=21, leaves=leaves, max_len=900)
+    faa, fmi = str(tmp_path / "db.faa"), str(tmp_path / "db.fmi")
+    synth.write_fasta(db, faa)
+    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+    seqs, off = synth.pack_reads(synth.make_reads(db, 4000, seed=9))
+    m1, m2 = synth.make_pairs(db, 600, seed=10)
+    pseqs, poff = synth.pack_reads(m1, m2)
+    ix = oracle.load_fmi(fmi)
+    want = {pe: oracle.classify(ix, None, oracle.params("mem", seg=1), s, o, paired=pe) for s, o, pe in ((seqs, off, False), (pseqs, poff, True))}
+    emu = util.Emu()
+    emu.lib.emu_has_text.argtypes = [C.c_void_p]
+    monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", "18")
+    for tv in ("none", "0", "1", "2", "3", "5"):
+        if tv == "none":
+            monkeypatch.setenv("KAIJU_EMU_NO_TEXT", "1")
+        else:
+            monkeypatch.delenv("KAIJU_EMU_NO_TEXT", raising=False)
+            monkeypatch.setenv("KAIJU_EMU_TV_SHIFT", tv)
+        h = emu.load(fmi)
+        assert emu.lib.emu_has_text(h) == (0 if tv == "none" else 1)
+        for s, o, pe in ((seqs, off, False), (pseqs, poff, True)):
+            got, _ = emu.classify(h, util.gp("mem"), s, o, paired=pe)
+            bad = [i for i in range(len(got)) if not util.same_hit(want[pe][i], got[i])]
+            assert not bad, (tv, pe, bad[:5])
+        emu.lib.emu_index_free(h)

@@ -14,7 +14,7 @@ reads = np.load(f"{W}/reads.npy")
 if len(sys.argv) > 5:
     reads = reads[: int(sys.argv[5])]
 seqs, off = synth.pack_reads(reads)
-index = api.Index(f"{W}/db.fmi")
+index = api.Index(os.environ.get("PROF_RUN_INDEX", f"{W}/db.fmi"))       # (PROF_RUN_INDEX: e.g. an image of the same index)
 clf = api.Classifier(index, api.default_params(mode, seg=seg))
 for _ in range(reps):
     hits = clf.classify(seqs, off)
