@@ -15,6 +15,8 @@ for ctrs in \
   "WRITE_SIZE" \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" ; do
   i=$((i+1))
+  # (PMC_PASSES="1 2": only those counter groups - the request counts the traffic figure is made of)
+  if [ -n "$PMC_PASSES" ]; then case " $PMC_PASSES " in *" $i "*) ;; *) continue ;; esac; fi
   timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pass$i -o p -- \
     python $R/bench.py --contexts 1 --steps 1 --warmup 0 --no-cpu-baseline --legs greedy,paired > $OUT/pass$i.json 2> $OUT/pass$i.log
   echo "pass $i rc=$? : $ctrs"
