@@ -59,6 +59,16 @@ void emu_index_free(void *h) { delete (EmuIndex *)h; }
 uint32_t emu_index_warnings(void *h) { return ((EmuIndex *)h)->packed.warnings; }
 // 1: the text arrays of text verification were built (sa_full / text / row_seq); number of rows whose row_seq says "no sequence"
 int emu_has_text(void *h) { return ((EmuIndex *)h)->packed.sa_full.empty() && ((EmuIndex *)h)->packed.sa_tpos5.empty() ? 0 : 1; }
+// the text arrays themselves (tests: the sequence walk of the wide layout builds what the per-row walk of the narrow one does)
+const uint8_t *emu_text(void *h, uint64_t *n) { const auto &t = ((EmuIndex *)h)->packed.text; *n = t.size(); return t.data(); }
+// text position of the suffix of row r: narrow sa_full[r]; wide the 5-byte entry of r (kTposNone-like ~0 when r is not a kept row)
+uint64_t emu_text_pos(void *h, uint64_t r) {
+  const PackedIndex &pk = ((EmuIndex *)h)->packed;
+  if (!pk.sa_full.empty()) return r < pk.sa_full.size() ? pk.sa_full[(size_t)r] : ~0ull;
+  if (pk.sa_tpos5.empty() || (r & ((1ull << pk.tv_shift) - 1ull)) || r >= pk.bwtlen) return ~0ull;
+  const uint8_t *e = pk.sa_tpos5.data() + (size_t)(r >> pk.tv_shift) * 5;
+  return (uint64_t)e[0] | (uint64_t)e[1] << 8 | (uint64_t)e[2] << 16 | (uint64_t)e[3] << 24 | (uint64_t)e[4] << 32;
+}
 uint64_t emu_rows_without_sequence(void *h) {
   uint64_t n = 0;
   for (uint32_t v : ((EmuIndex *)h)->packed.row_seq) n += v == 0xffffffffu;

@@ -754,6 +754,21 @@ def test_text_positions_of_an_index_with_64_bit_rows(oracle, tmp_path, monkeypat
     want = {pe: oracle.classify(ix, None, oracle.params("mem", seg=1), s, o, paired=pe) for s, o, pe in ((seqs, off, False), (pseqs, poff, True))}
     emu = util.Emu()
     emu.lib.emu_has_text.argtypes = [C.c_void_p]
+    emu.lib.emu_text.restype = C.POINTER(C.c_uint8)
+    emu.lib.emu_text.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    emu.lib.emu_text_pos.restype = C.c_uint64
+    emu.lib.emu_text_pos.argtypes = [C.c_void_p, C.c_uint64]
+
+    def arrays(h, rows):
+        n = C.c_uint64(0)
+        t = emu.lib.emu_text(h, C.byref(n))
+        return bytes(np.ctypeslib.as_array(t, shape=(n.value,))), [emu.lib.emu_text_pos(h, r) for r in rows]
+    # the narrow layout's arrays (one get_suffix walk per row) are what the wide layout's sequence walks must reproduce
+    monkeypatch.delenv("KAIJU_GPU_FORCE_WIDE", raising=False)
+    h = emu.load(fmi)
+    rows = list(range(0, int(db.total_aa) + db.nseq, 7))          # every seventh row of the index
+    text_narrow, pos_narrow = arrays(h, rows)
+    emu.lib.emu_index_free(h)
     monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", "18")
     for tv in ("none", "0", "1", "2", "3", "5"):
         if tv == "none":
@@ -763,6 +778,11 @@ def test_text_positions_of_an_index_with_64_bit_rows(oracle, tmp_path, monkeypat
             monkeypatch.setenv("KAIJU_EMU_TV_SHIFT", tv)
         h = emu.load(fmi)
         assert emu.lib.emu_has_text(h) == (0 if tv == "none" else 1)
+        if tv != "none":
+            text_wide, pos_wide = arrays(h, rows)
+            assert text_wide == text_narrow
+            keep = (1 << int(tv)) - 1
+            assert all(pw == (pn if r & keep == 0 else 2**64 - 1) for r, pn, pw in zip(rows, pos_narrow, pos_wide)), tv
         for s, o, pe in ((seqs, off, False), (pseqs, poff, True)):
             got, _ = emu.classify(h, util.gp("mem"), s, o, paired=pe)
             bad = [i for i in range(len(got)) if not util.same_hit(want[pe][i], got[i])]
