@@ -2,6 +2,8 @@
 # A/B of compile-time variants of the search lanes.  One library per variant under kaiju_amd/variants/ (git-ignored,
 # travels to the GPU box with the snapshot):
 #   mem_variants.sh build                      here (hipcc cross-compiles; ~35 s per variant)
+#   mem_variants.sh build_rev <rev> [tag]      here: the library of another commit (git archive of its sources into a temporary
+#                                              directory) as variants/libkaiju_gpu_<tag>.so - the "before" of an A/B (default tag: head)
 #   mem_variants.sh run <outdir> [mode] [n]    on the GPU box: the prepared workload with each library, search times and a
 #                                              checksum of the records (all variants must agree)
 # VARIANTS="cur prof" (default: the current source, the section profiler); add entries to DEF for new experiments.  Round 3
@@ -17,6 +19,14 @@ if [ "$1" = build ]; then
   for v in $LIST; do
     /opt/rocm/bin/hipcc $FLAGS ${DEF[$v]} -o $V/libkaiju_gpu_$v.so $SRC -lpthread && echo "built $v" || echo "$v: build failed"
   done
+  exit 0
+fi
+if [ "$1" = build_rev ]; then
+  REV=${2:?revision}; TAG=${3:-head}
+  T=$(mktemp -d) && mkdir -p $V
+  ( cd $R && git archive $REV kaiju_amd/csrc include ) | tar -x -C $T || { echo "no such revision: $REV"; exit 1; }
+  ( cd $T && /opt/rocm/bin/hipcc $FLAGS -o $V/libkaiju_gpu_$TAG.so $(echo $SRC | sed "s#$R/##g") -lpthread ) && echo "built $TAG from $REV" || echo "$TAG: build failed"
+  rm -rf $T
   exit 0
 fi
 OUT=$2; MODE=${3:-mem}; N=${4:-4000000}
