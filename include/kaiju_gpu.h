@@ -172,6 +172,14 @@ int kaiju_gpu_index_image_source_bytes(const char *image_path, uint64_t *fmi_byt
 int kaiju_gpu_index_image_info(const char *image_path, kaiju_gpu_index_info *info, uint64_t *streamed_bytes);
 
 int kaiju_gpu_index_get_info(const kaiju_gpu_index *ix, kaiju_gpu_index_info *info);
+/* Diagnostics: a position-sensitive 64-bit digest of every array the index holds in HBM (computed by a kernel, nothing is
+   copied back), so that two ways of loading one index - packed on the host, streamed from an image, streamed from the .fmi
+   and packed on the device (KAIJU_GPU_FMI_STREAM) - can be compared array by array at any size.  out[]: [0] rank blocks,
+   [1] count bases, [2] sampled sequence numbers, [3] taxon ids of the samples, [4] terminator rows, [5] taxon id and [6]
+   validity per sequence, [7] k-mer table, [8] k-mer lines, [9] text, [10] full suffix array / 40-bit text positions,
+   [11] sequence of every row, [12] k (letters of the k-mer table), [13] C[] ; 0 for an array the index does not have. */
+#define KAIJU_GPU_N_DIGESTS 14
+int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, uint32_t n_out);
 
 /* What the index occupies in HBM, array by array (bytes).  Per index row: rank blocks 2 B; suffix-array sample at exponent e:
    4 / 2^e B of sequence numbers and - indexes below 2^32 rows only - 8 / 2^e B of taxon ids; the k-mer table and its lines

@@ -155,6 +155,17 @@ class Index:
     def db_length(self):
         return self.info.db_length
 
+    DIGEST_NAMES = ("rank_blocks", "count_bases", "sa_seq", "sa_taxid", "term_rows", "seq_taxid", "seq_valid", "kmer_table",
+                    "kmer_lines", "text", "sa_full", "row_seq", "kmer_k", "C")
+
+    def digest(self) -> dict:
+        """kaiju_gpu_index_digest: a digest of every array this index holds in HBM (two loads of one index compare equal)"""
+        L = lib()
+        L.kaiju_gpu_index_digest.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        out = np.zeros(len(self.DIGEST_NAMES), dtype=np.uint64)
+        _check(L.kaiju_gpu_index_digest(self._h, out.ctypes.data, len(out)))
+        return {k: int(v) for k, v in zip(self.DIGEST_NAMES, out)}
+
     def close(self):
         if self._h:
             lib().kaiju_gpu_index_free(self._h)

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/kaiju_gpu.h"
+#include "fmi_stream.h"
 #include "host_index.h"
 #include "host_tables.h"
 #include "kj_core.h"
@@ -902,15 +903,36 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   // narrow index, 1 B of taxon ids
   ImageStreamer is;
   const std::string &ipath = pk.lazy.path;
-  if ((rc = upload_arr(ix.get(), is, ipath, pk.blocks64, pk.lazy.blocks64, &d.blocks64))) return rc;
-  d.mb_base = nullptr; d.mb_shift = pk.mb_shift;
-  if (!pk.mb_base.empty() && (rc = upload(ix.get(), pk.mb_base, &d.mb_base))) return rc;
-  d.sa_taxid = nullptr;
-  if (!pk.sa_taxid.empty() && (rc = upload(ix.get(), pk.sa_taxid, &d.sa_taxid))) return rc;
-  if ((rc = upload_arr(ix.get(), is, ipath, pk.sa_iseq, pk.lazy.sa_iseq, &d.sa_iseq))) return rc;
+  const bool streamed = !pk.stream.path.empty();       // a .fmi whose BWT and samples are still in the file (fmi_stream.h)
+  const uint32_t *d_stream_sa_pos = nullptr;
   if ((rc = upload(ix.get(), pk.seq_taxid, &d.seq_taxid))) return rc;
   if ((rc = upload(ix.get(), pk.seq_valid, &d.seq_valid))) return rc;
-  if ((rc = upload_arr(ix.get(), is, ipath, pk.term_pos, pk.lazy.term_pos, &d.term_pos))) return rc;
+  d.mb_base = nullptr; d.mb_shift = pk.mb_shift;
+  d.sa_taxid = nullptr;
+  if (streamed) {
+    // file -> page-locked pieces -> HBM, packed by kernels: no host copy of bwt[] / sa[], no packed arrays on the host
+    FmiStreamResult sr;
+    if ((rc = fmi_stream_to_device(pk.stream, pk, d.seq_taxid, d.seq_valid, sr, msg))) return fail(rc, msg);
+    for (void *p : {(void *)sr.blocks64, (void *)sr.mb_base, (void *)sr.sa_iseq, (void *)sr.sa_taxid, (void *)sr.term_pos}) if (p) ix->allocs.push_back(p);
+    d.blocks64 = sr.blocks64; d.mb_base = sr.mb_base; d.sa_iseq = sr.sa_iseq; d.sa_taxid = sr.sa_taxid; d.term_pos = sr.term_pos;
+    d_stream_sa_pos = sr.sa_pos;                       // (freed behind the text builder below)
+    if (sr.sa_pos) ix->allocs.push_back(sr.sa_pos);
+    memcpy(pk.C, sr.C, sizeof pk.C);
+    if (sr.mb_base) {                                  // (a few KB; kept on the host for the footprint and kaiju_gpu_index_load_devices)
+      pk.mb_base.resize((size_t)((pk.bwtlen >> pk.mb_shift) + 1) * 20);
+      KJ_HIP(hipMemcpy(pk.mb_base.data(), sr.mb_base, pk.mb_base.size() * 8, hipMemcpyDeviceToHost));
+    }
+    if (lc.on)
+      fprintf(stderr, "[kaiju_gpu load]   streamed from the .fmi: %.2f GB in %.2f s (%.1f GB/s; %.2f s of it reading pieces into page-locked "
+                      "memory, pieces of %.1f MB), packed on the device\n", sr.bytes_streamed * 1e-9, sr.seconds, sr.bytes_streamed * 1e-9 / std::max(sr.seconds, 1e-9),
+              sr.seconds_reading, sr.piece / 1048576.0);
+  } else {
+    if ((rc = upload_arr(ix.get(), is, ipath, pk.blocks64, pk.lazy.blocks64, &d.blocks64))) return rc;
+    if (!pk.mb_base.empty() && (rc = upload(ix.get(), pk.mb_base, &d.mb_base))) return rc;
+    if (!pk.sa_taxid.empty() && (rc = upload(ix.get(), pk.sa_taxid, &d.sa_taxid))) return rc;
+    if ((rc = upload_arr(ix.get(), is, ipath, pk.sa_iseq, pk.lazy.sa_iseq, &d.sa_iseq))) return rc;
+    if ((rc = upload_arr(ix.get(), is, ipath, pk.term_pos, pk.lazy.term_pos, &d.term_pos))) return rc;
+  }
   const double *dl = nullptr;
   if ((rc = upload(ix.get(), lnfact, &dl))) return rc;
   ix->st.lnfact = dl;
@@ -930,8 +952,29 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k; d.kline = nullptr;
   const uint64_t n_kmer32 = PackedIndex::count(pk.kmer32, pk.lazy.kmer32), n_kmer64 = PackedIndex::count(pk.kmer64, pk.lazy.kmer64);
   uint64_t kmer_bytes = 0;
-  if (pk.kmer_k) {
-    if (n_kmer32) { if ((rc = upload_arr(ix.get(), is, ipath, pk.kmer32, pk.lazy.kmer32, &d.kmer32))) return rc; }
+  // the depth the HOST packer builds (PackedIndex::build: 5, KAIJU_GPU_KMER up to 6); a streamed .fmi has no rank blocks on the
+  // host: its table starts on the device with the twenty one-letter intervals of InitialSI (bwt.c:146-152) and grows from there
+  uint32_t host_k = pk.kmer_k;
+  if (streamed && pk.alen == 21) {
+    host_k = 5;
+    if (const char *e = getenv("KAIJU_GPU_KMER")) { host_k = (uint32_t)atoi(e); if (host_k > 6) host_k = 6; }
+    if (host_k < 2) host_k = 0;
+    if (host_k) {
+      if (!d.mb_base) {
+        std::vector<uint2> k1(20);
+        for (uint32_t c = 1; c <= 20; c++) { const uint64_t len = pk.C[c + 1] - pk.C[c]; k1[c - 1] = uint2{len ? (uint32_t)pk.C[c] : 0u, (uint32_t)len}; }
+        if ((rc = upload(ix.get(), k1, &d.kmer32))) return rc;
+      } else {
+        std::vector<ulonglong2> k1(20);
+        for (uint32_t c = 1; c <= 20; c++) { const uint64_t len = pk.C[c + 1] - pk.C[c]; k1[c - 1] = ulonglong2{len ? pk.C[c] : 0ull, len}; }
+        if ((rc = upload(ix.get(), k1, &d.kmer64))) return rc;
+      }
+      d.kmer_k = 1;
+    }
+  }
+  if (host_k) {
+    if (streamed) {}
+    else if (n_kmer32) { if ((rc = upload_arr(ix.get(), is, ipath, pk.kmer32, pk.lazy.kmer32, &d.kmer32))) return rc; }
     else if ((rc = upload_arr(ix.get(), is, ipath, pk.kmer64, pk.lazy.kmer64, &d.kmer64))) return rc;
     lc.mark("upload of the packed arrays");
     if (is.bytes_streamed && lc.on)
@@ -941,9 +984,9 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     // Deeper tables are grown on the device, one letter at a time.  Depth: KAIJU_GPU_KMER, or the
     // largest k <= 7 whose table (20^k entries of 8 bytes) has at most 8 entries per index row -
     // 10 GB for a viruses-size index, which is what 288 GB of HBM are for.
-    uint32_t want = pk.kmer_k;
+    uint32_t want = host_k;
     if (const char *e = getenv("KAIJU_GPU_KMER")) want = (uint32_t)atoi(e);
-    else { uint64_t nn = 1; for (uint32_t q = 0; q < pk.kmer_k; q++) nn *= 20; while (want < 7 && nn * 20 <= 8 * pk.bwtlen) { nn *= 20; want++; } }
+    else { uint64_t nn = 1; for (uint32_t q = 0; q < host_k; q++) nn *= 20; while (want < 7 && nn * 20 <= 8 * pk.bwtlen) { nn *= 20; want++; } }
     if (want > 7) want = 7;
     if (d.kmer32 && d.blocks64 && want > d.kmer_k) {
       uint64_t np = 1;
@@ -1018,9 +1061,9 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     const bool want = !getenv("KAIJU_GPU_NO_TEXT") && !d.mb_base && d.blocks64 && PackedIndex::count(pk.sa_pos, pk.lazy.sa_pos) &&
                       pk.bwtlen + pk.nseq + 4 * (uint64_t)kTextPad < 0xffffffffull && need_peak < free_b / 2;
     if (want) {
-      const uint32_t *d_smp = nullptr;
-      if ((rc = upload_arr(ix.get(), is, ipath, pk.sa_pos, pk.lazy.sa_pos, &d_smp))) return rc;
-      void *smp_alloc = ix->allocs.back();
+      const uint32_t *d_smp = d_stream_sa_pos;
+      if (!d_smp && (rc = upload_arr(ix.get(), is, ipath, pk.sa_pos, pk.lazy.sa_pos, &d_smp))) return rc;
+      void *smp_alloc = const_cast<uint32_t *>(d_smp);
       uint32_t *row_seq = nullptr, *row_pos = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bad = nullptr, *sa_full = nullptr, *d_beyond = nullptr;
       uint8_t *text = nullptr;
       bool ok = hipMalloc((void **)&row_seq, pk.bwtlen * 4) == hipSuccess && hipMalloc((void **)&row_pos, pk.bwtlen * 4) == hipSuccess &&
@@ -1053,13 +1096,19 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
       if (!ok && row_seq) { (void)hipFree(row_seq); row_seq = nullptr; }     // (kept otherwise: DevIndex::row_seq)
       // (the sample offsets were only needed here)
       (void)hipFree(smp_alloc);
-      ix->allocs.pop_back();
+      ix->allocs.erase(std::find(ix->allocs.begin(), ix->allocs.end(), smp_alloc));
+      d_stream_sa_pos = nullptr;
       if (ok) {
         ix->allocs.push_back(sa_full); ix->allocs.push_back(text); ix->allocs.push_back(row_seq);
         d.sa_full = sa_full; d.text = text; d.row_seq = row_seq;
       }
       else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; }
     }
+  }
+  if (d_stream_sa_pos) {                                  // (streamed .fmi without text arrays: the sample offsets are not needed)
+    (void)hipFree(const_cast<uint32_t *>(d_stream_sa_pos));
+    ix->allocs.erase(std::find(ix->allocs.begin(), ix->allocs.end(), (void *)d_stream_sa_pos));
+    d_stream_sa_pos = nullptr;
   }
   // ---- the same for an index with 64-bit positions: the text (1 B per row) and the text position of every 2^tv_shift-th row
   //      (5 B each), the densest sample that - with the temporaries of the build and 8 GB for the classification contexts -
@@ -1130,7 +1179,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     f.rank_blocks = PackedIndex::count(pk.blocks64, pk.lazy.blocks64) * sizeof(RankBlock64);
     f.count_bases = pk.mb_base.size() * 8;
     f.sa_seq = PackedIndex::count(pk.sa_iseq, pk.lazy.sa_iseq) * 4;
-    f.sa_taxid = pk.sa_taxid.size() * 8;
+    f.sa_taxid = PackedIndex::count(pk.sa_taxid, pk.lazy.sa_taxid) * 8;
     f.seq_tables = pk.seq_taxid.size() * 8 + pk.seq_valid.size() + PackedIndex::count(pk.term_pos, pk.lazy.term_pos) * 8;
     uint64_t nw = 1;
     for (uint32_t q = 0; q < d.kmer_k; q++) nw *= 20;
@@ -1166,6 +1215,15 @@ static bool image_wants_streaming(const char *path) {
   if (getenv("KAIJU_GPU_STREAM_PIECE_KB") || getenv("KAIJU_GPU_STREAM_PIECE_MB")) return true;
   struct stat st;
   return stat(path, &st) == 0 && (uint64_t)st.st_size >= (2ull << 30);
+}
+
+// A .fmi of 1 GiB and more goes to the device in pieces and is packed there (fmi_stream.h): no host copy of the file, no packed
+// arrays on the host - the loader needs the names of the sequences and two page-locked pieces where PackedIndex::build needs
+// twice the file.  KAIJU_GPU_FMI_STREAM=1 / 0: always / never (tests run both ways and compare the device arrays).
+static bool fmi_wants_streaming(const char *path) {
+  if (const char *e = getenv("KAIJU_GPU_FMI_STREAM")) return atoi(e) != 0;
+  struct stat st;
+  return stat(path, &st) == 0 && (uint64_t)st.st_size >= (1ull << 30);
 }
 
 // does the file start with the magic of an index image?
@@ -1256,10 +1314,20 @@ extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_g
   FmiFile f;
   std::string msg;
   LoadClock lc;
-  int rc = f.load(fmi_path, msg);
-  lc.mark("read .fmi file");
+  const bool streamed = fmi_wants_streaming(fmi_path);
+  int rc = f.load(fmi_path, msg, streamed);
+  lc.mark(streamed ? "read .fmi file (headers, names)" : "read .fmi file");
   if (rc) { const int drc = device_check_result(dev); return drc ? drc : fail(rc, msg); }
-  return index_from_view(f.view(), device_id, out, &dev);
+  if (!streamed) return index_from_view(f.view(), device_id, out, &dev);
+  // the BWT and the sampled suffix array stay in the file: they are streamed to the device and packed there (fmi_stream.h)
+  PackedIndex pk;
+  rc = pk.build_streamed(f, fmi_path, msg);
+  lc.mark("names, taxon ids (host)");
+  const int drc = device_check_result(dev);
+  lc.mark("wait for the HIP runtime");
+  if (drc) return drc;
+  if (rc) return fail(rc, msg);
+  return index_from_packed(pk, device_id, out);
   });
 }
 
@@ -1285,8 +1353,9 @@ extern "C" int kaiju_gpu_index_load_devices(const char *fmi_path, const int *dev
   if (is_image_file(fmi_path)) rc = pk.read_image(fmi_path, msg, id_mode == 0 && image_wants_streaming(fmi_path));
   else {
     FmiFile f;
-    rc = f.load(fmi_path, msg);
-    if (rc == 0) rc = pk.build(f.view(), msg);
+    const bool streamed = fmi_wants_streaming(fmi_path);      // (every device then streams the file for itself: it is in the page cache)
+    rc = f.load(fmi_path, msg, streamed);
+    if (rc == 0) rc = streamed ? pk.build_streamed(f, fmi_path, msg) : pk.build(f.view(), msg);
   }
   const int drc = device_check_result(dev);
   if (drc) return drc;
@@ -1321,6 +1390,73 @@ extern "C" int kaiju_gpu_index_get_footprint(const kaiju_gpu_index *ix, kaiju_gp
   return KAIJU_GPU_OK;
 }
 extern "C" void kaiju_gpu_index_free(kaiju_gpu_index *ix) { delete ix; }
+
+// digest of `n` bytes: the sum over all 16-byte chunks of a mix of (chunk number, content); the last chunk is zero-padded
+__global__ void __launch_bounds__(256)
+k_digest(const uint8_t *__restrict__ p, uint64_t n, unsigned long long *out) {
+  const uint64_t chunks = (n + 15) >> 4;
+  uint64_t acc = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x; c < chunks; c += (uint64_t)gridDim.x * 256) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    if ((c << 4) + 16 <= n && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+      const uint4 v = reinterpret_cast<const uint4 *>(p)[c];
+      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+      for (uint32_t b = 0; b < 16 && (c << 4) + b < n; b++) w[b >> 2] |= (uint32_t)p[(c << 4) + b] << (8 * (b & 3));
+    }
+    uint64_t h = (c + 1) * 0x9E3779B97F4A7C15ull;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { h ^= w[q]; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 29; }
+    acc += h;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63u) == 0) atomicAdd(out, (unsigned long long)acc);
+}
+
+extern "C" int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, uint32_t n_out) {
+  return guarded([&]() -> int {
+  if (!ix || !out || n_out < KAIJU_GPU_N_DIGESTS) return fail(KAIJU_GPU_ERR_ARG, "bad argument");
+  KJ_HIP(hipSetDevice(ix->device));
+  const DevIndex &d = ix->dev;
+  uint64_t nw = 1;
+  for (uint32_t q = 0; q < d.kmer_k; q++) nw *= 20;
+  struct Arr { const void *p; uint64_t bytes; };
+  const Arr arrs[12] = {
+      {d.blocks64, ((d.bwtlen >> 6) + 1) * sizeof(RankBlock64)},
+      {d.mb_base, d.mb_base ? ((d.bwtlen >> d.mb_shift) + 1) * 20 * 8 : 0},
+      {d.sa_iseq, d.n_sa * 4},
+      {d.sa_taxid, d.sa_taxid ? (d.n_sa + 2) * 8 : 0},
+      {d.term_pos, (uint64_t)d.nseq * 8},
+      {d.seq_taxid, (uint64_t)d.nseq * 8},
+      {d.seq_valid, (uint64_t)d.nseq},
+      {d.kmer32 ? (const void *)d.kmer32 : (const void *)d.kmer64, d.kmer_k ? nw * (d.kmer32 ? sizeof(uint2) : sizeof(ulonglong2)) : 0},
+      {d.kline, d.kline ? nw / 20 * kKLineBytes : 0},
+      {d.text, d.text ? ix->fp.text : 0},
+      {d.sa_full ? (const void *)d.sa_full : (const void *)d.sa_tpos5, d.sa_full ? d.bwtlen * 4 : d.sa_tpos5 ? ix->fp.sa_full : 0},
+      {d.row_seq, d.row_seq ? d.bwtlen * 4 : 0}};
+  unsigned long long *acc = nullptr;
+  KJ_HIP(hipMalloc((void **)&acc, 12 * 8));
+  hipError_t e = hipMemset(acc, 0, 12 * 8);
+  for (int a = 0; a < 12 && e == hipSuccess; a++) {
+    if (!arrs[a].p || !arrs[a].bytes) continue;
+    const uint64_t chunks = (arrs[a].bytes + 15) >> 4;
+    hipLaunchKernelGGL(k_digest, dim3((unsigned)std::min<uint64_t>((chunks + 255) / 256, 1u << 16)), dim3(256), 0, 0,
+                       static_cast<const uint8_t *>(arrs[a].p), arrs[a].bytes, acc + a);
+    e = hipGetLastError();
+  }
+  unsigned long long h[12] = {0};
+  if (e == hipSuccess) e = hipMemcpy(h, acc, sizeof h, hipMemcpyDeviceToHost);
+  (void)hipFree(acc);
+  if (e != hipSuccess) return fail(KAIJU_GPU_ERR_HIP, hipGetErrorString(e));
+  for (int a = 0; a < 12; a++) out[a] = h[a];
+  out[12] = d.kmer_k;
+  uint64_t hc = 0;
+  for (int a = 0; a < 22; a++) hc = (hc ^ d.C[a]) * 0xD6E8FEB86659FD93ull + 1;
+  out[13] = hc;
+  return KAIJU_GPU_OK;
+  });
+}
 
 // ----------------------------------------------------------------------------------------
 // context

@@ -93,7 +93,7 @@ bool parse_taxid(const char *name, uint64_t &id) {
   return v != ULONG_MAX;
 }
 
-int FmiFile::load(const char *path, std::string &msg) {
+int FmiFile::load(const char *path, std::string &msg, bool lazy) {
   FILE *fp = fopen(path, "rb");
   if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
   Reader rd{fp};
@@ -124,15 +124,29 @@ int FmiFile::load(const char *path, std::string &msg) {
   }
   rd.skip((int64_t)nseq * 4);   // seqTermOrder: not used by the search
   rd.skip((int64_t)nseq * 8);   // seqlengths: not used by the search
-  sa.resize((size_t)ncheck * (size_t)nbytes);
-  rd.big(sa.data(), sa.size());
+  if (lazy) {
+    const off_t at = ftello(fp);
+    if (at < 0) rd.ok = false;
+    sa_off = (uint64_t)at;
+    if ((int64_t)ncheck * nbytes > fsize - (int64_t)at) rd.ok = false; else rd.skip((int64_t)ncheck * nbytes);
+  } else {
+    sa.resize((size_t)ncheck * (size_t)nbytes);
+    rd.big(sa.data(), sa.size());
+  }
   // FMI, bwt/fmicommon.h:190-217 + compactfmi.c:165-171
   rd.get(f_alen); rd.get(bwtlen); rd.get(N1); rd.get(N2);
   if (!rd.ok || f_alen != alen || bwtlen != len || N1 <= 0 || N2 <= 0 || (int64_t)N1 * alen * 8 > fsize || (int64_t)N2 * alen * 2 > fsize) {
     fclose(fp); msg = "not a Kaiju .fmi file (bad FMI header)"; return KAIJU_GPU_ERR_FORMAT;
   }
-  bwt.resize((size_t)bwtlen);
-  rd.big(bwt.data(), bwt.size());
+  if (lazy) {
+    const off_t at = ftello(fp);
+    if (at < 0) rd.ok = false;
+    bwt_off = (uint64_t)at;
+    if (bwtlen > fsize - (int64_t)at) rd.ok = false; else rd.skip(bwtlen);
+  } else {
+    bwt.resize((size_t)bwtlen);
+    rd.big(bwt.data(), bwt.size());
+  }
   rd.skip((int64_t)(N1 - 1) * alen * 8);
   index1_last.resize((size_t)alen);
   rd.bytes(index1_last.data(), (size_t)alen * 8);
@@ -156,8 +170,8 @@ HostIndexView FmiFile::view() const {
   return v;
 }
 
-int PackedIndex::build(const HostIndexView &v, std::string &msg) {
-  if (!v.bwt || !v.startLcode || !v.alphabet || !v.ids || v.bwtlen <= 0 || v.nseq <= 0) {
+int PackedIndex::build_head(const HostIndexView &v, uint8_t *lcode, std::string &msg) {
+  if (!v.startLcode || !v.alphabet || !v.ids || v.bwtlen <= 0 || v.nseq <= 0) {
     msg = "incomplete index view"; return KAIJU_GPU_ERR_ARG;
   }
   if (v.alen < 2 || v.alen > 21) {
@@ -174,13 +188,72 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     trans[tolower((unsigned char)alphabet[i]) & 127] = (uint8_t)i;
   }
   // byte code -> letter (fmi_fill_codes, compactfmi.c:75-89)
-  uint8_t lcode[256];
-  memset(lcode, 31, sizeof lcode);
+  memset(lcode, 31, 256);
   for (uint32_t a = 0; a < alen; a++) {
     const int s = v.startLcode[a], e = v.startLcode[a + 1];
     if (s < 0 || e > 256 || s > e) { msg = "bad startLcode table"; return KAIJU_GPU_ERR_FORMAT; }
     for (int k = s; k < e; k++) lcode[k] = (uint8_t)a;
   }
+  // KAIJU_GPU_FORCE_WIDE=<shift>: treat the index as one with 64-bit positions (tests of that path on small
+  // indexes; the value is the log2 of the rows per count base, 16..31)
+  wide = bwtlen >= 0xffffffffull;
+  mb_shift = 31;
+  if (const char *e = getenv("KAIJU_GPU_FORCE_WIDE")) { wide = true; const int v = atoi(e); if (v >= (int)kSbShift && v <= 31) mb_shift = (uint32_t)v; }
+  if (v.nbytes < 1 || v.nbytes > 8 || v.pbits < 0 || v.pbits > 62) { msg = "bad suffix array coding"; return KAIJU_GPU_ERR_FORMAT; }
+  return 0;
+}
+
+// sample geometry, warnings, names and taxon ids of the sequences
+void PackedIndex::build_names(const HostIndexView &v) {
+  sa_skip = (((uint64_t)nseq - 1) >> chpt_exp) + 1;
+  n_sa = (uint64_t)v.ncheck;
+  {
+    const uint64_t need = bwtlen > 0 ? (((bwtlen - 1) >> chpt_exp) - sa_skip + 1) : 0;
+    if (((bwtlen - 1) >> chpt_exp) >= sa_skip && need > n_sa) warnings |= KAIJU_IDX_WARN_SA_SHORT;
+  }
+  if (bwtlen > 65536 && (bwtlen % 65536 >= 65408 || bwtlen % 65536 == 0)) warnings |= KAIJU_IDX_WARN_RANK_BUG;
+  // taxon ids
+  seq_taxid.assign(nseq, 0);
+  seq_valid.assign(nseq, 0);
+  names.clear();
+  names.resize(nseq);
+  parallel_for(((uint64_t)nseq + 16383) / 16384, [&](uint64_t chunk) {
+    const uint32_t b = (uint32_t)(chunk * 16384), e = (uint32_t)std::min<uint64_t>(nseq, (uint64_t)b + 16384);
+    for (uint32_t i = b; i < e; i++) {
+      const char *nm = v.ids[i] ? v.ids[i] : "";
+      names[i] = nm;
+      uint64_t id = 0;
+      // bit 0: usable taxon id; bit 1: the name has an accession part in front of the last '_' (verbose column 6)
+      seq_valid[i] = parse_taxid(nm, id) ? (uint8_t)(strrchr(nm, '_') ? 3 : 1) : 0;
+      seq_taxid[i] = id;
+    }
+  });
+}
+
+// the small parts of a .fmi whose big arrays stay in the file (fmi_stream.h)
+int PackedIndex::build_streamed(const FmiFile &f, const char *path, std::string &msg) {
+  const HostIndexView v = f.view();
+  stream = FmiStreamSource{};
+  int rc = build_head(v, stream.lcode, msg);
+  if (rc) return rc;
+  build_names(v);
+  stream.path = path; stream.sa_off = f.sa_off; stream.bwt_off = f.bwt_off; stream.nbytes = f.nbytes; stream.pbits = f.pbits;
+  blocks64.clear(); mb_base.clear(); sa_taxid.clear(); sa_iseq.clear(); sa_pos.clear(); term_pos.clear(); kmer32.clear(); kmer64.clear();
+  kline.clear(); kmer_k = 0;
+  lazy = ImageLazy{};
+  lazy.blocks64.n = (bwtlen >> 6) + 1; lazy.sa_iseq.n = n_sa; lazy.term_pos.n = nseq;
+  if (!wide) { lazy.sa_taxid.n = n_sa + 2; if (f.pbits <= 32) lazy.sa_pos.n = n_sa; }
+  return 0;
+}
+
+int PackedIndex::build(const HostIndexView &v, std::string &msg) {
+  if (!v.bwt || !v.sa) { msg = "incomplete index view"; return KAIJU_GPU_ERR_ARG; }
+  uint8_t lcode[256];
+  {
+    const int rc = build_head(v, lcode, msg);
+    if (rc) return rc;
+  }
+  stream = FmiStreamSource{};
   const uint64_t nsb = (bwtlen >> kSbShift) + 1;            // the host packs in pieces ("superblocks") of 2^kSbShift symbols
   PackClock pc;
   std::vector<uint64_t> sb((size_t)nsb * 20, 0);            // C[c] + occurrences of c before every piece (not uploaded)
@@ -231,11 +304,6 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       }
     }
   }
-  // KAIJU_GPU_FORCE_WIDE=<shift>: treat the index as one with 64-bit positions (tests of that path on small
-  // indexes; the value is the log2 of the rows per count base, 16..31)
-  wide = bwtlen >= 0xffffffffull;
-  mb_shift = 31;
-  if (const char *e = getenv("KAIJU_GPU_FORCE_WIDE")) { wide = true; const int v = atoi(e); if (v >= (int)kSbShift && v <= 31) mb_shift = (uint32_t)v; }
   blocks64.clear(); mb_base.clear();
   const uint64_t nb64 = (bwtlen >> 6) + 1;
   blocks64.resize((size_t)nb64);
@@ -283,10 +351,9 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
   });
   pc.mark("rank blocks + terminator rows");
   // sampled suffix array: only the sequence number is needed (suffixArray.h:37-51)
-  sa_skip = (((uint64_t)nseq - 1) >> chpt_exp) + 1;
-  n_sa = (uint64_t)v.ncheck;
+  build_names(v);
+  pc.mark("names, taxon ids");
   sa_iseq.clear(); sa_iseq.resize((size_t)n_sa);
-  if (v.nbytes < 1 || v.nbytes > 8 || v.pbits < 0 || v.pbits > 62) { msg = "bad suffix array coding"; return KAIJU_GPU_ERR_FORMAT; }
   {
     const uint8_t *sa = v.sa;
     const int nb = v.nbytes, pb = v.pbits;
@@ -308,27 +375,6 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
     });
   }
   pc.mark("suffix array samples");
-  {
-    const uint64_t need = bwtlen > 0 ? (((bwtlen - 1) >> chpt_exp) - sa_skip + 1) : 0;
-    if (((bwtlen - 1) >> chpt_exp) >= sa_skip && need > n_sa) warnings |= KAIJU_IDX_WARN_SA_SHORT;
-  }
-  if (bwtlen > 65536 && (bwtlen % 65536 >= 65408 || bwtlen % 65536 == 0)) warnings |= KAIJU_IDX_WARN_RANK_BUG;
-  // taxon ids
-  seq_taxid.assign(nseq, 0);
-  seq_valid.assign(nseq, 0);
-  names.clear();
-  names.resize(nseq);
-  parallel_for(((uint64_t)nseq + 16383) / 16384, [&](uint64_t chunk) {
-    const uint32_t b = (uint32_t)(chunk * 16384), e = (uint32_t)std::min<uint64_t>(nseq, (uint64_t)b + 16384);
-    for (uint32_t i = b; i < e; i++) {
-      const char *nm = v.ids[i] ? v.ids[i] : "";
-      names[i] = nm;
-      uint64_t id = 0;
-      // bit 0: usable taxon id; bit 1: the name has an accession part in front of the last '_' (verbose column 6)
-      seq_valid[i] = parse_taxid(nm, id) ? (uint8_t)(strrchr(nm, '_') ? 3 : 1) : 0;
-      seq_taxid[i] = id;
-    }
-  });
   // the taxon id of every sampled row (second-generation lanes: the locate ends with ONE load).  Not for the wide layout:
   // 8 bytes per sample is a byte per row at e = 3 - its lanes read the sequence number and then seq_taxid
   sa_taxid.clear();
@@ -343,7 +389,7 @@ int PackedIndex::build(const HostIndexView &v, std::string &msg) {
       }
     });
   }
-  pc.mark("names, taxon ids");
+  pc.mark("taxon ids of the samples");
   {
     // the host builds at most 5 letters; the device grows the table further (capi.hip)
     uint32_t k = 5;
@@ -644,7 +690,7 @@ int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::stri
 uint64_t PackedIndex::bytes() const {
   return count(sa_iseq, lazy.sa_iseq) * 4 + seq_taxid.size() * 8 + seq_valid.size() + count(term_pos, lazy.term_pos) * 8 +
          count(kmer32, lazy.kmer32) * 8 + count(kmer64, lazy.kmer64) * 16 +
-         mb_base.size() * 8 + count(blocks64, lazy.blocks64) * sizeof(RankBlock64) + sa_taxid.size() * 8;
+         mb_base.size() * 8 + count(blocks64, lazy.blocks64) * sizeof(RankBlock64) + count(sa_taxid, lazy.sa_taxid) * 8;
 }
 
 DevIndex PackedIndex::host_view() const {

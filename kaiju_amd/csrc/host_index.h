@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kj_core.h"
+#include "fmi_stream.h"
 
 namespace kj {
 
@@ -62,8 +63,10 @@ struct FmiFile {
   BigVec<uint8_t> bwt;
   std::vector<int64_t> index1_last;   // index1[N1-1][*] = C[] as stored by the reference
   std::vector<int32_t> startLcode;
-  // returns 0 or a negative kaiju_gpu_status; msg receives details
-  int load(const char *path, std::string &msg);
+  // lazy load: where sa[] and bwt[] lie in the file (they are not read: fmi_stream.h streams them to the device)
+  uint64_t sa_off = 0, bwt_off = 0;
+  // returns 0 or a negative kaiju_gpu_status; msg receives details.  lazy: the two big arrays stay in the file
+  int load(const char *path, std::string &msg, bool lazy = false);
   HostIndexView view() const;
 };
 
@@ -73,6 +76,7 @@ struct LazyArr { uint64_t off = 0, n = 0; };
 struct ImageLazy {
   std::string path;            // empty: nothing is lazy
   LazyArr blocks64, sa_iseq, sa_pos, term_pos, kmer32, kmer64;
+  LazyArr sa_taxid;            // (streamed .fmi only: an image's taxon ids of the samples are read into host memory)
 };
 
 // the packed index in host memory, ready for upload
@@ -115,6 +119,14 @@ struct PackedIndex {
   uint8_t trans[128];               // translate2numbers table (sequence.c:68-97)
   // fills everything from a view; returns 0 or negative status
   int build(const HostIndexView &v, std::string &msg);
+  // the parts of build() that do not touch bwt[] / sa[]: header fields, translation table, byte code -> letter (lcode[256]),
+  // layout (narrow / wide) - and: sample geometry, warnings, names and taxon ids of the sequences
+  int build_head(const HostIndexView &v, uint8_t *lcode, std::string &msg);
+  void build_names(const HostIndexView &v);
+  // A .fmi whose big arrays stay in the file (FmiFile::load(.., lazy)): the small parts are built here, `stream` says where the
+  // rest is, `lazy` how many elements every device array will have; capi.hip lets fmi_stream_to_device pack them in HBM.
+  FmiStreamSource stream;
+  int build_streamed(const FmiFile &f, const char *path, std::string &msg);
   uint64_t bytes() const;
   // DevIndex whose pointers refer to THIS object's host vectors (used by the test emulation)
   DevIndex host_view() const;

@@ -16,6 +16,7 @@
 #include "../../kaiju_amd/csrc/host_index.h"
 #include "../../kaiju_amd/csrc/host_tables.h"
 #include "../../kaiju_amd/csrc/kj_core.h"
+#include "../../kaiju_amd/csrc/fmi_stream.h"
 
 using namespace kj;
 
@@ -429,6 +430,126 @@ extern "C" int emu_image_roundtrip(const char *fmi, const char *image) {
   if (a.names != b.names || a.alphabet != b.alphabet || memcmp(a.C, b.C, sizeof a.C) || memcmp(a.trans, b.trans, 128)) return 2;
   if (a.bwtlen != b.bwtlen || a.n_sa != b.n_sa || a.sa_skip != b.sa_skip || a.nseq != b.nseq || a.chpt_exp != b.chpt_exp ||
       a.alen != b.alen || a.warnings != b.warnings || a.kmer_k != b.kmer_k || a.mb_shift != b.mb_shift || a.wide != b.wide) return 3;
+  return 0;
+}
+
+// The streamed load of a .fmi (kaiju_amd/csrc/fmi_stream.h / .hip) on the host: the file's BWT and samples taken piece by piece,
+// the steps of k_pack_sa / k_pack_blocks / k_pack_scan / k_pack_finish / k_pack_add_c one after the other with the shared
+// per-block logic, and the outcome compared word for word with what PackedIndex::build packs.  piece: bytes per piece (a
+// multiple of 16384).  0 = identical; > 0 names the array that differs; < 0 a failed step.
+extern "C" int emu_stream_pack_check(const char *fmi, uint64_t piece) {
+  FmiFile full, lz; std::string msg;
+  if (full.load(fmi, msg)) return -1;
+  if (lz.load(fmi, msg, true)) return -2;
+  if (!lz.bwt.empty() || !lz.sa.empty() || lz.bwt_off == 0 || lz.sa_off == 0) return -3;
+  PackedIndex a, b;
+  if (a.build(full.view(), msg)) return -4;
+  if (b.build_streamed(lz, fmi, msg)) return -5;
+  if (b.wide != a.wide || b.mb_shift != a.mb_shift || b.n_sa != a.n_sa || b.sa_skip != a.sa_skip || b.warnings != a.warnings ||
+      b.names != a.names || b.seq_taxid != a.seq_taxid || b.seq_valid != a.seq_valid || memcmp(a.trans, b.trans, 128)) return 20;
+  FILE *fp = fopen(fmi, "rb");
+  if (!fp) return -6;
+  const FmiStreamSource &src = b.stream;
+  const uint64_t bwtlen = b.bwtlen, nb64 = (bwtlen >> 6) + 1, n_sa = b.n_sa;
+  const bool wide = b.wide;
+  const uint32_t mb_grp_shift = b.mb_shift - kPackGroupSymShift;
+  const uint64_t gsym = 1ull << kPackGroupSymShift;
+  if (piece < gsym || piece % gsym) return -7;
+  std::vector<uint8_t> raw((size_t)piece + 64);
+  // k_pack_sa
+  std::vector<uint32_t> sa_iseq((size_t)n_sa), sa_pos((!wide && src.pbits <= 32) ? (size_t)n_sa : 0);
+  std::vector<uint64_t> sa_taxid(!wide ? (size_t)n_sa + 2 : 0, ~0ull);
+  {
+    const uint64_t per_piece = piece / (uint64_t)src.nbytes;
+    for (uint64_t i0 = 0; i0 < n_sa; i0 += per_piece) {
+      const uint64_t n = std::min<uint64_t>(per_piece, n_sa - i0);
+      if (fseeko(fp, (off_t)(src.sa_off + i0 * src.nbytes), SEEK_SET) || fread(raw.data(), 1, (size_t)(n * src.nbytes), fp) != n * src.nbytes) { fclose(fp); return -8; }
+      for (uint64_t x = 0; x < n; x++) {
+        uint32_t is = 0, ps = 0;
+        pack_sa_entry(raw.data() + x * src.nbytes, src.nbytes, src.pbits, is, ps);
+        sa_iseq[(size_t)(i0 + x)] = is;
+        if (!sa_pos.empty()) sa_pos[(size_t)(i0 + x)] = ps;
+        if (!sa_taxid.empty()) sa_taxid[(size_t)(i0 + x)] = (is < b.nseq && b.seq_valid[is]) ? b.seq_taxid[is] : ~0ull;
+      }
+    }
+  }
+  // the BWT
+  std::vector<RankBlock64> blocks((size_t)nb64);
+  std::vector<uint64_t> term_pos(b.nseq, ~0ull), mbcount(wide ? (size_t)((bwtlen >> b.mb_shift) + 1) * 20 : 0, 0);
+  uint64_t carry[kPackChannels] = {0};
+  bool bad = false;
+  for (uint64_t p0 = 0; p0 < bwtlen; p0 += piece) {
+    const uint64_t len = std::min<uint64_t>(piece, bwtlen - p0);
+    const bool last = p0 + len == bwtlen;
+    if (fseeko(fp, (off_t)(src.bwt_off + p0), SEEK_SET) || fread(raw.data(), 1, (size_t)len, fp) != len) { fclose(fp); return -9; }
+    const uint64_t blk0 = p0 >> 6;
+    const uint32_t nblk = (uint32_t)((last ? nb64 : (p0 + len) >> 6) - blk0);
+    const uint32_t ngroups = (nblk + kPackGroupBlocks - 1) / kPackGroupBlocks;
+    const uint64_t grp0 = p0 >> kPackGroupSymShift;
+    std::vector<uint32_t> grp_tot((size_t)ngroups * kPackChannels, 0);
+    std::vector<uint64_t> grp_abs((size_t)ngroups * kPackChannels, 0);
+    // k_pack_blocks: counts in front of the block inside its group
+    for (uint32_t g = 0; g < ngroups; g++) {
+      uint32_t run[kPackChannels] = {0};
+      for (uint32_t t = 0; t < kPackGroupBlocks; t++) {
+        const uint32_t bi = g * kPackGroupBlocks + t;
+        if (bi >= nblk) break;
+        const uint64_t h0 = p0 + (uint64_t)bi * 64;
+        const uint32_t nsym = h0 >= bwtlen ? 0u : (uint32_t)std::min<uint64_t>(64, bwtlen - h0);
+        uint64_t pl[5]; uint32_t cnt[kPackChannels];
+        if (!pack_block_letters(raw.data() + (size_t)bi * 64, nsym, src.lcode, pl, cnt)) bad = true;
+        RankBlock64 &r = blocks[(size_t)(blk0 + bi)];
+        for (int q = 0; q < 5; q++) r.plane[q] = pl[q];
+        for (uint32_t c = 0; c < 20; c++) r.cnt[c] = run[c + 1];
+        r.pad[0] = run[0]; r.pad[1] = 0;
+        for (uint32_t c = 0; c < kPackChannels; c++) run[c] += cnt[c];
+      }
+      for (uint32_t c = 0; c < kPackChannels; c++) grp_tot[(size_t)g * kPackChannels + c] = run[c];
+    }
+    // k_pack_scan
+    for (uint32_t g = 0; g < ngroups; g++) {
+      const uint64_t gg = grp0 + g;
+      for (uint32_t c = 0; c < kPackChannels; c++) grp_abs[(size_t)g * kPackChannels + c] = carry[c];
+      if (wide && (gg & ((1ull << mb_grp_shift) - 1ull)) == 0)
+        for (uint32_t c = 0; c < 20; c++) mbcount[(size_t)(gg >> mb_grp_shift) * 20 + c] = carry[c + 1];
+      for (uint32_t c = 0; c < kPackChannels; c++) carry[c] += grp_tot[(size_t)g * kPackChannels + c];
+    }
+    // k_pack_finish
+    for (uint32_t bi = 0; bi < nblk; bi++) {
+      const uint32_t g = bi >> kPackGroupShift;
+      const uint64_t *ab = grp_abs.data() + (size_t)g * kPackChannels;
+      RankBlock64 &r = blocks[(size_t)(blk0 + bi)];
+      for (uint32_t c = 0; c < 20; c++) r.cnt[c] += (uint32_t)(ab[c + 1] - (wide ? mbcount[(size_t)((grp0 + g) >> mb_grp_shift) * 20 + c] : 0ull));
+      uint64_t z = ab[0] + r.pad[0];
+      uint64_t zm = ~(r.plane[0] | r.plane[1] | r.plane[2] | r.plane[3] | r.plane[4]);
+      while (zm) {
+        const uint32_t t = (uint32_t)__builtin_ctzll(zm);
+        if (z < b.nseq) term_pos[(size_t)z] = p0 + (uint64_t)bi * 64 + t; else bad = true;
+        z++; zm &= zm - 1ull;
+      }
+      r.pad[0] = 0;
+    }
+  }
+  fclose(fp);
+  if (bad) return -10;
+  uint64_t C[22], sum = 0;
+  for (uint32_t c = 0; c < kPackChannels; c++) sum += carry[c];
+  if (sum != bwtlen || carry[0] != b.nseq) return -11;
+  C[0] = 0;
+  for (uint32_t c = 1; c < b.alen; c++) C[c] = C[c - 1] + carry[c - 1];
+  for (uint32_t c = b.alen; c < 22; c++) C[c] = bwtlen;
+  if (wide) for (size_t x = 0; x < mbcount.size(); x++) mbcount[x] += C[1 + x % 20];
+  else for (auto &r : blocks) for (uint32_t c = 0; c < 20; c++) r.cnt[c] += (uint32_t)C[c + 1];
+  if (memcmp(C, a.C, sizeof C)) return 1;
+  if (blocks.size() != a.blocks64.size() || memcmp(blocks.data(), a.blocks64.data(), blocks.size() * sizeof(RankBlock64))) return 2;
+  if (mbcount.size() != a.mb_base.size() || (!mbcount.empty() && memcmp(mbcount.data(), a.mb_base.data(), mbcount.size() * 8))) return 3;
+  if (term_pos.size() != a.term_pos.size() || memcmp(term_pos.data(), a.term_pos.data(), term_pos.size() * 8)) return 4;
+  if (sa_iseq.size() != a.sa_iseq.size() || (n_sa && memcmp(sa_iseq.data(), a.sa_iseq.data(), (size_t)n_sa * 4))) return 5;
+  if (sa_pos.size() != a.sa_pos.size() || (!sa_pos.empty() && memcmp(sa_pos.data(), a.sa_pos.data(), sa_pos.size() * 4))) return 6;
+  if (sa_taxid.size() != a.sa_taxid.size() || (!sa_taxid.empty() && memcmp(sa_taxid.data(), a.sa_taxid.data(), sa_taxid.size() * 8))) return 7;
+  if (PackedIndex::count(b.blocks64, b.lazy.blocks64) != a.blocks64.size() || PackedIndex::count(b.sa_iseq, b.lazy.sa_iseq) != a.sa_iseq.size() ||
+      PackedIndex::count(b.sa_pos, b.lazy.sa_pos) != a.sa_pos.size() || PackedIndex::count(b.sa_taxid, b.lazy.sa_taxid) != a.sa_taxid.size() ||
+      PackedIndex::count(b.term_pos, b.lazy.term_pos) != a.term_pos.size()) return 8;
   return 0;
 }
 

@@ -182,3 +182,47 @@ def test_image_info_locates_the_streamed_arrays(golden, tmp_path):
     open(str(tmp_path / "cut.kjimg"), "wb").write(open(img, "rb").read()[: os.path.getsize(img) // 2])
     assert L.kaiju_gpu_index_image_info(str(tmp_path / "cut.kjimg").encode(), C.byref(info), None) < 0
     assert L.kaiju_gpu_index_image_info(golden.fmi.encode(), C.byref(info), None) < 0
+
+
+def test_streamed_pack_of_a_fmi_equals_the_host_pack(golden, tmp_path, monkeypatch):
+    """fmi_stream.h: a .fmi whose BWT and samples are packed piece by piece with running counts (what the kernels of
+    fmi_stream.hip do on the device) gives the arrays of PackedIndex::build word for word - rank blocks, count bases, terminator
+    rows, sampled sequence numbers / offsets / taxon ids, C[] - narrow and wide, with count bases that start inside a piece, a
+    BWT that ends on a block boundary's far side, pieces of one group and pieces larger than the file"""
+    import util
+    from kaiju_amd import mkfmi, synth
+    emu = util.Emu()
+    emu.lib.emu_stream_pack_check.argtypes = [C.c_char_p, C.c_uint64]
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    files = [golden.fmi]
+    for nseq, seed in ((700, 3), (1600, 4)):                  # (1600 % 8 == 0: the short sample array of KAIJU_IDX_WARN_SA_SHORT)
+        db = synth.make_db(nseq=nseq, seed=seed, leaves=leaves, max_len=700)
+        faa, fmi = str(tmp_path / f"db{nseq}.faa"), str(tmp_path / f"db{nseq}.fmi")
+        synth.write_fasta(db, faa)
+        mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+        files.append(fmi)
+    # databases whose BWT ends exactly on a group / block boundary (the block behind the end is a group, or a block, of its own)
+    rng = np.random.default_rng(8)
+    for rows in (32768, 32768 + 64, 16384 * 3 - 1):
+        nseq, lens = 40, []
+        left = rows - nseq
+        for i in range(nseq):
+            l = left - 30 * (nseq - 1 - i) if i == nseq - 1 else int(rng.integers(30, 2 * left // (nseq - i) - 30))
+            lens.append(l); left -= l
+        assert sum(lens) + nseq == rows and min(lens) >= 30
+        faa, fmi = str(tmp_path / f"rows{rows}.faa"), str(tmp_path / f"rows{rows}.fmi")
+        with open(faa, "w") as f:
+            for i, l in enumerate(lens):
+                f.write(f">s{i}_{leaves[i % len(leaves)]}\n" + "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), l)) + "\n")
+        mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+        import struct
+        assert struct.unpack_from("<q", open(fmi, "rb").read(8))[0] == rows
+        files.append(fmi)
+    for fmi in files:
+        for wide in (None, "16", "17", "31"):
+            if wide is None:
+                monkeypatch.delenv("KAIJU_GPU_FORCE_WIDE", raising=False)
+            else:
+                monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", wide)
+            for piece in (16384, 49152, 1 << 20, 1 << 26):
+                assert emu.lib.emu_stream_pack_check(fmi.encode(), piece) == 0, (fmi, wide, piece)
