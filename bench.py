@@ -518,10 +518,15 @@ def main():
                     help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")
     ap.add_argument("--no-seg", action="store_true")
     ap.add_argument("--paired", action="store_true", help="headline leg on 2 x 150-bp pairs instead of single reads")
-    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host,hard"),
-                    help="further legs in the same line: greedy, paired, host, hard (comma separated; '' = none).  hard: MEM and Greedy on "
+    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host,hard,wide"),
+                    help="further legs in the same line: greedy, paired, host, hard, wide (comma separated; '' = none).  hard: MEM and Greedy on "
                          "a database that is NOT i.i.d. (synth.make_db_hard: families of 50-500 near-identical proteins, low-complexity "
-                         "inserts; reads with Ns) - retries, inexact reads and the rate next to the i.i.d. legs")
+                         "inserts; reads with Ns) - retries, inexact reads and the rate next to the i.i.d. legs.  wide: MEM and Greedy on "
+                         "an index of 2^32 rows and more (the benchmark database with every protein --wide-copies times, written by "
+                         "kaiju_build_fmi_replicated without a second sort; the .fmi is streamed to HBM and packed there): the kernels "
+                         "of the layout with 64-bit positions - k_mem_wide2, k_mem_locate_wide / _team, k_greedy2_wide")
+    ap.add_argument("--wide-copies", type=int, default=23, help="copies of every protein in the index of the `wide` leg (23 x 191 M rows = 4.39 G > 2^32)")
+    ap.add_argument("--wide-reads", type=int, default=2_000_000)
     ap.add_argument("--hard-nseq", type=int, default=200_001)
     ap.add_argument("--hard-reads", type=int, default=2_000_000)
     ap.add_argument("--leg-steps", type=int, default=2)
@@ -722,6 +727,36 @@ def main():
             log(rank, "hard leg failed:", repr(e))
             hard = None
 
+    # ---------------- the wide leg: 2^32 rows and more on the benchmark database (its own index; 64-bit positions) ----------------
+    wide = None
+    if "wide" in legs_wanted and world == 1 and not big_db and copies == 1 and not args.paired:
+        try:
+            t1 = time.time()
+            wc = max(2, args.wide_copies)
+            wfmi = f"{W}/db_{args.nseq}_x{wc}.fmi"
+            if not os.path.exists(wfmi):
+                faa = f"{W}/db_{args.nseq}.faa"
+                if not os.path.exists(faa):
+                    synth.write_fasta(db, faa)
+                mkfmi.build_fmi_replicated(faa, wfmi + ".tmp", wc, threads=0, exponent=3, copy_taxids=np.asarray(leaves, dtype=np.uint64))
+                os.replace(wfmi + ".tmp", wfmi)
+            t_build = time.time() - t1
+            t2 = time.time()
+            windex = api.Index(wfmi, device=local_rank)
+            t_load = time.time() - t2
+            wreads = np.ascontiguousarray(reads[: min(args.wide_reads, n)])
+            log(rank, f"wide index: every protein x {wc} = {windex.info.bwtlen} rows, .fmi {os.path.getsize(wfmi)/1e9:.2f} GB ({t_build:.1f}s), "
+                      f"{windex.footprint.total/1e9:.2f} GB in HBM, loaded in {t_load:.1f}s")
+            wide = {"fmi": wfmi, "reads": wreads, "index": windex, "legs": {}, "copies": wc, "load_s": t_load, "build_s": t_build}
+            for nm, mode in (("wide", "mem"), ("wide_greedy", "greedy")):
+                leg = Leg(nm, mode, False, wreads, Lm, windex, dtax, dev, rank, world, seg, args.chunk, args.contexts)
+                leg.run(args.leg_steps, 1)
+                log(rank, f"leg {nm}: {leg.n * args.leg_steps / leg.elapsed / 1e6:.1f} M reads/s, {leg.retries / max(args.leg_steps, 1):.0f} reads per step in the retry pass")
+                wide["legs"][nm] = leg
+        except Exception as e:  # noqa: BLE001
+            log(rank, "wide leg failed:", repr(e))
+            wide = None
+
     # N > 1: a sample of EVERY rank's reads and of the records its timed kernels wrote goes to rank 0, which checks each against
     # the reference binary (an N-GPU line must not state a rate with nothing looking at the gathered records)
     rank_samples = None
@@ -740,7 +775,7 @@ def main():
         if args.no_cpu_baseline or world != 1:
             return out
         try:
-            if not args.no_ref_ops:
+            if not args.no_ref_ops and oracle_sample > 0:
                 out["ref_ops"] = reference_ops(W, fmi, rd[:oracle_sample], leg.mode, seg, leg.paired, Lm)
         except Exception as e:  # noqa: BLE001 - the accounting legs must never kill the measurement
             log(rank, f"reference op counts ({leg.name}) failed:", repr(e))
@@ -768,6 +803,10 @@ def main():
     if hard is not None:
         for nm, leg in hard["legs"].items():
             acc[nm] = cpu_leg(leg, hard["reads"], min(args.cpu_sample_legs, 200_000), 5000, fmi=hard["fmi"], tag_suffix="_hard")
+    if wide is not None:
+        # (one run of the reference per mode: it reads the 8 GB .fmi each time; no op counts of the instrumented oracle there)
+        for nm, leg in wide["legs"].items():
+            acc[nm] = cpu_leg(leg, wide["reads"], min(args.cpu_sample_legs, 100_000), 0, fmi=wide["fmi"], tag_suffix="_wide")
     per_rank_parity = None
     if rank_samples is not None:
         rds, recs, k = rank_samples
@@ -847,6 +886,27 @@ def main():
             if acc[nm]["parity"] is not None:
                 parity[nm] = acc[nm]["parity"]
             result[nm] = lr
+    if wide is not None:
+        wix = wide["index"]
+        for nm, leg in wide["legs"].items():
+            lr = leg.result(world, None, None, db.nseq * wide["copies"])
+            rec = np.frombuffer(leg.timed_compact.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
+            lr["workload"] = (f"index of 2^32 rows and more: the benchmark database with every protein x {wide['copies']} (copy t under another "
+                              f"taxon) = {wix.info.bwtlen} rows, .fmi {os.path.getsize(wide['fmi'])/1e9:.2f} GB written by kaiju_build_fmi_replicated "
+                              f"(no second sort); the first {leg.n} reads of the headline; kaiju -a {leg.mode}")
+            lr["index_hbm_bytes"] = wix.footprint.as_dict()
+            lr["index_load"] = {"path": ".fmi streamed to HBM in page-locked pieces and packed on the device (fmi_stream.hip): no host copy "
+                                        "of the BWT, the samples or the packed arrays" if os.path.getsize(wide["fmi"]) >= (1 << 30) and
+                                        os.environ.get("KAIJU_GPU_FMI_STREAM", "1") != "0" else "fmi: parsed, packed and uploaded from host memory",
+                                "seconds": wide["load_s"], "file_bytes": os.path.getsize(wide["fmi"]), "fmi_build_seconds": wide["build_s"]}
+            lr["id_cap_reads_per_step"] = int(((rec["info"] >> 8) & 1).sum())
+            lr["fraction_reads_with_hit"] = round(float(((rec["info"] & 0xff) > 0).mean()), 4)
+            if acc.get(nm, {}).get("baseline") is not None:
+                lr["cpu_baseline"] = acc[nm]["baseline"]
+            if acc.get(nm, {}).get("parity") is not None:
+                parity[nm] = acc[nm]["parity"]
+                lr["parity"] = acc[nm]["parity"]
+            result[nm] = lr
     if host is not None:
         result["host_buffers"] = host
     if per_rank_parity is not None:
@@ -854,7 +914,9 @@ def main():
         result["parity"] = parity
         ok = [p for p in per_rank_parity if "checked" in p]
         result["parity_checked_reads"] = sum(p["checked"] for p in ok)
-        result["mismatches"] = sum(p["mismatches"] for p in ok)
+        # (a rank whose comparison could not run is an error of the line, not a rank without mismatches)
+        result["parity_errors"] = len(per_rank_parity) - len(ok)
+        result["mismatches"] = sum(p["mismatches"] for p in ok) if len(ok) == len(per_rank_parity) else None
         parity = {}
     if parity:
         result["parity"] = parity

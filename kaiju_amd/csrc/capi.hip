@@ -577,6 +577,20 @@ k_rows_beyond(const uint32_t *__restrict__ beyond_rows, uint32_t n, uint32_t *__
   const uint32_t x = blockIdx.x * 256 + threadIdx.x;
   if (x < n) row_seq[beyond_rows[x]] = 0xffffffffu;          // a locate of that row finds no sequence (the reference reads out of bounds there)
 }
+// row -> sequence becomes row -> dense taxon index (DevIndex::row_tax), in place; out[x] = src[idx[x]] (the text positions of the
+// few rows behind the missing sample)
+__global__ void __launch_bounds__(256)
+k_row_tax(uint32_t *__restrict__ row_seq, uint64_t n, const uint32_t *__restrict__ seq_dense, uint32_t nseq) {
+  for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
+    const uint32_t q = row_seq[r];
+    row_seq[r] = q < nseq ? seq_dense[q] : 0xffffffffu;
+  }
+}
+__global__ void __launch_bounds__(256)
+k_gather_u32(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ out) {
+  const uint32_t x = blockIdx.x * 256 + threadIdx.x;
+  if (x < n) out[x] = src[idx[x]];
+}
 __global__ void __launch_bounds__(256)
 k_seq_lens(uint32_t nseq, const uint32_t *__restrict__ row_seq, const uint32_t *__restrict__ row_pos, uint32_t *__restrict__ len) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
@@ -608,7 +622,9 @@ k_seq_walk_len(DevIndex ix, uint32_t *next, uint32_t *__restrict__ t_seq, uint32
       k = t; n = 0; active = true;
     }
     const uint32_t c = symbol_at(ix, k);
-    if (c == 0 || n >= 0xfffffff0ull) {
+    // (no sequence is longer than the text, and its length must fit the 32 bits of len[]: a damaged image ends here - bad is set
+    //  below - instead of spinning for billions of LF steps)
+    if (c == 0 || n >= 0xfffffff0ull || n > ix.bwtlen) {
       const uint32_t q = c == 0 ? (uint32_t)rank_term(ix, k) : 0xffffffffu;
       if (q >= ix.nseq) { atomicOr(bad, 1u); t_seq[t] = 0; }
       else { t_seq[t] = q; len[q] = (uint32_t)n; }
@@ -1052,7 +1068,8 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   //      the peak of the build (two temporaries of 4 B per row next to the arrays) plus what the classification contexts of
   //      two streams allocate later (scratch of the search lanes, peptides, fragment lists: up to ~4 GB for 10 M-read batches) -
   //      an index that does not leave that much goes without the text arrays rather than failing in kaiju_gpu_create ----
-  d.sa_full = nullptr; d.text = nullptr; d.row_seq = nullptr;
+  d.sa_full = nullptr; d.text = nullptr; d.row_tax = nullptr; d.tax_of_dense = nullptr; d.n_dense = 0;
+  d.beyond_lo = d.beyond_n = d.beyond_row = 0;
   uint64_t text_bytes = 0;
   {
     size_t free_b = 0, total_b = 0;
@@ -1066,7 +1083,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
       void *smp_alloc = const_cast<uint32_t *>(d_smp);
       uint32_t *row_seq = nullptr, *row_pos = nullptr, *d_len = nullptr, *d_off = nullptr, *d_bad = nullptr, *sa_full = nullptr, *d_beyond = nullptr;
       uint8_t *text = nullptr;
-      bool ok = hipMalloc((void **)&row_seq, pk.bwtlen * 4) == hipSuccess && hipMalloc((void **)&row_pos, pk.bwtlen * 4) == hipSuccess &&
+      bool ok = hipMalloc((void **)&row_seq, pk.bwtlen * 4 + 16) == hipSuccess && hipMalloc((void **)&row_pos, pk.bwtlen * 4) == hipSuccess &&
                 hipMalloc((void **)&d_len, (size_t)pk.nseq * 4 + 16) == hipSuccess && hipMalloc((void **)&d_off, (size_t)pk.nseq * 4 + 16) == hipSuccess &&
                 hipMalloc((void **)&d_bad, 16) == hipSuccess && hipMalloc((void **)&d_beyond, (size_t)kBeyondRowsMax * 4) == hipSuccess;
       if (ok) {
@@ -1089,6 +1106,37 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
           hipLaunchKernelGGL(k_text_build, dim3(blocks), dim3(256), 0, 0, d, row_seq, row_pos, d_off, sa_full, text);
           if (bad[1]) hipLaunchKernelGGL(k_rows_beyond, dim3((bad[1] + 255) / 256), dim3(256), 0, 0, d_beyond, bad[1], row_seq);
           ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+          if (ok && bad[1]) {
+            // the rows behind the missing sample lie next to each other in the text (one walk: DevIndex::beyond_lo)
+            std::vector<uint32_t> rows(bad[1]), tp(bad[1]);
+            hipLaunchKernelGGL(k_gather_u32, dim3((bad[1] + 255) / 256), dim3(256), 0, 0, sa_full, d_beyond, bad[1], row_pos);   // (row_pos: free now)
+            ok = hipMemcpy(tp.data(), row_pos, (size_t)bad[1] * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(rows.data(), d_beyond, (size_t)bad[1] * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            if (ok) {
+              const uint32_t lo = *std::min_element(tp.begin(), tp.end()), hi = *std::max_element(tp.begin(), tp.end());
+              ok = hi - lo + 1 == bad[1];
+              d.beyond_lo = lo; d.beyond_n = bad[1]; d.beyond_row = rows[0];
+            }
+          }
+          if (ok) {
+            // row -> sequence -> dense taxon index (the locate's scan over the rows of a match: contiguous loads only)
+            std::vector<uint32_t> seq_dense;
+            std::vector<uint64_t> tax_of_dense;
+            dense_taxa(pk.seq_taxid, pk.seq_valid, seq_dense, tax_of_dense);
+            const uint32_t *d_sd = nullptr;
+            const uint64_t *d_td = nullptr;
+            if (upload(ix.get(), seq_dense, &d_sd) || upload(ix.get(), tax_of_dense, &d_td)) ok = false;
+            else {
+              hipLaunchKernelGGL(k_row_tax, dim3(blocks), dim3(256), 0, 0, row_seq, pk.bwtlen, d_sd, pk.nseq);
+              ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
+              ix->allocs.pop_back();                           // (tax_of_dense: re-registered below when everything worked)
+              ix->allocs.pop_back();
+              (void)hipFree(const_cast<uint32_t *>(d_sd));
+              if (ok) { d.tax_of_dense = d_td; d.n_dense = (uint32_t)tax_of_dense.size(); }
+              else (void)hipFree(const_cast<uint64_t *>(d_td));
+            }
+          }
+          if (!ok) { d.beyond_lo = d.beyond_n = d.beyond_row = 0; }
         }
       }
       (void)hipGetLastError();
@@ -1100,9 +1148,10 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
       d_stream_sa_pos = nullptr;
       if (ok) {
         ix->allocs.push_back(sa_full); ix->allocs.push_back(text); ix->allocs.push_back(row_seq);
-        d.sa_full = sa_full; d.text = text; d.row_seq = row_seq;
+        ix->allocs.push_back(const_cast<uint64_t *>(d.tax_of_dense));
+        d.sa_full = sa_full; d.text = text; d.row_tax = row_seq;
       }
-      else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; }
+      else { if (sa_full) (void)hipFree(sa_full); if (text) (void)hipFree(text); text_bytes = 0; d.tax_of_dense = nullptr; d.n_dense = 0; }
     }
   }
   if (d_stream_sa_pos) {                                  // (streamed .fmi without text arrays: the sample offsets are not needed)
@@ -1117,7 +1166,11 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   //      92 GB, nothing fits at refseq_nr's 58 G): measured on 4.35 G rows only (profiles/r04_wide_text) ----
   d.sa_tpos5 = nullptr; d.tv_shift = 0;
   uint64_t tpos_bytes = 0;
-  if (d.mb_base && d.blocks64 && d.term_pos && !getenv("KAIJU_GPU_NO_TEXT") && pk.bwtlen + 4 * (uint64_t)kTextPad < kTposNone) {
+  // (not on an index with the reference's short sample array: a text-grown match is recorded through the row where the text took
+  //  over, the lanes without the arrays record its own end row - and whether that row lies behind the missing sample would then
+  //  depend on whether the arrays fit; the narrow lane applies the skip to the grown match itself, DevIndex::beyond_lo)
+  if (d.mb_base && d.blocks64 && d.term_pos && !getenv("KAIJU_GPU_NO_TEXT") && pk.bwtlen + 4 * (uint64_t)kTextPad < kTposNone &&
+      !(pk.warnings & KAIJU_IDX_WARN_SA_SHORT)) {
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const uint64_t tb_est = pk.bwtlen + 3 * (uint64_t)kTextPad, tmp = (uint64_t)pk.nseq * 16 + 64;
@@ -1434,7 +1487,7 @@ extern "C" int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, 
       {d.kline, d.kline ? nw / 20 * kKLineBytes : 0},
       {d.text, d.text ? ix->fp.text : 0},
       {d.sa_full ? (const void *)d.sa_full : (const void *)d.sa_tpos5, d.sa_full ? d.bwtlen * 4 : d.sa_tpos5 ? ix->fp.sa_full : 0},
-      {d.row_seq, d.row_seq ? d.bwtlen * 4 : 0}};
+      {d.row_tax, d.row_tax ? d.bwtlen * 4 : 0}};
   unsigned long long *acc = nullptr;
   KJ_HIP(hipMalloc((void **)&acc, 12 * 8));
   hipError_t e = hipMemset(acc, 0, 12 * 8);
@@ -1792,7 +1845,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
       if (defer) {
-        if (mem_narrow2 && ix->dev.row_seq) {
+        if (mem_narrow2 && ix->dev.row_tax) {
           hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
           hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
         }
@@ -1874,7 +1927,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       KJ_HIP(hipGetLastError());
       if (pg.flags & kParamDeferLocate) {
         if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
-        else if (ix->dev.row_seq) {
+        else if (ix->dev.row_tax) {
           hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
           hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
         }

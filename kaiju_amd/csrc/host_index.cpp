@@ -93,6 +93,25 @@ bool parse_taxid(const char *name, uint64_t &id) {
   return v != ULONG_MAX;
 }
 
+void dense_taxa(const std::vector<uint64_t> &seq_taxid, const std::vector<uint8_t> &seq_valid, std::vector<uint32_t> &seq_dense,
+                std::vector<uint64_t> &tax_of_dense) {
+  const size_t n = seq_taxid.size();
+  seq_dense.assign(n, 0xffffffffu);
+  tax_of_dense.clear();
+  // open addressing over the distinct ids (a database has far fewer taxa than sequences)
+  size_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  std::vector<uint32_t> slot(cap, 0xffffffffu);
+  for (size_t i = 0; i < n; i++) {
+    if (!seq_valid[i]) continue;
+    const uint64_t id = seq_taxid[i];
+    size_t h = (size_t)((id * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+    while (slot[h] != 0xffffffffu && tax_of_dense[slot[h]] != id) h = (h + 1) & (cap - 1);
+    if (slot[h] == 0xffffffffu) { slot[h] = (uint32_t)tax_of_dense.size(); tax_of_dense.push_back(id); }
+    seq_dense[i] = slot[h];
+  }
+}
+
 int FmiFile::load(const char *path, std::string &msg, bool lazy) {
   FILE *fp = fopen(path, "rb");
   if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
@@ -605,7 +624,7 @@ int PackedIndex::read_image(const char *path, std::string &msg, bool lazy_big) {
 void PackedIndex::build_text_wide(uint32_t shift) {
   sa_full.clear(); text.clear(); row_seq.clear(); sa_tpos5.clear();
   tv_shift = shift;
-  if (!wide || blocks64.empty() || term_pos.empty() || shift > 8) return;
+  if (!wide || blocks64.empty() || term_pos.empty() || shift > 8 || (warnings & KAIJU_IDX_WARN_SA_SHORT)) return;   // (as capi.hip decides)
   const DevIndex d = host_view();
   std::vector<uint32_t> t_seq(nseq), len(nseq, 0);
   std::atomic<bool> ok{true};
@@ -639,7 +658,8 @@ void PackedIndex::build_text() {
   sa_full.clear(); text.clear(); row_seq.clear(); sa_tpos5.clear();
   if (wide || sa_pos.empty() || blocks64.empty() || bwtlen + nseq + 2 * kTextPad >= 0xffffffffull) return;
   const DevIndex d = host_view();
-  BigVec<uint32_t> rs((size_t)bwtlen), rp((size_t)bwtlen);
+  BigVec<uint32_t> rs((size_t)bwtlen + 4), rp((size_t)bwtlen);      // (rs: four entries of padding for the locate's 16-byte loads)
+  for (int q = 0; q < 4; q++) rs[(size_t)bwtlen + q] = 0xffffffffu;
   std::atomic<bool> ok{true};
   // (an index with the reference's short sample array, KAIJU_IDX_WARN_SA_SHORT: the handful of rows whose walk runs into the
   //  missing sample are resolved through the next one; a locate of such a row stays undefined, i.e. skipped - see below)
@@ -674,6 +694,21 @@ void PackedIndex::build_text() {
   });
   row_seq.swap(rs);
   for (uint64_t r : beyond_rows) row_seq[(size_t)r] = 0xffffffffu;        // located rows: no sequence (the reference reads out of bounds)
+  beyond_lo = beyond_n = beyond_row = 0;
+  if (!beyond_rows.empty()) {
+    // they lie next to each other in the text (one walk towards the missing sample): DevIndex::beyond_lo
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (uint64_t r : beyond_rows) { lo = std::min(lo, sa_full[(size_t)r]); hi = std::max(hi, sa_full[(size_t)r]); }
+    if (hi - lo + 1 != beyond_rows.size()) { sa_full.clear(); text.clear(); row_seq.clear(); return; }
+    beyond_lo = lo; beyond_n = (uint32_t)beyond_rows.size(); beyond_row = (uint32_t)beyond_rows[0];
+  }
+  // row -> sequence becomes row -> dense taxon index (DevIndex::row_tax)
+  std::vector<uint32_t> seq_dense;
+  dense_taxa(seq_taxid, seq_valid, seq_dense, tax_of_dense);
+  parallel_for((bwtlen + 65535) / 65536, [&](uint64_t chunk) {
+    const uint64_t b = chunk * 65536, e = std::min<uint64_t>(bwtlen, b + 65536);
+    for (uint64_t r = b; r < e; r++) { const uint32_t q = row_seq[(size_t)r]; row_seq[(size_t)r] = q < nseq ? seq_dense[q] : 0xffffffffu; }
+  });
 }
 
 int PackedIndex::image_source_bytes(const char *path, uint64_t &bytes, std::string &msg) {
@@ -707,7 +742,9 @@ DevIndex PackedIndex::host_view() const {
   d.kline = kline.empty() ? nullptr : kline.data();
   d.sa_full = sa_full.empty() ? nullptr : sa_full.data();
   d.text = text.empty() ? nullptr : text.data();
-  d.row_seq = row_seq.empty() ? nullptr : row_seq.data();
+  d.row_tax = row_seq.empty() ? nullptr : row_seq.data();
+  d.tax_of_dense = tax_of_dense.empty() ? nullptr : tax_of_dense.data(); d.n_dense = (uint32_t)tax_of_dense.size();
+  d.beyond_lo = beyond_lo; d.beyond_n = getenv("KAIJU_EMU_NO_BEYOND_RULE") ? 0u : beyond_n; d.beyond_row = beyond_row;   // (the knob: tests show what the rule is for)
   d.sa_tpos5 = sa_tpos5.empty() ? nullptr : sa_tpos5.data(); d.tv_shift = tv_shift;
   return d;
 }

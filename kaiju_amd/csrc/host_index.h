@@ -93,7 +93,9 @@ struct PackedIndex {
   BigVec<uint32_t> sa_pos;        // offset (within its sequence) of every sampled row: what the text builder needs besides sa_iseq
                                   // (narrow indexes; empty where an offset does not fit 32 bits)
   // text verification (DevIndex::sa_full / text), built on the HOST for the test emulation only - the device builds its own
-  BigVec<uint32_t> sa_full, row_seq;
+  BigVec<uint32_t> sa_full, row_seq;    // (row_seq: DevIndex::row_tax once build_text is through - dense taxon indices)
+  std::vector<uint64_t> tax_of_dense;
+  uint32_t beyond_lo = 0, beyond_n = 0, beyond_row = 0;   // DevIndex::beyond_*
   BigVec<uint8_t> text;
   BigVec<uint8_t> sa_tpos5;       // wide layout: DevIndex::sa_tpos5 (text position of every 2^tv_shift-th row)
   uint32_t tv_shift = 0;
@@ -140,6 +142,11 @@ struct PackedIndex {
   int read_image(const char *path, std::string &msg, bool lazy_big = false);
   static int image_source_bytes(const char *path, uint64_t &bytes, std::string &msg);   // header field of an image file
 };
+
+// the taxa of the sequences as dense indices in first-seen order (DevIndex::row_tax / tax_of_dense): seq_dense[i] = index of
+// sequence i's taxon, 0xffffffff for a name without a usable id
+void dense_taxa(const std::vector<uint64_t> &seq_taxid, const std::vector<uint8_t> &seq_valid, std::vector<uint32_t> &seq_dense,
+                std::vector<uint64_t> &tax_of_dense);
 
 // name -> taxon id with the rule of ids_from_SI (ConsumerThread.cpp:809-833)
 bool parse_taxid(const char *name, uint64_t &id);

@@ -98,8 +98,21 @@ struct DevIndex {
   // replace - in the benchmark workload - twenty dependent rank steps per such match, 36 of 76 steps per read.
   const uint32_t *sa_full;   // [bwtlen] position in text[] of the suffix of row r; nullptr = no text verification
   const uint8_t *text;       // 64 zero bytes, then per sequence (in the order of the sampled sequence numbers) 0 + its residues
-  const uint32_t *row_seq;   // [bwtlen] the sequence the suffix of row r lies in, as get_suffix finds it by walking to a sampled row
-                             // (built along with sa_full): k_mem_locate reads an id with two loads instead of walking; nullptr = walk
+  const uint32_t *row_tax;   // [bwtlen] the TAXON of the sequence the suffix of row r lies in (get_suffix's walk to a sampled row,
+                             // done for every row along with sa_full), as a dense index into tax_of_dense; 0xffffffff = the row
+                             // contributes no id (a name without a usable taxon id, ids_from_SI :809-833; a row behind the missing
+                             // sample of a KAIJU_IDX_WARN_SA_SHORT index).  The rows of a match are neighbours here: ids_from_SI's
+                             // scan over them is contiguous loads only (round 4 kept the SEQUENCE per row: two more, dependent,
+                             // random loads a row - seq_valid, seq_taxid - which was half the step on a database of protein
+                             // families).  nullptr = the locate walks
+  const uint64_t *tax_of_dense;  // [n_dense] taxon id of a dense index (kaijux ids: the sequence number itself)
+  uint32_t n_dense;
+  // KAIJU_IDX_WARN_SA_SHORT indexes with text arrays: the text positions [beyond_lo, beyond_lo + beyond_n) are the suffixes
+  // whose get_suffix walk runs into the missing sample (the reference reads out of bounds there; the walking locate skips such a
+  // row).  A match that the text grew is recorded through the row where the text took over, not through its own end row - so
+  // the lane applies the skip to the END of the grown match itself (K_SAPOS / K_TEXT), and the records do not depend on whether
+  // the text arrays exist.  beyond_row: a row of that range (its row_tax says "no id").  beyond_n = 0: nothing to do
+  uint32_t beyond_lo, beyond_n, beyond_row;
   // the same for indexes with 64-bit positions (mb_base set) that leave room: text[] as above and the position in it of the
   // suffix of every 2^tv_shift-th row, 40 bits each (tv_shift = 0 where HBM allows, e.g. 6 B per row at 4 G rows; 1 at
   // refseq_ref's 28 G rows: 3.5 B per row).  A one-row search steps on until its row is one of those (tv_shift = 1: one more
@@ -2508,6 +2521,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         const uint32_t q = (uint32_t)lo & 3u;
         kidx = q == 0 ? (uint32_t)gv.x : q == 1 ? (uint32_t)(gv.x >> 32) : q == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
         kind = K_TEXT;
+        // (KAIJU_IDX_WARN_SA_SHORT: a row behind the missing sample keeps stepping - the match is then recorded through its
+        //  own end row, whose locate decides as the lanes without the text arrays do; see DevIndex::beyond_lo)
+        if (ix.beyond_n && kidx - ix.beyond_lo < ix.beyond_n) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
       }
     } else if (kind == K_TEXT) {
       // UpdateSI on a one-row interval succeeds iff the letter in front of the suffix is the next letter of the read
@@ -2537,7 +2553,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       }
       if (best >= 0 || i <= kTextCmp) {
         const int x = best >= 0 ? i - kTextCmp + best : -1;
-        i = x < 0 ? 0 : x + 1;
+        const int i_new = x < 0 ? 0 : x + 1;
+        if constexpr (!WIDE) {
+          // (KAIJU_IDX_WARN_SA_SHORT: the suffix of the grown match itself lies behind the missing sample - its row gives no
+          //  id, as for the lanes that step there: recorded through a row that says so)
+          if (ix.beyond_n && kidx - (uint32_t)(i - i_new) - ix.beyond_lo < ix.beyond_n) { lo = (P)ix.beyond_row; hi = lo + 1; }
+        }
+        i = i_new;
         bk = BK_END_MATCH;                                  // (lo, hi still name the one row the search had reached: same sequence)
       } else {
         // all of them agree and there are more: one more round (fragments this long are rare: i <= kWin at the first one)
@@ -2787,20 +2809,21 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   const RankBlock64 *const blk0 = ix.blocks64;
   uint32_t nids = 0, flags = fl0 & ~kHitLocPending;          // (a Greedy read may carry kHitSiCap already)
   uint64_t id0 = 0;
-  uint64_t idr[MANYROWS ? kMaxIds : 1];
+  uint32_t idr[MANYROWS ? kMaxIds : 1];                      // MANYROWS: the dense taxon indices collected so far
   if constexpr (MANYROWS) {
 #pragma unroll
     for (int q = 0; q < kMaxIds; q++) idr[q] = 0;
   }
+  // an id of the read: a taxon id - or, on the row_tax path, its dense index (translated when the record is written)
   auto add_tax = [&](uint64_t tax) {
     bool dup = false;
     if constexpr (MANYROWS) {
 #pragma unroll
-      for (int q = 0; q < kMaxIds; q++) dup = dup || (q < (int)nids && idr[q] == tax);
+      for (int q = 0; q < kMaxIds; q++) dup = dup || (q < (int)nids && idr[q] == (uint32_t)tax);
       if (!dup && nids < (uint32_t)kMaxIds) {
 #pragma unroll
-        for (int q = 0; q < kMaxIds; q++) if (q == (int)nids) idr[q] = tax;
-        hit->taxid[nids++] = tax;
+        for (int q = 0; q < kMaxIds; q++) if (q == (int)nids) idr[q] = (uint32_t)tax;
+        nids++;
       }
     } else {
       if (nids >= 1 && tax == id0) dup = true;
@@ -2808,18 +2831,37 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
       if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
     }
   };
+  bool dense = false;
+  if constexpr (!WIDE) dense = ix.row_tax != nullptr;
+  static_assert(!MANYROWS || !WIDE, "the many-rows locate reads the row -> taxon table of a narrow index");
   bool done = false;
   for (uint32_t s = 0; s < nsi && !done; s++) {
     const P lo = WIDE ? (P)(e[s] & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)e[s];
     const uint32_t len = WIDE ? (uint32_t)(e[s] >> kLocWideShift) : (uint32_t)(e[s] >> 32);
     const P rowend = lo + (P)(int32_t)len;
+    if constexpr (MANYROWS) {
+      // ids_from_SI's loop over the rows of the match (:803-844), four rows per 16-byte load of the row -> taxon table
+      for (P row4 = lo & ~(P)3; row4 < rowend && !done; row4 += 4) {
+        const u128 v = *reinterpret_cast<const u128 *>(ix.row_tax + row4);
+        const uint32_t t4[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const P row = row4 + (P)q;
+          if (row >= lo && row < rowend && !done) {
+            if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; }     // :805-807, in front of every row
+            else if (t4[q] != 0xffffffffu) add_tax(t4[q]);
+          }
+        }
+      }
+      continue;
+    }
     for (P row = lo; row < rowend; row++) {
       if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; break; }     // :805-807
       if constexpr (!WIDE) {
-        if (ix.row_seq) {
-          // the walk below, precomputed for every row at index load (k_suffix_walk)
-          const uint32_t iseq = ix.row_seq[row];
-          if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+        if (dense) {
+          // the walk below, precomputed for every row at index load (k_suffix_walk), down to the taxon
+          const uint32_t t = ix.row_tax[row];
+          if (t != 0xffffffffu) add_tax(t);
           continue;
         }
       }
@@ -2855,6 +2897,12 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
         k = (P)(base + rb.cnt[c - 1u] + popc64(m & ((1ull << sft) - 1ull)));
       }
     }
+  }
+  if constexpr (MANYROWS) {
+#pragma unroll
+    for (int q = 0; q < kMaxIds; q++) if (q < (int)nids) hit->taxid[q] = ix.tax_of_dense[idr[q]];
+  } else if (dense) {
+    for (uint32_t q = 0; q < nids; q++) hit->taxid[q] = ix.tax_of_dense[q == 0 ? id0 : hit->taxid[q]];
   }
   for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;   // (the slots that held the matches and got no id)
   hit->n_ids = nids; hit->flags = flags;
@@ -2910,9 +2958,9 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
   // the id of one row: ~0 = none (a name without a usable id, or a row beyond the samples, where the reference reads out of bounds)
   auto walk = [&](P k) -> uint64_t {
     if constexpr (!WIDE) {
-      if (ix.row_seq) {                                       // the walk below, precomputed for every row at index load (k_suffix_walk)
-        const uint32_t iseq = ix.row_seq[k];
-        return (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
+      if (ix.row_tax) {                                       // the walk below, precomputed for every row at index load (k_suffix_walk)
+        const uint32_t t = ix.row_tax[k];
+        return t != 0xffffffffu ? ix.tax_of_dense[t] : ~0ull;
       }
     }
     for (;;) {

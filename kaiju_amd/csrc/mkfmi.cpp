@@ -551,7 +551,6 @@ int build(const char *faa, const char *out, int threads, int chpt_exp, uint64_t 
   ok &= W(startLcode, (size_t)(alen + 1) * 4);
   ok &= fclose(fp) == 0;
   if (!ok) { g_err = "write error"; return KAIJU_GPU_ERR_IO; }
-  return KAIJU_GPU_OK;  if (!ok) { g_err = "write error"; return KAIJU_GPU_ERR_IO; }
   bc.mark("write");
   return KAIJU_GPU_OK;
 }

@@ -31,11 +31,12 @@ struct EmuIndex {
 
 extern "C" {
 
-void *emu_index_load(const char *path, char *err, int errlen) {
+static void *emu_index_load_mode(const char *path, char *err, int errlen, bool xmode) {
   EmuIndex *ix = new EmuIndex();
   std::string msg;
   int rc = ix->file.load(path, msg);
   if (rc == 0) rc = ix->packed.build(ix->file.view(), msg);
+  if (rc == 0 && xmode) { ix->packed.to_sequence_ids(); ix->xmode = true; }     // (before the text arrays, as index_from_packed does)
   if (rc == 0) ix->packed.build_klines();          // (the device builds its k-mer lines in capi.hip: k_kline_build)
   if (rc == 0 && !getenv("KAIJU_EMU_NO_TEXT")) {
     // (... and its text arrays: k_suffix_walk, k_text_build; wide: k_seq_walk_len, k_seq_walk_fill - text positions of every
@@ -50,12 +51,9 @@ void *emu_index_load(const char *path, char *err, int errlen) {
   if (getenv("KAIJU_EMU_DROP_FILE")) { BigVec<uint8_t>().swap(ix->file.bwt); BigVec<uint8_t>().swap(ix->file.sa); }
   return ix;
 }
+void *emu_index_load(const char *path, char *err, int errlen) { return emu_index_load_mode(path, err, errlen, false); }
 // kaijux semantics: ids are sequence numbers
-void *emu_index_load_x(const char *path, char *err, int errlen) {
-  EmuIndex *ix = (EmuIndex *)emu_index_load(path, err, errlen);
-  if (ix) { ix->packed.to_sequence_ids(); ix->xmode = true; }
-  return ix;
-}
+void *emu_index_load_x(const char *path, char *err, int errlen) { return emu_index_load_mode(path, err, errlen, true); }
 void emu_index_free(void *h) { delete (EmuIndex *)h; }
 uint32_t emu_index_warnings(void *h) { return ((EmuIndex *)h)->packed.warnings; }
 // 1: the text arrays of text verification were built (sa_full / text / row_seq); number of rows whose row_seq says "no sequence"
@@ -72,7 +70,8 @@ uint64_t emu_text_pos(void *h, uint64_t r) {
 }
 uint64_t emu_rows_without_sequence(void *h) {
   uint64_t n = 0;
-  for (uint32_t v : ((EmuIndex *)h)->packed.row_seq) n += v == 0xffffffffu;
+  const PackedIndex &pk = ((EmuIndex *)h)->packed;
+  for (uint64_t r = 0; r < pk.bwtlen && r < pk.row_seq.size(); r++) n += pk.row_seq[(size_t)r] == 0xffffffffu;   // (behind the last row: padding)
   return n;
 }
 // the product's ln(n!) table (host_tables.cpp: build_seg_tables), entry n; -1 beyond it; emu_lnfact_n(): its length
@@ -345,7 +344,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     const bool serial = getenv("KAIJU_EMU_LOCATE_SERIAL") != nullptr;
     if (d.mb_base) { if (serial) mem_locate_read<true>(d, p, &hits[r]); else { TeamSerial<4> tm; mem_locate_read_team<true, 4>(d, p, &hits[r], tm); } }
     else if (serial) mem_locate_read<false>(d, p, &hits[r]);
-    else if (d.row_seq) { if (!mem_locate_read<false>(d, p, &hits[r], 8)) mem_locate_read<false, true>(d, p, &hits[r]); }   // (k_mem_locate, k_mem_locate_list)
+    else if (d.row_tax) { if (!mem_locate_read<false>(d, p, &hits[r], 8)) mem_locate_read<false, true>(d, p, &hits[r]); }   // (k_mem_locate, k_mem_locate_list)
     else { TeamSerial<4> tm; mem_locate_read_team<false, 4>(d, p, &hits[r], tm); }
   }
   // the exact pass (kj_core.h: BigSeg), as capi.hip's k_redo_* kernels run it behind the retry pass
