@@ -1375,6 +1375,7 @@ extern "C" int kaiju_gpu_index_load(const char *fmi_path, int device_id, kaiju_g
   // the BWT and the sampled suffix array stay in the file: they are streamed to the device and packed there (fmi_stream.h)
   PackedIndex pk;
   rc = pk.build_streamed(f, fmi_path, msg);
+  { std::vector<std::string>().swap(f.ids); std::vector<const char *>().swap(f.id_ptrs); }    // (pk has its own copy of the names)
   lc.mark("names, taxon ids (host)");
   const int drc = device_check_result(dev);
   lc.mark("wait for the HIP runtime");

@@ -10,6 +10,7 @@
 #   stats_greedy     ... of --mode greedy                                             -> kernel_stats_greedy.csv
 #   pmc              PMC passes of the search kernels (tests/tools/pmc_bench.sh) + profiles/traffic.json
 #   refseq_ref       BASELINE configs[3] at its named scale (28 G rows: 14.3 M proteins x 7): bench.py --image --paired
+#   refseq           BASELINE configs[4], single-GPU half (56 G rows: 14.3 M proteins x 14), the .fmi streamed to HBM, no image
 #   py:<script>      python <script> ("," stands for a blank)                         -> py_<n>.log
 #   sh:<script>      bash <script>                                                    -> sh_<n>.log
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -62,6 +63,43 @@ for task in "$@"; do
       ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$task -o s -- python $GRAFT_REPO_ROOT/bench.py --work $W --nseq $NSEQ --image --no-cpu-baseline --legs "" --steps 3 --warmup 1 $(echo $ARGS | sed 's/--steps [0-9]*//; s/--legs [a-z]*//') > $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.err )
       cp $O/stats_$task/s_kernel_stats.csv $O/kernel_stats_$task.csv 2>/dev/null; rm -rf $O/stats_$task; head -6 $O/kernel_stats_$task.csv
       kill $WD 2>/dev/null
+      sort -k2 -n $O/memory_$task.txt | tail -1 > $O/memory_peak_$task.txt; rm -f $O/memory_$task.txt
+      rm -rf $W ;;
+    refseq)
+      # BASELINE configs[4], its single-GPU half: a refseq-class index (README.md:102: 111 GB .fmi) on ONE MI355X.  The 4.0 G-row
+      # database of refseq_ref above with every protein FOURTEEN times = 56 G rows, .fmi ~107 GB in /dev/shm - and nothing else
+      # staged: the .fmi is streamed to HBM and packed there (fmi_stream.hip), no image, no host copy.  The .fmi is built by a
+      # process of its own (--prepare-only) so that the bench process's peak resident set is the LOADER's (+ the reads).
+      # Every step runs in a process group of its own; a watchdog ends exactly that group before the cgroup (300 GiB incl.
+      # /dev/shm) would end the box.
+      W=/dev/shm/kaiju_big_$task; mkdir -p $W
+      NSEQ=14300001; COPIES=${LEASE_REFSEQ_COPIES:-14}
+      ARGS="--copies $COPIES --paired --reads 5000000 --steps 10 --legs greedy --leg-steps 2 --cpu-sample 100000 --cpu-sample-legs 100000"
+      guarded() {        # guarded <log of stdout> <log of stderr> <command...>
+        local out=$1 err=$2; shift 2
+        setsid bash -c "exec $*" > $out 2> $err &
+        local bp=$!
+        ( while sleep 2; do
+            kill -0 $bp 2>/dev/null || break
+            cur=$(cat /sys/fs/cgroup/memory.current 2>/dev/null || echo 0)
+            echo "$(date +%s) $cur" >> $O/memory_$task.txt
+            if [ "$cur" -gt 300000000000 ]; then echo "[lease] memory watchdog: $cur bytes - ending the step" >> $err; kill -KILL -- -$bp; rm -rf $W; break; fi
+          done ) &
+        local wd=$!
+        wait $bp; local rc=$?
+        kill $wd 2>/dev/null
+        return $rc
+      }
+      t1=$(date +%s)
+      guarded $O/prepare_$task.log $O/prepare_$task.err timeout 1500 python bench.py --work $W --nseq $NSEQ --copies $COPIES --prepare-only
+      echo "[lease] prepare rc=$? ($(( $(date +%s) - t1 )) s)"; grep -v "kaiju mkfmi\]" $O/prepare_$task.err | tail -5
+      ls -la $W > $O/files_$task.txt; df -h /dev/shm >> $O/files_$task.txt; free -g >> $O/files_$task.txt
+      KAIJU_GPU_LOAD_TIMES=1 guarded $O/bench_$task.json $O/bench_$task.err timeout ${LEASE_BIG_TIMEOUT:-1500} python bench.py --work $W --nseq $NSEQ --warmup 1 --no-ref-ops $ARGS
+      echo "[lease] $task rc=$?"; grep -v "^\[kaiju_gpu pack\]" $O/bench_$task.err | tail -40
+      if [ -d $W ]; then
+        ( cd /tmp && KAIJU_GPU_LOAD_TIMES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_$task -o s -- python $GRAFT_REPO_ROOT/bench.py --work $W --nseq $NSEQ --no-cpu-baseline --legs "" --steps 3 --warmup 1 --copies $COPIES --paired --reads 5000000 > $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_${task}_under_rocprof.err )
+        cp $O/stats_$task/s_kernel_stats.csv $O/kernel_stats_$task.csv 2>/dev/null; rm -rf $O/stats_$task; head -8 $O/kernel_stats_$task.csv
+      fi
       sort -k2 -n $O/memory_$task.txt | tail -1 > $O/memory_peak_$task.txt; rm -f $O/memory_$task.txt
       rm -rf $W ;;
     py:*)

@@ -10,7 +10,7 @@
 # measured gate1 / gate3 / roll / locp / gdefer / g_occ3 this way (profiles/r03_variants/): the winners are the default code now
 R=$(cd "$(dirname "$0")/../.." && pwd)
 V=$R/kaiju_amd/variants
-SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp"
+SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/fmi_stream.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-gpu-rdc -Wno-unused-result -w"
 declare -A DEF=( [cur]="" [prof]="-DKJ_PROF" [stats]="-DKJ_STATS" [ovf]="-DKJ_OVF_STATS" [norule]="-DKJ_NO_SPAN_RULE -DKJ_NO_PROBE" [noprobe]="-DKJ_NO_PROBE" [nospaneq]="-DKJ_NO_SPAN_EQ" )
 LIST=${VARIANTS:-cur prof}
