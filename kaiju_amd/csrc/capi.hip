@@ -274,10 +274,13 @@ __device__ __forceinline__ void mem_body(const DevIndex &ix, const Params &p, co
   mem_lane<P>(ix, p, b, wl, ls, vb);
 }
 // second-generation lane (kj_core.h:mem_lane2): indexes below 2^32 symbols with a k-mer table
+#ifndef KJ_MEM_WAVES
+#define KJ_MEM_WAVES 4                             // wavefronts per SIMD the narrow MEM lane is compiled for (111 VGPRs since the locate left it)
+#endif
 #ifdef KJ_PROF
 __global__ void __launch_bounds__(kBlock, 3)      // (the section marks need a few registers: no spills at three wavefronts per SIMD)
 #else
-__global__ void __launch_bounds__(kBlock, 4)
+__global__ void __launch_bounds__(kBlock, KJ_MEM_WAVES)
 #endif
 k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
@@ -338,7 +341,7 @@ k_mem_locate_team(DevIndex ix, Params p, Batch b) {
 }
 // the same kernel under a second name for the second search of the lazy SEG flow (the few reads whose fragments SEG had
 // to cut), so that a kernel trace lists the full-size launches of k_mem by themselves
-__global__ void __launch_bounds__(kBlock, 4)
+__global__ void __launch_bounds__(kBlock, KJ_MEM_WAVES)
 k_mem_second(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
   const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1812,9 +1815,9 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
           else hipLaunchKernelGGL(k_mem_wide2, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
         }
       };
-      // reads with one or two longest matches are located by k_mem_locate behind the searches (KAIJU_GPU_MEM_LOCATE=inline: by
-      // the search lanes themselves, as in round 1)
-      const bool defer = mem_v2 && !xo && c->defer_locate;
+      // the second-generation lanes leave the longest matches of every read in its hit record; k_mem_locate* behind the
+      // searches turn them into ids (round 1-4: reads with three and more matches, and kaijux, were walked by the search lane)
+      const bool defer = mem_v2;
       Params pd = p;
       if (defer) pd.flags |= kParamDeferLocate;
       if (mem_v2) {

@@ -2173,11 +2173,11 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
 // in chunks of consecutive reads (one atomic per chunk, guided chunk size), lanes take reads
 // from the wave's chunk with a ballot/prefix count.
 // ----------------------------------------------------------------------------
-enum MemKind : int { K_STEP, K_KMER, K_LF1, K_LF2, K_SA, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT,
+enum MemKind : int { K_STEP, K_KMER, K_META, K_FRAG, K_FILL, K_IDLE, K_EXIT, K_WAIT,
                      K_SAPOS, K_TEXT,     // text verification: suffix-array entry of the row, then the text in front of it
                      K_PROBE,             // narrow: a k-mer lookup that decides L-k+1 end positions at once (kMemProbe)
                      K_BK = 16 };         // K_BK + b: bookkeeping block b of MemBk is due (no memory access)
-enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_LOC_NEXT_SI, BK_LOC_ROW, BK_FINISH };
+enum MemBk : int { BK_NONE, BK_END_MATCH, BK_START_J, BK_NEXT_FRAG, BK_LOC_INIT, BK_FINISH };
 
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -2227,11 +2227,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   bool fill_newfrag = false, fill_step = false;
   // first two maximal matches live in registers, further ones in the lane's scratch
   P s0lo = 0, s1lo = 0; uint32_t s0len = 0, s1len = 0, s0frag = 0, s1frag = 0;
-  // locate
-  uint32_t gs = 0, ge = 0, cur = 0, nids = 0, flags = 0;
-  P row = 0, rowend = 0, k = 0;
-  uint64_t id0 = 0, sa_idx = 0;
-  bool fresh = true;                          // k is the first row of its walk (the id cap is tested there)
+  // (the ids: every read leaves its longest matches in the hit record and k_mem_locate* walk them - since round 5 also reads
+  //  with three and more, whose walks used to run here with one lane of the wavefront at work and, on a database of protein
+  //  families or with an unlucky sample, for thousands of iterations behind the end of everything else)
+  uint32_t nids = 0, flags = 0;
+  P k = 0;                                    // (wide: text position of the row at hand, K_SAPOS / K_TEXT)
   Hit *hit = nullptr;
   LaneWin lw{ls.win, 0};
   const P check = (P)((1ull << ix.chpt_exp) - 1);
@@ -2317,24 +2317,23 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     KJ_PM(PM_LOAD);
     KJ_HISTO(5, kind);
     if (kind == K_STEP) KJ_HISTO(4, (uint32_t)(j - i + 1));   // match length before this step
-    const bool is_step = kind == K_STEP, is_lf = kind == K_LF1 || kind == K_LF2;
+    const bool is_step = kind == K_STEP;
     const bool is_kmer = kind == K_KMER || (!WIDE && kind == K_PROBE);
-    const P posA = is_step ? lo : is_lf ? k : 0;
+    const P posA = is_step ? lo : 0;
     const P posB = is_step ? hi : posA;
     if constexpr (COUNT) {
-      // one rank block line per LF step (K_LF1 and K_LF2 read the same block), one or two per UpdateSI
+      // one or two rank block lines per UpdateSI
       oc[kOpcLaneIters] += (kind != K_EXIT) ? 1u : 0u;
       if (kj_lane() == 0) oc[kOpcIters]++;
       if (is_kmer) oc[kOpcKmer]++;
       else if (kind == K_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
-      else if (kind == K_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
-      else if (kind == K_SA || kind == K_SAPOS) oc[kOpcSa]++;                 // (a suffix-array line either way)
+      else if (kind == K_SAPOS) oc[kOpcSa]++;                                  // (a suffix-array line)
       else if (kind == K_TEXT) oc[kOpcFill]++;                                 // (64 bytes of text: priced like a window)
       else if (kind == K_META) oc[kOpcMeta]++;
       else if (kind == K_FRAG) oc[kOpcFrag]++;
       else if (kind == K_FILL) { oc[kOpcFill]++; if (fill_newfrag && f < nf) oc[kOpcFrag]++; }
     }
-    const uint32_t cc = (is_step || kind == K_LF2) ? c : 1u;
+    const uint32_t cc = is_step ? c : 1u;
     const bool kline_step = !WIDE && is_kmer;
     u128 a01, a23, b01, b23;
     uint64_t a4, b4;
@@ -2365,7 +2364,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
     if (is_kmer) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
-    else if (kind == K_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == K_SAPOS) gaddr = WIDE ? ix.sa_tpos5 + (size_t)((uint64_t)lo >> ix.tv_shift) * 5u : reinterpret_cast<const uint8_t *>(ix.sa_full + lo);
     else if (kind == K_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == K_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
@@ -2393,13 +2391,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     // ---- (2) compute ----
     int bk = BK_NONE;
     bool noprobe = false;                                 // the search from j comes next whatever its k-mers say (a probe found its k-mer)
-    if (is_step || kind == K_LF2) {
+    if (is_step) {
       KJ_PM(PM_STEP);
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
       const P ra = (P)(mba + ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull)));
-      if (is_step) {
+      {
         // UpdateSI(str[i-1]) (bwt.c:160-173)
         const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
         const P rb = (P)(mbb + cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull)));
@@ -2418,10 +2416,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           else if (in_win(i - 1)) c = lw.w[i - 1 - lw.q];
           else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
         }
-      } else {
-        // second half of an LF step (FMindexCurrent, compactfmi.c:312-336): k = C[c] + rank(c, k)
-        k = ra; fresh = false;
-        bk = BK_LOC_ROW;                                   // re-enters at the checkpoint test
       }
     } else if (is_kmer) {
       KJ_PM(PM_KMER);
@@ -2471,46 +2465,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         }
         else { fill_top = i - 1; fill_newfrag = false; fill_step = true; kind = K_FILL; }
       }
-    } else if (kind == K_LF1) {
-      KJ_PM(PM_LF1);
-      // first half of an LF step: the BWT letter of row k
-      const uint32_t sft = k & 63u;
-      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
-          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
-      if (c != 0) kind = K_LF2;
-      else {
-        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
-        if constexpr (COUNT) oc[kOpcTerm]++;
-        const uint32_t iseq = (uint32_t)rank_term(ix, k);
-        if (iseq < ix.nseq && ix.seq_valid[iseq]) {
-          const uint64_t tax = ix.seq_taxid[iseq];
-          bool dup = false;
-          if (nids >= 1 && tax == id0) dup = true;
-          for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-          if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
-        }
-        row++;
-        k = row; fresh = true;
-        bk = BK_LOC_ROW;
-      }
-    } else if (kind == K_SA) {
-      KJ_PM(PM_SA);
-      uint64_t tax;
-      if constexpr (WIDE) {
-        // the wide layout keeps the sequence number of a sampled row (4 bytes), not its taxon id (8): one more, dependent, read
-        const uint32_t q = (uint32_t)sa_idx & 3u;
-        const uint32_t iseq = q == 0 ? (uint32_t)gv.x : q == 1 ? (uint32_t)(gv.x >> 32) : q == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
-        tax = (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
-      } else tax = ghalf ? gv.y : gv.x;
-      if (tax != ~0ull) {
-        bool dup = false;
-        if (nids >= 1 && tax == id0) dup = true;
-        for (uint32_t q = 1; q < nids && !dup; q++) if (hit->taxid[q] == tax) dup = true;
-        if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
-      }
-      row++;
-      k = row; fresh = true;
-      bk = BK_LOC_ROW;
     } else if (kind == K_SAPOS) {
       // position in the text of the suffix of row lo = of fragment position i
       if constexpr (WIDE) {
@@ -2605,8 +2559,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
     KJ_PM(PM_TAIL);
     // ONE pass over the blocks, which stand in the order of the usual flow (a `while` around them made every variable of the
     // lane a loop-carried value: the compiler copied some thirty registers at the head of that loop and again at every join -
-    // half of the kernel's VALU instructions were v_mov).  The one transition against that order - the walk over the rows of
-    // three and more longest matches: LOC_ROW -> LOC_NEXT_SI - waits for the next iteration (kind = K_BK + block).
+    // half of the kernel's VALU instructions were v_mov).
     {
       if (bk == BK_END_MATCH) {
         KJ_PM(PM_END_MATCH);
@@ -2713,13 +2666,12 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           else if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
           else flags = kHitInternalOverflow;
           bk = BK_FINISH;
-        } else if (!XORDER && (p.flags & kParamDeferLocate) && nsi <= 2u &&
-                   (!WIDE || (s0len < kLocWideMaxLen && (nsi < 2u || s1len < kLocWideMaxLen)))) {
+        } else if (nsi <= 2u && (!WIDE || (s0len < kLocWideMaxLen && (nsi < 2u || s1len < kLocWideMaxLen)))) {
           // the locate walks of 64 different reads share nothing: they run with two or three lanes of a wavefront active
-          // (a third of this kernel's time, profiles/r02_gprof).  The matches are noted in the order in which the walk
-          // below would visit them (matches of one fragment: found for descending j, visited for ascending j) and
-          // k_mem_locate walks them with every lane at work.
-          const bool swap = nsi == 2u && s0frag == s1frag;
+          // (a third of this kernel's time, profiles/r02_gprof).  The matches are noted in the order in which ids_from_SI
+          // visits them (matches of one fragment: found for descending j, visited for ascending j; kaijux - XORDER - keeps
+          // the order in which they were found) and k_mem_locate* walk them with every lane at work.
+          const bool swap = !XORDER && nsi == 2u && s0frag == s1frag;
           // (narrow: row | length << 32; wide: row | length << 40, lengths below 2^24)
           const uint64_t e0 = WIDE ? ((uint64_t)s0lo | (uint64_t)s0len << kLocWideShift) : ((uint64_t)(uint32_t)s0lo | (uint64_t)s0len << 32);
           const uint64_t e1 = WIDE ? ((uint64_t)s1lo | (uint64_t)s1len << kLocWideShift) : ((uint64_t)(uint32_t)s1lo | (uint64_t)s1len << 32);
@@ -2727,44 +2679,34 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           if (nsi == 2u) hit->taxid[1] = swap ? e0 : e1;
           nids = nsi; flags = kHitLocPending;
           bk = BK_FINISH;
-        } else { gs = ge = 0; cur = XORDER ? 1u : 0u; bk = BK_LOC_NEXT_SI; }
-      }
-      if (bk == BK_LOC_NEXT_SI) {
-        KJ_PM(PM_LOC_NEXT_SI);
-        // matches of one fragment were found for descending j but are visited for ascending j
-        // (greedyExact prepends, ids_from_SI_recursive walks from the head, :835-845).
-        // XORDER (kaijux, whose classify_length searches with maxMatches(.., 1), ConsumerThreadx.cpp:135): the list
-        // head is the match found FIRST, the others follow newest first (insert_SI_sorted, bwt.c:241-245), i.e. the
-        // visiting order is gs, ge-1, ge-2, .., gs+1; cur runs from ge+1 down to gs+1 and cur == ge stands for gs
-        bool any = true;
-        if (cur == gs + (XORDER ? 1u : 0u)) {
-          gs = ge;
-          if (gs >= nsi) { bk = BK_FINISH; any = false; }
-          else {
-            const uint32_t fr = si_frag(gs);
-            ge = gs + 1;
-            while (ge < nsi && si_frag(ge) == fr) ge++;
-            cur = ge + (XORDER ? 1u : 0u);
+        } else {
+          // three and more longest matches (two reads in ten thousand on random data, a few in a hundred on a database of
+          // protein families): all of them go into the record as well - nsi <= si_cap = 16 of its 21 slots - in visiting order:
+          // the matches of one fragment stand together (found for descending j); greedyExact prepends and
+          // ids_from_SI_recursive walks from the head (:835-845), so a fragment's matches are visited for ascending j.
+          // XORDER (kaijux, whose classify_length searches with maxMatches(.., 1), ConsumerThreadx.cpp:135): the list head is
+          // the match found FIRST, the others follow newest first (insert_SI_sorted, bwt.c:241-245): gs, ge-1, .., gs+1.
+          bool big = false;
+          if constexpr (WIDE) for (uint32_t e = 0; e < nsi; e++) big = big || si_len(e) >= kLocWideMaxLen;
+          if (big || nsi > (uint32_t)kMaxIds) {
+            // (an interval of 2^24 rows and more does not fit the record's entry: the retry pass walks such a read itself)
+            if (p.flags & kParamLazySeg) flags = kHitRetry;
+            else if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+            else flags = kHitInternalOverflow;
+          } else {
+            uint32_t q = 0, gs = 0;
+            while (gs < nsi) {
+              const uint32_t fr = si_frag(gs);
+              uint32_t ge = gs + 1;
+              while (ge < nsi && si_frag(ge) == fr) ge++;
+              if (XORDER) hit->taxid[q++] = WIDE ? ((uint64_t)si_lo(gs) | (uint64_t)si_len(gs) << kLocWideShift) : ((uint64_t)(uint32_t)si_lo(gs) | (uint64_t)si_len(gs) << 32);
+              for (uint32_t e = ge; e-- > gs + (XORDER ? 1u : 0u);)
+                hit->taxid[q++] = WIDE ? ((uint64_t)si_lo(e) | (uint64_t)si_len(e) << kLocWideShift) : ((uint64_t)(uint32_t)si_lo(e) | (uint64_t)si_len(e) << 32);
+              gs = ge;
+            }
+            nids = nsi; flags = kHitLocPending;
           }
-        }
-        if (any) {
-          cur--;
-          const uint32_t e = (XORDER && cur == ge) ? gs : cur;
-          row = si_lo(e); rowend = row + (P)(int32_t)si_len(e);
-          k = row; fresh = true;
-          bk = BK_LOC_ROW;
-        }
-      }
-      if (bk == BK_LOC_ROW) {
-        KJ_PM(PM_LOC_ROW);
-        // k is either a fresh row (k == row) or the row reached by the LF walk so far
-        if (row >= rowend) bk = BK_LOC_NEXT_SI;
-        else if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; bk = BK_FINISH; }   // :805-807
-        else if ((k & check) != 0) { kind = K_LF1; bk = BK_NONE; }
-        else {
-          sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-          if (sa_idx < ix.n_sa) { kind = K_SA; bk = BK_NONE; }
-          else { row++; k = row; fresh = true; }           // (the reference reads out of bounds here): skip the row
+          bk = BK_FINISH;
         }
       }
       if (bk == BK_FINISH) {
@@ -2800,10 +2742,26 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   const uint32_t fl0 = hit->flags;
   if (!(fl0 & kHitLocPending)) return true;
   const uint32_t nsi = hit->n_ids;
-  const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
-  if (defer_rows) {
-    const uint64_t rows = (WIDE ? (e[0] >> kLocWideShift) : (e[0] >> 32)) + (nsi > 1u ? (WIDE ? (e[1] >> kLocWideShift) : (e[1] >> 32)) : 0ull);
-    if (rows > defer_rows) return false;
+  // the matches (row | length): the lean instantiation holds two in registers and hands reads with more on (they are rare:
+  // two in ten thousand on random data) - the many-rows one reads every entry when its turn comes: it only writes the record
+  // when it is through.  (Host emulation without a list: all of them copied first.)
+  constexpr uint32_t kEMax = MANYROWS ? 1u : 16u;
+  uint64_t e[kEMax];
+  e[0] = hit->taxid[0];
+  if constexpr (!MANYROWS) {
+    e[1] = nsi > 1u ? hit->taxid[1] : 0ull;
+    if (nsi > 2u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      return false;                                          // (device: k_mem_locate always has a list - k_mem_locate_list - behind it)
+#else
+      if (defer_rows) return false;
+      for (uint32_t q = 2; q < nsi && q < kEMax; q++) e[q] = hit->taxid[q];
+#endif
+    }
+    if (defer_rows) {
+      const uint64_t rows = (WIDE ? (e[0] >> kLocWideShift) : (e[0] >> 32)) + (nsi > 1u ? (WIDE ? (e[1] >> kLocWideShift) : (e[1] >> 32)) : 0ull);
+      if (rows > defer_rows) return false;
+    }
   }
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
@@ -2836,8 +2794,9 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   static_assert(!MANYROWS || !WIDE, "the many-rows locate reads the row -> taxon table of a narrow index");
   bool done = false;
   for (uint32_t s = 0; s < nsi && !done; s++) {
-    const P lo = WIDE ? (P)(e[s] & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)e[s];
-    const uint32_t len = WIDE ? (uint32_t)(e[s] >> kLocWideShift) : (uint32_t)(e[s] >> 32);
+    const uint64_t es = MANYROWS ? hit->taxid[s] : e[MANYROWS ? 0 : s];
+    const P lo = WIDE ? (P)(es & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)es;
+    const uint32_t len = WIDE ? (uint32_t)(es >> kLocWideShift) : (uint32_t)(es >> 32);
     const P rowend = lo + (P)(int32_t)len;
     if constexpr (MANYROWS) {
       // ids_from_SI's loop over the rows of the match (:803-844), four rows per 16-byte load of the row -> taxon table
@@ -2924,6 +2883,10 @@ struct TeamSerial {
   KJ_HD uint64_t get(int q) const { return vals[q]; }
   KJ_HD bool leader() const { return true; }
   KJ_HD bool from_leader(bool v) const { return v; }
+  // the matches of the read (row | length, up to sixteen), copied before the first id is written over them
+  uint64_t ent[16];
+  KJ_HD void load_entries(const uint64_t *rec, uint32_t n) { for (uint32_t q = 0; q < 16u; q++) ent[q] = q < n ? rec[q] : 0ull; }
+  KJ_HD uint64_t entry(uint32_t q) const { return ent[q]; }
 };
 #if defined(__HIPCC__)
 template <int T>
@@ -2936,6 +2899,19 @@ struct TeamWave {
   }
   __device__ __forceinline__ bool leader() const { return (threadIdx.x & (T - 1)) == 0; }
   __device__ __forceinline__ bool from_leader(bool v) const { return __shfl((int)v, (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)), 64) != 0; }
+  // the matches of the read (row | length, up to sixteen): lane t of the team keeps entries t, t + T, .. in registers - the
+  // leader writes ids over them later - and hands one out by a shuffle
+  uint64_t ent[16 / T];
+  __device__ __forceinline__ void load_entries(const uint64_t *rec, uint32_t n) {
+    const uint32_t tl = threadIdx.x & (T - 1);
+#pragma unroll
+    for (uint32_t q = 0; q < 16u / T; q++) ent[q] = tl + q * T < n ? rec[tl + q * T] : 0ull;
+  }
+  __device__ __forceinline__ uint64_t entry(uint32_t q) const {
+    const int src = (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)) + (int)(q % T);
+    const uint64_t v = ent[q / T];
+    return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32;
+  }
 };
 #endif
 template <bool WIDE, int T, class Team>
@@ -2944,7 +2920,8 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
   const uint32_t fl0 = hit->flags;                            // (every lane of the team reads the same record: team-uniform)
   if (!(fl0 & kHitLocPending)) return;
   const uint32_t nsi = hit->n_ids;
-  const uint64_t e[2] = {hit->taxid[0], nsi > 1u ? hit->taxid[1] : 0ull};
+  // the matches (row | length), up to sixteen: every lane of the team reads all of them before the leader writes the first id
+  team.load_entries(hit->taxid, nsi);
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
   uint32_t nids = 0, flags = fl0 & ~kHitLocPending;           // (the leader's; a Greedy read may carry kHitSiCap already)
@@ -2989,9 +2966,12 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
     }
   };
   bool done = false;                                          // team-uniform
-  for (uint32_t s = 0; s < nsi && !done; s++) {
-    const P lo = WIDE ? (P)(e[s] & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)e[s];
-    const uint32_t len = WIDE ? (uint32_t)(e[s] >> kLocWideShift) : (uint32_t)(e[s] >> 32);
+#pragma unroll
+  for (uint32_t s = 0; s < 16u; s++) {
+    const uint64_t es = team.entry(s);                        // (fully unrolled: which register of which lane is known here)
+    if (s >= nsi || done) continue;
+    const P lo = WIDE ? (P)(es & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)es;
+    const uint32_t len = WIDE ? (uint32_t)(es >> kLocWideShift) : (uint32_t)(es >> 32);
     const P rowend = lo + (P)(int32_t)len;
     for (P row0 = lo; row0 < rowend && !done; row0 += (P)T) {
       team.compute([&](int tl) -> uint64_t { const P row = row0 + (P)tl; return row < rowend ? walk(row) : ~0ull; });

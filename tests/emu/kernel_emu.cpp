@@ -242,10 +242,9 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         else { if (xo) mem_lane2<true, true>(d, pp, b, w2, ls); else mem_lane2<true>(d, pp, b, w2, ls); }
       };
       if (mem_v2 && pass == 0) {
-        // (capi.hip: the ids of reads with one or two longest matches are located by k_mem_locate behind the searches)
-        const bool defer = !xo && !getenv("KAIJU_EMU_LOCATE_INLINE");
+        // (capi.hip: the lanes leave the longest matches in the hit records, k_mem_locate* behind the searches walk them)
         Params pd = p;
-        if (defer) pd.flags |= kParamDeferLocate;
+        pd.flags |= kParamDeferLocate;
         Params pm = pd;
         if (lazy) pm.flags |= kParamLazySeg;
         lane_v2(pm, wl);

@@ -82,17 +82,18 @@ def test_golden_short_reads_fast_path(gpu_lib, golden, gidx, oracle, ohandles, m
 
 @pytest.mark.parametrize("seg", [1, 0])
 def test_mem_locate_by_the_search_lanes(gpu_lib, golden, gidx, oracle, ohandles, seg, monkeypatch):
-    """KAIJU_GPU_MEM_LOCATE=inline: the MEM lanes walk to the ids themselves (the flow before k_mem_locate, still the one of
-    reads with more than two longest matches); short reads and pairs vs the oracle and vs the default flow"""
+    """KAIJU_GPU_MEM_LANE=v1: the first-generation MEM lanes, which walk to the ids themselves (the second-generation ones leave
+    every read's longest matches to k_mem_locate*); short reads and pairs vs the oracle and vs the default flow"""
     api = gpu_lib
     ix, tax = ohandles
     _, sseqs, soff = golden.short()
     for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True)):
         oh = oracle.classify(ix, tax, oracle.params("mem", seg=seg, use_evalue=0), seqs, off, paired=pe)
-        monkeypatch.delenv("KAIJU_GPU_MEM_LOCATE", raising=False)
+        monkeypatch.delenv("KAIJU_GPU_MEM_LANE", raising=False)
         hd = api.Classifier(gidx, api.default_params("mem", seg=seg)).classify(seqs, off, paired=pe)
-        monkeypatch.setenv("KAIJU_GPU_MEM_LOCATE", "inline")
+        monkeypatch.setenv("KAIJU_GPU_MEM_LANE", "v1")
         hi = api.Classifier(gidx, api.default_params("mem", seg=seg)).classify(seqs, off, paired=pe)
+        monkeypatch.delenv("KAIJU_GPU_MEM_LANE")
         for hits in (hd, hi):
             bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
             assert not bad, (seg, pe, bad[:5])

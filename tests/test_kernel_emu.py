@@ -94,17 +94,18 @@ def test_fast_stage1_and_lazy_seg_on_short_reads(oracle, emu, golden, handles, m
 
 @pytest.mark.parametrize("seg", [1, 0])
 def test_mem_locate_in_a_pass_of_its_own(oracle, emu, golden, handles, seg, monkeypatch):
-    """MEM: reads with one or two longest matches leave them in the hit record and mem_locate_read (k_mem_locate on the
-    device) walks to their ids behind the searches; the lanes walking themselves (KAIJU_EMU_LOCATE_INLINE, the flow of
-    KAIJU_GPU_MEM_LOCATE=inline) must give the same records - single reads, pairs, the general set with long reads"""
+    """MEM: the second-generation lanes leave the longest matches of a read in its hit record and mem_locate_read*
+    (k_mem_locate* on the device) walk to the ids behind the searches; the first-generation lane, which walks itself
+    (KAIJU_EMU_LANE=v1), must give the same records - single reads, pairs, the general set with long reads"""
     h, ix, tax = handles
     _, sseqs, soff = golden.short()
     for seqs, off, pe in ((sseqs, soff, False), (golden.pseqs, golden.poff, True), (golden.seqs, golden.off, False)):
         oh = oracle.classify(ix, tax, oracle.params("mem", seg=seg, use_evalue=0), seqs, off, paired=pe)
-        monkeypatch.delenv("KAIJU_EMU_LOCATE_INLINE", raising=False)
+        monkeypatch.delenv("KAIJU_EMU_LANE", raising=False)
         gd, _ = emu.classify(h, util.gp("mem", seg=seg), seqs, off, paired=pe)
-        monkeypatch.setenv("KAIJU_EMU_LOCATE_INLINE", "1")
+        monkeypatch.setenv("KAIJU_EMU_LANE", "v1")
         gi, _ = emu.classify(h, util.gp("mem", seg=seg), seqs, off, paired=pe)
+        monkeypatch.delenv("KAIJU_EMU_LANE")
         assert (gd == gi).all()
         bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gd[i])]
         assert not bad, (seg, pe, bad[:5])
@@ -841,3 +842,63 @@ def test_redundant_databases_and_the_span_rule_for_any_interval_size(oracle, tmp
                         many += int((gh["n_ids"] >= 5).sum())
                 e.lib.emu_index_free(h)
         assert many > 100, many          # (matches of many rows under several taxa: what the i.i.d. databases do not have)
+
+
+def test_reads_with_many_longest_matches(oracle, tmp_path, monkeypatch):
+    """Reads whose longest matches are MANY (three to sixteen equally long ones, in one fragment and in several): since round 5
+    they too leave their matches in the hit record - in ids_from_SI's visiting order (:835-845), kaijux in maxMatches' list
+    order - and the locate kernels turn them into ids (k_mem_locate_list with the row -> taxon table, teams without it).
+    More than sixteen go to the retry pass.  Narrow, forced wide, without the text arrays, kaijux ids - against the oracle."""
+    from kaiju_amd import mkfmi
+    rng = np.random.default_rng(17)
+    aa = list("ACDEFGHIKLMNPQRSTVWY")
+    codon = {"A": "GCT", "C": "TGT", "D": "GAT", "E": "GAA", "F": "TTT", "G": "GGT", "H": "CAT", "I": "ATT", "K": "AAA", "L": "CTT",
+             "M": "ATG", "N": "AAT", "P": "CCT", "Q": "CAA", "R": "CGT", "S": "TCT", "T": "ACT", "V": "GTT", "W": "TGG", "Y": "TAT"}
+    nmotif, mlen = 40, 12
+    motifs = ["".join(rng.choice(aa, mlen)) for _ in range(nmotif)]
+    faa, fmi = str(tmp_path / "m.faa"), str(tmp_path / "m.fmi")
+    with open(faa, "w") as f:
+        for i, m in enumerate(motifs):
+            for c in range(1 + i % 3):                          # a motif lies in one to three sequences (other taxa)
+                f.write(f">M{i}c{c}_{10 + (7 * i + c) % 23}\n" + "".join(rng.choice(aa, int(rng.integers(20, 60)))) + m +
+                        "".join(rng.choice(aa, int(rng.integers(20, 60)))) + "\n")
+    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+    reads = []
+    for _ in range(300):
+        k = int(rng.integers(3, 19))                            # motifs per read: 3 .. 18 (more than sixteen: the retry pass)
+        pep = ""
+        for _ in range(k):
+            pep += motifs[int(rng.integers(0, nmotif))] + "".join(rng.choice(aa, int(rng.integers(1, 4))))
+            if rng.random() < 0.25:
+                pep += "*"                                        # a stop: the next motifs lie in another fragment
+        nt = "".join("TAA" if c == "*" else codon[c] for c in pep)
+        if rng.random() < 0.5:                                    # the other strand
+            nt = nt[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        reads.append(np.frombuffer(nt.encode(), dtype=np.uint8))
+    seqs, off = util.pack(reads)
+    ix = oracle.load_fmi(fmi)
+    want = oracle.classify(ix, None, oracle.params("mem", seg=0), seqs, off)
+    assert (np.array([int(w["n_ids"]) for w in want]) >= 3).mean() > 0.3     # (ids, not matches: most reads have 3+ matches)
+    emu = util.Emu()
+    for env in ({}, {"KAIJU_GPU_FORCE_WIDE": "17"}, {"KAIJU_EMU_NO_TEXT": "1"}, {"KAIJU_EMU_LOCATE_SERIAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = emu.load(fmi)
+        got, nretry = emu.classify(h, util.gp("mem", seg=0), seqs, off)
+        bad = [i for i in range(len(want)) if not util.same_hit(want[i], got[i])]
+        assert not bad, (env, bad[:5])
+        assert nretry > 0                                         # (reads with seventeen and eighteen matches)
+        emu.lib.emu_index_free(h)
+        for k in env:
+            monkeypatch.delenv(k)
+    # kaijux ids: the matches in the order maxMatches(.., 1) lists them
+    xo = oracle.classify(ix, None, oracle.params("mem", seg=0, kaijux=1), seqs, off)
+    import ctypes as C
+    emu.lib.emu_index_load_x.restype = C.c_void_p
+    emu.lib.emu_index_load_x.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    err = C.create_string_buffer(256)
+    hx = emu.lib.emu_index_load_x(fmi.encode(), err, 256)
+    assert hx, err.value
+    gx, _ = emu.classify(hx, util.gp("mem", seg=0), seqs, off)
+    bad = [i for i in range(len(xo)) if not util.same_hit(xo[i], gx[i])]
+    assert not bad, bad[:5]
