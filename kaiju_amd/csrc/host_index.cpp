@@ -115,6 +115,7 @@ void dense_taxa(const std::vector<uint64_t> &seq_taxid, const std::vector<uint8_
 int FmiFile::load(const char *path, std::string &msg, bool lazy) {
   FILE *fp = fopen(path, "rb");
   if (!fp) { msg = std::string("cannot open ") + path; return KAIJU_GPU_ERR_IO; }
+  (void)setvbuf(fp, nullptr, _IOFBF, 8u << 20);      // (the names: two small reads per sequence, 200 M sequences in a refseq-class file)
   Reader rd{fp};
   // (sizes in the headers are checked against the size of the file before anything is allocated from them)
   int64_t fsize = 0;
@@ -136,10 +137,10 @@ int FmiFile::load(const char *path, std::string &msg, bool lazy) {
   }
   ids.resize((size_t)nseq);
   for (int32_t i = 0; i < nseq && rd.ok; i++) {
-    uint8_t l = 0;
-    rd.get(l);
-    ids[(size_t)i].resize(l);
-    rd.bytes(l ? &ids[(size_t)i][0] : nullptr, l);
+    const int l = getc_unlocked(fp);                   // (one thread reads this file: no lock per byte)
+    if (l == EOF) { rd.ok = false; break; }
+    ids[(size_t)i].resize((size_t)l);
+    if (l && fread_unlocked(&ids[(size_t)i][0], 1, (size_t)l, fp) != (size_t)l) rd.ok = false;
   }
   rd.skip((int64_t)nseq * 4);   // seqTermOrder: not used by the search
   rd.skip((int64_t)nseq * 8);   // seqlengths: not used by the search
@@ -223,7 +224,7 @@ int PackedIndex::build_head(const HostIndexView &v, uint8_t *lcode, std::string 
 }
 
 // sample geometry, warnings, names and taxon ids of the sequences
-void PackedIndex::build_names(const HostIndexView &v) {
+void PackedIndex::build_names(const HostIndexView &v, std::vector<std::string> *owned) {
   sa_skip = (((uint64_t)nseq - 1) >> chpt_exp) + 1;
   n_sa = (uint64_t)v.ncheck;
   {
@@ -235,12 +236,13 @@ void PackedIndex::build_names(const HostIndexView &v) {
   seq_taxid.assign(nseq, 0);
   seq_valid.assign(nseq, 0);
   names.clear();
-  names.resize(nseq);
+  const bool take = owned && owned->size() == nseq;       // (a streamed load hands its strings over instead of copying 200 M of them)
+  if (take) names.swap(*owned); else names.resize(nseq);
   parallel_for(((uint64_t)nseq + 16383) / 16384, [&](uint64_t chunk) {
     const uint32_t b = (uint32_t)(chunk * 16384), e = (uint32_t)std::min<uint64_t>(nseq, (uint64_t)b + 16384);
     for (uint32_t i = b; i < e; i++) {
-      const char *nm = v.ids[i] ? v.ids[i] : "";
-      names[i] = nm;
+      if (!take) names[i] = v.ids[i] ? v.ids[i] : "";
+      const char *nm = names[i].c_str();
       uint64_t id = 0;
       // bit 0: usable taxon id; bit 1: the name has an accession part in front of the last '_' (verbose column 6)
       seq_valid[i] = parse_taxid(nm, id) ? (uint8_t)(strrchr(nm, '_') ? 3 : 1) : 0;
@@ -250,12 +252,13 @@ void PackedIndex::build_names(const HostIndexView &v) {
 }
 
 // the small parts of a .fmi whose big arrays stay in the file (fmi_stream.h)
-int PackedIndex::build_streamed(const FmiFile &f, const char *path, std::string &msg) {
+int PackedIndex::build_streamed(FmiFile &f, const char *path, std::string &msg) {
   const HostIndexView v = f.view();
   stream = FmiStreamSource{};
   int rc = build_head(v, stream.lcode, msg);
   if (rc) return rc;
-  build_names(v);
+  build_names(v, &f.ids);                                  // (f.ids / f.id_ptrs are gone afterwards)
+  f.id_ptrs.clear();
   stream.path = path; stream.sa_off = f.sa_off; stream.bwt_off = f.bwt_off; stream.nbytes = f.nbytes; stream.pbits = f.pbits;
   blocks64.clear(); mb_base.clear(); sa_taxid.clear(); sa_iseq.clear(); sa_pos.clear(); term_pos.clear(); kmer32.clear(); kmer64.clear();
   kline.clear(); kmer_k = 0;

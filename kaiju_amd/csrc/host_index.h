@@ -124,11 +124,11 @@ struct PackedIndex {
   // the parts of build() that do not touch bwt[] / sa[]: header fields, translation table, byte code -> letter (lcode[256]),
   // layout (narrow / wide) - and: sample geometry, warnings, names and taxon ids of the sequences
   int build_head(const HostIndexView &v, uint8_t *lcode, std::string &msg);
-  void build_names(const HostIndexView &v);
+  void build_names(const HostIndexView &v, std::vector<std::string> *owned = nullptr);
   // A .fmi whose big arrays stay in the file (FmiFile::load(.., lazy)): the small parts are built here, `stream` says where the
   // rest is, `lazy` how many elements every device array will have; capi.hip lets fmi_stream_to_device pack them in HBM.
   FmiStreamSource stream;
-  int build_streamed(const FmiFile &f, const char *path, std::string &msg);
+  int build_streamed(FmiFile &f, const char *path, std::string &msg);     // (takes f's names)
   uint64_t bytes() const;
   // DevIndex whose pointers refer to THIS object's host vectors (used by the test emulation)
   DevIndex host_view() const;
