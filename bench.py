@@ -115,7 +115,7 @@ def reference_ops(W, fmi, reads_sample, mode, seg, paired, Lm):
             "sample": k, "oracle_reads_per_s": k / max(t, 1e-9)}
 
 
-def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample, tag_suffix=""):
+def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample, tag_suffix="", extra=()):
     """the unmodified reference on `sample` of the reads: (baseline dict, per-read (classified, taxon) arrays)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
@@ -134,7 +134,7 @@ def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample, tag_suffi
         with open(fo, "wb") as f:
             f.write(fastq_bytes(part[:1]))
     out = f"{W}/cpu_{tag}_out.tsv"
-    base = [po.REF_KAIJU, "-t", nodes, "-f", fmi, "-a", mode, "-z", str(cores), "-o", out]
+    base = [po.REF_KAIJU, "-t", nodes, "-f", fmi, "-a", mode, "-z", str(cores), "-o", out] + list(extra)
     if not seg:
         base.append("-X")
 
@@ -158,7 +158,7 @@ def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample, tag_suffi
         t_end = time.time()
         t_load, t_cls = t_start - t0, max(t_end - t_start, 1e-6)
         bl = {"value": s / t_cls, "unit": "reads/s" if not paired else "pairs/s", "cores": cores, "kind": "reference",
-              "sample": f"{s} of the benchmark {'pairs' if paired else 'reads'}, kaiju -z {cores} -a {mode}{'' if seg else ' -X'} -v; "
+              "sample": f"{s} of the benchmark {'pairs' if paired else 'reads'}, kaiju -z {cores} -a {mode}{'' if seg else ' -X'}{' ' + ' '.join(extra) if extra else ''} -v; "
                         f"one run: {t_cls:.1f}s from its 'Start classification' line to its end (index load {t_load:.1f}s before it)"}
         import shutil
         shutil.copyfile(outv, out)          # (the consistency check below then compares the run with itself)
@@ -171,7 +171,7 @@ def run_reference(W, fmi, nodes, reads, Lm, paired, mode, seg, sample, tag_suffi
         t_all = time.time() - t0
         t_cls = max(t_all - t_load, 1e-6)
         bl = {"value": s / t_cls, "unit": "reads/s" if not paired else "pairs/s", "cores": cores, "kind": "reference",
-              "sample": f"{s} of the benchmark {'pairs' if paired else 'reads'}, kaiju -z {cores} -a {mode}{'' if seg else ' -X'}; "
+              "sample": f"{s} of the benchmark {'pairs' if paired else 'reads'}, kaiju -z {cores} -a {mode}{'' if seg else ' -X'}{' ' + ' '.join(extra) if extra else ''}; "
                         f"wall {t_all:.1f}s minus index load {t_load:.1f}s"}
         # parity lines: the same reads once more with -v (column 4 = match length / score of the best match,
         # ConsumerThread.cpp:724-739 + extraoutput), untimed - the baseline above is the reference's plain run
@@ -266,13 +266,14 @@ def image_is_fresh(img, fmi):
 # one leg = one workload timed like the headline
 # ----------------------------------------------------------------------------------------------
 class Leg:
-    def __init__(self, name, mode, paired, reads, Lm, index, dtax, dev, rank, world, seg, chunk, nctx):
+    def __init__(self, name, mode, paired, reads, Lm, index, dtax, dev, rank, world, seg, chunk, nctx, protein=False):
         import torch
         self.torch = torch
         self.name, self.mode, self.paired, self.reads, self.Lm = name, mode, paired, reads, Lm
         self.index, self.dtax, self.dev, self.rank, self.world = index, dtax, dev, rank, world
         self.n, self.L = reads.shape
-        self.params = api.default_params(mode, seg=seg)
+        self.protein = protein
+        self.params = api.default_params(mode, seg=seg, input_is_protein=1 if protein else 0)
         self.nctx = max(1, nctx)
         self.clfs = [api.Classifier(index, self.params) for _ in range(self.nctx)]
         for c in self.clfs:
@@ -533,13 +534,17 @@ def main():
                     help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")
     ap.add_argument("--no-seg", action="store_true")
     ap.add_argument("--paired", action="store_true", help="headline leg on 2 x 150-bp pairs instead of single reads")
-    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host,hard,wide"),
-                    help="further legs in the same line: greedy, paired, host, hard, wide (comma separated; '' = none).  hard: MEM and Greedy on "
+    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host,hard,wide,long,protein"),
+                    help="further legs in the same line: greedy, paired, host, hard, wide, long, protein (comma separated; '' = none).  long / "
+                         "protein: what users also feed it - 250-bp reads and protein reads (kaiju -p), MEM, --other-reads per step.  hard: MEM and Greedy on "
                          "a database that is NOT i.i.d. (synth.make_db_hard: families of 50-500 near-identical proteins, low-complexity "
                          "inserts; reads with Ns) - retries, inexact reads and the rate next to the i.i.d. legs.  wide: MEM and Greedy on "
                          "an index of 2^32 rows and more (the benchmark database with every protein --wide-copies times, written by "
                          "kaiju_build_fmi_replicated without a second sort; the .fmi is streamed to HBM and packed there): the kernels "
                          "of the layout with 64-bit positions - k_mem_wide2, k_mem_locate_wide / _team, k_greedy2_wide")
+    ap.add_argument("--other-reads", type=int, default=2_000_000,
+                    help="reads per step of the legs `long` (250-bp reads: mates beyond 191 nt take the general stage 1, k_fragments) and "
+                         "`protein` (100-residue protein reads, kaiju -p: k_fragments_protein)")
     ap.add_argument("--wide-copies", type=int, default=23, help="copies of every protein in the index of the `wide` leg (23 x 191 M rows = 4.39 G > 2^32)")
     ap.add_argument("--wide-reads", type=int, default=2_000_000)
     ap.add_argument("--hard-nseq", type=int, default=200_001)
@@ -724,6 +729,25 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(rank, "host_buffers leg failed:", repr(e))
 
+    # ---------------- reads that are not 150 bp: 250-bp reads (general stage 1) and protein reads (kaiju -p) ----------------
+    other = {}
+    if world == 1 and not args.paired and not big_db:
+        try:
+            if "long" in legs_wanted:
+                rd = synth.make_reads(db, min(args.other_reads, n), seed=781, read_len=250)
+                leg = Leg("long", "mem", False, rd, 250, index, dtax, dev, rank, world, seg, args.chunk, args.contexts)
+                leg.run(args.leg_steps, 1)
+                log(rank, f"leg long (250-bp reads): {leg.n * args.leg_steps / leg.elapsed / 1e6:.1f} M reads/s")
+                other["long"] = leg
+            if "protein" in legs_wanted:
+                rd = synth.make_protein_reads(db, min(args.other_reads, n), seed=782, read_len=100)
+                leg = Leg("protein", "mem", False, rd, 100, index, dtax, dev, rank, world, seg, args.chunk, args.contexts, protein=True)
+                leg.run(args.leg_steps, 1)
+                log(rank, f"leg protein (100-residue protein reads, kaiju -p): {leg.n * args.leg_steps / leg.elapsed / 1e6:.1f} M reads/s")
+                other["protein"] = leg
+        except Exception as e:  # noqa: BLE001
+            log(rank, "long / protein leg failed:", repr(e))
+
     # ---------------- the hostile leg: a database that is not i.i.d. (its own index next to the benchmark's) ----------------
     hard = None
     if "hard" in legs_wanted and world == 1 and not big_db and copies == 1:
@@ -797,11 +821,12 @@ def main():
             return out
         try:
             if not args.no_ref_ops and oracle_sample > 0:
-                out["ref_ops"] = reference_ops(W, fmi, rd[:oracle_sample], leg.mode, seg, leg.paired, Lm)
+                out["ref_ops"] = reference_ops(W, fmi, rd[:oracle_sample], leg.mode, seg, leg.paired, leg.Lm)
         except Exception as e:  # noqa: BLE001 - the accounting legs must never kill the measurement
             log(rank, f"reference op counts ({leg.name}) failed:", repr(e))
         try:
-            bl, ref = run_reference(W, fmi, nodes, rd, Lm, leg.paired, leg.mode, seg, sample, tag_suffix)
+            bl, ref = run_reference(W, fmi, nodes, rd, leg.Lm, leg.paired, leg.mode, seg, sample, tag_suffix,
+                                    extra=("-p",) if leg.protein else ())
             out["baseline"] = bl
             if ref is not None:
                 k = len(ref[0])
@@ -824,6 +849,8 @@ def main():
     if hard is not None:
         for nm, leg in hard["legs"].items():
             acc[nm] = cpu_leg(leg, hard["reads"], min(args.cpu_sample_legs, 200_000), 5000, fmi=hard["fmi"], tag_suffix="_hard")
+    for nm, leg in other.items():
+        acc[nm] = cpu_leg(leg, leg.reads, min(args.cpu_sample_legs, 200_000), 0, tag_suffix="_" + nm)
     if wide is not None:
         # (one run of the reference per mode: it reads the 8 GB .fmi each time; no op counts of the instrumented oracle there)
         for nm, leg in wide["legs"].items():
@@ -907,6 +934,19 @@ def main():
             if acc[nm]["parity"] is not None:
                 parity[nm] = acc[nm]["parity"]
             result[nm] = lr
+    for nm, leg in other.items():
+        lr = leg.result(world, None, None, db.nseq)
+        rec = np.frombuffer(leg.timed_compact.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
+        lr["workload"] = (f"the same index, {leg.n} synthetic 250-bp reads per step (mates beyond 191 nt: the general stage 1, k_fragments), kaiju -a mem"
+                          if nm == "long" else
+                          f"the same index, {leg.n} synthetic protein reads of 100 residues per step (70% database windows with 0-5 substitutions), "
+                          f"kaiju -a mem -p (k_fragments_protein)")
+        lr["fraction_reads_with_hit"] = round(float(((rec["info"] & 0xff) > 0).mean()), 4)
+        if acc.get(nm, {}).get("baseline") is not None:
+            lr["cpu_baseline"] = acc[nm]["baseline"]
+        if acc.get(nm, {}).get("parity") is not None:
+            parity[nm] = acc[nm]["parity"]
+        result[nm] = lr
     if wide is not None:
         wix = wide["index"]
         for nm, leg in wide["legs"].items():

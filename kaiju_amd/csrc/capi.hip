@@ -506,7 +506,10 @@ k_greedy2_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, Seg
   greedy2_body<true, false>(ix, g_ct, p, sq, b, wl, ga);
 }
 // the same lane with 64-bit positions: indexes of 2^32 rows and more (the k-mer table instead of the lines)
-__global__ void __launch_bounds__(kBlock, 2)
+#ifndef KJ_GW_WAVES
+#define KJ_GW_WAVES kGreedyWavesPerSimd             // (169 VGPRs since the locate left the lane: one register from three wavefronts per SIMD)
+#endif
+__global__ void __launch_bounds__(kBlock, KJ_GW_WAVES)
 k_greedy2_wide(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
   greedy2_body<false, true>(ix, g_ct, p, sq, b, wl, ga);
 }
@@ -1913,7 +1916,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     }
     if (n > 0) {
       Params pg = p;
-      if (use_g2 && c->defer_locate) pg.flags |= kParamDeferLocate;       // (experiment: reads with one best match -> k_mem_locate)
+      if (use_g2) pg.flags |= kParamDeferLocate;       // (greedy_lane2 leaves every read's best matches to k_mem_locate*)
       const bool g_wide = ix->dev.mb_base != nullptr;
       if (use_g2 && c->count_ops && g_wide)
         hipLaunchKernelGGL(k_greedy2_wide_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);

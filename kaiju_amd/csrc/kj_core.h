@@ -2728,6 +2728,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 #endif
 }
 
+constexpr uint32_t kLocMaxEntries = 24;      // matches a hit record can hold for the locate kernels (MEM: 16 = the lane's match buffer; Greedy: max_matches_SI = 20; record: 21 slots)
 // The ids of a read whose longest matches mem_lane2 left in its hit record (kHitLocPending): ids_from_SI for every match in
 // turn (ConsumerThread.cpp:799-845; get_suffix bwt.c:105-121, FMindexCurrent compactfmi.c:312-336) - the same steps as
 // BK_LOC_ROW / K_LF1 / K_LF2 / K_SA of the lane, one read per lane, narrow index.
@@ -2745,7 +2746,7 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   // the matches (row | length): the lean instantiation holds two in registers and hands reads with more on (they are rare:
   // two in ten thousand on random data) - the many-rows one reads every entry when its turn comes: it only writes the record
   // when it is through.  (Host emulation without a list: all of them copied first.)
-  constexpr uint32_t kEMax = MANYROWS ? 1u : 16u;
+  constexpr uint32_t kEMax = MANYROWS ? 1u : kLocMaxEntries;
   uint64_t e[kEMax];
   e[0] = hit->taxid[0];
   if constexpr (!MANYROWS) {
@@ -2883,9 +2884,9 @@ struct TeamSerial {
   KJ_HD uint64_t get(int q) const { return vals[q]; }
   KJ_HD bool leader() const { return true; }
   KJ_HD bool from_leader(bool v) const { return v; }
-  // the matches of the read (row | length, up to sixteen), copied before the first id is written over them
-  uint64_t ent[16];
-  KJ_HD void load_entries(const uint64_t *rec, uint32_t n) { for (uint32_t q = 0; q < 16u; q++) ent[q] = q < n ? rec[q] : 0ull; }
+  // the matches of the read (row | length, up to kLocMaxEntries), copied before the first id is written over them
+  uint64_t ent[kLocMaxEntries];
+  KJ_HD void load_entries(const uint64_t *rec, uint32_t n) { for (uint32_t q = 0; q < kLocMaxEntries; q++) ent[q] = q < n ? rec[q] : 0ull; }
   KJ_HD uint64_t entry(uint32_t q) const { return ent[q]; }
 };
 #if defined(__HIPCC__)
@@ -2899,13 +2900,13 @@ struct TeamWave {
   }
   __device__ __forceinline__ bool leader() const { return (threadIdx.x & (T - 1)) == 0; }
   __device__ __forceinline__ bool from_leader(bool v) const { return __shfl((int)v, (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)), 64) != 0; }
-  // the matches of the read (row | length, up to sixteen): lane t of the team keeps entries t, t + T, .. in registers - the
+  // the matches of the read (row | length, up to kLocMaxEntries): lane t of the team keeps entries t, t + T, .. in registers - the
   // leader writes ids over them later - and hands one out by a shuffle
-  uint64_t ent[16 / T];
+  uint64_t ent[kLocMaxEntries / T];
   __device__ __forceinline__ void load_entries(const uint64_t *rec, uint32_t n) {
     const uint32_t tl = threadIdx.x & (T - 1);
 #pragma unroll
-    for (uint32_t q = 0; q < 16u / T; q++) ent[q] = tl + q * T < n ? rec[tl + q * T] : 0ull;
+    for (uint32_t q = 0; q < kLocMaxEntries / T; q++) ent[q] = tl + q * T < n ? rec[tl + q * T] : 0ull;
   }
   __device__ __forceinline__ uint64_t entry(uint32_t q) const {
     const int src = (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)) + (int)(q % T);
@@ -2920,7 +2921,7 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
   const uint32_t fl0 = hit->flags;                            // (every lane of the team reads the same record: team-uniform)
   if (!(fl0 & kHitLocPending)) return;
   const uint32_t nsi = hit->n_ids;
-  // the matches (row | length), up to sixteen: every lane of the team reads all of them before the leader writes the first id
+  // the matches (row | length): every lane of the team keeps its share before the leader writes the first id
   team.load_entries(hit->taxid, nsi);
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
@@ -2967,7 +2968,7 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
   };
   bool done = false;                                          // team-uniform
 #pragma unroll
-  for (uint32_t s = 0; s < 16u; s++) {
+  for (uint32_t s = 0; s < kLocMaxEntries; s++) {
     const uint64_t es = team.entry(s);                        // (fully unrolled: which register of which lane is known here)
     if (s >= nsi || done) continue;
     const P lo = WIDE ? (P)(es & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)es;
@@ -3502,12 +3503,11 @@ struct GreedyScratch2 {
   uint32_t *sub;               // LDS, kGSubStride words: the substitutions of the variant at hand + slow-part state
 };
 
-enum GKind : int { G_STEP, G_KMER, G_PROBE, G_LF1, G_LF2, G_SA,                            // fast (G_PROBE: a k-mer lookup, kGreedyProbe)
+enum GKind : int { G_STEP, G_KMER, G_PROBE,                                              // fast (G_PROBE: a k-mer lookup, kGreedyProbe)
                    G_VMULTI, G_META, G_FRAG, G_FILL, G_POPITEM, G_MLOAD, G_WAIT, G_IDLE,   // heavy iterations only
                    G_EXIT };
-enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J, GB_LOC_ROW,                            // fast
-                 GB_AFTER_SEARCH, GB_VAR_NEXT, GB_VAR_MATCH, GB_EVAL_NEXT, GB_EVAL_MATCH, GB_POP, GB_FINISH,
-                 GB_LOC_NEXT_SI, GB_DONE };
+enum GBk : int { GB_NONE, GB_END_MATCH, GB_START_J,                                        // fast
+                 GB_AFTER_SEARCH, GB_VAR_NEXT, GB_VAR_MATCH, GB_EVAL_NEXT, GB_EVAL_MATCH, GB_POP, GB_FINISH, GB_DONE };
 enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 
 // the lane's scratch in device memory: pointers kept per lane, or (three wavefronts per SIMD) recomputed from the lane number
@@ -3573,12 +3573,9 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   // variant generation
   uint32_t &vorig = gs.sub[12], &vscore = gs.sub[13], &vlen = gs.sub[14];
   vorig = vscore = vlen = 0;
-  // locate
-  uint32_t cur = 0, nids = 0;
-  P row = 0, rowend = 0, k = 0;
-  uint64_t id0 = 0;
-  P sa_idx = 0;                                  // (an index below 2^32 rows has fewer samples than that)
-  bool fresh = true;
+  // (the ids: a read leaves its best matches - up to max_matches_SI = 20 of them - in the hit record, k_mem_locate* walk them;
+  //  until round 5 a read with more than one walked here, one lane of the wavefront at work)
+  uint32_t nids = 0;
 #define KJ_G_HIT (b.hits + r)                    /* (recomputed: two registers less than a pointer kept per lane) */
   int fill_top = 0, fill_ret = FR_START_J;
   bool fill_pref = false;
@@ -3687,23 +3684,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         nbest++;
       } else flags |= kHitSiCap;
     }
-  };
-  // one row of the locate walk: k is a fresh row (k == row) or the row reached by the LF walk
-  auto loc_row = [&]() -> int {
-    for (;;) {
-      if (row >= rowend) return GB_LOC_NEXT_SI;
-      if (fresh && nids > p.max_match_ids) { flags |= kHitIdCap; return GB_DONE; }     // :805-807
-      if ((k & check) != 0) { kind = G_LF1; return GB_NONE; }
-      const uint64_t sa64 = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
-      sa_idx = (P)sa64;
-      if (sa64 < ix.n_sa) { kind = G_SA; return GB_NONE; }
-      row++; k = row; fresh = true;                        // (the reference reads out of bounds here): skip the row
-    }
-  };
-  auto add_tax = [&](uint64_t tax) {
-    bool dup = false;
-    for (uint32_t q = 0; q < nids && !dup; q++) if (KJ_G_HIT->taxid[q] == tax) dup = true;
-    if (!dup && nids < (uint32_t)kMaxIds) KJ_G_HIT->taxid[nids++] = tax;
   };
 
 #if defined(KJ_STATS) && defined(__HIP_DEVICE_COMPILE__)
@@ -3940,36 +3920,27 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             bk = GB_DONE;
           } else {
             KJ_G_HIT->best = nbest ? best : 0u;
-            cur = 0;
-            bk = GB_LOC_NEXT_SI;
-            // experiment for round 3: a read that ends with ONE best match leaves it in the hit record for
-            // k_mem_locate, as the MEM lanes do (the locate sections of this lane run with one or two lanes active: 7 % of it)
-            if (nbest == 1u && (p.flags & kParamDeferLocate)) {
+            // the best matches go into the hit record - row | length, in the order of the list (eval_match_scores appends,
+            // ids_from_SI walks from the head: ConsumerThread.cpp:751-797, :799-845) - and k_mem_locate* turn them into ids
+            // with every lane at work: nbest <= max_matches_SI = 20 of the record's 21 slots
+            bool big = nbest > (uint32_t)kMaxIds;
+            if constexpr (WIDE) for (uint32_t q = 0; q < nbest && !big; q++) big = GS_BESTW[q].len >= kLocWideMaxLen;
+            if (big) {
+              // (more matches than slots - max_matches_SI raised by a caller -, or a wide interval of 2^24 rows and more: the
+              //  retry pass, whose lane walks itself)
+              KJ_G_HIT->best = 0;
+              if (wl.retry_list) { wl.retry_list[append_slot(wl.retry_count)] = r; flags = kHitRetry; }
+              else flags = kHitInternalOverflow;
+            } else if (nbest) {
               if constexpr (WIDE) {
-                const GBest2W gb = GS_BESTW[0];
-                if (gb.len < kLocWideMaxLen) {
-                  KJ_G_HIT->taxid[0] = gb.lo | (uint64_t)gb.len << kLocWideShift;
-                  nids = 1; flags |= kHitLocPending;
-                  bk = GB_DONE;
-                }
+                for (uint32_t q = 0; q < nbest; q++) { const GBest2W gb = GS_BESTW[q]; KJ_G_HIT->taxid[q] = gb.lo | (uint64_t)gb.len << kLocWideShift; }
               } else {
                 KJ_G_HIT->taxid[0] = (uint64_t)b0lo | (uint64_t)b0len << 32;
-                nids = 1; flags |= kHitLocPending;
-                bk = GB_DONE;
+                for (uint32_t q = 1; q < nbest; q++) { const GBest2 gb = GS_BEST[q]; KJ_G_HIT->taxid[q] = (uint64_t)gb.lo | (uint64_t)gb.len << 32; }
               }
+              nids = nbest; flags |= kHitLocPending;
             }
-          }
-        }
-        if (bk == GB_LOC_NEXT_SI) {
-          if (cur >= nbest) bk = GB_DONE;
-          else {
-            if constexpr (WIDE) { const GBest2W gb = GS_BESTW[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
-            else if (cur == 0) { row = b0lo; rowend = b0lo + b0len; }
-            else { const GBest2 gb = GS_BEST[cur]; row = gb.lo; rowend = gb.lo + gb.len; }
-            cur++;
-            k = row; fresh = true;
-            bk = loc_row();
-            if (bk == GB_LOC_NEXT_SI) continue;
+            bk = GB_DONE;
           }
         }
         if (bk == GB_DONE) {
@@ -4019,18 +3990,16 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     if (heavy) st_nheavy++;
 #endif
     KJ_HISTO(6, kind);
-    const bool is_step = kind == G_STEP, is_vm = kind == G_VMULTI, is_lf = kind == G_LF1 || kind == G_LF2;
+    const bool is_step = kind == G_STEP, is_vm = kind == G_VMULTI;
     const bool is_kmer = kind == G_KMER || (!WIDE && kind == G_PROBE);
     const P vlo = m_lo, vhi = m_lo + m_len;
-    const P posA = is_step ? lo : is_vm ? vlo : is_lf ? k : 0;
+    const P posA = is_step ? lo : is_vm ? vlo : 0;
     const P posB = is_step ? hi : is_vm ? vhi : posA;
     if constexpr (COUNT) {
       oc[kOpcLaneIters] += (kind != G_EXIT && kind != G_WAIT) ? 1u : 0u;
       if (kj_lane() == 0) oc[kOpcIters]++;
       if (is_kmer) oc[kOpcKmer]++;
       else if (kind == G_STEP) { oc[kOpcStep]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
-      else if (kind == G_LF1) { oc[kOpcLf]++; oc[kOpcLfLines]++; }
-      else if (kind == G_SA) oc[kOpcSa]++;
       else if (heavy) {
         if (kind == G_VMULTI) { oc[kOpcVmulti]++; oc[kOpcStepLines] += ((posA >> 6) != (posB >> 6)) ? 2u : 1u; }
         else if (kind == G_META) oc[kOpcMeta]++;
@@ -4040,7 +4009,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         else if (kind == G_MLOAD) oc[kOpcMload]++;
       }
     }
-    const uint32_t cc = (is_step || kind == G_LF2) ? c : 1u;
+    const uint32_t cc = is_step ? c : 1u;
     const RankBlock64 *pa = blk0 + (posA >> 6), *pb = blk0 + (posB >> 6);
     const u128 a01 = *reinterpret_cast<const u128 *>(&pa->plane[0]);
     const u128 a23 = *reinterpret_cast<const u128 *>(&pa->plane[2]);
@@ -4061,7 +4030,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     }
     const uint8_t *gaddr = reinterpret_cast<const uint8_t *>(blk0);
     if (is_kmer) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.kmer64 + kidx) : ix.kline + (size_t)kidx * 2u;
-    else if (kind == G_SA) gaddr = WIDE ? reinterpret_cast<const uint8_t *>(ix.sa_iseq + sa_idx) : reinterpret_cast<const uint8_t *>(ix.sa_taxid + sa_idx);
     else if (kind == G_META) gaddr = reinterpret_cast<const uint8_t *>(b.meta + r);
     else if (kind == G_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == G_FILL && fill_pref && fo < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + fo);
@@ -4090,14 +4058,14 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     // ---- (2) compute ----
     KJ_TICK(st_load)
     int bk = GB_NONE;
-    if (is_step || kind == G_LF2) {
+    if (is_step) {
       KJ_P(PS_STEP);
-      if (is_step) KJ_HISTO(12, t_nmm == 0 ? 0 : (uint64_t)(hi - lo) == 1 ? 1 : 2);                              // (UpdateSI steps: originals / variants on one row / on more)
+      KJ_HISTO(12, t_nmm == 0 ? 0 : (uint64_t)(hi - lo) == 1 ? 1 : 2);                              // (UpdateSI steps: originals / variants on one row / on more)
       const uint64_t ia = (cc & 1u) ? 0ull : ~0ull, ib = (cc & 2u) ? 0ull : ~0ull, ic = (cc & 4u) ? 0ull : ~0ull,
                      id = (cc & 8u) ? 0ull : ~0ull, ie = (cc & 16u) ? 0ull : ~0ull;
       const uint64_t ma = (a01.x ^ ia) & (a01.y ^ ib) & (a23.x ^ ic) & (a23.y ^ id) & (a4 ^ ie);
       const P ra = (P)(mba + ca + popc64(ma & ((1ull << (posA & 63u)) - 1ull)));
-      if (is_step) {
+      {
         // UpdateSI(str[i-1]) (bwt.c:160-173)
         const uint64_t mb = (b01.x ^ ia) & (b01.y ^ ib) & (b23.x ^ ic) & (b23.y ^ id) & (b4 ^ ie);
         const P rb = (P)(mbb + cb + popc64(mb & ((1ull << (posB & 63u)) - 1ull)));
@@ -4113,9 +4081,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           else if (in_win(i - 1)) c = win[i - 1 - wq];
           else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
         }
-      } else {
-        k = ra; fresh = false;                             // second half of an LF step
-        bk = GB_LOC_ROW;
       }
     } else if (is_kmer) {
       KJ_P(PS_KMER);
@@ -4168,34 +4133,6 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
         else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; }
       }
       }
-    } else if (kind == G_LF1) {
-      KJ_P(PS_LF1);
-      const uint32_t sft = k & 63u;
-      c = (uint32_t)((a01.x >> sft) & 1ull) | (uint32_t)((a01.y >> sft) & 1ull) << 1 | (uint32_t)((a23.x >> sft) & 1ull) << 2 |
-          (uint32_t)((a23.y >> sft) & 1ull) << 3 | (uint32_t)((a4 >> sft) & 1ull) << 4;
-      if (c != 0) kind = G_LF2;
-      else {
-        // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
-        const uint32_t iseq = (uint32_t)rank_term(ix, k);
-if constexpr (COUNT) oc[kOpcTerm]++;
-                if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
-        row++;
-        k = row; fresh = true;
-        bk = GB_LOC_ROW;
-      }
-    } else if (kind == G_SA) {
-      KJ_P(PS_SA);
-      uint64_t tax;
-      if constexpr (WIDE) {
-        // the wide layout keeps the sequence number of a sampled row (4 bytes), not its taxon id: one more, dependent, read
-        const uint32_t q4 = (uint32_t)sa_idx & 3u;
-        const uint32_t iseq = q4 == 0 ? (uint32_t)gv.x : q4 == 1 ? (uint32_t)(gv.x >> 32) : q4 == 2 ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32);
-        tax = (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
-      } else tax = ghalf ? gv.y : gv.x;
-      if (tax != ~0ull) add_tax(tax);
-      row++;
-      k = row; fresh = true;
-      bk = GB_LOC_ROW;
     } else if (heavy) {
       KJ_TICK(st_fast)
       if (is_vm) {
@@ -4523,8 +4460,7 @@ if constexpr (COUNT) oc[kOpcTerm]++;
           else { fill_top = i - 1; fill_ret = FR_STEP; fill_pref = false; kind = G_FILL; bk = GB_NONE; }
         }
       }
-      if (bk == GB_LOC_ROW) { KJ_P(PS_LOC_ROW); bk = loc_row(); }
-      if (bk > GB_LOC_ROW) { bk_pend = bk; kind = G_WAIT; bk = GB_NONE; }
+      if (bk > GB_START_J) { bk_pend = bk; kind = G_WAIT; bk = GB_NONE; }
     }
   }
   if constexpr (COUNT) opc_flush(opc_of(wl), oc);
