@@ -882,7 +882,7 @@ def main():
         "value": hr["value"], "unit": hr["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": hr["ms_per_step"], "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{'refseq_ref-class (2^32 rows and more: 64-bit positions)' if index.info.bwtlen >= 2 ** 32 else 'viruses-like'} "
+        "config": {"workload": f"{('refseq-class' if index.info.bwtlen >= 40e9 else 'refseq_ref-class') + ' (2^32 rows and more: 64-bit positions)' if index.info.bwtlen >= 2 ** 32 else 'viruses-like'} "
                                f"synthetic index ({db.nseq} proteins, {db.total_aa} aa{'' if copies == 1 else f', every protein x {copies}: {index.info.bwtlen} rows'}, .fmi "
                                f"{os.path.getsize(fmi)/1e6:.0f} MB, e=3); {n} synthetic {'2x' if args.paired else ''}{Lm}-bp reads{' (pairs)' if args.paired else ''} per GPU per step{' (one workload of %d split over the ranks)' % args.reads if args.strong else ''} "
                                f"(70% back-translated DB windows, 30% random); kaiju -a {args.mode} -m 11"
