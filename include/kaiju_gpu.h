@@ -197,7 +197,7 @@ typedef struct kaiju_gpu_index_footprint {
                           /* the 40-bit text position of every 2^s-th row (wide indexes: s = 0 .. 3 by the room left)     */
   uint64_t other;         /* constant tables                                                                              */
   uint64_t total;
-  uint32_t kmer_k, wide;  /* k of the table; 1 = 64-bit positions                                                         */
+  uint32_t kmer_k, wide;  /* k of the k-mer lines (narrow: a five-letter table stays next to them) or of the table; 1 = 64-bit positions */
 } kaiju_gpu_index_footprint;
 int kaiju_gpu_index_get_footprint(const kaiju_gpu_index *ix, kaiju_gpu_index_footprint *out);
 void kaiju_gpu_index_free(kaiju_gpu_index *ix);

@@ -82,13 +82,16 @@ k_fragments(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch 
 // strings stored unit by unit from registers.  LDS: the tables, the fragment list of every lane (dword-interleaved over the
 // wavefront) and, TRIG, its letter-count rows.
 constexpr int kS1Block = 64;
-template <bool TRIG>
+// UNITS: 16-residue units per frame string - kS1Units (mates up to 191 nt: the benchmark's reads) or kS1UnitsLong (up to 287 nt:
+// 250-bp MiSeq reads; 128-bit masks)
+template <bool TRIG, int UNITS = kS1Units>
 __global__ void __launch_bounds__(kS1Block)
 k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQueue sq, uint32_t *err) {
+  constexpr int kTs = UNITS <= kS1Units ? kTsBuf : kTsBufLong;
   __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
   __shared__ uint32_t s_codes[2 * kS1ListCap * kS1Block];
   __shared__ __attribute__((aligned(4))) uint8_t s_cnt[TRIG ? kS1Block * kS1CntStride : 4];
-  __shared__ __attribute__((aligned(4))) uint8_t s_ts[TRIG ? kS1Block * kTsBuf : 4];
+  __shared__ __attribute__((aligned(4))) uint8_t s_ts[TRIG ? kS1Block * kTs : 4];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
     uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
@@ -101,8 +104,8 @@ k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQue
   S1Lane ln;
   ln.codes = s_codes + threadIdx.x; ln.code_stride = kS1Block;
   ln.cnt = s_cnt + (TRIG ? threadIdx.x * kS1CntStride : 0);
-  ln.tsbuf = s_ts + (TRIG ? threadIdx.x * kTsBuf : 0);
-  build_fragments_fast<TRIG>(s_t, p, b, sq, r, &e, ln);
+  ln.tsbuf = s_ts + (TRIG ? threadIdx.x * kTs : 0);
+  build_fragments_fast<TRIG, UNITS>(s_t, p, b, sq, r, &e, ln);
   if (e) atomicOr(err, e);
 }
 
@@ -971,11 +974,13 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   ix->d_ct = const_cast<ConstTables *>(dct);
   for (int a = 0; a < 22; a++) d.C[a] = pk.C[a];
   d.bwtlen = pk.bwtlen; d.n_sa = pk.n_sa; d.sa_skip = pk.sa_skip; d.nseq = pk.nseq; d.chpt_exp = pk.chpt_exp;
-  d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k; d.kline = nullptr;
+  d.kmer32 = nullptr; d.kmer64 = nullptr; d.kmer_k = pk.kmer_k; d.kline = nullptr; d.kline_k = 0;
   const uint64_t n_kmer32 = PackedIndex::count(pk.kmer32, pk.lazy.kmer32), n_kmer64 = PackedIndex::count(pk.kmer64, pk.lazy.kmer64);
   uint64_t kmer_bytes = 0;
   // the depth the HOST packer builds (PackedIndex::build: 5, KAIJU_GPU_KMER up to 6); a streamed .fmi has no rank blocks on the
   // host: its table starts on the device with the twenty one-letter intervals of InitialSI (bwt.c:146-152) and grows from there
+  constexpr uint32_t kKmerResidentK = 5;          // depth of the table a narrow index keeps next to its k-mer lines
+  void *kmer5 = nullptr;
   uint32_t host_k = pk.kmer_k;
   if (streamed && pk.alen == 21) {
     host_k = 5;
@@ -1022,7 +1027,9 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         hipLaunchKernelGGL(k_kmer_extend, dim3((unsigned)blocks), dim3(256), 0, 0, d.blocks64, cur, static_cast<uint2 *>(child), np);
         KJ_HIP(hipGetLastError());
         KJ_HIP(hipDeviceSynchronize());
-        (void)hipFree(cur_alloc);
+        // (the five-letter level stays: what remains resident once the lines of the deeper table exist, see below)
+        if (d.kmer_k == kKmerResidentK && !d.mb_base && !getenv("KAIJU_GPU_KEEP_KMER_TABLE")) kmer5 = cur_alloc;
+        else (void)hipFree(cur_alloc);
         ix->allocs.back() = child;
         cur_alloc = child; cur = static_cast<const uint2 *>(child);
         np *= 20; d.kmer_k++;
@@ -1043,9 +1050,22 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
         KJ_HIP(hipGetLastError());
         KJ_HIP(hipDeviceSynchronize());
         d.kline = static_cast<const uint8_t *>(lines);
+        d.kline_k = d.kmer_k;
         kmer_bytes += nl * kKLineBytes;
+        if (kmer5) {
+          // The second-generation lanes read the LINES only; the table itself (20^7 entries: 10.2 GB on a viruses-size index,
+          // half of its footprint) served the first-generation lanes - verbose output, the retry pass - which are as exact
+          // with the five-letter level: that one stays (25.6 MB), the deep table goes
+          ix->allocs.pop_back();                                        // (lines)
+          (void)hipFree(ix->allocs.back());                             // (the deep table)
+          ix->allocs.back() = kmer5;
+          ix->allocs.push_back(lines);
+          d.kmer32 = static_cast<const uint2 *>(kmer5); d.kmer_k = kKmerResidentK;
+          kmer5 = nullptr;
+        }
       } else (void)hipGetLastError();      // (no room: the lanes of the first generation serve, with the table)
     }
+    if (kmer5) { (void)hipFree(kmer5); kmer5 = nullptr; }               // (no lines were built: the deep table stays as it is)
     if (d.kmer64 && d.blocks64 && d.mb_base && want > d.kmer_k) {
       uint64_t np = 1;
       for (uint32_t q = 0; q < d.kmer_k; q++) np *= 20;
@@ -1243,12 +1263,14 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     uint64_t nw = 1;
     for (uint32_t q = 0; q < d.kmer_k; q++) nw *= 20;
     f.kmer_table = d.kmer_k ? nw * (d.kmer64 ? sizeof(ulonglong2) : sizeof(uint2)) : 0;
-    f.kmer_lines = d.kline ? nw / 20 * kKLineBytes : 0;
+    uint64_t nlw = 1;
+    for (uint32_t q = 1; q < d.kline_k; q++) nlw *= 20;
+    f.kmer_lines = d.kline ? nlw * kKLineBytes : 0;
     f.other = sizeof(ConstTables) + sizeof(Stage1Tables) + lnfact.size() * 8;
     f.text = d.text ? text_bytes : 0;
     f.sa_full = d.sa_full ? pk.bwtlen * 8 : d.sa_tpos5 ? tpos_bytes : 0;   // (+ the sequence of every row, DevIndex::row_seq; wide: the text positions)
     f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other + f.text + f.sa_full;
-    f.kmer_k = d.kmer_k; f.wide = d.mb_base ? 1u : 0u;
+    f.kmer_k = std::max(d.kmer_k, d.kline_k); f.wide = d.mb_base ? 1u : 0u;
     inf.device_bytes = f.total;
     if (getenv("KAIJU_GPU_LOAD_TIMES"))
       fprintf(stderr, "[kaiju_gpu load] HBM: rank blocks %.2f GB, count bases %.3f GB, SA sample %.2f (sequence numbers) + %.2f (taxon ids) GB, "
@@ -1479,8 +1501,9 @@ extern "C" int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, 
   if (!ix || !out || n_out < KAIJU_GPU_N_DIGESTS) return fail(KAIJU_GPU_ERR_ARG, "bad argument");
   KJ_HIP(hipSetDevice(ix->device));
   const DevIndex &d = ix->dev;
-  uint64_t nw = 1;
+  uint64_t nw = 1, nlw = 1;
   for (uint32_t q = 0; q < d.kmer_k; q++) nw *= 20;
+  for (uint32_t q = 1; q < d.kline_k; q++) nlw *= 20;
   struct Arr { const void *p; uint64_t bytes; };
   const Arr arrs[12] = {
       {d.blocks64, ((d.bwtlen >> 6) + 1) * sizeof(RankBlock64)},
@@ -1491,7 +1514,7 @@ extern "C" int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, 
       {d.seq_taxid, (uint64_t)d.nseq * 8},
       {d.seq_valid, (uint64_t)d.nseq},
       {d.kmer32 ? (const void *)d.kmer32 : (const void *)d.kmer64, d.kmer_k ? nw * (d.kmer32 ? sizeof(uint2) : sizeof(ulonglong2)) : 0},
-      {d.kline, d.kline ? nw / 20 * kKLineBytes : 0},
+      {d.kline, d.kline ? nlw * kKLineBytes : 0},
       {d.text, d.text ? ix->fp.text : 0},
       {d.sa_full ? (const void *)d.sa_full : (const void *)d.sa_tpos5, d.sa_full ? d.bwtlen * 4 : d.sa_tpos5 ? ix->fp.sa_full : 0},
       {d.row_tax, d.row_tax ? d.bwtlen * 4 : 0}};
@@ -1510,7 +1533,7 @@ extern "C" int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, 
   (void)hipFree(acc);
   if (e != hipSuccess) return fail(KAIJU_GPU_ERR_HIP, hipGetErrorString(e));
   for (int a = 0; a < 12; a++) out[a] = h[a];
-  out[12] = d.kmer_k;
+  out[12] = d.kmer_k | (uint64_t)d.kline_k << 8;
   uint64_t hc = 0;
   for (int a = 0; a < 22; a++) hc = (hc ^ d.C[a]) * 0xD6E8FEB86659FD93ull + 1;
   out[13] = hc;
@@ -1630,8 +1653,9 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   if (p->mode == 0) KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_mem, kBlock, 0));
   else {
     const bool g_wide = ix->dev.mb_base != nullptr;
-    c->greedy2 = ix->dev.blocks64 && (g_wide ? ix->dev.kmer64 != nullptr : ix->dev.kline != nullptr) && ix->dev.kmer_k >= 2 &&
-                 ix->dev.kmer_k <= p->seed_length && p->seed_length >= 3;
+    const uint32_t g_k = g_wide ? ix->dev.kmer_k : ix->dev.kline_k;
+    c->greedy2 = ix->dev.blocks64 && (g_wide ? ix->dev.kmer64 != nullptr : ix->dev.kline != nullptr) && g_k >= 2 &&
+                 g_k <= p->seed_length && p->seed_length >= 3;
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; }
     if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (c->greedy_gate & ~0xffu) | (uint32_t)v; }
     // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
@@ -1711,12 +1735,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
   const dim3 grid_team((unsigned)(((uint64_t)n * kLocTeam + 255) / 256));          // k_mem_locate_wide / _team: kLocTeam lanes per read
-  // which stage 1 / SEG flow: the fast stage 1 serves mates up to kS1MaxLen nucleotides; in MEM mode on the second-generation
+  // which stage 1 / SEG flow: the fast stage 1 serves mates up to kS1MaxLenLong nucleotides (two instantiations); in MEM mode on the second-generation
   // lanes SEG is then looked at lazily (kj_core.h: kParamLazySeg), everywhere else stage 1 detects the SEG trigger itself
-  const bool mem_narrow2 = ix->dev.blocks64 && ix->dev.kline && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
+  const bool mem_narrow2 = ix->dev.blocks64 && ix->dev.kline && ix->dev.kline_k >= 2 && ix->dev.kline_k <= p.m;
   const bool mem_wide2 = ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
   const bool mem_v2 = p.mode == 0 && (mem_narrow2 || mem_wide2) && !c->mem_v1 && !c->verbose;
-  const bool fast1 = !protein && !c->stage1_old && max_read_len <= kS1MaxLen && p.m >= 1 && p.m <= 64;
+  const bool fast1 = !protein && !c->stage1_old && max_read_len <= kS1MaxLenLong && p.m >= 1 && p.m <= 64;
+  const bool long1 = max_read_len > kS1MaxLen;              // (192 .. 287 nt: the instantiation with six units per frame string)
   const bool lazy = fast1 && mem_v2 && p.seg && c->lazy_seg;
   const bool trig1 = fast1 && p.seg && !lazy;
   if (n > 0) {
@@ -1726,6 +1751,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     if (protein)
       hipLaunchKernelGGL(k_fragments_protein, dim3((n + kFragBlock - 1) / kFragBlock), dim3(kFragBlock), 0, s,
                          ix->d_ct, p, ix->st, b, sq, cnt + 3);
+    else if (fast1 && trig1 && long1)
+      hipLaunchKernelGGL((k_fragments_fast<true, kS1UnitsLong>), dim3((n + kS1Block - 1) / kS1Block), dim3(kS1Block), 0, s, ix->d_s1, p, b, sq, cnt + 3);
+    else if (fast1 && long1)
+      hipLaunchKernelGGL((k_fragments_fast<false, kS1UnitsLong>), dim3((n + kS1Block - 1) / kS1Block), dim3(kS1Block), 0, s, ix->d_s1, p, b, sq, cnt + 3);
     else if (fast1 && trig1)
       hipLaunchKernelGGL(k_fragments_fast<true>, dim3((n + kS1Block - 1) / kS1Block), dim3(kS1Block), 0, s, ix->d_s1, p, b, sq, cnt + 3);
     else if (fast1)

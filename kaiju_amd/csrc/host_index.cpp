@@ -742,7 +742,7 @@ DevIndex PackedIndex::host_view() const {
   d.kmer32 = kmer32.empty() ? nullptr : kmer32.data();
   d.kmer64 = kmer64.empty() ? nullptr : kmer64.data();
   d.kmer_k = kmer_k;
-  d.kline = kline.empty() ? nullptr : kline.data();
+  d.kline = kline.empty() ? nullptr : kline.data(); d.kline_k = kline.empty() ? 0u : kmer_k;
   d.sa_full = sa_full.empty() ? nullptr : sa_full.data();
   d.text = text.empty() ? nullptr : text.data();
   d.row_tax = row_seq.empty() ? nullptr : row_seq.data();

@@ -89,7 +89,10 @@ struct DevIndex {
   // the suffix interval of M.a for all twenty letters a (a = w[j]: the k-mer that ends at j, 6 bytes each, KLine below) and
   // one bit per letter b saying whether b.M occurs at all (b = w[j-k]: the k-mer that ends at j-1).  Three of four k-mers
   // of a read are not in the index: their lookups cost no line of their own any more.
-  const uint8_t *kline;      // [20^(kmer_k-1)] lines of 128 bytes; nullptr = none
+  const uint8_t *kline;      // [20^(kline_k-1)] lines of 128 bytes; nullptr = none
+  uint32_t kline_k;          // letters of the words the LINES describe.  The device builds them from a table of that depth and then
+                             // keeps only a five-letter table (25 MB instead of 10 GB at k = 7) for the lanes that read the table -
+                             // the first generation: verbose output, retry pass - so kmer_k <= kline_k there
   // TEXT VERIFICATION (narrow indexes that leave room): the database itself - text[] in index-alphabet codes,
   // every sequence behind a 0 byte - and the position in it of the suffix of EVERY row (the full suffix array, 4 bytes a row).
   // Once a backward search has narrowed to one row and still has letters to go, its match grows exactly as far as the read
@@ -1374,8 +1377,65 @@ struct Stage1Tables {        // built on the host (host_tables.cpp: build_stage1
   int32_t pad[3];
 };
 static_assert(sizeof(Stage1Tables) % 16 == 0, "Stage1Tables is copied in 16-byte pieces");
-constexpr int kS1Units = 4;                          // 16-residue units per frame string
+constexpr int kS1Units = 4;                          // 16-residue units per frame string: the benchmark's instantiation (150-bp reads)
 constexpr uint32_t kS1MaxLen = 48 * kS1Units - 1;    // len / 3 + 1 <= 16 * kS1Units
+constexpr int kS1UnitsLong = 6;                      // ... and the one for mates of 192 .. 287 nucleotides (250-bp MiSeq reads): the
+constexpr uint32_t kS1MaxLenLong = 48 * kS1UnitsLong - 1;   // per-frame masks ("residue is no stop") are 128 bits wide there
+// the masks of the fast stage 1: one bit per codon of a frame - 64 bits for kS1Units, two words for kS1UnitsLong
+struct Mask128 { uint64_t lo, hi; };
+KJ_HD uint64_t mk_zero(uint64_t) { return 0; }
+KJ_HD Mask128 mk_zero(Mask128) { return Mask128{0, 0}; }
+KJ_HD void mk_or16(uint64_t &m, uint32_t bits, uint32_t b) { m |= (uint64_t)bits << (16u * b); }
+KJ_HD void mk_or16(Mask128 &m, uint32_t bits, uint32_t b) { if (b < 4u) m.lo |= (uint64_t)bits << (16u * b); else m.hi |= (uint64_t)bits << (16u * (b - 4u)); }
+KJ_HD void mk_setbit(uint64_t &m, uint32_t k, bool v) { m |= (uint64_t)(v ? 1u : 0u) << k; }
+KJ_HD void mk_setbit(Mask128 &m, uint32_t k, bool v) { if (k < 64u) m.lo |= (uint64_t)(v ? 1u : 0u) << k; else m.hi |= (uint64_t)(v ? 1u : 0u) << (k - 64u); }
+KJ_HD bool mk_any(uint64_t m) { return m != 0; }
+KJ_HD bool mk_any(const Mask128 &m) { return (m.lo | m.hi) != 0; }
+KJ_HD uint64_t mk_shr(uint64_t m, uint32_t n) { return n >= 64u ? 0ull : m >> n; }
+KJ_HD Mask128 mk_shr(const Mask128 &m, uint32_t n) {
+  if (n == 0u) return m;
+  if (n >= 128u) return Mask128{0, 0};
+  if (n >= 64u) return Mask128{m.hi >> (n - 64u), 0};
+  return Mask128{(m.lo >> n) | (m.hi << (64u - n)), m.hi >> n};
+}
+KJ_HD uint64_t mk_shl(uint64_t m, uint32_t n) { return n >= 64u ? 0ull : m << n; }
+KJ_HD Mask128 mk_shl(const Mask128 &m, uint32_t n) {
+  if (n == 0u) return m;
+  if (n >= 128u) return Mask128{0, 0};
+  if (n >= 64u) return Mask128{0, m.lo << (n - 64u)};
+  return Mask128{m.lo << n, (m.hi << n) | (m.lo >> (64u - n))};
+}
+KJ_HD uint64_t mk_and(uint64_t a, uint64_t b) { return a & b; }
+KJ_HD Mask128 mk_and(const Mask128 &a, const Mask128 &b) { return Mask128{a.lo & b.lo, a.hi & b.hi}; }
+KJ_HD uint32_t mk_ctz(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
+KJ_HD uint32_t mk_ctz(const Mask128 &m) { return m.lo ? (uint32_t)__builtin_ctzll(m.lo) : 64u + (uint32_t)__builtin_ctzll(m.hi); }
+// the lowest run of ones of E cleared; its length in `run`
+KJ_HD uint64_t mk_clear_lowest_run(uint64_t E, uint32_t &run) {
+  const uint64_t low = E & (~E + 1ull), E2 = E & (E + low);
+  run = popc64(E ^ E2);
+  return E2;
+}
+KJ_HD Mask128 mk_clear_lowest_run(const Mask128 &E, uint32_t &run) {
+  // low = E & -E; sum = E + low (128-bit); E2 = E & sum
+  Mask128 low;
+  if (E.lo) { low.lo = E.lo & (~E.lo + 1ull); low.hi = 0; } else { low.lo = 0; low.hi = E.hi & (~E.hi + 1ull); }
+  Mask128 sum;
+  sum.lo = E.lo + low.lo;
+  sum.hi = E.hi + low.hi + (sum.lo < E.lo ? 1ull : 0ull);
+  const Mask128 E2{E.lo & sum.lo, E.hi & sum.hi};
+  run = popc64(E.lo ^ E2.lo) + popc64(E.hi ^ E2.hi);
+  return E2;
+}
+// are any of the `count` bits from bit `from` on set?
+KJ_HD bool mk_range_any(uint64_t m, uint32_t from, uint32_t count) {
+  return (mk_shr(m, from) & (count >= 64u ? ~0ull : ((1ull << count) - 1ull))) != 0;
+}
+KJ_HD bool mk_range_any(const Mask128 &m, uint32_t from, uint32_t count) {
+  const Mask128 t = mk_shr(m, from);
+  if (count >= 128u) return mk_any(t);
+  if (count >= 64u) return t.lo != 0 || (t.hi & (count == 64u ? 0ull : ((1ull << (count - 64u)) - 1ull))) != 0;
+  return (t.lo & ((1ull << count) - 1ull)) != 0;
+}
 constexpr int kS1ListCap = 24;                       // fragments ranked in LDS (two words each); a longer list is sorted in place
 constexpr int kS1CntRow = 24;                        // bytes of the letter-count row of a trigger scan (21 used)
 constexpr int kS1CntStride = kS1CntRow + 4;          // per lane: 7 dwords apart (odd: lanes spread over the banks)
@@ -1392,9 +1452,10 @@ struct S1Lane {              // per-lane LDS of the fast stage 1
 // One mate: strings to dst (16-byte aligned, six strings of u = len / 48 + 1 units) and the masks of the residues that are
 // no stops (ns), bit = processing index (the codon number along the read for both strands: string index for a forward
 // frame, distance from the string end for a reverse one).
-KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_t *dst, uint64_t *ns) {
+template <class MaskT>
+KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_t *dst, MaskT *ns) {
   const uint32_t u = len / 48u + 1u;
-  for (int f = 0; f < 6; f++) ns[f] = 0;
+  for (int f = 0; f < 6; f++) ns[f] = mk_zero(MaskT{});
   NucReader nr;
   nr.s = s; nr.len = len;
   u128 c0 = nr.chunk(0), c1 = nr.chunk(1), c2 = nr.chunk(2), c3 = nr.chunk(3);
@@ -1432,8 +1493,8 @@ KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_
       *reinterpret_cast<u128 *>(dst + (size_t)g * (16 * u) + 16 * b) = v;
       v.x = ru[g][0] | (uint64_t)ru[g][1] << 32; v.y = ru[g][2] | (uint64_t)ru[g][3] << 32;
       *reinterpret_cast<u128 *>(dst + (size_t)(4 + g) * (16 * u) - 16 * (b + 1)) = v;
-      ns[g] |= (uint64_t)mf[g] << (16 * b);
-      ns[3 + g] |= (uint64_t)mr[g] << (16 * b);
+      mk_or16(ns[g], mf[g], b);
+      mk_or16(ns[3 + g], mr[g], b);
     }
     c0 = c3; c1 = n1; c2 = n2; c3 = n3;
   }
@@ -1447,14 +1508,15 @@ KJ_HD void s1_mate(const Stage1Tables &t, const uint8_t *s, uint32_t len, uint8_
 // ending at x0[k] is at or below the trigger entropy H <= 2.2 (n <= 64); otherwise whether any window is.
 constexpr int kTsLead = 16;                           // zero bytes in front of a staged string
 constexpr int kTsBuf = kTsLead + 80 + 4;              // per lane: the zeros, up to five units, 25 dwords in all (odd: banks)
-template <bool MASK>
-KJ_HD uint64_t trig_scan(const Stage1Tables &t, const uint8_t *x0, uint32_t n, uint32_t lead, const uint8_t *zero, uint8_t *row) {
+constexpr int kTsBufLong = kTsLead + 96 + 4;          // ... six units (kS1UnitsLong), 29 dwords
+template <bool MASK, class MaskT = uint64_t>
+KJ_HD MaskT trig_scan(const Stage1Tables &t, const uint8_t *x0, uint32_t n, uint32_t lead, const uint8_t *zero, uint8_t *row) {
   uint32_t *c32 = reinterpret_cast<uint32_t *>(row);
 #pragma unroll
   for (int q = 0; q < kS1CntRow / 4; q++) c32[q] = q == 0 ? (kS1StopCnt + 12u * 4u) : 0u;
   int32_t sc = 12 * t.dtab[13];
   const uint8_t *db = reinterpret_cast<const uint8_t *>(t.dtab);
-  uint64_t mask = 0;
+  MaskT mask = mk_zero(MaskT{});
   for (uint32_t k = 0; k < n; k++) {
     const uint32_t x = x0[k];
     const uint32_t y = *(k < lead ? zero : x0 + k - 12);
@@ -1464,8 +1526,7 @@ KJ_HD uint64_t trig_scan(const Stage1Tables &t, const uint8_t *x0, uint32_t n, u
     const uint32_t cy = row[y] - 4u;
     row[y] = (uint8_t)cy;
     sc -= *reinterpret_cast<const int32_t *>(db + cy);
-    if (MASK) mask |= (uint64_t)(sc <= t.locut32 ? 1u : 0u) << k;
-    else mask |= sc <= t.locut32 ? 1ull : 0ull;
+    mk_setbit(mask, MASK ? k : 0u, sc <= t.locut32);
   }
   return mask;
 }
@@ -1484,9 +1545,15 @@ KJ_HD void trig_stage(const uint8_t *src, uint32_t nu, uint8_t *buf) {
 // entropy, s_SegSeq blast_seg.c:2061; same answer as seg_triggers); fragments longer than 64 residues: seg_triggers
 KJ_HD bool trig_fragment(const Stage1Tables &t, const uint8_t *pep, uint32_t start, uint32_t len, uint8_t *buf, uint8_t *row) {
   if (len < (uint32_t)kSegWindow) return false;
-  const uint32_t a = start & 15u;
-  trig_stage(pep + (start - a), (a + len + 15u) >> 4, buf);
-  return trig_scan<false>(t, buf + kTsLead + a, len, 12, buf, row) != 0;
+  // (a fragment of more than 64 residues - reads beyond 191 nt - in pieces of 64 that share eleven residues: every 12-window
+  //  lies inside one of them, and a piece with its alignment slack fits the five units of the staging buffer)
+  for (uint32_t at = 0;; at += 64u - ((uint32_t)kSegWindow - 1u)) {
+    const uint32_t n = len - at < 64u ? len - at : 64u;
+    const uint32_t a = (start + at) & 15u;
+    trig_stage(pep + (start + at - a), (a + n + 15u) >> 4, buf);
+    if (trig_scan<false>(t, buf + kTsLead + a, n, 12, buf, row) != 0) return true;
+    if (at + n >= len) return false;
+  }
 }
 KJ_HD uint64_t bitrev64(uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1498,6 +1565,10 @@ KJ_HD uint64_t bitrev64(uint64_t v) {
 #endif
 }
 
+// the low `nbits` bits of m in reverse order (nbits = 16 u: a whole frame string)
+KJ_HD uint64_t mk_rev_low(uint64_t m, uint32_t nbits) { return bitrev64(m) >> (64u - nbits); }
+KJ_HD Mask128 mk_rev_low(const Mask128 &m, uint32_t nbits) { return mk_shr(Mask128{bitrev64(m.hi), bitrev64(m.lo)}, 128u - nbits); }
+
 // where fragment [a, a + l) (processing indices) of string f of a mate lies in the mate's area
 KJ_HD uint32_t s1_start(int f, uint32_t u, uint32_t a, uint32_t l) {
   return f < 3 ? (uint32_t)f * (16 * u) + a : (uint32_t)(f + 1) * (16 * u) - a - l;
@@ -1505,8 +1576,8 @@ KJ_HD uint32_t s1_start(int f, uint32_t u, uint32_t a, uint32_t l) {
 
 // Fragment list of read r from the masks of its mates.  `emit` receives (start in the read's area, length, emission
 // moment, trigger flag) of every run of at least m residues, in no particular order.
-template <class Emit>
-KJ_HD void s1_runs(const uint64_t *ns, const uint64_t *tg, uint32_t len, uint32_t m, uint32_t area, uint32_t seq_base,
+template <class MaskT, class Emit>
+KJ_HD void s1_runs(const MaskT *ns, const MaskT *tg, uint32_t len, uint32_t m, uint32_t area, uint32_t seq_base,
                    Emit &&emit) {
   if (m > 64u || m == 0u) return;
   const uint32_t top = len - 3, u = len / 48u + 1u;
@@ -1516,18 +1587,16 @@ KJ_HD void s1_runs(const uint64_t *ns, const uint64_t *tg, uint32_t len, uint32_
   const uint32_t seqF = seq_base, seqR = seq_base + len + 3;
   for (int f = 0; f < 6; f++) {
     const int g = f < 3 ? f : f - 3;
-    const uint64_t M = ns[f];
     // E: positions where a run of m residues starts
-    uint64_t E = M;
+    MaskT E = ns[f];
     uint32_t w = 1;
-    while (2 * w <= m) { E &= E >> w; w *= 2; }
-    if (w < m) E &= E >> (m - w);
-    while (E) {
-      const uint64_t low = E & (~E + 1ull);
-      const uint32_t a = (uint32_t)__builtin_ctzll(E);
-      const uint64_t E2 = E & (E + low);                     // the lowest run of E cleared
-      const uint32_t l = popc64(E ^ E2) + m - 1;
-      E = E2;
+    while (2 * w <= m) { E = mk_and(E, mk_shr(E, w)); w *= 2; }
+    if (w < m) E = mk_and(E, mk_shr(E, m - w));
+    while (mk_any(E)) {
+      const uint32_t a = mk_ctz(E);
+      uint32_t run = 0;
+      E = mk_clear_lowest_run(E, run);                       // the lowest run of E cleared
+      const uint32_t l = run + m - 1;
       uint32_t seq;
       if (f < 3) {
         const uint32_t p = 3 * (a + l) + (uint32_t)g;        // position of the stop behind the run
@@ -1535,7 +1604,7 @@ KJ_HD void s1_runs(const uint64_t *ns, const uint64_t *tg, uint32_t len, uint32_
       } else {
         seq = a == 0 ? seqR + len + (uint32_t)g : seqR + (top - (3 * (a - 1) + (uint32_t)g));
       }
-      const bool trig = l >= 12u && ((tg[f] >> (a + 11u)) & ((l - 11u >= 64u) ? ~0ull : ((1ull << (l - 11u)) - 1ull))) != 0;
+      const bool trig = l >= 12u && mk_range_any(tg[f], a + 11u, l - 11u);
       emit(area + s1_start(f, u, a, l), l, seq, trig);
     }
   }
@@ -1544,9 +1613,12 @@ KJ_HD void s1_runs(const uint64_t *ns, const uint64_t *tg, uint32_t len, uint32_
 // stage 1 for read r, fast path.  TRIG: fragments whose 12-windows reach the SEG trigger entropy are queued for the SEG
 // pass (as build_fragments does); otherwise the fragment flags are 0 and SEG is looked at lazily (kParamLazySeg) or not
 // at all (-X).
-template <bool TRIG>
+template <bool TRIG, int UNITS = kS1Units>
 KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Batch &b, const SegQueue &sq, uint32_t r,
                                 uint32_t *err_flags, const S1Lane &ln) {
+  typedef typename std::conditional<(UNITS <= 4), uint64_t, Mask128>::type MaskT;
+  constexpr uint32_t kMaxLen = 48u * (uint32_t)UNITS - 1u;
+  static_assert(UNITS == kS1Units || UNITS == kS1UnitsLong, "frame strings of four or six units");
   const uint64_t o0 = b.off[2 * (uint64_t)r], o1 = b.off[2 * (uint64_t)r + 1], o2 = b.off[2 * (uint64_t)r + 2];
   uint32_t len1 = (uint32_t)(o1 - o0), len2 = (uint32_t)(o2 - o1);
   const uint32_t m3 = p.m * 3;
@@ -1555,7 +1627,7 @@ KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Ba
   const uint32_t cap = frag_cap(b.off, r, p.m);
   const uint64_t pbase = pep_base(b.off, r);
   uint32_t n = 0, pending = 0;
-  if (len1 > kS1MaxLen || len2 > kS1MaxLen) {                // the caller promised shorter reads (kaiju_gpu_set_max_read_length)
+  if (len1 > kMaxLen || len2 > kMaxLen) {                    // the caller promised shorter reads (kaiju_gpu_set_max_read_length)
     if (err_flags) *err_flags |= kErrReadTooLong;
     len1 = len2 = 0;
   }
@@ -1583,15 +1655,16 @@ KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Ba
       }
       n++;
     };
-    uint64_t ns[6], tg[6] = {0, 0, 0, 0, 0, 0};
+    MaskT ns[6], tg[6];
+    for (int f = 0; f < 6; f++) tg[f] = mk_zero(MaskT{});
     // TRIG: the trigger windows of a mate's six strings (stops and all), in memory order; for a reverse string that is
     // the other way round: the window ending at byte o of 16u is the one that starts at processing index 16u - 1 - o
     auto scan_mate = [&](uint8_t *dst, uint32_t len) {
       const uint32_t u = len / 48u + 1u;
       for (int f = 0; f < 6; f++) {
         trig_stage(dst + (size_t)f * 16 * u, u, ln.tsbuf);
-        const uint64_t mm = trig_scan<true>(t, ln.tsbuf + kTsLead, 16 * u, 0, ln.tsbuf, ln.cnt);
-        tg[f] = f < 3 ? mm : (bitrev64(mm) >> (64 - 16 * u)) << 11;
+        const MaskT mm = trig_scan<true, MaskT>(t, ln.tsbuf + kTsLead, 16 * u, 0, ln.tsbuf, ln.cnt);
+        tg[f] = f < 3 ? mm : mk_shl(mk_rev_low(mm, 16 * u), 11);
       }
     };
     if (len1 >= m3) {
@@ -1604,7 +1677,8 @@ KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Ba
       if (TRIG && p.seg) scan_mate(area + mate_bytes, len2);
       s1_runs(ns, tg, len2, p.m, mate_bytes, 2 * len1 + 6, emit);
     }
-    // (emission moments stay below 2 * (len1 + len2) + 12 <= 780, keys below 11 * 64, starts below 768, lengths <= 64)
+    // (emission moments stay below 2 * (len1 + len2) + 12 <= 780 - 1160 with six units -, keys below 11 * 96, starts below
+    //  1152, lengths <= 96: the list words hold 11 bits of moment, 7 bits of length)
     auto final_flags = [&](uint32_t trig, uint32_t k) -> uint32_t {
       if (!TRIG || !p.seg) return 0u;
       if (!trig) return kFragChecked;                        // SEG would report nothing for this fragment
@@ -2237,7 +2311,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   const P check = (P)((1ull << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
   // the narrow lane looks k-mers up in the k-mer LINES (DevIndex::kline), the wide one in the table of 16-byte entries
-  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.m && (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kline)) ? ix.kmer_k : 0;
+  const uint32_t ktab = WIDE ? ix.kmer_k : ix.kline_k;      // (narrow: the k-mer lines; wide: the table)
+  const uint32_t kk = (ktab >= 2 && ktab <= p.m && (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kline)) ? ktab : 0;
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0;                 // the wave's chunk of work items (wave-uniform)
   const RankBlock64 *const blk0 = ix.blocks64;
@@ -3586,8 +3661,9 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
   int wq = 0;                                   // fragment position of win[0]
   const P check = (P)((1u << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
-  const uint32_t kk = (ix.kmer_k >= 2 && ix.kmer_k <= p.seed_length && p.seed_length >= 3 &&
-                       (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kline)) ? ix.kmer_k : 0;
+  const uint32_t ktab = WIDE ? ix.kmer_k : ix.kline_k;      // (narrow: the k-mer lines; wide: the table)
+  const uint32_t kk = (ktab >= 2 && ktab <= p.seed_length && p.seed_length >= 3 &&
+                       (WIDE ? (const void *)ix.kmer64 : (const void *)ix.kline)) ? ktab : 0;
   const uint32_t nwaves = kj_nwaves();
   uint32_t wnext = 0, wend = 0, itc = 0;
   const RankBlock64 *const blk0 = ix.blocks64;

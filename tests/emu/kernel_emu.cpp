@@ -155,7 +155,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   // lanes then looks at SEG lazily
   const char *lane_env = getenv("KAIJU_EMU_LANE");
   const bool mem_v2 = p.mode == 0 && d.blocks64 && (d.kmer32 || (d.mb_base && d.kmer64)) && !lane_env && !g_vb.n_acc;
-  const bool fast1 = !(p.flags & kParamProtein) && !getenv("KAIJU_EMU_STAGE1_OLD") && maxlen <= kS1MaxLen && p.m >= 1 && p.m <= 64;
+  const bool fast1 = !(p.flags & kParamProtein) && !getenv("KAIJU_EMU_STAGE1_OLD") && maxlen <= kS1MaxLenLong && p.m >= 1 && p.m <= 64;
+  const bool long1 = maxlen > kS1MaxLen;
   const bool lazy = fast1 && mem_v2 && p.seg && !getenv("KAIJU_EMU_LAZY_OFF");
   const bool trig1 = fast1 && p.seg && !lazy;
   Stage1Tables s1tab;
@@ -169,13 +170,15 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     const Stage1Tables &s1 = s1tab;
     uint32_t codes[2 * kS1ListCap];
     alignas(4) uint8_t cnt[kS1CntStride];
-    alignas(4) uint8_t tsbuf[kTsBuf];
+    alignas(4) uint8_t tsbuf[kTsBufLong];
     S1Lane ln{codes, 1, cnt, tsbuf};
     for (uint32_t r = 0; r < n; r++) {
       for (auto &x : codes) x = 0xdeadbeefu;
       memset(cnt, 0xee, sizeof cnt);
       memset(tsbuf, 0xee, sizeof tsbuf);
-      if (trig1) build_fragments_fast<true>(s1, p, b, sq, r, &err, ln);
+      if (trig1 && long1) build_fragments_fast<true, kS1UnitsLong>(s1, p, b, sq, r, &err, ln);
+      else if (long1) build_fragments_fast<false, kS1UnitsLong>(s1, p, b, sq, r, &err, ln);
+      else if (trig1) build_fragments_fast<true>(s1, p, b, sq, r, &err, ln);
       else build_fragments_fast<false>(s1, p, b, sq, r, &err, ln);
     }
   } else

@@ -902,3 +902,55 @@ def test_reads_with_many_longest_matches(oracle, tmp_path, monkeypatch):
     gx, _ = emu.classify(hx, util.gp("mem", seg=0), seqs, off)
     bad = [i for i in range(len(xo)) if not util.same_hit(xo[i], gx[i])]
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("mode,seg", CASES)
+def test_fast_stage1_for_mates_up_to_287_nt(oracle, emu, golden, handles, mode, seg, monkeypatch):
+    """build_fragments_fast<.., kS1UnitsLong>: mates of 192 .. 287 nucleotides (250-bp MiSeq reads, 2 x 250 pairs) take the fast
+    stage 1 with six units per frame string and 128-bit masks - fragments of up to 95 residues, more than 24 of them per
+    pair, SEG trigger windows beyond bit 63, k_trigcheck's scan in pieces.  Against the oracle, and the fragment lists
+    against the general stage 1 (KAIJU_EMU_STAGE1_OLD)."""
+    from kaiju_amd import synth
+    h, ix, tax = handles
+    rng = np.random.default_rng(23)
+    _, dbseqs = util.read_fasta(os.path.join(util.GOLD, "db.faa"))
+    prot = [p.decode() for p in dbseqs if len(p) >= 100]
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    codon = {"A": "GCT", "C": "TGT", "D": "GAT", "E": "GAA", "F": "TTT", "G": "GGT", "H": "CAT", "I": "ATT", "K": "AAA", "L": "CTT",
+             "M": "ATG", "N": "AAT", "P": "CCT", "Q": "CAA", "R": "CGT", "S": "TCT", "T": "ACT", "V": "GTT", "W": "TGG", "Y": "TAT"}
+
+    def one(L):
+        if prot and rng.random() < 0.7:
+            p = prot[int(rng.integers(0, len(prot)))]
+            k = int(rng.integers(0, len(p) - 96))
+            pep = "".join(c if c in codon else "A" for c in p[k:k + 96])
+            if rng.random() < 0.3:                               # a low-complexity stretch: SEG trigger windows far into the string
+                q = int(rng.integers(40, 80)); pep = pep[:q] + "S" * 14 + pep[q + 14:]
+            nt = "".join(codon[c] for c in pep)
+            nt = "ACGT"[int(rng.integers(0, 4))] * int(rng.integers(0, 3)) + nt
+        else:
+            nt = "".join(rng.choice(list("ACGT"), 300))
+        nt = nt[:L]
+        if rng.random() < 0.2:
+            q = int(rng.integers(0, L)); nt = nt[:q] + "N" + nt[q + 1:]
+        if rng.random() < 0.5:
+            nt = nt[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+        return np.frombuffer(nt.encode(), dtype=np.uint8)
+
+    lens = [192, 193, 239, 240, 241, 250, 251, 286, 287]
+    reads = [one(int(rng.choice(lens))) for _ in range(400)] + [one(150) for _ in range(20)]
+    m1 = [one(int(rng.choice(lens))) for _ in range(200)]
+    m2 = [one(int(rng.choice(lens + [100]))) for _ in range(200)]
+    for seqs, off, pe in (util.pack(reads) + (False,), util.pack(m1, m2) + (True,)):
+        oh = oracle.classify(ix, tax, oracle.params(mode, seg=seg, use_evalue=0), seqs, off, paired=pe)
+        monkeypatch.delenv("KAIJU_EMU_STAGE1_OLD", raising=False)
+        gh, _, frags_fast = emu.classify(h, util.gp(mode, seg=seg), seqs, off, paired=pe, want_frags=True)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], gh[i])]
+        assert not bad, (pe, bad[:5], oh[bad[0]], gh[bad[0]])
+        monkeypatch.setenv("KAIJU_EMU_STAGE1_OLD", "1")
+        g2, _, frags_old = emu.classify(h, util.gp(mode, seg=seg), seqs, off, paired=pe, want_frags=True)
+        monkeypatch.delenv("KAIJU_EMU_STAGE1_OLD")
+        assert (g2 == gh).all()
+        if not (mode == "mem" and seg):
+            assert frags_fast == frags_old
+        assert (gh["n_ids"] > 0).mean() > 0.3
