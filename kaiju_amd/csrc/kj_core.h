@@ -1391,14 +1391,14 @@ KJ_HD void mk_setbit(uint64_t &m, uint32_t k, bool v) { m |= (uint64_t)(v ? 1u :
 KJ_HD void mk_setbit(Mask128 &m, uint32_t k, bool v) { if (k < 64u) m.lo |= (uint64_t)(v ? 1u : 0u) << k; else m.hi |= (uint64_t)(v ? 1u : 0u) << (k - 64u); }
 KJ_HD bool mk_any(uint64_t m) { return m != 0; }
 KJ_HD bool mk_any(const Mask128 &m) { return (m.lo | m.hi) != 0; }
-KJ_HD uint64_t mk_shr(uint64_t m, uint32_t n) { return n >= 64u ? 0ull : m >> n; }
+KJ_HD uint64_t mk_shr(uint64_t m, uint32_t n) { return m >> n; }            // (n < 64 at every call: erosion steps, a + 11 <= 63)
 KJ_HD Mask128 mk_shr(const Mask128 &m, uint32_t n) {
   if (n == 0u) return m;
   if (n >= 128u) return Mask128{0, 0};
   if (n >= 64u) return Mask128{m.hi >> (n - 64u), 0};
   return Mask128{(m.lo >> n) | (m.hi << (64u - n)), m.hi >> n};
 }
-KJ_HD uint64_t mk_shl(uint64_t m, uint32_t n) { return n >= 64u ? 0ull : m << n; }
+KJ_HD uint64_t mk_shl(uint64_t m, uint32_t n) { return m << n; }
 KJ_HD Mask128 mk_shl(const Mask128 &m, uint32_t n) {
   if (n == 0u) return m;
   if (n >= 128u) return Mask128{0, 0};

@@ -38,8 +38,8 @@ for task in "$@"; do
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_g -o s -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --mode greedy --legs "" --steps 3 > $GRAFT_REPO_ROOT/$O/bench_greedy_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_greedy_under_rocprof.err )
       cp $O/stats_g/s_kernel_stats.csv $O/kernel_stats_greedy.csv 2>/dev/null; rm -rf $O/stats_g; echo "[lease] stats_greedy"; head -6 $O/kernel_stats_greedy.csv ;;
     pmc)
-      bash tests/tools/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1; tail -3 $O/pmc.log
-      python tests/tools/pmc_bench_collect.py $O/pmc profiles/traffic.json profiles/r04_pmc > $O/pmc_collect.log 2>&1; cp profiles/traffic.json profiles/traffic_all_kernels.json $O/ 2>/dev/null; tail -3 $O/pmc_collect.log ;;
+      bash tests/tools/pmc_bench.sh $O/pmc > $O/pmc.log 2>&1; tail -5 $O/pmc.log
+      python tests/tools/pmc_bench_collect.py $O/pmc $O/traffic.json profiles/${PMC_RAW_NAME:-r05_pmc} > $O/pmc_collect.log 2>&1; tail -3 $O/pmc_collect.log ;;
     refseq_ref)
       # BASELINE configs[3]: refseq_ref class, 28 G rows.  The box's cgroup allows 300 GiB of memory INCLUDING /dev/shm (the host
       # has 3 TB, / only 79 GB): a real sort of 28 G suffixes (224 GB of 64-bit positions) does not fit, so the index is the one of
