@@ -630,12 +630,12 @@ def main():
         log(rank, f"index {os.path.getsize(fmi)/1e6:.0f} MB file{'' if copies == 1 else f' ({copies} copies of every protein)'} "
                   f"({time.time()-t0:.1f}s)")
     kdist.barrier()
-    # N ranks, one host: the .fmi is parsed and packed ONCE (rank 0 writes the device image next to it, no GPU needed), the
-    # ranks upload that image - and only a few at a time, so that the host never holds more than `conc` copies of the packed
-    # arrays (a refseq-class image is 150 GB; eight at once would not fit the host that eight parsed .fmi would not fit either)
     load_path = fmi
     load_info = {"path": "fmi: parsed, packed and uploaded from host memory"}
-    if world > 1 or args.image:
+    # (N ranks, one host: a .fmi of 1 GiB and more is streamed to HBM by every rank for itself - it sits in the page cache, a rank
+    #  needs the names and two page-locked pieces -, a smaller one is parsed and packed per rank, four at a time; the device image
+    #  of round 4 only on request)
+    if args.image:
         img = fmi + ".kjimg"
         if rank == 0 and not image_is_fresh(img, fmi):
             t1 = time.time()
@@ -652,7 +652,7 @@ def main():
         log(rank, "prepared:", load_path)
         return
     # (the image pieces go through page-locked buffers, 0.5 GB per rank: all ranks may load at once; a .fmi is parsed on the host)
-    conc = max(1, int(os.environ.get("KAIJU_BENCH_LOAD_CONCURRENCY", "8" if load_path != fmi else "4")))
+    conc = max(1, int(os.environ.get("KAIJU_BENCH_LOAD_CONCURRENCY", "8" if load_path != fmi or os.path.getsize(fmi) >= (1 << 30) else "4")))
     index = None
     t1 = time.time()
     for g in range(0, world, conc):

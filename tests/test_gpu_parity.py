@@ -526,6 +526,8 @@ def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, 
     grown along the text (DevIndex::beyond_lo), so a result does not depend on whether the arrays found room in HBM.  Forced
     wide: such an index gets no text arrays at all."""
     wide = bool(os.environ.get("KAIJU_GPU_FORCE_WIDE"))
+    if os.environ.get("KAIJU_GPU_NO_TEXT"):
+        pytest.skip("the suite runs without text arrays altogether (tests/tools/forced_wide_suite.sh): nothing to compare")
     from kaiju_amd import mkfmi, synth
     api = gpu_lib
     _, leaves = synth.make_taxonomy(3, 3, 3)
