@@ -298,13 +298,7 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
   ls.prof = s_prof[threadIdx.x >> 6];
   if ((threadIdx.x & 63) == 0) { ls.prof[0] = __builtin_readcyclecounter(); ls.prof[1] = PM_HEAD; }
 #endif
-#ifdef KJ_MEM_LDS_STATE
-  __shared__ uint32_t s_st[kBlock * kMemStWords];
-  ls.st = s_st + threadIdx.x;
-  mem_lane2<false, false, false, true>(ix, p, b, wl, ls);
-#else
   mem_lane2<false>(ix, p, b, wl, ls);
-#endif
 }
 // the ids of the reads whose longest matches the lanes above left in their hit records (kParamDeferLocate): one lane per read
 // (narrow index with the row -> sequence table: an id is two loads, and the rows of a match are neighbours in that table -
@@ -358,13 +352,7 @@ k_mem_second(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint3
   ls.si = si_all + lane * si_cap;
   ls.si_cap = si_cap;
   ls.win = s_win + threadIdx.x * kWinStride;
-#ifdef KJ_MEM_LDS_STATE
-  __shared__ uint32_t s_st[kBlock * kMemStWords];
-  ls.st = s_st + threadIdx.x;
-  mem_lane2<false, false, false, true>(ix, p, b, wl, ls);
-#else
   mem_lane2<false>(ix, p, b, wl, ls);
-#endif
 }
 // the same lane with 64-bit positions: indexes of 2^32 rows and more (counts relative to mb_base, 16-byte k-mer entries)
 __global__ void __launch_bounds__(kBlock, 3)

@@ -1915,7 +1915,6 @@ struct LaneScratch {
   SIEntry *si;               // this lane's match buffer
   uint32_t si_cap;
   uint8_t *win;              // this lane's peptide window (kWin bytes)
-  uint32_t *st = nullptr;    // mem_lane2<.., LDSST>: this lane's row of rarely touched state (kMemStWords words, kMemStStride apart)
   unsigned long long *prof = nullptr;   // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PM_N)
   uint8_t *coop = nullptr;   // wide lanes: the wavefront's kCoopBytesPerWave bytes of LDS (coop_fetch2; 16-byte aligned, wave-uniform)
 };
@@ -2279,18 +2278,7 @@ static int kj_single_at = 0;
 #define KJ_HIST_SINGLE(is1, len)
 #define KJ_HIST_SINGLE_END(l)
 #endif
-// LDSST (narrow lane, experiment of round 5): the state that only the fragment switches and the end of a read touch - the
-// second match, the prefetched descriptor, the read's number and offsets: fourteen words - lives in the lane's LDS row
-// (LaneScratch::st) instead of registers, which is what five wavefronts per SIMD would need (96 VGPRs)
-template <bool L> struct RareWord { uint32_t v = 0; KJ_HD uint32_t &at(uint32_t *) { return v; } };
-template <> struct RareWord<true> { KJ_HD uint32_t &at(uint32_t *p) { return *p; } };
-#if defined(__HIP_DEVICE_COMPILE__)
-constexpr uint32_t kMemStStride = 256;               // word k of lane t: st[k * 256 + t] (the lanes of a block side by side: no bank conflicts)
-#else
-constexpr uint32_t kMemStStride = 1;
-#endif
-constexpr uint32_t kMemStWords = 14;
-template <bool WIDE, bool XORDER = false, bool COUNT = false, bool LDSST = false>
+template <bool WIDE, bool XORDER = false, bool COUNT = false>
 KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
                      const LaneScratch &ls) {
   uint32_t oc[kOpcN];
@@ -2299,15 +2287,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   int kind = K_IDLE;
   // read
-  constexpr bool LS = LDSST && !WIDE;
-  uint32_t *const stp = ls.st;
-#define KJ_RW(name, k) RareWord<LS> name##_h; uint32_t &name = name##_h.at(stp + (k) * kMemStStride); name = 0
-  uint32_t f = 0, fcur = 0;
-  KJ_RW(r, 0); KJ_RW(nf, 1); KJ_RW(fbase, 2);
-  KJ_RW(pep_lo, 3); KJ_RW(pep_hi, 4);
-  KJ_RW(dn_start, 5); KJ_RW(dn_len, 6); KJ_RW(dn_key, 7); KJ_RW(dn_flags, 8);
+  uint32_t r = 0, nf = 0, f = 0, fcur = 0, fbase = 0;
+  uint64_t pepoff = 0;
+  Frag dnext; dnext.start = dnext.len = dnext.key = dnext.flags = 0;
   // fragment / search
-  KJ_RW(fs_lo, 9); KJ_RW(fs_hi, 10);
+  uint64_t fsoff = 0;
   int flen = 0, j = 0, i = 0;
   P lo = 0, hi = 0;
   uint32_t c = 1, L = p.m, nsi = 0, kidx = 0;
@@ -2316,16 +2300,13 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
   int fill_top = 0;
   bool fill_newfrag = false, fill_step = false;
   // first two maximal matches live in registers, further ones in the lane's scratch
-  P s0lo = 0, s1lo_w = 0; uint32_t s0len = 0, s0frag = 0;
-  KJ_RW(s1lo_n, 11); KJ_RW(s1len, 12); KJ_RW(s1frag, 13);
-#undef KJ_RW
-  auto s1lo_get = [&]() -> P { if constexpr (WIDE) return s1lo_w; else return (P)s1lo_n; };
+  P s0lo = 0, s1lo = 0; uint32_t s0len = 0, s1len = 0, s0frag = 0, s1frag = 0;
   // (the ids: every read leaves its longest matches in the hit record and k_mem_locate* walk them - since round 5 also reads
   //  with three and more, whose walks used to run here with one lane of the wavefront at work and, on a database of protein
   //  families or with an unlucky sample, for thousands of iterations behind the end of everything else)
   uint32_t nids = 0, flags = 0;
   P k = 0;                                    // (wide: text position of the row at hand, K_SAPOS / K_TEXT)
-#define KJ_M_HIT (b.hits + r)                   /* (recomputed where a read ends: two registers less than a pointer kept per lane) */
+  Hit *hit = nullptr;
   LaneWin lw{ls.win, 0};
   const P check = (P)((1ull << ix.chpt_exp) - 1);
   const uint32_t n_items = wl.n_items_ptr ? *wl.n_items_ptr : wl.n_items;
@@ -2359,7 +2340,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 #endif
   }
 
-  auto si_lo = [&](uint32_t e) -> P { return e == 0 ? s0lo : e == 1 ? s1lo_get() : (P)ls.si[e].lo; };
+  auto si_lo = [&](uint32_t e) -> P { return e == 0 ? s0lo : e == 1 ? s1lo : (P)ls.si[e].lo; };
   auto si_len = [&](uint32_t e) -> uint32_t { return e == 0 ? s0len : e == 1 ? s1len : ls.si[e].len; };
   auto si_frag = [&](uint32_t e) -> uint32_t { return e == 0 ? s0frag : e == 1 ? s1frag : ls.si[e].frag; };
   auto in_win = [&](int pos) -> bool { return pos >= lw.q && pos < lw.q + kWin; };
@@ -2476,7 +2457,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (fq < 0) fq = 0;
       // (K_TEXT: the 64 bytes of the database that lie where fragment positions 0..63 would if the match went on)
       // (K_TEXT: the kTextCmp bytes of the database in front of the suffix, i.e. where fragment positions i-kTextCmp .. i-1 would lie)
-      const uint8_t *src = kind == K_FILL ? b.pep + ((uint64_t)fs_lo | (uint64_t)fs_hi << 32) + fq : kind != K_TEXT ? reinterpret_cast<const uint8_t *>(blk0)
+      const uint8_t *src = kind == K_FILL ? b.pep + fsoff + fq : kind != K_TEXT ? reinterpret_cast<const uint8_t *>(blk0)
                            : WIDE ? ix.text + (size_t)((uint64_t)k - (uint64_t)kTextCmp) : ix.text + (kidx - (uint32_t)kTextCmp);
       const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
       w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
@@ -2618,16 +2599,17 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       bk = kind - K_BK;                                      // a bookkeeping block left over from the last iteration
     } else if (kind == K_META) {
       KJ_PM(PM_META);
-      pep_lo = (uint32_t)gv.x; pep_hi = (uint32_t)(gv.x >> 32);
+      pepoff = gv.x;
       fbase = (uint32_t)gv.y;
       nf = (uint32_t)(gv.y >> 32) & ~kNfragSegPending;
       f = 0; L = p.m; nsi = 0; found = false; ovf = false;
       multi = false;
+      hit = b.hits + r;
       if (nf == 0) bk = BK_LOC_INIT; else kind = K_FRAG;
     } else if (kind == K_FRAG) {
       KJ_PM(PM_FRAG);
-      dn_start = (uint32_t)gv.x; dn_len = (uint32_t)(gv.x >> 32);
-      dn_key = (uint32_t)gv.y; dn_flags = (uint32_t)(gv.y >> 32);
+      dnext.start = (uint32_t)gv.x; dnext.len = (uint32_t)(gv.x >> 32);
+      dnext.key = (uint32_t)gv.y; dnext.flags = (uint32_t)(gv.y >> 32);
       bk = BK_NEXT_FRAG;
     } else if (kind == K_FILL) {
       KJ_PM(PM_FILL);
@@ -2639,8 +2621,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       d32[12] = (uint32_t)w3.x; d32[13] = (uint32_t)(w3.x >> 32); d32[14] = (uint32_t)w3.y; d32[15] = (uint32_t)(w3.y >> 32);
       if (fill_newfrag) {
         if (f < nf) {
-          dn_start = (uint32_t)gv.x; dn_len = (uint32_t)(gv.x >> 32);
-          dn_key = (uint32_t)gv.y; dn_flags = (uint32_t)(gv.y >> 32);
+          dnext.start = (uint32_t)gv.x; dnext.len = (uint32_t)(gv.x >> 32);
+          dnext.key = (uint32_t)gv.y; dnext.flags = (uint32_t)(gv.y >> 32);
         }
         bk = BK_START_J;
       } else if (fill_step) { c = lw.w[i - 1 - lw.q]; kind = K_STEP; }
@@ -2678,7 +2660,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           const uint32_t ilen = (uint32_t)(int32_t)(hi - lo);
           if (nsi != 0 && fcur != s0frag) multi = true;      // (lazy SEG: longest matches in more than one fragment)
           if (nsi == 0) { s0lo = lo; s0len = ilen; s0frag = fcur; }
-          else if (nsi == 1) { if constexpr (WIDE) s1lo_w = lo; else s1lo_n = (uint32_t)lo; s1len = ilen; s1frag = fcur; }
+          else if (nsi == 1) { s1lo = lo; s1len = ilen; s1frag = fcur; }
           else if (nsi < ls.si_cap) { SIEntry e; e.lo = lo; e.len = ilen; e.frag = fcur; ls.si[nsi] = e; if constexpr (COUNT) oc[kOpcSiSpill]++; }
           else ovf = true;
           nsi++;
@@ -2733,12 +2715,11 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
         KJ_PM(PM_NEXT_FRAG);
         // getNextFragment(longest): stop when the best remaining key < longest (:550, :279);
         // dnext is the prefetched descriptor of fragment f
-        if (f >= nf || (found && dn_key < L)) bk = BK_LOC_INIT;
+        if (f >= nf || (found && dnext.key < L)) bk = BK_LOC_INIT;
         else {
           fcur = f; f++;
           skipj = false;
-          { const uint64_t fo = ((uint64_t)pep_lo | (uint64_t)pep_hi << 32) + dn_start; fs_lo = (uint32_t)fo; fs_hi = (uint32_t)(fo >> 32); }
-          flen = (int)dn_len;
+          fsoff = pepoff + dnext.start; flen = (int)dnext.len;
           j = flen - 1;
           i = flen;                                        // (span rule: no earlier search in this fragment)
           pj = -1;
@@ -2749,10 +2730,10 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       if (bk == BK_LOC_INIT) {
         KJ_PM(PM_LOC_INIT);
         nids = 0; flags = 0;
-        KJ_M_HIT->best = found ? L : 0u;
+        hit->best = found ? L : 0u;
         // lazy SEG (kParamLazySeg, wave-uniform): the fragment that holds the longest matches, or the note that there
         // are several
-        KJ_M_HIT->reserved = ((p.flags & kParamLazySeg) && found) ? (ovf ? kWinForce : ((s0frag + 1u) | (multi ? kWinMulti : 0u))) : 0u;
+        hit->reserved = ((p.flags & kParamLazySeg) && found) ? (ovf ? kWinForce : ((s0frag + 1u) | (multi ? kWinMulti : 0u))) : 0u;
         if (!found) bk = BK_FINISH;
         else if (ovf) {
           // (lazy SEG: the read takes the SEG pass first; the search behind it sends it to the retry pass)
@@ -2768,9 +2749,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           const bool swap = !XORDER && nsi == 2u && s0frag == s1frag;
           // (narrow: row | length << 32; wide: row | length << 40, lengths below 2^24)
           const uint64_t e0 = WIDE ? ((uint64_t)s0lo | (uint64_t)s0len << kLocWideShift) : ((uint64_t)(uint32_t)s0lo | (uint64_t)s0len << 32);
-          const uint64_t e1 = WIDE ? ((uint64_t)s1lo_get() | (uint64_t)s1len << kLocWideShift) : ((uint64_t)(uint32_t)s1lo_get() | (uint64_t)s1len << 32);
-          KJ_M_HIT->taxid[0] = swap ? e1 : e0;
-          if (nsi == 2u) KJ_M_HIT->taxid[1] = swap ? e0 : e1;
+          const uint64_t e1 = WIDE ? ((uint64_t)s1lo | (uint64_t)s1len << kLocWideShift) : ((uint64_t)(uint32_t)s1lo | (uint64_t)s1len << 32);
+          hit->taxid[0] = swap ? e1 : e0;
+          if (nsi == 2u) hit->taxid[1] = swap ? e0 : e1;
           nids = nsi; flags = kHitLocPending;
           bk = BK_FINISH;
         } else {
@@ -2793,9 +2774,9 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
               const uint32_t fr = si_frag(gs);
               uint32_t ge = gs + 1;
               while (ge < nsi && si_frag(ge) == fr) ge++;
-              if (XORDER) KJ_M_HIT->taxid[q++] = WIDE ? ((uint64_t)si_lo(gs) | (uint64_t)si_len(gs) << kLocWideShift) : ((uint64_t)(uint32_t)si_lo(gs) | (uint64_t)si_len(gs) << 32);
+              if (XORDER) hit->taxid[q++] = WIDE ? ((uint64_t)si_lo(gs) | (uint64_t)si_len(gs) << kLocWideShift) : ((uint64_t)(uint32_t)si_lo(gs) | (uint64_t)si_len(gs) << 32);
               for (uint32_t e = ge; e-- > gs + (XORDER ? 1u : 0u);)
-                KJ_M_HIT->taxid[q++] = WIDE ? ((uint64_t)si_lo(e) | (uint64_t)si_len(e) << kLocWideShift) : ((uint64_t)(uint32_t)si_lo(e) | (uint64_t)si_len(e) << 32);
+                hit->taxid[q++] = WIDE ? ((uint64_t)si_lo(e) | (uint64_t)si_len(e) << kLocWideShift) : ((uint64_t)(uint32_t)si_lo(e) | (uint64_t)si_len(e) << 32);
               gs = ge;
             }
             nids = nsi; flags = kHitLocPending;
@@ -2805,7 +2786,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
       }
       if (bk == BK_FINISH) {
         KJ_PM(PM_FINISH);
-        KJ_M_HIT->n_ids = nids; KJ_M_HIT->flags = flags;
+        hit->n_ids = nids; hit->flags = flags;
         if constexpr (COUNT) oc[kOpcHit]++;
         kind = K_IDLE; bk = BK_NONE;
       }
@@ -2822,7 +2803,6 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
 #endif
 }
 
-#undef KJ_M_HIT
 constexpr uint32_t kLocMaxEntries = 24;      // matches a hit record can hold for the locate kernels (MEM: 16 = the lane's match buffer; Greedy: max_matches_SI = 20; record: 21 slots)
 // The ids of a read whose longest matches mem_lane2 left in its hit record (kHitLocPending): ids_from_SI for every match in
 // turn (ConsumerThread.cpp:799-845; get_suffix bwt.c:105-121, FMindexCurrent compactfmi.c:312-336) - the same steps as

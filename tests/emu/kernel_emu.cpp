@@ -240,14 +240,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1", "wide" or default (v2 where possible)
       const bool xo = (p.flags & kParamXOrder) != 0;
-      // (KAIJU_EMU_LDS_STATE: the narrow lane with its rarely touched state in the LDS row, mem_lane2<.., LDSST>)
-      uint32_t st_row[kMemStWords];
-      for (auto &x : st_row) x = 0xdeadbeefu;
-      ls.st = st_row;
-      const bool ldsst = getenv("KAIJU_EMU_LDS_STATE") != nullptr;
       auto lane_v2 = [&](const Params &pp, const WorkList &w2) {
-        if (d.kmer32 && ldsst && !xo) mem_lane2<false, false, false, true>(d, pp, b, w2, ls);
-        else
         if (d.kmer32) { if (xo) mem_lane2<false, true>(d, pp, b, w2, ls); else mem_lane2<false>(d, pp, b, w2, ls); }
         else { if (xo) mem_lane2<true, true>(d, pp, b, w2, ls); else mem_lane2<true>(d, pp, b, w2, ls); }
       };
