@@ -246,7 +246,7 @@ void PackedIndex::build_names(const HostIndexView &v, std::vector<std::string> *
       uint64_t id = 0;
       // bit 0: usable taxon id; bit 1: the name has an accession part in front of the last '_' (verbose column 6)
       seq_valid[i] = parse_taxid(nm, id) ? (uint8_t)(strrchr(nm, '_') ? 3 : 1) : 0;
-      seq_taxid[i] = id;
+      seq_taxid[i] = seq_valid[i] ? id : ~0ull;               // (~0: no id - what the locate walks test, one table instead of two)
     }
   });
 }
@@ -476,7 +476,7 @@ void PackedIndex::to_sequence_ids() {
 
 // ---- device image file: header, then every array as (u64 element count, raw elements) ----
 namespace {
-const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '5'};
+const char kImageMagic[8] = {'K', 'J', 'G', 'P', 'U', 'I', 'M', '6'};   // (6: seq_taxid holds ~0 for names without an id)
 struct ImgHeader {
   char magic[8];
   uint64_t sizes[8];          // [0] size in bytes of the .fmi the image was made from, [1..3] sizeof RankBlock64, uint2, ulonglong2

@@ -68,7 +68,8 @@ struct DevIndex {
   uint32_t mb_shift;         //   2^mb_shift rows; nullptr / 0 when the counts in blocks64 are absolute
   const uint64_t *sa_taxid;  // taxon id of every sampled SA row (~0 = unusable name), for the MEM kernel
   const uint32_t *sa_iseq;   // sequence number of every sampled SA row (rows >= nseq)
-  const uint64_t *seq_taxid; // taxon id per sequence (rule of ConsumerThread.cpp:809-833)
+  const uint64_t *seq_taxid; // taxon id per sequence (rule of ConsumerThread.cpp:809-833); ~0 where the name gives none (seq_valid 0):
+                             // the locate walks read ONE table per row (round 5; strtoul's ULONG_MAX is the reference's "no id")
   const uint8_t *seq_valid;  // 0 where strtoul gave ULONG_MAX
   const uint64_t *term_pos;  // sorted BWT positions holding the terminator (letter 0)
   uint64_t C[22];            // C[c] = first SA row of suffixes starting with letter c; C[21] = bwtlen
@@ -2906,7 +2907,7 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
           const uint64_t sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
           if (sa_idx < ix.n_sa) {
             uint64_t tax;
-            if constexpr (WIDE) { const uint32_t iseq = ix.sa_iseq[sa_idx]; tax = (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull; }
+            if constexpr (WIDE) { const uint32_t iseq = ix.sa_iseq[sa_idx]; tax = iseq < ix.nseq ? ix.seq_taxid[iseq] : ~0ull; }
             else tax = ix.sa_taxid[sa_idx];
             if (tax != ~0ull) add_tax(tax);
           }
@@ -2920,7 +2921,7 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
         if (c == 0) {
           // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
           const uint32_t iseq = (uint32_t)rank_term(ix, k);
-          if (iseq < ix.nseq && ix.seq_valid[iseq]) add_tax(ix.seq_taxid[iseq]);
+          if (iseq < ix.nseq) { const uint64_t tax = ix.seq_taxid[iseq]; if (tax != ~0ull) add_tax(tax); }
           break;
         }
         const uint64_t ia = (c & 1u) ? 0ull : ~0ull, ib = (c & 2u) ? 0ull : ~0ull, ic = (c & 4u) ? 0ull : ~0ull,
@@ -3020,7 +3021,7 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
       if ((k & check) == 0) {
         const uint64_t sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
         if (sa_idx >= ix.n_sa) return ~0ull;
-        if constexpr (WIDE) { const uint32_t iseq = ix.sa_iseq[sa_idx]; return (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull; }
+        if constexpr (WIDE) { const uint32_t iseq = ix.sa_iseq[sa_idx]; return iseq < ix.nseq ? ix.seq_taxid[iseq] : ~0ull; }
         else return ix.sa_taxid[sa_idx];
       }
       const RankBlock64 &rb = blk0[k >> 6];
@@ -3031,7 +3032,7 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
       if (c == 0) {
         // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
         const uint32_t iseq = (uint32_t)rank_term(ix, k);
-        return (iseq < ix.nseq && ix.seq_valid[iseq]) ? ix.seq_taxid[iseq] : ~0ull;
+        return iseq < ix.nseq ? ix.seq_taxid[iseq] : ~0ull;
       }
       const uint64_t ia = (c & 1u) ? 0ull : ~0ull, ib = (c & 2u) ? 0ull : ~0ull, ic = (c & 4u) ? 0ull : ~0ull,
                      id = (c & 8u) ? 0ull : ~0ull, ie = (c & 16u) ? 0ull : ~0ull;
