@@ -266,6 +266,8 @@ def image_is_fresh(img, fmi):
 # one leg = one workload timed like the headline
 # ----------------------------------------------------------------------------------------------
 class Leg:
+    comm = None          # --gather lib: this rank's kaiju_gpu_comm (the library's own RCCL gather instead of torch.distributed's)
+
     def __init__(self, name, mode, paired, reads, Lm, index, dtax, dev, rank, world, seg, chunk, nctx, protein=False):
         import torch
         self.torch = torch
@@ -315,7 +317,7 @@ class Leg:
         streams" of SURVEY.md 8b): while one chunk is in its search kernel the next one runs stage 1 and the SEG pass."""
         torch = self.torch
         nctx = nctx or self.nctx
-        g = kdist.HitGatherer(self.world, self.rank, keep_results=False)
+        g = kdist.LibGatherer(Leg.comm) if Leg.comm is not None else kdist.HitGatherer(self.world, self.rank, keep_results=False)
         pending = [None] * nctx
         main = torch.cuda.current_stream(self.dev)
         for s in self.streams:
@@ -567,6 +569,10 @@ def main():
                     help="skip the op counts of the reference's algorithm (roofline.work_rate): the instrumented oracle reads the "
                          ".fmi once more, a minute for a refseq-class index")
     ap.add_argument("--prepare-only", action="store_true", help="build the database, the .fmi (and the image with --image) and exit; no GPU needed")
+    ap.add_argument("--gather", default=os.environ.get("KAIJU_BENCH_GATHER", "torch"), choices=["torch", "lib"],
+                    help="who gathers the 16-byte records on rank 0: torch.distributed (backend nccl = RCCL; the default, what the "
+                         "driver's launcher sets up) or the library's own collective (kaiju_gpu_comm_create / "
+                         "kaiju_gpu_gather_compact: librccl opened by libkaiju_gpu.so, one ncclGather per chunk, no torch in the data path)")
     ap.add_argument("--parity-sample", type=int, default=200_000,
                     help="N > 1: reads (pairs) of EVERY rank whose gathered records rank 0 compares with the reference binary")
     args = ap.parse_args()
@@ -669,6 +675,9 @@ def main():
                              "BWT, the samples or the packed arrays")
     log(rank, f"index in HBM: {index.footprint.total/1e9:.2f} GB, loaded in {load_info['seconds']:.1f}s ({load_info['path'].split(':')[0]})")
     dtax = api.DeviceTaxonomy(api.Taxonomy(nodes), local_rank)
+    if args.gather == "lib" and (world > 1 or os.environ.get("KAIJU_DIST_FORCE_INIT") == "1"):
+        Leg.comm = kdist.make_comm(W, rank, world, local_rank)
+        log(rank, f"gather through the library's RCCL communicator ({world} rank(s))")
     n = args.reads
     Lm = 150
     if args.strong:
@@ -894,6 +903,8 @@ def main():
                    "ranks": world, "per_rank_units_per_s": per_rank,
                    "process_group": ({"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size()}
                                      if torch.distributed.is_initialized() else None),
+                   "gather_by": ("library: kaiju_gpu_gather_compact (librccl, ncclGather)" if Leg.comm is not None else
+                                 "torch.distributed.gather (backend nccl = RCCL)" if torch.distributed.is_initialized() else None),
                    "gather": (f"one async RCCL gather of 16-B records (device LCA of the 184-B hit records) per chunk to rank 0; "
                               f"{head.gathered_timed / max(args.steps, 1):.0f} B into rank 0 per step"
                               if world > 1 else "none (1 GPU); device LCA to 16-B records still runs"),

@@ -299,6 +299,26 @@ int kaiju_gpu_lca_batch(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const k
 int kaiju_finalize_compact(const kaiju_gpu_params *p, double db_length, const kaiju_gpu_compact *recs,
                            const uint64_t *off, uint32_t n_reads, int paired, kaiju_result *out);
 
+/* ---- several processes of a node, one per GPU: the gather --------------- */
+/* BASELINE north star: "reads shard embarrassingly across the GPUs of one node with the index replicated per GPU and per-GPU
+   hit lists gathered with a single RCCL gather over xGMI".  The reference has no exchange (its threads append to one output
+   stream under a mutex, ConsumerThread.cpp:847-856; the thread fan-out is kaiju.cpp:250-257); here every rank classifies its
+   shard, the device LCA turns the hits into 16-byte records and ONE collective per batch brings them to the rank that
+   writes the output.  kaiju_gpu_comm_create: rank 0 makes the communicator's id and leaves it in `rendezvous_path` (any path
+   all ranks see, e.g. under /dev/shm; the others wait for it up to two minutes).  librccl is opened on the first call
+   (dlopen): nothing links it, a single-GPU run never loads it.
+   kaiju_gpu_gather_compact: n records of EVERY rank (the same n everywhere) into d_recv on `root`, rank r's at d_recv + r * n;
+   d_recv is ignored elsewhere.  Asynchronous on `stream` (a hipStream_t; kaiju_gpu_get_stream() of the context that wrote
+   d_send orders it behind the batch).  Without a HIP device: KAIJU_GPU_ERR_NO_DEVICE. */
+typedef struct kaiju_gpu_comm kaiju_gpu_comm;
+int kaiju_gpu_comm_create(const char *rendezvous_path, int rank, int world, int device_id, kaiju_gpu_comm **out);
+void kaiju_gpu_comm_destroy(kaiju_gpu_comm *comm);
+int kaiju_gpu_comm_rank(const kaiju_gpu_comm *comm);
+int kaiju_gpu_comm_world(const kaiju_gpu_comm *comm);
+int kaiju_gpu_gather_compact(kaiju_gpu_comm *comm, const kaiju_gpu_compact *d_send, uint32_t n, kaiju_gpu_compact *d_recv,
+                             int root, void *stream);
+const char *kaiju_gpu_comm_last_error(void);
+
 int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p, double db_length,
                         const kaiju_gpu_hit *hits, const uint64_t *off, uint32_t n_reads,
                         int paired, kaiju_result *out);

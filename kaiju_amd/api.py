@@ -178,6 +178,40 @@ class Index:
             pass
 
 
+class Comm:
+    """The processes of a node, one per GPU (kaiju_gpu_comm_create): rank 0 leaves the communicator's id in `rendezvous_path`.
+    gather_compact() = ONE RCCL gather of 16-byte records to `root` (kaiju_gpu_gather_compact), asynchronous on `stream`."""
+
+    def __init__(self, rendezvous_path: str, rank: int, world: int, device: int = 0):
+        L = lib()
+        L.kaiju_gpu_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.kaiju_gpu_comm_destroy.argtypes = [C.c_void_p]
+        L.kaiju_gpu_gather_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+        L.kaiju_gpu_comm_last_error.restype = C.c_char_p
+        self._h = C.c_void_p()
+        rc = L.kaiju_gpu_comm_create(rendezvous_path.encode(), rank, world, device, C.byref(self._h))
+        if rc != 0:
+            raise KaijuGpuError(f"{L.kaiju_gpu_strerror(rc).decode()} ({rc}): {L.kaiju_gpu_comm_last_error().decode()}")
+        self.rank, self.world = rank, world
+
+    def gather_compact(self, d_send_ptr: int, n: int, d_recv_ptr: int, root: int = 0, stream: int = 0):
+        L = lib()
+        rc = L.kaiju_gpu_gather_compact(self._h, d_send_ptr, n, d_recv_ptr, root, stream)
+        if rc != 0:
+            raise KaijuGpuError(f"{L.kaiju_gpu_strerror(rc).decode()} ({rc}): {L.kaiju_gpu_comm_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            lib().kaiju_gpu_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def write_index_image(fmi_path: str, image_path: str):
     """pack a .fmi once into the HBM layout and write it as a device image (loads with Index(image_path))"""
     L = lib()

@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkaiju_gpu.so")
-SOURCES = ["capi.hip", "fmi_stream.hip", "exact_pass.hip", "host_index.cpp", "host_tables.cpp", "taxonomy.cpp", "mkfmi.cpp"]
+SOURCES = ["capi.hip", "fmi_stream.hip", "exact_pass.hip", "host_index.cpp", "host_tables.cpp", "taxonomy.cpp", "mkfmi.cpp", "rccl_gather.cpp"]
 HEADERS = ["kj_core.h", "fmi_stream.h", "exact_pass.h", "host_index.h", "host_tables.h", os.path.join("..", "..", "include", "kaiju_gpu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-gpu-rdc", "-Wno-unused-result"]
@@ -34,7 +34,7 @@ def needs_build():
 
 def build(force=False, verbose=False):
     if force or needs_build():
-        cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
+        cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

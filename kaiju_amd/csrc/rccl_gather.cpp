@@ -1,0 +1,155 @@
+// rccl_gather.cpp — the one collective of the path, in the product: per-GPU 16-byte records gathered on one rank with a single
+// RCCL gather over xGMI (BASELINE north star; the reference has no exchange at all: its threads write to one stream under a
+// mutex, ConsumerThread.cpp:847-856, kaiju.cpp:250-257).  One process per GPU; the processes of a node find each other through
+// a file (rank 0 leaves the communicator's id there).  librccl is opened at the first use (dlopen): the library and the
+// command line programs do not link it, a single-GPU run never loads it.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/kaiju_gpu.h"
+
+namespace {
+
+// the part of rccl.h this file needs (the header itself pulls in HIP device headers)
+constexpr int kUniqueIdBytes = 128;                 // NCCL_UNIQUE_ID_BYTES
+struct UniqueId { char internal[kUniqueIdBytes]; };
+typedef void *Comm;
+constexpr int kNcclSuccess = 0, kNcclUint8 = 1;
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(UniqueId *) = nullptr;
+  int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*Gather)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;      // RCCL's own (rccl.h: ncclGather)
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    auto sym = [&](const char *n) { return dlsym(lib, n); };
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+    Gather = reinterpret_cast<decltype(Gather)>(sym("ncclGather"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+    Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || (!Gather && !(GroupStart && GroupEnd && Send && Recv))) {
+      err = "librccl lacks the entry points of a gather"; dlclose(lib); lib = nullptr; return false;
+    }
+    return true;
+  }
+};
+Rccl g_rccl;
+std::mutex g_mu;
+
+thread_local std::string tl_err;
+int fail(int code, const std::string &m) { tl_err = m; return code; }
+double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+}  // namespace
+
+struct kaiju_gpu_comm {
+  Comm comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+};
+
+extern "C" const char *kaiju_gpu_comm_last_error(void) { return tl_err.c_str(); }
+
+extern "C" int kaiju_gpu_comm_create(const char *rendezvous_path, int rank, int world, int device_id, kaiju_gpu_comm **out) {
+  if (!out) return fail(KAIJU_GPU_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!rendezvous_path || world < 1 || rank < 0 || rank >= world) return fail(KAIJU_GPU_ERR_ARG, "bad rank / world / rendezvous path");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(KAIJU_GPU_ERR_NO_DEVICE, "hipGetDeviceCount found no device");
+  if (device_id < 0 || device_id >= ndev) return fail(KAIJU_GPU_ERR_ARG, "device_id out of range");
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_rccl.load()) return fail(KAIJU_GPU_ERR_UNSUPPORTED, g_rccl.err);
+  }
+  if (hipSetDevice(device_id) != hipSuccess) return fail(KAIJU_GPU_ERR_HIP, "hipSetDevice");
+  // the communicator's id: made by rank 0, left in the file (written next to it, then renamed: a reader never sees half of it)
+  UniqueId id;
+  memset(&id, 0, sizeof id);
+  if (rank == 0) {
+    const int rc = g_rccl.GetUniqueId(&id);
+    if (rc != kNcclSuccess) return fail(KAIJU_GPU_ERR_HIP, std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+    const std::string tmp = std::string(rendezvous_path) + ".tmp";
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    const bool ok = fp && fwrite(&id, sizeof id, 1, fp) == 1;
+    if (fp) fclose(fp);
+    if (!ok || rename(tmp.c_str(), rendezvous_path) != 0) return fail(KAIJU_GPU_ERR_IO, std::string("cannot write ") + rendezvous_path);
+  } else {
+    const double t0 = now_s();
+    for (;;) {
+      struct stat st;
+      if (stat(rendezvous_path, &st) == 0 && st.st_size == (off_t)sizeof id) {
+        FILE *fp = fopen(rendezvous_path, "rb");
+        const bool ok = fp && fread(&id, sizeof id, 1, fp) == 1;
+        if (fp) fclose(fp);
+        if (ok) break;
+      }
+      if (now_s() - t0 > 120.0) return fail(KAIJU_GPU_ERR_IO, std::string("no communicator id appeared in ") + rendezvous_path);
+      usleep(2000);
+    }
+  }
+  kaiju_gpu_comm *c = new kaiju_gpu_comm();
+  c->rank = rank; c->world = world; c->device = device_id;
+  const int rc = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (rc != kNcclSuccess) { delete c; return fail(KAIJU_GPU_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?")); }
+  *out = c;
+  return KAIJU_GPU_OK;
+}
+
+extern "C" void kaiju_gpu_comm_destroy(kaiju_gpu_comm *c) {
+  if (!c) return;
+  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  delete c;
+}
+
+extern "C" int kaiju_gpu_comm_rank(const kaiju_gpu_comm *c) { return c ? c->rank : -1; }
+extern "C" int kaiju_gpu_comm_world(const kaiju_gpu_comm *c) { return c ? c->world : 0; }
+
+// n records of 16 bytes from every rank into d_recv of `root` (rank r's at d_recv + r * n); asynchronous on `stream`
+extern "C" int kaiju_gpu_gather_compact(kaiju_gpu_comm *c, const kaiju_gpu_compact *d_send, uint32_t n, kaiju_gpu_compact *d_recv,
+                                        int root, void *stream) {
+  if (!c || !c->comm || root < 0 || root >= c->world || (n && !d_send) || (c->rank == root && n && !d_recv))
+    return fail(KAIJU_GPU_ERR_ARG, "bad argument");
+  if (hipSetDevice(c->device) != hipSuccess) return fail(KAIJU_GPU_ERR_HIP, "hipSetDevice");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t bytes = (size_t)n * sizeof(kaiju_gpu_compact);
+  int rc = kNcclSuccess;
+  if (g_rccl.Gather) rc = g_rccl.Gather(d_send, d_recv, bytes, kNcclUint8, root, c->comm, s);     // ONE collective
+  else {
+    // the same as grouped point-to-point calls (what ncclGather is inside): still one group = one launch
+    rc = g_rccl.GroupStart();
+    if (rc == kNcclSuccess && c->rank == root)
+      for (int r = 0; r < c->world && rc == kNcclSuccess; r++)
+        rc = g_rccl.Recv(reinterpret_cast<uint8_t *>(d_recv) + (size_t)r * bytes, bytes, kNcclUint8, r, c->comm, s);
+    if (rc == kNcclSuccess) rc = g_rccl.Send(d_send, bytes, kNcclUint8, root, c->comm, s);
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc == kNcclSuccess) rc = rc2;
+  }
+  if (rc != kNcclSuccess) return fail(KAIJU_GPU_ERR_HIP, std::string("RCCL gather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+  return KAIJU_GPU_OK;
+}

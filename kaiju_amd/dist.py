@@ -80,6 +80,56 @@ class HitGatherer:
             self._retire(self.pending.pop(0))
 
 
+class LibGatherer:
+    """The same through the LIBRARY's collective (kaiju_gpu_comm_create / kaiju_gpu_gather_compact: librccl opened by the
+    library itself, no torch in the data path): one RCCL gather of 16-byte records per chunk to rank 0, asynchronous on the
+    stream the chunk's kernels run on.  ``comm``: api.Comm of this rank (make_comm below)."""
+
+    def __init__(self, comm, keep_results: bool = False):
+        self.comm, self.world, self.rank = comm, comm.world, comm.rank
+        self.keep = keep_results
+        self.results = []
+        self.bytes_gathered = 0
+        self._recv = {}
+
+    def gather(self, chunk):
+        import torch
+        n = chunk.numel() * chunk.element_size() // 16
+        recv_ptr = 0
+        if self.rank == 0:
+            key = (chunk.numel(), len(self.results) if self.keep else 0)
+            if key not in self._recv:
+                self._recv[key] = torch.empty(chunk.numel() * self.world, dtype=chunk.dtype, device=chunk.device)
+            recv_ptr = self._recv[key].data_ptr()
+            if self.keep:
+                self.results.append(self._recv[key])
+        self.comm.gather_compact(chunk.data_ptr(), n, recv_ptr, 0, torch.cuda.current_stream(chunk.device).cuda_stream)
+        self.bytes_gathered += chunk.numel() * chunk.element_size() * (self.world - 1)
+
+    def wait(self):
+        pass                      # (stream-ordered: the caller synchronises the streams it launched on)
+
+
+def make_comm(work_dir: str, rank: int, world: int, device: int):
+    """api.Comm of this rank; the rendezvous file gets a name no earlier job has used (rank 0 picks it, torch.distributed -
+    when it is up - tells the others; a single rank needs nobody)"""
+    import time
+    import torch.distributed as dist
+    from . import api
+    name = [f"{work_dir}/kaiju_comm_{os.getpid()}_{time.time_ns()}.id"]
+    if dist.is_initialized():
+        dist.broadcast_object_list(name, src=0)
+    comm = api.Comm(name[0], rank, world, device)
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
+        try:
+            os.remove(name[0])
+        except OSError:
+            pass
+    return comm
+
+
 def gather_to_root(t, world: int, rank: int):
     """one tensor of every rank on rank 0 (a list in rank order; None elsewhere) - the parity samples of an N-rank bench
     line, not the data path"""

@@ -226,3 +226,22 @@ def test_streamed_pack_of_a_fmi_equals_the_host_pack(golden, tmp_path, monkeypat
                 monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", wide)
             for piece in (16384, 49152, 1 << 20, 1 << 26):
                 assert emu.lib.emu_stream_pack_check(fmi.encode(), piece) == 0, (fmi, wide, piece)
+
+
+def test_the_gather_entry_points_without_a_device(tmp_path):
+    """kaiju_gpu_comm_create (the product-side RCCL gather): bad arguments and a missing device give a status, nothing is
+    loaded or written (librccl is only opened once a device is there)"""
+    L = api.lib()
+    L.kaiju_gpu_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.kaiju_gpu_comm_last_error.restype = C.c_char_p
+    L.kaiju_gpu_gather_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+    h = C.c_void_p()
+    path = str(tmp_path / "comm.id").encode()
+    assert L.kaiju_gpu_comm_create(path, 3, 2, 0, C.byref(h)) == -1 and not h.value        # KAIJU_GPU_ERR_ARG
+    assert L.kaiju_gpu_comm_create(None, 0, 1, 0, C.byref(h)) == -1
+    if api.device_count() == 0:
+        assert L.kaiju_gpu_comm_create(path, 0, 1, 0, C.byref(h)) == -4                    # KAIJU_GPU_ERR_NO_DEVICE
+        assert not os.path.exists(path.decode())
+    assert L.kaiju_gpu_gather_compact(None, None, 0, None, 0, None) == -1
+    L.kaiju_gpu_comm_destroy.argtypes = [C.c_void_p]
+    L.kaiju_gpu_comm_destroy(None)

@@ -30,3 +30,52 @@ def test_single_rank_through_rccl(gpu_lib, tmp_path):
     pg = line["config"]["process_group"]
     assert pg == {"backend": "nccl", "world_size": 1}, pg
     assert abs(line["config"]["per_rank_units_per_s"][0] - line["value"]) < 0.02 * line["value"]
+
+
+def test_the_librarys_own_gather(gpu_lib, golden, tmp_path):
+    """kaiju_gpu_comm_create / kaiju_gpu_gather_compact: the collective of the path in the PRODUCT (librccl opened by
+    libkaiju_gpu.so itself, ncclGather of 16-byte records to the root) - a communicator of one rank on this box's GPU: the
+    records a batch left on the device arrive unchanged, stream-ordered behind the kernels that wrote them."""
+    import numpy as np
+    import torch
+    api = gpu_lib
+    idx = api.Index(golden.fmi)
+    tax = api.Taxonomy(golden.nodes)
+    dtax = api.DeviceTaxonomy(tax, 0)
+    clf = api.Classifier(idx, api.default_params("mem"))
+    want = clf.classify_compact(dtax, golden.seqs, golden.off)
+    n = len(want)
+    comm = api.Comm(str(tmp_path / "comm.id"), 0, 1, 0)
+    dev = torch.device("cuda", 0)
+    d_seqs = torch.from_numpy(np.ascontiguousarray(golden.seqs)).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(golden.off).view(np.int64)).to(dev)
+    d_hits = torch.zeros(n * 184, dtype=torch.uint8, device=dev)
+    d_rec = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_all = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    clf.set_max_read_length(int((golden.off[1::2] - golden.off[0:-1:2]).max()))
+    stream = clf.stream_handle()
+    clf.classify_device(d_seqs.data_ptr(), d_seqs.numel(), d_off.data_ptr(), n, d_hits.data_ptr(), stream=0)
+    clf.lca_device(dtax, d_hits.data_ptr(), n, d_rec.data_ptr(), stream=0)
+    comm.gather_compact(d_rec.data_ptr(), n, d_all.data_ptr(), root=0, stream=stream)
+    clf.synchronize()
+    got = np.frombuffer(d_all.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
+    assert (got == want).all()
+    assert (got["lca"] != 0).mean() > 0.3
+    comm.close()
+    with pytest.raises(api.KaijuGpuError):
+        api.Comm(str(tmp_path / "comm2.id"), 1, 1, 0)               # rank outside the world
+
+
+def test_single_rank_bench_with_the_librarys_gather(gpu_lib, tmp_path):
+    """bench.py --gather lib: the N-rank harness with the library's collective in place of torch.distributed.gather"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, KAIJU_DIST_FORCE_INIT="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), KAIJU_BENCH_WORK=str(tmp_path / "work"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--reads", "200000",
+                        "--nseq", "20001", "--legs", "", "--no-cpu-baseline", "--gather", "lib"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["config"]["gather_by"].startswith("library"), line["config"]["gather_by"]
+    assert line["value"] > 0
