@@ -318,6 +318,9 @@ int kaiju_gpu_comm_world(const kaiju_gpu_comm *comm);
 int kaiju_gpu_gather_compact(kaiju_gpu_comm *comm, const kaiju_gpu_compact *d_send, uint32_t n, kaiju_gpu_compact *d_recv,
                              int root, void *stream);
 const char *kaiju_gpu_comm_last_error(void);
+/* the librccl the gather runs on ("" before the first communicator): the one that lies next to the HIP runtime this process
+   uses - a Python host may hold two ROCm stacks, the system's and the one bundled with torch */
+const char *kaiju_gpu_comm_library(void);
 
 int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p, double db_length,
                         const kaiju_gpu_hit *hits, const uint64_t *off, uint32_t n_reads,

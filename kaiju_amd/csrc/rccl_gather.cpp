@@ -36,12 +36,28 @@ struct Rccl {
   int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
-  std::string err;
+  std::string err, path;
   bool load() {
     if (lib) return true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
+    // The RCCL that belongs to the HIP runtime THIS process runs on: a process may hold two ROCm stacks (a Python host: the
+    // system's under /opt/rocm and the one bundled with torch), whichever libamdhip64 was loaded first serves everybody - and
+    // an RCCL of the other stack would bring up a second HSA runtime that finds no device ("no ROCm-capable device is
+    // detected" from ncclCommInitRank).  So: first the librccl that lies next to the libamdhip64 in use, then the usual names.
+    std::string beside;
+    {
+      Dl_info info;
+      if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        beside = info.dli_fname;
+        const size_t slash = beside.rfind('/');
+        beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1);
+      }
+    }
+    const std::string cands[] = {beside.empty() ? std::string() : beside + "librccl.so.1", beside.empty() ? std::string() : beside + "librccl.so",
+                                 "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const std::string &name : cands) {
+      if (name.empty()) continue;
+      lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (lib) { path = name; break; }
     }
     if (!lib) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
     auto sym = [&](const char *n) { return dlsym(lib, n); };
@@ -88,6 +104,10 @@ extern "C" int kaiju_gpu_comm_create(const char *rendezvous_path, int rank, int 
     if (!g_rccl.load()) return fail(KAIJU_GPU_ERR_UNSUPPORTED, g_rccl.err);
   }
   if (hipSetDevice(device_id) != hipSuccess) return fail(KAIJU_GPU_ERR_HIP, "hipSetDevice");
+  // (RCCL tests hipGetLastError() behind its own launches: an error code left behind by an earlier call of this process - a
+  //  probing hipMalloc that was allowed to fail, an event query that said "not ready" - must not become its "unhandled error")
+  (void)hipDeviceSynchronize();
+  (void)hipGetLastError();
   // the communicator's id: made by rank 0, left in the file (written next to it, then renamed: a reader never sees half of it)
   UniqueId id;
   memset(&id, 0, sizeof id);
@@ -127,6 +147,8 @@ extern "C" void kaiju_gpu_comm_destroy(kaiju_gpu_comm *c) {
   delete c;
 }
 
+/* which librccl the gather runs on (diagnostics; "" before the first communicator) */
+extern "C" const char *kaiju_gpu_comm_library(void) { return g_rccl.path.c_str(); }
 extern "C" int kaiju_gpu_comm_rank(const kaiju_gpu_comm *c) { return c ? c->rank : -1; }
 extern "C" int kaiju_gpu_comm_world(const kaiju_gpu_comm *c) { return c ? c->world : 0; }
 
@@ -137,6 +159,7 @@ extern "C" int kaiju_gpu_gather_compact(kaiju_gpu_comm *c, const kaiju_gpu_compa
     return fail(KAIJU_GPU_ERR_ARG, "bad argument");
   if (hipSetDevice(c->device) != hipSuccess) return fail(KAIJU_GPU_ERR_HIP, "hipSetDevice");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  (void)hipGetLastError();
   const size_t bytes = (size_t)n * sizeof(kaiju_gpu_compact);
   int rc = kNcclSuccess;
   if (g_rccl.Gather) rc = g_rccl.Gather(d_send, d_recv, bytes, kNcclUint8, root, c->comm, s);     // ONE collective

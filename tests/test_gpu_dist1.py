@@ -35,10 +35,15 @@ def test_single_rank_through_rccl(gpu_lib, tmp_path):
 def test_the_librarys_own_gather(gpu_lib, golden, tmp_path):
     """kaiju_gpu_comm_create / kaiju_gpu_gather_compact: the collective of the path in the PRODUCT (librccl opened by
     libkaiju_gpu.so itself, ncclGather of 16-byte records to the root) - a communicator of one rank on this box's GPU: the
-    records a batch left on the device arrive unchanged, stream-ordered behind the kernels that wrote them."""
+    records a batch left on the device arrive unchanged, stream-ordered behind the kernels that wrote them.
+    (Device buffers through ctypes on the HIP runtime the library is linked against, as in test_gpu_parity: torch in THIS
+    process would bring a second ROCm stack along, whose runtime finds no device; bench.py --gather lib, below, is the
+    torch-first order - there the library picks the librccl that lies next to torch's HIP runtime.)"""
+    import ctypes as C
     import numpy as np
-    import torch
+    from test_gpu_parity import Hip
     api = gpu_lib
+    hip = Hip()
     idx = api.Index(golden.fmi)
     tax = api.Taxonomy(golden.nodes)
     dtax = api.DeviceTaxonomy(tax, 0)
@@ -46,24 +51,29 @@ def test_the_librarys_own_gather(gpu_lib, golden, tmp_path):
     want = clf.classify_compact(dtax, golden.seqs, golden.off)
     n = len(want)
     comm = api.Comm(str(tmp_path / "comm.id"), 0, 1, 0)
-    dev = torch.device("cuda", 0)
-    d_seqs = torch.from_numpy(np.ascontiguousarray(golden.seqs)).to(dev)
-    d_off = torch.from_numpy(np.ascontiguousarray(golden.off).view(np.int64)).to(dev)
-    d_hits = torch.zeros(n * 184, dtype=torch.uint8, device=dev)
-    d_rec = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-    d_all = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-    clf.set_max_read_length(int((golden.off[1::2] - golden.off[0:-1:2]).max()))
+    api.lib().kaiju_gpu_comm_library.restype = C.c_char_p
+    assert b"rccl" in api.lib().kaiju_gpu_comm_library()
+    seqs = np.ascontiguousarray(golden.seqs, dtype=np.uint8)
+    off = np.ascontiguousarray(golden.off, dtype=np.uint64)
+    d_seqs, d_off = hip.malloc(seqs.nbytes + 64), hip.malloc(off.nbytes)
+    d_hits, d_rec, d_all = hip.malloc(n * 184), hip.malloc(n * 16), hip.malloc(n * 16)
+    hip.h2d(d_seqs, seqs)
+    hip.h2d(d_off, off)
+    hip.memset(d_all, n * 16)
+    clf.set_max_read_length(int((off[1:] - off[:-1]).max()))
     stream = clf.stream_handle()
-    clf.classify_device(d_seqs.data_ptr(), d_seqs.numel(), d_off.data_ptr(), n, d_hits.data_ptr(), stream=0)
-    clf.lca_device(dtax, d_hits.data_ptr(), n, d_rec.data_ptr(), stream=0)
-    comm.gather_compact(d_rec.data_ptr(), n, d_all.data_ptr(), root=0, stream=stream)
+    clf.classify_device(d_seqs, seqs.nbytes, d_off, n, d_hits, stream=0)
+    clf.lca_device(dtax, d_hits, n, d_rec, stream=0)
+    comm.gather_compact(d_rec, n, d_all, root=0, stream=stream)
     clf.synchronize()
-    got = np.frombuffer(d_all.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
+    got = np.frombuffer(hip.d2h(d_all, n * 16).tobytes(), dtype=api.COMPACT_DTYPE)
     assert (got == want).all()
     assert (got["lca"] != 0).mean() > 0.3
     comm.close()
     with pytest.raises(api.KaijuGpuError):
         api.Comm(str(tmp_path / "comm2.id"), 1, 1, 0)               # rank outside the world
+    for p in (d_seqs, d_off, d_hits, d_rec, d_all):
+        hip.free(p)
 
 
 def test_single_rank_bench_with_the_librarys_gather(gpu_lib, tmp_path):
