@@ -10,14 +10,14 @@
 # measured gate1 / gate3 / roll / locp / gdefer / g_occ3 this way (profiles/r03_variants/): the winners are the default code now
 R=$(cd "$(dirname "$0")/../.." && pwd)
 V=$R/kaiju_amd/variants
-SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/fmi_stream.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp"
+SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/fmi_stream.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp $R/kaiju_amd/csrc/rccl_gather.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-gpu-rdc -Wno-unused-result -w"
 declare -A DEF=( [cur]="" [prof]="-DKJ_PROF" [stats]="-DKJ_STATS" [ovf]="-DKJ_OVF_STATS" [norule]="-DKJ_NO_SPAN_RULE -DKJ_NO_PROBE" [noprobe]="-DKJ_NO_PROBE" [nospaneq]="-DKJ_NO_SPAN_EQ" [w5]="-DKJ_MEM_WAVES=5" [w6]="-DKJ_MEM_WAVES=6" )
 LIST=${VARIANTS:-cur prof}
 if [ "$1" = build ]; then
   mkdir -p $V
   for v in $LIST; do
-    /opt/rocm/bin/hipcc $FLAGS ${DEF[$v]} -o $V/libkaiju_gpu_$v.so $SRC -lpthread && echo "built $v" || echo "$v: build failed"
+    /opt/rocm/bin/hipcc $FLAGS ${DEF[$v]} -o $V/libkaiju_gpu_$v.so $SRC -lpthread -ldl && echo "built $v" || echo "$v: build failed"
   done
   exit 0
 fi
