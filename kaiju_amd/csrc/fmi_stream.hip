@@ -384,7 +384,8 @@ int fmi_stream_to_device(const FmiStreamSource &src, const PackedIndex &pk, cons
   } catch (const HipFail &f) {
     (void)hipGetLastError();
     msg = f.what;
-    return f.what.compare(0, 11, "cannot open") == 0 || f.what.compare(0, 10, "short read") == 0 ? KAIJU_GPU_ERR_IO : KAIJU_GPU_ERR_HIP;
+    if (f.what.compare(0, 11, "cannot open") == 0 || f.what.compare(0, 10, "short read") == 0) return KAIJU_GPU_ERR_IO;
+    return f.what.find("out of memory") != std::string::npos ? KAIJU_GPU_ERR_NOMEM : KAIJU_GPU_ERR_HIP;
   }
 }
 
