@@ -300,7 +300,7 @@ class Leg:
             self.streams = [torch.cuda.ExternalStream(self.clfs[0].stream_handle(), device=dev)] + [torch.cuda.Stream(dev) for _ in range(self.nctx - 1)]
         else:
             self.streams = [torch.cuda.ExternalStream(c.stream_handle(), device=dev) for c in self.clfs]
-        self.kern_ms, self.stage_ms, self.retries, self.gathered = [], {"translate": 0.0, "seg": 0.0, "search": 0.0, "retry": 0.0}, 0, 0
+        self.kern_ms, self.stage_ms, self.retries, self.gathered = [], {"translate": 0.0, "seg": 0.0, "search": 0.0, "post_search": 0.0}, 0, 0
 
     def _collect(self, c, m, record):
         st = c.stats()                  # HIP events of that context's last chunk (blocks until its kernels are done)
@@ -308,7 +308,7 @@ class Leg:
             raise SystemExit(f"device-side capacity error flags {st.error_flags}")
         if record:
             self.kern_ms.append((st.ms_search, m))
-            for k, v in (("translate", st.ms_translate), ("seg", st.ms_seg), ("search", st.ms_search), ("retry", st.ms_retry)):
+            for k, v in (("translate", st.ms_translate), ("seg", st.ms_seg), ("search", st.ms_search), ("post_search", st.ms_retry)):
                 self.stage_ms[k] += v
             self.retries += st.n_overflow_retries
 
@@ -511,6 +511,94 @@ def load_traffic(mode, paired, seg, nseq, per_launch):
 _TRAFFIC_NOTES = {}          # what the matching record of profiles/traffic.json says about when it was collected
 
 
+LINE_LIMIT = 4096            # the driver extracts the LAST stdout line; round 5's 28 KB line was not parsed
+
+
+def _finite(x):
+    """JSON has no Infinity / NaN: such a figure becomes null (json.dumps(.., allow_nan=False) then never raises)"""
+    if isinstance(x, float):
+        return x if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, np.generic):
+        return _finite(x.item())
+    return x
+
+
+def _sig(x, digits=5):
+    if isinstance(x, float) and math.isfinite(x) and x != 0.0:
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+LEG_NAMES = ("greedy", "paired", "hard", "hard_greedy", "wide", "wide_greedy", "long", "protein", "host_buffers")
+
+
+def summary_line(result: dict, detail_path) -> str:
+    """The ONE line the driver parses: the contract's keys, the roofline of the dominant kernel, the CPU baseline, the parity
+    totals and one figure per further leg - at most LINE_LIMIT bytes.  Everything else (op counts, stage tables, per-leg
+    rooflines and baselines, index footprint, notes) is in the file `detail` names (and on stderr)."""
+    r = _finite(result)
+    cfg, roof = r.get("config", {}), r.get("roofline", {})
+    out = {k: r.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _sig(out["value"], 7), _sig(out["ms_per_step"], 6)
+    out["config"] = {"workload": str(cfg.get("workload", ""))[:600], "reads_per_gpu_per_step": cfg.get("reads_per_gpu_per_step"),
+                     "ranks": cfg.get("ranks"), "gather": str(cfg.get("gather") or "none")[:160], "gather_by": cfg.get("gather_by"),
+                     "process_group": cfg.get("process_group"),
+                     "per_rank_units_per_s": [_sig(v) for v in (cfg.get("per_rank_units_per_s") or [])][:16]}
+    out["roofline"] = {k: _sig(roof.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                      "algorithmic_bytes_per_unit", "units_per_launch", "avg_launch_ms")}
+    st = roof.get("stage_ms_per_step_exclusive")
+    if st:
+        out["stage_ms"] = {k: _sig(v, 4) for k, v in st.items()}
+    cb = r.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": str(cb.get("sample", ""))[:200]}
+    if "parity_checked_reads" in r:
+        out["parity"] = {"checked": r.get("parity_checked_reads"), "mismatches": r.get("mismatches")}
+        if r.get("parity_errors"):
+            out["parity"]["errors"] = r["parity_errors"]
+    legs = {}
+    for nm in LEG_NAMES:
+        if isinstance(r.get(nm), dict) and "value" in r[nm]:
+            lg = {"value": _sig(r[nm]["value"]), "unit": r[nm].get("unit")}
+            lroof = r[nm].get("roofline")
+            if lroof:
+                lg["kernel"], lg["frac"], lg["avg_launch_ms"] = lroof.get("kernel"), _sig(lroof.get("frac"), 3), _sig(lroof.get("avg_launch_ms"), 4)
+            legs[nm] = lg
+    if legs:
+        out["legs"] = legs
+    out["detail"] = detail_path
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line) >= LINE_LIMIT:                    # (cannot happen with the caps above; the contract matters more than the extras)
+        for k in ("stage_ms", "legs"):
+            out.pop(k, None)
+        out["config"]["workload"] = out["config"]["workload"][:200]
+        line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    assert len(line) < LINE_LIMIT
+    return line
+
+
+def write_detail(result: dict, work: str, world: int):
+    """the full structure of the run: into a file (repo-relative gpurun_out/ when writable, else --work) and onto stderr"""
+    text = json.dumps(_finite(result), allow_nan=False, indent=1)
+    print("[bench] detail:", json.dumps(_finite(result), allow_nan=False), file=sys.stderr, flush=True)
+    for d in (os.path.join(ROOT, "gpurun_out"), work):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, f"bench_detail_n{world}.json")
+            with open(path, "w") as f:
+                f.write(text)
+            return os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+        except OSError:
+            continue
+    return None
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -545,7 +633,7 @@ def main():
                          "kaiju_build_fmi_replicated without a second sort; the .fmi is streamed to HBM and packed there): the kernels "
                          "of the layout with 64-bit positions - k_mem_wide2, k_mem_locate_wide / _team, k_greedy2_wide")
     ap.add_argument("--other-reads", type=int, default=2_000_000,
-                    help="reads per step of the legs `long` (250-bp reads: mates beyond 191 nt take the general stage 1, k_fragments) and "
+                    help="reads per step of the legs `long` (250-bp reads: mates of 192 - 287 nt take k_fragments_fast<.., 6>) and "
                          "`protein` (100-residue protein reads, kaiju -p: k_fragments_protein)")
     ap.add_argument("--wide-copies", type=int, default=23, help="copies of every protein in the index of the `wide` leg (23 x 191 M rows = 4.39 G > 2^32)")
     ap.add_argument("--wide-reads", type=int, default=2_000_000)
@@ -738,7 +826,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(rank, "host_buffers leg failed:", repr(e))
 
-    # ---------------- reads that are not 150 bp: 250-bp reads (general stage 1) and protein reads (kaiju -p) ----------------
+    # ---------------- reads that are not 150 bp: 250-bp reads (six-unit stage 1) and protein reads (kaiju -p) ----------------
     other = {}
     if world == 1 and not args.paired and not big_db:
         try:
@@ -948,7 +1036,7 @@ def main():
     for nm, leg in other.items():
         lr = leg.result(world, None, None, db.nseq)
         rec = np.frombuffer(leg.timed_compact.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
-        lr["workload"] = (f"the same index, {leg.n} synthetic 250-bp reads per step (mates beyond 191 nt: the general stage 1, k_fragments), kaiju -a mem"
+        lr["workload"] = (f"the same index, {leg.n} synthetic 250-bp reads per step (mates of 192 - 287 nt: the six-unit stage 1, k_fragments_fast<.., 6>), kaiju -a mem"
                           if nm == "long" else
                           f"the same index, {leg.n} synthetic protein reads of 100 residues per step (70% database windows with 0-5 substitutions), "
                           f"kaiju -a mem -p (k_fragments_protein)")
@@ -1001,7 +1089,8 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:  # noqa: BLE001
         pass
-    print(json.dumps(result), flush=True)
+    detail = write_detail(result, W, world)
+    print(summary_line(result, detail), flush=True)
 
 
 if __name__ == "__main__":

@@ -304,9 +304,12 @@ int kaiju_finalize_compact(const kaiju_gpu_params *p, double db_length, const ka
    hit lists gathered with a single RCCL gather over xGMI".  The reference has no exchange (its threads append to one output
    stream under a mutex, ConsumerThread.cpp:847-856; the thread fan-out is kaiju.cpp:250-257); here every rank classifies its
    shard, the device LCA turns the hits into 16-byte records and ONE collective per batch brings them to the rank that
-   writes the output.  kaiju_gpu_comm_create: rank 0 makes the communicator's id and leaves it in `rendezvous_path` (any path
-   all ranks see, e.g. under /dev/shm; the others wait for it up to two minutes).  librccl is opened on the first call
-   (dlopen): nothing links it, a single-GPU run never loads it.
+   writes the output.  kaiju_gpu_comm_create: rank 0 makes the communicator's id and hands it over through `rendezvous_path`
+   (any path all ranks of the job see and may write next to, e.g. under /dev/shm; up to two minutes for everybody to arrive).
+   The path need not be fresh: rank r > 0 announces itself with a random nonce in `<path>.r<r>`, takes the id only from a file
+   that carries that nonce and removes its nonce file; rank 0 removes whatever lay at `<path>` before, and the file itself once
+   every rank has acknowledged - a file left by an earlier job is never taken for this job's id.  Two jobs must not use ONE
+   path at the same time.  librccl is opened on the first call (dlopen): nothing links it, a single-GPU run never loads it.
    kaiju_gpu_gather_compact: n records of EVERY rank (the same n everywhere) into d_recv on `root`, rank r's at d_recv + r * n;
    d_recv is ignored elsewhere.  Asynchronous on `stream` (a hipStream_t; kaiju_gpu_get_stream() of the context that wrote
    d_send orders it behind the batch).  Without a HIP device: KAIJU_GPU_ERR_NO_DEVICE. */
@@ -325,21 +328,6 @@ const char *kaiju_gpu_comm_library(void);
 int kaiju_finalize_hits(kaiju_taxonomy *t, const kaiju_gpu_params *p, double db_length,
                         const kaiju_gpu_hit *hits, const uint64_t *off, uint32_t n_reads,
                         int paired, kaiju_result *out);
-
-/* ---- index construction (off-line) ------------------------------------ */
-/* Protein FASTA -> .fmi, format-compatible with the reference's kaiju-mkbwt (-a
-   ACDEFGHIKLMNPQRSTVWY -e chpt_exp, util/kaiju-makedb:373) followed by kaiju-mkfmi
-   (bwt/mkbwt.c:922-1099, bwt/mkfmi.c:21-97); the reference binary reads the result.
-   threads <= 0: all hardware threads.  Host only. */
-int kaiju_build_fmi(const char *faa_path, const char *out_fmi_path, int threads, int chpt_exp);
-/* The .fmi of the database in which every sequence of the FASTA occurs `copies` times in a row, without sorting it again (equal
-   suffixes order by file position, so every row of the file's own index becomes `copies` rows); byte for byte what
-   kaiju_build_fmi writes for the FASTA with the repeats spelled out.  Test / benchmark infrastructure: an index of 2^32 rows
-   and more (the layout with 64-bit positions) from a small FASTA in seconds.  copy_taxids (may be NULL): copy t of sequence
-   number i, named X_<id>, is named X_<copy_taxids[(i + t) % n_copy_taxids]>. */
-int kaiju_build_fmi_replicated(const char *faa_path, const char *out_fmi_path, int threads, int chpt_exp, uint64_t copies,
-                               const uint64_t *copy_taxids, uint32_t n_copy_taxids);
-const char *kaiju_build_fmi_error(void);
 
 #ifdef __cplusplus
 }

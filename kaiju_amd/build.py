@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkaiju_gpu.so")
-SOURCES = ["capi.hip", "fmi_stream.hip", "exact_pass.hip", "host_index.cpp", "host_tables.cpp", "taxonomy.cpp", "mkfmi.cpp", "rccl_gather.cpp"]
+SOURCES = ["capi.hip", "fmi_stream.hip", "exact_pass.hip", "host_index.cpp", "host_tables.cpp", "taxonomy.cpp", "rccl_gather.cpp"]
 HEADERS = ["kj_core.h", "fmi_stream.h", "exact_pass.h", "host_index.h", "host_tables.h", os.path.join("..", "..", "include", "kaiju_gpu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-gpu-rdc", "-Wno-unused-result"]
@@ -32,7 +32,22 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+MKFMI_LIB = os.path.join(HERE, "libkaiju_mkfmi.so")
+MKFMI_SRC = [os.path.join(CSRC, "mkfmi.cpp"), os.path.join(CSRC, "mkfmi.h")]
+
+
+def build_mkfmi(force=False, verbose=False):
+    """the index builder: test / benchmark infrastructure in a library of its own (host only; csrc/mkfmi.h says why it exists)"""
+    if force or not os.path.exists(MKFMI_LIB) or any(os.path.getmtime(d) > os.path.getmtime(MKFMI_LIB) for d in MKFMI_SRC):
+        cmd = ["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-o", MKFMI_LIB, MKFMI_SRC[0], "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return MKFMI_LIB
+
+
 def build(force=False, verbose=False):
+    build_mkfmi(force=force, verbose=verbose)
     if force or needs_build():
         cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread", "-ldl"]
         if verbose:

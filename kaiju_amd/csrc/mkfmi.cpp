@@ -35,7 +35,7 @@
 #include <time.h>
 #include <vector>
 
-#include "../../include/kaiju_gpu.h"
+#include "mkfmi.h"
 
 namespace {
 

@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 #include <hip/hip_runtime_api.h>
 
@@ -54,12 +56,15 @@ struct Rccl {
     }
     const std::string cands[] = {beside.empty() ? std::string() : beside + "librccl.so.1", beside.empty() ? std::string() : beside + "librccl.so",
                                  "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string tried;
     for (const std::string &name : cands) {
       if (name.empty()) continue;
       lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (lib) { path = name; break; }
+      const char *e = dlerror();                      // (ONE call: glibc clears the message when it is read)
+      tried += std::string(tried.empty() ? "" : "; ") + (e ? e : name.c_str());
     }
-    if (!lib) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    if (!lib) { err = std::string("librccl not found: ") + tried; return false; }
     auto sym = [&](const char *n) { return dlsym(lib, n); };
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
@@ -82,6 +87,92 @@ std::mutex g_mu;
 thread_local std::string tl_err;
 int fail(int code, const std::string &m) { tl_err = m; return code; }
 double now_s() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+// rank 0 hands `*id` to the other ranks of THIS job through files (see below); KAIJU_GPU_OK or an error code + tl_err
+int exchange_id(const char *rendezvous_path, int rank, int world, UniqueId *id, double timeout_s) {
+  // The communicator's id travels through files.  A path may have been used before (a job that died, a rank that polls before
+  // rank 0 has started): nothing that lies there is trusted.  Rank r > 0 leaves a random 64-bit nonce in `<path>.r<r>`; rank 0
+  // removes whatever `<path>` held, makes the id and writes {magic, world, the nonces it has read, id} (next to it, then
+  // renamed: a reader never sees half of it); rank r takes the id only from a file that carries ITS nonce and then removes its
+  // nonce file - the acknowledgement rank 0 waits for (re-reading the nonces meanwhile: one left by a dead job is replaced by
+  // its rank and the file is written again).  When every rank has acknowledged, rank 0 removes the file.
+  const std::string base = rendezvous_path;
+  auto nonce_path = [&](int r) { return base + ".r" + std::to_string(r); };
+  auto write_atomically = [&](const std::string &path, const void *data, size_t bytes) {
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    const bool ok = fp && fwrite(data, bytes, 1, fp) == 1;
+    if (fp) fclose(fp);
+    if (!ok || rename(tmp.c_str(), path.c_str()) != 0) { unlink(tmp.c_str()); return false; }
+    return true;
+  };
+  auto read_whole = [&](const std::string &path, void *data, size_t bytes) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || st.st_size != (off_t)bytes) return false;
+    FILE *fp = fopen(path.c_str(), "rb");
+    const bool ok = fp && fread(data, bytes, 1, fp) == 1;
+    if (fp) fclose(fp);
+    return ok;
+  };
+  constexpr uint64_t kMagic = 0x4b4a434f4d4d3031ull;      // "KJCOMM01"
+  const size_t file_words = 2 + (size_t)world;             // magic, world, nonce of rank 1 .. world-1 (slot 0 unused)
+  const size_t file_bytes = file_words * 8 + sizeof *id;
+  std::vector<uint8_t> buf(file_bytes, 0);
+  const double t0 = now_s();
+  const double kWait = timeout_s;
+  if (rank == 0) {
+    std::vector<uint64_t> nonce(world, 0), seen(world, 0);
+    std::vector<char> acked(world, 0);
+    bool written = false;
+    for (;;) {
+      bool all_known = true, all_acked = true, changed = false;
+      for (int r = 1; r < world; r++) {
+        uint64_t v = 0;
+        if (read_whole(nonce_path(r), &v, sizeof v)) {
+          if (!seen[r] || v != nonce[r]) { nonce[r] = v; seen[r] = 1; changed = true; }
+          all_acked = false;
+        } else if (written && seen[r]) acked[r] = 1;         // its nonce file is gone: the rank has the id
+        if (!seen[r]) all_known = false;
+        if (!acked[r]) all_acked = false;
+      }
+      if (all_known && (changed || !written)) {
+        uint64_t *w = reinterpret_cast<uint64_t *>(buf.data());
+        w[0] = kMagic; w[1] = (uint64_t)world;
+        for (int r = 1; r < world; r++) w[2 + r] = nonce[r];
+        memcpy(buf.data() + file_words * 8, id, sizeof *id);
+        if (!write_atomically(base, buf.data(), file_bytes)) return fail(KAIJU_GPU_ERR_IO, std::string("cannot write ") + rendezvous_path);
+        written = true;
+        std::fill(acked.begin(), acked.end(), 0);
+        continue;
+      }
+      if (written && all_acked) break;
+      if (now_s() - t0 > kWait) { unlink(rendezvous_path); return fail(KAIJU_GPU_ERR_IO, std::string("not every rank answered through ") + rendezvous_path); }
+      usleep(2000);
+    }
+    unlink(rendezvous_path);                                 // every rank has acknowledged: nothing is left behind
+  } else {
+    uint64_t mine = 0;
+    {
+      FILE *fp = fopen("/dev/urandom", "rb");
+      if (!fp || fread(&mine, sizeof mine, 1, fp) != 1) mine = 0;
+      if (fp) fclose(fp);
+      timespec t; clock_gettime(CLOCK_REALTIME, &t);
+      if (!mine) mine = ((uint64_t)t.tv_nsec << 32) ^ (uint64_t)t.tv_sec ^ ((uint64_t)getpid() << 17);
+      mine |= 1;                                             // (never 0)
+    }
+    if (!write_atomically(nonce_path(rank), &mine, sizeof mine)) return fail(KAIJU_GPU_ERR_IO, std::string("cannot write ") + nonce_path(rank));
+    for (;;) {
+      if (read_whole(base, buf.data(), file_bytes)) {
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(buf.data());
+        if (w[0] == kMagic && w[1] == (uint64_t)world && w[2 + rank] == mine) { memcpy(id, buf.data() + file_words * 8, sizeof *id); break; }
+      }
+      if (now_s() - t0 > kWait) { unlink(nonce_path(rank).c_str()); return fail(KAIJU_GPU_ERR_IO, std::string("no communicator id for this job appeared in ") + rendezvous_path); }
+      usleep(2000);
+    }
+    unlink(nonce_path(rank).c_str());
+  }
+  return KAIJU_GPU_OK;
+}
 
 }  // namespace
 
@@ -108,37 +199,32 @@ extern "C" int kaiju_gpu_comm_create(const char *rendezvous_path, int rank, int 
   //  probing hipMalloc that was allowed to fail, an event query that said "not ready" - must not become its "unhandled error")
   (void)hipDeviceSynchronize();
   (void)hipGetLastError();
-  // the communicator's id: made by rank 0, left in the file (written next to it, then renamed: a reader never sees half of it)
   UniqueId id;
   memset(&id, 0, sizeof id);
   if (rank == 0) {
+    unlink(rendezvous_path);
     const int rc = g_rccl.GetUniqueId(&id);
     if (rc != kNcclSuccess) return fail(KAIJU_GPU_ERR_HIP, std::string("ncclGetUniqueId: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
-    const std::string tmp = std::string(rendezvous_path) + ".tmp";
-    FILE *fp = fopen(tmp.c_str(), "wb");
-    const bool ok = fp && fwrite(&id, sizeof id, 1, fp) == 1;
-    if (fp) fclose(fp);
-    if (!ok || rename(tmp.c_str(), rendezvous_path) != 0) return fail(KAIJU_GPU_ERR_IO, std::string("cannot write ") + rendezvous_path);
-  } else {
-    const double t0 = now_s();
-    for (;;) {
-      struct stat st;
-      if (stat(rendezvous_path, &st) == 0 && st.st_size == (off_t)sizeof id) {
-        FILE *fp = fopen(rendezvous_path, "rb");
-        const bool ok = fp && fread(&id, sizeof id, 1, fp) == 1;
-        if (fp) fclose(fp);
-        if (ok) break;
-      }
-      if (now_s() - t0 > 120.0) return fail(KAIJU_GPU_ERR_IO, std::string("no communicator id appeared in ") + rendezvous_path);
-      usleep(2000);
-    }
   }
+  if (const int rc = exchange_id(rendezvous_path, rank, world, &id, 120.0)) return rc;
   kaiju_gpu_comm *c = new kaiju_gpu_comm();
   c->rank = rank; c->world = world; c->device = device_id;
   const int rc = g_rccl.CommInitRank(&c->comm, world, id, rank);
   if (rc != kNcclSuccess) { delete c; return fail(KAIJU_GPU_ERR_HIP, std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?")); }
   *out = c;
   return KAIJU_GPU_OK;
+}
+
+/* the file exchange alone (host only; tests/test_capi.py: stale files of an earlier job, ranks that start in any order):
+   rank 0 passes 128 bytes in, the others get them */
+extern "C" int kaiju_gpu_comm_exchange_id(const char *rendezvous_path, int rank, int world, uint8_t *id128, double timeout_s) {
+  if (!rendezvous_path || !id128 || world < 1 || rank < 0 || rank >= world) return fail(KAIJU_GPU_ERR_ARG, "bad argument");
+  UniqueId id;
+  memcpy(&id, id128, sizeof id);
+  if (rank == 0) unlink(rendezvous_path);
+  const int rc = exchange_id(rendezvous_path, rank, world, &id, timeout_s);
+  if (rc == KAIJU_GPU_OK) memcpy(id128, &id, sizeof id);
+  return rc;
 }
 
 extern "C" void kaiju_gpu_comm_destroy(kaiju_gpu_comm *c) {

@@ -245,3 +245,43 @@ def test_the_gather_entry_points_without_a_device(tmp_path):
     assert L.kaiju_gpu_gather_compact(None, None, 0, None, 0, None) == -1
     L.kaiju_gpu_comm_destroy.argtypes = [C.c_void_p]
     L.kaiju_gpu_comm_destroy(None)
+
+
+def test_comm_rendezvous_ignores_what_an_earlier_job_left(tmp_path):
+    """kaiju_gpu_comm_create's file exchange (rccl_gather.cpp: exchange_id), host only: a stale id file and stale nonce files
+    of a dead job lie at the path, the ranks start in any order - every rank ends up with THIS job's 128 bytes and nothing is
+    left behind.  (a reader used to take any 128-byte file for the id.)"""
+    import threading
+    import time
+    L = api.lib()
+    L.kaiju_gpu_comm_exchange_id.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_double]
+    path = tmp_path / "comm.id"
+    world = 4
+    for order in ([0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1]):
+        # leftovers of a job that died: an id file of the right size for this world, a nonce file of rank 2
+        path.write_bytes(b"\x31\x30\x4d\x4d\x4f\x43\x4a\x4b" + world.to_bytes(8, "little") + b"\x07" * (8 * world) + b"\xee" * 128)
+        (tmp_path / "comm.id.r2").write_bytes(b"\x07" * 8)
+        job_id = os.urandom(128)
+        bufs = [C.create_string_buffer(job_id if r == 0 else b"\0" * 128, 128) for r in range(world)]
+        rcs = [None] * world
+
+        def run(r):
+            rcs[r] = L.kaiju_gpu_comm_exchange_id(str(path).encode(), r, world, bufs[r], 30.0)
+        th = []
+        for r in order:
+            t = threading.Thread(target=run, args=(r,))
+            t.start()
+            th.append(t)
+            time.sleep(0.05)
+        for t in th:
+            t.join()
+        assert rcs == [0] * world, rcs
+        for r in range(world):
+            assert bufs[r].raw == job_id, r
+        assert sorted(os.listdir(tmp_path)) == [], os.listdir(tmp_path)
+    # a rank whose job never shows up gives up with a status (and removes its nonce file)
+    b = C.create_string_buffer(128)
+    assert L.kaiju_gpu_comm_exchange_id(str(path).encode(), 1, 2, b, 0.3) == -2
+    assert os.listdir(tmp_path) == []
+    # one rank: nobody to wait for
+    assert L.kaiju_gpu_comm_exchange_id(str(path).encode(), 0, 1, b, 1.0) == 0
