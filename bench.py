@@ -401,7 +401,7 @@ class Leg:
         alg = algorithmic_bytes(oc, nseq) * (per_launch / first)          # counted on chunk 0, scaled to the mean launch
         achieved = alg / (excl_ms * 1e-3) / 1e9 if excl_ms > 0 else 0.0
         wide_ix = self.index.info.bwtlen >= 2 ** 32
-        roof = {"bound": "hbm", "kernel": ("k_mem_wide2" if wide_ix else "k_mem") if self.mode == "mem" else ("k_greedy2_wide" if wide_ix else "k_greedy2"),
+        roof = {"bound": "hbm", "kernel": ("k_mem_wide2" if wide_ix else "k_mem") if self.mode == "mem" else ("k_greedy2_wide" if wide_ix else ("k_greedy3" if os.environ.get("KAIJU_GPU_GREEDY_LANE") == "v3" else "k_greedy2")),
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 **({"traffic_note": _TRAFFIC_NOTES[(self.mode, bool(self.paired))]}

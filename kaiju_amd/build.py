@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkaiju_gpu.so")
 SOURCES = ["capi.hip", "fmi_stream.hip", "exact_pass.hip", "host_index.cpp", "host_tables.cpp", "taxonomy.cpp", "rccl_gather.cpp"]
-HEADERS = ["kj_core.h", "fmi_stream.h", "exact_pass.h", "host_index.h", "host_tables.h", os.path.join("..", "..", "include", "kaiju_gpu.h")]
+HEADERS = ["kj_core.h", "kj_greedy3.h", "fmi_stream.h", "exact_pass.h", "host_index.h", "host_tables.h", os.path.join("..", "..", "include", "kaiju_gpu.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-gpu-rdc", "-Wno-unused-result"]
 

@@ -38,6 +38,7 @@
 #include "kj_core.h"
 #include "taxonomy.h"
 #include "exact_pass.h"
+#include "kj_greedy3.h"
 
 using namespace kj;
 
@@ -519,6 +520,54 @@ k_greedy2_wide(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQ
 __global__ void __launch_bounds__(kBlock, 1)
 k_greedy2_wide_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
   greedy2_body<true, true>(ix, g_ct, p, sq, b, wl, ga);
+}
+
+// third-generation Greedy (kj_greedy3.h): ONE block of kG3Threads threads per CU owns kG3Pool reads as rows of LDS, its
+// wavefronts pull rows by class - the lanes of a wavefront run the same piece of the algorithm.  Narrow indexes with k-mer lines.
+template <bool COUNT>
+__device__ __forceinline__ void greedy3_body(const DevIndex &ix, const ConstTables *__restrict__ g_ct, const Params &p, const SegQueue &sq,
+                                             const Batch &b, const WorkList &wl, const GreedyArrays2 &ga, uint32_t split) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_all[kG3LdsBytes / 4];
+  uint32_t *s_prio = s_all;
+  uint32_t *s_mq = s_prio + kG3Pool * kG3PrioWords;
+  uint32_t *s_win = s_mq + kG3Pool * kG3MqWords;
+  uint32_t *s_st = s_win + kG3Pool * kG3WinWords;
+  uint32_t *s_cls = s_st + kG3Pool * kG3StWords;
+  uint32_t *s_cnt = s_cls + kG3Pool;
+  uint16_t *s_tmp = reinterpret_cast<uint16_t *>(s_cnt + 32);
+  ConstTables &s_ct = *reinterpret_cast<ConstTables *>(s_tmp + (kG3Threads / 64) * 64);
+  for (uint32_t x = threadIdx.x; x < (uint32_t)(kG3Pool * (kG3RowBytes / 4)); x += blockDim.x) s_all[x] = 0;
+  for (uint32_t x = threadIdx.x; x < (uint32_t)kG3Pool; x += blockDim.x) s_cls[x] = C3_IDLE;
+  if (threadIdx.x < 32) s_cnt[threadIdx.x] = threadIdx.x == (uint32_t)C3_IDLE ? (uint32_t)kG3Pool : 0u;
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&s_ct);
+    for (uint32_t x = threadIdx.x; x < sizeof(ConstTables) / 4; x += blockDim.x) dst[x] = src[x];
+  }
+  __syncthreads();
+  G3Ctx gx;
+  gx.prio = s_prio; gx.win = s_win; gx.mq = s_mq; gx.st = s_st; gx.cls = s_cls; gx.cnt = s_cnt;
+  gx.tmp = s_tmp + (threadIdx.x >> 6) * 64;
+  gx.pool = ga.pool; gx.prio_ext = ga.prio_ext; gx.matches = ga.matches; gx.mq_ext = ga.mq_ext; gx.best = ga.best;
+  gx.row0 = blockIdx.x * (uint32_t)kG3Pool; gx.npool = kG3Pool; gx.split = split;
+  gx.prof = nullptr;
+#ifdef KJ_PROF
+  __shared__ unsigned long long s_prof[kG3Threads / 64][2 + 3 * PS_N];
+  if constexpr (!COUNT) {
+    for (int x = threadIdx.x & 63; x < 2 + 3 * PS_N; x += 64) s_prof[threadIdx.x >> 6][x] = 0;
+    gx.prof = s_prof[threadIdx.x >> 6];
+    if ((threadIdx.x & 63) == 0) { gx.prof[0] = __builtin_readcyclecounter(); gx.prof[1] = PS_HEAD; }
+  }
+#endif
+  greedy_lane3<COUNT>(ix, s_ct, p, sq, b, wl, gx);
+}
+__global__ void __launch_bounds__(kG3Threads, 2)
+k_greedy3(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga, uint32_t split) {
+  greedy3_body<false>(ix, g_ct, p, sq, b, wl, ga, split);
+}
+__global__ void __launch_bounds__(kG3Threads, 2)
+k_greedy3_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga, uint32_t split) {
+  greedy3_body<true>(ix, g_ct, p, sq, b, wl, ga, split);
 }
 
 // Index load: the k-mer table one letter deeper.  child[idx * 20 + c - 1] = UpdateSI(parent[idx], c)
@@ -1561,6 +1610,9 @@ struct kaiju_gpu_ctx {
   DevBuf scratch_main[10], scratch_retry[5], h_compact;
   DevBuf redo_bitmap, redo_list, redo_items, redo_index, redo_pool, redo_work, redo_cls;    // the exact pass
   bool greedy2 = false;
+  bool greedy3 = false;            // KAIJU_GPU_GREEDY_LANE=v3: the row-pool lane (kj_greedy3.h; narrow index with k-mer lines)
+  uint32_t g3_split = 1;           // KAIJU_GPU_G3_SPLIT
+  uint32_t g3_threads = kG3Threads;// KAIJU_GPU_G3_THREADS (a multiple of 64)
   uint32_t greedy_gate = 1u | 32u << 8;   // heavy iteration every 2nd, or as soon as half the wavefront waits for one (measured: r02_gprof; round 3,
                                            // with the span rule and the probes thinning the fast iterations: every 2nd beats every 4th, profiles/r03_l14)
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
@@ -1655,6 +1707,11 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
     c->greedy2 = ix->dev.blocks64 && (g_wide ? ix->dev.kmer64 != nullptr : ix->dev.kline != nullptr) && g_k >= 2 &&
                  g_k <= p->seed_length && p->seed_length >= 3;
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; }
+    // (the row-pool lane is parity-green but SLOWER than greedy_lane2 at the 480 rows a CU's LDS holds - DESIGN.md 6b, round 6:
+    //  opt-in, KAIJU_GPU_GREEDY_LANE=v3)
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v3")) c->greedy3 = c->greedy2 && !g_wide; }
+    if (const char *e = getenv("KAIJU_GPU_G3_SPLIT")) c->g3_split = (uint32_t)atoi(e);
+    if (const char *e = getenv("KAIJU_GPU_G3_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= kG3Threads && v % 64 == 0) c->g3_threads = (uint32_t)v; }
     if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (c->greedy_gate & ~0xffu) | (uint32_t)v; }
     // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
     if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate = (c->greedy_gate & 0xffu) | (uint32_t)v << 8; }
@@ -1898,6 +1955,9 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     GreedyArrays ga;
     ga.pool_cap = 192; ga.match_cap = 64;
     const bool use_g2 = c->greedy2 && !c->verbose;
+    const bool use_g3 = use_g2 && c->greedy3;
+    // (the row-pool lane: one block per CU, kG3Pool rows each - its scratch in device memory is per ROW)
+    const uint64_t lanes_g2 = use_g3 ? (uint64_t)c->n_cu * kG3Pool : lanes_main;
     if (!use_g2) {
       if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
       if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
@@ -1929,12 +1989,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     }
     GreedyArrays2 g2{};
     if (use_g2) {
-      if ((rc = ensure(c->scratch_main[5], (lanes_main * (8 * kGSlotsAll) + 4) * sizeof(u128)))) return rc;
-      if ((rc = ensure(c->scratch_main[6], (lanes_main * (kGSlotsAll - kGSlots) + 16) * sizeof(uint32_t)))) return rc;   // (+ slack: read 16 bytes at a time)
-      if ((rc = ensure(c->scratch_main[7], lanes_main * kGMaxMAll * sizeof(GMatch2)))) return rc;
-      if ((rc = ensure(c->scratch_main[8], lanes_main * (kGMaxMAll - kGMaxM) * sizeof(uint16_t)))) return rc;
+      if ((rc = ensure(c->scratch_main[5], (lanes_g2 * (8 * kGSlotsAll) + 4) * sizeof(u128)))) return rc;
+      if ((rc = ensure(c->scratch_main[6], (lanes_g2 * (kGSlotsAll - kGSlots) + 16) * sizeof(uint32_t)))) return rc;   // (+ slack: read 16 bytes at a time)
+      if ((rc = ensure(c->scratch_main[7], lanes_g2 * kGMaxMAll * sizeof(GMatch2)))) return rc;
+      if ((rc = ensure(c->scratch_main[8], lanes_g2 * (kGMaxMAll - kGMaxM) * sizeof(uint16_t)))) return rc;
       const bool g_wide = ix->dev.mb_base != nullptr;
-      if ((rc = ensure(c->scratch_main[9], lanes_main * 64 * (g_wide ? sizeof(GBest2W) : sizeof(GBest2))))) return rc;
+      if ((rc = ensure(c->scratch_main[9], lanes_g2 * 64 * (g_wide ? sizeof(GBest2W) : sizeof(GBest2))))) return rc;
       g2.pool = static_cast<u128 *>(c->scratch_main[5].p); g2.prio_ext = static_cast<uint32_t *>(c->scratch_main[6].p);
       g2.matches = static_cast<GMatch2 *>(c->scratch_main[7].p); g2.mq_ext = static_cast<uint16_t *>(c->scratch_main[8].p);
       g2.best = g_wide ? nullptr : static_cast<GBest2 *>(c->scratch_main[9].p);
@@ -1945,7 +2005,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       Params pg = p;
       if (use_g2) pg.flags |= kParamDeferLocate;       // (greedy_lane2 leaves every read's best matches to k_mem_locate*)
       const bool g_wide = ix->dev.mb_base != nullptr;
-      if (use_g2 && c->count_ops && g_wide)
+      if (use_g3 && c->count_ops)
+        hipLaunchKernelGGL(k_greedy3_count, dim3(c->n_cu), dim3(c->g3_threads), 0, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2, c->g3_split);
+      else if (use_g3)
+        hipLaunchKernelGGL(k_greedy3, dim3(c->n_cu), dim3(c->g3_threads), 0, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2, c->g3_split);
+      else if (use_g2 && c->count_ops && g_wide)
         hipLaunchKernelGGL(k_greedy2_wide_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
       else if (use_g2 && g_wide)
         hipLaunchKernelGGL(k_greedy2_wide, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);

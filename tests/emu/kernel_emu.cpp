@@ -16,6 +16,7 @@
 #include "../../kaiju_amd/csrc/host_index.h"
 #include "../../kaiju_amd/csrc/host_tables.h"
 #include "../../kaiju_amd/csrc/kj_core.h"
+#include "../../kaiju_amd/csrc/kj_greedy3.h"
 #include "../../kaiju_amd/csrc/fmi_stream.h"
 
 using namespace kj;
@@ -333,8 +334,24 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         g2.sub = lds_sub;
         Params pg = p;
         pg.flags |= kParamDeferLocate;
+        const char *g3e = getenv("KAIJU_EMU_GREEDY");       // "3": the row-pool lane (kj_greedy3.h; narrow indexes) - the product's KAIJU_GPU_GREEDY_LANE=v3
         if (d.mb_base) greedy_lane2<false, true>(d, ix->ct, pg, sq, b, wl, g2);
-        else greedy_lane2(d, ix->ct, pg, sq, b, wl, g2);
+        else if (!(g3e && !strcmp(g3e, "3"))) greedy_lane2(d, ix->ct, pg, sq, b, wl, g2);
+        else {
+          // third generation (kj_greedy3.h): the read's state in a row of "LDS"; here a pool of one row
+          alignas(16) uint32_t r_prio[kG3PrioWords], r_win[kG3WinWords], r_mq[kG3MqWords], r_st[kG3StWords], r_cls[1], r_cnt[32];
+          uint16_t r_tmp[64];
+          for (auto &x : r_prio) x = 0;
+          for (auto &x : r_win) x = 0;
+          for (auto &x : r_mq) x = 0;
+          for (auto &x : r_st) x = 0;
+          for (auto &x : r_cnt) x = 0;
+          r_cls[0] = C3_IDLE;
+          const char *sp = getenv("KAIJU_EMU_G3_SPLIT");
+          G3Ctx gx{r_prio, r_win, r_mq, r_st, r_cls, r_cnt, r_tmp, pool2.data(), prio_ext.data(), matches2.data(), mq_ext.data(), best2.data(),
+                   0u, 1u, sp ? (uint32_t)atoi(sp) : 1u, nullptr};
+          greedy_lane3(d, ix->ct, pg, sq, b, wl, gx);
+        }
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }

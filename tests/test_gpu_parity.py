@@ -552,3 +552,31 @@ def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, 
             assert (a["n_ids"] > 0).mean() > 0.4
 
 
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_greedy_row_pool_lane(gpu_lib, golden, gidx, oracle, ohandles, big, split, monkeypatch):
+    """KAIJU_GPU_GREEDY_LANE=v3 (kj_greedy3.h: the reads of a block as rows of LDS, wavefronts pull rows by class) writes the
+    records greedy_lane2 writes: the golden reads against the oracle, 400 k benchmark reads against the default lane"""
+    api = gpu_lib
+    ix, tax = ohandles
+    ref_clf = api.Classifier(big["index"], api.default_params("greedy", seg=1))
+    n = min(400000, len(big["reads"]))
+    from kaiju_amd import synth
+    s2, o2 = synth.pack_reads(big["reads"][:n])
+    want = ref_clf.classify(s2, o2).copy()
+    monkeypatch.setenv("KAIJU_GPU_GREEDY_LANE", "v3")
+    monkeypatch.setenv("KAIJU_GPU_G3_SPLIT", split)
+    for seg in (1, 0):
+        clf = api.Classifier(gidx, api.default_params("greedy", seg=seg))
+        hits = clf.classify(golden.seqs, golden.off)
+        assert clf.stats().error_flags == 0
+        oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg, use_evalue=0), golden.seqs, golden.off)
+        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
+        assert not bad, (seg, bad[:5])
+    clf = api.Classifier(big["index"], api.default_params("greedy", seg=1))
+    got = clf.classify(s2, o2)
+    assert clf.stats().error_flags == 0
+    for f in ("best", "n_ids", "flags"):
+        assert (got[f] == want[f]).all(), f
+    assert (got["taxid"] == want["taxid"]).all()

@@ -187,10 +187,16 @@ def test_mem_lane_generations_agree(oracle, emu, golden, handles, lane, monkeypa
         assert not bad, (lane, seg, "paired", bad[:5])
 
 
-@pytest.mark.parametrize("lane,gate", [("v1", None), (None, "0"), (None, "1"), (None, None), (None, "7")])
+@pytest.mark.parametrize("lane,gate", [("v1", None), (None, "0"), (None, "1"), (None, None), (None, "7"), ("v3", None), ("v3", "nosplit")])
 def test_greedy_lane_generations_agree(oracle, emu, golden, handles, lane, gate, monkeypatch):
-    """first-generation Greedy lane and the second-generation lane (any period of its slow part) == oracle"""
+    """first-generation Greedy lane, the second-generation lane (any period of its slow part) and the row-pool lane of
+    kj_greedy3.h (one slow block per pull, or the whole chain) == oracle"""
     h, ix, tax = handles
+    if lane == "v3":
+        monkeypatch.setenv("KAIJU_EMU_GREEDY", "3")
+        if gate:
+            monkeypatch.setenv("KAIJU_EMU_G3_SPLIT", "0")
+        lane = gate = None
     if lane:
         monkeypatch.setenv("KAIJU_EMU_LANE", lane)
     if gate:
@@ -208,10 +214,13 @@ def test_greedy_lane_generations_agree(oracle, emu, golden, handles, lane, gate,
         assert not bad, (lane, gate, seg, "paired", bad[:5])
 
 
-def test_greedy_lane2_spill_and_retry(oracle, golden, handles):
-    """the second-generation Greedy lane built with tiny bounds (-DKJ_G_SMALL): match lengths and queue
+@pytest.mark.parametrize("g3", [False, True])
+def test_greedy_lane2_spill_and_retry(oracle, golden, handles, g3, monkeypatch):
+    """the second-generation Greedy lane (and the row-pool lane) built with tiny bounds (-DKJ_G_SMALL): match lengths and queue
     priorities spill from the LDS rows to global scratch, reads beyond the bounds take the retry pass"""
     import os
+    if g3:
+        monkeypatch.setenv("KAIJU_EMU_GREEDY", "3")
     small = util.Emu(so=os.path.join(util.EMU_DIR, "libkaiju_kernel_emu_small.so"), defines=("KJ_G_SMALL",))
     _, ix, tax = handles
     h = small.load(golden.fmi)

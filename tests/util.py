@@ -35,7 +35,7 @@ def build_emu(so=None, defines=()):
     so = so or EMU_SO
     srcs = [os.path.join(EMU_DIR, "kernel_emu.cpp")] + [os.path.join(CSRC, f) for f in
                                                         ("host_index.cpp", "host_tables.cpp", "taxonomy.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kj_core.h", "host_index.h", "host_tables.h", "fmi_stream.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kj_core.h", "kj_greedy3.h", "host_index.h", "host_tables.h", "fmi_stream.h")]
     if os.path.exists(so) and all(os.path.getmtime(d) <= os.path.getmtime(so) for d in deps):
         return
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", "-pthread"]
