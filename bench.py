@@ -332,9 +332,13 @@ class Leg:
             out_view = self.d_out[lo * HIT_BYTES: hi * HIT_BYTES]
             cview = self.d_compact[lo * COMPACT_BYTES: hi * COMPACT_BYTES]
             with torch.cuda.stream(s):
-                c.classify_device(self.d_seqs.data_ptr() + lo * self.L, m * self.L, d_off.data_ptr(), m, out_view.data_ptr(),
-                                  paired=self.paired, stream=s.cuda_stream)
-                c.lca_device(self.dtax, out_view.data_ptr(), m, cview.data_ptr(), stream=s.cuda_stream)
+                if os.environ.get("KAIJU_BENCH_TWO_CALLS"):       # (A/B: the two entry points of rounds 1-5)
+                    c.classify_device(self.d_seqs.data_ptr() + lo * self.L, m * self.L, d_off.data_ptr(), m, out_view.data_ptr(),
+                                      paired=self.paired, stream=s.cuda_stream)
+                    c.lca_device(self.dtax, out_view.data_ptr(), m, cview.data_ptr(), stream=s.cuda_stream)
+                else:
+                    c.classify_device_compact(self.dtax, self.d_seqs.data_ptr() + lo * self.L, m * self.L, d_off.data_ptr(), m,
+                                              out_view.data_ptr(), cview.data_ptr(), paired=self.paired, stream=s.cuda_stream)
                 g.gather(cview)
             pending[k % nctx] = m
         for k in range(nctx):
@@ -495,10 +499,18 @@ def host_buffers_leg(index, dtax, reads, Lm, seg, dev, calls=4, chunk=2_500_000,
                            "never the headline value"}
 
 
-def load_traffic(mode, paired, seg, nseq, per_launch):
+def load_traffic(mode, paired, seg, nseq, per_launch, leg=None):
+    """HBM bytes per launch of the leg's search kernel from the committed PMC passes (profiles/traffic.json); records of the
+    legs other than headline / greedy / paired carry the leg's name (tests/tools/pmc_legs.sh)"""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for rec in json.load(f)["measurements"]:
+                if leg is not None:
+                    if rec.get("leg") == leg and rec["reads_per_launch"] == int(per_launch):
+                        return rec["hbm_bytes_per_launch"]
+                    continue
+                if rec.get("leg"):
+                    continue
                 if (rec["mode"] == mode and int(rec["seg"]) == int(seg) and rec["nseq"] == nseq and
                         bool(rec.get("paired", False)) == bool(paired) and rec["reads_per_launch"] == int(per_launch)):
                     _TRAFFIC_NOTES[(mode, bool(paired))] = rec.get("note")
@@ -569,6 +581,8 @@ def summary_line(result: dict, detail_path) -> str:
             lroof = r[nm].get("roofline")
             if lroof:
                 lg["kernel"], lg["frac"], lg["avg_launch_ms"] = lroof.get("kernel"), _sig(lroof.get("frac"), 3), _sig(lroof.get("avg_launch_ms"), 4)
+                if lroof.get("traffic") is not None:
+                    lg["traffic"] = _sig(lroof.get("traffic"), 4)
             legs[nm] = lg
     if legs:
         out["legs"] = legs
@@ -1020,7 +1034,7 @@ def main():
             result[nm] = lr
     if hard is not None:
         for nm, leg in hard["legs"].items():
-            lr = leg.result(world, acc[nm]["ref_ops"], None, hard["db"].nseq)
+            lr = leg.result(world, acc[nm]["ref_ops"], load_traffic(None, None, None, None, leg.bounds[0][1] - leg.bounds[0][0], leg=nm), hard["db"].nseq)
             rec = np.frombuffer(leg.timed_compact.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
             lr["workload"] = (f"NOT i.i.d.: {hard['db'].nseq} proteins / {hard['db'].total_aa} aa in families of 50-500 near-identical members "
                               f"(0.5-3 % substitutions), low-complexity inserts in 5 % of them; {leg.n} 150-bp reads per step, 5 % of them with "
@@ -1034,7 +1048,7 @@ def main():
                 parity[nm] = acc[nm]["parity"]
             result[nm] = lr
     for nm, leg in other.items():
-        lr = leg.result(world, None, None, db.nseq)
+        lr = leg.result(world, None, load_traffic(None, None, None, None, leg.bounds[0][1] - leg.bounds[0][0], leg=nm), db.nseq)
         rec = np.frombuffer(leg.timed_compact.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
         lr["workload"] = (f"the same index, {leg.n} synthetic 250-bp reads per step (mates of 192 - 287 nt: the six-unit stage 1, k_fragments_fast<.., 6>), kaiju -a mem"
                           if nm == "long" else
@@ -1049,7 +1063,7 @@ def main():
     if wide is not None:
         wix = wide["index"]
         for nm, leg in wide["legs"].items():
-            lr = leg.result(world, None, None, db.nseq * wide["copies"])
+            lr = leg.result(world, None, load_traffic(None, None, None, None, leg.bounds[0][1] - leg.bounds[0][0], leg=nm), db.nseq * wide["copies"])
             rec = np.frombuffer(leg.timed_compact.cpu().numpy().tobytes(), dtype=api.COMPACT_DTYPE)
             lr["workload"] = (f"index of 2^32 rows and more: the benchmark database with every protein x {wide['copies']} (copy t under another "
                               f"taxon) = {wix.info.bwtlen} rows, .fmi {os.path.getsize(wide['fmi'])/1e9:.2f} GB written by kaiju_build_fmi_replicated "

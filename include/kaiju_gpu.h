@@ -289,6 +289,14 @@ void kaiju_gpu_taxonomy_free(kaiju_gpu_taxonomy *t);
    stream, i.e. behind a classify_batch_device call that was also given NULL) */
 int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const kaiju_gpu_hit *d_hits,
                                uint32_t n_reads, kaiju_gpu_compact *d_out, void *stream);
+/* kaiju_gpu_classify_batch_device + kaiju_gpu_lca_batch_device in ONE call (round 6): where the configuration allows - MEM on an
+   index below 2^32 rows with its row -> taxon table - the search's post-search pass writes the 16-byte records itself instead
+   of a pass of its own over the 184-byte ones; everywhere else this is the two calls.  d_hits (n records) is written as by
+   kaiju_gpu_classify_batch_device.  What the reference does at this point: ids_from_SI + lca_from_ids per read in its
+   ConsumerThread (src/ConsumerThread.cpp:591-612, src/util.cpp:194-263) */
+int kaiju_gpu_classify_batch_device_compact(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const void *d_seqs, uint64_t seq_bytes,
+                                            const uint64_t *d_off, uint32_t n_reads, int paired,
+                                            kaiju_gpu_hit *d_hits, kaiju_gpu_compact *d_out, void *stream);
 /* kaiju_gpu_classify_batch followed by the LCA on the device: host buffers in, 16-byte records out */
 int kaiju_gpu_classify_batch_compact(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const char *seqs,
                                      const uint64_t *off, uint32_t n_reads, int paired, kaiju_gpu_compact *out);

@@ -99,6 +99,8 @@ def lib():
     L.kaiju_gpu_taxonomy_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.kaiju_gpu_taxonomy_free.argtypes = [C.c_void_p]
     L.kaiju_gpu_lca_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.kaiju_gpu_classify_batch_device_compact.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
+                                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kaiju_gpu_classify_batch_verbose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p,
                                                    C.c_void_p, C.c_void_p, C.c_uint32]
     L.kaiju_gpu_index_seq_name.restype = C.c_char_p
@@ -318,6 +320,13 @@ class Classifier:
         """hit records -> 16-byte compact records (LCA on the device); asynchronous on ``stream``."""
         _check(lib().kaiju_gpu_lca_batch_device(self._h, dtax._h, d_hits_ptr, n, d_out_ptr, stream))
 
+    def classify_device_compact(self, dtax: "DeviceTaxonomy", d_seqs_ptr: int, seq_bytes: int, d_off_ptr: int, n: int,
+                                d_hits_ptr: int, d_out_ptr: int, paired=False, stream: int = 0):
+        """classify_device + lca_device in one call (kaiju_gpu_classify_batch_device_compact): the search's own post-search
+        pass writes the 16-byte records where the configuration allows"""
+        _check(lib().kaiju_gpu_classify_batch_device_compact(self._h, dtax._h, d_seqs_ptr, seq_bytes, d_off_ptr, n,
+                                                             1 if paired else 0, d_hits_ptr, d_out_ptr, stream))
+
     def classify_verbose(self, seqs: np.ndarray, off: np.ndarray, paired=False):
         """kaiju -v: (hit records, per read the sorted accession list of column 6, the text of column 7)"""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
@@ -356,7 +365,7 @@ class Classifier:
 
     OP_COUNT_NAMES = ("kmer_lookups", "update_si", "update_si_lines", "lf_steps", "lf_lines", "sa_samples", "read_meta",
                       "frag_desc", "window_fills", "term_searches", "si_spills", "hits", "multi_letter_steps", "items_read",
-                      "matches_read", "items_written", "matches_written", "wave_iterations", "lane_iterations", "record_bytes")
+                      "matches_read", "items_written", "matches_written", "wave_iterations", "lane_iterations", "record_bytes", "window_lines")
 
     def count_ops(self, on: bool):
         """accounting: the next batches run the counting instantiation of the search lane (never a timed launch)"""

@@ -46,6 +46,7 @@ using namespace kj;
 // kernels
 // ----------------------------------------------------------------------------------------
 constexpr int kBlock = 256;
+constexpr uint32_t kLocDeferRows = 8;     // k_mem_locate / k_mem_post1: reads whose matches hold more rows go to the many-rows instantiation
 
 __device__ __forceinline__ void load_tables(ConstTables &s_ct, const ConstTables *g_ct) {
   const uint32_t *src = reinterpret_cast<const uint32_t *>(g_ct);
@@ -197,6 +198,95 @@ k_seg_apply_list(const ConstTables *__restrict__ g_ct, Params p, Batch b, SegQue
   if (e) atomicOr(err, e);
 }
 
+// ---- the post-search pass of the narrow MEM lanes, fused (round 6) ---------------------------------------------------------
+// Until round 5 the records of a batch were streamed four times behind k_mem: k_trigcheck (4 bytes of 184 looked at),
+// k_mem_locate, k_mem_locate_list and - a call of its own - k_lca.  k_mem_post1 is the three of them in ONE pass for the reads
+// whose record is final after it (93 % of the benchmark's): the lazy-SEG look at the fragment that holds the longest matches
+// (k_trigcheck's test), the ids of the matches (mem_locate_read, row -> taxon table) and, LCA, the 16-byte record
+// (lca_from_ids util.cpp:194-263).  Reads that are not through - listed for the SEG pass, sent to the retry pass, matches of
+// many rows - go on the `todo` list; k_mem_post2 finishes them behind the second search, the retry pass and the exact pass.
+template <bool LCA>
+__global__ void __launch_bounds__(256)
+k_mem_post1(const Stage1Tables *__restrict__ g_t, DevIndex ix, Params p, Batch b, DevTaxonomy t, CompactHit *__restrict__ compact, int lazy,
+            uint32_t *seglist, uint32_t *segcount, uint32_t *todo, uint32_t *todocount) {
+  __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
+  __shared__ __attribute__((aligned(4))) uint8_t s_cnt[256 * kS1CntStride];
+  __shared__ __attribute__((aligned(4))) uint8_t s_ts[256 * kTsBuf];
+  if (lazy) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
+    uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
+    for (uint32_t i = threadIdx.x; i < sizeof(Stage1Tables) / 16; i += 256) dst[i] = src[i];
+    __syncthreads();
+  }
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  bool need = false, later = false;
+  if (r < b.n_reads) {
+    Hit *h = b.hits + r;
+    const uint32_t v = lazy ? h->reserved : 0u;
+    if (v != 0) {
+      h->reserved = 0;
+      need = v == kWinForce;
+      if (!need) {
+        uint8_t *row = s_cnt + threadIdx.x * kS1CntStride, *buf = s_ts + threadIdx.x * kTsBuf;
+        const ReadMeta rm = b.meta[r];
+        const Frag *F = b.frags + rm.frag;
+        const uint8_t *pep = b.pep + rm.pep;
+        if (!(v & kWinMulti)) {
+          const Frag f = F[(v & ~kWinMulti) - 1u];
+          need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
+        } else {
+          // several fragments hold a longest match: every fragment long enough to be one of them is looked at
+          const uint32_t best = h->best, nf = rm.nfrag & ~kNfragSegPending;
+          for (uint32_t k = 0; k < nf && !need; k++) {
+            const Frag f = F[k];
+            if (f.len >= best) need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
+          }
+        }
+      }
+    }
+    if (!need) {
+      if (h->flags & kHitRetry) later = true;                               // (the retry pass writes this record)
+      else if (!mem_locate_read<false>(ix, p, h, kLocDeferRows)) later = true;   // (matches of many rows: k_mem_post2's instantiation)
+      else if (LCA) compact[r] = compact_hit(t, *h);
+    }
+  }
+  // the two lists: one atomic per wavefront and list
+  const uint32_t lane = threadIdx.x & 63u;
+  {
+    const uint64_t m = __ballot(need);
+    if (m) {
+      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(segcount, (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, (int)leader, 64);
+      if (need) seglist[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+    }
+  }
+  {
+    const bool td = need || later;
+    const uint64_t m = __ballot(td);
+    if (m) {
+      const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(todocount, (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, (int)leader, 64);
+      if (td) todo[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+    }
+  }
+}
+template <bool LCA>
+__global__ void __launch_bounds__(256)
+k_mem_post2(DevIndex ix, Params p, Batch b, DevTaxonomy t, CompactHit *__restrict__ compact, const uint32_t *__restrict__ todo,
+            const uint32_t *__restrict__ todocount) {
+  const uint32_t n = *todocount;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t r = todo[i];
+    Hit *h = b.hits + r;
+    if (!mem_locate_read<false>(ix, p, h, kLocDeferRows)) mem_locate_read<false, true>(ix, p, h);
+    if (LCA) compact[r] = compact_hit(t, *h);
+  }
+}
+
 // Stage 1 for protein reads (kaiju -p, kaijup): one lane per read, peptides written in place
 __global__ void __launch_bounds__(kFragBlock)
 k_fragments_protein(const ConstTables *__restrict__ g_ct, Params p, SegTables st, Batch b, SegQueue sq, uint32_t *err) {
@@ -307,7 +397,6 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
 //  What such matches cost was the look-up of every row's taxon among the ids collected so far: reads whose matches hold more
 //  than kLocDeferRows rows are listed - one atomic per wavefront - and located by k_mem_locate_list, the instantiation that
 //  keeps the collected ids in registers)
-constexpr uint32_t kLocDeferRows = 8;
 __global__ void __launch_bounds__(256)
 k_mem_locate(DevIndex ix, Params p, Batch b, uint32_t *list, uint32_t *count) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
@@ -328,7 +417,10 @@ k_mem_locate_list(DevIndex ix, Params p, Batch b, const uint32_t *__restrict__ l
 }
 // Indexes without the row -> sequence table (wide ones; narrow ones that had no room for the text arrays): a TEAM of kLocTeam
 // lanes per read walks the rows of a match side by side (mem_locate_read_team)
-constexpr int kLocTeam = 8;
+#ifndef KJ_LOC_TEAM
+#define KJ_LOC_TEAM 8
+#endif
+constexpr int kLocTeam = KJ_LOC_TEAM;             // (a power of two up to 64; 16 and 32 measured in round 6: DESIGN.md 6b)
 __global__ void __launch_bounds__(256)
 k_mem_locate_wide(DevIndex ix, Params p, Batch b) {
   const uint32_t r = (blockIdx.x * 256 + threadIdx.x) / kLocTeam;
@@ -1590,6 +1682,23 @@ extern "C" int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, 
   });
 }
 
+struct kaiju_gpu_taxonomy {
+  int device = 0;
+  DevTaxonomy dev{};
+  std::vector<void *> allocs;
+  ~kaiju_gpu_taxonomy() {
+    (void)hipSetDevice(device);
+    for (void *p : allocs) (void)hipFree(p);
+  }
+};
+
+__global__ void __launch_bounds__(256)
+k_lca(DevTaxonomy t, const Hit *__restrict__ hits, uint32_t n, CompactHit *__restrict__ out) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n) return;
+  out[r] = compact_hit(t, hits[r]);
+}
+
 // ----------------------------------------------------------------------------------------
 // context
 // ----------------------------------------------------------------------------------------
@@ -1621,7 +1730,8 @@ struct kaiju_gpu_ctx {
   bool mem_v1 = false;             // KAIJU_GPU_MEM_LANE=v1 (read once, at context creation)
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
-  DevBuf seglist, loc_list;
+  DevBuf seglist, loc_list, todo_list;
+  bool fused_post = true;          // KAIJU_GPU_FUSED_POST=0: k_trigcheck / k_mem_locate / k_lca as separate passes (A/B measurements)
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
   DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
@@ -1632,7 +1742,7 @@ struct kaiju_gpu_ctx {
   ~kaiju_gpu_ctx() {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
-    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist, &loc_list,
+    DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist, &loc_list, &todo_list,
                      &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry,
                      &redo_bitmap, &redo_list, &redo_items, &redo_index, &redo_pool, &redo_work, &redo_cls};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
@@ -1691,6 +1801,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   c->dump_frags = getenv("KAIJU_GPU_DUMP_FRAGS");
   if (const char *e = getenv("KAIJU_GPU_STAGE1")) c->stage1_old = !strcmp(e, "old");
   if (const char *e = getenv("KAIJU_GPU_LAZY_SEG")) c->lazy_seg = atoi(e) != 0;
+  if (const char *e = getenv("KAIJU_GPU_FUSED_POST")) c->fused_post = atoi(e) != 0;
   // kaijux: the MEM search of ConsumerThreadx.cpp:135 (maxMatches(.., 1)) finds the same longest matches as
   // greedyExact but lists them in another order, which shows where the id cap cuts and in the peptides of -v
   if (ix->id_mode == KAIJU_GPU_IDS_SEQUENCE && p->mode == 0) c->kp.flags |= kParamXOrder;
@@ -1744,8 +1855,11 @@ extern "C" void kaiju_gpu_destroy(kaiju_gpu_ctx *ctx) { delete ctx; }
 
 // counters buffer layout (uint32): [0] main work counter, [1] retry work counter,
 // [2] retry list length, [3] stage-1 error flags
+// tax / d_compact: not null = the 16-byte records (LCA on the device) are written too - by the fused post-search pass where
+// that serves the configuration (k_mem_post1 / k_mem_post2), by k_lca behind everything else otherwise
 static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes, const uint64_t *d_off,
-                        uint32_t n, int paired, uint32_t max_read_len, kaiju_gpu_hit *d_out, hipStream_t s) {
+                        uint32_t n, int paired, uint32_t max_read_len, kaiju_gpu_hit *d_out, hipStream_t s,
+                        const kaiju_gpu_taxonomy *tax = nullptr, kaiju_gpu_compact *d_compact = nullptr) {
   const kaiju_gpu_index *ix = c->ix;
   const Params &p = c->kp;
   if (max_read_len == 0) max_read_len = 1024;
@@ -1789,6 +1903,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
+  bool fused = false;              // the records (and, with a taxonomy, the 16-byte records) are finished by k_mem_post1 / _post2
   const dim3 grid_team((unsigned)(((uint64_t)n * kLocTeam + 255) / 256));          // k_mem_locate_wide / _team: kLocTeam lanes per read
   // which stage 1 / SEG flow: the fast stage 1 serves mates up to kS1MaxLenLong nucleotides (two instantiations); in MEM mode on the second-generation
   // lanes SEG is then looked at lazily (kj_core.h: kParamLazySeg), everywhere else stage 1 detects the SEG trigger itself
@@ -1917,12 +2032,27 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main, si_main, si_cap, vb);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
+      // the fused post-search pass (k_mem_post1 / _post2): narrow lanes with the row -> taxon table, SEG lazily or not at all
+      // (an eager SEG pass may send ANY read to the exact pass: nothing is final before that)
+      fused = mem_v2 && mem_narrow2 && ix->dev.row_tax && (lazy || !p.seg) && c->fused_post;
+      uint32_t *todo = nullptr;
+      const DevTaxonomy dt = tax ? tax->dev : DevTaxonomy{};
+      CompactHit *const cmp = reinterpret_cast<CompactHit *>(d_compact);
+      if (fused) {
+        if ((rc = ensure(c->seglist, (size_t)n * 4 + 16))) return rc;
+        if ((rc = ensure(c->todo_list, (size_t)n * 4 + 16))) return rc;
+        todo = static_cast<uint32_t *>(c->todo_list.p);
+        uint32_t *seglist = static_cast<uint32_t *>(c->seglist.p);
+        if (tax) hipLaunchKernelGGL(k_mem_post1<true>, grid_reads, dim3(256), 0, s, ix->d_s1, ix->dev, p, b, dt, cmp, lazy ? 1 : 0, seglist, cnt + 22, todo, cnt + 26);
+        else hipLaunchKernelGGL(k_mem_post1<false>, grid_reads, dim3(256), 0, s, ix->d_s1, ix->dev, p, b, dt, cmp, lazy ? 1 : 0, seglist, cnt + 22, todo, cnt + 26);
+        KJ_HIP(hipGetLastError());
+      }
       if (lazy) {
         // reads whose longest matches lie in fragments that SEG would cut: listed, SEG pass for their fragments, the
         // lists rewritten, searched again (counters: [22] listed reads, [23] work counter of that search)
         if ((rc = ensure(c->seglist, (size_t)n * 4 + 16))) return rc;
         uint32_t *seglist = static_cast<uint32_t *>(c->seglist.p);
-        hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->d_s1, b, seglist, cnt + 22);
+        if (!fused) hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->d_s1, b, seglist, cnt + 22);
         hipLaunchKernelGGL(k_segflag, dim3(c->n_cu * 4), dim3(256), 0, s, p, ix->st, b, sq, seglist, cnt + 22, cnt + 3);
         hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 32), dim3(kSegBlock), 0, s, p, ix->st, b, sq);
         hipLaunchKernelGGL(k_seg_apply_list, dim3(c->n_cu * 4), blk, 0, s, ix->d_ct, p, b, sq, seglist, cnt + 22, cnt + 3);
@@ -1935,7 +2065,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
-      if (defer) {
+      if (defer && !fused) {
         if (mem_narrow2 && ix->dev.row_tax) {
           hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
           hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
@@ -1948,6 +2078,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         xp.si = static_cast<SIEntry *>(c->scratch_retry[0].p); xp.si_cap = si_cap_retry; xp.blocks_search = blocks_retry;
         xp.vb = vb;
         KJ_HIP(kj_launch_exact_pass(xp));
+      }
+      if (fused) {
+        // the reads that were not through after k_mem_post1 (second search, retry pass, exact pass, matches of many rows)
+        if (tax) hipLaunchKernelGGL(k_mem_post2<true>, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, dt, cmp, todo, cnt + 26);
+        else hipLaunchKernelGGL(k_mem_post2<false>, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, dt, cmp, todo, cnt + 26);
+        KJ_HIP(hipGetLastError());
       }
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
   } else {
@@ -2040,6 +2176,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       }
     } else KJ_HIP(hipEventRecord(c->ev[3], s));
   }
+  if (tax && !fused && n > 0) {
+    hipLaunchKernelGGL(k_lca, dim3((n + 255) / 256), dim3(256), 0, s, tax->dev, reinterpret_cast<const Hit *>(d_out), n,
+                       reinterpret_cast<CompactHit *>(d_compact));
+    KJ_HIP(hipGetLastError());
+  }
   KJ_HIP(hipEventRecord(c->ev[4], s));
   c->ev_valid = true;
   c->last_n = n;
@@ -2082,7 +2223,8 @@ extern "C" int kaiju_gpu_classify_batch_device(kaiju_gpu_ctx *ctx, const void *d
 }
 
 // host buffers -> device, kernels queued on the context's stream; the hit records stay in ctx->h_hits
-static int classify_host_buffers(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads, int paired) {
+static int classify_host_buffers(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads, int paired,
+                                 const kaiju_gpu_taxonomy *tax = nullptr) {
   KJ_HIP(hipSetDevice(ctx->ix->device));
   if (off[0] != 0) return fail(KAIJU_GPU_ERR_ARG, "off[0] must be 0");
   const uint64_t seq_bytes = off[2 * (uint64_t)n_reads];
@@ -2101,8 +2243,10 @@ static int classify_host_buffers(kaiju_gpu_ctx *ctx, const char *seqs, const uin
   hipStream_t s = ctx->stream;
   if (seq_bytes) KJ_HIP(hipMemcpyAsync(ctx->h_seqs.p, seqs, seq_bytes, hipMemcpyHostToDevice, s));
   KJ_HIP(hipMemcpyAsync(ctx->h_off.p, off, (2 * (size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+  if (tax && (rc = ensure(ctx->h_compact, (size_t)n_reads * sizeof(kaiju_gpu_compact)))) return rc;
   return launch_batch(ctx, ctx->h_seqs.p, seq_bytes, static_cast<const uint64_t *>(ctx->h_off.p), n_reads, paired,
-                      max_len ? max_len : 1, static_cast<kaiju_gpu_hit *>(ctx->h_hits.p), s);
+                      max_len ? max_len : 1, static_cast<kaiju_gpu_hit *>(ctx->h_hits.p), s, tax,
+                      tax ? static_cast<kaiju_gpu_compact *>(ctx->h_compact.p) : nullptr);
 }
 
 extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off,
@@ -2119,6 +2263,20 @@ extern "C" int kaiju_gpu_classify_batch(kaiju_gpu_ctx *ctx, const char *seqs, co
   });
 }
 
+// kaiju_gpu_classify_batch_device and kaiju_gpu_lca_batch_device in one call: the 16-byte records are written by the search's
+// own post-search pass where the configuration allows (no separate pass over the 184-byte records)
+extern "C" int kaiju_gpu_classify_batch_device_compact(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const void *d_seqs, uint64_t seq_bytes,
+                                                       const uint64_t *d_off, uint32_t n_reads, int paired,
+                                                       kaiju_gpu_hit *d_hits, kaiju_gpu_compact *d_out, void *stream) {
+  return guarded([&]() -> int {
+  if (!ctx || !t || (!d_seqs && seq_bytes) || !d_off || (!d_hits && n_reads) || (!d_out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  if (t->device != ctx->ix->device) return fail(KAIJU_GPU_ERR_ARG, "taxonomy lives on another device");
+  KJ_HIP(hipSetDevice(ctx->ix->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  return launch_batch(ctx, d_seqs, seq_bytes, d_off, n_reads, paired, ctx->max_read_len, d_hits, s, t, d_out);
+  });
+}
+
 extern "C" int kaiju_gpu_set_max_read_length(kaiju_gpu_ctx *ctx, uint32_t max_read_len) {
   if (!ctx || max_read_len == 0 || max_read_len > 0x3fffffffu) return fail(KAIJU_GPU_ERR_ARG, "bad max_read_len");
   ctx->max_read_len = max_read_len;
@@ -2126,23 +2284,6 @@ extern "C" int kaiju_gpu_set_max_read_length(kaiju_gpu_ctx *ctx, uint32_t max_re
 }
 
 // ---- LCA on the device ---------------------------------------------------------------------------
-struct kaiju_gpu_taxonomy {
-  int device = 0;
-  DevTaxonomy dev{};
-  std::vector<void *> allocs;
-  ~kaiju_gpu_taxonomy() {
-    (void)hipSetDevice(device);
-    for (void *p : allocs) (void)hipFree(p);
-  }
-};
-
-__global__ void __launch_bounds__(256)
-k_lca(DevTaxonomy t, const Hit *__restrict__ hits, uint32_t n, CompactHit *__restrict__ out) {
-  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= n) return;
-  out[r] = compact_hit(t, hits[r]);
-}
-
 extern "C" int kaiju_gpu_taxonomy_upload(const kaiju_taxonomy *t, int device_id, kaiju_gpu_taxonomy **out) {
   return guarded([&]() -> int {
   if (!t || !out) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
@@ -2253,13 +2394,9 @@ extern "C" int kaiju_gpu_classify_batch_compact(kaiju_gpu_ctx *ctx, const kaiju_
   if (!ctx || !t || !off || (!out && n_reads)) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   if (t->device != ctx->ix->device) return fail(KAIJU_GPU_ERR_ARG, "taxonomy lives on another device");
   if (n_reads == 0) return KAIJU_GPU_OK;
-  int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
+  int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired, t);      // (the 16-byte records come with the search)
   if (rc) return rc;
-  if ((rc = ensure(ctx->h_compact, (size_t)n_reads * sizeof(kaiju_gpu_compact)))) return rc;
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k_lca, dim3((n_reads + 255) / 256), dim3(256), 0, s, t->dev,
-                     static_cast<const Hit *>(ctx->h_hits.p), n_reads, static_cast<CompactHit *>(ctx->h_compact.p));
-  KJ_HIP(hipGetLastError());
   KJ_HIP(hipMemcpyAsync(out, ctx->h_compact.p, (size_t)n_reads * sizeof(kaiju_gpu_compact), hipMemcpyDeviceToHost, s));
   KJ_HIP(hipStreamSynchronize(s));
   return KAIJU_GPU_OK;

@@ -1940,7 +1940,9 @@ KJ_HD unsigned long long *opc_of(const WorkList &wl) {
 // a timed launch.
 enum OpCount : int {
   kOpcKmer, kOpcStep, kOpcStepLines, kOpcLf, kOpcLfLines, kOpcSa, kOpcMeta, kOpcFrag, kOpcFill, kOpcTerm, kOpcSiSpill,
-  kOpcHit, kOpcVmulti, kOpcPopItem, kOpcMload, kOpcPush, kOpcMatchWr, kOpcIters, kOpcLaneIters, kOpcRecBytes, kOpcN
+  kOpcHit, kOpcVmulti, kOpcPopItem, kOpcMload, kOpcPush, kOpcMatchWr, kOpcIters, kOpcLaneIters, kOpcRecBytes,
+  kOpcFillLines,             // 128-byte lines the 64-byte window / text loads touch (unaligned: one or two each; MEM lanes)
+  kOpcN
 };
 #if defined(__HIP_DEVICE_COMPILE__)
 KJ_HD void opc_flush(unsigned long long *dst, const uint32_t *oc) {
@@ -2462,6 +2464,8 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
                            : WIDE ? ix.text + (size_t)((uint64_t)k - (uint64_t)kTextCmp) : ix.text + (kidx - (uint32_t)kTextCmp);
       const u128_unaligned *s16 = reinterpret_cast<const u128_unaligned *>(src);
       w0 = s16[0]; w1 = s16[1]; w2 = s16[2]; w3 = s16[3];
+      if constexpr (COUNT)
+        if (kind == K_FILL || kind == K_TEXT) oc[kOpcFillLines] += ((uint32_t)(reinterpret_cast<uintptr_t>(src) & 127u) + 64u > 128u) ? 2u : 1u;
     }
 
     // ---- (2) compute ----
@@ -2955,9 +2959,12 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
 //   TeamWave<T> (device): shuffles;  TeamSerial<T> (host emulation): the T walks run one after the other into an array.
 template <int T>
 struct TeamSerial {
-  uint64_t vals[T];
+  uint64_t vals[T], vals2[T];
   template <class F> KJ_HD void compute(F &&f) { for (int tl = 0; tl < T; tl++) vals[tl] = f(tl); }
   KJ_HD uint64_t get(int q) const { return vals[q]; }
+  // two rows per lane (KJ_LOC_ILP): f(tl, a, b) fills the ids of rows tl and T + tl of the round
+  template <class F> KJ_HD void compute2(F &&f) { for (int tl = 0; tl < T; tl++) f(tl, vals[tl], vals2[tl]); }
+  KJ_HD uint64_t get2(int q) const { return vals2[q]; }
   KJ_HD bool leader() const { return true; }
   KJ_HD bool from_leader(bool v) const { return v; }
   // the matches of the read (row | length, up to kLocMaxEntries), copied before the first id is written over them
@@ -2968,21 +2975,27 @@ struct TeamSerial {
 #if defined(__HIPCC__)
 template <int T>
 struct TeamWave {
-  uint64_t mine;
+  uint64_t mine, mine2 = ~0ull;
   template <class F> __device__ __forceinline__ void compute(F &&f) { mine = f((int)(threadIdx.x & (T - 1))); }
   __device__ __forceinline__ uint64_t get(int q) const {
     const int src = (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)) + q;
     return (uint64_t)(uint32_t)__shfl((int)(uint32_t)mine, src, 64) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(mine >> 32), src, 64) << 32;
   }
+  template <class F> __device__ __forceinline__ void compute2(F &&f) { f((int)(threadIdx.x & (T - 1)), mine, mine2); }
+  __device__ __forceinline__ uint64_t get2(int q) const {
+    const int src = (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)) + q;
+    return (uint64_t)(uint32_t)__shfl((int)(uint32_t)mine2, src, 64) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(mine2 >> 32), src, 64) << 32;
+  }
   __device__ __forceinline__ bool leader() const { return (threadIdx.x & (T - 1)) == 0; }
   __device__ __forceinline__ bool from_leader(bool v) const { return __shfl((int)v, (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)), 64) != 0; }
   // the matches of the read (row | length, up to kLocMaxEntries): lane t of the team keeps entries t, t + T, .. in registers - the
   // leader writes ids over them later - and hands one out by a shuffle
-  uint64_t ent[kLocMaxEntries / T];
+  static constexpr uint32_t kEnt = (kLocMaxEntries + T - 1) / T;
+  uint64_t ent[kEnt];
   __device__ __forceinline__ void load_entries(const uint64_t *rec, uint32_t n) {
     const uint32_t tl = threadIdx.x & (T - 1);
 #pragma unroll
-    for (uint32_t q = 0; q < kLocMaxEntries / T; q++) ent[q] = tl + q * T < n ? rec[tl + q * T] : 0ull;
+    for (uint32_t q = 0; q < kEnt; q++) ent[q] = tl + q * T < n ? rec[tl + q * T] : 0ull;
   }
   __device__ __forceinline__ uint64_t entry(uint32_t q) const {
     const int src = (int)((threadIdx.x & 63u) & ~(uint32_t)(T - 1)) + (int)(q % T);
@@ -2990,6 +3003,9 @@ struct TeamWave {
     return (uint64_t)(uint32_t)__shfl((int)(uint32_t)v, src, 64) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64) << 32;
   }
 };
+#endif
+#ifndef KJ_LOC_ILP
+#define KJ_LOC_ILP 1                      // rows a lane of a locate team walks side by side (2: DESIGN.md 6b, round 6)
 #endif
 template <bool WIDE, int T, class Team>
 KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, Team &team) {
@@ -3050,6 +3066,82 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
     const P lo = WIDE ? (P)(es & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)es;
     const uint32_t len = WIDE ? (uint32_t)(es >> kLocWideShift) : (uint32_t)(es >> 32);
     const P rowend = lo + (P)(int32_t)len;
+#if KJ_LOC_ILP == 2
+    // two rows per lane and round, their walks interleaved step by step: the loads of the two are in flight together (a walk is
+    // a chain of dependent loads, and matches of fifteen or twenty-three rows - a refseq-class index holds every protein in many
+    // near-identical copies - took two or three rounds of T rows one after the other)
+    for (P row0 = lo; row0 < rowend && !done; row0 += (P)(2 * T)) {
+      team.compute2([&](int tl, uint64_t &ta, uint64_t &tb) {
+        const P ra = row0 + (P)tl, rb2 = row0 + (P)T + (P)tl;
+        if constexpr (!WIDE) if (ix.row_tax) { ta = ra < rowend ? walk(ra) : ~0ull; tb = rb2 < rowend ? walk(rb2) : ~0ull; return; }
+        P k[2] = {ra, rb2};
+        bool fin[2] = {!(ra < rowend), !(rb2 < rowend)};
+        uint64_t res[2] = {~0ull, ~0ull};
+        while (!(fin[0] && fin[1])) {
+          // rows that stand on a sample (or beyond the samples) are through; the others load their rank block
+          const RankBlock64 *rbp[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            if (!fin[h] && (k[h] & check) == 0) {
+              const uint64_t sa_idx = ((uint64_t)k[h] >> ix.chpt_exp) - ix.sa_skip;
+              if (sa_idx < ix.n_sa) {
+                if constexpr (WIDE) { const uint32_t iseq = ix.sa_iseq[sa_idx]; res[h] = iseq < ix.nseq ? ix.seq_taxid[iseq] : ~0ull; }
+                else res[h] = ix.sa_taxid[sa_idx];
+              }
+              fin[h] = true;
+            }
+            rbp[h] = blk0 + (fin[h] ? (P)0 : (k[h] >> 6));
+          }
+          uint64_t pl[2][5];
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) pl[h][x] = rbp[h]->plane[x];
+          uint32_t cc[2];
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const uint32_t sft = (uint32_t)k[h] & 63u;
+            cc[h] = (uint32_t)((pl[h][0] >> sft) & 1ull) | (uint32_t)((pl[h][1] >> sft) & 1ull) << 1 | (uint32_t)((pl[h][2] >> sft) & 1ull) << 2 |
+                    (uint32_t)((pl[h][3] >> sft) & 1ull) << 3 | (uint32_t)((pl[h][4] >> sft) & 1ull) << 4;
+          }
+          uint64_t base[2] = {0, 0};
+          uint32_t cnt[2] = {0, 0};
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            if (fin[h] || cc[h] == 0) continue;
+            if constexpr (WIDE) base[h] = ix.mb_base[(size_t)((uint64_t)k[h] >> ix.mb_shift) * 20 + (cc[h] - 1u)];
+            cnt[h] = rbp[h]->cnt[cc[h] - 1u];
+          }
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            if (fin[h]) continue;
+            if (cc[h] == 0) {
+              // the walk ran into the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+              const uint32_t iseq = (uint32_t)rank_term(ix, k[h]);
+              res[h] = iseq < ix.nseq ? ix.seq_taxid[iseq] : ~0ull;
+              fin[h] = true;
+              continue;
+            }
+            const uint32_t c = cc[h], sft = (uint32_t)k[h] & 63u;
+            const uint64_t ia = (c & 1u) ? 0ull : ~0ull, ib = (c & 2u) ? 0ull : ~0ull, ic = (c & 4u) ? 0ull : ~0ull,
+                           id = (c & 8u) ? 0ull : ~0ull, ie = (c & 16u) ? 0ull : ~0ull;
+            const uint64_t m = (pl[h][0] ^ ia) & (pl[h][1] ^ ib) & (pl[h][2] ^ ic) & (pl[h][3] ^ id) & (pl[h][4] ^ ie);
+            k[h] = (P)(base[h] + cnt[h] + popc64(m & ((1ull << sft) - 1ull)));
+          }
+        }
+        ta = res[0]; tb = res[1];
+      });
+#pragma unroll
+      for (int hq = 0; hq < 2 * T; hq++) {
+        const uint64_t tax = hq < T ? team.get(hq) : team.get2(hq - T);
+        if (team.leader() && !done && row0 + (P)hq < rowend) {
+          if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; }     // :805-807, tested in front of every row
+          else if (tax != ~0ull) add_tax(tax);
+        }
+      }
+      done = team.from_leader(done);
+    }
+#else
     for (P row0 = lo; row0 < rowend && !done; row0 += (P)T) {
       team.compute([&](int tl) -> uint64_t { const P row = row0 + (P)tl; return row < rowend ? walk(row) : ~0ull; });
 #pragma unroll
@@ -3062,6 +3154,7 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
       }
       done = team.from_leader(done);
     }
+#endif
   }
   if (!team.leader()) return;
   for (uint32_t q = nids; q < nsi; q++) hit->taxid[q] = 0;   // (the slots that held the matches and got no id)

@@ -27,6 +27,11 @@ def oracle():
 def emu():
     """the kernel logic of kaiju_amd/csrc/kj_core.h compiled for the host (test infrastructure)"""
     import util
+    # KAIJU_EMU_DEFINES="KJ_LOC_ILP=2 ...": the whole emulator suite on a compile-time variant of the lanes (a library of its own)
+    defs = tuple(os.environ.get("KAIJU_EMU_DEFINES", "").split())
+    if defs:
+        tag = "".join(c if c.isalnum() else "_" for c in "_".join(defs))
+        return util.Emu(so=os.path.join(util.EMU_DIR, f"libkaiju_kernel_emu_{tag}.so"), defines=defs)
     return util.Emu()
 
 

@@ -515,8 +515,45 @@ def test_device_resident_entry_points(gpu_lib, golden, gidx, mode):
                 assert oc["update_si"] <= oc["update_si_lines"] <= 2 * (oc["update_si"] + oc["multi_letter_steps"])
     got = clf.classify_compact(dtax, seqs, off)
     assert (got == want).all()
+    # kaiju_gpu_classify_batch_device_compact: the two calls in one (MEM: the fused post-search pass writes the 16-byte records)
+    for stream in (0, hip.stream()):
+        hip.memset(d_hits, n * 184)
+        hip.memset(d_rec, n * 16)
+        clf.classify_device_compact(dtax, d_seqs, seqs.nbytes, d_off, n, d_hits, d_rec, stream=stream)
+        clf.synchronize()
+        hits = np.frombuffer(hip.d2h(d_hits, n * 184).tobytes(), dtype=api.HIT_DTYPE)
+        rec = np.frombuffer(hip.d2h(d_rec, n * 16).tobytes(), dtype=api.COMPACT_DTYPE)
+        assert all(util.same_hit(a, b) for a, b in zip(want_hits, hits)), stream != 0
+        assert (rec == want).all(), stream != 0
     for p in (d_seqs, d_off, d_hits, d_rec):
         hip.free(p)
+
+
+@pytest.mark.parametrize("seg", [1, 0])
+def test_fused_post_search_pass(gpu_lib, big, seg, monkeypatch):
+    """k_mem_post1 / _post2 (the lazy-SEG look, the locate and the LCA in one pass over the records) write what k_trigcheck,
+    k_mem_locate, k_mem_locate_list and k_lca wrote as separate passes (KAIJU_GPU_FUSED_POST=0): hit records and 16-byte records
+    of 1 M benchmark reads, single and paired"""
+    api = gpu_lib
+    from kaiju_amd import synth
+    tax = api.Taxonomy(f"{big['W']}/nodes.dmp")
+    dtax = api.DeviceTaxonomy(tax, 0)
+    n = min(1000000, len(big["reads"]))
+    for paired in (False, True):
+        if paired:
+            s2, o2 = synth.pack_reads(big["reads"][:n // 2], big["reads"][n // 2:n])
+        else:
+            s2, o2 = synth.pack_reads(big["reads"][:n])
+        out = {}
+        for fused in ("0", "1"):
+            monkeypatch.setenv("KAIJU_GPU_FUSED_POST", fused)
+            clf = api.Classifier(big["index"], api.default_params("mem", seg=seg))
+            hits = clf.classify(s2, o2, paired=paired).copy()
+            assert clf.stats().error_flags == 0
+            out[fused] = (hits, clf.classify_compact(dtax, s2, o2, paired=paired).copy(), clf.lca(dtax, hits).copy())
+        for f in ("best", "n_ids", "flags", "reserved", "taxid"):
+            assert (out["0"][0][f] == out["1"][0][f]).all(), (paired, f)
+        assert (out["0"][1] == out["1"][1]).all() and (out["1"][1] == out["1"][2]).all(), paired
 
 
 def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, monkeypatch):
