@@ -291,8 +291,10 @@ int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, 
                                uint32_t n_reads, kaiju_gpu_compact *d_out, void *stream);
 /* kaiju_gpu_classify_batch_device + kaiju_gpu_lca_batch_device in ONE call (round 6): where the configuration allows - MEM on an
    index below 2^32 rows with its row -> taxon table - the search's post-search pass writes the 16-byte records itself instead
-   of a pass of its own over the 184-byte ones; everywhere else this is the two calls.  d_hits (n records) is written as by
-   kaiju_gpu_classify_batch_device.  What the reference does at this point: ids_from_SI + lca_from_ids per read in its
+   of a pass of its own over the 184-byte ones; everywhere else this is the two calls.  d_hits (n records) is the search's working
+   set here, not an output: behind the call best / n_ids / flags and the first n_ids ids of every record are what
+   kaiju_gpu_classify_batch_device writes, the id slots behind them are unspecified (not zeroed: 1.84 GB less to write per
+   10 M reads).  What the reference does at this point: ids_from_SI + lca_from_ids per read in its
    ConsumerThread (src/ConsumerThread.cpp:591-612, src/util.cpp:194-263) */
 int kaiju_gpu_classify_batch_device_compact(kaiju_gpu_ctx *ctx, const kaiju_gpu_taxonomy *t, const void *d_seqs, uint64_t seq_bytes,
                                             const uint64_t *d_off, uint32_t n_reads, int paired,

@@ -38,7 +38,9 @@
 #include "kj_core.h"
 #include "taxonomy.h"
 #include "exact_pass.h"
+#ifdef KJ_GREEDY3                    // the experimental row-pool Greedy lane: variant builds only
 #include "kj_greedy3.h"
+#endif
 
 using namespace kj;
 
@@ -614,6 +616,7 @@ k_greedy2_wide_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p
   greedy2_body<true, true>(ix, g_ct, p, sq, b, wl, ga);
 }
 
+#ifdef KJ_GREEDY3
 // third-generation Greedy (kj_greedy3.h): ONE block of kG3Threads threads per CU owns kG3Pool reads as rows of LDS, its
 // wavefronts pull rows by class - the lanes of a wavefront run the same piece of the algorithm.  Narrow indexes with k-mer lines.
 template <bool COUNT>
@@ -661,6 +664,8 @@ __global__ void __launch_bounds__(kG3Threads, 2)
 k_greedy3_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga, uint32_t split) {
   greedy3_body<true>(ix, g_ct, p, sq, b, wl, ga, split);
 }
+
+#endif
 
 // Index load: the k-mer table one letter deeper.  child[idx * 20 + c - 1] = UpdateSI(parent[idx], c)
 // (bwt.c:160-173) for all 20 letters from the two rank blocks at the ends of the parent's interval;
@@ -1721,7 +1726,7 @@ struct kaiju_gpu_ctx {
   bool greedy2 = false;
   bool greedy3 = false;            // KAIJU_GPU_GREEDY_LANE=v3: the row-pool lane (kj_greedy3.h; narrow index with k-mer lines)
   uint32_t g3_split = 1;           // KAIJU_GPU_G3_SPLIT
-  uint32_t g3_threads = kG3Threads;// KAIJU_GPU_G3_THREADS (a multiple of 64)
+  uint32_t g3_threads = 512;       // KAIJU_GPU_G3_THREADS (a multiple of 64)
   uint32_t greedy_gate = 1u | 32u << 8;   // heavy iteration every 2nd, or as soon as half the wavefront waits for one (measured: r02_gprof; round 3,
                                            // with the span rule and the probes thinning the fast iterations: every 2nd beats every 4th, profiles/r03_l14)
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
@@ -1820,9 +1825,15 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v1")) c->greedy2 = false; }
     // (the row-pool lane is parity-green but SLOWER than greedy_lane2 at the 480 rows a CU's LDS holds - DESIGN.md 6b, round 6:
     //  opt-in, KAIJU_GPU_GREEDY_LANE=v3)
+#ifdef KJ_GREEDY3
     if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) { if (!strcmp(e, "v3")) c->greedy3 = c->greedy2 && !g_wide; }
     if (const char *e = getenv("KAIJU_GPU_G3_SPLIT")) c->g3_split = (uint32_t)atoi(e);
     if (const char *e = getenv("KAIJU_GPU_G3_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= kG3Threads && v % 64 == 0) c->g3_threads = (uint32_t)v; }
+#else
+    if (const char *e = getenv("KAIJU_GPU_GREEDY_LANE")) {
+      if (!strcmp(e, "v3")) return fail(KAIJU_GPU_ERR_UNSUPPORTED, "KAIJU_GPU_GREEDY_LANE=v3: this library was built without -DKJ_GREEDY3 (tests/tools/mem_variants.sh, variant g3)");
+    }
+#endif
     if (const char *e = getenv("KAIJU_GPU_GREEDY_GATE")) { int v = atoi(e); if (v == 0 || v == 1 || v == 3 || v == 7 || v == 15) c->greedy_gate = (c->greedy_gate & ~0xffu) | (uint32_t)v; }
     // (bits 8..: heavy iteration as soon as that many lanes of the wavefront wait for the slow part; 0 = period only)
     if (const char *e = getenv("KAIJU_GPU_GREEDY_WAITERS")) { int v = atoi(e); if (v >= 0 && v <= 64) c->greedy_gate = (c->greedy_gate & 0xffu) | (uint32_t)v << 8; }
@@ -1900,7 +1911,6 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
 #else
   KJ_HIP(hipMemsetAsync(cnt, 0, 1024, s));
 #endif
-  if (n > 0) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));   // unused id slots read as 0
   KJ_HIP(hipEventRecord(c->ev[0], s));
   const dim3 grid_reads((n + kBlock - 1) / kBlock), blk(kBlock);
   bool fused = false;              // the records (and, with a taxonomy, the 16-byte records) are finished by k_mem_post1 / _post2
@@ -1914,6 +1924,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   const bool long1 = max_read_len > kS1MaxLen;              // (192 .. 287 nt: the instantiation with six units per frame string)
   const bool lazy = fast1 && mem_v2 && p.seg && c->lazy_seg;
   const bool trig1 = fast1 && p.seg && !lazy;
+  // the fused post-search pass (k_mem_post1 / _post2): narrow MEM lanes with the row -> taxon table, SEG lazily or not at all
+  // (an eager SEG pass may send ANY read to the exact pass: nothing is final before that)
+  fused = p.mode == 0 && mem_v2 && mem_narrow2 && ix->dev.row_tax && (lazy || !p.seg) && c->fused_post && n > 0;
+  // unused id slots read as 0.  Not with the 16-byte records as the output on the fused path: the lanes write the header of every
+  // record and the entries they announce in it, k_mem_post1 / _post2 read nothing else - d_hits is scratch there (1.84 GB less to
+  // write per 10 M reads)
+  if (n > 0 && !(fused && tax)) KJ_HIP(hipMemsetAsync(d_out, 0, (size_t)n * sizeof(kaiju_gpu_hit), s));
   if (n > 0) {
     // LDS staging area per lane: all frame strings of a read (or pair), rounded to 16 bytes
     uint32_t per_lane = (uint32_t)((2 * max_pair + 12 + 15) & ~15ull);
@@ -2032,9 +2049,6 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         hipLaunchKernelGGL(k_mem_wide, dim3(c->blocks_main), blk, 0, s, ix->dev, p, b, wl_main, si_main, si_cap, vb);
       KJ_HIP(hipGetLastError());
       KJ_HIP(hipEventRecord(c->ev[3], s));
-      // the fused post-search pass (k_mem_post1 / _post2): narrow lanes with the row -> taxon table, SEG lazily or not at all
-      // (an eager SEG pass may send ANY read to the exact pass: nothing is final before that)
-      fused = mem_v2 && mem_narrow2 && ix->dev.row_tax && (lazy || !p.seg) && c->fused_post;
       uint32_t *todo = nullptr;
       const DevTaxonomy dt = tax ? tax->dev : DevTaxonomy{};
       CompactHit *const cmp = reinterpret_cast<CompactHit *>(d_compact);
@@ -2093,7 +2107,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     const bool use_g2 = c->greedy2 && !c->verbose;
     const bool use_g3 = use_g2 && c->greedy3;
     // (the row-pool lane: one block per CU, kG3Pool rows each - its scratch in device memory is per ROW)
+#ifdef KJ_GREEDY3
     const uint64_t lanes_g2 = use_g3 ? (uint64_t)c->n_cu * kG3Pool : lanes_main;
+#else
+    const uint64_t lanes_g2 = lanes_main;
+#endif
     if (!use_g2) {
       if ((rc = ensure(c->scratch_main[0], lanes_main * ga.pool_cap * sizeof(GItem)))) return rc;
       if ((rc = ensure(c->scratch_main[1], lanes_main * ga.pool_cap * sizeof(uint16_t)))) return rc;
@@ -2141,11 +2159,14 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       Params pg = p;
       if (use_g2) pg.flags |= kParamDeferLocate;       // (greedy_lane2 leaves every read's best matches to k_mem_locate*)
       const bool g_wide = ix->dev.mb_base != nullptr;
+#ifdef KJ_GREEDY3
       if (use_g3 && c->count_ops)
         hipLaunchKernelGGL(k_greedy3_count, dim3(c->n_cu), dim3(c->g3_threads), 0, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2, c->g3_split);
       else if (use_g3)
         hipLaunchKernelGGL(k_greedy3, dim3(c->n_cu), dim3(c->g3_threads), 0, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2, c->g3_split);
-      else if (use_g2 && c->count_ops && g_wide)
+      else
+#endif
+      if (use_g2 && c->count_ops && g_wide)
         hipLaunchKernelGGL(k_greedy2_wide_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
       else if (use_g2 && g_wide)
         hipLaunchKernelGGL(k_greedy2_wide, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);

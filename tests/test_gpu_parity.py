@@ -592,6 +592,112 @@ def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, 
 
 
 @pytest.mark.parametrize("split", ["1", "0"])
+def test_greedy_row_pool_lane(gpu_lib, golden, big, split, tmp_path):
+    """the experimental row-pool Greedy lane (kj_greedy3.h: the reads of a block as rows of LDS, wavefronts pull rows by class; a
+    variant build, -DKJ_GREEDY3 + KAIJU_GPU_GREEDY_LANE=v3 - DESIGN.md 6b) writes the records greedy_lane2 writes: the golden
+    reads with and without SEG, 400 k benchmark reads.  The variant library is loaded by a process of its own."""
+    import subprocess
+    import sys
+    api = gpu_lib
+    lib = os.path.join(util.ROOT, "kaiju_amd", "variants", "libkaiju_gpu_g3.so")
+    deps = [os.path.join(util.ROOT, "kaiju_amd", "csrc", f) for f in ("capi.hip", "kj_core.h", "kj_greedy3.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
+        subprocess.run(["bash", os.path.join(util.ROOT, "tests", "tools", "mem_variants.sh"), "build"], check=True,
+                       env=dict(os.environ, VARIANTS="g3"))
+    from kaiju_amd import synth
+    n = min(400000, len(big["reads"]))
+    s2, o2 = synth.pack_reads(big["reads"][:n])
+    np.save(tmp_path / "seqs.npy", s2)
+    np.save(tmp_path / "off.npy", o2)
+    want = {}
+    for seg in (1, 0):
+        want[("golden", seg)] = api.Classifier(api.Index(golden.fmi), api.default_params("greedy", seg=seg)).classify(golden.seqs, golden.off).copy()
+    want[("big", 1)] = api.Classifier(big["index"], api.default_params("greedy", seg=1)).classify(s2, o2).copy()
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {util.ROOT!r}); sys.path.insert(0, {os.path.join(util.ROOT, 'tests')!r})
+import util
+from kaiju_amd import api
+g = util.Golden()
+for seg in (1, 0):
+    clf = api.Classifier(api.Index(g.fmi), api.default_params("greedy", seg=seg))
+    np.save({str(tmp_path)!r} + f"/golden_{{seg}}.npy", clf.classify(g.seqs, g.off))
+    assert clf.stats().error_flags == 0
+clf = api.Classifier(api.Index({big['W']!r} + "/db.fmi"), api.default_params("greedy", seg=1))
+np.save({str(tmp_path)!r} + "/big_1.npy", clf.classify(np.load({str(tmp_path)!r} + "/seqs.npy"), np.load({str(tmp_path)!r} + "/off.npy")))
+assert clf.stats().error_flags == 0
+"""
+    subprocess.run([sys.executable, "-c", code], check=True,
+                   env=dict(os.environ, KAIJU_GPU_LIB=lib, KAIJU_GPU_GREEDY_LANE="v3", KAIJU_GPU_G3_SPLIT=split))
+    for (name, seg), w in want.items():
+        got = np.load(tmp_path / f"{name}_{seg}.npy")
+        for f in ("best", "n_ids", "flags", "taxid"):
+            assert (got[f] == w[f]).all(), (name, seg, f)
+
+
+@pytest.mark.parametrize("seg", [1, 0])
+def test_fused_post_search_pass(gpu_lib, big, seg, monkeypatch):
+    """k_mem_post1 / _post2 (the lazy-SEG look, the locate and the LCA in one pass over the records) write what k_trigcheck,
+    k_mem_locate, k_mem_locate_list and k_lca wrote as separate passes (KAIJU_GPU_FUSED_POST=0): hit records and 16-byte records
+    of 1 M benchmark reads, single and paired"""
+    api = gpu_lib
+    from kaiju_amd import synth
+    tax = api.Taxonomy(f"{big['W']}/nodes.dmp")
+    dtax = api.DeviceTaxonomy(tax, 0)
+    n = min(1000000, len(big["reads"]))
+    for paired in (False, True):
+        if paired:
+            s2, o2 = synth.pack_reads(big["reads"][:n // 2], big["reads"][n // 2:n])
+        else:
+            s2, o2 = synth.pack_reads(big["reads"][:n])
+        out = {}
+        for fused in ("0", "1"):
+            monkeypatch.setenv("KAIJU_GPU_FUSED_POST", fused)
+            clf = api.Classifier(big["index"], api.default_params("mem", seg=seg))
+            hits = clf.classify(s2, o2, paired=paired).copy()
+            assert clf.stats().error_flags == 0
+            out[fused] = (hits, clf.classify_compact(dtax, s2, o2, paired=paired).copy(), clf.lca(dtax, hits).copy())
+        for f in ("best", "n_ids", "flags", "reserved", "taxid"):
+            assert (out["0"][0][f] == out["1"][0][f]).all(), (paired, f)
+        assert (out["0"][1] == out["1"][1]).all() and (out["1"][1] == out["1"][2]).all(), paired
+
+
+def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, monkeypatch):
+    """an index with the reference's short suffix-array sample (nseq % 8 == 0, KAIJU_IDX_WARN_SA_SHORT) gets its text arrays
+    too (the rows behind the missing sample are resolved through the next one) - and the SAME records as without them: a row
+    behind the missing sample gives no id (the reference reads out of bounds there), also when the match that ends there was
+    grown along the text (DevIndex::beyond_lo), so a result does not depend on whether the arrays found room in HBM.  Forced
+    wide: such an index gets no text arrays at all."""
+    wide = bool(os.environ.get("KAIJU_GPU_FORCE_WIDE"))
+    if os.environ.get("KAIJU_GPU_NO_TEXT"):
+        pytest.skip("the suite runs without text arrays altogether (tests/tools/forced_wide_suite.sh): nothing to compare")
+    from kaiju_amd import mkfmi, synth
+    api = gpu_lib
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=1600, seed=11, leaves=leaves, max_len=700)
+    faa, fmi = str(tmp_path / "db.faa"), str(tmp_path / "db.fmi")
+    synth.write_fasta(db, faa)
+    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
+    seqs, off = synth.pack_reads(synth.make_reads(db, 20000, seed=5))
+    m1, m2 = synth.make_pairs(db, 6000, seed=6)
+    pseqs, poff = synth.pack_reads(m1, m2)
+    with_text = api.Index(fmi)
+    assert with_text.info.warnings & 1
+    assert (with_text.footprint.text == 0) if wide else (with_text.footprint.text > 0 and with_text.footprint.sa_full > 0)
+    monkeypatch.setenv("KAIJU_GPU_NO_TEXT", "1")
+    without = api.Index(fmi)
+    assert without.footprint.text == 0
+    for mode in ("mem", "greedy"):
+        for s, o, pe in ((seqs, off, False), (pseqs, poff, True)):
+            a = api.Classifier(with_text, api.default_params(mode, seg=1)).classify(s, o, paired=pe)
+            b = api.Classifier(without, api.default_params(mode, seg=1)).classify(s, o, paired=pe)
+            assert (a == b).all(), (mode, pe, np.nonzero(a != b)[0][:5])
+            assert (a["n_ids"] > 0).mean() > 0.4
+
+
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
 def test_greedy_row_pool_lane(gpu_lib, golden, gidx, oracle, ohandles, big, split, monkeypatch):
     """KAIJU_GPU_GREEDY_LANE=v3 (kj_greedy3.h: the reads of a block as rows of LDS, wavefronts pull rows by class) writes the
     records greedy_lane2 writes: the golden reads against the oracle, 400 k benchmark reads against the default lane"""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the search kernels of the legs hard / hard_greedy / wide / wide_greedy / long / protein (round 6: every leg
-# that carries a roofline gets its `traffic`): bench.py under rocprofv3 --pmc with a tiny headline (100 k reads - its launches
-# are far shorter than the leg's and fall out by duration) and ONE leg group per run, the two request-count groups only.
+# that carries a roofline gets its `traffic`): bench.py under rocprofv3 --pmc with ONE leg group per run (wide / long / protein take the first reads of the headline's
+# workload, so the headline has the leg's size: 2 M reads; the collector tells the launches apart by kernel name and order), the two request-count groups only.
 #   usage: pmc_legs.sh <outdir> [legs...]      then: pmc_legs_collect.py <outdir> profiles/traffic.json
 OUT=$1; shift
 LEGS=${@:-hard wide long protein}
@@ -15,7 +15,7 @@ for leg in $LEGS; do
     i=$((i+1))
     mkdir -p $OUT/$leg
     timeout 900 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/$leg/pass$i -o p -- \
-      python $R/bench.py --reads 100000 --contexts 1 --steps 1 --warmup 0 --leg-steps 1 --no-cpu-baseline --no-ref-ops --parity-sample 0 --legs $leg \
+      python $R/bench.py --reads 2000000 --contexts 1 --steps 1 --warmup 0 --leg-steps 1 --no-cpu-baseline --no-ref-ops --parity-sample 0 --legs $leg \
       > $OUT/$leg/pass$i.json 2> $OUT/$leg/pass$i.log
     echo "$leg pass $i rc=$? : $ctrs"
     rm -f $OUT/$leg/pass$i/p_agent_info.csv
