@@ -253,3 +253,76 @@ def test_device_list_is_validated(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run(base, env=dict(os.environ, KAIJU_GPU_PARSE_ONLY="1", KAIJU_GPU_DEVICES="0,0", KAIJU_GPU_DEVICES_ALLOW_REPEAT="1"), capture_output=True)
     assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("kind", ["level1", "level9", "members", "small_members", "syncflush", "stored", "fixed", "fasta"])
+def test_gzip_inflated_by_several_threads(have_cli, tmp_path, kind):
+    """.gz input of some size is inflated by several threads (csrc/host/pargz.h: every thread enters the deflate stream at a
+    block start it searched for, with markers for the 32 KB of text it cannot know; CRC-32 and length of every member are
+    checked): the records are those of zlib's gzread (KAIJU_GPU_GZ_THREADS=1) - compression levels, several members, members
+    of 64 KB (bgzip-like), sync-flush points (pigz), stored blocks, fixed Huffman codes (no block start to find: one thread),
+    FASTA; pieces of 256 KB so that a few megabytes make dozens of them"""
+    import zlib
+    rng = np.random.default_rng(9)
+    n = 60000
+    if kind == "fasta":
+        recs = [b">s%d d\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), int(rng.integers(50, 400))).tolist())) for i in range(n)]
+    else:
+        recs = []
+        for i in range(n):
+            L = int(rng.integers(30, 151))
+            recs.append(b"@read%d/1\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGTN"), L).tolist()), bytes(rng.integers(35, 74, L).astype(np.uint8).tolist())))
+    text = b"".join(recs)
+
+    def zc(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+        return co.compress(data) + co.flush()
+    if kind == "level1":
+        blob = zc(text, 1)
+    elif kind == "level9":
+        blob = zc(text, 9)
+    elif kind == "members":
+        blob = b"".join(zc(text[i:i + 3_000_000]) for i in range(0, len(text), 3_000_000))
+    elif kind == "small_members":
+        blob = b"".join(zc(text[i:i + 65280]) for i in range(0, len(text), 65280))
+    elif kind == "syncflush":
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        parts = []
+        for i in range(0, len(text), 131072):
+            parts += [co.compress(text[i:i + 131072]), co.flush(zlib.Z_SYNC_FLUSH)]
+        blob = b"".join(parts) + co.flush()
+    elif kind == "stored":
+        blob = zc(text, 0)
+    elif kind == "fixed":
+        blob = zc(text, 6, zlib.Z_FIXED)
+    else:
+        blob = zc(text)
+    assert len(blob) > (2 << 20)                       # (smaller files keep gzread)
+    path = tmp_path / ("r.fa.gz" if kind == "fasta" else "r.fq.gz")
+    path.write_bytes(blob)
+    out = {}
+    for threads in ("1", "5"):
+        env = dict(os.environ, KAIJU_GPU_PARSE_ONLY="1", KAIJU_GPU_GZ_THREADS=threads, KAIJU_GPU_GZ_PIECE=str(256 << 10))
+        r = subprocess.run([CLI, "-i", str(path)], env=env, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-400:]
+        out[threads] = r.stdout
+    assert out["1"] == out["5"]
+    assert out["5"].count(b"\n") == n
+
+
+def test_damaged_gzip_is_an_error(have_cli, tmp_path):
+    """a byte flipped in the middle of a .gz file: the several-thread inflate ends with an error (a block that does not decode,
+    or the CRC-32 of the member), as gzread does - never with silently different reads"""
+    import zlib
+    rng = np.random.default_rng(10)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGT"), 150).tolist()), b"I" * 150) for i in range(60000))
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    blob = bytearray(co.compress(text) + co.flush())
+    assert len(blob) > (2 << 20)
+    blob[len(blob) // 2] ^= 0x10
+    path = tmp_path / "bad.fq.gz"
+    path.write_bytes(bytes(blob))
+    for threads in ("1", "5"):
+        env = dict(os.environ, KAIJU_GPU_PARSE_ONLY="1", KAIJU_GPU_GZ_THREADS=threads, KAIJU_GPU_GZ_PIECE=str(256 << 10))
+        r = subprocess.run([CLI, "-i", str(path)], env=env, capture_output=True, timeout=300)
+        assert r.returncode != 0 and (b"gzip" in r.stderr or b"Error while reading" in r.stderr), (threads, r.stderr.decode()[-300:])

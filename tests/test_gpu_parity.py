@@ -633,93 +633,3 @@ assert clf.stats().error_flags == 0
         got = np.load(tmp_path / f"{name}_{seg}.npy")
         for f in ("best", "n_ids", "flags", "taxid"):
             assert (got[f] == w[f]).all(), (name, seg, f)
-
-
-@pytest.mark.parametrize("seg", [1, 0])
-def test_fused_post_search_pass(gpu_lib, big, seg, monkeypatch):
-    """k_mem_post1 / _post2 (the lazy-SEG look, the locate and the LCA in one pass over the records) write what k_trigcheck,
-    k_mem_locate, k_mem_locate_list and k_lca wrote as separate passes (KAIJU_GPU_FUSED_POST=0): hit records and 16-byte records
-    of 1 M benchmark reads, single and paired"""
-    api = gpu_lib
-    from kaiju_amd import synth
-    tax = api.Taxonomy(f"{big['W']}/nodes.dmp")
-    dtax = api.DeviceTaxonomy(tax, 0)
-    n = min(1000000, len(big["reads"]))
-    for paired in (False, True):
-        if paired:
-            s2, o2 = synth.pack_reads(big["reads"][:n // 2], big["reads"][n // 2:n])
-        else:
-            s2, o2 = synth.pack_reads(big["reads"][:n])
-        out = {}
-        for fused in ("0", "1"):
-            monkeypatch.setenv("KAIJU_GPU_FUSED_POST", fused)
-            clf = api.Classifier(big["index"], api.default_params("mem", seg=seg))
-            hits = clf.classify(s2, o2, paired=paired).copy()
-            assert clf.stats().error_flags == 0
-            out[fused] = (hits, clf.classify_compact(dtax, s2, o2, paired=paired).copy(), clf.lca(dtax, hits).copy())
-        for f in ("best", "n_ids", "flags", "reserved", "taxid"):
-            assert (out["0"][0][f] == out["1"][0][f]).all(), (paired, f)
-        assert (out["0"][1] == out["1"][1]).all() and (out["1"][1] == out["1"][2]).all(), paired
-
-
-def test_text_arrays_on_an_index_with_the_short_sample_array(gpu_lib, tmp_path, monkeypatch):
-    """an index with the reference's short suffix-array sample (nseq % 8 == 0, KAIJU_IDX_WARN_SA_SHORT) gets its text arrays
-    too (the rows behind the missing sample are resolved through the next one) - and the SAME records as without them: a row
-    behind the missing sample gives no id (the reference reads out of bounds there), also when the match that ends there was
-    grown along the text (DevIndex::beyond_lo), so a result does not depend on whether the arrays found room in HBM.  Forced
-    wide: such an index gets no text arrays at all."""
-    wide = bool(os.environ.get("KAIJU_GPU_FORCE_WIDE"))
-    if os.environ.get("KAIJU_GPU_NO_TEXT"):
-        pytest.skip("the suite runs without text arrays altogether (tests/tools/forced_wide_suite.sh): nothing to compare")
-    from kaiju_amd import mkfmi, synth
-    api = gpu_lib
-    _, leaves = synth.make_taxonomy(3, 3, 3)
-    db = synth.make_db(nseq=1600, seed=11, leaves=leaves, max_len=700)
-    faa, fmi = str(tmp_path / "db.faa"), str(tmp_path / "db.fmi")
-    synth.write_fasta(db, faa)
-    mkfmi.build_fmi(faa, fmi, threads=2, exponent=3)
-    seqs, off = synth.pack_reads(synth.make_reads(db, 20000, seed=5))
-    m1, m2 = synth.make_pairs(db, 6000, seed=6)
-    pseqs, poff = synth.pack_reads(m1, m2)
-    with_text = api.Index(fmi)
-    assert with_text.info.warnings & 1
-    assert (with_text.footprint.text == 0) if wide else (with_text.footprint.text > 0 and with_text.footprint.sa_full > 0)
-    monkeypatch.setenv("KAIJU_GPU_NO_TEXT", "1")
-    without = api.Index(fmi)
-    assert without.footprint.text == 0
-    for mode in ("mem", "greedy"):
-        for s, o, pe in ((seqs, off, False), (pseqs, poff, True)):
-            a = api.Classifier(with_text, api.default_params(mode, seg=1)).classify(s, o, paired=pe)
-            b = api.Classifier(without, api.default_params(mode, seg=1)).classify(s, o, paired=pe)
-            assert (a == b).all(), (mode, pe, np.nonzero(a != b)[0][:5])
-            assert (a["n_ids"] > 0).mean() > 0.4
-
-
-
-
-@pytest.mark.parametrize("split", ["1", "0"])
-def test_greedy_row_pool_lane(gpu_lib, golden, gidx, oracle, ohandles, big, split, monkeypatch):
-    """KAIJU_GPU_GREEDY_LANE=v3 (kj_greedy3.h: the reads of a block as rows of LDS, wavefronts pull rows by class) writes the
-    records greedy_lane2 writes: the golden reads against the oracle, 400 k benchmark reads against the default lane"""
-    api = gpu_lib
-    ix, tax = ohandles
-    ref_clf = api.Classifier(big["index"], api.default_params("greedy", seg=1))
-    n = min(400000, len(big["reads"]))
-    from kaiju_amd import synth
-    s2, o2 = synth.pack_reads(big["reads"][:n])
-    want = ref_clf.classify(s2, o2).copy()
-    monkeypatch.setenv("KAIJU_GPU_GREEDY_LANE", "v3")
-    monkeypatch.setenv("KAIJU_GPU_G3_SPLIT", split)
-    for seg in (1, 0):
-        clf = api.Classifier(gidx, api.default_params("greedy", seg=seg))
-        hits = clf.classify(golden.seqs, golden.off)
-        assert clf.stats().error_flags == 0
-        oh = oracle.classify(ix, tax, oracle.params("greedy", seg=seg, use_evalue=0), golden.seqs, golden.off)
-        bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], hits[i])]
-        assert not bad, (seg, bad[:5])
-    clf = api.Classifier(big["index"], api.default_params("greedy", seg=1))
-    got = clf.classify(s2, o2)
-    assert clf.stats().error_flags == 0
-    for f in ("best", "n_ids", "flags"):
-        assert (got[f] == want[f]).all(), f
-    assert (got["taxid"] == want["taxid"]).all()
