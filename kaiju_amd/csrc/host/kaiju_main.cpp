@@ -183,7 +183,9 @@ struct BlockReader {
     }
     // a .gz file of some size is mapped as it is and inflated by several threads (pargz.h: one zlib stream feeds 1.7 M reads/s,
     // the GPU takes fifty times that); KAIJU_GPU_GZ_THREADS=1, small files and pipes keep zlib's gzread
-    if (gz && regular && st.st_size >= (2 << 20)) {
+    long gz_min = 2 << 20;
+    if (const char *e = getenv("KAIJU_GPU_GZ_MIN")) gz_min = atol(e);       // (tests: the several-thread path on small files)
+    if (gz && regular && st.st_size >= gz_min && st.st_size >= 64) {
       unsigned zt = std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
       if (const char *e = getenv("KAIJU_GPU_GZ_THREADS")) zt = (unsigned)std::max(1, atoi(e));
       if (zt >= 2) {
@@ -205,6 +207,10 @@ struct BlockReader {
     }
   }
   ~BlockReader() {
+    if (pz && getenv("KAIJU_GPU_STAGE_TIMES"))
+      fprintf(stderr, "[gz %s] producer: block-start search %.2f s, inflate %.2f s, markers + newlines + crc %.2f s, waiting for the reader %.2f s; "
+              "%llu pieces entered at a found block start, %llu inflated by the thread in front of them\n", path.c_str(), pz->t_find, pz->t_inflate,
+              pz->t_resolve, pz->t_wait, (unsigned long long)pz->pieces_entered, (unsigned long long)pz->pieces_absorbed);
     for (auto &x : scanners) if (x.joinable()) x.join();
     if (fp) gzclose(fp);
     // (the mapping outlives the reader: blocks in the pipeline still point into it; run_sample() unmaps it when every
@@ -395,9 +401,103 @@ struct BlockReader {
     return bytes ? (uint64_t)((double)(rec_start.size()) * (double)(size - pos) / (double)bytes) : 0;
   }
 
+  // ---- .gz files inflated by several threads (pargz.h): the text arrives in pieces, each with the positions of its newlines -
+  // the record walk below costs a few loads per record (one thread; the memchr walk of the streamed path does 7 M records/s)
+  // and every byte is copied once, from its piece into the block
+  std::deque<pargz::Text> pq;            // pieces not handed out in full yet
+  uint64_t pq_base = 0;                  // position in the inflated text of pq[0]'s first byte
+  uint64_t p_pos = 0;                    // ... of the next record
+  bool p_eof = false;                    // no piece is left to fetch
+  size_t nl_k = 0, nl_i = 0;             // the newline cursor: piece pq[nl_k], entry nl_i of its list
+  bool p_fetch() {
+    if (p_eof) return false;
+    pargz::Text t;
+    if (!pz->next_piece(t)) { p_eof = true; return false; }
+    pq.push_back(std::move(t));
+    return true;
+  }
+  uint64_t p_end() const { uint64_t e = pq_base; for (const auto &t : pq) e += t.n; return e; }
+  // is there a byte at position a (fetches pieces as needed)?
+  bool p_have(uint64_t a) { while (a >= p_end()) if (!p_fetch()) return false; return true; }
+  char p_ch(uint64_t a) const {
+    uint64_t o = a - pq_base;
+    for (const auto &t : pq) { if (o < t.n) return (char)t.buf.data()[o]; o -= t.n; }
+    return 0;
+  }
+  // one past the first newline at or behind a (a < end of the text); at the end of the file a last line without one ends there
+  uint64_t p_line_end(uint64_t a) {
+    for (;;) {
+      uint64_t start = pq_base;
+      for (size_t k = 0; k < nl_k && k < pq.size(); k++) start += pq[k].n;
+      while (nl_k < pq.size()) {
+        const auto &t = pq[nl_k];
+        while (nl_i < t.nl.size() && start + t.nl[nl_i] < a) nl_i++;
+        if (nl_i < t.nl.size()) return start + t.nl[nl_i] + 1;
+        start += t.n; nl_k++; nl_i = 0;
+      }
+      if (!p_fetch()) return p_end();
+    }
+  }
+  // the end of the record that starts with the first non-empty line at or behind a; NONE: nothing but empty lines is left
+  uint64_t p_record_end(uint64_t a) {
+    uint64_t q = a, e;
+    for (;;) {
+      if (!p_have(q)) return NONE;
+      e = p_line_end(q);
+      if (e - q == 1 && p_ch(q) == '\n') { q = e; continue; }      // getline gave an empty line
+      break;
+    }
+    if (first) {
+      if (p_ch(q) == '@') fastq = true;
+      else if (p_ch(q) != '>') die("Auto-detection of file type for file " + path + " failed.");
+      first = false;
+    }
+    uint64_t r = e;
+    if (fastq) {
+      for (int lines = 0; lines < 3; lines++) {
+        if (!p_have(r)) break;                                      // fewer lines at the end of the file are fine
+        r = p_line_end(r);
+      }
+      return r;
+    }
+    for (;;) {
+      if (!p_have(r)) return r;
+      if (p_ch(r) == '>') return r;
+      r = p_line_end(r);
+    }
+  }
+  bool next_pieces(RawBlock &out, uint32_t want) {
+    const uint64_t from = p_pos;
+    uint64_t p = p_pos;
+    while (out.n_records < want) {
+      const uint64_t e = p_record_end(p);
+      if (e == NONE) { p = p_end(); break; }
+      p = e; out.n_records++;
+    }
+    p_pos = p;
+    if (out.n_records == 0) { pq.clear(); return false; }
+    // the block's text: one copy, piece by piece
+    out.own.reserve((size_t)(p - from));
+    uint64_t start = pq_base;
+    for (const auto &t : pq) {
+      const uint64_t lo = std::max(from, start), hi = std::min(p, start + t.n);
+      if (lo < hi) out.own.insert(out.own.end(), reinterpret_cast<const char *>(t.buf.data()) + (lo - start), reinterpret_cast<const char *>(t.buf.data()) + (hi - start));
+      start += t.n;
+    }
+    out.text = out.own.data(); out.size = out.own.size(); out.fastq = fastq;
+    // pieces that lie in front of the next record are done with
+    while (!pq.empty() && pq_base + pq.front().n <= p_pos) {
+      pq_base += pq.front().n;
+      pq.pop_front();
+      if (nl_k > 0) nl_k--; else nl_i = 0;
+    }
+    return true;
+  }
+
   // false when the file is exhausted and nothing was produced
   bool next(RawBlock &out, uint32_t want) {
     out.n_records = 0; out.own.clear();
+    if (pz) return next_pieces(out, want);
     if (prescanned) {
       // (the end of a block is the start of the record behind it: one more start than records must be known)
       while (!all_merged && rec_start.size() <= next_rec + (size_t)want) merge_next_piece();

@@ -25,6 +25,9 @@
 // first piece's thread alone.  KAIJU_GPU_GZ_THREADS=1 keeps zlib's gzread (the caller's old path).
 #pragma once
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -393,9 +396,40 @@ inline uint64_t find_block_start(const uint8_t *data, size_t size, uint64_t from
 
 // ---- the reader ----------------------------------------------------------------------------------------------------------
 // read(dst, n): the next bytes of the inflated text (0 at the end); errors are fatal through the callback given to open()
+// one stretch of the inflated text, in file order; nl: the positions of its '\n' bytes (found by the thread that resolved it:
+// the caller's record walk then costs a few loads per record instead of a memchr per line)
+struct Text {
+  RawBuf<uint8_t> buf;
+  size_t n = 0;
+  std::vector<uint32_t> nl;
+};
+inline void find_newlines(const uint8_t *p, size_t n, std::vector<uint32_t> &nl) {
+  nl.clear();
+  nl.reserve(n / 64 + 16);
+  size_t i = 0;
+#if defined(__SSE2__)
+  const __m128i nlv = _mm_set1_epi8('\n');
+  for (; i + 16 <= n; i += 16) {
+    unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + i)), nlv));
+    while (m) { nl.push_back((uint32_t)(i + (size_t)__builtin_ctz(m))); m &= m - 1; }
+  }
+#endif
+  for (; i < n; i++) if (p[i] == '\n') nl.push_back((uint32_t)i);
+}
+
 class Reader {
  public:
   ~Reader() { stop(); }
+  // the next stretch of text (blocks until one is there); false at the end of the file
+  bool next_piece(Text &out) {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [this] { return !ready_.empty() || done_; });
+    if (ready_.empty()) return false;
+    out = std::move(ready_.front()); ready_.pop_front();
+    lk.unlock();
+    cv_.notify_all();
+    return true;
+  }
   // data / size: the whole .gz file (memory-mapped by the caller); threads >= 2
   bool open(const uint8_t *data, size_t size, unsigned threads, std::function<void(const std::string &)> fatal) {
     d_ = data; n_ = size; T_ = std::max(2u, threads); fatal_ = std::move(fatal);
@@ -437,6 +471,7 @@ class Reader {
     bool failed = false;
     RawBuf<uint8_t> text;            // resolved
     size_t n_text = 0;
+    std::vector<uint32_t> nl;        // its newlines
     std::vector<std::pair<size_t, uint32_t>> crc_parts;   // per stretch between member ends: (length, crc32)
   };
   const uint8_t *d_ = nullptr;
@@ -447,7 +482,6 @@ class Reader {
   std::thread producer_;
   std::mutex m_;
   std::condition_variable cv_;
-  struct Text { RawBuf<uint8_t> buf; size_t n = 0; };
   std::deque<Text> ready_;
   bool done_ = false, quit_ = false;
   Text cur_;
@@ -466,11 +500,11 @@ class Reader {
     for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
     for (auto &x : th) x.join();
   }
-  void emit(RawBuf<uint8_t> &&v, size_t n) {
+  void emit(RawBuf<uint8_t> &&v, size_t n, std::vector<uint32_t> &&nl) {
     std::unique_lock<std::mutex> lk(m_);
     cv_.wait(lk, [this] { return ready_.size() < 2 * (size_t)T_ || quit_; });
     if (quit_) return;
-    Text t; t.buf = std::move(v); t.n = n;
+    Text t; t.buf = std::move(v); t.n = n; t.nl = std::move(nl);
     ready_.push_back(std::move(t));
     lk.unlock();
     cv_.notify_all();
@@ -567,6 +601,7 @@ class Reader {
         const uint8_t *w = wins[x].data();
         uint8_t *dst = pc.text.data();
         for (size_t i = 0; i < n_out; i++) { const uint16_t v = src[i]; dst[i] = v < 256 ? (uint8_t)v : w[v - 256u]; }
+        find_newlines(dst, n_out, pc.nl);
         // crc32 of the stretches between member ends
         size_t from = 0;
         for (size_t e = 0; e <= pc.inf.ends.size(); e++) {
@@ -613,7 +648,7 @@ class Reader {
         win_valid = std::min<size_t>(kWindow, ended ? since : win_valid + since);
       }
       t0 = tnow();
-      for (size_t x = 0; x < live.size(); x++) emit(std::move(ps[live[x]].text), ps[live[x]].n_text);
+      for (size_t x = 0; x < live.size(); x++) emit(std::move(ps[live[x]].text), ps[live[x]].n_text, std::move(ps[live[x]].nl));
       t_wait += tnow() - t0;
     }
     { std::lock_guard<std::mutex> lk(m_); done_ = true; }

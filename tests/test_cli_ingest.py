@@ -50,8 +50,10 @@ def ref_records(text: bytes):
     return out
 
 
-def run_cli(tmp_path, f1, f2=None, batch=None, prescan_threads=None, piece=None):
+def run_cli(tmp_path, f1, f2=None, batch=None, prescan_threads=None, piece=None, gz_threads=None, gz_piece=None):
     env = dict(os.environ, KAIJU_GPU_PARSE_ONLY="1")
+    if gz_threads:                            # .gz files of any size through the several-thread inflate (csrc/host/pargz.h)
+        env.update(KAIJU_GPU_GZ_MIN="0", KAIJU_GPU_GZ_THREADS=str(gz_threads), KAIJU_GPU_GZ_PIECE=str(gz_piece or 4096))
     if prescan_threads:                       # several boundary-scan threads even on these small files
         env["KAIJU_GPU_PRESCAN"] = "1"
         env["KAIJU_GPU_PRESCAN_MIN"] = "0"
@@ -99,6 +101,32 @@ def have_cli():
     from kaiju_amd import build
     build.build()
     assert os.path.exists(CLI)
+
+
+@pytest.mark.parametrize("variant", ["crlf", "blanks", "nofinal", "truncated", "plain"])
+@pytest.mark.parametrize("kind", ["fastq", "fasta"])
+def test_gz_piece_stream_ingest(have_cli, tmp_path, variant, kind):
+    """the record walk over the pieces of a .gz file inflated by several threads (BlockReader::next_pieces: newline lists, records
+    that straddle pieces) finds the records of the reference's reading loop: CRLF, blank lines, no final newline, a truncated
+    last record; pieces of a few kilobytes, batches of 1 .. 1000 records"""
+    rng = np.random.default_rng(31)
+    if kind == "fastq":
+        text = make_fastq(rng, 3000, crlf=variant == "crlf", blanks=variant == "blanks", final_newline=variant != "nofinal")
+    else:
+        text = make_fasta(rng, 2000)
+        if variant == "crlf":
+            text = text.replace(b"\n", b"\r\n")
+        if variant == "nofinal":
+            text = text.rstrip(b"\n")
+    if variant == "truncated":
+        text = text[: len(text) - 150]
+    path = tmp_path / ("r.fq.gz" if kind == "fastq" else "r.fa.gz")
+    with gzip.open(path, "wb") as f:
+        f.write(text)
+    want = ref_records(text)
+    for batch, threads, piece in ((None, 3, 4096), (1, 2, 1024), (7, 5, 20000), (1000, 4, 300)):
+        got = run_cli(tmp_path, path, batch=batch, gz_threads=threads, gz_piece=piece)
+        assert [(g[0], g[1]) for g in got] == want, (batch, threads, piece)
 
 
 @pytest.mark.parametrize("variant", ["plain", "crlf", "blanks", "nofinal", "gz", "truncated"])
