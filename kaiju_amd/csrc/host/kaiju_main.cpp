@@ -103,6 +103,18 @@ struct RawBlock {
   std::vector<char> own;       // backing store unless the file is memory-mapped
   uint32_t n_records = 0;
   bool fastq = false;
+  // .gz input inflated by several threads: the block's text as stretches of the inflated pieces, which `keep` holds alive;
+  // gather() - run by the PARSER that takes the block, not by the one reader thread - makes it one stretch
+  std::vector<std::pair<const char *, size_t>> segs;
+  std::vector<std::shared_ptr<pargz::Text>> keep;
+  void gather() {
+    if (segs.empty()) return;
+    if (segs.size() == 1) { text = segs[0].first; return; }      // (the pieces stay alive with the block)
+    own.clear(); own.reserve(size);
+    for (const auto &sg : segs) own.insert(own.end(), sg.first, sg.first + sg.second);
+    text = own.data();
+    segs.clear(); keep.clear();
+  }
 };
 
 // Hands out blocks of `want` whole records.  Plain files are memory-mapped (blocks point into the
@@ -156,7 +168,7 @@ struct BlockReader {
   size_t map_size = 0;
   // streamed
   gzFile fp = nullptr;
-  std::unique_ptr<pargz::Reader> pz;       // .gz files of some size: inflated by several threads (pargz.h)
+  std::shared_ptr<pargz::Reader> pz;       // .gz files of some size: inflated by several threads (pargz.h)
   std::vector<char> buf;
   // common view of the text not yet handed out: [data + pos, data + size)
   const char *data = nullptr;
@@ -404,33 +416,35 @@ struct BlockReader {
   // ---- .gz files inflated by several threads (pargz.h): the text arrives in pieces, each with the positions of its newlines -
   // the record walk below costs a few loads per record (one thread; the memchr walk of the streamed path does 7 M records/s)
   // and every byte is copied once, from its piece into the block
-  std::deque<pargz::Text> pq;            // pieces not handed out in full yet
+  std::deque<std::shared_ptr<pargz::Text>> pq;   // pieces not handed out in full yet (blocks in the pipeline hold them too)
   uint64_t pq_base = 0;                  // position in the inflated text of pq[0]'s first byte
   uint64_t p_pos = 0;                    // ... of the next record
   bool p_eof = false;                    // no piece is left to fetch
   size_t nl_k = 0, nl_i = 0;             // the newline cursor: piece pq[nl_k], entry nl_i of its list
   bool p_fetch() {
     if (p_eof) return false;
-    pargz::Text t;
-    if (!pz->next_piece(t)) { p_eof = true; return false; }
+    // (a piece the last block is through with goes back to the inflater, which uses its buffers again)
+    std::shared_ptr<pargz::Reader> r = pz;
+    std::shared_ptr<pargz::Text> t(new pargz::Text(), [r](pargz::Text *x) { r->recycle(std::move(*x)); delete x; });
+    if (!pz->next_piece(*t)) { p_eof = true; return false; }
     pq.push_back(std::move(t));
     return true;
   }
-  uint64_t p_end() const { uint64_t e = pq_base; for (const auto &t : pq) e += t.n; return e; }
+  uint64_t p_end() const { uint64_t e = pq_base; for (const auto &t : pq) e += t->n; return e; }
   // is there a byte at position a (fetches pieces as needed)?
   bool p_have(uint64_t a) { while (a >= p_end()) if (!p_fetch()) return false; return true; }
   char p_ch(uint64_t a) const {
     uint64_t o = a - pq_base;
-    for (const auto &t : pq) { if (o < t.n) return (char)t.buf.data()[o]; o -= t.n; }
+    for (const auto &t : pq) { if (o < t->n) return (char)t->buf.data()[o]; o -= t->n; }
     return 0;
   }
   // one past the first newline at or behind a (a < end of the text); at the end of the file a last line without one ends there
   uint64_t p_line_end(uint64_t a) {
     for (;;) {
       uint64_t start = pq_base;
-      for (size_t k = 0; k < nl_k && k < pq.size(); k++) start += pq[k].n;
+      for (size_t k = 0; k < nl_k && k < pq.size(); k++) start += pq[k]->n;
       while (nl_k < pq.size()) {
-        const auto &t = pq[nl_k];
+        const pargz::Text &t = *pq[nl_k];
         while (nl_i < t.nl.size() && start + t.nl[nl_i] < a) nl_i++;
         if (nl_i < t.nl.size()) return start + t.nl[nl_i] + 1;
         start += t.n; nl_k++; nl_i = 0;
@@ -476,18 +490,18 @@ struct BlockReader {
     }
     p_pos = p;
     if (out.n_records == 0) { pq.clear(); return false; }
-    // the block's text: one copy, piece by piece
-    out.own.reserve((size_t)(p - from));
+    // the block's text: stretches of the pieces (RawBlock::gather, run by the parser that takes the block, copies them once)
+    out.segs.clear(); out.keep.clear();
     uint64_t start = pq_base;
     for (const auto &t : pq) {
-      const uint64_t lo = std::max(from, start), hi = std::min(p, start + t.n);
-      if (lo < hi) out.own.insert(out.own.end(), reinterpret_cast<const char *>(t.buf.data()) + (lo - start), reinterpret_cast<const char *>(t.buf.data()) + (hi - start));
-      start += t.n;
+      const uint64_t lo = std::max(from, start), hi = std::min(p, start + t->n);
+      if (lo < hi) { out.segs.emplace_back(reinterpret_cast<const char *>(t->buf.data()) + (lo - start), (size_t)(hi - lo)); out.keep.push_back(t); }
+      start += t->n;
     }
-    out.text = out.own.data(); out.size = out.own.size(); out.fastq = fastq;
+    out.text = nullptr; out.size = (size_t)(p - from); out.fastq = fastq;
     // pieces that lie in front of the next record are done with
-    while (!pq.empty() && pq_base + pq.front().n <= p_pos) {
-      pq_base += pq.front().n;
+    while (!pq.empty() && pq_base + pq.front()->n <= p_pos) {
+      pq_base += pq.front()->n;
       pq.pop_front();
       if (nl_k > 0) nl_k--; else nl_i = 0;
     }
@@ -1026,7 +1040,7 @@ int main(int argc, char **argv) {
         for (;;) {
           std::unique_ptr<Batch> b = pool.get();               // (first the batch, then the block: see BatchPool)
           if (!q_raw.take_any(seq, pr)) { pool.put(std::move(b)); break; }
-          { StageTimer tm(g_ns_parse); parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b); }
+          { StageTimer tm(g_ns_parse); pr.a->gather(); if (pr.b) pr.b->gather(); parse_blocks(*pr.a, pr.b.get(), in1_fn, in2_fn, *b); }
           if (paired && pr.b->n_records > pr.a->n_records)
             fprintf(stderr, "Warning: File %s has more reads then file %s\n", in2_fn.c_str(), in1_fn.c_str());
           q_parsed.put(seq, std::move(b));

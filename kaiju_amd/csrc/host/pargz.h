@@ -352,8 +352,7 @@ struct Inflater {
 
 // ---- the search for a block start ----------------------------------------------------------------------------------------
 // the first bit position in [from, to) at which a dynamic block starts (see the top of the file for what that means), kNoStart if none
-inline uint64_t find_block_start(const uint8_t *data, size_t size, uint64_t from, uint64_t to) {
-  Inflater<uint16_t> trial;
+inline uint64_t find_block_start(const uint8_t *data, size_t size, uint64_t from, uint64_t to, Inflater<uint16_t> &trial) {
   trial.text_only = true;
   for (uint64_t s = from; s < to; s++) {
     // the cheap part first: BFINAL = 0, BTYPE = 2, HLIT <= 29, HDIST <= 29, and a complete code-length code
@@ -448,6 +447,7 @@ class Reader {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this] { return !ready_.empty() || done_; });
         if (ready_.empty()) break;
+        if (cur_.buf.size() && free_texts_.size() < 4 * (size_t)T_) free_texts_.push_back(std::move(cur_));
         cur_ = std::move(ready_.front()); ready_.pop_front(); cur_at_ = 0;
         lk.unlock();
         cv_.notify_all();
@@ -460,6 +460,12 @@ class Reader {
     return got;
   }
   double t_find = 0, t_inflate = 0, t_resolve = 0, t_wait = 0;   // wall time of the producer in its phases (seconds)
+  // a piece the caller is through with: its buffers serve a later piece (a fresh 18 MB allocation per piece is an mmap, its
+  // first touch 4 500 page faults and its release a TLB shootdown on every thread: more than the inflation itself on 64 threads)
+  void recycle(Text &&t) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (free_texts_.size() < 4 * (size_t)T_) free_texts_.push_back(std::move(t));
+  }
   uint64_t pieces_entered = 0, pieces_absorbed = 0;         // statistics: pieces a thread entered at a found start / pieces
                                                             // that were inflated by the thread of the piece in front of them
  private:
@@ -469,9 +475,13 @@ class Reader {
     uint64_t end_bit = 0;            // where its inflation stopped
     size_t stopped_at = 0;           // index of the piece whose start it reached (or pieces.size(): the end of the round / file)
     bool failed = false;
-    RawBuf<uint8_t> text;            // resolved
-    size_t n_text = 0;
-    std::vector<uint32_t> nl;        // its newlines
+    Text text;                       // resolved: bytes and newlines
+    Inflater<uint16_t> trial;        // the search's scratch
+    void reset() {
+      start = kNoStart; end_bit = 0; stopped_at = 0; failed = false; crc_parts.clear();
+      inf.ends.clear(); inf.file_done = false; inf.err = nullptr; inf.text_only = false;
+      text.n = 0; text.nl.clear();
+    }
     std::vector<std::pair<size_t, uint32_t>> crc_parts;   // per stretch between member ends: (length, crc32)
   };
   const uint8_t *d_ = nullptr;
@@ -480,9 +490,11 @@ class Reader {
   uint64_t first_bit_ = 0;
   std::function<void(const std::string &)> fatal_;
   std::thread producer_;
+  std::vector<Piece> ps_;
   std::mutex m_;
   std::condition_variable cv_;
   std::deque<Text> ready_;
+  std::vector<Text> free_texts_;
   bool done_ = false, quit_ = false;
   Text cur_;
   size_t cur_at_ = 0;
@@ -500,11 +512,10 @@ class Reader {
     for (size_t i; (i = next.fetch_add(1)) < n;) f(i);
     for (auto &x : th) x.join();
   }
-  void emit(RawBuf<uint8_t> &&v, size_t n, std::vector<uint32_t> &&nl) {
+  void emit(Text &&t) {
     std::unique_lock<std::mutex> lk(m_);
     cv_.wait(lk, [this] { return ready_.size() < 2 * (size_t)T_ || quit_; });
     if (quit_) return;
-    Text t; t.buf = std::move(v); t.n = n; t.nl = std::move(nl);
     ready_.push_back(std::move(t));
     lk.unlock();
     cv_.notify_all();
@@ -524,7 +535,10 @@ class Reader {
       const size_t base = (size_t)(at >> 3);
       size_t np = std::min<size_t>(T_, (n_ - base + piece_ - 1) / piece_);
       if (np == 0) np = 1;
-      std::vector<Piece> ps(np + 1);                          // (+ 1: the first piece of the NEXT round, only its start is looked for)
+      if (ps_.size() < np + 1) ps_.resize((size_t)T_ + 1);    // (+ 1: the first piece of the NEXT round, only its start is looked for)
+      std::vector<Piece> &ps = ps_;
+      const size_t n_ps = np + 1;
+      for (size_t k = 0; k < n_ps; k++) ps[k].reset();
       ps[0].start = at;
       auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
       double t0 = tnow();
@@ -533,7 +547,7 @@ class Reader {
         const size_t from = base + k * piece_;
         if (from >= n_) return;
         const uint64_t lim = (uint64_t)std::min(n_, from + piece_) * 8u;
-        ps[k].start = find_block_start(d_, n_, (uint64_t)from * 8u, lim);
+        ps[k].start = find_block_start(d_, n_, (uint64_t)from * 8u, lim, ps[k].trial);
       });
       t_find += tnow() - t0; t0 = tnow();
       // inflate: piece k from its start until it stands on the start of a later piece (or the end of the file)
@@ -550,10 +564,10 @@ class Reader {
         for (;;) {
           const int r = inf.block(~(size_t)0);
           if (r < 0) { pc.failed = true; break; }
-          if (inf.file_done) { nxt = ps.size(); break; }
+          if (inf.file_done) { nxt = n_ps; break; }
           const uint64_t p = inf.b.bitpos();
-          while (nxt < ps.size() && (ps[nxt].start == kNoStart || ps[nxt].start < p)) nxt++;
-          if (nxt >= ps.size()) {
+          while (nxt < n_ps && (ps[nxt].start == kNoStart || ps[nxt].start < p)) nxt++;
+          if (nxt >= n_ps) {
             // beyond the last start of the round: stop at this block boundary if it lies in the next round's territory
             if ((size_t)(p >> 3) >= base + np * piece_) break;
             continue;
@@ -595,13 +609,17 @@ class Reader {
       parallel(live.size(), [&](size_t x) {
         Piece &pc = ps[live[x]];
         const size_t n_out = pc.inf.o - kWindow;
-        pc.text.resize(n_out + 1);
-        pc.n_text = n_out;
+        {
+          std::lock_guard<std::mutex> lk(m_);
+          if (!free_texts_.empty()) { pc.text = std::move(free_texts_.back()); free_texts_.pop_back(); pc.text.nl.clear(); }
+        }
+        pc.text.buf.resize(n_out + 1);
+        pc.text.n = n_out;
         const uint16_t *src = pc.inf.out.data() + kWindow;
         const uint8_t *w = wins[x].data();
-        uint8_t *dst = pc.text.data();
+        uint8_t *dst = pc.text.buf.data();
         for (size_t i = 0; i < n_out; i++) { const uint16_t v = src[i]; dst[i] = v < 256 ? (uint8_t)v : w[v - 256u]; }
-        find_newlines(dst, n_out, pc.nl);
+        find_newlines(dst, n_out, pc.text.nl);
         // crc32 of the stretches between member ends
         size_t from = 0;
         for (size_t e = 0; e <= pc.inf.ends.size(); e++) {
@@ -641,14 +659,14 @@ class Reader {
         bool ended = false;
         for (size_t x = live.size(); x-- > 0 && !ended;) {
           Piece &pc = ps[live[x]];
-          const size_t n_out = pc.n_text;
+          const size_t n_out = pc.text.n;
           if (!pc.inf.ends.empty()) { since += n_out - (size_t)(pc.inf.ends.back().out_pos - kWindow); ended = true; }
           else since += n_out;
         }
         win_valid = std::min<size_t>(kWindow, ended ? since : win_valid + since);
       }
       t0 = tnow();
-      for (size_t x = 0; x < live.size(); x++) emit(std::move(ps[live[x]].text), ps[live[x]].n_text, std::move(ps[live[x]].nl));
+      for (size_t x = 0; x < live.size(); x++) emit(std::move(ps[live[x]].text));
       t_wait += tnow() - t0;
     }
     { std::lock_guard<std::mutex> lk(m_); done_ = true; }

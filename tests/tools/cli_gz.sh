@@ -24,16 +24,17 @@ for p in $W/half_0*; do gzip -6 -c $p > $p.gz & done; wait
 cat $W/half_00.gz $W/half_01.gz $W/half_00.gz $W/half_01.gz $W/half_00.gz $W/half_01.gz $W/half_00.gz $W/half_01.gz > $W/reads48.fq.gz; rm -f $W/half_0*
 echo "48 M reads gzip -6: $(ls -la $W/reads48.fq.gz | awk '{print $5}') bytes in $(( $(date +%s) - t0 )) s" | tee $O/gz.txt
 mkdir -p /tmp/kjgz; g++ -O2 -std=c++17 -o /tmp/kjgz/pargz_test $R/tests/tools/pargz_test.cpp -lz -lpthread
-for t in 8 16 32 64 128; do echo "inflate only, $t threads: $(PARGZ_NO_OUTPUT=1 /tmp/kjgz/pargz_test $W/reads48.fq.gz $t 2>&1 | tr '\n' ' ')" | tee -a $O/gz.txt; done
+for t in 16 32 64; do echo "inflate only, $t threads: $(PARGZ_NO_OUTPUT=1 /tmp/kjgz/pargz_test $W/reads48.fq.gz $t 2>&1 | tr '\n' ' ')" | tee -a $O/gz.txt; done
 ( time gzip -dc $W/reads48.fq.gz > /dev/null ) 2>&1 | grep real | sed 's/^/gzip -dc: /' | tee -a $O/gz.txt
 run() { local tag=$1 mode=$2; shift 2; local t0=$(date +%s.%N)
   env "$@" KAIJU_GPU_STAGE_TIMES=1 $CLI -t $W/nodes.dmp -f $W/db.fmi -i $W/reads48.fq.gz -o $W/out_$tag.tsv -a $mode 2> $O/err_$tag.txt; local rc=$?; local t1=$(date +%s.%N)
   echo "== $tag rc=$rc: $(python3 -c "w=$t1-$t0; print(round(w, 2), 's wall ->', round(48 / w, 2), 'M reads/s end to end')")" | tee -a $O/gz.txt; }
 run warm mem KAIJU_GPU_GZ_THREADS=32 > /dev/null
-run parse_only_t1 mem KAIJU_GPU_PARSE_ONLY=1 KAIJU_GPU_GZ_THREADS=1
-for t in 8 16 32 64; do run parse_only_t$t mem KAIJU_GPU_PARSE_ONLY=1 KAIJU_GPU_GZ_THREADS=$t; done
+for t in 32; do run parse_only_t$t mem KAIJU_GPU_PARSE_ONLY=1 KAIJU_GPU_GZ_THREADS=$t; done
 run mem_t1 mem KAIJU_GPU_GZ_THREADS=1
 for t in 8 16 32 64; do run mem_t$t mem KAIJU_GPU_GZ_THREADS=$t; done
+run mem_t32_piece8 mem KAIJU_GPU_GZ_THREADS=32 KAIJU_GPU_GZ_PIECE=8388608
+run mem_t32_piece2 mem KAIJU_GPU_GZ_THREADS=32 KAIJU_GPU_GZ_PIECE=2097152
 run mem_default mem A=1
 grep '^\[gz' $O/err_mem_default.txt | tee -a $O/gz.txt
 grep 'CPU time per stage' $O/err_mem_default.txt | tee -a $O/gz.txt
