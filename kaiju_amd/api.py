@@ -365,7 +365,7 @@ class Classifier:
 
     OP_COUNT_NAMES = ("kmer_lookups", "update_si", "update_si_lines", "lf_steps", "lf_lines", "sa_samples", "read_meta",
                       "frag_desc", "window_fills", "term_searches", "si_spills", "hits", "multi_letter_steps", "items_read",
-                      "matches_read", "items_written", "matches_written", "wave_iterations", "lane_iterations", "record_bytes", "window_lines")
+                      "matches_read", "items_written", "matches_written", "wave_iterations", "lane_iterations", "record_bytes", "pruned_chains", "window_lines")
 
     def count_ops(self, on: bool):
         """accounting: the next batches run the counting instantiation of the search lane (never a timed launch)"""

@@ -1941,6 +1941,7 @@ KJ_HD unsigned long long *opc_of(const WorkList &wl) {
 enum OpCount : int {
   kOpcKmer, kOpcStep, kOpcStepLines, kOpcLf, kOpcLfLines, kOpcSa, kOpcMeta, kOpcFrag, kOpcFill, kOpcTerm, kOpcSiSpill,
   kOpcHit, kOpcVmulti, kOpcPopItem, kOpcMload, kOpcPush, kOpcMatchWr, kOpcIters, kOpcLaneIters, kOpcRecBytes,
+  kOpcPruned,                // Greedy: one-row variant chains that were not queued (kChainPrune)
   kOpcFillLines,             // 128-byte lines the 64-byte window / text loads touch (unaligned: one or two each; MEM lanes)
   kOpcN
 };
@@ -3672,6 +3673,67 @@ struct GreedyScratch2 {
   uint32_t *sub;               // LDS, kGSubStride words: the substitutions of the variant at hand + slow-part state
 };
 
+#ifdef KJ_NO_CHAIN_PRUNE                            // (A/B measurements, tests: the lane that queues every variant)
+constexpr bool kChainPrune = false;
+#else
+constexpr bool kChainPrune = true;
+#endif
+// Can the variant item whose match [pz, j] (l0 = j - pz + 1 letters, nmm substitutions so far) lies on ONE database row, or any
+// item that descends from it, ever hold a match of p.m letters?  (greedy_lane2: kChainPrune.)  Everything the reference does with
+// such an item is an ungapped comparison of the fragment with the database text in front of the row's suffix: the match grows
+// while the letters agree (UpdateSI on one row, bwt.c:160-173), a substitution (:346-395) takes the text's letter at a letter
+// that differs and costs one of the p.mismatches, and the item dies at the next difference once they are spent (:443-449).  So
+// the longest match the chain can reach ends in front of the (allowed + 1)-th difference - a matter of the MASK of differences
+// between the sixteen letters in front of the match on both sides, no loop, no score.  Scores, thresholds, terminators and the
+// order of the queue can only end the chain earlier.  tx: text[tp - 16, tp) of the match's text position tp; win / wq: the
+// lane's window of the fragment (the letters in front of pz are the fragment's own: a chain substitutes from right to left).
+// Conservative: what it cannot see (letters in front of the window, a chain longer than sixteen letters) counts as reachable.
+KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz, int j, const u128 &tx, uint32_t nmm) {
+  const int a = pz - wq;                                    // letters of the fragment in front of pz that the window holds
+  if (a <= 0) return pz == 0 ? (j - pz + 1 < (int)p.m) : false;
+  if (a < 16 && wq > 0) return false;
+  // f: the sixteen letters of the fragment in front of pz, laid out like tx (the letter at distance k, k = 0 next to the match,
+  // in byte 15 - k); letters in front of the fragment's start read as zeros, which differ from every letter
+  const uint32_t *w32 = reinterpret_cast<const uint32_t *>(win);
+  u128 f;
+  if (a >= 16) {
+    const int o = a - 16, d = o >> 2;
+    const uint32_t sh = (uint32_t)(o & 3);
+    const uint32_t q0 = w32[d], q1 = w32[d + 1], q2 = w32[d + 2], q3 = w32[d + 3], q4 = sh ? w32[d + 4] : 0u;
+    const uint32_t r0 = kj_alignbyte(q1, q0, sh), r1 = kj_alignbyte(q2, q1, sh), r2 = kj_alignbyte(q3, q2, sh), r3 = kj_alignbyte(q4, q3, sh);
+    f.x = r0 | (uint64_t)r1 << 32; f.y = r2 | (uint64_t)r3 << 32;
+  } else {
+    // the window starts with the fragment (wq = 0): its first a letters, moved up to bytes 16 - a .. 15
+    const uint64_t lo = w32[0] | (uint64_t)w32[1] << 32, hi = w32[2] | (uint64_t)w32[3] << 32;
+    const uint32_t sb = 8u * (uint32_t)(16 - a);            // 8 .. 120 bits up
+    if (sb >= 64u) { f.x = 0; f.y = lo << (sb - 64u); }
+    else { f.x = lo << sb; f.y = (hi << sb) | (lo >> (64u - sb)); }
+    // (bytes of the window behind letter a - 1 that were shifted in: only the low 16 - a bytes are meant to be zero; the
+    //  letters at and behind pz landed above byte 15 and fell out)
+  }
+  auto diff_bits = [](uint64_t x) -> uint32_t {             // bit i = byte i of x is not zero
+    const uint64_t t = ((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x;
+    return (uint32_t)(((t & 0x8080808080808080ull) >> 7) * 0x0102040810204080ull >> 56);
+  };
+  // mask of differences by distance: byte 15 - k of f ^ tx <-> bit k
+  const uint32_t mx = diff_bits(f.x ^ tx.x), my = diff_bits(f.y ^ tx.y);      // bit i <-> byte i (low half), byte 8 + i (high half)
+  uint32_t m16 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  m16 = (__brev(my) >> 24) | (__brev(mx) >> 24) << 8;
+#else
+  for (int i = 0; i < 8; i++) { m16 |= ((my >> i) & 1u) << (7 - i); m16 |= ((mx >> i) & 1u) << (15 - i); }
+#endif
+  if (a < 16) m16 |= 0xffffu << a;                          // in front of the fragment's start nothing matches and nothing is substituted
+  // the substitutions that are left take the first differences; the chain ends in front of the next one
+  uint32_t m = m16;
+  for (uint32_t q = nmm; q < p.mismatches && m; q++) m &= m - 1u;
+  if (m == 0) return false;                                 // fewer differences than that within sixteen letters: it may go on
+  int e = 0;
+  while (!((m >> e) & 1u)) e++;
+  if (a < 16 && e > a) e = a;
+  return j - pz + 1 + e < (int)p.m;
+}
+
 enum GKind : int { G_STEP, G_KMER, G_PROBE,                                              // fast (G_PROBE: a k-mer lookup, kGreedyProbe)
                    G_VMULTI, G_META, G_FRAG, G_FILL, G_POPITEM, G_MLOAD, G_WAIT, G_IDLE,   // heavy iterations only
                    G_EXIT };
@@ -4204,7 +4266,12 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     else if (kind == G_FRAG) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase);
     else if (kind == G_FILL && fill_pref && fo < nf) gaddr = reinterpret_cast<const uint8_t *>(b.frags + fbase + fo);
     else if (kind == G_MLOAD) gaddr = reinterpret_cast<const uint8_t *>(GS_MATCHES + mx);
+    // (kChainPrune: the text position of a one-row match comes with the rank lines of its substitution step - its one variant
+    //  lies one letter in front of it in the text)
+    const bool sa_hint = kChainPrune && !WIDE && is_vm && m_len == 1u && ix.sa_full && ix.text && (uint64_t)m_lo + 4u <= ix.bwtlen;   // (the aligned 16 bytes stay inside the array)
+    if (sa_hint) gaddr = reinterpret_cast<const uint8_t *>(ix.sa_full + (uint32_t)m_lo);
     const uint32_t ghalf = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 3) & 1u;
+    const uint32_t gword = (uint32_t)(reinterpret_cast<uintptr_t>(gaddr) >> 2) & 3u;
     const u128 gv = *reinterpret_cast<const u128_unaligned *>(kline_step ? reinterpret_cast<uintptr_t>(gaddr)
                                                                           : reinterpret_cast<uintptr_t>(gaddr) & ~(uintptr_t)15);
     // ten 16-byte reads from two lane-chosen places: a window (G_FILL), a queued item (G_POPITEM)
@@ -4305,6 +4372,8 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
       }
     } else if (heavy) {
       KJ_TICK(st_fast)
+      uint32_t vtp = 0;                                      // kChainPrune: text position of the one variant of a one-row match
+      if (sa_hint) vtp = (gword == 0u ? (uint32_t)gv.x : gword == 1u ? (uint32_t)(gv.x >> 32) : gword == 2u ? (uint32_t)gv.y : (uint32_t)(gv.y >> 32)) - 1u;
       if (is_vm) {
         KJ_P(PS_VM_RANK);
         KJ_HISTO(8, m_len == 1 ? 0 : m_len <= 4 ? 1 : 2); KJ_HISTO(9, t_nmm);   // (rows of the interval the substitutes are tried on)
@@ -4379,6 +4448,35 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           KJ_P(PS_VM_PUSH);
           if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; KJ_OVF(wl, 4); break; }
           const int bss = (int)diag(cx);
+          if constexpr (kChainPrune && !WIDE) {
+            // A variant on ONE database row is the root of a CHAIN: UpdateSI on a one-row interval succeeds iff the letter in
+            // front of the row's suffix is the letter asked for (bwt.c:160-173), the one substitute that exists at the next
+            // mismatch is the text's letter there (ConsumerThread.cpp:366-392), and the row it leads to is one row again - so
+            // everything the reference will do with this item and its descendants is an ungapped comparison of the fragment with
+            // the database text in front of that suffix, with up to `mismatches` substitutions.  If NO item of the chain can
+            // ever hold a match of m letters, none reaches eval_match_scores (:482: `if (m_ql >= min_fragment_length)`), and the
+            // chain changes nothing: best, the list of best matches and the flags stay as they are, and the sequence numbers it
+            // would have used keep the order of all other items (they only break ties, and they grow with time whether or not
+            // some are skipped).  Such an item is not queued (round 6; kj_chain_hopeless).  19.6 of the 24 variant items a
+            // benchmark read pops hang on one row, and 15 of them are of this kind: seeds of seven or eight letters in a wrong
+            // frame that three substitutions cannot turn into a match of eleven.
+            // (an item whose match has m letters already is not looked at: on a database of protein families most one-row variants
+            //  are of that kind, and the look costs a dependent load)
+            if (rb - ra == (P)1 && ix.sa_full && ix.text && m_ql + 1u < p.m) {
+              // (the text position of the variant's match: one letter in front of its parent's when that had one row - that
+              //  row's position came with the rank lines -, else the entry of the variant's own row)
+#ifdef KJ_CHAIN_PRUNE_HINT_ONLY
+              const uint32_t tp = vtp;
+#else
+              const uint32_t tp = vtp ? vtp : ix.sa_full[(uint32_t)ra];
+#endif
+              if (tp >= 16u + kTextPad &&
+                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u)) {
+                if constexpr (COUNT) oc[kOpcPruned]++;
+                continue;
+              }
+            }
+          }
           const uint32_t sl = push_slot(key, qseq + ct.subst_rank[vorig][cx - 1u]);
           if (sl == ~0u) break;
           uint32_t e0 = sa0, e1 = sa1;

@@ -214,6 +214,26 @@ def test_greedy_lane_generations_agree(oracle, emu, golden, handles, lane, gate,
         assert not bad, (lane, gate, seg, "paired", bad[:5])
 
 
+def test_greedy_chain_pruning_changes_nothing(oracle, emu, golden, handles):
+    """greedy_lane2 does not queue a variant on ONE database row whose chain can never hold a match of m letters (kChainPrune,
+    kj_chain_hopeless: a mask of differences between fragment and database text): records identical to the lane built without
+    it (-DKJ_NO_CHAIN_PRUNE) and to the oracle - golden reads, pairs, long reads; 0 to 5 mismatches, m = 11 and m = 15"""
+    import os
+    plain = util.Emu(so=os.path.join(util.EMU_DIR, "libkaiju_kernel_emu_noprune.so"), defines=("KJ_NO_CHAIN_PRUNE",))
+    h, ix, tax = handles
+    h0 = plain.load(golden.fmi)
+    lseqs, loff = util.pack(util.long_reads(n=40))
+    for seqs, off, pe in ((golden.seqs, golden.off, False), (golden.pseqs, golden.poff, True), (lseqs, loff, False)):
+        for kw in (dict(), dict(mismatches=0), dict(mismatches=1), dict(mismatches=5, min_score=50), dict(m=15), dict(seg=0)):
+            okw = {("min_fragment_length" if k == "m" else k): v for k, v in kw.items()}
+            oh = oracle.classify(ix, tax, oracle.params("greedy", use_evalue=0, **okw), seqs, off, paired=pe)
+            a, _ = emu.classify(h, util.gp("greedy", use_evalue=0, **kw), seqs, off, paired=pe)
+            b, _ = plain.classify(h0, util.gp("greedy", use_evalue=0, **kw), seqs, off, paired=pe)
+            assert (a == b).all(), (pe, kw)
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], a[i])]
+            assert not bad, (pe, kw, bad[:5])
+
+
 @pytest.mark.parametrize("g3", [False, True])
 def test_greedy_lane2_spill_and_retry(oracle, golden, handles, g3, monkeypatch):
     """the second-generation Greedy lane (and the row-pool lane) built with tiny bounds (-DKJ_G_SMALL): match lengths and queue

@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import util  # noqa: E402
 
-emu = util.Emu("/tmp/libkaiju_kernel_emu_hist.so", defines=("KJ_HIST",))
+_x = tuple(os.environ.get("HIST_DEFINES", "").split())
+emu = util.Emu("/tmp/libkaiju_kernel_emu_hist" + "".join("_" + d for d in _x) + ".so", defines=("KJ_HIST",) + _x)
 emu.lib.emu_hist.restype = C.POINTER(C.c_ulonglong * (16 * 64))
 W = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
