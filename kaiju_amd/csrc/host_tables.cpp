@@ -50,6 +50,9 @@ int build_const_tables(const uint8_t trans[128], ConstTables &t, std::string &ms
       for (int b = 19; b >= 0; b--)
         if (b != a && kB62[a][b] == s) t.subst[a][n++] = (uint8_t)b;
     if (n != 19) { msg = "internal: substitution table"; return KAIJU_GPU_ERR_ARG; }
+    // (the bounds of kj_chain_hopeless, kj_core.h: no diagonal entry above kMaxDiagScore, none off the diagonal above kMaxSubstScore)
+    for (int b = 0; b < 20; b++)
+      if (kB62[a][b] > (a == b ? kMaxDiagScore : kMaxSubstScore)) { msg = "internal: BLOSUM62 bounds of the chain test"; return KAIJU_GPU_ERR_ARG; }
   }
   uint8_t aa2int[128];
   memset(aa2int, 255, sizeof aa2int);

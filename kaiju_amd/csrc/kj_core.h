@@ -1642,8 +1642,15 @@ KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Ba
     auto emit = [&](uint32_t start, uint32_t l, uint32_t seq, bool trig) {
       uint32_t key = l;
       if (p.mode == 1) {
+        // (the fragment's letters, four per load: a byte load per residue of every fragment made the Greedy instantiation read
+        //  its own strings back with 250 requests per read - round 6)
         key = 0;
-        for (uint32_t x = 0; x < l; x++) key += t.diag[area[start + x]];
+        uint32_t x = 0;
+        for (; x + 4 <= l; x += 4) {
+          const uint32_t w = *reinterpret_cast<const u32_unaligned *>(area + start + x);
+          key += (uint32_t)t.diag[w & 255u] + t.diag[(w >> 8) & 255u] + t.diag[(w >> 16) & 255u] + t.diag[w >> 24];
+        }
+        for (; x < l; x++) key += t.diag[area[start + x]];
         if (key < p.min_score) return;
       }
       if (n >= cap) return;                                   // cannot happen: cap is a proven bound
@@ -3688,9 +3695,13 @@ constexpr bool kChainPrune = true;
 // order of the queue can only end the chain earlier.  tx: text[tp - 16, tp) of the match's text position tp; win / wq: the
 // lane's window of the fragment (the letters in front of pz are the fragment's own: a chain substitutes from right to left).
 // Conservative: what it cannot see (letters in front of the window, a chain longer than sixteen letters) counts as reachable.
-KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz, int j, const u128 &tx, uint32_t nmm) {
+// sc0: the score of the item's own match (eval_match_scores' m_dsum + diff).  A letter the chain gains adds at most 11 to it
+// (the largest entry of the BLOSUM62 diagonal: W), a substitution at most kMaxSubstScore (the largest entry off the diagonal;
+// host_tables.cpp checks both against the table): if even that stays below min_score, no item of the chain passes the gate.
+constexpr int kMaxDiagScore = 11, kMaxSubstScore = 4;
+KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz, int j, const u128 &tx, uint32_t nmm, int sc0) {
   const int a = pz - wq;                                    // letters of the fragment in front of pz that the window holds
-  if (a <= 0) return pz == 0 ? (j - pz + 1 < (int)p.m) : false;
+  if (a <= 0) return pz == 0 ? (j - pz + 1 < (int)p.m || sc0 < (int)p.min_score) : false;
   if (a < 16 && wq > 0) return false;
   // f: the sixteen letters of the fragment in front of pz, laid out like tx (the letter at distance k, k = 0 next to the match,
   // in byte 15 - k); letters in front of the fragment's start read as zeros, which differ from every letter
@@ -3731,7 +3742,10 @@ KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz
   int e = 0;
   while (!((m >> e) & 1u)) e++;
   if (a < 16 && e > a) e = a;
-  return j - pz + 1 + e < (int)p.m;
+  if (j - pz + 1 + e < (int)p.m) return true;
+  // of the e letters gained, those at a difference were substituted
+  const int nsub = (int)popc64((uint64_t)(m16 & ((1u << e) - 1u)));
+  return sc0 + kMaxDiagScore * (e - nsub) + kMaxSubstScore * nsub < (int)p.min_score;
 }
 
 enum GKind : int { G_STEP, G_KMER, G_PROBE,                                              // fast (G_PROBE: a k-mer lookup, kGreedyProbe)
@@ -4460,9 +4474,10 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             // some are skipped).  Such an item is not queued (round 6; kj_chain_hopeless).  19.6 of the 24 variant items a
             // benchmark read pops hang on one row, and 15 of them are of this kind: seeds of seven or eight letters in a wrong
             // frame that three substitutions cannot turn into a match of eleven.
-            // (an item whose match has m letters already is not looked at: on a database of protein families most one-row variants
-            //  are of that kind, and the look costs a dependent load)
-            if (rb - ra == (P)1 && ix.sa_full && ix.text && m_ql + 1u < p.m) {
+            // (an item that passes the gate itself - m letters, min_score - is not looked at: on a database of protein families most
+            //  one-row variants are of that kind, and the look costs a dependent load)
+            const int sc0 = (int)m_dsum + t_diff + bos;           // the variant's own score (eval_match_scores: m_dsum + diff)
+            if (rb - ra == (P)1 && ix.sa_full && ix.text && (m_ql + 1u < p.m || sc0 < (int)p.min_score)) {
               // (the text position of the variant's match: one letter in front of its parent's when that had one row - that
               //  row's position came with the rank lines -, else the entry of the variant's own row)
 #ifdef KJ_CHAIN_PRUNE_HINT_ONLY
@@ -4471,7 +4486,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
               const uint32_t tp = vtp ? vtp : ix.sa_full[(uint32_t)ra];
 #endif
               if (tp >= 16u + kTextPad &&
-                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u)) {
+                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0)) {
                 if constexpr (COUNT) oc[kOpcPruned]++;
                 continue;
               }
