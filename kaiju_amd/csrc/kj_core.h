@@ -4485,6 +4485,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
 #else
               const uint32_t tp = vtp ? vtp : ix.sa_full[(uint32_t)ra];
 #endif
+              if constexpr (COUNT) oc[kOpcSa] += vtp ? 1u : 2u;    // (a line of text, and the row's entry of the full suffix array unless it came with the rank lines)
               if (tp >= 16u + kTextPad &&
                   kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0)) {
                 if constexpr (COUNT) oc[kOpcPruned]++;
