@@ -3699,9 +3699,11 @@ constexpr bool kChainPrune = true;
 // (the largest entry of the BLOSUM62 diagonal: W), a substitution at most kMaxSubstScore (the largest entry off the diagonal;
 // host_tables.cpp checks both against the table): if even that stays below min_score, no item of the chain passes the gate.
 constexpr int kMaxDiagScore = 11, kMaxSubstScore = 4;
-KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz, int j, const u128 &tx, uint32_t nmm, int sc0) {
+// thr: the score an item has to reach to matter - min_score, or the read's best score so far if that is higher (a match below
+// `best` changes nothing, :757-775, and best only grows)
+KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz, int j, const u128 &tx, uint32_t nmm, int sc0, int thr) {
   const int a = pz - wq;                                    // letters of the fragment in front of pz that the window holds
-  if (a <= 0) return pz == 0 ? (j - pz + 1 < (int)p.m || sc0 < (int)p.min_score) : false;
+  if (a <= 0) return pz == 0 ? (j - pz + 1 < (int)p.m || sc0 < thr) : false;
   if (a < 16 && wq > 0) return false;
   // f: the sixteen letters of the fragment in front of pz, laid out like tx (the letter at distance k, k = 0 next to the match,
   // in byte 15 - k); letters in front of the fragment's start read as zeros, which differ from every letter
@@ -3745,7 +3747,7 @@ KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz
   if (j - pz + 1 + e < (int)p.m) return true;
   // of the e letters gained, those at a difference were substituted
   const int nsub = (int)popc64((uint64_t)(m16 & ((1u << e) - 1u)));
-  return sc0 + kMaxDiagScore * (e - nsub) + kMaxSubstScore * nsub < (int)p.min_score;
+  return sc0 + kMaxDiagScore * (e - nsub) + kMaxSubstScore * nsub < thr;
 }
 
 enum GKind : int { G_STEP, G_KMER, G_PROBE,                                              // fast (G_PROBE: a k-mer lookup, kGreedyProbe)
@@ -4477,7 +4479,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             // (an item that passes the gate itself - m letters, min_score - is not looked at: on a database of protein families most
             //  one-row variants are of that kind, and the look costs a dependent load)
             const int sc0 = (int)m_dsum + t_diff + bos;           // the variant's own score (eval_match_scores: m_dsum + diff)
-            if (rb - ra == (P)1 && ix.sa_full && ix.text && (m_ql + 1u < p.m || sc0 < (int)p.min_score)) {
+            if (rb - ra == (P)1 && ix.sa_full && ix.text && (m_ql + 1u < p.m || sc0 < thr)) {
               // (the text position of the variant's match: one letter in front of its parent's when that had one row - that
               //  row's position came with the rank lines -, else the entry of the variant's own row)
 #ifdef KJ_CHAIN_PRUNE_HINT_ONLY
@@ -4487,7 +4489,7 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
 #endif
               if constexpr (COUNT) oc[kOpcSa] += vtp ? 1u : 2u;    // (a line of text, and the row's entry of the full suffix array unless it came with the rank lines)
               if (tp >= 16u + kTextPad &&
-                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0)) {
+                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0, thr)) {
                 if constexpr (COUNT) oc[kOpcPruned]++;
                 continue;
               }
