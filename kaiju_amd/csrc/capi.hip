@@ -1127,6 +1127,8 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   // host: its table starts on the device with the twenty one-letter intervals of InitialSI (bwt.c:146-152) and grows from there
   constexpr uint32_t kKmerResidentK = 5;          // depth of the table a narrow index keeps next to its k-mer lines
   void *kmer5 = nullptr;
+  // (the five-letter level is in nobody's list while the deeper levels grow: an early return below must not leak it)
+  struct FreeOnExit { void *&p; ~FreeOnExit() { if (p) (void)hipFree(p); } } kmer5_guard{kmer5};
   uint32_t host_k = pk.kmer_k;
   if (streamed && pk.alen == 21) {
     host_k = 5;

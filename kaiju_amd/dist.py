@@ -83,7 +83,11 @@ class HitGatherer:
 class LibGatherer:
     """The same through the LIBRARY's collective (kaiju_gpu_comm_create / kaiju_gpu_gather_compact: librccl opened by the
     library itself, no torch in the data path): one RCCL gather of 16-byte records per chunk to rank 0, asynchronous on the
-    stream the chunk's kernels run on.  ``comm``: api.Comm of this rank (make_comm below)."""
+    stream the chunk's kernels run on.  ``comm``: api.Comm of this rank (make_comm below).
+    Without ``keep_results`` rank 0 receives every chunk of a size into ONE buffer: the gathers are stream-ordered, so a later
+    chunk overwrites an earlier one - that mode is for timing; with ``keep_results`` every gather gets a buffer of its own.
+    What a gather costs on one GPU: 0.04 ms of kernel and 0.3 - 0.5 ms of host-side enqueue per call - one gather
+    per step, not one per chunk."""
 
     def __init__(self, comm, keep_results: bool = False):
         self.comm, self.world, self.rank = comm, comm.world, comm.rank
