@@ -867,7 +867,7 @@ def main():
             hdb = synth.make_db_hard(nseq=args.hard_nseq, seed=4321, leaves=leaves)
             hfmi = f"{W}/db_hard_{args.hard_nseq}.fmi"
             if not os.path.exists(hfmi):
-                synth.write_fasta(hdb, f"{W}/db_hard_{args.hard_nseq}.faa")
+                (synth.write_fasta_large if hdb.nseq > 1_000_000 else synth.write_fasta)(hdb, f"{W}/db_hard_{args.hard_nseq}.faa")
                 mkfmi.build_fmi(f"{W}/db_hard_{args.hard_nseq}.faa", hfmi + ".tmp", threads=0, exponent=3)
                 os.replace(hfmi + ".tmp", hfmi)
             hindex = api.Index(hfmi, device=local_rank)

@@ -91,11 +91,9 @@ constexpr int kS1Block = 64;
 template <bool TRIG, int UNITS = kS1Units>
 __global__ void __launch_bounds__(kS1Block)
 k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQueue sq, uint32_t *err) {
-  constexpr int kTs = UNITS <= kS1Units ? kTsBuf : kTsBufLong;
   __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
   __shared__ uint32_t s_codes[2 * kS1ListCap * kS1Block];
   __shared__ __attribute__((aligned(4))) uint8_t s_cnt[TRIG ? kS1Block * kS1CntStride : 4];
-  __shared__ __attribute__((aligned(4))) uint8_t s_ts[TRIG ? kS1Block * kTs : 4];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
     uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
@@ -108,7 +106,7 @@ k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQue
   S1Lane ln;
   ln.codes = s_codes + threadIdx.x; ln.code_stride = kS1Block;
   ln.cnt = s_cnt + (TRIG ? threadIdx.x * kS1CntStride : 0);
-  ln.tsbuf = s_ts + (TRIG ? threadIdx.x * kTs : 0);
+  ln.tsbuf = nullptr;                                  // (the scan of whole strings takes its residues from registers)
   build_fragments_fast<TRIG, UNITS>(s_t, p, b, sq, r, &e, ln);
   if (e) atomicOr(err, e);
 }
@@ -326,6 +324,22 @@ struct CoopWave {
   }
 };
 
+// a TEAM of T lanes per fragment (T a power of two below 64, the lanes of a team next to each other): the 64 / T teams of a
+// wavefront work on fragments of their own
+template <int T>
+struct CoopTeam {
+  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & (uint32_t)(T - 1)); }
+  __device__ __forceinline__ int width() const { return T; }
+  __device__ __forceinline__ void reduce_min(double &prob, int &t) const {
+#pragma unroll
+    for (int o = T / 2; o > 0; o >>= 1) {
+      const double op = __shfl_xor(prob, o, 64);
+      const int ot = __shfl_xor(t, o, 64);
+      if (op < prob || (op == prob && ot < t)) { prob = op; t = ot; }
+    }
+  }
+};
+
 // SEG pass: one wavefront (= one 64-thread block at a time) per fragment that stage 1 flagged; the
 // fragment is copied to LDS first.  The number of fragments lives in device memory.
 constexpr int kSegBlock = 64, kSegStage = 2048;
@@ -344,6 +358,39 @@ k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   const uint32_t n = min(*sq.count, sq.cap);
   for (uint32_t s = blockIdx.x; s < n; s += gridDim.x)       // trip count is uniform over the block
     seg_compute(cx, coop, b, p, sq, s, s_frag, kSegStage, s_work, s_cls, [] { __syncthreads(); });
+}
+// The same with 64 / T fragments per wavefront.  A fragment of a 150-bp read has 35 residues on average: what a wavefront
+// spends on it is mostly WAITING - the chain work item -> read -> fragment descriptor -> residues (four dependent loads), the
+// window classes, the scan that runs the same in every lane - and only s_Trim's sub-windows (66 .. 200 of them for the usual
+// raw segment of 12 .. 20 residues) use the lanes.  With teams the chains of 64 / T fragments overlap and s_Trim keeps the
+// same number of lanes busy.  The teams of a wavefront run in lock step where their control flow agrees and one after the
+// other where it does not; LDS: every team its own stage (kSegStage / teams bytes: longer fragments are read from device
+// memory, seg_compute), classes and lists.  The team's "barrier" is a fence: its lanes belong to one wavefront.
+#ifndef KJ_SEG_WAVES
+#define KJ_SEG_WAVES 3                    // (131 registers: four wavefronts per SIMD would spill 36 bytes a lane)
+#endif
+template <int T>
+__global__ void __launch_bounds__(kSegBlock, KJ_SEG_WAVES)
+k_seg_teams(Params p, SegTables st, Batch b, SegQueue sq) {
+  constexpr int NT = kSegBlock / T, kStage = kSegStage / NT;
+  __shared__ int64_t s_entg[13];
+  __shared__ double s_lnf[kSegLnf];
+  __shared__ __attribute__((aligned(16))) uint8_t s_frag[kSegStage];
+  __shared__ int32_t s_work[NT * 4 * kSegMaxRegions];
+  __shared__ uint8_t s_cls[kSegStage];
+  if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
+  if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
+  __syncthreads();
+  const SegCtx cx = seg_ctx(st, s_entg, s_lnf);
+  const CoopTeam<T> coop;
+  const uint32_t team = threadIdx.x / (uint32_t)T;
+  const uint32_t n = min(*sq.count, sq.cap);
+  for (uint32_t s0 = blockIdx.x * NT; s0 < n; s0 += gridDim.x * NT) {
+    const uint32_t s = s0 + team;
+    if (s < n)
+      seg_compute(cx, coop, b, p, sq, s, s_frag + team * kStage, kStage, s_work + team * 4 * kSegMaxRegions, s_cls + team * kStage,
+                  [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); });
+  }
 }
 
 // MEM: apply the SEG records to the fragment lists
@@ -399,10 +446,13 @@ k_mem(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_
 //  What such matches cost was the look-up of every row's taxon among the ids collected so far: reads whose matches hold more
 //  than kLocDeferRows rows are listed - one atomic per wavefront - and located by k_mem_locate_list, the instantiation that
 //  keeps the collected ids in registers)
+// WIDE: an index with 64-bit positions that had room for its row -> taxon table (112 GB at refseq_ref's 28 G rows: the 288 GB
+// of an MI355X hold it next to the index; without it: k_mem_locate_wide below)
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 k_mem_locate(DevIndex ix, Params p, Batch b, uint32_t *list, uint32_t *count) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  const bool defer = r < b.n_reads && !mem_locate_read<false>(ix, p, b.hits + r, list ? kLocDeferRows : 0u);
+  const bool defer = r < b.n_reads && !mem_locate_read<WIDE>(ix, p, b.hits + r, list ? kLocDeferRows : 0u);
   const uint64_t m = __ballot(defer);
   if (m) {
     const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__builtin_ctzll(m);
@@ -412,10 +462,11 @@ k_mem_locate(DevIndex ix, Params p, Batch b, uint32_t *list, uint32_t *count) {
     if (defer) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
   }
 }
+template <bool WIDE>
 __global__ void __launch_bounds__(256)
 k_mem_locate_list(DevIndex ix, Params p, Batch b, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count) {
   const uint32_t n = *count;
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) mem_locate_read<false, true>(ix, p, b.hits + list[t]);
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < n; t += gridDim.x * 256) mem_locate_read<WIDE, true>(ix, p, b.hits + list[t]);
 }
 // Indexes without the row -> sequence table (wide ones; narrow ones that had no room for the text arrays): a TEAM of kLocTeam
 // lanes per read walks the rows of a match side by side (mem_locate_read_team)
@@ -789,9 +840,12 @@ k_seq_walk_len(DevIndex ix, uint32_t *next, uint32_t *__restrict__ t_seq, uint32
 }
 __global__ void __launch_bounds__(256)
 k_seq_walk_fill(DevIndex ix, uint32_t *next, const uint32_t *__restrict__ t_seq, const uint32_t *__restrict__ len, const uint64_t *__restrict__ off,
-                uint8_t *__restrict__ text, uint8_t *__restrict__ tpos5, uint32_t tv_shift) {
+                uint8_t *__restrict__ text, uint8_t *__restrict__ tpos5, uint32_t tv_shift,
+                uint32_t *__restrict__ row_tax, const uint32_t *__restrict__ seq_dense) {
+  // text / tpos5 (both or neither) and row_tax are optional: the walk fills what the index had room for
   const uint64_t tvm = (1ull << tv_shift) - 1ull;
   uint64_t k = 0, g = 0, left = 0;
+  uint32_t dq = 0xffffffffu;
   bool active = false;
   for (;;) {
     if (!active) {
@@ -799,10 +853,14 @@ k_seq_walk_fill(DevIndex ix, uint32_t *next, const uint32_t *__restrict__ t_seq,
       if (t >= ix.nseq) break;
       const uint32_t q = t_seq[t];
       k = t; g = off[(size_t)q + 1]; left = (uint64_t)len[q] + 1; active = true;
+      if (row_tax) dq = seq_dense[q];
     }
-    if ((k & tvm) == 0) put_tpos5(tpos5, k >> tv_shift, g);
+    if (row_tax) row_tax[k] = dq;
     const uint32_t c = symbol_at(ix, k);
-    text[g - 1] = (uint8_t)c;
+    if (text) {
+      if ((k & tvm) == 0) put_tpos5(tpos5, k >> tv_shift, g);
+      text[g - 1] = (uint8_t)c;
+    }
     if (c == 0 || --left == 0) active = false;
     else { k = rank_c(ix, c, k); g--; }
   }
@@ -1339,25 +1397,39 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
   //      (KAIJU_GPU_TV_SHIFT=s forces a sample; every second row at refseq_ref's 28 G rows would be 98 GB next to the index's
   //      92 GB, nothing fits at refseq_nr's 58 G): measured on 4.35 G rows only (profiles/r04_wide_text) ----
   d.sa_tpos5 = nullptr; d.tv_shift = 0;
-  uint64_t tpos_bytes = 0;
+  uint64_t tpos_bytes = 0, rowtax_bytes = 0;
+  // ---- and the row -> taxon table (4 B per row, DevIndex::row_tax): with it the ids of a match are contiguous loads, as on a
+  //      narrow index, instead of a walk of up to 2^e LF steps per row - k_mem_locate_wide was the largest kernel of a step
+  //      wherever matches hold many rows (a database of protein families at 4.5 G rows: 35 of 47 ms per 2 M reads; refseq_ref's
+  //      28 G rows with every protein seven times: 25 of 64 ms).  It comes FIRST when HBM is short (the text arrays save 6 % of
+  //      the search kernel, section 5b of DESIGN.md): built when it fits - with 8 GB for the classification contexts - in 70 % of
+  //      the free HBM, i.e. up to about 30 G rows on a 288 GB MI355X (112 GB at 28 G rows next to the index's 92 GB);
+  //      KAIJU_GPU_ROW_TAX=0 / 1 overrides.  Filled by the same walk of every sequence that writes the text ----
   // (not on an index with the reference's short sample array: a text-grown match is recorded through the row where the text took
   //  over, the lanes without the arrays record its own end row - and whether that row lies behind the missing sample would then
-  //  depend on whether the arrays fit; the narrow lane applies the skip to the grown match itself, DevIndex::beyond_lo)
+  //  depend on whether the arrays fit; the narrow lane applies the skip to the grown match itself, DevIndex::beyond_lo.  The
+  //  row -> taxon table likewise: the rows behind the missing sample are skipped by the walk, and known only to it)
   if (d.mb_base && d.blocks64 && d.term_pos && !getenv("KAIJU_GPU_NO_TEXT") && pk.bwtlen + 4 * (uint64_t)kTextPad < kTposNone &&
       !(pk.warnings & KAIJU_IDX_WARN_SA_SHORT)) {
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
-    const uint64_t tb_est = pk.bwtlen + 3 * (uint64_t)kTextPad, tmp = (uint64_t)pk.nseq * 16 + 64;
+    const uint64_t tb_est = pk.bwtlen + 3 * (uint64_t)kTextPad, tmp = (uint64_t)pk.nseq * 20 + 64;
+    const uint64_t rt_est = pk.bwtlen * 4 + 64;
+    bool rt = (double)(rt_est + tmp + (8ull << 30)) <= 0.7 * (double)free_b;
+    if (const char *e = getenv("KAIJU_GPU_ROW_TAX")) rt = atoi(e) != 0;
+    const double free_tv = (double)free_b - (rt ? (double)rt_est : 0.0);
     int tv = -1;
     if (const char *e = getenv("KAIJU_GPU_TV_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 8) tv = v; }
     else if (pk.bwtlen < (1ull << 34))
       for (int v = 0; v <= 3 && tv < 0; v++)
-        if ((double)(tb_est + ((pk.bwtlen >> v) + 1) * 5 + tmp + (8ull << 30)) <= 0.6 * (double)free_b) tv = v;
-    if (tv >= 0) {
-      uint32_t *t_seq = nullptr, *d_len = nullptr, *d_cnt = nullptr;
+        if ((double)(tb_est + ((pk.bwtlen >> v) + 1) * 5 + tmp + (8ull << 30)) <= 0.6 * free_tv) tv = v;
+    if (tv >= 0 || rt) {
+      uint32_t *t_seq = nullptr, *d_len = nullptr, *d_cnt = nullptr, *row_tax = nullptr;
       uint64_t *d_off = nullptr;
       uint8_t *text = nullptr, *tpos = nullptr;
-      tpos_bytes = ((pk.bwtlen >> tv) + 1) * 5 + 16;
+      const uint32_t *d_sd = nullptr;
+      const uint64_t *d_td = nullptr;
+      if (tv >= 0) tpos_bytes = ((pk.bwtlen >> tv) + 1) * 5 + 16;
       bool ok = hipMalloc((void **)&t_seq, (size_t)pk.nseq * 4 + 16) == hipSuccess && hipMalloc((void **)&d_len, (size_t)pk.nseq * 4 + 16) == hipSuccess &&
                 hipMalloc((void **)&d_off, ((size_t)pk.nseq + 1) * 8) == hipSuccess && hipMalloc((void **)&d_cnt, 16) == hipSuccess;
       if (ok) {
@@ -1374,25 +1446,46 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
              hipMemcpy(cnt, d_cnt, 8, hipMemcpyDeviceToHost) == hipSuccess && cnt[1] == 0;
         off[0] = kTextPad;
         for (uint32_t q = 0; q < pk.nseq; q++) off[(size_t)q + 1] = off[q] + len[q] + 1;
-        text_bytes = off[pk.nseq] + 2 * kTextPad;
         // (every row lies on exactly one walk: the lengths add up to the rows of the index, or the index is damaged)
-        ok = ok && off[pk.nseq] - kTextPad == pk.bwtlen && text_bytes < kTposNone &&
-             hipMemcpy(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
-             hipMalloc((void **)&text, text_bytes) == hipSuccess && hipMalloc((void **)&tpos, tpos_bytes) == hipSuccess;
-        if (ok) {
-          (void)hipMemset(text, 0, text_bytes);
-          (void)hipMemset(tpos, 0xff, tpos_bytes);
+        ok = ok && off[pk.nseq] - kTextPad == pk.bwtlen &&
+             hipMemcpy(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice) == hipSuccess;
+        if (ok && tv >= 0) {
+          text_bytes = off[pk.nseq] + 2 * kTextPad;
+          // (no room after all, or a text beyond 40-bit positions: the table below is still built)
+          if (!(text_bytes < kTposNone && hipMalloc((void **)&text, text_bytes) == hipSuccess && hipMalloc((void **)&tpos, tpos_bytes) == hipSuccess)) {
+            (void)hipGetLastError();
+            if (text) (void)hipFree(text);
+            text = nullptr; tpos = nullptr; text_bytes = 0; tpos_bytes = 0; tv = -1;
+          }
+        }
+        if (ok && rt) {
+          std::vector<uint32_t> seq_dense;
+          std::vector<uint64_t> tax_of_dense;
+          dense_taxa(pk.seq_taxid, pk.seq_valid, seq_dense, tax_of_dense);
+          rowtax_bytes = pk.bwtlen * 4 + 64;                   // (+ slack: the many-rows locate reads 16 bytes at a time)
+          if (upload(ix.get(), seq_dense, &d_sd) == 0) { ix->allocs.pop_back(); } else d_sd = nullptr;
+          if (d_sd && upload(ix.get(), tax_of_dense, &d_td) == 0) { ix->allocs.pop_back(); } else d_td = nullptr;
+          if (!(d_sd && d_td && hipMalloc((void **)&row_tax, rowtax_bytes) == hipSuccess)) {
+            (void)hipGetLastError();
+            row_tax = nullptr; rowtax_bytes = 0; rt = false;
+          } else { d.n_dense = (uint32_t)tax_of_dense.size(); }
+        }
+        if (ok && (text || row_tax)) {
+          if (text) { (void)hipMemset(text, 0, text_bytes); (void)hipMemset(tpos, 0xff, tpos_bytes); }
+          if (row_tax) (void)hipMemset(row_tax, 0xff, rowtax_bytes);
           (void)hipMemset(d_cnt, 0, 16);
-          hipLaunchKernelGGL(k_seq_walk_fill, dim3(blocks), dim3(256), 0, 0, d, d_cnt, t_seq, d_len, d_off, text, tpos, (uint32_t)tv);
+          hipLaunchKernelGGL(k_seq_walk_fill, dim3(blocks), dim3(256), 0, 0, d, d_cnt, t_seq, d_len, d_off, text, tpos, (uint32_t)std::max(tv, 0), row_tax, d_sd);
           ok = hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess;
         }
       }
       (void)hipGetLastError();
-      for (void *q : {(void *)t_seq, (void *)d_len, (void *)d_off, (void *)d_cnt}) if (q) (void)hipFree(q);
-      if (ok) { ix->allocs.push_back(text); ix->allocs.push_back(tpos); d.text = text; d.sa_tpos5 = tpos; d.tv_shift = (uint32_t)tv; }
+      for (void *q : {(void *)t_seq, (void *)d_len, (void *)d_off, (void *)d_cnt, (void *)d_sd}) if (q) (void)hipFree(q);
+      if (ok && text) { ix->allocs.push_back(text); ix->allocs.push_back(tpos); d.text = text; d.sa_tpos5 = tpos; d.tv_shift = (uint32_t)tv; }
       else { if (text) (void)hipFree(text); if (tpos) (void)hipFree(tpos); text_bytes = 0; tpos_bytes = 0; }
+      if (ok && row_tax) { ix->allocs.push_back(row_tax); ix->allocs.push_back(const_cast<uint64_t *>(d_td)); d.row_tax = row_tax; d.tax_of_dense = d_td; }
+      else { if (row_tax) (void)hipFree(row_tax); if (d_td) (void)hipFree(const_cast<uint64_t *>(d_td)); rowtax_bytes = 0; d.n_dense = 0; }
     }
-    lc.mark("text + text positions (device, 64-bit rows)");
+    lc.mark("text + text positions, row -> taxon table (device, 64-bit rows)");
   } else
   lc.mark("text + full suffix array (device)");
   kaiju_gpu_index_info &inf = ix->info;
@@ -1416,7 +1509,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     f.kmer_lines = d.kline ? nlw * kKLineBytes : 0;
     f.other = sizeof(ConstTables) + sizeof(Stage1Tables) + lnfact.size() * 8;
     f.text = d.text ? text_bytes : 0;
-    f.sa_full = d.sa_full ? pk.bwtlen * 8 : d.sa_tpos5 ? tpos_bytes : 0;   // (+ the sequence of every row, DevIndex::row_seq; wide: the text positions)
+    f.sa_full = d.sa_full ? pk.bwtlen * 8 : (d.sa_tpos5 ? tpos_bytes : 0) + (d.mb_base && d.row_tax ? rowtax_bytes : 0);   // (+ the taxon of every row, DevIndex::row_tax; wide: the text positions + that table)
     f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other + f.text + f.sa_full;
     f.kmer_k = std::max(d.kmer_k, d.kline_k); f.wide = d.mb_base ? 1u : 0u;
     inf.device_bytes = f.total;
@@ -1738,6 +1831,7 @@ struct kaiju_gpu_ctx {
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
   DevBuf seglist, loc_list, todo_list;
+  int seg_team = 16;               // KAIJU_GPU_SEG_TEAM: lanes per fragment of the SEG pass (8, 16, 32; 64 = one wavefront per fragment, k_seg)
   bool fused_post = true;          // KAIJU_GPU_FUSED_POST=0: k_trigcheck / k_mem_locate / k_lca as separate passes (A/B measurements)
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
@@ -1809,6 +1903,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   if (const char *e = getenv("KAIJU_GPU_STAGE1")) c->stage1_old = !strcmp(e, "old");
   if (const char *e = getenv("KAIJU_GPU_LAZY_SEG")) c->lazy_seg = atoi(e) != 0;
   if (const char *e = getenv("KAIJU_GPU_FUSED_POST")) c->fused_post = atoi(e) != 0;
+  if (const char *e = getenv("KAIJU_GPU_SEG_TEAM")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) c->seg_team = v; }
   // kaijux: the MEM search of ConsumerThreadx.cpp:135 (maxMatches(.., 1)) finds the same longest matches as
   // greedyExact but lists them in another order, which shows where the id cap cuts and in the peptides of -v
   if (ix->id_mode == KAIJU_GPU_IDS_SEQUENCE && p->mode == 0) c->kp.flags |= kParamXOrder;
@@ -1870,6 +1965,16 @@ extern "C" void kaiju_gpu_destroy(kaiju_gpu_ctx *ctx) { delete ctx; }
 // [2] retry list length, [3] stage-1 error flags
 // tax / d_compact: not null = the 16-byte records (LCA on the device) are written too - by the fused post-search pass where
 // that serves the configuration (k_mem_post1 / k_mem_post2), by k_lca behind everything else otherwise
+// the SEG pass over the fragments stage 1 (or k_segflag) queued
+static void launch_seg(const kaiju_gpu_ctx *c, hipStream_t s, const Params &p, const SegTables &st, const Batch &b, const SegQueue &sq) {
+  const dim3 grid(c->n_cu * 32), blk(kSegBlock);
+  switch (c->seg_team) {
+    case 8: hipLaunchKernelGGL(k_seg_teams<8>, grid, blk, 0, s, p, st, b, sq); break;
+    case 16: hipLaunchKernelGGL(k_seg_teams<16>, grid, blk, 0, s, p, st, b, sq); break;
+    case 32: hipLaunchKernelGGL(k_seg_teams<32>, grid, blk, 0, s, p, st, b, sq); break;
+    default: hipLaunchKernelGGL(k_seg, grid, blk, 0, s, p, st, b, sq); break;
+  }
+}
 static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes, const uint64_t *d_off,
                         uint32_t n, int paired, uint32_t max_read_len, kaiju_gpu_hit *d_out, hipStream_t s,
                         const kaiju_gpu_taxonomy *tax = nullptr, kaiju_gpu_compact *d_compact = nullptr) {
@@ -1955,7 +2060,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   }
   KJ_HIP(hipEventRecord(c->ev[1], s));
   if (n > 0 && p.seg && !lazy) {
-    hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 32), dim3(kSegBlock), 0, s, p, ix->st, b, sq);
+    launch_seg(c, s, p, ix->st, b, sq);
     KJ_HIP(hipGetLastError());
     if (p.mode == 0) {
       hipLaunchKernelGGL(k_seg_apply, grid_reads, blk, 0, s, ix->d_ct, p, b, sq, cnt + 3);
@@ -2070,7 +2175,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         uint32_t *seglist = static_cast<uint32_t *>(c->seglist.p);
         if (!fused) hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->d_s1, b, seglist, cnt + 22);
         hipLaunchKernelGGL(k_segflag, dim3(c->n_cu * 4), dim3(256), 0, s, p, ix->st, b, sq, seglist, cnt + 22, cnt + 3);
-        hipLaunchKernelGGL(k_seg, dim3(c->n_cu * 32), dim3(kSegBlock), 0, s, p, ix->st, b, sq);
+        launch_seg(c, s, p, ix->st, b, sq);
         hipLaunchKernelGGL(k_seg_apply_list, dim3(c->n_cu * 4), blk, 0, s, ix->d_ct, p, b, sq, seglist, cnt + 22, cnt + 3);
         WorkList wl_seg;
         wl_seg.counter = cnt + 23; wl_seg.reads = seglist; wl_seg.n_items_ptr = cnt + 22; wl_seg.n_items = 0;
@@ -2083,10 +2188,14 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       KJ_HIP(hipGetLastError());
       if (defer && !fused) {
         if (mem_narrow2 && ix->dev.row_tax) {
-          hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
-          hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+          hipLaunchKernelGGL(k_mem_locate<false>, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+          hipLaunchKernelGGL(k_mem_locate_list<false>, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
         }
         else if (mem_narrow2) hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
+        else if (ix->dev.row_tax) {
+          hipLaunchKernelGGL(k_mem_locate<true>, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+          hipLaunchKernelGGL(k_mem_locate_list<true>, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
+        }
         else hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());
       }
@@ -2183,10 +2292,14 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
       if (pg.flags & kParamDeferLocate) {
-        if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
+        if (g_wide && ix->dev.row_tax) {
+          hipLaunchKernelGGL(k_mem_locate<true>, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+          hipLaunchKernelGGL(k_mem_locate_list<true>, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+        }
+        else if (g_wide) hipLaunchKernelGGL(k_mem_locate_wide, grid_team, dim3(256), 0, s, ix->dev, p, b);
         else if (ix->dev.row_tax) {
-          hipLaunchKernelGGL(k_mem_locate, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
-          hipLaunchKernelGGL(k_mem_locate_list, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+          hipLaunchKernelGGL(k_mem_locate<false>, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
+          hipLaunchKernelGGL(k_mem_locate_list<false>, dim3(c->n_cu * 8), dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
         }
         else hipLaunchKernelGGL(k_mem_locate_team, grid_team, dim3(256), 0, s, ix->dev, p, b);
         KJ_HIP(hipGetLastError());

@@ -648,11 +648,19 @@ void PackedIndex::build_text_wide(uint32_t shift) {
   if (off[nseq] + 2 * kTextPad >= kTposNone) return;
   text.assign((size_t)(off[nseq] + 2 * kTextPad), 0);
   sa_tpos5.assign((size_t)(((bwtlen >> shift) + 1) * 5 + 16), 0xff);
+  // the row -> dense taxon index table of a wide index (capi.hip builds it where HBM has room; KAIJU_EMU_NO_ROW_TAX: without)
+  std::vector<uint32_t> seq_dense;
+  const bool rt = !getenv("KAIJU_EMU_NO_ROW_TAX");
+  if (rt) {
+    dense_taxa(seq_taxid, seq_valid, seq_dense, tax_of_dense);
+    row_seq.resize((size_t)bwtlen + 16);
+    for (size_t r = 0; r < row_seq.size(); r++) row_seq[r] = 0xffffffffu;
+  }
   parallel_for(((uint64_t)nseq + 255) / 256, [&](uint64_t chunk) {
     const uint64_t b = chunk * 256, e = std::min<uint64_t>(nseq, b + 256);
     for (uint64_t t = b; t < e; t++) {
       const uint32_t q = t_seq[(size_t)t];
-      seq_walk_fill(d, t, off[(size_t)q + 1], len[q], text.data(), sa_tpos5.data(), shift);
+      seq_walk_fill(d, t, off[(size_t)q + 1], len[q], text.data(), sa_tpos5.data(), shift, rt ? row_seq.data() : nullptr, rt ? seq_dense[q] : 0xffffffffu);
     }
   });
 }

@@ -519,13 +519,17 @@ KJ_HD void put_tpos5(uint8_t *a, uint64_t idx, uint64_t g) {
   uint8_t *e = a + idx * 5u;
   e[0] = (uint8_t)g; e[1] = (uint8_t)(g >> 8); e[2] = (uint8_t)(g >> 16); e[3] = (uint8_t)(g >> 24); e[4] = (uint8_t)(g >> 32);
 }
-KJ_HD void seq_walk_fill(const DevIndex &ix, uint64_t t, uint64_t g_end, uint64_t n, uint8_t *text, uint8_t *tpos5, uint32_t tv_shift) {
+// row_tax (optional): every row on the way also gets `dense`, the dense taxon index of the walk's sequence (DevIndex::row_tax
+// of an index with 64-bit positions; text / tpos5 may then be null)
+KJ_HD void seq_walk_fill(const DevIndex &ix, uint64_t t, uint64_t g_end, uint64_t n, uint8_t *text, uint8_t *tpos5, uint32_t tv_shift,
+                         uint32_t *row_tax = nullptr, uint32_t dense = 0xffffffffu) {
   const uint64_t tvm = (1ull << tv_shift) - 1ull;
   uint64_t k = t, g = g_end;
   for (uint64_t step = 0; step <= n; step++) {
-    if ((k & tvm) == 0) put_tpos5(tpos5, k >> tv_shift, g);
+    if (tpos5 && (k & tvm) == 0) put_tpos5(tpos5, k >> tv_shift, g);
+    if (row_tax) row_tax[k] = dense;
     const uint32_t c = symbol_at(ix, k);
-    text[g - 1] = (uint8_t)c;
+    if (text) text[g - 1] = (uint8_t)c;
     if (c == 0) return;
     k = rank_c(ix, c, k);
     g--;
@@ -1300,6 +1304,9 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
     auto final_flags = [&](uint32_t trig, uint32_t k) -> uint32_t {
       if (!p.seg) return 0u;
       if (!trig) return kFragChecked;                        // SEG would report nothing for this fragment
+#ifdef KJ_S1_NOAPPEND                                        // (timing experiments only: wrong results)
+      return kFragChecked;
+#endif
       const uint32_t slot = append_slot(sq.count);
       if (slot >= sq.cap) { if (err_flags) *err_flags |= 2u; return kFragChecked; }
       SegWork wk; wk.read = r; wk.frag = k;
@@ -1531,6 +1538,44 @@ KJ_HD MaskT trig_scan(const Stage1Tables &t, const uint8_t *x0, uint32_t n, uint
   }
   return mask;
 }
+// The same scan over the nu <= UNITS 16-byte units of a whole frame string at src (16-byte aligned), the residues taken from
+// REGISTERS: the unit that is scanned and the one before it (the letter that leaves the window ending at byte j of a unit is
+// byte j + 4 of the previous unit or byte j - 12 of this one; in front of the string: stops).  Both counts of a step are read
+// before either is written - a letter that joins AND leaves changes nothing -, so a step waits for ONE trip to LDS; the scan
+// through the staging buffer above waits for six (its byte pointers may alias each other as far as the compiler can tell, so
+// the loads of x, count[x], y, count[y] and the two stores between them stay in program order).
+template <int UNITS, class MaskT>
+KJ_HD MaskT trig_scan_units(const Stage1Tables &t, const uint8_t *src, uint32_t nu, uint8_t *row) {
+  uint32_t *c32 = reinterpret_cast<uint32_t *>(row);
+#pragma unroll
+  for (int q = 0; q < kS1CntRow / 4; q++) c32[q] = q == 0 ? (kS1StopCnt + 12u * 4u) : 0u;
+  int32_t sc = 12 * t.dtab[13];
+  const uint8_t *db = reinterpret_cast<const uint8_t *>(t.dtab);
+  MaskT mask = mk_zero(MaskT{});
+  uint32_t pw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < UNITS; k++) {
+    if ((uint32_t)k < nu) {
+      const u128 v = *reinterpret_cast<const u128 *>(src + 16 * k);
+      const uint32_t w[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const uint32_t x = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+        const uint32_t y = j < 12 ? (pw[(j + 4) >> 2] >> (8 * ((j + 4) & 3))) & 255u : (w[(j - 12) >> 2] >> (8 * ((j - 12) & 3))) & 255u;
+        const uint32_t rx = row[x], ry = row[y];
+        const bool same = x == y;
+        row[x] = (uint8_t)(same ? rx : rx + 4u);
+        row[y] = (uint8_t)(same ? rx : ry - 4u);
+        const int32_t dx = *reinterpret_cast<const int32_t *>(db + rx), dy = *reinterpret_cast<const int32_t *>(db + ry - 4u);
+        sc += same ? 0 : dx - dy;
+        mk_setbit(mask, (uint32_t)(16 * k + j), sc <= t.locut32);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) pw[q] = w[q];
+    }
+  }
+  return mask;
+}
 // nu 16-byte units from device memory (16-byte aligned) behind the zeros of the lane's staging buffer
 KJ_HD void trig_stage(const uint8_t *src, uint32_t nu, uint8_t *buf) {
   uint32_t *b32 = reinterpret_cast<uint32_t *>(buf);
@@ -1670,14 +1715,17 @@ KJ_HD void build_fragments_fast(const Stage1Tables &t, const Params &p, const Ba
     auto scan_mate = [&](uint8_t *dst, uint32_t len) {
       const uint32_t u = len / 48u + 1u;
       for (int f = 0; f < 6; f++) {
-        trig_stage(dst + (size_t)f * 16 * u, u, ln.tsbuf);
-        const MaskT mm = trig_scan<true, MaskT>(t, ln.tsbuf + kTsLead, 16 * u, 0, ln.tsbuf, ln.cnt);
-        tg[f] = f < 3 ? mm : mk_shl(mk_rev_low(mm, 16 * u), 11);
+        const MaskT mm = trig_scan_units<UNITS, MaskT>(t, dst + (size_t)f * 16 * u, u, ln.cnt);
+        const MaskT tv = f < 3 ? mm : mk_shl(mk_rev_low(mm, 16 * u), 11);
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (q == f) tg[q] = tv;  // (the loop over f stays a loop - 64 to 96 unrolled steps each -: no dynamic index into registers)
       }
     };
     if (len1 >= m3) {
       s1_mate(t, b.seqs + o0, len1, area, ns);
+#ifndef KJ_S1_NOSCAN                                         // (timing experiments only: wrong results)
       if (TRIG && p.seg) scan_mate(area, len1);
+#endif
       s1_runs(ns, tg, len1, p.m, 0, 0, emit);
     }
     if (b.paired && len2 >= m3) {
@@ -2878,9 +2926,7 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
       if (!dup && nids < (uint32_t)kMaxIds) { if (nids == 0) id0 = tax; hit->taxid[nids++] = tax; }
     }
   };
-  bool dense = false;
-  if constexpr (!WIDE) dense = ix.row_tax != nullptr;
-  static_assert(!MANYROWS || !WIDE, "the many-rows locate reads the row -> taxon table of a narrow index");
+  const bool dense = ix.row_tax != nullptr;                   // (wide indexes: where HBM had room for it, capi.hip)
   bool done = false;
   for (uint32_t s = 0; s < nsi && !done; s++) {
     const uint64_t es = MANYROWS ? hit->taxid[s] : e[MANYROWS ? 0 : s];
@@ -2905,13 +2951,11 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
     }
     for (P row = lo; row < rowend; row++) {
       if (nids > p.max_match_ids) { flags |= kHitIdCap; done = true; break; }     // :805-807
-      if constexpr (!WIDE) {
-        if (dense) {
-          // the walk below, precomputed for every row at index load (k_suffix_walk), down to the taxon
-          const uint32_t t = ix.row_tax[row];
-          if (t != 0xffffffffu) add_tax(t);
-          continue;
-        }
+      if (dense) {
+        // the walk below, precomputed for every row at index load (k_suffix_walk; wide: k_seq_walk_fill), down to the taxon
+        const uint32_t t = ix.row_tax[row];
+        if (t != 0xffffffffu) add_tax(t);
+        continue;
       }
       P k = row;
       for (;;) {
@@ -3035,11 +3079,9 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
   };
   // the id of one row: ~0 = none (a name without a usable id, or a row beyond the samples, where the reference reads out of bounds)
   auto walk = [&](P k) -> uint64_t {
-    if constexpr (!WIDE) {
-      if (ix.row_tax) {                                       // the walk below, precomputed for every row at index load (k_suffix_walk)
-        const uint32_t t = ix.row_tax[k];
-        return t != 0xffffffffu ? ix.tax_of_dense[t] : ~0ull;
-      }
+    if (ix.row_tax) {                                         // the walk below, precomputed for every row at index load (k_suffix_walk)
+      const uint32_t t = ix.row_tax[k];
+      return t != 0xffffffffu ? ix.tax_of_dense[t] : ~0ull;
     }
     for (;;) {
       if ((k & check) == 0) {
@@ -3081,7 +3123,7 @@ KJ_HD void mem_locate_read_team(const DevIndex &ix, const Params &p, Hit *hit, T
     for (P row0 = lo; row0 < rowend && !done; row0 += (P)(2 * T)) {
       team.compute2([&](int tl, uint64_t &ta, uint64_t &tb) {
         const P ra = row0 + (P)tl, rb2 = row0 + (P)T + (P)tl;
-        if constexpr (!WIDE) if (ix.row_tax) { ta = ra < rowend ? walk(ra) : ~0ull; tb = rb2 < rowend ? walk(rb2) : ~0ull; return; }
+        if (ix.row_tax) { ta = ra < rowend ? walk(ra) : ~0ull; tb = rb2 < rowend ? walk(rb2) : ~0ull; return; }
         P k[2] = {ra, rb2};
         bool fin[2] = {!(ra < rowend), !(rb2 < rowend)};
         uint64_t res[2] = {~0ull, ~0ull};

@@ -238,7 +238,8 @@ def make_db_hard(nseq=200001, seed=4321, leaves=None, fam_lo=50, fam_hi=500, fra
     offsets = np.zeros(nseq + 1, dtype=np.int64)
     np.cumsum(lens, out=offsets[1:])
     taxids = np.concatenate(taxids).astype(np.int64)
-    return SynthDB(codes=np.concatenate(seqs), offsets=offsets, taxids=taxids, names=[f"WP{n:09d}.1_{t}" for n, t in enumerate(taxids)])
+    names = _LazyNames(taxids) if nseq > 1_000_000 else [f"WP{n:09d}.1_{t}" for n, t in enumerate(taxids)]
+    return SynthDB(codes=np.concatenate(seqs), offsets=offsets, taxids=taxids, names=names)
 
 
 def sprinkle_n(reads: np.ndarray, seed=99, frac_reads=0.05, max_n=4):

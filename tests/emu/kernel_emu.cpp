@@ -185,6 +185,11 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   } else
   for (uint32_t r = 0; r < n; r++) build_fragments(ix->ct, p, TrigCtx{ix->st.ent_g32, ix->st.ent_locut32}, b, sq, r, &err, staged ? stage.data() : nullptr, 4, (uint32_t)(stage.size() / 4));
   if (p.seg && !lazy) {
+    if (getenv("KAIJU_EMU_SEG_COUNT")) {                 // how much work the eager SEG pass gets (tools: sizing of k_seg)
+      uint64_t tl = 0;
+      for (uint32_t s = 0; s < seg_count && s < seg_cap; s++) tl += b.frags[b.meta[seg_items[s].read].frag + seg_items[s].frag].len;
+      fprintf(stderr, "[emu] SEG pass: %u fragments of %u reads, %.1f residues each\n", seg_count, n, seg_count ? (double)tl / seg_count : 0.0);
+    }
     int32_t segwork[4 * kSegMaxRegions];
     std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
     std::vector<uint8_t> segcls(64);
@@ -361,7 +366,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   //  team of four whose walks run one after the other, KAIJU_EMU_LOCATE_SERIAL=1: the one-lane function)
   if (locate_pass) for (uint32_t r = 0; r < n; r++) {
     const bool serial = getenv("KAIJU_EMU_LOCATE_SERIAL") != nullptr;
-    if (d.mb_base) { if (serial) mem_locate_read<true>(d, p, &hits[r]); else { TeamSerial<4> tm; mem_locate_read_team<true, 4>(d, p, &hits[r], tm); } }
+    if (d.mb_base && d.row_tax && !serial) { if (!mem_locate_read<true>(d, p, &hits[r], 8)) mem_locate_read<true, true>(d, p, &hits[r]); }   // (k_mem_locate<true>, k_mem_locate_list<true>)
+    else if (d.mb_base) { if (serial) mem_locate_read<true>(d, p, &hits[r]); else { TeamSerial<4> tm; mem_locate_read_team<true, 4>(d, p, &hits[r], tm); } }
     else if (serial) mem_locate_read<false>(d, p, &hits[r]);
     else if (d.row_tax) { if (!mem_locate_read<false>(d, p, &hits[r], 8)) mem_locate_read<false, true>(d, p, &hits[r]); }   // (k_mem_locate, k_mem_locate_list)
     else { TeamSerial<4> tm; mem_locate_read_team<false, 4>(d, p, &hits[r], tm); }

@@ -120,12 +120,14 @@ def test_device_lca_compact_records(gpu_lib, golden, gidx, mode, seg):
             assert (ref[n][0] == "C") == bool(r["classified"]) and (not r["classified"] or int(r["taxon"]) == ref[n][1]), n
 
 
-@pytest.mark.parametrize("shift", ["16", "20", "31"])
-def test_wide_index_path(gpu_lib, golden, oracle, ohandles, shift, monkeypatch):
+@pytest.mark.parametrize("shift,rowtax", [("16", "1"), ("20", "1"), ("31", "1"), ("20", "0")])
+def test_wide_index_path(gpu_lib, golden, oracle, ohandles, shift, rowtax, monkeypatch):
     """indexes of 2^32 rows and more: 64-bit positions, rank counts relative to a base every 2^shift rows, 16-byte
-    k-mer entries grown on the device - forced here on the small golden index (KAIJU_GPU_FORCE_WIDE)"""
+    k-mer entries grown on the device - forced here on the small golden index (KAIJU_GPU_FORCE_WIDE); the ids through the
+    row -> taxon table (k_mem_locate<true>, k_mem_locate_list<true>) and, without it, through the walks of k_mem_locate_wide"""
     api = gpu_lib
     monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
+    monkeypatch.setenv("KAIJU_GPU_ROW_TAX", rowtax)
     monkeypatch.setenv("KAIJU_GPU_KMER", "6")
     idx = api.Index(golden.fmi)
     ix, tax = ohandles
@@ -157,16 +159,23 @@ def test_text_positions_of_an_index_with_64_bit_rows(gpu_lib, oracle, tmp_path, 
     ix = oracle.load_fmi(fmi)
     want = {pe: oracle.classify(ix, None, oracle.params("mem", seg=1), s, o, paired=pe) for s, o, pe in ((seqs, off, False), (pseqs, poff, True))}
     monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", "18")
-    for tv in ("none", "auto", "0", "1", "3"):
+    # (tv "-1": no text, only the row -> taxon table - what a refseq_ref-class index gets; "1/walks": the text without that table)
+    for tv in ("none", "auto", "0", "1", "3", "-1", "1/walks"):
         monkeypatch.delenv("KAIJU_GPU_NO_TEXT", raising=False)
         monkeypatch.delenv("KAIJU_GPU_TV_SHIFT", raising=False)
+        monkeypatch.delenv("KAIJU_GPU_ROW_TAX", raising=False)
         if tv == "none":
             monkeypatch.setenv("KAIJU_GPU_NO_TEXT", "1")
+        elif tv == "1/walks":
+            monkeypatch.setenv("KAIJU_GPU_TV_SHIFT", "1")
+            monkeypatch.setenv("KAIJU_GPU_ROW_TAX", "0")
         elif tv != "auto":
             monkeypatch.setenv("KAIJU_GPU_TV_SHIFT", tv)
         idx = api.Index(fmi)
         fp = idx.footprint
-        assert fp.wide == 1 and (fp.text > 0) == (tv != "none") and (fp.sa_full > 0) == (tv != "none")
+        assert fp.wide == 1 and (fp.text > 0) == (tv not in ("none", "-1")) and (fp.sa_full > 0) == (tv != "none")
+        rows = int(idx.info.bwtlen)
+        assert (fp.sa_full >= 4 * rows) == (tv not in ("none", "1/walks"))          # (the table: 4 B per row)
         clf = api.Classifier(idx, api.default_params("mem", seg=1))
         for s, o, pe in ((seqs, off, False), (pseqs, poff, True)):
             hits = clf.classify(s, o, paired=pe)

@@ -314,11 +314,14 @@ def test_verbose_columns(emu, golden, handles, mode):
         E.emu_set_verbose(None, None, None, None, 0)
 
 
-@pytest.mark.parametrize("shift", ["16", "19"])
-def test_wide_mem_lane(oracle, emu, golden, handles, shift, monkeypatch):
+@pytest.mark.parametrize("shift,rowtax", [("16", True), ("19", True), ("19", False)])
+def test_wide_mem_lane(oracle, emu, golden, handles, shift, rowtax, monkeypatch):
     """second-generation MEM lane with 64-bit positions (indexes of 2^32 rows and more), forced on the golden index:
-    rank counts relative to a base every 2^shift rows, 16-byte k-mer entries"""
+    rank counts relative to a base every 2^shift rows, 16-byte k-mer entries; the ids through the row -> taxon table
+    (mem_locate_read<true>, <true, true>: where HBM has room for it) and through the walks of a team (without)"""
     monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
+    if not rowtax:
+        monkeypatch.setenv("KAIJU_EMU_NO_ROW_TAX", "1")
     h = emu.load(golden.fmi)
     _, ix, tax = handles
     reads = util.long_reads(n=30)
@@ -331,12 +334,14 @@ def test_wide_mem_lane(oracle, emu, golden, handles, shift, monkeypatch):
             assert not bad, (shift, seg, pe, bad[:5])
 
 
-@pytest.mark.parametrize("shift", ["16", "19"])
-def test_wide_greedy_lane(oracle, emu, golden, handles, shift, monkeypatch):
+@pytest.mark.parametrize("shift,rowtax", [("16", True), ("19", True), ("19", False)])
+def test_wide_greedy_lane(oracle, emu, golden, handles, shift, rowtax, monkeypatch):
     """second-generation Greedy lane with 64-bit positions (greedy_lane2<COUNT, WIDE = true>), forced on the golden index:
     the k-mer table of 16-byte entries, block counts relative to a base every 2^shift rows, sequence numbers at the sampled rows,
     queue items and match records in their wide packing; single reads, pairs, long reads, parameter variants"""
     monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
+    if not rowtax:
+        monkeypatch.setenv("KAIJU_EMU_NO_ROW_TAX", "1")
     h = emu.load(golden.fmi)
     _, ix, tax = handles
     reads = util.long_reads(n=30)
@@ -909,7 +914,8 @@ def test_reads_with_many_longest_matches(oracle, tmp_path, monkeypatch):
     want = oracle.classify(ix, None, oracle.params("mem", seg=0), seqs, off)
     assert (np.array([int(w["n_ids"]) for w in want]) >= 3).mean() > 0.3     # (ids, not matches: most reads have 3+ matches)
     emu = util.Emu()
-    for env in ({}, {"KAIJU_GPU_FORCE_WIDE": "17"}, {"KAIJU_EMU_NO_TEXT": "1"}, {"KAIJU_EMU_LOCATE_SERIAL": "1"}):
+    for env in ({}, {"KAIJU_GPU_FORCE_WIDE": "17"}, {"KAIJU_GPU_FORCE_WIDE": "17", "KAIJU_EMU_NO_ROW_TAX": "1"}, {"KAIJU_EMU_NO_TEXT": "1"},
+                {"KAIJU_EMU_LOCATE_SERIAL": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = emu.load(fmi)
