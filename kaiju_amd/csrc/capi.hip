@@ -955,6 +955,7 @@ struct kaiju_gpu_index {
   std::vector<void *> allocs;
   kaiju_gpu_index_info info{};
   kaiju_gpu_index_footprint fp{};
+  uint64_t tpos_bytes = 0;        // bytes of DevIndex::sa_tpos5 (fp.sa_full also counts the row -> taxon table of a wide index)
   std::vector<std::string> names;
   int id_mode = 0;                // KAIJU_GPU_IDS_TAXON / KAIJU_GPU_IDS_SEQUENCE
   ~kaiju_gpu_index() {
@@ -1509,6 +1510,7 @@ static int index_from_packed(PackedIndex &pk, int device_id, kaiju_gpu_index **o
     f.kmer_lines = d.kline ? nlw * kKLineBytes : 0;
     f.other = sizeof(ConstTables) + sizeof(Stage1Tables) + lnfact.size() * 8;
     f.text = d.text ? text_bytes : 0;
+    ix->tpos_bytes = d.sa_tpos5 ? tpos_bytes : 0;
     f.sa_full = d.sa_full ? pk.bwtlen * 8 : (d.sa_tpos5 ? tpos_bytes : 0) + (d.mb_base && d.row_tax ? rowtax_bytes : 0);   // (+ the taxon of every row, DevIndex::row_tax; wide: the text positions + that table)
     f.total = f.rank_blocks + f.count_bases + f.sa_seq + f.sa_taxid + f.seq_tables + f.kmer_table + f.kmer_lines + f.other + f.text + f.sa_full;
     f.kmer_k = std::max(d.kmer_k, d.kline_k); f.wide = d.mb_base ? 1u : 0u;
@@ -1757,7 +1759,7 @@ extern "C" int kaiju_gpu_index_digest(const kaiju_gpu_index *ix, uint64_t *out, 
       {d.kmer32 ? (const void *)d.kmer32 : (const void *)d.kmer64, d.kmer_k ? nw * (d.kmer32 ? sizeof(uint2) : sizeof(ulonglong2)) : 0},
       {d.kline, d.kline ? nlw * kKLineBytes : 0},
       {d.text, d.text ? ix->fp.text : 0},
-      {d.sa_full ? (const void *)d.sa_full : (const void *)d.sa_tpos5, d.sa_full ? d.bwtlen * 4 : d.sa_tpos5 ? ix->fp.sa_full : 0},
+      {d.sa_full ? (const void *)d.sa_full : (const void *)d.sa_tpos5, d.sa_full ? d.bwtlen * 4 : d.sa_tpos5 ? ix->tpos_bytes : 0},
       {d.row_tax, d.row_tax ? d.bwtlen * 4 : 0}};
   unsigned long long *acc = nullptr;
   KJ_HIP(hipMalloc((void **)&acc, 12 * 8));
@@ -1831,7 +1833,7 @@ struct kaiju_gpu_ctx {
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
   DevBuf seglist, loc_list, todo_list;
-  int seg_team = 16;               // KAIJU_GPU_SEG_TEAM: lanes per fragment of the SEG pass (8, 16, 32; 64 = one wavefront per fragment, k_seg)
+  int seg_team = 64;               // KAIJU_GPU_SEG_TEAM: lanes per fragment of the SEG pass (64 = one wavefront per fragment, k_seg; 8, 16, 32: k_seg_teams, slower - DESIGN.md 6b)
   bool fused_post = true;          // KAIJU_GPU_FUSED_POST=0: k_trigcheck / k_mem_locate / k_lca as separate passes (A/B measurements)
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
