@@ -117,7 +117,7 @@ k_fragments_fast(const Stage1Tables *__restrict__ g_t, Params p, Batch b, SegQue
 // result already: SEG would leave exactly those fragments alone, and the pieces of the others are substrings of their
 // parents, which did not match longer.  The other reads are listed here and take the SEG pass.
 __global__ void __launch_bounds__(256)
-k_trigcheck(const Stage1Tables *__restrict__ g_t, Batch b, uint32_t *seglist, uint32_t *segcount) {
+k_trigcheck(const Stage1Tables *__restrict__ g_t, Params p, Batch b, uint32_t *seglist, uint32_t *segcount) {
   __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
   __shared__ __attribute__((aligned(4))) uint8_t s_cnt[256 * kS1CntStride];
   __shared__ __attribute__((aligned(4))) uint8_t s_ts[256 * kTsBuf];
@@ -132,24 +132,7 @@ k_trigcheck(const Stage1Tables *__restrict__ g_t, Batch b, uint32_t *seglist, ui
   const uint32_t v = b.hits[r].reserved;
   if (v == 0) return;
   b.hits[r].reserved = 0;
-  bool need = v == kWinForce;
-  if (!need) {
-    uint8_t *row = s_cnt + threadIdx.x * kS1CntStride, *buf = s_ts + threadIdx.x * kTsBuf;
-    const ReadMeta rm = b.meta[r];
-    const Frag *F = b.frags + rm.frag;
-    const uint8_t *pep = b.pep + rm.pep;
-    if (!(v & kWinMulti)) {
-      const Frag f = F[(v & ~kWinMulti) - 1u];
-      need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
-    } else {
-      // several fragments hold a longest match: every fragment long enough to be one of them is looked at
-      const uint32_t best = b.hits[r].best, nf = rm.nfrag & ~kNfragSegPending;
-      for (uint32_t k = 0; k < nf && !need; k++) {
-        const Frag f = F[k];
-        if (f.len >= best) need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
-      }
-    }
-  }
+  const bool need = lazy_seg_needed(s_t, p, b, r, b.hits + r, v, s_ts + threadIdx.x * kTsBuf, s_cnt + threadIdx.x * kS1CntStride);
   if (need) seglist[atomicAdd(segcount, 1u)] = r;
 }
 // the listed reads: SEG trigger test of all their fragments (what stage 1 does eagerly elsewhere), hit record cleared
@@ -225,24 +208,7 @@ k_mem_post1(const Stage1Tables *__restrict__ g_t, DevIndex ix, Params p, Batch b
     const uint32_t v = lazy ? h->reserved : 0u;
     if (v != 0) {
       h->reserved = 0;
-      need = v == kWinForce;
-      if (!need) {
-        uint8_t *row = s_cnt + threadIdx.x * kS1CntStride, *buf = s_ts + threadIdx.x * kTsBuf;
-        const ReadMeta rm = b.meta[r];
-        const Frag *F = b.frags + rm.frag;
-        const uint8_t *pep = b.pep + rm.pep;
-        if (!(v & kWinMulti)) {
-          const Frag f = F[(v & ~kWinMulti) - 1u];
-          need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
-        } else {
-          // several fragments hold a longest match: every fragment long enough to be one of them is looked at
-          const uint32_t best = h->best, nf = rm.nfrag & ~kNfragSegPending;
-          for (uint32_t k = 0; k < nf && !need; k++) {
-            const Frag f = F[k];
-            if (f.len >= best) need = trig_fragment(s_t, pep, f.start, f.len, buf, row);
-          }
-        }
-      }
+      need = lazy_seg_needed(s_t, p, b, r, h, v, s_ts + threadIdx.x * kTsBuf, s_cnt + threadIdx.x * kS1CntStride);
     }
     if (!need) {
       if (h->flags & kHitRetry) later = true;                               // (the retry pass writes this record)
@@ -312,6 +278,9 @@ k_fragments_protein(const ConstTables *__restrict__ g_ct, Params p, SegTables st
 
 // one wavefront per fragment: lanes share the sub-windows of s_Trim
 struct CoopWave {
+  uint64_t *prefix = nullptr;                     // LDS: 2 * (kSegPacked + 1) words (seg_trim's prefix counts)
+  __device__ __forceinline__ uint64_t *pref() const { return prefix; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }     // (the block is one wavefront)
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int width() const { return 64; }
   __device__ __forceinline__ void reduce_min(double &prob, int &t) const {
@@ -328,6 +297,9 @@ struct CoopWave {
 // wavefront work on fragments of their own
 template <int T>
 struct CoopTeam {
+  uint64_t *prefix = nullptr;
+  __device__ __forceinline__ uint64_t *pref() const { return prefix; }
+  __device__ __forceinline__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & (uint32_t)(T - 1)); }
   __device__ __forceinline__ int width() const { return T; }
   __device__ __forceinline__ void reduce_min(double &prob, int &t) const {
@@ -354,7 +326,9 @@ k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
   __syncthreads();
   const SegCtx cx = seg_ctx(st, s_entg, s_lnf);
-  const CoopWave coop;
+  __shared__ uint64_t s_pref[2 * (kSegPacked + 1)];
+  CoopWave coop;
+  coop.prefix = s_pref;
   const uint32_t n = min(*sq.count, sq.cap);
   for (uint32_t s = blockIdx.x; s < n; s += gridDim.x)       // trip count is uniform over the block
     seg_compute(cx, coop, b, p, sq, s, s_frag, kSegStage, s_work, s_cls, [] { __syncthreads(); });
@@ -382,8 +356,10 @@ k_seg_teams(Params p, SegTables st, Batch b, SegQueue sq) {
   if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
   __syncthreads();
   const SegCtx cx = seg_ctx(st, s_entg, s_lnf);
-  const CoopTeam<T> coop;
+  __shared__ uint64_t s_pref[NT * 2 * (kSegPacked + 1)];
   const uint32_t team = threadIdx.x / (uint32_t)T;
+  CoopTeam<T> coop;
+  coop.prefix = s_pref + team * 2 * (kSegPacked + 1);
   const uint32_t n = min(*sq.count, sq.cap);
   for (uint32_t s0 = blockIdx.x * NT; s0 < n; s0 += gridDim.x * NT) {
     const uint32_t s = s0 + team;
@@ -2175,7 +2151,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         // lists rewritten, searched again (counters: [22] listed reads, [23] work counter of that search)
         if ((rc = ensure(c->seglist, (size_t)n * 4 + 16))) return rc;
         uint32_t *seglist = static_cast<uint32_t *>(c->seglist.p);
-        if (!fused) hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->d_s1, b, seglist, cnt + 22);
+        if (!fused) hipLaunchKernelGGL(k_trigcheck, grid_reads, dim3(256), 0, s, ix->d_s1, p, b, seglist, cnt + 22);
         hipLaunchKernelGGL(k_segflag, dim3(c->n_cu * 4), dim3(256), 0, s, p, ix->st, b, sq, seglist, cnt + 22, cnt + 3);
         launch_seg(c, s, p, ix->st, b, sq);
         hipLaunchKernelGGL(k_seg_apply_list, dim3(c->n_cu * 4), blk, 0, s, ix->d_ct, p, b, sq, seglist, cnt + 22, cnt + 3);

@@ -21,6 +21,8 @@ __device__ __forceinline__ void x_load_tables(ConstTables &s_ct, const ConstTabl
 
 // one wavefront per fragment: the lanes share the sub-windows of s_Trim (as capi.hip's SEG pass)
 struct XCoopWave {
+  __device__ __forceinline__ uint64_t *pref() const { return nullptr; }   // (not on the hot path: every sub-window counts its letters)
+  __device__ __forceinline__ void sync() const {}
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int width() const { return 64; }
   __device__ __forceinline__ void reduce_min(double &prob, int &t) const {

@@ -598,10 +598,15 @@ KJ_HD SegCtx seg_ctx(const SegTables &st, const int64_t *ent_g, const double *ln
 }
 
 // how the sub-windows of s_Trim are spread: one lane (host emulation) or a wavefront
+// pref(): 2 * (kSegPacked + 1) 64-bit words shared by the lanes (the prefix counts of s_Trim's raw segment) or nullptr: every
+// sub-window then counts its own letters; sync(): the lanes' writes to it are visible to each other
 struct CoopSerial {
+  uint64_t *prefix = nullptr;
   KJ_HD int lane() const { return 0; }
   KJ_HD int width() const { return 1; }
   KJ_HD void reduce_min(double &, int &) const {}
+  KJ_HD uint64_t *pref() const { return prefix; }
+  KJ_HD void sync() const {}
 };
 
 struct SegWin {              // 12-window: nibble-packed counts of the 20 letters + entropy score
@@ -650,12 +655,17 @@ KJ_HD int zero_fields6(uint64_t x) {
 
 // ln P0 of the sub-window s[i .. i+l) (s_GetProb blast_seg.c:1944-1967 with s_LnAss :1890-1933 and
 // s_LnPerm :1864-1879 on the descending state vector), l <= kSegPacked
+KJ_HD double seg_prob_of_counts(const SegCtx &cx, uint64_t c0, uint64_t c1, int l);
 KJ_HD double seg_window_prob_packed(const SegCtx &cx, const uint8_t *s, int l, int i) {
   uint64_t c0 = 0, c1 = 0;             // 6-bit counts, letters 0..9 and 10..19
   for (int k = 0; k < l; k++) {
     const uint32_t a = KJ_SL(s, i + k);
     if (a < 10) c0 += 1ull << (6 * a); else c1 += 1ull << (6 * (a - 10));
   }
+  return seg_prob_of_counts(cx, c0, c1, l);
+}
+// ... from the packed counts of the window's letters (l of them)
+KJ_HD double seg_prob_of_counts(const SegCtx &cx, uint64_t c0, uint64_t c1, int l) {
   const uint64_t REP = 0x041041041041041ull;      // 1 in every field
   double ans1 = cx.lnf[20];
   double ans2 = kj_lnfact(cx, l);
@@ -723,10 +733,28 @@ KJ_HD void seg_trim(const SegCtx &cx, const Coop &coop, const uint8_t *s, int le
   double best = 1.;
   int best_t = 0x7fffffff;
   int d = 0, base = 0;                            // base = d(d+1)/2 <= t
+  // The counts of a sub-window are the difference of two PREFIX counts of the raw segment (fields of six bits, no borrows: a
+  // prefix count never falls): pref[2j], pref[2j + 1] = the packed counts of s[0 .. j), written once per call - lane j counts
+  // its j letters - where every one of the len (len - 1) / 2 sub-windows used to count its own (a third of the instructions
+  // of this function, which is where the SEG pass spends its time: profiles/r06_seg_teams)
+  uint64_t *pref = len <= kSegPacked ? coop.pref() : nullptr;
+  if (pref) {
+    coop.sync();                                  // (the previous call's prefix counts are no longer read)
+    for (int j = coop.lane(); j <= len; j += coop.width()) {
+      uint64_t c0 = 0, c1 = 0;
+      for (int k = 0; k < j; k++) {
+        const uint32_t a = KJ_SL(s, k);
+        if (a < 10) c0 += 1ull << (6 * a); else c1 += 1ull << (6 * (a - 10));
+      }
+      pref[2 * j] = c0; pref[2 * j + 1] = c1;
+    }
+    coop.sync();
+  }
   for (int t = coop.lane(); t < W; t += coop.width()) {
     while (base + d + 1 <= t) { base += d + 1; d++; }
     const int i = t - base, l = len - d;
-    const double prob = l <= kSegPacked ? seg_window_prob_packed(cx, s, l, i) : seg_window_prob_generic(cx, s, l, i);
+    const double prob = pref ? seg_prob_of_counts(cx, pref[2 * (i + l)] - pref[2 * i], pref[2 * (i + l) + 1] - pref[2 * i + 1], l)
+                        : l <= kSegPacked ? seg_window_prob_packed(cx, s, l, i) : seg_window_prob_generic(cx, s, l, i);
     if (prob < best) { best = prob; best_t = t; }
   }
   coop.reduce_min(best, best_t);
@@ -1600,6 +1628,25 @@ KJ_HD bool trig_fragment(const Stage1Tables &t, const uint8_t *pep, uint32_t sta
     if (trig_scan<false>(t, buf + kTsLead + a, n, 12, buf, row) != 0) return true;
     if (at + n >= len) return false;
   }
+}
+// Lazy SEG, the check behind the unsplit search (k_trigcheck, k_mem_post1): v = the record's `reserved` word
+// (!= 0: the fragment(s) that hold the read's longest match(es)).  Does the read have to take the SEG pass?
+KJ_HD bool lazy_seg_needed(const Stage1Tables &t, const Params &p, const Batch &b, uint32_t r, const Hit *h, uint32_t v, uint8_t *buf, uint8_t *row) {
+  if (v == kWinForce) return true;
+  const ReadMeta rm = b.meta[r];
+  const Frag *F = b.frags + rm.frag;
+  const uint8_t *pep = b.pep + rm.pep;
+  if (!(v & kWinMulti)) {
+    const Frag f = F[(v & ~kWinMulti) - 1u];
+    return trig_fragment(t, pep, f.start, f.len, buf, row);
+  }
+  // several fragments hold a longest match: every fragment long enough to be one of them is looked at
+  const uint32_t best = h->best, nf = rm.nfrag & ~kNfragSegPending;
+  for (uint32_t k = 0; k < nf; k++) {
+    const Frag f = F[k];
+    if (f.len >= best && trig_fragment(t, pep, f.start, f.len, buf, row)) return true;
+  }
+  return false;
 }
 KJ_HD uint64_t bitrev64(uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)

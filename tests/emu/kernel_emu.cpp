@@ -89,6 +89,14 @@ uint64_t emu_rank(void *h, uint32_t c, uint64_t k) {
 uint32_t emu_symbol(void *h, uint64_t k) { DevIndex d = ((EmuIndex *)h)->packed.host_view(); return symbol_at(d, k); }
 
 // SEG on an ASCII peptide (letters of the 20 amino acids)
+// the SEG code's cooperation object of the emulation: one lane, with the prefix-count scratch of s_Trim (the device's k_seg
+// has it in LDS) unless KAIJU_EMU_NO_SEG_PREFIX is set (every sub-window then counts its own letters: the two must agree)
+static CoopSerial emu_coop() {
+  static thread_local uint64_t pref[2 * (kSegPacked + 1)];
+  CoopSerial c;
+  c.prefix = getenv("KAIJU_EMU_NO_SEG_PREFIX") ? nullptr : pref;
+  return c;
+}
 int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   EmuIndex *ix = (EmuIndex *)h;
   std::vector<uint8_t> codes((size_t)len + 1);
@@ -98,7 +106,7 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   int32_t work[2 * kSegMaxRegions];
   std::vector<uint8_t> cls((size_t)len + 1);
   const bool use_cls = !getenv("KAIJU_EMU_SEG_NOCLS");
-  int n = seg_regions(cx, CoopSerial{}, codes.data(), len, left, right, ov, work, use_cls ? cls.data() : nullptr, [] {});
+  int n = seg_regions(cx, emu_coop(), codes.data(), len, left, right, ov, work, use_cls ? cls.data() : nullptr, [] {});
   return ov ? -1 : n;
 }
 
@@ -194,7 +202,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
     std::vector<uint8_t> segstage(64);   // small on purpose: exercises both the staged and the direct path
     std::vector<uint8_t> segcls(64);
     for (uint32_t s = 0; s < seg_count && s < seg_cap; s++)
-      seg_compute(cx, CoopSerial{}, b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
+      seg_compute(cx, emu_coop(), b, p, sq, s, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
     if (p.mode == 0) for (uint32_t r = 0; r < n; r++) seg_apply_mem(ix->ct, p, b, sq, r, &err);
   }
   if (frag_dump) {
@@ -264,19 +272,16 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
             const uint32_t vv = hits[r].reserved;
             if (vv == 0) continue;
             hits[r].reserved = 0;
-            bool need = vv == kWinForce;
-            const Frag *F = frags.data() + meta[r].frag;
-            const uint8_t *pp = pep.data() + meta[r].pep;
-            auto trig = [&](const Frag &f) {
-              alignas(4) uint8_t row[kS1CntStride], tb[kTsBuf];
+            alignas(4) uint8_t row[kS1CntStride], tb[kTsBuf];
+            const bool need = lazy_seg_needed(s1tab, p, b, r, &hits[r], vv, tb, row);
+            if (vv != kWinForce && !(vv & kWinMulti)) {
+              // (the check agrees with the SEG code's own trigger test)
+              const Frag *F = frags.data() + meta[r].frag;
+              const uint8_t *pp = pep.data() + meta[r].pep;
+              const Frag &f = F[(vv & ~kWinMulti) - 1u];
               const bool a = trig_fragment(s1tab, pp, f.start, f.len, tb, row), bb = seg_triggers(cx, pp + f.start, (int)f.len);
               if (a != bb) { fprintf(stderr, "[emu] trig_fragment disagrees with seg_triggers\n"); abort(); }
-              return a;
-            };
-            if (!need && !(vv & kWinMulti)) need = trig(F[(vv & ~kWinMulti) - 1u]);
-            else if (!need) {
-              for (uint32_t k = 0; k < (meta[r].nfrag & ~kNfragSegPending) && !need; k++)
-                if (F[k].len >= hits[r].best) need = trig(F[k]);
+              if (need != a) { fprintf(stderr, "[emu] lazy_seg_needed disagrees with trig_fragment\n"); abort(); }
             }
             if (need) seglist.push_back(r);
           }
@@ -300,7 +305,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
           int32_t segwork[4 * kSegMaxRegions];
           std::vector<uint8_t> segstage(64), segcls(64);
           for (uint32_t s2 = 0; s2 < seg_count && s2 < seg_cap; s2++)
-            seg_compute(cx, CoopSerial{}, b, p, sq, s2, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
+            seg_compute(cx, emu_coop(), b, p, sq, s2, segstage.data(), (uint32_t)segstage.size(), segwork, segcls.data(), [] {});
           for (uint32_t r : seglist) seg_apply_mem(ix->ct, p, b, sq, r, &err);
           uint32_t counter2 = 0, nlist = (uint32_t)seglist.size();
           WorkList w2;
@@ -406,7 +411,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       std::vector<int32_t> work2((size_t)4 * cap_ints);
       std::vector<uint8_t> cls2((size_t)max_frag + 64);
       for (uint32_t s2 = 0; s2 < count2 && s2 < cap2; s2++)
-        seg_compute_big(cx, CoopSerial{}, b, sq2, big, s2, work2.data(), cap_ints, cls2.data(), &err, [] {});
+        seg_compute_big(cx, emu_coop(), b, sq2, big, s2, work2.data(), cap_ints, cls2.data(), &err, [] {});
       if (p.mode == 0) for (uint32_t r : redo) seg_apply_mem_big(ix->ct, p, b, big, r);
       WorkList wl;
       uint32_t rcount = (uint32_t)redo.size();

@@ -31,12 +31,34 @@ def test_packed_rank_matches_fmindex(oracle, emu, golden, handles):
     assert emu.lib.emu_index_warnings(h) == 0
 
 
-def test_seg_known_answers(emu, golden, handles):
+@pytest.mark.parametrize("prefix", [True, False])
+def test_seg_known_answers(oracle, emu, golden, handles, prefix, monkeypatch):
+    """s_Trim's sub-windows from the prefix counts of the raw segment (what k_seg does) and each counting its own letters:
+    the reference's known answers, and the oracle's regions on low-complexity strings of 12 .. 150 residues (raw segments
+    beyond 63 residues take the generic window function)"""
+    if not prefix:
+        monkeypatch.setenv("KAIJU_EMU_NO_SEG_PREFIX", "1")
     h = handles[0]
     with open(os.path.join(golden.dir, "kat_seg.json")) as f:
         kat = json.load(f)
     for aa, regs in kat:
         assert emu.seg(h, aa.encode()) == [tuple(r) for r in regs], aa
+    rng = np.random.default_rng(77)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    nlow = 0
+    for _ in range(1500):
+        n = int(rng.integers(12, 151))
+        few = rng.choice(letters, size=int(rng.integers(1, 5)), replace=False)
+        aa = rng.choice(letters, size=n)
+        a = int(rng.integers(0, n))
+        b = min(n, a + int(rng.integers(8, 90)))
+        aa[a:b] = rng.choice(few, size=b - a)                     # a low-complexity stretch
+        aa = aa.tobytes()
+        want = oracle.seg(aa)
+        nlow += bool(want)
+        if len(want) <= 15:
+            assert emu.seg(h, aa) == [tuple(r) for r in want], aa
+    assert nlow > 1000
 
 
 def test_fragment_lists(oracle, emu, golden, handles):
