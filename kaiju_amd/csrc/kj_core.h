@@ -36,6 +36,7 @@ namespace kj {
 struct u128 { uint64_t x, y; };
 typedef u128 u128_unaligned __attribute__((aligned(1)));
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef uint64_t u64_unaligned __attribute__((aligned(1)));
 
 // ----------------------------------------------------------------------------
 // constants shared with the host
@@ -590,10 +591,12 @@ struct SegCtx {                        // tables as the SEG code sees them (LDS 
   const double *lnf;                   // [kSegLnf] head of the ln(n!) table
   const double *lnfact;                // whole table (global memory)
   uint32_t lnfact_n;
+  const uint64_t *rep = nullptr;       // [64] k in every 6-bit field (k * 0x041041041041041; LDS on the device - a 64-bit product is three
+                                       // quarter-rate multiplies there) or nullptr: multiply
 };
-KJ_HD SegCtx seg_ctx(const SegTables &st, const int64_t *ent_g, const double *lnf) {
+KJ_HD SegCtx seg_ctx(const SegTables &st, const int64_t *ent_g, const double *lnf, const uint64_t *rep = nullptr) {
   SegCtx c; c.ent_g = ent_g; c.ent_locut = st.ent_locut; c.ent_hicut = st.ent_hicut;
-  c.lnf = lnf; c.lnfact = st.lnfact; c.lnfact_n = st.lnfact_n;
+  c.lnf = lnf; c.lnfact = st.lnfact; c.lnfact_n = st.lnfact_n; c.rep = rep;
   return c;
 }
 
@@ -678,13 +681,13 @@ KJ_HD double seg_prob_of_counts(const SegCtx &cx, uint64_t c0, uint64_t c1, int 
     int lo = 1, hi = l;                            // invariant: some count >= lo, none > hi
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      const uint64_t T = REP * (uint64_t)(32 - mid);
+      const uint64_t T = cx.rep ? cx.rep[32 - mid] : REP * (uint64_t)(32 - mid);
       if (((c0 + T) | (c1 + T)) & HI) lo = mid; else hi = mid - 1;
     }
     vtop = lo;
   }
-  for (int v = vtop; v >= 1 && rem > 0; v--) {    // descending count value
-    const uint64_t V = REP * (uint64_t)v;
+  uint64_t V = cx.rep ? cx.rep[vtop & 63] : REP * (uint64_t)vtop;   // (l <= kSegPacked = 63)
+  for (int v = vtop; v >= 1 && rem > 0; v--, V -= REP) {    // descending count value, V = v in every field
     const int n = zero_fields6(c0 ^ V) + zero_fields6(c1 ^ V);   // letters occurring exactly v times
     if (n) {
       ans1 -= cx.lnf[n];
@@ -3788,6 +3791,11 @@ constexpr bool kChainPrune = true;
 // (the largest entry of the BLOSUM62 diagonal: W), a substitution at most kMaxSubstScore (the largest entry off the diagonal;
 // host_tables.cpp checks both against the table): if even that stays below min_score, no item of the chain passes the gate.
 constexpr int kMaxDiagScore = 11, kMaxSubstScore = 4;
+#ifdef KJ_WIDE_CHAIN_PRUNE
+constexpr bool kWideChainPrune = true;        // the test in greedy_lane2<.., WIDE> as well (24 bytes of scratch a lane at three wavefronts per SIMD)
+#else
+constexpr bool kWideChainPrune = false;
+#endif
 // thr: the score an item has to reach to matter - min_score, or the read's best score so far if that is higher (a match below
 // `best` changes nothing, :757-775, and best only grows)
 KJ_HD bool kj_chain_hopeless(const Params &p, const uint8_t *win, int wq, int pz, int j, const u128 &tx, uint32_t nmm, int sc0, int thr) {
@@ -4553,6 +4561,20 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
           KJ_P(PS_VM_PUSH);
           if (vlen > 0xffffu || m_ql + 1u > 0xffffu) { ovf = true; KJ_OVF(wl, 4); break; }
           const int bss = (int)diag(cx);
+          if constexpr (kChainPrune && WIDE && kWideChainPrune) {
+            // the same test on an index with 64-bit rows that keeps the text and the text position of EVERY row (tv_shift 0: up
+            // to 2^34 rows where HBM has room); the position is read here - the load phase has no slot for it
+            const int sc0 = (int)m_dsum + t_diff + bos;
+            if (rb - ra == (P)1 && ix.sa_tpos5 && ix.tv_shift == 0u && ix.text && (m_ql + 1u < p.m || sc0 < thr)) {
+              const uint64_t tp = *reinterpret_cast<const u64_unaligned *>(ix.sa_tpos5 + (size_t)ra * 5u) & kTposNone;
+              if constexpr (COUNT) oc[kOpcSa] += 2u;
+              if (tp != kTposNone && tp >= 16u + kTextPad &&
+                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0, thr)) {
+                if constexpr (COUNT) oc[kOpcPruned]++;
+                continue;
+              }
+            }
+          }
           if constexpr (kChainPrune && !WIDE) {
             // A variant on ONE database row is the root of a CHAIN: UpdateSI on a one-row interval succeeds iff the letter in
             // front of the row's suffix is the letter asked for (bwt.c:160-173), the one substitute that exists at the next
