@@ -324,10 +324,8 @@ k_seg(Params p, SegTables st, Batch b, SegQueue sq) {
   __shared__ uint8_t s_cls[kSegStage];
   if (threadIdx.x < 13) s_entg[threadIdx.x] = st.ent_g[threadIdx.x];
   if (threadIdx.x < kSegLnf) s_lnf[threadIdx.x] = st.lnfact[threadIdx.x];
-  __shared__ uint64_t s_rep[64];
-  s_rep[threadIdx.x & 63u] = 0x041041041041041ull * (uint64_t)(threadIdx.x & 63u);
   __syncthreads();
-  const SegCtx cx = seg_ctx(st, s_entg, s_lnf, s_rep);
+  const SegCtx cx = seg_ctx(st, s_entg, s_lnf);
   __shared__ uint64_t s_pref[2 * (kSegPacked + 1)];
   CoopWave coop;
   coop.prefix = s_pref;

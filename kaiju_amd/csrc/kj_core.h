@@ -591,12 +591,10 @@ struct SegCtx {                        // tables as the SEG code sees them (LDS 
   const double *lnf;                   // [kSegLnf] head of the ln(n!) table
   const double *lnfact;                // whole table (global memory)
   uint32_t lnfact_n;
-  const uint64_t *rep = nullptr;       // [64] k in every 6-bit field (k * 0x041041041041041; LDS on the device - a 64-bit product is three
-                                       // quarter-rate multiplies there) or nullptr: multiply
 };
-KJ_HD SegCtx seg_ctx(const SegTables &st, const int64_t *ent_g, const double *lnf, const uint64_t *rep = nullptr) {
+KJ_HD SegCtx seg_ctx(const SegTables &st, const int64_t *ent_g, const double *lnf) {
   SegCtx c; c.ent_g = ent_g; c.ent_locut = st.ent_locut; c.ent_hicut = st.ent_hicut;
-  c.lnf = lnf; c.lnfact = st.lnfact; c.lnfact_n = st.lnfact_n; c.rep = rep;
+  c.lnf = lnf; c.lnfact = st.lnfact; c.lnfact_n = st.lnfact_n;
   return c;
 }
 
@@ -681,12 +679,12 @@ KJ_HD double seg_prob_of_counts(const SegCtx &cx, uint64_t c0, uint64_t c1, int 
     int lo = 1, hi = l;                            // invariant: some count >= lo, none > hi
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      const uint64_t T = cx.rep ? cx.rep[32 - mid] : REP * (uint64_t)(32 - mid);
+      const uint64_t T = REP * (uint64_t)(32 - mid);
       if (((c0 + T) | (c1 + T)) & HI) lo = mid; else hi = mid - 1;
     }
     vtop = lo;
   }
-  uint64_t V = cx.rep ? cx.rep[vtop & 63] : REP * (uint64_t)vtop;   // (l <= kSegPacked = 63)
+  uint64_t V = REP * (uint64_t)vtop;
   for (int v = vtop; v >= 1 && rem > 0; v--, V -= REP) {    // descending count value, V = v in every field
     const int n = zero_fields6(c0 ^ V) + zero_fields6(c1 ^ V);   // letters occurring exactly v times
     if (n) {
@@ -3791,10 +3789,11 @@ constexpr bool kChainPrune = true;
 // (the largest entry of the BLOSUM62 diagonal: W), a substitution at most kMaxSubstScore (the largest entry off the diagonal;
 // host_tables.cpp checks both against the table): if even that stays below min_score, no item of the chain passes the gate.
 constexpr int kMaxDiagScore = 11, kMaxSubstScore = 4;
-#ifdef KJ_WIDE_CHAIN_PRUNE
-constexpr bool kWideChainPrune = true;        // the test in greedy_lane2<.., WIDE> as well (24 bytes of scratch a lane at three wavefronts per SIMD)
+#ifdef KJ_NO_WIDE_CHAIN_PRUNE
+constexpr bool kWideChainPrune = false;       // (A/B measurements)
 #else
-constexpr bool kWideChainPrune = false;
+constexpr bool kWideChainPrune = true;        // the test in greedy_lane2<.., WIDE> as well (24 bytes of scratch a lane at three wavefronts
+                                              // per SIMD; k_greedy2_wide on an index without one-row matches: 47.8 ms with and without)
 #endif
 // thr: the score an item has to reach to matter - min_score, or the read's best score so far if that is higher (a match below
 // `best` changes nothing, :757-775, and best only grows)

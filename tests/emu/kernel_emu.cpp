@@ -91,13 +91,6 @@ uint32_t emu_symbol(void *h, uint64_t k) { DevIndex d = ((EmuIndex *)h)->packed.
 // SEG on an ASCII peptide (letters of the 20 amino acids)
 // the SEG code's cooperation object of the emulation: one lane, with the prefix-count scratch of s_Trim (the device's k_seg
 // has it in LDS) unless KAIJU_EMU_NO_SEG_PREFIX is set (every sub-window then counts its own letters: the two must agree)
-// ... and the table "k in every 6-bit field" of the window function (LDS in k_seg), with the same switch
-static const uint64_t *emu_rep() {
-  static uint64_t rep[64];
-  static bool init = false;
-  if (!init) { for (int k = 0; k < 64; k++) rep[k] = 0x041041041041041ull * (uint64_t)k; init = true; }
-  return getenv("KAIJU_EMU_NO_SEG_PREFIX") ? nullptr : rep;
-}
 static CoopSerial emu_coop() {
   static thread_local uint64_t pref[2 * (kSegPacked + 1)];
   CoopSerial c;
@@ -109,7 +102,7 @@ int emu_seg(void *h, const char *aa, int len, int32_t *left, int32_t *right) {
   std::vector<uint8_t> codes((size_t)len + 1);
   for (int i = 0; i < len; i++) codes[(size_t)i] = ix->packed.trans[(unsigned char)aa[i] & 127];
   bool ov = false;
-  const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact, emu_rep());
+  const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact);
   int32_t work[2 * kSegMaxRegions];
   std::vector<uint8_t> cls((size_t)len + 1);
   const bool use_cls = !getenv("KAIJU_EMU_SEG_NOCLS");
@@ -163,7 +156,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   std::vector<SegWork> seg_items(seg_cap);
   std::vector<SegRec> seg_recs(seg_cap);
   SegQueue sq{seg_items.data(), seg_recs.data(), &seg_count, seg_cap};
-  const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact, emu_rep());
+  const SegCtx cx = seg_ctx(ix->st, ix->st.ent_g, ix->st.lnfact);
   // peptides are staged (here: linear scratch) and copied out, as the kernel does with its LDS area
   std::vector<uint8_t> stage((size_t)4 * maxlen + 256);
   const bool staged = !getenv("KAIJU_EMU_NOSTAGE");

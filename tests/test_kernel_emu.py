@@ -356,11 +356,15 @@ def test_wide_mem_lane(oracle, emu, golden, handles, shift, rowtax, monkeypatch)
             assert not bad, (shift, seg, pe, bad[:5])
 
 
-@pytest.mark.parametrize("shift,rowtax", [("16", True), ("19", True), ("19", False)])
+@pytest.mark.parametrize("shift,rowtax", [("16", True), ("19", True), ("19", False), ("18/tv0", True)])
 def test_wide_greedy_lane(oracle, emu, golden, handles, shift, rowtax, monkeypatch):
     """second-generation Greedy lane with 64-bit positions (greedy_lane2<COUNT, WIDE = true>), forced on the golden index:
     the k-mer table of 16-byte entries, block counts relative to a base every 2^shift rows, sequence numbers at the sampled rows,
-    queue items and match records in their wide packing; single reads, pairs, long reads, parameter variants"""
+    queue items and match records in their wide packing; single reads, pairs, long reads, parameter variants.  "/tv0": the
+    text position of EVERY row is kept - the chain test of the narrow lane (kChainPrune) then runs in the wide one as well"""
+    if shift.endswith("/tv0"):
+        shift = shift[:-4]
+        monkeypatch.setenv("KAIJU_EMU_TV_SHIFT", "0")
     monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", shift)
     if not rowtax:
         monkeypatch.setenv("KAIJU_EMU_NO_ROW_TAX", "1")
