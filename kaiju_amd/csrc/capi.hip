@@ -120,7 +120,6 @@ __global__ void __launch_bounds__(256)
 k_trigcheck(const Stage1Tables *__restrict__ g_t, Params p, Batch b, uint32_t *seglist, uint32_t *segcount) {
   __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
   __shared__ __attribute__((aligned(4))) uint8_t s_cnt[256 * kS1CntStride];
-  __shared__ __attribute__((aligned(4))) uint8_t s_ts[256 * kTsBuf];
   {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
     uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
@@ -132,7 +131,7 @@ k_trigcheck(const Stage1Tables *__restrict__ g_t, Params p, Batch b, uint32_t *s
   const uint32_t v = b.hits[r].reserved;
   if (v == 0) return;
   b.hits[r].reserved = 0;
-  const bool need = lazy_seg_needed(s_t, p, b, r, b.hits + r, v, s_ts + threadIdx.x * kTsBuf, s_cnt + threadIdx.x * kS1CntStride);
+  const bool need = lazy_seg_needed(s_t, p, b, r, b.hits + r, v, nullptr, s_cnt + threadIdx.x * kS1CntStride);
   if (need) seglist[atomicAdd(segcount, 1u)] = r;
 }
 // the listed reads: SEG trigger test of all their fragments (what stage 1 does eagerly elsewhere), hit record cleared
@@ -188,13 +187,17 @@ k_seg_apply_list(const ConstTables *__restrict__ g_ct, Params p, Batch b, SegQue
 // (k_trigcheck's test), the ids of the matches (mem_locate_read, row -> taxon table) and, LCA, the 16-byte record
 // (lca_from_ids util.cpp:194-263).  Reads that are not through - listed for the SEG pass, sent to the retry pass, matches of
 // many rows - go on the `todo` list; k_mem_post2 finishes them behind the second search, the retry pass and the exact pass.
+#ifdef KJ_POST_WAVES                      // (A/B measurements: any value makes the compiler aim at 68 registers and 96 more bytes of scratch)
+#define KJ_POST_BOUNDS __launch_bounds__(256, KJ_POST_WAVES)
+#else
+#define KJ_POST_BOUNDS __launch_bounds__(256)
+#endif
 template <bool LCA>
-__global__ void __launch_bounds__(256)
+__global__ void KJ_POST_BOUNDS
 k_mem_post1(const Stage1Tables *__restrict__ g_t, DevIndex ix, Params p, Batch b, DevTaxonomy t, CompactHit *__restrict__ compact, int lazy,
             uint32_t *seglist, uint32_t *segcount, uint32_t *todo, uint32_t *todocount) {
   __shared__ __attribute__((aligned(16))) Stage1Tables s_t;
   __shared__ __attribute__((aligned(4))) uint8_t s_cnt[256 * kS1CntStride];
-  __shared__ __attribute__((aligned(4))) uint8_t s_ts[256 * kTsBuf];
   if (lazy) {
     const uint4 *src = reinterpret_cast<const uint4 *>(g_t);
     uint4 *dst = reinterpret_cast<uint4 *>(&s_t);
@@ -208,12 +211,18 @@ k_mem_post1(const Stage1Tables *__restrict__ g_t, DevIndex ix, Params p, Batch b
     const uint32_t v = lazy ? h->reserved : 0u;
     if (v != 0) {
       h->reserved = 0;
-      need = lazy_seg_needed(s_t, p, b, r, h, v, s_ts + threadIdx.x * kTsBuf, s_cnt + threadIdx.x * kS1CntStride);
+#ifndef KJ_POST_NOTRIG                                       // (timing experiments only: wrong results)
+      need = lazy_seg_needed(s_t, p, b, r, h, v, nullptr, s_cnt + threadIdx.x * kS1CntStride);
+#endif
     }
     if (!need) {
       if (h->flags & kHitRetry) later = true;                               // (the retry pass writes this record)
+#ifdef KJ_POST_NOLOCATE                                      // (timing experiments only: wrong results)
+      else if (LCA) { CompactHit ch; ch.lca = 0; ch.best = h->best; ch.info = 0; compact[r] = ch; }
+#else
       else if (!mem_locate_read<false>(ix, p, h, kLocDeferRows)) later = true;   // (matches of many rows: k_mem_post2's instantiation)
       else if (LCA) compact[r] = compact_hit(t, *h);
+#endif
     }
   }
   // the two lists: one atomic per wavefront and list

@@ -1630,8 +1630,53 @@ KJ_HD bool trig_fragment(const Stage1Tables &t, const uint8_t *pep, uint32_t sta
     if (at + n >= len) return false;
   }
 }
+// The same without the staging buffer, for a fragment of any length: the 16-byte units that hold the fragment are loaded from
+// device memory one after the other, the bytes outside the fragment made stops (a window with a stop in it never triggers,
+// and the scan starts out as twelve stops: exactly the windows inside the fragment count), and the sixteen steps of a unit
+// take their residues from registers - the unit itself and the one before it, as trig_scan_units does: ONE trip to LDS per
+// residue (the two counts) where the staged scan makes six one after the other.  This is what the lazy SEG check of MEM runs per
+// read with a hit (k_mem_post1: 1.8 of its 3.4 ms per 10 M reads were this test, profiles/r06_l29).
+KJ_HD bool trig_fragment_units(const Stage1Tables &t, const uint8_t *pep, uint32_t start, uint32_t len, uint8_t *row) {
+  if (len < (uint32_t)kSegWindow) return false;
+  const uint32_t a = start & 15u, end = a + len, nu = (end + 15u) >> 4;
+  const uint8_t *src = pep + (start - a);
+  uint32_t *c32 = reinterpret_cast<uint32_t *>(row);
+#pragma unroll
+  for (int q = 0; q < kS1CntRow / 4; q++) c32[q] = q == 0 ? (kS1StopCnt + 12u * 4u) : 0u;
+  int32_t sc = 12 * t.dtab[13];
+  const uint8_t *db = reinterpret_cast<const uint8_t *>(t.dtab);
+  uint32_t pw[4] = {0u, 0u, 0u, 0u};
+  bool any = false;
+  for (uint32_t k = 0; k < nu && !any; k++) {
+    const u128 v = *reinterpret_cast<const u128 *>(src + 16 * k);
+    uint32_t w[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint32_t P = 16u * k + 4u * (uint32_t)q;           // position of the dword's first byte
+      const uint32_t lo = a <= P ? 0xffffffffu : (a - P >= 4u ? 0u : 0xffffffffu << (8u * (a - P)));
+      const uint32_t hi = end >= P + 4u ? 0xffffffffu : (end <= P ? 0u : 0xffffffffu >> (8u * (P + 4u - end)));
+      w[q] &= lo & hi;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t x = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+      const uint32_t y = j < 12 ? (pw[(j + 4) >> 2] >> (8 * ((j + 4) & 3))) & 255u : (w[(j - 12) >> 2] >> (8 * ((j - 12) & 3))) & 255u;
+      const uint32_t rx = row[x], ry = row[y];
+      const bool same = x == y;
+      row[x] = (uint8_t)(same ? rx : rx + 4u);
+      row[y] = (uint8_t)(same ? rx : ry - 4u);
+      const int32_t dx = *reinterpret_cast<const int32_t *>(db + rx), dy = *reinterpret_cast<const int32_t *>(db + ry - 4u);
+      sc += same ? 0 : dx - dy;
+      any = any || sc <= t.locut32;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) pw[q] = w[q];
+  }
+  return any;
+}
 // Lazy SEG, the check behind the unsplit search (k_trigcheck, k_mem_post1): v = the record's `reserved` word
-// (!= 0: the fragment(s) that hold the read's longest match(es)).  Does the read have to take the SEG pass?
+// (!= 0: the fragment(s) that hold the read's longest match(es)).  Does the read have to take the SEG pass?  (buf: the lane's
+// staging buffer for the staged form of the trigger test - host emulation of it -, nullptr: trig_fragment_units)
 KJ_HD bool lazy_seg_needed(const Stage1Tables &t, const Params &p, const Batch &b, uint32_t r, const Hit *h, uint32_t v, uint8_t *buf, uint8_t *row) {
   if (v == kWinForce) return true;
   const ReadMeta rm = b.meta[r];
@@ -1639,13 +1684,13 @@ KJ_HD bool lazy_seg_needed(const Stage1Tables &t, const Params &p, const Batch &
   const uint8_t *pep = b.pep + rm.pep;
   if (!(v & kWinMulti)) {
     const Frag f = F[(v & ~kWinMulti) - 1u];
-    return trig_fragment(t, pep, f.start, f.len, buf, row);
+    return buf ? trig_fragment(t, pep, f.start, f.len, buf, row) : trig_fragment_units(t, pep, f.start, f.len, row);
   }
   // several fragments hold a longest match: every fragment long enough to be one of them is looked at
   const uint32_t best = h->best, nf = rm.nfrag & ~kNfragSegPending;
   for (uint32_t k = 0; k < nf; k++) {
     const Frag f = F[k];
-    if (f.len >= best && trig_fragment(t, pep, f.start, f.len, buf, row)) return true;
+    if (f.len >= best && (buf ? trig_fragment(t, pep, f.start, f.len, buf, row) : trig_fragment_units(t, pep, f.start, f.len, row))) return true;
   }
   return false;
 }
@@ -2930,7 +2975,11 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   // the matches (row | length): the lean instantiation holds two in registers and hands reads with more on (they are rare:
   // two in ten thousand on random data) - the many-rows one reads every entry when its turn comes: it only writes the record
   // when it is through.  (Host emulation without a list: all of them copied first.)
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr uint32_t kEMax = MANYROWS ? 1u : 2u;              // (no array behind a run-time index: it would live in scratch memory)
+#else
   constexpr uint32_t kEMax = MANYROWS ? 1u : kLocMaxEntries;
+#endif
   uint64_t e[kEMax];
   e[0] = hit->taxid[0];
   if constexpr (!MANYROWS) {
@@ -2977,7 +3026,11 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   const bool dense = ix.row_tax != nullptr;                   // (wide indexes: where HBM had room for it, capi.hip)
   bool done = false;
   for (uint32_t s = 0; s < nsi && !done; s++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t es = MANYROWS ? hit->taxid[s] : (s == 0u ? e[0] : e[kEMax - 1u]);    // (device: nsi <= 2 here)
+#else
     const uint64_t es = MANYROWS ? hit->taxid[s] : e[MANYROWS ? 0 : s];
+#endif
     const P lo = WIDE ? (P)(es & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)es;
     const uint32_t len = WIDE ? (uint32_t)(es >> kLocWideShift) : (uint32_t)(es >> 32);
     const P rowend = lo + (P)(int32_t)len;

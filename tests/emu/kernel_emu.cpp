@@ -273,7 +273,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
             if (vv == 0) continue;
             hits[r].reserved = 0;
             alignas(4) uint8_t row[kS1CntStride], tb[kTsBuf];
-            const bool need = lazy_seg_needed(s1tab, p, b, r, &hits[r], vv, tb, row);
+            const bool need = lazy_seg_needed(s1tab, p, b, r, &hits[r], vv, nullptr, row);      // (the device's form: trig_fragment_units)
+            if (need != lazy_seg_needed(s1tab, p, b, r, &hits[r], vv, tb, row)) { fprintf(stderr, "[emu] trig_fragment_units disagrees with the staged scan\n"); abort(); }
             if (vv != kWinForce && !(vv & kWinMulti)) {
               // (the check agrees with the SEG code's own trigger test)
               const Frag *F = frags.data() + meta[r].frag;
