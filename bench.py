@@ -276,6 +276,14 @@ class Leg:
         self.n, self.L = reads.shape
         self.protein = protein
         self.params = api.default_params(mode, seg=seg, input_is_protein=1 if protein else 0)
+        # chunk 0 / nctx 0 = chosen here: a MEM leg of 4 M reads (pairs) and more runs as TWO chunks on two contexts - while one
+        # chunk is in k_mem the other's stage 1 and post-search kernels run next to it (profiles/r06_l31: 395.8 -> 426.2 M
+        # reads/s, pairs 216.0 -> 229.7; 2 M-read legs + 1.5 %, Greedy 61.5 -> 55.2: its persistent kernel leaves no room) -,
+        # everything else as ONE launch on one context
+        if nctx <= 0:
+            nctx = 2 if (mode == "mem" and self.n >= 4_000_000 and chunk <= 0) else 1
+        if chunk <= 0:
+            chunk = (self.n + nctx - 1) // nctx
         self.nctx = max(1, nctx)
         self.clfs = [api.Classifier(index, self.params) for _ in range(self.nctx)]
         for c in self.clfs:
@@ -413,8 +421,10 @@ class Leg:
                 "algorithmic_bytes_per_launch": alg, "units_per_launch": per_launch,
                 "algorithmic_bytes_per_unit": alg / max(per_launch, 1.0),
                 "avg_launch_ms": excl_ms,
-                "avg_launch_ms_note": "HIP events around the kernel, chunks strictly one after the other (two extra untimed passes, the smaller figure; "
-                                      "rocprofv3 --kernel-trace of `bench.py --contexts 1` shows the same average)",
+                "avg_launch_ms_note": ("HIP events around the kernel, chunks strictly one after the other (two extra untimed passes, the smaller figure; "
+                                       "rocprofv3 --kernel-trace of `bench.py --contexts 1 --chunk %d` shows the same average)" % self.chunk)
+                                      + ("; live_avg_launch_ms = the same launches in the timed steps, where the two contexts' kernels run next to "
+                                         "each other and a launch lasts longer than it would alone" if self.nctx > 1 and len(self.bounds) > 1 else ""),
                 "live_avg_launch_ms": live_ms,
                 "ops_per_unit": {k: v / first for k, v in oc.items()},
                 "stage_ms_per_step_exclusive": dict(self.excl_stage),
@@ -626,13 +636,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("KAIJU_BENCH_READS", 10_000_000)),
                     help="reads per GPU per step")
-    ap.add_argument("--contexts", type=int, default=1,
-                    help="classification contexts that ping-pong the chunks of a step on their HIP streams (default 1: the persistent "
-                         "search kernels leave no room for the other context's kernels - measured in rounds 2 and 3: +1.6 %% and "
-                         "nothing, less than what a second launch per step costs; DESIGN.md 6b)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 10_000_000)),
-                    help="reads (pairs) per launch; default: the whole step in one launch (a persistent kernel ends in a tail "
-                         "in which its lanes run dry: round 2 measured 10 M per launch 189.7, 2 x 5 M 184.1 M reads/s)")
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("KAIJU_BENCH_CONTEXTS", 0)),
+                    help="classification contexts that ping-pong the chunks of a step on their HIP streams; default 0 = per leg: two "
+                         "for a MEM leg of 4 M reads and more (each context one half of the step: + 7.7 %% in round 6 - rounds 2 and 3 had "
+                         "measured + 1.6 %% and nothing, the step had fewer kernels next to k_mem then), one otherwise (Greedy loses "
+                         "10 %% with two: its persistent kernel leaves no room; DESIGN.md 5d)")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("KAIJU_BENCH_CHUNK", 0)),
+                    help="reads (pairs) per launch; default 0: the step divided by the contexts (a persistent kernel ends in a tail in "
+                         "which its lanes run dry - more launches per step than contexts only cost: 2 x 5 M 426, 4 x 2.5 M on two "
+                         "contexts 396 M reads/s)")
     ap.add_argument("--nseq", type=int, default=int(os.environ.get("KAIJU_BENCH_NSEQ", 680_001)))
     ap.add_argument("--mode", default=os.environ.get("KAIJU_BENCH_MODE", "mem"), choices=["mem", "greedy"],
                     help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")

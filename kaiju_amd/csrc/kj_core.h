@@ -1647,8 +1647,10 @@ KJ_HD bool trig_fragment_units(const Stage1Tables &t, const uint8_t *pep, uint32
   const uint8_t *db = reinterpret_cast<const uint8_t *>(t.dtab);
   uint32_t pw[4] = {0u, 0u, 0u, 0u};
   bool any = false;
+  u128 nxt = *reinterpret_cast<const u128 *>(src);
   for (uint32_t k = 0; k < nu && !any; k++) {
-    const u128 v = *reinterpret_cast<const u128 *>(src + 16 * k);
+    const u128 v = nxt;
+    if (k + 1u < nu) nxt = *reinterpret_cast<const u128 *>(src + 16 * (k + 1u));   // (on its way while this unit is scanned)
     uint32_t w[4] = {(uint32_t)v.x, (uint32_t)(v.x >> 32), (uint32_t)v.y, (uint32_t)(v.y >> 32)};
 #pragma unroll
     for (int q = 0; q < 4; q++) {

@@ -6,7 +6,8 @@
 #   smoke            __graft_entry__.smoke()                                          -> smoke.log
 #   bench            python bench.py (default line: headline + legs + CPU baseline)   -> bench_n1.json / .err
 #   bench:<args>     python bench.py <args> ("," stands for a blank)                  -> bench_<n>.json / .err
-#   stats            rocprofv3 --kernel-trace --stats of the headline leg             -> kernel_stats.csv
+#   stats            rocprofv3 --kernel-trace --stats of the headline leg, its launches   -> kernel_stats.csv
+#                    (5 M reads each) one after the other: --contexts 1 --chunk 5000000
 #   stats_greedy     ... of --mode greedy                                             -> kernel_stats_greedy.csv
 #   pmc              PMC passes of the search kernels (tests/tools/pmc_bench.sh) + profiles/traffic.json
 #   refseq_ref       BASELINE configs[3] at its named scale (28 G rows: 14.3 M proteins x 7): bench.py --image --paired
@@ -32,7 +33,7 @@ for task in "$@"; do
       args=$(echo "${task#bench:}" | tr ',' ' ')
       timeout 2400 python bench.py $args > $O/bench_$n.json 2> $O/bench_$n.err; echo "[lease] bench $args rc=$?"; tail -6 $O/bench_$n.err ;;
     stats)
-      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --legs "" --steps 5 > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_under_rocprof.err )
+      ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats -o s -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --legs "" --steps 5 --contexts 1 --chunk 5000000 > $GRAFT_REPO_ROOT/$O/bench_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_under_rocprof.err )
       cp $O/stats/s_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null; rm -rf $O/stats; echo "[lease] stats"; head -8 $O/kernel_stats.csv ;;
     stats_greedy)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_g -o s -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --mode greedy --legs "" --steps 3 > $GRAFT_REPO_ROOT/$O/bench_greedy_under_rocprof.json 2> $GRAFT_REPO_ROOT/$O/bench_greedy_under_rocprof.err )
