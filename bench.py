@@ -284,6 +284,8 @@ class Leg:
             nctx = 2 if (mode == "mem" and self.n >= 4_000_000 and chunk <= 0) else 1
         if chunk <= 0:
             chunk = (self.n + nctx - 1) // nctx
+        if os.environ.get("KAIJU_BENCH_SERIAL"):      # (PMC passes: the launches of the default line, one after the other on one context)
+            nctx = 1
         self.nctx = max(1, nctx)
         self.clfs = [api.Classifier(index, self.params) for _ in range(self.nctx)]
         for c in self.clfs:

@@ -2,6 +2,9 @@
 # HBM traffic of the search kernels at the benchmark's launch sizes: bench.py itself under rocprofv3 --pmc, one counter
 # group per run (only --kernel-trace next to --pmc); raw CSVs stay in <outdir>, pmc_bench_collect.py turns them into
 # profiles/traffic.json.      usage: pmc_bench.sh <outdir>
+# PMC_BENCH_ARGS=" " (instead of the default "--contexts 1": one launch per step): the launch sizes of the default line - a MEM step of
+# 4 M reads and more as two halves -, one after the other (KAIJU_BENCH_SERIAL); pmc_bench_collect.py then wants PMC_MEM_LAUNCH /
+# PMC_PAIR_LAUNCH (reads / pairs per launch) and, to keep the records that are there, PMC_MERGE=<traffic.json>
 OUT=$1
 R=$(cd "$(dirname "$0")/../.." && pwd)
 export TMPDIR=/tmp
@@ -18,7 +21,7 @@ for ctrs in \
   # (PMC_PASSES="1 2": only those counter groups - the request counts the traffic figure is made of)
   if [ -n "$PMC_PASSES" ]; then case " $PMC_PASSES " in *" $i "*) ;; *) continue ;; esac; fi
   timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $OUT/pass$i -o p -- \
-    python $R/bench.py --contexts 1 --steps 1 --warmup 0 --no-cpu-baseline --legs greedy,paired > $OUT/pass$i.json 2> $OUT/pass$i.log
+    env KAIJU_BENCH_SERIAL=1 python $R/bench.py ${PMC_BENCH_ARGS:---contexts 1} --steps 1 --warmup 0 --no-cpu-baseline --legs greedy,paired > $OUT/pass$i.json 2> $OUT/pass$i.log
   echo "pass $i rc=$? : $ctrs"
   rm -f $OUT/pass$i/p_agent_info.csv
 done

@@ -7,6 +7,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 src, out = sys.argv[1], sys.argv[2]
@@ -46,7 +47,7 @@ for name, (kern, paired) in legs.items():
         continue
     mean = lambda xs: sum(v for v, _, _ in xs) / len(xs)
     r, r32, w, w64 = mean(rd), mean(rd32) if rd32 else 0.0, mean(wr), mean(wr64) if wr64 else 0.0
-    rec = {"mode": "greedy" if name == "greedy" else "mem", "paired": paired, "seg": 1, "nseq": 680001, "reads_per_launch": 5000000 if paired else 10000000,
+    rec = {"mode": "greedy" if name == "greedy" else "mem", "paired": paired, "seg": 1, "nseq": 680001, "reads_per_launch": int(os.environ.get("PMC_PAIR_LAUNCH", 5000000)) if paired else (10000000 if name == "greedy" else int(os.environ.get("PMC_MEM_LAUNCH", 10000000))),
            "kernel": kern, "launches_averaged": len(rd),
            "hbm_bytes_per_launch": (r - r32) * 128.0 + r32 * 32.0 + w64 * 64.0 + (w - w64) * 32.0,
            "counters_per_launch": {"TCC_EA0_RDREQ_sum": r, "TCC_EA0_RDREQ_32B_sum": r32, "TCC_EA0_WRREQ_sum": w, "TCC_EA0_WRREQ_64B_sum": w64,
@@ -60,6 +61,12 @@ for name, (kern, paired) in legs.items():
                      "--no-cpu-baseline --legs greedy,paired` (tests/tools/pmc_bench.sh); read requests x 128 B (32-B ones x 32 B), "
                      "write requests x 64 B (64-B ones) / x 32 B; mean over the launches of full size"}
     meas.append(rec)
+if os.environ.get("PMC_MERGE"):
+    # keep what is there; a new record replaces the one of the same leg / mode / pairing / launch size
+    key = lambda m: (m.get("leg"), m["mode"], bool(m.get("paired")), m["reads_per_launch"])
+    old = json.load(open(os.environ["PMC_MERGE"]))["measurements"]
+    new = {key(m) for m in meas}
+    meas = [m for m in old if key(m) not in new] + meas
 json.dump({"measurements": meas}, open(out, "w"), indent=1)
 for m in meas:
     print(m["kernel"], "paired" if m["paired"] else m["mode"], "%.1f GB per launch" % (m["hbm_bytes_per_launch"] / 1e9), "in %.2f ms" % m["kernel_ms_under_pmc"],
