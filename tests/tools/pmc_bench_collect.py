@@ -63,13 +63,13 @@ for name, (kern, paired) in legs.items():
     meas.append(rec)
 if os.environ.get("PMC_MERGE"):
     # keep what is there; a new record replaces the one of the same leg / mode / pairing / launch size
-    key = lambda m: (m.get("leg"), m["mode"], bool(m.get("paired")), m["reads_per_launch"])
+    key = lambda m: (m.get("leg"), m.get("mode"), bool(m.get("paired")), m["reads_per_launch"])
     old = json.load(open(os.environ["PMC_MERGE"]))["measurements"]
     new = {key(m) for m in meas}
     meas = [m for m in old if key(m) not in new] + meas
 json.dump({"measurements": meas}, open(out, "w"), indent=1)
 for m in meas:
-    print(m["kernel"], "paired" if m["paired"] else m["mode"], "%.1f GB per launch" % (m["hbm_bytes_per_launch"] / 1e9), "in %.2f ms" % m["kernel_ms_under_pmc"],
+    print(m["kernel"], m.get("leg") or ("paired" if m.get("paired") else m.get("mode")), "%.1f GB per launch" % (m["hbm_bytes_per_launch"] / 1e9), "in %.2f ms" % m["kernel_ms_under_pmc"],
           "=> %.2f TB/s" % (m["hbm_bytes_per_launch"] / m["kernel_ms_under_pmc"] / 1e9))
 # the other kernels: totals per launch, for DESIGN.md
 summary = {}
