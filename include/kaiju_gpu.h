@@ -193,8 +193,9 @@ typedef struct kaiju_gpu_index_footprint {
   uint64_t kmer_table;    /* suffix interval of every k-letter word                                                       */
   uint64_t kmer_lines;    /* the same as 128-byte lines for two end positions each (narrow indexes)                       */
   uint64_t text;          /* the database text (indexes that leave room for it: text verification of long matches)       */
-  uint64_t sa_full;       /* ... and position + sequence of every row's suffix, 2 x 4 bytes per row (narrow indexes), or  */
+  uint64_t sa_full;       /* ... and position + taxon of every row's suffix, 2 x 4 bytes per row (narrow indexes), or     */
                           /* the 40-bit text position of every 2^s-th row (wide indexes: s = 0 .. 3 by the room left)     */
+                          /* + the taxon of every row, 4 bytes each (wide indexes that leave room: KAIJU_GPU_ROW_TAX)     */
   uint64_t other;         /* constant tables                                                                              */
   uint64_t total;
   uint32_t kmer_k, wide;  /* k of the k-mer lines (narrow: a five-letter table stays next to them) or of the table; 1 = 64-bit positions */
