@@ -3844,6 +3844,10 @@ constexpr bool kChainPrune = true;
 // (the largest entry of the BLOSUM62 diagonal: W), a substitution at most kMaxSubstScore (the largest entry off the diagonal;
 // host_tables.cpp checks both against the table): if even that stays below min_score, no item of the chain passes the gate.
 constexpr int kMaxDiagScore = 11, kMaxSubstScore = 4;
+#ifndef KJ_CHAIN_ROWS
+#define KJ_CHAIN_ROWS 4
+#endif
+constexpr int kChainRows = KJ_CHAIN_ROWS;     // variants on up to this many rows are tested (every row's chain); 1: round 6's first form
 #ifdef KJ_NO_WIDE_CHAIN_PRUNE
 constexpr bool kWideChainPrune = false;       // (A/B measurements)
 #else
@@ -4619,11 +4623,15 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             // the same test on an index with 64-bit rows that keeps the text and the text position of EVERY row (tv_shift 0: up
             // to 2^34 rows where HBM has room); the position is read here - the load phase has no slot for it
             const int sc0 = (int)m_dsum + t_diff + bos;
-            if (rb - ra == (P)1 && ix.sa_tpos5 && ix.tv_shift == 0u && ix.text && (m_ql + 1u < p.m || sc0 < thr)) {
-              const uint64_t tp = *reinterpret_cast<const u64_unaligned *>(ix.sa_tpos5 + (size_t)ra * 5u) & kTposNone;
-              if constexpr (COUNT) oc[kOpcSa] += 2u;
-              if (tp != kTposNone && tp >= 16u + kTextPad &&
-                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0, thr)) {
+            if (rb - ra <= (P)kChainRows && ix.sa_tpos5 && ix.tv_shift == 0u && ix.text && (m_ql + 1u < p.m || sc0 < thr)) {
+              bool hopeless = true;
+              for (P q = ra; q < rb && hopeless; q++) {              // (every row's chain, as in the narrow lane below)
+                const uint64_t tp = *reinterpret_cast<const u64_unaligned *>(ix.sa_tpos5 + (size_t)q * 5u) & kTposNone;
+                if constexpr (COUNT) oc[kOpcSa] += 2u;
+                hopeless = tp != kTposNone && tp >= 16u + kTextPad &&
+                           kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0, thr);
+              }
+              if (hopeless) {
                 if constexpr (COUNT) oc[kOpcPruned]++;
                 continue;
               }
@@ -4644,17 +4652,27 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
             // (an item that passes the gate itself - m letters, min_score - is not looked at: on a database of protein families most
             //  one-row variants are of that kind, and the look costs a dependent load)
             const int sc0 = (int)m_dsum + t_diff + bos;           // the variant's own score (eval_match_scores: m_dsum + diff)
-            if (rb - ra == (P)1 && ix.sa_full && ix.text && (m_ql + 1u < p.m || sc0 < thr)) {
-              // (the text position of the variant's match: one letter in front of its parent's when that had one row - that
-              //  row's position came with the rank lines -, else the entry of the variant's own row)
+            // (round 6, later: a variant on a FEW rows - kChainRows; on the benchmark index 3.4 of the 5.5 items a read still
+            //  queued hung on two rows, a protein and its mutated copy - is not queued if the chain of EVERY one of its rows is
+            //  hopeless: whatever item descends from it ends on a non-empty subset of those rows, and for any row r of that
+            //  subset the path that led there is a path of r's own chain - the fragment's letter where r's text has it, a
+            //  substitution by r's letter where it has not -, with the same substitutions and the same score)
+            const P nrows = rb - ra;
+            if (nrows <= (P)kChainRows && ix.sa_full && ix.text && (m_ql + 1u < p.m || sc0 < thr)) {
+              bool hopeless = true;
+              for (P q = ra; q < rb && hopeless; q++) {
+                // (the text position of the variant's match: one letter in front of its parent's when that had one row - that
+                //  row's position came with the rank lines -, else the entry of the row)
 #ifdef KJ_CHAIN_PRUNE_HINT_ONLY
-              const uint32_t tp = vtp;
+                const uint32_t tp = nrows == (P)1 ? vtp : 0u;
 #else
-              const uint32_t tp = vtp ? vtp : ix.sa_full[(uint32_t)ra];
+                const uint32_t tp = (nrows == (P)1 && vtp) ? vtp : ix.sa_full[(uint32_t)q];
 #endif
-              if constexpr (COUNT) oc[kOpcSa] += vtp ? 1u : 2u;    // (a line of text, and the row's entry of the full suffix array unless it came with the rank lines)
-              if (tp >= 16u + kTextPad &&
-                  kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0, thr)) {
+                if constexpr (COUNT) oc[kOpcSa] += (nrows == (P)1 && vtp) ? 1u : 2u;    // (a line of text, and the row's entry of the full suffix array unless it came with the rank lines)
+                hopeless = tp >= 16u + kTextPad &&
+                           kj_chain_hopeless(p, win, wq, (int)pz, (int)m_qi + (int)m_ql - 1, *reinterpret_cast<const u128_unaligned *>(ix.text + tp - 16u), t_nmm + 1u, sc0, thr);
+              }
+              if (hopeless) {
                 if constexpr (COUNT) oc[kOpcPruned]++;
                 continue;
               }

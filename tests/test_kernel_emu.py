@@ -254,6 +254,26 @@ def test_greedy_chain_pruning_changes_nothing(oracle, emu, golden, handles):
             assert (a == b).all(), (pe, kw)
             bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], a[i])]
             assert not bad, (pe, kw, bad[:5])
+    # variants on TWO to four rows (kChainRows): a database with mutated copies of its proteins (1 - 15 % substitutions: what
+    # bench.py's database holds) - most seeds then lie on a protein and its copy
+    import tempfile
+    from kaiju_amd import mkfmi, synth
+    _, leaves = synth.make_taxonomy(3, 3, 3)
+    db = synth.make_db(nseq=4001, seed=31, leaves=leaves, max_len=600)
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_fasta(db, d + "/db.faa")
+        mkfmi.build_fmi(d + "/db.faa", d + "/db.fmi", threads=4, exponent=3)
+        seqs, off = synth.pack_reads(synth.make_reads(db, 6000, seed=32))
+        oix = oracle.load_fmi(d + "/db.fmi")
+        h1, h2 = emu.load(d + "/db.fmi"), plain.load(d + "/db.fmi")
+        for kw in (dict(), dict(mismatches=5, min_score=50), dict(m=15)):
+            okw = {("min_fragment_length" if k == "m" else k): v for k, v in kw.items()}
+            oh = oracle.classify(oix, None, oracle.params("greedy", use_evalue=0, **okw), seqs, off)
+            a, _ = emu.classify(h1, util.gp("greedy", use_evalue=0, **kw), seqs, off)
+            b, _ = plain.classify(h2, util.gp("greedy", use_evalue=0, **kw), seqs, off)
+            assert (a == b).all(), kw
+            bad = [i for i in range(len(oh)) if not util.same_hit(oh[i], a[i])]
+            assert not bad, (kw, bad[:5])
 
 
 @pytest.mark.parametrize("g3", [False, True])
