@@ -89,3 +89,22 @@ def test_single_rank_bench_with_the_librarys_gather(gpu_lib, tmp_path):
     line = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert line["config"]["gather_by"].startswith("library"), line["config"]["gather_by"]
     assert line["value"] > 0
+
+
+@pytest.mark.parametrize("gather", ["torch", "lib"])
+def test_two_halves_on_two_contexts_gather_twice(gpu_lib, tmp_path, gather):
+    """the default shape of a MEM step of 4 M reads and more - two halves on two contexts, each half gathered in stream order
+    behind its kernels - through RCCL with a process group of one rank (what every rank does at N > 1)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, KAIJU_DIST_FORCE_INIT="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port), KAIJU_BENCH_WORK=str(tmp_path / "work"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "4000000",
+                        "--nseq", "20001", "--legs", "", "--no-cpu-baseline", "--gather", gather], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    err = r.stderr.decode()
+    line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert line["value"] > 0 and line["config"]["process_group"]["backend"] == "nccl"
+    detail = json.loads(err[err.index("[bench] detail: ") + len("[bench] detail: "):].splitlines()[0])
+    assert detail["config"]["contexts_in_flight"] == 2 and detail["config"]["chunk"] == 2000000, detail["config"]
