@@ -1333,9 +1333,6 @@ KJ_HD void build_fragments(const ConstTables &t, const Params &p, const TrigCtx 
     auto final_flags = [&](uint32_t trig, uint32_t k) -> uint32_t {
       if (!p.seg) return 0u;
       if (!trig) return kFragChecked;                        // SEG would report nothing for this fragment
-#ifdef KJ_S1_NOAPPEND                                        // (timing experiments only: wrong results)
-      return kFragChecked;
-#endif
       const uint32_t slot = append_slot(sq.count);
       if (slot >= sq.cap) { if (err_flags) *err_flags |= 2u; return kFragChecked; }
       SegWork wk; wk.read = r; wk.frag = k;

@@ -13,7 +13,7 @@ V=$R/kaiju_amd/variants
 SRC="$R/kaiju_amd/csrc/capi.hip $R/kaiju_amd/csrc/fmi_stream.hip $R/kaiju_amd/csrc/exact_pass.hip $R/kaiju_amd/csrc/host_index.cpp $R/kaiju_amd/csrc/host_tables.cpp $R/kaiju_amd/csrc/taxonomy.cpp $R/kaiju_amd/csrc/mkfmi.cpp $R/kaiju_amd/csrc/rccl_gather.cpp"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-gpu-rdc -Wno-unused-result -w"
 declare -A DEF=( [cur]="" [prof]="-DKJ_PROF" [stats]="-DKJ_STATS" [ovf]="-DKJ_OVF_STATS" [norule]="-DKJ_NO_SPAN_RULE -DKJ_NO_PROBE" [noprobe]="-DKJ_NO_PROBE" [nospaneq]="-DKJ_NO_SPAN_EQ" [w5]="-DKJ_MEM_WAVES=5" [w6]="-DKJ_MEM_WAVES=6"
-  [noprune]="-DKJ_NO_CHAIN_PRUNE" [prunehint]="-DKJ_CHAIN_PRUNE_HINT_ONLY" [g3]="-DKJ_GREEDY3" [g3prof]="-DKJ_GREEDY3 -DKJ_PROF" [loc16]="-DKJ_LOC_TEAM=16" [loc32]="-DKJ_LOC_TEAM=32" [ilp2]="-DKJ_LOC_ILP=2" [ilp2_16]="-DKJ_LOC_ILP=2 -DKJ_LOC_TEAM=16" [ilp2_4]="-DKJ_LOC_ILP=2 -DKJ_LOC_TEAM=4" [segw4]="-DKJ_SEG_WAVES=4" [nowidecp]="-DKJ_NO_WIDE_CHAIN_PRUNE" [postw6]="-DKJ_POST_WAVES=6" [postw5]="-DKJ_POST_WAVES=5" [postnotrig]="-DKJ_POST_NOTRIG" [postnoloc]="-DKJ_POST_NOLOCATE" [postnone]="-DKJ_POST_NOTRIG -DKJ_POST_NOLOCATE" [s1noscan]="-DKJ_S1_NOSCAN" [s1noappend]="-DKJ_S1_NOAPPEND" )
+  [noprune]="-DKJ_NO_CHAIN_PRUNE" [prunehint]="-DKJ_CHAIN_PRUNE_HINT_ONLY" [g3]="-DKJ_GREEDY3" [g3prof]="-DKJ_GREEDY3 -DKJ_PROF" [loc16]="-DKJ_LOC_TEAM=16" [loc32]="-DKJ_LOC_TEAM=32" [ilp2]="-DKJ_LOC_ILP=2" [ilp2_16]="-DKJ_LOC_ILP=2 -DKJ_LOC_TEAM=16" [ilp2_4]="-DKJ_LOC_ILP=2 -DKJ_LOC_TEAM=4" [segw4]="-DKJ_SEG_WAVES=4" [nowidecp]="-DKJ_NO_WIDE_CHAIN_PRUNE" [postw6]="-DKJ_POST_WAVES=6" [postw5]="-DKJ_POST_WAVES=5" [postnotrig]="-DKJ_POST_NOTRIG" [postnoloc]="-DKJ_POST_NOLOCATE" [postnone]="-DKJ_POST_NOTRIG -DKJ_POST_NOLOCATE" [s1noscan]="-DKJ_S1_NOSCAN" )
 LIST=${VARIANTS:-cur prof}
 if [ "$1" = build ]; then
   mkdir -p $V
