@@ -257,18 +257,27 @@ uint64_t kaiju_taxonomy_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n);
 /* ConsumerThread.cpp:527-536 (Greedy), :614-623 (MEM), :820-824 (accessions).  Per read: the
    sequences whose names give the accession set of column 6 (first 20 distinct ones in the order the
    reference visits the rows; the caller prints the sorted set of kaiju_gpu_index_seq_name() prefixes
-   up to the last '_') and the text of column 7 ("PEPTIDE,PEPTIDE,").  Runs the first-generation
-   search kernels (a few times slower than the default path). */
+   up to the last '_') and the text of column 7 ("PEPTIDE,PEPTIDE,").  MEM mode: the search kernels of
+   the default path in an instantiation that notes where every match lies in its read, and a pass over
+   the records in front of the locate (k_mem_vb / k_mem_wide2_vb, k_mem_verbose); Greedy mode: the
+   first-generation search kernels (a few times slower than the default path). */
 #define KAIJU_GPU_MAX_ACC 20
 typedef struct {
   uint32_t n_acc;
-  uint32_t text_len;                      /* bytes at text + r * text_stride, 0-terminated */
+  uint32_t text_len;                      /* bytes at text + r * text_stride, 0-terminated (packed: at *text + text_pos[r]) */
   uint32_t truncated;                     /* the peptides did not fit */
   uint32_t acc_iseq[KAIJU_GPU_MAX_ACC];
 } kaiju_gpu_verbose;
 int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
                                      int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, char *text,
                                      uint32_t text_stride);
+/* The same with column 7 of the whole batch as ONE string owned by the context: read r's text is
+   (*text)[text_pos[r] .. text_pos[r] + vout[r].text_len), not terminated; *text_bytes = the length of
+   the string.  *text stays valid until the next verbose call on this context (or its destruction).
+   No row of text_stride bytes per read to allocate and walk: what the command line programs call. */
+int kaiju_gpu_classify_batch_verbose_packed(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
+                                            int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, uint64_t *text_pos,
+                                            const char **text, uint64_t *text_bytes);
 /* text_stride that holds column 7 of every read of a batch whose longest read (both mates of a pair together) has
    max_pair_len letters: callers size `text` with it instead of guessing the library's bound */
 uint32_t kaiju_gpu_verbose_text_stride(uint32_t max_pair_len, int input_is_protein);

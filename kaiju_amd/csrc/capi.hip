@@ -524,6 +524,65 @@ k_mem_wide2_count(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, 
   if (p.flags & kParamXOrder) mem_lane2<true, true, true>(ix, p, b, wl, ls);
   else mem_lane2<true, false, true>(ix, p, b, wl, ls);
 }
+// kaiju -v in MEM mode (kaiju_gpu_classify_batch_verbose): the same lanes noting where every recorded match lies in its read
+// (kj_core.h: VERBOSE, LaneScratch::vbm = the reads' rows of VerboseOut::acc), and the pass that turns the records and those
+// notes into columns 6 / 7 (mem_verbose_read) - in front of the locate kernels, which overwrite the matches with their ids
+__global__ void __launch_bounds__(kBlock, 2)
+k_mem_vb(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap, uint32_t *vbm) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  ls.vbm = vbm;
+  if (p.flags & kParamXOrder) mem_lane2<false, true, false, true>(ix, p, b, wl, ls);
+  else mem_lane2<false, false, false, true>(ix, p, b, wl, ls);
+}
+__global__ void __launch_bounds__(kBlock, 2)
+k_mem_wide2_vb(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uint32_t si_cap, uint32_t *vbm) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kBlock * kWinStride];
+  const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  LaneScratch ls;
+  ls.si = si_all + lane * si_cap;
+  ls.si_cap = si_cap;
+  ls.win = s_win + threadIdx.x * kWinStride;
+  __shared__ __attribute__((aligned(16))) uint8_t s_coop[(kBlock / 64) * kCoopBytesPerWave];
+  ls.coop = s_coop + (threadIdx.x >> 6) * kCoopBytesPerWave;
+  ls.vbm = vbm;
+  if (p.flags & kParamXOrder) mem_lane2<true, true, false, true>(ix, p, b, wl, ls);
+  else mem_lane2<true, false, false, true>(ix, p, b, wl, ls);
+}
+template <bool WIDE>
+__global__ void __launch_bounds__(256)
+k_mem_verbose(DevIndex ix, Params p, Batch b, VerboseOut vb) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r < b.n_reads) mem_verbose_read<WIDE>(ix, p, b, r, vb);
+}
+// Column 7 on its way to the host: the lanes write a read's peptides as index-alphabet codes into its own row of text_cap bytes
+// (1 KB per 150-bp read, of which a classified read uses ~40).  This pass turns the codes into letters and packs the rows of all
+// reads into one string - a wavefront's reads next to each other, the wavefronts where one atomic per wavefront puts them -
+// so that the host fetches the bytes that were written (tens of MB per 2 M reads) instead of every row (2 GB).
+struct VbAlphabet { char c[32]; uint32_t n; };
+__global__ void __launch_bounds__(256)
+k_vb_pack(VerboseOut vb, uint32_t n, VbAlphabet al, uint8_t *__restrict__ packed, uint64_t *__restrict__ pos, unsigned long long *total) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t w = 0;
+  if (r < n) { w = vb.text_len[r]; if (w > vb.text_cap) w = vb.text_cap; }
+  uint32_t incl = w;                                       // inclusive prefix sum over the wavefront
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += v; }
+  const uint32_t wave_total = (uint32_t)__shfl((int)incl, 63, 64);
+  unsigned long long base = 0;
+  if (lane == 63u && wave_total) base = atomicAdd(total, (unsigned long long)wave_total);
+  base = (unsigned long long)__shfl((long long)base, 63, 64);
+  if (r >= n) return;
+  const uint64_t at = base + incl - w;
+  pos[r] = at;
+  const uint8_t *src = vb.text + (size_t)r * vb.text_cap;
+  for (uint32_t x = 0; x < w; x++) { const uint8_t c = src[x]; packed[at + x] = c == 255 ? (uint8_t)',' : (c < al.n ? (uint8_t)al.c[c] : (uint8_t)'?'); }
+}
 // kaijux (ids = database sequences): the matches of a fragment are visited in the list order of maxMatches(.., 1)
 // (kj_core.h: XORDER); the first-generation lanes take the same switch from Params::flags
 __global__ void __launch_bounds__(kBlock, 4)
@@ -1815,6 +1874,7 @@ struct kaiju_gpu_ctx {
   bool exact_pass = true;          // KAIJU_GPU_EXACT_PASS=0 switches the exact pass off (its reads stay flagged)
   bool count_ops = false;          // kaiju_gpu_set_count_ops: the main pass runs the counting instantiation of its lane
   bool mem_v1 = false;             // KAIJU_GPU_MEM_LANE=v1 (read once, at context creation)
+  bool verbose_v1 = false;         // KAIJU_GPU_VERBOSE_LANE=v1: -v in MEM mode from the first-generation lanes (until round 6 the only way; A/B)
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
   DevBuf seglist, loc_list, todo_list;
@@ -1823,6 +1883,9 @@ struct kaiju_gpu_ctx {
   const char *dump_frags = nullptr;// KAIJU_GPU_DUMP_FRAGS (developer aid; read once)
   uint32_t vb_text_cap = 0;
   DevBuf vb_nacc, vb_acc, vb_tlen, vb_text, vb_bestv, vb_bestv_retry;
+  DevBuf vb_packed, vb_pos;          // column 7 packed for the way to the host (k_vb_pack)
+  std::vector<uint8_t> vb_host;      // ... and where it arrives
+  std::vector<uint32_t> vb_h_nacc, vb_h_acc;   // (host side of the accessions: kept, so that a call does not fault 80 bytes per read in again)
   DevBuf h_seqs, h_off, h_hits;      // staging for the host-buffer entry point
   kaiju_gpu_stats stats{};
   uint32_t last_n = 0;
@@ -1831,7 +1894,7 @@ struct kaiju_gpu_ctx {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     DevBuf *all[] = {&pep, &frags, &meta, &counters, &retry_list, &seg_items, &seg_recs, &h_seqs, &h_off, &h_hits, &h_compact, &seglist, &loc_list, &todo_list,
-                     &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry,
+                     &vb_nacc, &vb_acc, &vb_tlen, &vb_text, &vb_bestv, &vb_bestv_retry, &vb_packed, &vb_pos,
                      &redo_bitmap, &redo_list, &redo_items, &redo_index, &redo_pool, &redo_work, &redo_cls};
     for (DevBuf *b : all) if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < 10; i++) if (scratch_main[i].p) (void)hipFree(scratch_main[i].p);
@@ -1886,6 +1949,7 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   if (const char *e = getenv("KAIJU_GPU_DEBUG")) c->kp.debug = (uint32_t)atoi(e);
   if (const char *e = getenv("KAIJU_GPU_EXACT_PASS")) c->exact_pass = atoi(e) != 0;
   if (const char *e = getenv("KAIJU_GPU_MEM_LANE")) c->mem_v1 = !strcmp(e, "v1");
+  if (const char *e = getenv("KAIJU_GPU_VERBOSE_LANE")) c->verbose_v1 = !strcmp(e, "v1");
   c->dump_frags = getenv("KAIJU_GPU_DUMP_FRAGS");
   if (const char *e = getenv("KAIJU_GPU_STAGE1")) c->stage1_old = !strcmp(e, "old");
   if (const char *e = getenv("KAIJU_GPU_LAZY_SEG")) c->lazy_seg = atoi(e) != 0;
@@ -2013,14 +2077,18 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   // lanes SEG is then looked at lazily (kj_core.h: kParamLazySeg), everywhere else stage 1 detects the SEG trigger itself
   const bool mem_narrow2 = ix->dev.blocks64 && ix->dev.kline && ix->dev.kline_k >= 2 && ix->dev.kline_k <= p.m;
   const bool mem_wide2 = ix->dev.blocks64 && ix->dev.mb_base && ix->dev.kmer64 && ix->dev.kmer_k >= 2 && ix->dev.kmer_k <= p.m;
-  const bool mem_v2 = p.mode == 0 && (mem_narrow2 || mem_wide2) && !c->mem_v1 && !c->verbose;
+  // kaiju -v in MEM mode: the VERBOSE instantiations of those lanes + k_mem_verbose - where a match's place in its read fits the
+  // 16 + 16 bits of the lanes' notes (reads of 196 000 nt and more: the first-generation lanes, which also serve -v in Greedy
+  // mode, the retry pass and the exact pass)
+  const bool vb_v2 = c->verbose && !c->verbose_v1 && max_read_len / 3 + 4 < 65536 && 2 * max_pair / (p.m + 1) + 8 < 65536;
+  const bool mem_v2 = p.mode == 0 && (mem_narrow2 || mem_wide2) && !c->mem_v1 && (!c->verbose || vb_v2);
   const bool fast1 = !protein && !c->stage1_old && max_read_len <= kS1MaxLenLong && p.m >= 1 && p.m <= 64;
   const bool long1 = max_read_len > kS1MaxLen;              // (192 .. 287 nt: the instantiation with six units per frame string)
   const bool lazy = fast1 && mem_v2 && p.seg && c->lazy_seg;
   const bool trig1 = fast1 && p.seg && !lazy;
   // the fused post-search pass (k_mem_post1 / _post2): narrow MEM lanes with the row -> taxon table, SEG lazily or not at all
   // (an eager SEG pass may send ANY read to the exact pass: nothing is final before that)
-  fused = p.mode == 0 && mem_v2 && mem_narrow2 && ix->dev.row_tax && (lazy || !p.seg) && c->fused_post && n > 0;
+  fused = p.mode == 0 && mem_v2 && mem_narrow2 && ix->dev.row_tax && (lazy || !p.seg) && c->fused_post && n > 0 && !c->verbose;
   // unused id slots read as 0.  Not with the 16-byte records as the output on the fused path: the lanes write the header of every
   // record and the entries they announce in it, k_mem_post1 / _post2 read nothing else - d_hits is scratch there (1.84 GB less to
   // write per 10 M reads)
@@ -2117,6 +2185,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       SIEntry *si_main = static_cast<SIEntry *>(c->scratch_main[0].p);
       // the second-generation lane that serves this index (narrow: below 2^32 rows; wide: 64-bit positions)
       auto launch_v2 = [&](const Params &pp, const WorkList &wl, bool counting, bool second = false) {
+        if (c->verbose) {
+          if (mem_narrow2) hipLaunchKernelGGL(k_mem_vb, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap, vb.acc);
+          else hipLaunchKernelGGL(k_mem_wide2_vb, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap, vb.acc);
+        } else
         if (mem_narrow2) {
           if (second && !xo) hipLaunchKernelGGL(k_mem_second, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
           else if (counting) hipLaunchKernelGGL(k_mem_count, dim3(c->blocks_main), blk, 0, s, ix->dev, pp, b, wl, si_main, si_cap);
@@ -2173,6 +2245,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       hipLaunchKernelGGL(k_mem_retry, dim3(blocks_retry), blk, 0, s, ix->dev, p, b, wl_retry,
                          static_cast<SIEntry *>(c->scratch_retry[0].p), si_cap_retry, vb);
       KJ_HIP(hipGetLastError());
+      if (defer && c->verbose) {
+        // columns 6 / 7 of the reads whose matches wait in their records (the retry pass above wrote its reads' own)
+        if (mem_narrow2) hipLaunchKernelGGL(k_mem_verbose<false>, grid_reads, dim3(256), 0, s, ix->dev, p, b, vb);
+        else hipLaunchKernelGGL(k_mem_verbose<true>, grid_reads, dim3(256), 0, s, ix->dev, p, b, vb);
+        KJ_HIP(hipGetLastError());
+      }
       if (defer && !fused) {
         if (mem_narrow2 && ix->dev.row_tax) {
           hipLaunchKernelGGL(k_mem_locate<false>, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 24);
@@ -2458,42 +2536,96 @@ extern "C" int kaiju_gpu_lca_batch_device(kaiju_gpu_ctx *ctx, const kaiju_gpu_ta
   return KAIJU_GPU_OK;
 }
 
+// (the part both entry points share: classification, k_vb_pack, the records / accessions / packed text fetched - the text
+//  into ctx->vb_host, read r's at pos[r])
+static int verbose_core(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads, int paired, kaiju_gpu_hit *out,
+                        kaiju_gpu_verbose *vout, std::vector<uint64_t> &pos, std::vector<uint32_t> &tlen) {
+  ctx->verbose = true;
+  int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
+  ctx->verbose = false;
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  // column 7: letters, packed on the device (k_vb_pack) - the rows of text_cap bytes stay there
+  const char *alpha = ctx->ix->info.alphabet;
+  VbAlphabet al{};
+  al.n = (uint32_t)std::min<size_t>(strlen(alpha), sizeof al.c);
+  memcpy(al.c, alpha, al.n);
+  if ((rc = ensure(ctx->vb_packed, (size_t)n_reads * ctx->vb_text_cap + 16))) return rc;
+  if ((rc = ensure(ctx->vb_pos, (size_t)n_reads * 8 + 16))) return rc;
+  VerboseOut vbd{static_cast<uint32_t *>(ctx->vb_nacc.p), static_cast<uint32_t *>(ctx->vb_acc.p), static_cast<uint32_t *>(ctx->vb_tlen.p),
+                 static_cast<uint8_t *>(ctx->vb_text.p), ctx->vb_text_cap};
+  unsigned long long *d_total = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(ctx->vb_pos.p) + (size_t)n_reads * 8);
+  KJ_HIP(hipMemsetAsync(d_total, 0, 8, s));
+  hipLaunchKernelGGL(k_vb_pack, dim3((n_reads + 255) / 256), dim3(256), 0, s, vbd, n_reads, al, static_cast<uint8_t *>(ctx->vb_packed.p),
+                     static_cast<uint64_t *>(ctx->vb_pos.p), d_total);
+  KJ_HIP(hipGetLastError());
+  std::vector<uint32_t> &nacc = ctx->vb_h_nacc, &acc = ctx->vb_h_acc;
+  if (nacc.size() < n_reads) nacc.resize(n_reads);
+  if (acc.size() < (size_t)n_reads * kVbAcc) acc.resize((size_t)n_reads * kVbAcc);
+  pos.resize((size_t)n_reads + 1); tlen.resize(n_reads);
+  KJ_HIP(hipMemcpyAsync(out, ctx->h_hits.p, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(nacc.data(), ctx->vb_nacc.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(tlen.data(), ctx->vb_tlen.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(acc.data(), ctx->vb_acc.p, (size_t)n_reads * kVbAcc * 4, hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipMemcpyAsync(pos.data(), ctx->vb_pos.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+  KJ_HIP(hipStreamSynchronize(s));
+  const uint64_t total = pos[n_reads];
+  if (total > (uint64_t)n_reads * ctx->vb_text_cap) return fail(KAIJU_GPU_ERR_HIP, "k_vb_pack: impossible total");
+  if (ctx->vb_host.size() < total) ctx->vb_host.resize((size_t)total);
+  if (total) KJ_HIP(hipMemcpy(ctx->vb_host.data(), ctx->vb_packed.p, (size_t)total, hipMemcpyDeviceToHost));
+  for (uint32_t r = 0; r < n_reads; r++) {
+    kaiju_gpu_verbose &v = vout[r];
+    v.n_acc = nacc[r] > (uint32_t)kVbAcc ? (uint32_t)kVbAcc : nacc[r];
+    for (uint32_t q = 0; q < (uint32_t)KAIJU_GPU_MAX_ACC; q++) v.acc_iseq[q] = q < v.n_acc ? acc[(size_t)r * kVbAcc + q] : 0;
+    v.text_len = tlen[r] < ctx->vb_text_cap ? tlen[r] : ctx->vb_text_cap;
+    v.truncated = tlen[r] > ctx->vb_text_cap ? 1u : 0u;
+  }
+  return KAIJU_GPU_OK;
+}
+
 // Verbose classification (the reference's -v): hit records plus, per read, the sequences that give
-// column 6 and the text of column 7.  Runs the first-generation lanes.
+// column 6 and the text of column 7.  MEM mode: the second-generation lanes (k_mem_vb / k_mem_wide2_vb + k_mem_verbose);
+// Greedy mode, the retry pass and the exact pass: the first-generation lanes.
 extern "C" int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
                                                 int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, char *text,
                                                 uint32_t text_stride) {
   return guarded([&]() -> int {
   if (!ctx || !off || (n_reads && (!out || !vout || !text))) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
   if (n_reads == 0) return KAIJU_GPU_OK;
-  ctx->verbose = true;
-  int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
-  ctx->verbose = false;
+  std::vector<uint64_t> pos;
+  std::vector<uint32_t> tlen;
+  int rc = verbose_core(ctx, seqs, off, n_reads, paired, out, vout, pos, tlen);
   if (rc) return rc;
-  hipStream_t s = ctx->stream;
-  std::vector<uint32_t> nacc(n_reads), tlen(n_reads), acc((size_t)n_reads * kVbAcc);
-  std::vector<uint8_t> codes((size_t)n_reads * ctx->vb_text_cap);
-  KJ_HIP(hipMemcpyAsync(out, ctx->h_hits.p, (size_t)n_reads * sizeof(kaiju_gpu_hit), hipMemcpyDeviceToHost, s));
-  KJ_HIP(hipMemcpyAsync(nacc.data(), ctx->vb_nacc.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
-  KJ_HIP(hipMemcpyAsync(tlen.data(), ctx->vb_tlen.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
-  KJ_HIP(hipMemcpyAsync(acc.data(), ctx->vb_acc.p, acc.size() * 4, hipMemcpyDeviceToHost, s));
-  KJ_HIP(hipMemcpyAsync(codes.data(), ctx->vb_text.p, codes.size(), hipMemcpyDeviceToHost, s));
-  KJ_HIP(hipStreamSynchronize(s));
-  const char *alpha = ctx->ix->info.alphabet;
-  const size_t alen = strlen(alpha);
   for (uint32_t r = 0; r < n_reads; r++) {
     kaiju_gpu_verbose &v = vout[r];
-    v.n_acc = nacc[r] > (uint32_t)kVbAcc ? (uint32_t)kVbAcc : nacc[r];
-    for (uint32_t q = 0; q < (uint32_t)KAIJU_GPU_MAX_ACC; q++) v.acc_iseq[q] = q < v.n_acc ? acc[(size_t)r * kVbAcc + q] : 0;
-    const uint32_t have = tlen[r] < ctx->vb_text_cap ? tlen[r] : ctx->vb_text_cap;
-    v.truncated = (tlen[r] > ctx->vb_text_cap || have + 1 > text_stride) ? 1u : 0u;
+    const uint32_t have = v.text_len;
+    if (have + 1 > text_stride) v.truncated = 1u;
     const uint32_t w = have + 1 <= text_stride ? have : (text_stride ? text_stride - 1 : 0);
     char *dst = text + (size_t)r * text_stride;
-    const uint8_t *src = codes.data() + (size_t)r * ctx->vb_text_cap;
-    for (uint32_t x = 0; x < w; x++) dst[x] = src[x] == 255 ? ',' : (src[x] < alen ? alpha[src[x]] : '?');
+    if (w) memcpy(dst, ctx->vb_host.data() + pos[r], w);
     if (text_stride) dst[w] = 0;
     v.text_len = w;
   }
+  return KAIJU_GPU_OK;
+  });
+}
+
+// The same with column 7 of the whole batch as ONE string that the context owns (no row of text_stride bytes per read for the
+// caller to allocate, fault in and walk: at 150 bp a row is 1 KB, of which a classified read uses ~40 bytes)
+extern "C" int kaiju_gpu_classify_batch_verbose_packed(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
+                                                       int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, uint64_t *text_pos,
+                                                       const char **text, uint64_t *text_bytes) {
+  return guarded([&]() -> int {
+  if (!ctx || !off || !text || !text_bytes || (n_reads && (!out || !vout || !text_pos))) return fail(KAIJU_GPU_ERR_ARG, "NULL argument");
+  *text = nullptr; *text_bytes = 0;
+  if (n_reads == 0) return KAIJU_GPU_OK;
+  std::vector<uint64_t> pos;
+  std::vector<uint32_t> tlen;
+  int rc = verbose_core(ctx, seqs, off, n_reads, paired, out, vout, pos, tlen);
+  if (rc) return rc;
+  memcpy(text_pos, pos.data(), (size_t)n_reads * 8);
+  *text = reinterpret_cast<const char *>(ctx->vb_host.data());
+  *text_bytes = pos[n_reads];
   return KAIJU_GPU_OK;
   });
 }

@@ -586,20 +586,18 @@ struct Batch {
   // results
   HugeVec<kaiju_gpu_hit> hits;             // -v only
   HugeVec<kaiju_gpu_verbose> vrec;         // -v only: columns 6/7
-  // -v only: the matched peptides (column 7).  The library wants one stride for all reads of a call - room for the longest
-  // of them, up to 64 KB - so a batch is classified in pieces of at most verbose_text_budget() bytes of text: one 10-kb read in a
-  // batch of a million no longer asks for 64 GB
-  struct VPiece { uint32_t lo = 0, n = 0, stride = 0; CharVec text; };
-  std::vector<VPiece> vpieces;
-  const char *vtext_of(size_t r) const {
-    for (const VPiece &p : vpieces) if (r >= p.lo && r < (size_t)p.lo + p.n) return p.text.data() + (r - p.lo) * (size_t)p.stride;
-    return nullptr;
-  }
+  // -v only: the matched peptides (column 7), one string for the batch (kaiju_gpu_classify_batch_verbose_packed); read r's
+  // starts at vpos[r].  On the DEVICE a read still has a row for the longest read of its call - up to 64 KB - so a batch is
+  // classified in pieces of at most verbose_text_budget() bytes of rows: one 10-kb read in a batch of a million does not ask
+  // for 64 GB
+  CharVec vtext;
+  HugeVec<uint64_t> vpos;
+  const char *vtext_of(size_t r) const { return vtext.data() + vpos[r]; }
   HugeVec<kaiju_gpu_compact> compact;
   std::string text;
   void reset() {                           // empty, capacities kept
     seqs.clear(); off.assign(1, 0); names.clear(); name_off.assign(1, 0);
-    hits.clear(); vrec.clear(); vpieces.clear(); compact.clear(); text.clear();
+    hits.clear(); vrec.clear(); vtext.clear(); vpos.clear(); compact.clear(); text.clear();
   }
 };
 
@@ -1063,31 +1061,37 @@ int main(int argc, char **argv) {
           if (verbose) {
             b->hits.resize(n);
             b->vrec.resize(n);
+            b->vpos.resize(n);
             std::vector<uint64_t> poff;
             piece_error_flags = 0;
             for (uint32_t lo = 0; lo < n && r == 0;) {
               // the longest piece from read lo on whose text fits the budget (at least one read)
               uint64_t maxpair = 0;
-              uint32_t hi = lo, stride = 0;
+              uint32_t hi = lo;
               while (hi < n) {
                 const uint64_t mp = std::max<uint64_t>(maxpair, b->off[2 * (size_t)hi + 2] - b->off[2 * (size_t)hi]);
                 const uint32_t st = kaiju_gpu_verbose_text_stride((uint32_t)mp, protein ? 1 : 0);
                 if (hi > lo && (uint64_t)(hi - lo + 1) * st > verbose_text_budget()) break;
-                maxpair = mp; stride = st; hi++;
+                maxpair = mp; hi++;
               }
-              b->vpieces.emplace_back();
-              Batch::VPiece &pc = b->vpieces.back();
-              pc.lo = lo; pc.n = hi - lo; pc.stride = stride;
-              pc.text.resize((size_t)pc.n * stride);
+              const uint32_t pn = hi - lo;
               const uint64_t base = b->off[2 * (size_t)lo];
               const uint64_t *po = b->off.data() + 2 * (size_t)lo;
               if (base != 0) {                   // (the entry point wants off[0] == 0)
-                poff.resize(2 * (size_t)pc.n + 1);
+                poff.resize(2 * (size_t)pn + 1);
                 for (size_t q = 0; q < poff.size(); q++) poff[q] = po[q] - base;
                 po = poff.data();
               }
-              r = kaiju_gpu_classify_batch_verbose(ctx[k], b->seqs.data() + base, po, pc.n, paired ? 1 : 0, b->hits.data() + lo,
-                                                   b->vrec.data() + lo, pc.text.data(), stride);
+              const char *ptext = nullptr;
+              uint64_t pbytes = 0;
+              r = kaiju_gpu_classify_batch_verbose_packed(ctx[k], b->seqs.data() + base, po, pn, paired ? 1 : 0, b->hits.data() + lo,
+                                                          b->vrec.data() + lo, b->vpos.data() + lo, &ptext, &pbytes);
+              if (r == 0) {
+                // (the string belongs to the context until its next call: the piece's text moves behind the batch's)
+                const uint64_t at = b->vtext.size();
+                b->vtext.insert(b->vtext.end(), ptext, ptext + pbytes);
+                if (at) for (uint32_t q = lo; q < hi; q++) b->vpos[q] += at;
+              }
               // (the device counters are zeroed per launch: the flags of every piece count, not only the last one's)
               { kaiju_gpu_stats ps; if (r == 0 && kaiju_gpu_get_stats(ctx[k], &ps) == 0) piece_error_flags |= ps.error_flags; }
               lo = hi;

@@ -2065,6 +2065,8 @@ struct LaneScratch {
   uint8_t *win;              // this lane's peptide window (kWin bytes)
   unsigned long long *prof = nullptr;   // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PM_N)
   uint8_t *coop = nullptr;   // wide lanes: the wavefront's kCoopBytesPerWave bytes of LDS (coop_fetch2; 16-byte aligned, wave-uniform)
+  uint32_t *vbm = nullptr;   // VERBOSE instantiations of mem_lane2: [n][kVbAcc] words, where every recorded match lies in its read
+                             // (fragment << 16 | start, in the order found) - mem_verbose_read turns them into columns 6 / 7
 };
 
 struct WorkList {
@@ -2113,6 +2115,7 @@ KJ_HD void opc_flush(unsigned long long *dst, const uint32_t *oc) { for (int x =
 // best SI with the substitutions of its variant applied, :780-790).
 // ----------------------------------------------------------------------------
 constexpr int kVbAcc = 20;
+constexpr int kVbMem = 16;    // matches of a read that the VERBOSE instantiations of mem_lane2 describe (= the lanes' match buffer, si_cap)
 struct VerboseOut {           // all pointers null: verbose output off
   uint32_t *n_acc;            // [n]
   uint32_t *acc;              // [n][kVbAcc] sequence numbers
@@ -2429,7 +2432,7 @@ static int kj_single_at = 0;
 #define KJ_HIST_SINGLE(is1, len)
 #define KJ_HIST_SINGLE_END(l)
 #endif
-template <bool WIDE, bool XORDER = false, bool COUNT = false>
+template <bool WIDE, bool XORDER = false, bool COUNT = false, bool VERBOSE = false>
 KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const WorkList &wl,
                      const LaneScratch &ls) {
   uint32_t oc[kOpcN];
@@ -2812,6 +2815,7 @@ KJ_HD void mem_lane2(const DevIndex &ix, const Params &p, const Batch &b, const 
           if (l > L) { nsi = 0; ovf = false; L = l; multi = false; }   // shorter matches are dropped (bwt.c:366-370, :577-582)
           const uint32_t ilen = (uint32_t)(int32_t)(hi - lo);
           if (nsi != 0 && fcur != s0frag) multi = true;      // (lazy SEG: longest matches in more than one fragment)
+          if constexpr (VERBOSE) { if (nsi < (uint32_t)kVbMem) ls.vbm[(size_t)r * kVbAcc + nsi] = fcur << 16 | ((uint32_t)i & 0xffffu); }
           if (nsi == 0) { s0lo = lo; s0len = ilen; s0frag = fcur; }
           else if (nsi == 1) { s1lo = lo; s1len = ilen; s1frag = fcur; }
           else if (nsi < ls.si_cap) { SIEntry e; e.lo = lo; e.len = ilen; e.frag = fcur; ls.si[nsi] = e; if constexpr (COUNT) oc[kOpcSiSpill]++; }
@@ -3101,6 +3105,79 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
   return true;
 }
 
+
+// Columns 6 and 7 of kaiju -v for a read of the second-generation MEM lanes (ConsumerThread.cpp:580-590, :614-623, :820-824),
+// from what the VERBOSE instantiation of mem_lane2 left behind: the matches in the hit record (visiting order, as for
+// mem_locate_read, which runs BEHIND this and turns them into ids) and, in the read's row of VerboseOut::acc, where every one
+// of them lies in the read (fragment << 16 | start, in the order found).  Column 7: classify_length pushes
+// fragment.substr(si->qi, si->ql) of the list HEAD of every fragment that holds a longest match (greedyExact prepends: the
+// match found last; kaijux' maxMatches(.., 1): the one found first), in the order the fragments were searched - for every
+// fragment, whatever ids_from_SI's limit does later.  Column 6: ids_from_SI's loop over the rows with its limit on the number
+// of distinct taxon ids in front of every row (:805-807), get_suffix's walk for the sequence number (the row -> taxon table
+// does not know the sequence), the name noted before the id is (:822-824, :834).  One lane per read: this is the verbose
+// path, a walk per row is what the reference pays too.
+template <bool WIDE>
+KJ_HD void mem_verbose_read(const DevIndex &ix, const Params &p, const Batch &b, uint32_t r, const VerboseOut &vb) {
+  typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
+  const Hit *hit = b.hits + r;
+  if (!(hit->flags & kHitLocPending) || !vb.n_acc) return;
+  const uint32_t nsi = hit->n_ids < (uint32_t)kVbMem ? hit->n_ids : (uint32_t)kVbMem;
+  const bool xo = (p.flags & kParamXOrder) != 0;
+  uint32_t where[kVbMem];
+  for (uint32_t q = 0; q < nsi; q++) where[q] = vb.acc[(size_t)r * kVbAcc + q];
+  vb.n_acc[r] = 0; vb.text_len[r] = 0;
+  const ReadMeta rm = b.meta[r];
+  const Frag *F = b.frags + rm.frag;
+  const uint8_t *pep = b.pep + rm.pep;
+  const uint32_t L = hit->best;
+  for (uint32_t gs = 0; gs < nsi;) {
+    const uint32_t fr = where[gs] >> 16;
+    uint32_t ge = gs + 1;
+    while (ge < nsi && (where[ge] >> 16) == fr) ge++;
+    vb_text(vb, r, pep + F[fr].start + (where[xo ? gs : ge - 1] & 0xffffu), L, 0, nullptr, nullptr, 0);
+    gs = ge;
+  }
+  const P check = (P)((1ull << ix.chpt_exp) - 1ull);
+  const RankBlock64 *const blk0 = ix.blocks64;
+  uint64_t ids[kMaxIds];
+  uint32_t nids = 0;
+  for (uint32_t s = 0; s < nsi; s++) {
+    const uint64_t es = hit->taxid[s];
+    const P lo = WIDE ? (P)(es & ((1ull << kLocWideShift) - 1ull)) : (P)(uint32_t)es;
+    const uint32_t len = WIDE ? (uint32_t)(es >> kLocWideShift) : (uint32_t)(es >> 32);
+    const P rowend = lo + (P)(int32_t)len;
+    for (P row = lo; row < rowend; row++) {
+      if (nids > p.max_match_ids) return;                    // :805-807 (and every later match breaks at its first row)
+      P k = row;
+      uint32_t iseq = 0xffffffffu;
+      for (;;) {
+        if ((k & check) == 0) {
+          const uint64_t sa_idx = ((uint64_t)k >> ix.chpt_exp) - ix.sa_skip;
+          if (sa_idx < ix.n_sa) iseq = ix.sa_iseq[sa_idx];   // (beyond the samples the reference reads out of bounds: the row is skipped)
+          break;
+        }
+        const RankBlock64 &rb = blk0[k >> 6];
+        const uint32_t sft = (uint32_t)k & 63u;
+        const uint32_t c = (uint32_t)((rb.plane[0] >> sft) & 1ull) | (uint32_t)((rb.plane[1] >> sft) & 1ull) << 1 |
+                           (uint32_t)((rb.plane[2] >> sft) & 1ull) << 2 | (uint32_t)((rb.plane[3] >> sft) & 1ull) << 3 |
+                           (uint32_t)((rb.plane[4] >> sft) & 1ull) << 4;
+        if (c == 0) { iseq = (uint32_t)rank_term(ix, k); break; }      // the start of a sequence: its number is the rank of the terminator (bwt.c:120)
+        const uint64_t ia = (c & 1u) ? 0ull : ~0ull, ib = (c & 2u) ? 0ull : ~0ull, ic = (c & 4u) ? 0ull : ~0ull,
+                       id = (c & 8u) ? 0ull : ~0ull, ie = (c & 16u) ? 0ull : ~0ull;
+        const uint64_t m = (rb.plane[0] ^ ia) & (rb.plane[1] ^ ib) & (rb.plane[2] ^ ic) & (rb.plane[3] ^ id) & (rb.plane[4] ^ ie);
+        uint64_t base = 0;
+        if constexpr (WIDE) base = ix.mb_base[(size_t)((uint64_t)k >> ix.mb_shift) * 20 + (c - 1u)];
+        k = (P)(base + rb.cnt[c - 1u] + popc64(m & ((1ull << sft) - 1ull)));
+      }
+      if (iseq >= ix.nseq || !ix.seq_valid[iseq]) continue;
+      vb_acc(vb, ix, r, iseq);
+      const uint64_t tax = ix.seq_taxid[iseq];
+      bool dup = false;
+      for (uint32_t q = 0; q < nids; q++) dup = dup || ids[q] == tax;
+      if (!dup && nids < (uint32_t)kMaxIds) ids[nids++] = tax;
+    }
+  }
+}
 
 // The same for a TEAM of T lanes per read (T a power of two, the lanes of a team next to each other in the wavefront): the rows
 // of a match are walked T at a time, one row per lane, and the team's first lane then takes their ids in row order - the

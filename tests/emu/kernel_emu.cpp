@@ -163,7 +163,10 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   // which flow (capi.hip: launch_batch): the fast stage 1 for mates up to kS1MaxLen nucleotides; MEM on the second-generation
   // lanes then looks at SEG lazily
   const char *lane_env = getenv("KAIJU_EMU_LANE");
-  const bool mem_v2 = p.mode == 0 && d.blocks64 && (d.kmer32 || (d.mb_base && d.kmer64)) && !lane_env && !g_vb.n_acc;
+  // (verbose output: the VERBOSE instantiations of the second-generation lanes + mem_verbose_read, as capi.hip; KAIJU_EMU_VERBOSE_V1
+  //  = the first-generation lanes, which wrote columns 6 / 7 until round 6)
+  const bool vb_v2 = g_vb.n_acc && !getenv("KAIJU_EMU_VERBOSE_V1");
+  const bool mem_v2 = p.mode == 0 && d.blocks64 && (d.kmer32 || (d.mb_base && d.kmer64)) && !lane_env && (!g_vb.n_acc || vb_v2);
   const bool fast1 = !(p.flags & kParamProtein) && !getenv("KAIJU_EMU_STAGE1_OLD") && maxlen <= kS1MaxLenLong && p.m >= 1 && p.m <= 64;
   const bool long1 = maxlen > kS1MaxLen;
   const bool lazy = fast1 && mem_v2 && p.seg && !getenv("KAIJU_EMU_LAZY_OFF");
@@ -254,8 +257,13 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       LaneScratch ls{si.data(), (uint32_t)si.size(), win};
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1", "wide" or default (v2 where possible)
       const bool xo = (p.flags & kParamXOrder) != 0;
+      if (vb_v2) ls.vbm = g_vb.acc;
       auto lane_v2 = [&](const Params &pp, const WorkList &w2) {
-        if (d.kmer32) { if (xo) mem_lane2<false, true>(d, pp, b, w2, ls); else mem_lane2<false>(d, pp, b, w2, ls); }
+        if (vb_v2) {                                     // (k_mem_vb / k_mem_wide2_vb)
+          if (d.kmer32) { if (xo) mem_lane2<false, true, false, true>(d, pp, b, w2, ls); else mem_lane2<false, false, false, true>(d, pp, b, w2, ls); }
+          else { if (xo) mem_lane2<true, true, false, true>(d, pp, b, w2, ls); else mem_lane2<true, false, false, true>(d, pp, b, w2, ls); }
+        }
+        else if (d.kmer32) { if (xo) mem_lane2<false, true>(d, pp, b, w2, ls); else mem_lane2<false>(d, pp, b, w2, ls); }
         else { if (xo) mem_lane2<true, true>(d, pp, b, w2, ls); else mem_lane2<true>(d, pp, b, w2, ls); }
       };
       if (mem_v2 && pass == 0) {
@@ -366,6 +374,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       } else greedy_lane(d, ix->ct, p, sq, b, wl, gs, g_vb);
     }
   }
+  // k_mem_verbose (capi.hip): columns 6 / 7 of the reads whose matches wait in their records, in front of the locate
+  if (mem_v2 && vb_v2) for (uint32_t r = 0; r < n; r++) { if (d.mb_base) mem_verbose_read<true>(d, p, b, r, g_vb); else mem_verbose_read<false>(d, p, b, r, g_vb); }
   // k_mem_locate (capi.hip): behind the main, the second and the retry search
   const bool locate_pass = true;
   // (indexes without the row -> sequence table are located by teams of lanes on the device: k_mem_locate_wide / _team; here a

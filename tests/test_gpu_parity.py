@@ -217,17 +217,21 @@ def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
         api.Index(bad)
 
 
-@pytest.mark.parametrize("mode,seg", CASES)
-def test_verbose_columns(gpu_lib, golden, gidx, mode, seg):
-    """kaiju -v columns 6 (accessions) and 7 (matched peptides) == the reference's lines, single and paired"""
+@pytest.mark.parametrize("mode,seg,lane", [(m, s, "default") for m, s in CASES] + [("mem", 1, "v1"), ("mem", 0, "v1")])
+def test_verbose_columns(gpu_lib, golden, gidx, mode, seg, lane, monkeypatch):
+    """kaiju -v columns 6 (accessions) and 7 (matched peptides) == the reference's lines, single and paired.  MEM mode: from
+    the second-generation lanes (k_mem_vb + k_mem_verbose; default) and from the first-generation lanes
+    (KAIJU_GPU_VERBOSE_LANE=v1, read when the context is created); Greedy: the first-generation lanes either way"""
     api = gpu_lib
+    if lane == "v1":
+        monkeypatch.setenv("KAIJU_GPU_VERBOSE_LANE", "v1")
     clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
     tax = api.Taxonomy(golden.nodes)
     for seqs, off, names, pe, tsv in ((golden.seqs, golden.off, golden.names, False, f"ref_{mode}_{seg}.tsv"),
                                       (golden.pseqs, golden.poff, golden.pnames, True, f"ref_{mode}_{seg}_pe.tsv")):
         hits, accs, peps = clf.classify_verbose(seqs, off, paired=pe)
         plain = clf.classify(seqs, off, paired=pe)
-        assert all(util.same_hit(a, b) for a, b in zip(plain, hits))          # first-generation lanes == default lanes
+        assert all(util.same_hit(a, b) for a, b in zip(plain, hits))          # the verbose pass == the plain one
         res = clf.finalize(tax, hits, off, pe)
         lines = {}
         with open(os.path.join(golden.dir, tsv)) as f:

@@ -310,14 +310,23 @@ def test_long_reads(oracle, emu, handles, mode):
         assert not bad, (mode, seg, bad[:5], len(reads[bad[0]]))
 
 
-@pytest.mark.parametrize("mode", ["mem", "greedy"])
-def test_verbose_columns(emu, golden, handles, mode):
-    """columns 6 (accessions) and 7 (matched peptides) of kaiju -v from the first-generation lanes == the
-    reference's lines (single and paired, SEG on and off)"""
+@pytest.mark.parametrize("mode,lanes", [("mem", "v2"), ("mem", "v1"), ("mem", "wide16"), ("mem", "wide19-walk"), ("greedy", "v1")])
+def test_verbose_columns(emu, golden, handles, mode, lanes, monkeypatch):
+    """columns 6 (accessions) and 7 (matched peptides) of kaiju -v == the reference's lines (single and paired, SEG on and
+    off).  MEM: from the VERBOSE instantiation of the second-generation lanes + mem_verbose_read (v2; wide*: the same with
+    64-bit positions forced on the golden index) and from the first-generation lanes (v1: what the retry and exact passes
+    still run); Greedy: the first-generation lanes"""
     import ctypes as C
     import os
     from kaiju_amd import api
     h = handles[0]
+    if lanes == "v1" and mode == "mem":
+        monkeypatch.setenv("KAIJU_EMU_VERBOSE_V1", "1")
+    if lanes.startswith("wide"):
+        monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", lanes[4:6])
+        if lanes.endswith("walk"):
+            monkeypatch.setenv("KAIJU_EMU_NO_ROW_TAX", "1")
+        h = emu.load(golden.fmi)
     E = emu.lib
     E.emu_set_verbose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     E.emu_seq_name.restype = C.c_char_p
