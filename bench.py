@@ -511,6 +511,59 @@ def host_buffers_leg(index, dtax, reads, Lm, seg, dev, calls=4, chunk=2_500_000,
                            "never the headline value"}
 
 
+def verbose_leg(index, reads, Lm, seg, W, n=400_000, calls=3):
+    """kaiju -v in MEM mode through the entry point a host caller uses (kaiju_gpu_classify_batch_verbose: host buffers in; 184-byte
+    records, accessions and the matched peptides out - PCIe inclusive, never the headline value), next to the plain call on the
+    same reads (kaiju_gpu_classify_batch), and columns 4 - 7 of its reads against the lines of the reference's -v run that the
+    headline's CPU baseline left behind (ConsumerThread.cpp:614-623: match length, ids, accessions, peptides)"""
+    n = min(n, len(reads))
+    rd = np.ascontiguousarray(reads[:n, :Lm])
+    seqs = rd.reshape(-1)
+    off = offsets(n, Lm, Lm, False)
+    clf = api.Classifier(index, api.default_params("mem", seg=seg))
+    try:
+        hits, v, text, stride = clf.classify_verbose_raw(seqs, off)          # (warm-up: the context's buffers)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            hits, v, text, stride = clf.classify_verbose_raw(seqs, off)
+        el = (time.perf_counter() - t0) / calls
+        clf.classify(seqs, off)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            plain = clf.classify(seqs, off)
+        elp = (time.perf_counter() - t0) / calls
+        out = {"value": n / el, "unit": "reads/s", "reads_per_call": n, "calls": calls, "plain_call_reads_per_s": n / elp,
+               "cost_over_plain_call": round(el / elp, 3), "records_equal_plain_call": bool((hits == plain).all()),
+               "entry_point": "kaiju_gpu_classify_batch_verbose (pageable host buffers in; records, accessions and peptides out; blocking) "
+                              "against kaiju_gpu_classify_batch on the same reads; MEM mode: k_mem_vb + k_mem_verbose + k_vb_pack",
+               "parity": None}
+        refv = f"{W}/cpu_mem_out_v.tsv"
+        if os.path.exists(refv):
+            accs, peps = clf.verbose_columns(v, text, stride)
+            checked = bad = 0
+            first_bad = None
+            with open(refv) as f:
+                for line in f:
+                    c = line.rstrip("\n").split("\t")
+                    r = int(c[1][1:])
+                    if r >= n:
+                        continue
+                    if c[0] != "C":
+                        continue                               # (U lines have no columns 4 - 7; C/U itself is the headline's parity)
+                    checked += 1
+                    h = hits[r]
+                    ids = "".join(f"{int(x)}," for x in sorted(int(t) for t in h["taxid"][:int(h["n_ids"])]))
+                    ok = (len(c) >= 7 and int(c[3]) == int(h["best"]) and c[4] == ids and c[5] == "".join(a + "," for a in accs[r]) and c[6] == peps[r])
+                    if not ok:
+                        bad += 1
+                        first_bad = first_bad or (c[1], c[3:], int(h["best"]), accs[r], peps[r])
+            out["parity"] = {"checked": checked, "mismatches": bad, "first": repr(first_bad)[:300] if first_bad else None,
+                             "against": "columns 4 - 7 of the reference binary's -v lines for the same reads (classified reads)"}
+        return out
+    finally:
+        clf.close()
+
+
 def load_traffic(mode, paired, seg, nseq, per_launch, leg=None):
     """HBM bytes per launch of the leg's search kernel from the committed PMC passes (profiles/traffic.json); records of the
     legs other than headline / greedy / paired carry the leg's name (tests/tools/pmc_legs.sh)"""
@@ -557,7 +610,7 @@ def _sig(x, digits=5):
     return x
 
 
-LEG_NAMES = ("greedy", "paired", "hard", "hard_greedy", "wide", "wide_greedy", "long", "protein", "host_buffers")
+LEG_NAMES = ("greedy", "paired", "hard", "hard_greedy", "wide", "wide_greedy", "long", "protein", "host_buffers", "verbose")
 
 
 def summary_line(result: dict, detail_path) -> str:
@@ -652,8 +705,9 @@ def main():
                     help="mode of the headline leg (the metric of BASELINE.json is quoted on mem)")
     ap.add_argument("--no-seg", action="store_true")
     ap.add_argument("--paired", action="store_true", help="headline leg on 2 x 150-bp pairs instead of single reads")
-    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host,hard,wide,long,protein"),
-                    help="further legs in the same line: greedy, paired, host, hard, wide, long, protein (comma separated; '' = none).  long / "
+    ap.add_argument("--legs", default=os.environ.get("KAIJU_BENCH_LEGS", "greedy,paired,host,hard,wide,long,protein,verbose"),
+                    help="further legs in the same line: greedy, paired, host, hard, wide, long, protein, verbose (comma separated; '' = none).  verbose: "
+                         "kaiju -v in MEM mode through the host entry point, 400 000 reads, columns 4 - 7 against the reference's -v lines.  long / "
                          "protein: what users also feed it - 250-bp reads and protein reads (kaiju -p), MEM, --other-reads per step.  hard: MEM and Greedy on "
                          "a database that is NOT i.i.d. (synth.make_db_hard: families of 50-500 near-identical proteins, low-complexity "
                          "inserts; reads with Ns) - retries, inexact reads and the rate next to the i.i.d. legs.  wide: MEM and Greedy on "
@@ -1097,6 +1151,15 @@ def main():
             result[nm] = lr
     if host is not None:
         result["host_buffers"] = host
+    if "verbose" in legs_wanted and world == 1 and args.mode == "mem" and not args.paired and not big_db:
+        try:
+            vl = verbose_leg(index, reads, Lm, seg, W)
+            result["verbose"] = vl
+            log(rank, f"leg verbose: {vl['value']/1e6:.1f} M reads/s ({vl['cost_over_plain_call']} x the plain host call), parity {vl['parity']}")
+            if vl.get("parity"):
+                parity["verbose"] = {"checked": vl["parity"]["checked"], "mismatches": vl["parity"]["mismatches"]}
+        except Exception as e:  # noqa: BLE001
+            log(rank, "verbose leg failed:", repr(e))
     if per_rank_parity is not None:
         parity["per_rank"] = per_rank_parity
         result["parity"] = parity

@@ -327,6 +327,39 @@ class Classifier:
         _check(lib().kaiju_gpu_classify_batch_device_compact(self._h, dtax._h, d_seqs_ptr, seq_bytes, d_off_ptr, n,
                                                              1 if paired else 0, d_hits_ptr, d_out_ptr, stream))
 
+    def classify_verbose_raw(self, seqs: np.ndarray, off: np.ndarray, paired=False):
+        """kaiju -v, the library call alone (kaiju_gpu_classify_batch_verbose): (hit records, kaiju_gpu_verbose records, the rows
+        of column-7 text, their stride); the output arrays are kept between calls of the same size"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = (len(off) - 1) // 2
+        maxpair = int((off[2::2] - off[0:-1:2]).max()) if n else 0
+        lib().kaiju_gpu_verbose_text_stride.restype = C.c_uint32
+        lib().kaiju_gpu_verbose_text_stride.argtypes = [C.c_uint32, C.c_int]
+        stride = int(lib().kaiju_gpu_verbose_text_stride(maxpair, int(self.params.input_is_protein)))
+        kept = getattr(self, "_vb_out", None)
+        if kept is None or kept[0] != (n, stride):
+            kept = ((n, stride), np.zeros(n, dtype=HIT_DTYPE), np.zeros(n, dtype=VERBOSE_DTYPE), np.zeros(n * stride, dtype=np.uint8))
+            self._vb_out = kept
+        _, hits, v, text = kept
+        _check(lib().kaiju_gpu_classify_batch_verbose(self._h, seqs.ctypes.data, off.ctypes.data, n, 1 if paired else 0,
+                                                      hits.ctypes.data, v.ctypes.data, text.ctypes.data, stride))
+        return hits, v, text, stride
+
+    def verbose_columns(self, v, text, stride):
+        """(per read the sorted accession list of column 6, the text of column 7) from what classify_verbose_raw returned"""
+        n = len(v)
+        accs, peps = [], []
+        for r in range(n):
+            names = set()
+            for q in range(int(v[r]["n_acc"])):
+                nm = lib().kaiju_gpu_index_seq_name(self.index._h, int(v[r]["acc_iseq"][q]))
+                if nm and b"_" in nm:
+                    names.add(nm[: nm.rindex(b"_")].decode())
+            accs.append(sorted(names))
+            peps.append(bytes(text[r * stride: r * stride + int(v[r]["text_len"])]).decode())
+        return accs, peps
+
     def classify_verbose(self, seqs: np.ndarray, off: np.ndarray, paired=False):
         """kaiju -v: (hit records, per read the sorted accession list of column 6, the text of column 7)"""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)

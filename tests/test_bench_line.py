@@ -42,6 +42,7 @@ def test_summary_line_survives_infinities_long_strings_and_eight_ranks():
     full["config"]["workload"] = "x" * 5000
     full["cpu_baseline"]["sample"] = "y" * 5000
     full["n_gpus"] = 8
+    full["verbose"] = {"value": 2.5e6, "unit": "reads/s", "parity": {"checked": 280000, "mismatches": 0}}     # (round 6's leg)
     full["config"]["per_rank_units_per_s"] = [3.9e8 + k for k in range(8)]
     line = bench.summary_line(full, None)
     assert len(line) < 4096
@@ -49,6 +50,7 @@ def test_summary_line_survives_infinities_long_strings_and_eight_ranks():
     assert "Infinity" not in line and "NaN" not in line
     assert d["roofline"]["achieved"] is None and d["roofline"]["frac"] is None
     assert len(d["config"]["per_rank_units_per_s"]) == 8
+    assert d["legs"]["verbose"]["value"] == 2.5e6
 
 
 def test_detail_file_holds_the_full_structure(tmp_path, capsys):
