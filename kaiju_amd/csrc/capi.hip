@@ -1868,6 +1868,8 @@ struct kaiju_gpu_ctx {
   bool greedy3 = false;            // KAIJU_GPU_GREEDY_LANE=v3: the row-pool lane (kj_greedy3.h; narrow index with k-mer lines)
   uint32_t g3_split = 1;           // KAIJU_GPU_G3_SPLIT
   uint32_t g3_threads = 512;       // KAIJU_GPU_G3_THREADS (a multiple of 64)
+  uint32_t g1_pool = 192, g1_match = 64;   // first-generation Greedy lanes: queue slots and match records per lane of the main pass
+  bool g1_pool_set = false;                // (KAIJU_GPU_G1_POOL given: also for -v)
   uint32_t greedy_gate = 1u | 32u << 8;   // heavy iteration every 2nd, or as soon as half the wavefront waits for one (measured: r02_gprof; round 3,
                                            // with the span rule and the probes thinning the fast iterations: every 2nd beats every 4th, profiles/r03_l14)
   bool verbose = false;            // kaiju_gpu_classify_batch_verbose: first-generation lanes + columns 6/7
@@ -2003,6 +2005,11 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
   if (const char *e = getenv("KAIJU_GPU_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }
   c->blocks_main = c->n_cu * occ;
   c->blocks_retry = p->mode == 0 ? 16 : 4;
+  // (measurement knobs of the first-generation Greedy lanes, which serve -v: queue slots / match records per lane in the main
+  //  pass, blocks of the retry pass - its lanes own 65535 slots each, 5.4 MB)
+  if (const char *e = getenv("KAIJU_GPU_G1_POOL")) { int v = atoi(e); if (v >= 64 && v <= 65535) { c->g1_pool = (uint32_t)v; c->g1_pool_set = true; } }
+  if (const char *e = getenv("KAIJU_GPU_G1_MATCH")) { int v = atoi(e); if (v >= 16 && v <= 65535) c->g1_match = (uint32_t)v; }
+  if (const char *e = getenv("KAIJU_GPU_RETRY_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 256) c->blocks_retry = v; }
   KJ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto &e : c->ev) KJ_HIP(hipEventCreate(&e));
   *out = c.release();
@@ -2279,7 +2286,10 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
   } else {
     const uint32_t frag_max = max_read_len / 3 + 4;
     GreedyArrays ga;
-    ga.pool_cap = 192; ga.match_cap = 64;
+    // (-v: 512 slots.  With 192, 54 of 250 000 benchmark reads ran out of slots and went to the retry pass - whose few lanes
+    //  then worked 180 ms on them, next to 100 ms for everything else: profiles/r06_l41/g1_probe.txt.  82 bytes a slot:
+    //  11 GB of scratch for a -v run in Greedy mode instead of 4)
+    ga.pool_cap = (c->verbose && !c->g1_pool_set) ? std::max<uint32_t>(c->g1_pool, 512u) : c->g1_pool; ga.match_cap = c->g1_match;
     const bool use_g2 = c->greedy2 && !c->verbose;
     const bool use_g3 = use_g2 && c->greedy3;
     // (the row-pool lane: one block per CU, kG3Pool rows each - its scratch in device memory is per ROW)

@@ -217,7 +217,7 @@ def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
         api.Index(bad)
 
 
-@pytest.mark.parametrize("mode,seg,lane", [(m, s, "default") for m, s in CASES] + [("mem", 1, "v1"), ("mem", 0, "v1")])
+@pytest.mark.parametrize("mode,seg,lane", [(m, s, "default") for m, s in CASES] + [("mem", 1, "v1"), ("mem", 0, "v1"), ("greedy", 1, "pool64")])
 def test_verbose_columns(gpu_lib, golden, gidx, mode, seg, lane, monkeypatch):
     """kaiju -v columns 6 (accessions) and 7 (matched peptides) == the reference's lines, single and paired.  MEM mode: from
     the second-generation lanes (k_mem_vb + k_mem_verbose; default) and from the first-generation lanes
@@ -225,6 +225,8 @@ def test_verbose_columns(gpu_lib, golden, gidx, mode, seg, lane, monkeypatch):
     api = gpu_lib
     if lane == "v1":
         monkeypatch.setenv("KAIJU_GPU_VERBOSE_LANE", "v1")
+    if lane == "pool64":                 # (-v runs the Greedy main pass with 512 queue slots per lane: 64 sends reads to the retry pass)
+        monkeypatch.setenv("KAIJU_GPU_G1_POOL", "64")
     clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
     tax = api.Taxonomy(golden.nodes)
     for seqs, off, names, pe, tsv in ((golden.seqs, golden.off, golden.names, False, f"ref_{mode}_{seg}.tsv"),
