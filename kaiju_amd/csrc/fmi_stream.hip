@@ -289,8 +289,8 @@ int fmi_stream_to_device(const FmiStreamSource &src, const PackedIndex &pk, cons
   try {
     const uint64_t bwtlen = pk.bwtlen, nb64 = (bwtlen >> 6) + 1, n_sa = pk.n_sa;
     const bool wide = pk.wide;
-    const uint32_t mb_grp_shift = pk.mb_shift - kPackGroupSymShift;
     if (wide && (pk.mb_shift < kPackGroupSymShift + 1 || pk.mb_shift > 31)) { msg = "bad count-base shift"; return KAIJU_GPU_ERR_ARG; }
+    const uint32_t mb_grp_shift = wide ? pk.mb_shift - kPackGroupSymShift : 0u;      // (narrow: no count bases; the kernels still shift by it)
     if (src.nbytes < 1 || src.nbytes > 8 || src.pbits < 0 || src.pbits > 62) { msg = "bad suffix array coding"; return KAIJU_GPU_ERR_FORMAT; }
     // piece size: KAIJU_GPU_STREAM_PIECE_MB / _KB (tests), default 256 MB, never much more than half of the larger array (a
     // small index does not pay for page-locking memory it does not fill); a multiple of the group size, at most 1 GB
