@@ -257,10 +257,11 @@ uint64_t kaiju_taxonomy_lca(kaiju_taxonomy *t, const uint64_t *ids, uint32_t n);
 /* ConsumerThread.cpp:527-536 (Greedy), :614-623 (MEM), :820-824 (accessions).  Per read: the
    sequences whose names give the accession set of column 6 (first 20 distinct ones in the order the
    reference visits the rows; the caller prints the sorted set of kaiju_gpu_index_seq_name() prefixes
-   up to the last '_') and the text of column 7 ("PEPTIDE,PEPTIDE,").  MEM mode: the search kernels of
-   the default path in an instantiation that notes where every match lies in its read, and a pass over
-   the records in front of the locate (k_mem_vb / k_mem_wide2_vb, k_mem_verbose); Greedy mode: the
-   first-generation search kernels (a few times slower than the default path). */
+   up to the last '_') and the text of column 7 ("PEPTIDE,PEPTIDE,").  The search kernels of the
+   default path in instantiations that note where every match lies in its read (MEM: k_mem_vb /
+   k_mem_wide2_vb) or keep, per best match, its place and the substitutions of its variant (Greedy:
+   k_greedy2_vb / k_greedy2_wide_vb), and a pass over the records in front of the locate
+   (k_mem_verbose).  Reads that take the retry pass or the exact pass: first-generation kernels. */
 #define KAIJU_GPU_MAX_ACC 20
 typedef struct {
   uint32_t n_acc;

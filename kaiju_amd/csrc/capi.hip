@@ -30,6 +30,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
 
 #include "../../include/kaiju_gpu.h"
 #include "fmi_stream.h"
@@ -553,11 +554,11 @@ k_mem_wide2_vb(DevIndex ix, Params p, Batch b, WorkList wl, SIEntry *si_all, uin
   if (p.flags & kParamXOrder) mem_lane2<true, true, false, true>(ix, p, b, wl, ls);
   else mem_lane2<true, false, false, true>(ix, p, b, wl, ls);
 }
-template <bool WIDE>
+template <bool WIDE, bool TEXT = true>
 __global__ void __launch_bounds__(256)
 k_mem_verbose(DevIndex ix, Params p, Batch b, VerboseOut vb) {
   const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  if (r < b.n_reads) mem_verbose_read<WIDE>(ix, p, b, r, vb);
+  if (r < b.n_reads) mem_verbose_read<WIDE, TEXT>(ix, p, b, r, vb);
 }
 // Column 7 on its way to the host: the lanes write a read's peptides as index-alphabet codes into its own row of text_cap bytes
 // (1 KB per 150-bp read, of which a classified read uses ~40).  This pass turns the codes into letters and packs the rows of all
@@ -657,9 +658,11 @@ struct GreedyArrays2 {
   u128 *pool; uint32_t *prio_ext; GMatch2 *matches; uint16_t *mq_ext; GBest2 *best;
   uint32_t gate;
   GBest2W *bestw;                // wide indexes: best is nullptr then
+  GBestV *bestv;                 // kaiju -v (k_greedy2_vb / k_greedy2_wide_vb): 64 per lane; else nullptr
+  VerboseOut vb;
 };
 constexpr size_t kGreedy2Lds = (size_t)kBlock * (kGWinStride + kGMqStride + kGPrioStride + kGSubStride) * 4 + sizeof(ConstTables);
-template <bool COUNT, bool WIDE>
+template <bool COUNT, bool WIDE, bool VERBOSE = false>
 __device__ __forceinline__ void greedy2_body(const DevIndex &ix, const ConstTables *__restrict__ g_ct, const Params &p, const SegQueue &sq,
                                              const Batch &b, const WorkList &wl, const GreedyArrays2 &ga) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -688,7 +691,8 @@ __device__ __forceinline__ void greedy2_body(const DevIndex &ix, const ConstTabl
     if ((threadIdx.x & 63) == 0) { gs.prof[0] = __builtin_readcyclecounter(); gs.prof[1] = PS_HEAD; }
   }
 #endif
-  greedy_lane2<COUNT, WIDE>(ix, s_ct, p, sq, b, wl, gs);
+  if constexpr (VERBOSE) { gs.bestv = ga.bestv; gs.vb = ga.vb; }
+  greedy_lane2<COUNT, WIDE, VERBOSE>(ix, s_ct, p, sq, b, wl, gs);
 }
 __global__ void __launch_bounds__(kBlock, kGreedyWavesPerSimd)
 k_greedy2(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
@@ -709,6 +713,17 @@ k_greedy2_wide(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQ
 __global__ void __launch_bounds__(kBlock, 1)
 k_greedy2_wide_count(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
   greedy2_body<true, true>(ix, g_ct, p, sq, b, wl, ga);
+}
+
+// kaiju -v in Greedy mode: the same lanes keeping, per best match, where its peptide comes from (kj_core.h: VERBOSE, GBestV) and
+// writing column 7 when a read is through; column 6 follows from the records (k_mem_verbose<.., false>, in front of the locate)
+__global__ void __launch_bounds__(kBlock, 2)
+k_greedy2_vb(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+  greedy2_body<false, false, true>(ix, g_ct, p, sq, b, wl, ga);
+}
+__global__ void __launch_bounds__(kBlock, 2)
+k_greedy2_wide_vb(DevIndex ix, const ConstTables *__restrict__ g_ct, Params p, SegQueue sq, Batch b, WorkList wl, GreedyArrays2 ga) {
+  greedy2_body<false, true, true>(ix, g_ct, p, sq, b, wl, ga);
 }
 
 #ifdef KJ_GREEDY3
@@ -1876,7 +1891,7 @@ struct kaiju_gpu_ctx {
   bool exact_pass = true;          // KAIJU_GPU_EXACT_PASS=0 switches the exact pass off (its reads stay flagged)
   bool count_ops = false;          // kaiju_gpu_set_count_ops: the main pass runs the counting instantiation of its lane
   bool mem_v1 = false;             // KAIJU_GPU_MEM_LANE=v1 (read once, at context creation)
-  bool verbose_v1 = false;         // KAIJU_GPU_VERBOSE_LANE=v1: -v in MEM mode from the first-generation lanes (until round 6 the only way; A/B)
+  bool verbose_v1 = false;         // KAIJU_GPU_VERBOSE_LANE=v1: -v from the first-generation lanes (until round 6 the only way; A/B)
   bool stage1_old = false;         // KAIJU_GPU_STAGE1=old: build_fragments for every read length (A/B measurements)
   bool lazy_seg = true;            // KAIJU_GPU_LAZY_SEG=0: SEG pass over every flagged fragment in MEM mode too
   DevBuf seglist, loc_list, todo_list;
@@ -1996,6 +2011,8 @@ extern "C" int kaiju_gpu_create(kaiju_gpu_ctx **out, const kaiju_gpu_index *ix, 
                                  (int)kGreedy2Lds));
       KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2_wide_count), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)kGreedy2Lds));
+      KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2_vb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGreedy2Lds));
+      KJ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_greedy2_wide_vb), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGreedy2Lds));
       if (g_wide) KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy2_wide, kBlock, kGreedy2Lds));
       else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy2, kBlock, kGreedy2Lds));
     } else KJ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_greedy, kBlock, 0));
@@ -2033,6 +2050,16 @@ static void launch_seg(const kaiju_gpu_ctx *c, hipStream_t s, const Params &p, c
     default: hipLaunchKernelGGL(k_seg, grid, blk, 0, s, p, st, b, sq); break;
   }
 }
+// KAIJU_GPU_CALL_TIMES=1: host-side marks of a classification call on stderr (ms since the first mark; which thread) - where a
+// call's wall time goes when it is not in the kernels (allocations of a context's first call, copies, waits)
+static void call_mark(const char *what) {
+  static const bool on = getenv("KAIJU_GPU_CALL_TIMES") != nullptr;
+  if (!on) return;
+  static const auto t0 = std::chrono::steady_clock::now();
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  fprintf(stderr, "[call %8.1f ms, thread %04x] %s\n", ms, (unsigned)(std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xffffu), what);
+}
+
 static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes, const uint64_t *d_off,
                         uint32_t n, int paired, uint32_t max_read_len, kaiju_gpu_hit *d_out, hipStream_t s,
                         const kaiju_gpu_taxonomy *tax = nullptr, kaiju_gpu_compact *d_compact = nullptr) {
@@ -2047,6 +2074,7 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     max_read_len *= 3;
   }
   const uint64_t max_pair = (uint64_t)max_read_len * (paired ? 2 : 1);
+  call_mark("launch_batch: begin");
   // stage buffers
   const uint64_t pep_bytes = 2 * seq_bytes + kPepPerRead * n + 32 + 256;   // pep_base() + window over-read slack
   const uint64_t n_frag_slots = 2 * ((2 * seq_bytes) / (p.m + 1) + 7ull * n) + 8;
@@ -2290,8 +2318,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
     //  then worked 180 ms on them, next to 100 ms for everything else: profiles/r06_l41/g1_probe.txt.  82 bytes a slot:
     //  11 GB of scratch for a -v run in Greedy mode instead of 4)
     ga.pool_cap = (c->verbose && !c->g1_pool_set) ? std::max<uint32_t>(c->g1_pool, 512u) : c->g1_pool; ga.match_cap = c->g1_match;
-    const bool use_g2 = c->greedy2 && !c->verbose;
-    const bool use_g3 = use_g2 && c->greedy3;
+    // (-v: the VERBOSE instantiation of the second-generation lane unless KAIJU_GPU_VERBOSE_LANE=v1 - fragment positions must fit
+    //  the 16 bits of a GBestV's substitution positions, as in the lane itself)
+    const bool vb_g2 = c->verbose && !c->verbose_v1 && max_read_len / 3 + 4 < 65536;
+    const bool use_g2 = c->greedy2 && (!c->verbose || vb_g2);
+    const bool use_g3 = use_g2 && c->greedy3 && !c->verbose;
     // (the row-pool lane: one block per CU, kG3Pool rows each - its scratch in device memory is per ROW)
 #ifdef KJ_GREEDY3
     const uint64_t lanes_g2 = use_g3 ? (uint64_t)c->n_cu * kG3Pool : lanes_main;
@@ -2340,7 +2371,13 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       g2.best = g_wide ? nullptr : static_cast<GBest2 *>(c->scratch_main[9].p);
       g2.bestw = g_wide ? static_cast<GBest2W *>(c->scratch_main[9].p) : nullptr;
       g2.gate = c->greedy_gate;
+      g2.bestv = nullptr; g2.vb = vb;
+      if (c->verbose) {
+        if ((rc = ensure(c->vb_bestv, lanes_g2 * 64 * sizeof(GBestV)))) return rc;
+        g2.bestv = static_cast<GBestV *>(c->vb_bestv.p);
+      }
     }
+    call_mark("launch_batch: Greedy scratch in place");
     if (n > 0) {
       Params pg = p;
       if (use_g2) pg.flags |= kParamDeferLocate;       // (greedy_lane2 leaves every read's best matches to k_mem_locate*)
@@ -2352,7 +2389,11 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
         hipLaunchKernelGGL(k_greedy3, dim3(c->n_cu), dim3(c->g3_threads), 0, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2, c->g3_split);
       else
 #endif
-      if (use_g2 && c->count_ops && g_wide)
+      if (use_g2 && c->verbose && g_wide)
+        hipLaunchKernelGGL(k_greedy2_wide_vb, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
+      else if (use_g2 && c->verbose)
+        hipLaunchKernelGGL(k_greedy2_vb, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
+      else if (use_g2 && c->count_ops && g_wide)
         hipLaunchKernelGGL(k_greedy2_wide_count, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
       else if (use_g2 && g_wide)
         hipLaunchKernelGGL(k_greedy2_wide, dim3(c->blocks_main), blk, kGreedy2Lds, s, ix->dev, ix->d_ct, pg, sq, b, wl_main, g2);
@@ -2366,6 +2407,12 @@ static int launch_batch(kaiju_gpu_ctx *c, const void *d_seqs, uint64_t seq_bytes
       KJ_HIP(hipEventRecord(c->ev[3], s));
       hipLaunchKernelGGL(k_greedy_retry, dim3(c->blocks_retry), blk, 0, s, ix->dev, ix->d_ct, p, sq, b, wl_retry, gr, vb);
       KJ_HIP(hipGetLastError());
+      if ((pg.flags & kParamDeferLocate) && c->verbose) {
+        // column 6 of the reads whose best matches wait in their records (the retry pass above wrote its reads' own columns)
+        if (g_wide) hipLaunchKernelGGL((k_mem_verbose<true, false>), grid_reads, dim3(256), 0, s, ix->dev, p, b, vb);
+        else hipLaunchKernelGGL((k_mem_verbose<false, false>), grid_reads, dim3(256), 0, s, ix->dev, p, b, vb);
+        KJ_HIP(hipGetLastError());
+      }
       if (pg.flags & kParamDeferLocate) {
         if (g_wide && ix->dev.row_tax) {
           hipLaunchKernelGGL(k_mem_locate<true>, grid_reads, dim3(256), 0, s, ix->dev, p, b, loc_list, cnt + 25);
@@ -2554,6 +2601,7 @@ static int verbose_core(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *of
   int rc = classify_host_buffers(ctx, seqs, off, n_reads, paired);
   ctx->verbose = false;
   if (rc) return rc;
+  call_mark("verbose: launch_batch returned");
   hipStream_t s = ctx->stream;
   // column 7: letters, packed on the device (k_vb_pack) - the rows of text_cap bytes stay there
   const char *alpha = ctx->ix->info.alphabet;
@@ -2578,7 +2626,9 @@ static int verbose_core(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *of
   KJ_HIP(hipMemcpyAsync(tlen.data(), ctx->vb_tlen.p, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
   KJ_HIP(hipMemcpyAsync(acc.data(), ctx->vb_acc.p, (size_t)n_reads * kVbAcc * 4, hipMemcpyDeviceToHost, s));
   KJ_HIP(hipMemcpyAsync(pos.data(), ctx->vb_pos.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+  call_mark("verbose: everything queued");
   KJ_HIP(hipStreamSynchronize(s));
+  call_mark("verbose: stream drained (records, accessions, positions on the host)");
   const uint64_t total = pos[n_reads];
   if (total > (uint64_t)n_reads * ctx->vb_text_cap) return fail(KAIJU_GPU_ERR_HIP, "k_vb_pack: impossible total");
   if (ctx->vb_host.size() < total) ctx->vb_host.resize((size_t)total);
@@ -2594,8 +2644,8 @@ static int verbose_core(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *of
 }
 
 // Verbose classification (the reference's -v): hit records plus, per read, the sequences that give
-// column 6 and the text of column 7.  MEM mode: the second-generation lanes (k_mem_vb / k_mem_wide2_vb + k_mem_verbose);
-// Greedy mode, the retry pass and the exact pass: the first-generation lanes.
+// column 6 and the text of column 7.  The second-generation lanes (MEM: k_mem_vb / k_mem_wide2_vb, Greedy: k_greedy2_vb /
+// k_greedy2_wide_vb; + k_mem_verbose); the retry pass and the exact pass: the first-generation lanes.
 extern "C" int kaiju_gpu_classify_batch_verbose(kaiju_gpu_ctx *ctx, const char *seqs, const uint64_t *off, uint32_t n_reads,
                                                 int paired, kaiju_gpu_hit *out, kaiju_gpu_verbose *vout, char *text,
                                                 uint32_t text_stride) {

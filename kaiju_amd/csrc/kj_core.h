@@ -3116,27 +3116,33 @@ KJ_HD bool mem_locate_read(const DevIndex &ix, const Params &p, Hit *hit, uint32
 // of distinct taxon ids in front of every row (:805-807), get_suffix's walk for the sequence number (the row -> taxon table
 // does not know the sequence), the name noted before the id is (:822-824, :834).  One lane per read: this is the verbose
 // path, a walk per row is what the reference pays too.
-template <bool WIDE>
+// TEXT = false: column 6 only - the reads of the VERBOSE Greedy lane (greedy_lane2), which writes column 7 itself: its record
+// holds the best matches in list order (eval_match_scores appends, ids_from_SI walks from the head), up to max_matches_SI = 20.
+template <bool WIDE, bool TEXT = true>
 KJ_HD void mem_verbose_read(const DevIndex &ix, const Params &p, const Batch &b, uint32_t r, const VerboseOut &vb) {
   typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
   const Hit *hit = b.hits + r;
   if (!(hit->flags & kHitLocPending) || !vb.n_acc) return;
-  const uint32_t nsi = hit->n_ids < (uint32_t)kVbMem ? hit->n_ids : (uint32_t)kVbMem;
-  const bool xo = (p.flags & kParamXOrder) != 0;
-  uint32_t where[kVbMem];
-  for (uint32_t q = 0; q < nsi; q++) where[q] = vb.acc[(size_t)r * kVbAcc + q];
-  vb.n_acc[r] = 0; vb.text_len[r] = 0;
-  const ReadMeta rm = b.meta[r];
-  const Frag *F = b.frags + rm.frag;
-  const uint8_t *pep = b.pep + rm.pep;
-  const uint32_t L = hit->best;
-  for (uint32_t gs = 0; gs < nsi;) {
-    const uint32_t fr = where[gs] >> 16;
-    uint32_t ge = gs + 1;
-    while (ge < nsi && (where[ge] >> 16) == fr) ge++;
-    vb_text(vb, r, pep + F[fr].start + (where[xo ? gs : ge - 1] & 0xffffu), L, 0, nullptr, nullptr, 0);
-    gs = ge;
+  const uint32_t ncap = TEXT ? (uint32_t)kVbMem : (uint32_t)kMaxIds;
+  const uint32_t nsi = hit->n_ids < ncap ? hit->n_ids : ncap;
+  if constexpr (TEXT) {
+    const bool xo = (p.flags & kParamXOrder) != 0;
+    uint32_t where[kVbMem];
+    for (uint32_t q = 0; q < nsi; q++) where[q] = vb.acc[(size_t)r * kVbAcc + q];
+    vb.text_len[r] = 0;
+    const ReadMeta rm = b.meta[r];
+    const Frag *F = b.frags + rm.frag;
+    const uint8_t *pep = b.pep + rm.pep;
+    const uint32_t L = hit->best;
+    for (uint32_t gs = 0; gs < nsi;) {
+      const uint32_t fr = where[gs] >> 16;
+      uint32_t ge = gs + 1;
+      while (ge < nsi && (where[ge] >> 16) == fr) ge++;
+      vb_text(vb, r, pep + F[fr].start + (where[xo ? gs : ge - 1] & 0xffffu), L, 0, nullptr, nullptr, 0);
+      gs = ge;
+    }
   }
+  vb.n_acc[r] = 0;
   const P check = (P)((1ull << ix.chpt_exp) - 1ull);
   const RankBlock64 *const blk0 = ix.blocks64;
   uint64_t ids[kMaxIds];
@@ -3897,6 +3903,10 @@ struct GreedyScratch2 {
   unsigned long long *prof;    // -DKJ_PROF: the wavefront's LDS row (2 + 3 * PS_N)
   uint32_t lane;               // the device-memory pointers above are the bases of all lanes, this is the lane's number
   uint32_t *sub;               // LDS, kGSubStride words: the substitutions of the variant at hand + slow-part state
+  // VERBOSE instantiation (kaiju -v): where the peptide of every best match comes from - base of all lanes, 64 per lane - and
+  // the reads' column-7 rows (the accessions of column 6 follow from the record: mem_verbose_read<.., false>)
+  GBestV *bestv = nullptr;
+  VerboseOut vb{nullptr, nullptr, nullptr, nullptr, 0};
 };
 
 #ifdef KJ_NO_CHAIN_PRUNE                            // (A/B measurements, tests: the lane that queues every variant)
@@ -4004,7 +4014,7 @@ enum GFillRet : int { FR_START_J, FR_STEP, FR_VARM };
 #else
 #define KJ_OVF(wl, why) ((void)0)
 #endif
-template <bool COUNT = false, bool WIDE = false>
+template <bool COUNT = false, bool WIDE = false, bool VERBOSE = false>
 KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params &p, const SegQueue &sq,
                         const Batch &b, const WorkList &wl, const GreedyScratch2 &gs) {
   typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type P;
@@ -4155,6 +4165,17 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
     if (score > best) { best = score; nbest = 0; }
     if (score == best) {
       if (nbest < p.max_matches_SI && nbest < 64) {
+        if constexpr (VERBOSE) {
+          // what frag->seq.substr(qi, ql) will need (ConsumerThread.cpp:783, :789): the item's place in the read, the match's in
+          // the item, the substitutions the variant carries (positions relative to the item's start)
+          GBestV bv; bv.start = t_start; bv.qi = m_qi; bv.ql = m_ql; bv.num_mm = t_nmm;
+          for (uint32_t x = 0; x < (uint32_t)kMaxMismatch; x++) {
+            const uint32_t pw = x < 2 ? sp0 : x < 4 ? sp1 : x < 6 ? sp2 : sp3;
+            bv.sub_pos[x] = (uint16_t)((pw >> ((x & 1u) * 16u)) & 0xffffu);
+            bv.sub_aa[x] = (uint8_t)((x < 4 ? sa0 : sa1) >> ((x & 3u) * 8u));
+          }
+          gs.bestv[(size_t)gs.lane * 64 + nbest] = bv;
+        }
         if constexpr (WIDE) { GBest2W gb; gb.lo = m_lo; gb.len = m_len; gb.pad = 0; GS_BESTW[nbest] = gb; }
         else if (nbest == 0) { b0lo = (uint32_t)m_lo; b0len = m_len; }
         else { GBest2 gb; gb.lo = (uint32_t)m_lo; gb.len = m_len; GS_BEST[nbest] = gb; }
@@ -4416,6 +4437,15 @@ KJ_HD void greedy_lane2(const DevIndex &ix, const ConstTables &ct, const Params 
                 for (uint32_t q = 1; q < nbest; q++) { const GBest2 gb = GS_BEST[q]; KJ_G_HIT->taxid[q] = (uint64_t)gb.lo | (uint64_t)gb.len << 32; }
               }
               nids = nbest; flags |= kHitLocPending;
+              if constexpr (VERBOSE) {
+                // column 7: the peptide of every best match in list order with the variant's substitutions applied (:780-790)
+                vb_reset(gs.vb, r);
+                for (uint32_t x = 0; x < nbest; x++) {
+                  const GBestV bv = gs.bestv[(size_t)gs.lane * 64 + x];
+                  vb_text(gs.vb, r, b.pep + pepoff + bv.start + bv.qi, bv.ql, bv.num_mm < (uint32_t)kMaxMismatch ? bv.num_mm : (uint32_t)kMaxMismatch,
+                          bv.sub_pos, bv.sub_aa, (int)bv.qi);
+                }
+              }
             }
             bk = GB_DONE;
           }

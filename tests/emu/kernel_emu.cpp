@@ -334,7 +334,7 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
       const char *v = getenv("KAIJU_EMU_LANE");        // "v1" or default (v2 where possible)
       std::vector<GBestV> bestvv(64);
       gs.bestv = g_vb.n_acc ? bestvv.data() : nullptr;
-      if (d.blocks64 && (d.kline || (d.mb_base && d.kmer64)) && !v && pass == 0 && !g_vb.n_acc) {
+      if (d.blocks64 && (d.kline || (d.mb_base && d.kmer64)) && !v && pass == 0 && (!g_vb.n_acc || vb_v2)) {
         alignas(16) uint32_t lds_win[kGWinStride], lds_mq[kGMqStride], lds_prio[kGPrioStride];
         for (auto &x : lds_win) x = 0xdeadbeefu;
         for (auto &x : lds_mq) x = 0xdeadbeefu;
@@ -354,7 +354,11 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
         Params pg = p;
         pg.flags |= kParamDeferLocate;
         const char *g3e = getenv("KAIJU_EMU_GREEDY");       // "3": the row-pool lane (kj_greedy3.h; narrow indexes) - the product's KAIJU_GPU_GREEDY_LANE=v3
-        if (d.mb_base) greedy_lane2<false, true>(d, ix->ct, pg, sq, b, wl, g2);
+        std::vector<GBestV> bestv2(64);
+        if (vb_v2) { g2.bestv = bestv2.data(); g2.vb = g_vb; g2.lane = 0; }      // (k_greedy2_vb / k_greedy2_wide_vb)
+        if (vb_v2 && d.mb_base) greedy_lane2<false, true, true>(d, ix->ct, pg, sq, b, wl, g2);
+        else if (vb_v2) greedy_lane2<false, false, true>(d, ix->ct, pg, sq, b, wl, g2);
+        else if (d.mb_base) greedy_lane2<false, true>(d, ix->ct, pg, sq, b, wl, g2);
         else if (!(g3e && !strcmp(g3e, "3"))) greedy_lane2(d, ix->ct, pg, sq, b, wl, g2);
         else {
           // third generation (kj_greedy3.h): the read's state in a row of "LDS"; here a pool of one row
@@ -376,6 +380,8 @@ int emu_classify(void *h, const kaiju_gpu_params *gp, const char *seqs, const ui
   }
   // k_mem_verbose (capi.hip): columns 6 / 7 of the reads whose matches wait in their records, in front of the locate
   if (mem_v2 && vb_v2) for (uint32_t r = 0; r < n; r++) { if (d.mb_base) mem_verbose_read<true>(d, p, b, r, g_vb); else mem_verbose_read<false>(d, p, b, r, g_vb); }
+  // (Greedy: the VERBOSE lane wrote column 7 itself; column 6 from its records)
+  if (p.mode != 0 && vb_v2) for (uint32_t r = 0; r < n; r++) { if (d.mb_base) mem_verbose_read<true, false>(d, p, b, r, g_vb); else mem_verbose_read<false, false>(d, p, b, r, g_vb); }
   // k_mem_locate (capi.hip): behind the main, the second and the retry search
   const bool locate_pass = true;
   // (indexes without the row -> sequence table are located by teams of lanes on the device: k_mem_locate_wide / _team; here a

@@ -217,15 +217,15 @@ def test_index_image_loads_like_the_fmi(gpu_lib, golden, gidx, tmp_path):
         api.Index(bad)
 
 
-@pytest.mark.parametrize("mode,seg,lane", [(m, s, "default") for m, s in CASES] + [("mem", 1, "v1"), ("mem", 0, "v1"), ("greedy", 1, "pool64")])
+@pytest.mark.parametrize("mode,seg,lane", [(m, s, "default") for m, s in CASES] + [(m, s, "v1") for m, s in CASES] + [("greedy", 1, "v1pool64")])
 def test_verbose_columns(gpu_lib, golden, gidx, mode, seg, lane, monkeypatch):
-    """kaiju -v columns 6 (accessions) and 7 (matched peptides) == the reference's lines, single and paired.  MEM mode: from
-    the second-generation lanes (k_mem_vb + k_mem_verbose; default) and from the first-generation lanes
-    (KAIJU_GPU_VERBOSE_LANE=v1, read when the context is created); Greedy: the first-generation lanes either way"""
+    """kaiju -v columns 6 (accessions) and 7 (matched peptides) == the reference's lines, single and paired: from the
+    second-generation lanes (k_mem_vb / k_greedy2_vb + k_mem_verbose; default) and from the first-generation lanes
+    (KAIJU_GPU_VERBOSE_LANE=v1, read when the context is created), which the retry and exact passes still run"""
     api = gpu_lib
-    if lane == "v1":
+    if lane.startswith("v1"):
         monkeypatch.setenv("KAIJU_GPU_VERBOSE_LANE", "v1")
-    if lane == "pool64":                 # (-v runs the Greedy main pass with 512 queue slots per lane: 64 sends reads to the retry pass)
+    if lane == "v1pool64":               # (-v gives the first-generation Greedy main pass 512 queue slots per lane: 64 sends reads to the retry pass)
         monkeypatch.setenv("KAIJU_GPU_G1_POOL", "64")
     clf = api.Classifier(gidx, api.default_params(mode, seg=seg))
     tax = api.Taxonomy(golden.nodes)

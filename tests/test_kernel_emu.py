@@ -310,17 +310,18 @@ def test_long_reads(oracle, emu, handles, mode):
         assert not bad, (mode, seg, bad[:5], len(reads[bad[0]]))
 
 
-@pytest.mark.parametrize("mode,lanes", [("mem", "v2"), ("mem", "v1"), ("mem", "wide16"), ("mem", "wide19-walk"), ("greedy", "v1")])
+@pytest.mark.parametrize("mode,lanes", [("mem", "v2"), ("mem", "v1"), ("mem", "wide16"), ("mem", "wide19-walk"),
+                                        ("greedy", "v2"), ("greedy", "v1"), ("greedy", "wide16"), ("greedy", "wide19-walk")])
 def test_verbose_columns(emu, golden, handles, mode, lanes, monkeypatch):
     """columns 6 (accessions) and 7 (matched peptides) of kaiju -v == the reference's lines (single and paired, SEG on and
-    off).  MEM: from the VERBOSE instantiation of the second-generation lanes + mem_verbose_read (v2; wide*: the same with
+    off).  From the VERBOSE instantiations of the second-generation lanes + mem_verbose_read (v2; wide*: the same with
     64-bit positions forced on the golden index) and from the first-generation lanes (v1: what the retry and exact passes
-    still run); Greedy: the first-generation lanes"""
+    still run)"""
     import ctypes as C
     import os
     from kaiju_amd import api
     h = handles[0]
-    if lanes == "v1" and mode == "mem":
+    if lanes == "v1":
         monkeypatch.setenv("KAIJU_EMU_VERBOSE_V1", "1")
     if lanes.startswith("wide"):
         monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", lanes[4:6])

@@ -25,7 +25,7 @@ for mode in os.environ.get("VB_MODES", "mem,greedy").split(","):     # (VB_MODES
         subprocess.run([cli, "-t", f"{W}/nodes.dmp", "-f", f"{W}/db.fmi", "-i", fq, "-o", f"{W}/vg.tsv", "-a", mode, "-v"] + seg, check=True)
         tg = time.time() - t
         t1 = None
-        if mode == "mem":                                      # (the first-generation lanes, which wrote the columns until round 6)
+        if True:                                               # (the first-generation lanes, which wrote the columns until round 6)
             t = time.time()
             subprocess.run([cli, "-t", f"{W}/nodes.dmp", "-f", f"{W}/db.fmi", "-i", fq, "-o", f"{W}/vg1.tsv", "-a", mode, "-v"] + seg, check=True,
                            env=dict(os.environ, KAIJU_GPU_VERBOSE_LANE="v1"))

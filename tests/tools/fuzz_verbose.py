@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""kaiju -v in MEM mode, host emulation: columns 6 / 7 from the second-generation lanes (VERBOSE instantiation of mem_lane2 +
+"""kaiju -v (MEM and Greedy), host emulation: columns 6 / 7 from the second-generation lanes (VERBOSE instantiations of mem_lane2 / greedy_lane2 +
 mem_verbose_read) against the first-generation lanes' (pinned on the reference's lines by test_verbose_columns), on the
 random databases / reads / parameters of fuzz_emu.py.  Accessions compare as sets (the host sorts them), peptides byte for
 byte.  usage: fuzz_verbose.py [rounds] [seed] [first]; KAIJU_GPU_FORCE_WIDE=16 in the environment: the wide lanes;
@@ -68,9 +68,14 @@ def main(rounds=None, seed=None, first=None):
             paired = rng.random() < 0.4
             r2 = [fz.make_read(rng, seqs) for _ in range(n)] if paired else None
             sq, off = util.pack(r1, r2)
-            for seg in (0, 1):
-                m = int(rng.choice([7, 9, 11, 11, 15, 20]))
-                gp = util.gp("mem", m=m, seg=seg)
+            for seg, mode in ((0, "mem"), (1, "mem"), (int(rng.integers(0, 2)), "greedy"), (int(rng.integers(0, 2)), "greedy")):
+                if mode == "mem":
+                    m = int(rng.choice([7, 9, 11, 11, 15, 20]))
+                    gp = util.gp("mem", m=m, seg=seg)
+                else:
+                    m = int(rng.choice([9, 11, 11, 13]))
+                    gp = util.gp("greedy", m=m, mismatches=int(rng.choice([0, 1, 3, 3, 5])), min_score=int(rng.choice([30, 65, 65, 90])),
+                                 seed_length=int(rng.choice([7, 7, 8, 10])), seg=seg)
                 a = run(emu, h, gp, sq, off, paired, n, cap, v1=True)
                 b = run(emu, h, gp, sq, off, paired, n, cap, v1=False)
                 if a[0] is None or b[0] is None:
@@ -86,7 +91,7 @@ def main(rounds=None, seed=None, first=None):
                     #  - and the second-generation path - have pushed every fragment's peptide by then)
                     capped = int(a[0][r]["flags"]) & 0x1
                     if not ok or sa != sb or (ta != tb and not (capped and tb.startswith(ta))):
-                        print("MISMATCH round", rnd, "seed", seed, "seg", seg, "m", m, "paired", paired, "read", r, flush=True)
+                        print("MISMATCH round", rnd, "seed", seed, mode, "seg", seg, "m", m, "paired", paired, "read", r, flush=True)
                         print("  v1", a[0][r]["best"], sorted(sa), ta)
                         print("  v2", b[0][r]["best"], sorted(sb), tb)
                         print("  read", r1[r][:150])
