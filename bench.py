@@ -511,7 +511,7 @@ def host_buffers_leg(index, dtax, reads, Lm, seg, dev, calls=4, chunk=2_500_000,
                            "never the headline value"}
 
 
-def verbose_leg(index, reads, Lm, seg, W, n=400_000, calls=3):
+def verbose_leg(index, reads, Lm, seg, W, n=400_000, calls=3, mode="mem"):
     """kaiju -v in MEM mode through the entry point a host caller uses (kaiju_gpu_classify_batch_verbose: host buffers in; 184-byte
     records, accessions and the matched peptides out - PCIe inclusive, never the headline value), next to the plain call on the
     same reads (kaiju_gpu_classify_batch), and columns 4 - 7 of its reads against the lines of the reference's -v run that the
@@ -520,7 +520,7 @@ def verbose_leg(index, reads, Lm, seg, W, n=400_000, calls=3):
     rd = np.ascontiguousarray(reads[:n, :Lm])
     seqs = rd.reshape(-1)
     off = offsets(n, Lm, Lm, False)
-    clf = api.Classifier(index, api.default_params("mem", seg=seg))
+    clf = api.Classifier(index, api.default_params(mode, seg=seg))
     try:
         hits, v, text, stride = clf.classify_verbose_raw(seqs, off)          # (warm-up: the context's buffers)
         t0 = time.perf_counter()
@@ -535,9 +535,10 @@ def verbose_leg(index, reads, Lm, seg, W, n=400_000, calls=3):
         out = {"value": n / el, "unit": "reads/s", "reads_per_call": n, "calls": calls, "plain_call_reads_per_s": n / elp,
                "cost_over_plain_call": round(el / elp, 3), "records_equal_plain_call": bool((hits == plain).all()),
                "entry_point": "kaiju_gpu_classify_batch_verbose (pageable host buffers in; records, accessions and peptides out; blocking) "
-                              "against kaiju_gpu_classify_batch on the same reads; MEM mode: k_mem_vb + k_mem_verbose + k_vb_pack",
+                              "against kaiju_gpu_classify_batch on the same reads; " +
+                              ("MEM mode: k_mem_vb + k_mem_verbose + k_vb_pack" if mode == "mem" else "Greedy mode: k_greedy2_vb + k_mem_verbose<.., false> + k_vb_pack"),
                "parity": None}
-        refv = f"{W}/cpu_mem_out_v.tsv"
+        refv = f"{W}/cpu_{mode}_out_v.tsv"
         if os.path.exists(refv):
             accs, peps = clf.verbose_columns(v, text, stride)
             checked = bad = 0
@@ -553,6 +554,7 @@ def verbose_leg(index, reads, Lm, seg, W, n=400_000, calls=3):
                     checked += 1
                     h = hits[r]
                     ids = "".join(f"{int(x)}," for x in sorted(int(t) for t in h["taxid"][:int(h["n_ids"])]))
+                    # (Greedy: a read the reference classifies passed its E-value gate; the columns are those of its best matches either way)
                     ok = (len(c) >= 7 and int(c[3]) == int(h["best"]) and c[4] == ids and c[5] == "".join(a + "," for a in accs[r]) and c[6] == peps[r])
                     if not ok:
                         bad += 1
@@ -1158,6 +1160,12 @@ def main():
             log(rank, f"leg verbose: {vl['value']/1e6:.1f} M reads/s ({vl['cost_over_plain_call']} x the plain host call), parity {vl['parity']}")
             if vl.get("parity"):
                 parity["verbose"] = {"checked": vl["parity"]["checked"], "mismatches": vl["parity"]["mismatches"]}
+            if "greedy" in extra:                          # (the Greedy leg's CPU baseline left the reference's -v lines of its sample behind)
+                vg = verbose_leg(index, keep["greedy"][1], Lm, seg, W, mode="greedy")
+                vl["greedy"] = vg
+                log(rank, f"leg verbose, Greedy: {vg['value']/1e6:.1f} M reads/s ({vg['cost_over_plain_call']} x the plain host call), parity {vg['parity']}")
+                if vg.get("parity"):
+                    parity["verbose_greedy"] = {"checked": vg["parity"]["checked"], "mismatches": vg["parity"]["mismatches"]}
         except Exception as e:  # noqa: BLE001
             log(rank, "verbose leg failed:", repr(e))
     if per_rank_parity is not None:
