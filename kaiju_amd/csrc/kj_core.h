@@ -2326,6 +2326,18 @@ KJ_HD void mem_lane(const DevIndex &ix, const Params &p, const Batch &b, const W
           else { k = row; lf_check(); }
         }
         if (st == MS_LOC_DONE) {
+          if (vb.text && (flags & kHitIdCap)) {
+            // ids_from_SI's limit ended the traversal - but classify_length pushed the peptide of EVERY fragment that holds a
+            // longest match while it searched (:580-590): the fragments behind the one at hand (round 6: a third of the reads
+            // of a database of protein families end this way, and their column 7 was short, profiles/r06_l46)
+            for (uint32_t g = ge; g < nsi;) {
+              const uint32_t fr = ls.si[g].frag;
+              uint32_t e = g + 1;
+              while (e < nsi && ls.si[e].frag == fr) e++;
+              vb_text(vb, r, pep + F[fr].start + (uint32_t)(ls.si[xo ? g : e - 1].lo >> kSiQiShift), L, 0, nullptr, nullptr, 0);
+              g = e;
+            }
+          }
           hit->n_ids = nids; hit->flags = flags;
           st = MS_FETCH;
         }

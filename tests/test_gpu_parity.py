@@ -648,3 +648,43 @@ assert clf.stats().error_flags == 0
         got = np.load(tmp_path / f"{name}_{seg}.npy")
         for f in ("best", "n_ids", "flags", "taxid"):
             assert (got[f] == w[f]).all(), (name, seg, f)
+
+
+@pytest.mark.parametrize("mode,lane", [("mem", "default"), ("mem", "v1"), ("greedy", "default"), ("greedy", "v1")])
+def test_verbose_columns_under_the_id_cap(gpu_lib, golden, mode, lane, monkeypatch):
+    """kaiju -v when ids_from_SI's limit (more than 20 distinct taxon ids) ends the traversal before the last fragment
+    (tests/golden/idcap: a family of 30 identical proteins under 30 taxa; make_golden_idcap.py): columns 4 - 7 == the
+    reference's lines - the peptide of EVERY fragment that holds a longest match (ConsumerThread.cpp:580-590), no ids or
+    accessions from the matches behind the limit (:805-807)"""
+    api = gpu_lib
+    d = os.path.join(golden.dir, "idcap")
+    if lane == "v1":
+        monkeypatch.setenv("KAIJU_GPU_VERBOSE_LANE", "v1")
+    idx = api.Index(os.path.join(d, "db.fmi"))
+    names, reads = util.read_fastq(os.path.join(d, "reads.fq"))
+    pnames, p1 = util.read_fastq(os.path.join(d, "pairs_1.fq"))
+    _, p2 = util.read_fastq(os.path.join(d, "pairs_2.fq"))
+    ncap = 0
+    try:
+        for seg in (1, 0):
+            clf = api.Classifier(idx, api.default_params(mode, seg=seg))
+            for (seqs, off), nms, pe, tsv in ((util.pack(reads), names, False, f"ref_{mode}_{seg}.tsv"),
+                                              (util.pack(p1, p2), pnames, True, f"ref_{mode}_{seg}_pe.tsv")):
+                hits, accs, peps = clf.classify_verbose(seqs, off, paired=pe)
+                lines = {}
+                with open(os.path.join(d, tsv)) as f:
+                    for line in f:
+                        p = line.rstrip("\n").split("\t")
+                        lines[p[1]] = p
+                for nm, h, a, t in zip(nms, hits, accs, peps):
+                    ref = lines[nm]
+                    if ref[0] != "C":
+                        continue
+                    ids = "".join(f"{x}," for x in sorted(int(x) for x in h["taxid"][:h["n_ids"]]))
+                    assert int(ref[3]) == int(h["best"]) and ref[4] == ids and ref[5] == "".join(x + "," for x in a) and ref[6] == t, \
+                        (mode, lane, seg, pe, nm, ref[3:], ids, a, t)
+                    ncap += int(h["n_ids"]) == 21
+            clf.close()
+    finally:
+        idx.close()
+    assert ncap >= 8

@@ -1045,3 +1045,56 @@ def test_fast_stage1_for_mates_up_to_287_nt(oracle, emu, golden, handles, mode, 
         if not (mode == "mem" and seg):
             assert frags_fast == frags_old
         assert (gh["n_ids"] > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("mode,lanes", [("mem", "v2"), ("mem", "v1"), ("mem", "wide16"), ("greedy", "v2"), ("greedy", "v1"), ("greedy", "wide16")])
+def test_verbose_columns_under_the_id_cap(emu, golden, mode, lanes, monkeypatch):
+    """kaiju -v when ids_from_SI's limit (more than 20 distinct taxon ids, ConsumerThread.cpp:805-807) ends the traversal before
+    the last fragment: a family of 30 identical proteins under 30 taxa, reads whose fragments hold equally long matches in the
+    family and elsewhere (tests/golden/idcap, written by make_golden_idcap.py with the reference binary).  The reference has
+    pushed the peptide of EVERY such fragment by then (:580-590) - until round 6 the first-generation MEM lane stopped at the
+    limit; matches behind it add neither ids nor accessions.  All of columns 4 - 7 == the reference's lines."""
+    import ctypes as C
+    import os
+    d = os.path.join(golden.dir, "idcap")
+    if lanes == "v1":
+        monkeypatch.setenv("KAIJU_EMU_VERBOSE_V1", "1")
+    if lanes.startswith("wide"):
+        monkeypatch.setenv("KAIJU_GPU_FORCE_WIDE", lanes[4:6])
+    h = emu.load(os.path.join(d, "db.fmi"))
+    E = emu.lib
+    E.emu_seq_name.restype = C.c_char_p
+    E.emu_seq_name.argtypes = [C.c_void_p, C.c_uint32]
+    E.emu_alphabet.restype = C.c_char_p
+    E.emu_alphabet.argtypes = [C.c_void_p]
+    alpha = E.emu_alphabet(h)
+    names, reads = util.read_fastq(os.path.join(d, "reads.fq"))
+    pnames, p1 = util.read_fastq(os.path.join(d, "pairs_1.fq"))
+    _, p2 = util.read_fastq(os.path.join(d, "pairs_2.fq"))
+    seqs, off = util.pack(reads)
+    pseqs, poff = util.pack(p1, p2)
+    ncap = 0
+    for seg in (1, 0):
+        for sq, of, nms, pe, tsv in ((seqs, off, names, False, f"ref_{mode}_{seg}.tsv"), (pseqs, poff, pnames, True, f"ref_{mode}_{seg}_pe.tsv")):
+            n = len(nms)
+            nacc, acc, tlen, text, cap = _verbose_buffers(E, n)
+            try:
+                gh, _ = emu.classify(h, util.gp(mode, seg=seg), sq, of, paired=pe)
+            finally:
+                E.emu_set_verbose(None, None, None, None, 0)
+            lines = _tsv_lines(os.path.join(d, tsv))
+            for r, nm in enumerate(nms):
+                ref = lines[nm]
+                if ref[0] != "C":
+                    continue
+                accs = set()
+                for q in range(int(nacc[r])):
+                    s = E.emu_seq_name(h, int(acc[r * 20 + q]))
+                    if s and b"_" in s:
+                        accs.add(s[: s.rindex(b"_")].decode())
+                t = "".join("," if c == 255 else chr(alpha[c]) for c in text[r * cap: r * cap + int(tlen[r])])
+                ids = "".join(f"{x}," for x in sorted(int(x) for x in gh[r]["taxid"][:gh[r]["n_ids"]]))
+                assert int(ref[3]) == int(gh[r]["best"]) and ref[4] == ids and ref[5] == "".join(x + "," for x in sorted(accs)) and ref[6] == t, \
+                    (mode, lanes, seg, pe, nm, ref[3:], ids, sorted(accs), t)
+                ncap += int(gh[r]["n_ids"]) == 21
+    assert ncap >= 8                                       # (the fixture does what it is for)
