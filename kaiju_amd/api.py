@@ -346,6 +346,26 @@ class Classifier:
                                                       hits.ctypes.data, v.ctypes.data, text.ctypes.data, stride))
         return hits, v, text, stride
 
+    def classify_verbose_packed(self, seqs: np.ndarray, off: np.ndarray, paired=False):
+        """kaiju -v with column 7 of the batch as ONE string (kaiju_gpu_classify_batch_verbose_packed, what the command line
+        programs call): (hit records, kaiju_gpu_verbose records, per read the position of its text, a COPY of the string -
+        the library's own is valid until the context's next verbose call)"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = (len(off) - 1) // 2
+        hits = np.zeros(n, dtype=HIT_DTYPE)
+        v = np.zeros(n, dtype=VERBOSE_DTYPE)
+        pos = np.zeros(n, dtype=np.uint64)
+        text = C.c_void_p()
+        nbytes = C.c_uint64()
+        f = lib().kaiju_gpu_classify_batch_verbose_packed
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        f.restype = C.c_int
+        _check(f(self._h, seqs.ctypes.data, off.ctypes.data, n, 1 if paired else 0, hits.ctypes.data, v.ctypes.data, pos.ctypes.data,
+                 C.byref(text), C.byref(nbytes)))
+        return hits, v, pos, (C.string_at(text.value, nbytes.value) if nbytes.value else b"")
+
     def verbose_columns(self, v, text, stride):
         """(per read the sorted accession list of column 6, the text of column 7) from what classify_verbose_raw returned"""
         n = len(v)

@@ -688,3 +688,22 @@ def test_verbose_columns_under_the_id_cap(gpu_lib, golden, mode, lane, monkeypat
     finally:
         idx.close()
     assert ncap >= 8
+
+
+@pytest.mark.parametrize("mode", ["mem", "greedy"])
+def test_verbose_packed_equals_strided(gpu_lib, golden, gidx, mode):
+    """kaiju_gpu_classify_batch_verbose_packed (column 7 of the batch as one string: the command line programs) == the entry point
+    with a row of text_stride bytes per read, record for record and byte for byte; an empty batch is an empty string"""
+    api = gpu_lib
+    clf = api.Classifier(gidx, api.default_params(mode, seg=1))
+    for seqs, off, pe in ((golden.seqs, golden.off, False), (golden.pseqs, golden.poff, True)):
+        hits, v, text, stride = clf.classify_verbose_raw(seqs, off, paired=pe)
+        hits, v = hits.copy(), v.copy()
+        rows = [bytes(text[r * stride: r * stride + int(v[r]["text_len"])]) for r in range(len(v))]
+        h2, v2, pos, s = clf.classify_verbose_packed(seqs, off, paired=pe)
+        assert (hits == h2).all() and (v == v2).all()
+        assert [s[int(pos[r]): int(pos[r]) + int(v2[r]["text_len"])] for r in range(len(v2))] == rows
+        assert sum(len(x) for x in rows) == len(s) and any(rows)
+    h0, v0, p0, s0 = clf.classify_verbose_packed(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    assert len(h0) == 0 and s0 == b""
+    clf.close()
